@@ -1,0 +1,156 @@
+/*
+ * scanerf_hip.h -- C ABI of libscanerf_hip.so: the MI355X (gfx950) implementation of
+ * ScaNeRF's per-tile volume-rendering hot path.
+ *
+ * Drop-in boundary: one entry point per op of the reference's two pybind modules
+ * (CUDA_EXT: cuda/binding.cpp:10-54, HASHGRID: hashgrid/binding.cpp:9-44) that lies on
+ * the hot path, plus the fused fast-path entry points.  Plain pointers and sizes only
+ * (no torch types).  Every pointer is a DEVICE pointer unless marked [host].  All
+ * tensors are contiguous row-major.  Outputs are pre-allocated and pre-filled by the
+ * caller exactly as the reference's Python does (sentinel -1 / zeros); the library
+ * never allocates and keeps no state between calls.
+ *
+ * Every function returns 0 on success, non-zero on failure; scanerf_last_error()
+ * returns a thread-local message for the last failure.  Launches are asynchronous on
+ * `stream` (a hipStream_t passed as void*; NULL = the null stream); no call synchronises.
+ *
+ * Citations are file:line under the reference repository.
+ */
+#ifndef SCANERF_HIP_H_
+#define SCANERF_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void *scanerf_stream_t; /* hipStream_t */
+
+#define SCANERF_PARAMSIZE 13994 /* hashgrid/include/decoder.h:20 */
+
+/* feature-table element types (scanerf_*: `feat_dtype`) */
+#define SCANERF_F32 0
+#define SCANERF_F16 1
+#define SCANERF_BF16 2
+
+const char *scanerf_last_error(void);
+int scanerf_abi_version(void);
+
+/* ---- CUDA_EXT surface ------------------------------------------------------------ */
+
+/* cuda/compute_ray_kernel.cu:95-115 (compute_ray.h:9-14).  locs [B,3] i32 (view,px,py),
+ * Ks [C,9], C2Ws [C,12] -> rays_o, rays_d [B,3] */
+int scanerf_compute_ray_forward(float *rays_o, float *rays_d, const float *Ks, const float *C2Ws,
+                                const int32_t *locs, int B, scanerf_stream_t stream);
+
+/* cuda/compute_ray_kernel.cu:117-136 (compute_ray.h:16-21).  grad_C2Ws [C,12] is ACCUMULATED
+ * into.  Implements the correct adjoint (per-ray gradients); the reference reads
+ * grad_rays_*[view_idx] (compute_ray_kernel.cu:71-72), see DESIGN.md. */
+int scanerf_compute_ray_backward(const float *grad_rays_o, const float *grad_rays_d, const float *Ks,
+                                 float *grad_C2Ws, const int32_t *locs, int B, int num_cam,
+                                 scanerf_stream_t stream);
+
+/* cuda/helper_kernel.cu:130-148 (K=1) and :177-197 (v2).  center,size [K,3]; bounds [B,K,2] */
+int scanerf_ray_aabb_intersection(const float *rays_o, const float *rays_d, const float *center,
+                                  const float *size, float *bounds, int B, int K, scanerf_stream_t stream);
+
+/* cuda/helper_kernel.cu:645-671: the live training sampler.  occ = bool grid [2^lx,2^ly,2^lz]
+ * (1 byte/cell), log2dim [3] i32, corner/size [3] (all device); z_vals,dists [B,S] pre-filled -1. */
+int scanerf_sample_points_grid(const float *rays_o, const float *rays_d, float *z_vals, float *dists,
+                               const float *block_corner, const float *block_size, const uint8_t *occ,
+                               const int32_t *log2dim, int B, int S, scanerf_stream_t stream);
+
+/* cuda/sample_kernel.cu:102-126.  Rays that miss the box are left untouched (the reference
+ * device-asserts); *missed (device i32, may be NULL) counts them. */
+int scanerf_sample_insideout_block(const float *rays_o, const float *rays_d, int S, int S_bg,
+                                   const float *block_center, const float *block_size, float far_,
+                                   float *z_vals, float *z_vals_bg, int32_t *missed, int B,
+                                   scanerf_stream_t stream);
+
+/* cuda/sample_kernel.cu:48-68 */
+int scanerf_background_sampling(const float *starts, const float *bg_depth, float *z_vals, int S,
+                                float sample_range, int B, scanerf_stream_t stream);
+
+/* cuda/adam_kernel.cu:72-94 / :147-169.  Arrays are [K,8] (index = row*8+dim, dim<param_dim);
+ * `step` is the PREVIOUS step count (the kernel uses step+1: adam.h:16 `int &step` quirk).
+ * Entries whose grad is exactly 0 are skipped (no moment decay).  fp16: moments are IEEE half. */
+int scanerf_adam_step(float *params, const float *grad, float *exp_avg, float *exp_avg_sq, float lr,
+                      float beta1, float beta2, float eps, int step, int64_t K, int param_dim,
+                      scanerf_stream_t stream);
+int scanerf_adam_step_fp16(float *params, const float *grad, void *exp_avg, void *exp_avg_sq, float lr,
+                           float beta1, float beta2, float eps, int step, int64_t K, int param_dim,
+                           scanerf_stream_t stream);
+
+/* ---- HASHGRID surface ------------------------------------------------------------ */
+
+/* hashgrid/src/hashgrid_bg_kernel.cu:229-249.  points [N,3] in [-2,2]; features [L,T,2]
+ * (feat_dtype); resolutions [L,3] i32; outputs [N,L,2] f32.  T must be a power of two. */
+int scanerf_embedding_bg_forward(const float *points, float *outputs, const void *features,
+                                 const int32_t *resolutions, int N, int L, int T, int feat_dtype,
+                                 scanerf_stream_t stream);
+/* hashgrid/src/hashgrid_bg_kernel.cu:251-275.  grad_points [N,3] and grad_features [L,T,2]
+ * (f32) are ACCUMULATED into (caller zero-fills: PyHashGridBG.py:27-28).  Either may be NULL. */
+int scanerf_embedding_bg_backward(const float *points, const float *grad_in, float *grad_points,
+                                  float *grad_features, const float *features, const int32_t *resolutions,
+                                  int N, int L, int T, scanerf_stream_t stream);
+/* hashgrid/src/hashgrid_kernel.cu:246-270 / :272-300 (world-space box variant) */
+int scanerf_embedding_forward(const float *points, float *outputs, const float *features,
+                              const float *block_corner, const float *block_size,
+                              const int32_t *resolutions, int N, int L, int T, scanerf_stream_t stream);
+int scanerf_embedding_backward(const float *points, const float *grad_in, float *grad_points,
+                               float *grad_features, const float *features, const float *block_corner,
+                               const float *block_size, const int32_t *resolutions, int N, int L, int T,
+                               scanerf_stream_t stream);
+
+/* ---- fused fast path -------------------------------------------------------------- */
+
+/* One launch for hashgrid/__init__.py:512-596 (HashGrid.render_batch_rays): for each ray,
+ * samples o+z*d -> contraction (mode 0: contract_fore :394-395, 1: contract_bg :397-411) ->
+ * 16-level hash lookup -> ShallowMLP (network.py:172-190) -> cal_integrate_weight/accumulate
+ * (:344-366).  Nothing per-sample is materialised except `weights`.
+ *
+ *   rays_o, rays_d [B,3]; z_vals, dists [B,S]; features [16,T,2] (feat_dtype);
+ *   resolutions [16,3] i32; mlp_blob [13994] f32 in decoder.h blob order (rendering.py:101-112);
+ *   weight_feature [32] f32 (hashgrid/__init__.py:228-235 repeated x2);
+ *   min_bbox, bbox_size [3] [host] (the HashGrid 2x box);
+ *   out_ray [B,16] f32: rgb(3, clamped) depth(1) T_left(1) diffuse(3) specular(3) tint(3)
+ *                       sum_w_spec2 (1: sum_i w_i*|c_s,i|^2, the l2_reg_specular numerator) pad(1);
+ *   weights [B,S] f32 (may be NULL).
+ */
+typedef struct {
+    int contract_mode; /* 0 fore, 1 bg */
+    int infinity;      /* dists[:, -1] = 1e10 (hashgrid/__init__.py:349-350) */
+    float min_bbox[3];
+    float bbox_size[3];
+} scanerf_render_cfg;
+
+/* Packs the decoder blob (+ weight_feature folded into the first layer) into the LDS image
+ * the fused kernels stage (csrc/render_common.h).  workspace: scanerf_render_workspace_floats()
+ * f32, 16-byte aligned, caller-owned; re-pack whenever the blob or weight_feature changes. */
+int scanerf_render_workspace_floats(void);
+int scanerf_pack_decoder(const float *mlp_blob, const float *weight_feature, float *workspace,
+                         scanerf_stream_t stream);
+
+/* ray_valid [B] u8 (may be NULL): rays with 0 render as zeros with T_left = 1
+ * (hashgrid/__init__.py:427-431) and are skipped. */
+int scanerf_render_forward_packed(const float *rays_o, const float *rays_d, const float *z_vals,
+                                  const float *dists, const void *features, int feat_dtype,
+                                  const int32_t *resolutions, const float *workspace,
+                                  const scanerf_render_cfg *cfg /*[host]*/, const uint8_t *ray_valid,
+                                  float *out_ray, float *weights, int B, int S, int T,
+                                  scanerf_stream_t stream);
+
+/* Encoder with an explicit mapping (for benchmarks and the two-kernel path):
+ * variant 0 auto / 1 XCD-partitioned by level / 2 level-fastest; level_major_out != 0 writes
+ * [L][N][2] instead of the binding surface's [N][L][2]. */
+int scanerf_embedding_bg_forward_ex(const float *points, float *outputs, const void *features,
+                                    const int32_t *resolutions, int N, int L, int T, int feat_dtype,
+                                    int variant, int level_major_out, scanerf_stream_t stream);
+
+#define SCANERF_RAY_OUT 16
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SCANERF_HIP_H_ */

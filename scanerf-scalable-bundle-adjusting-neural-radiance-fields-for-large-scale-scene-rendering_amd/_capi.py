@@ -1,0 +1,89 @@
+"""ctypes view of libscanerf_hip.so (the C ABI declared in include/scanerf_hip.h).
+
+There is no CPU fallback: if the HIP library is missing, or a tensor is not a
+contiguous tensor of the expected dtype on a HIP device, the call raises.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libscanerf_hip.so")
+
+F32, F16, BF16 = 0, 1, 2
+RAY_OUT = 16
+PARAMSIZE = 13994
+
+_lib = None
+
+# every symbol include/scanerf_hip.h declares
+SYMBOLS = [
+    "scanerf_last_error", "scanerf_abi_version", "scanerf_compute_ray_forward", "scanerf_compute_ray_backward",
+    "scanerf_ray_aabb_intersection", "scanerf_sample_points_grid", "scanerf_sample_insideout_block",
+    "scanerf_background_sampling", "scanerf_adam_step", "scanerf_adam_step_fp16", "scanerf_embedding_bg_forward",
+    "scanerf_embedding_bg_backward", "scanerf_embedding_forward", "scanerf_embedding_backward",
+    "scanerf_render_workspace_floats", "scanerf_pack_decoder", "scanerf_render_forward_packed",
+    "scanerf_embedding_bg_forward_ex",
+]
+
+
+class RenderCfg(ctypes.Structure):
+    _fields_ = [("contract_mode", ctypes.c_int), ("infinity", ctypes.c_int),
+                ("min_bbox", ctypes.c_float * 3), ("bbox_size", ctypes.c_float * 3)]
+
+
+def lib():
+    """Load the HIP library or fail loudly (no fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"scanerf: HIP library not built: {LIB_PATH} is missing. "
+                "Run `python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc, gfx950).")
+        l = ctypes.CDLL(LIB_PATH)
+        l.scanerf_last_error.restype = ctypes.c_char_p
+        for name in SYMBOLS:
+            if not hasattr(l, name):
+                raise RuntimeError(f"scanerf: {LIB_PATH} does not export {name}")
+        _lib = l
+    return _lib
+
+
+def check(status, what):
+    if status != 0:
+        msg = lib().scanerf_last_error().decode("utf-8", "replace")
+        raise RuntimeError(f"scanerf {what} failed ({status}): {msg}")
+
+
+def stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+_DT = {torch.float32: "f32", torch.int32: "i32", torch.bool: "bool", torch.uint8: "u8", torch.float16: "f16",
+       torch.bfloat16: "bf16", torch.int64: "i64", torch.int16: "i16"}
+
+
+def dev_ptr(t, dtypes, name, allow_none=False):
+    """Device pointer of a contiguous GPU tensor; validates what the reference leaves unchecked
+    (the reference casts data_ptr blindly and calls .contiguous() even on outputs, so a
+    non-contiguous output silently receives nothing)."""
+    if t is None:
+        if allow_none:
+            return ctypes.c_void_p(0)
+        raise RuntimeError(f"scanerf: {name} is None")
+    if not isinstance(t, torch.Tensor):
+        raise RuntimeError(f"scanerf: {name} must be a torch.Tensor, got {type(t).__name__}")
+    if not t.is_cuda:
+        raise RuntimeError(f"scanerf: {name} must live on the GPU (no CPU path exists); got device {t.device}")
+    if not isinstance(dtypes, (tuple, list)):
+        dtypes = (dtypes,)
+    if t.dtype not in dtypes:
+        raise RuntimeError(f"scanerf: {name} has dtype {t.dtype}, expected {[_DT.get(d, d) for d in dtypes]}")
+    if not t.is_contiguous():
+        raise RuntimeError(f"scanerf: {name} must be contiguous")
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def feat_dtype_code(t):
+    return {torch.float32: F32, torch.float16: F16, torch.bfloat16: BF16}[t.dtype]

@@ -1,0 +1,50 @@
+// common.h -- shared host/device helpers for libscanerf_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "scanerf_hip.h"
+
+#define SCANERF_API extern "C" __attribute__((visibility("default")))
+
+namespace scanerf {
+
+constexpr int kWave = 64;          // CDNA4 wavefront
+constexpr int kNumCU = 256;        // MI355X
+constexpr int kNumXCD = 8;
+
+// thread-local last error (scanerf_last_error)
+void set_error(const char *fmt, ...);
+
+inline int check_launch(const char *what)
+{
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("%s: %s", what, hipGetErrorString(e));
+        return 1;
+    }
+    return 0;
+}
+
+#define SCANERF_REQUIRE(cond, ...)                 \
+    do {                                           \
+        if (!(cond)) {                             \
+            scanerf::set_error(__VA_ARGS__);       \
+            return 2;                              \
+        }                                          \
+    } while (0)
+
+inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// Grid for memory-bound 1-thread-per-item kernels: enough blocks to fill 256 CUs several
+// times over, grid-stride the rest.
+inline int stream_grid(int64_t items, int block, int max_blocks = kNumCU * 16)
+{
+    int64_t g = (items + block - 1) / block;
+    if (g < 1) g = 1;
+    if (g > max_blocks) g = max_blocks;
+    return (int)g;
+}
+
+}  // namespace scanerf

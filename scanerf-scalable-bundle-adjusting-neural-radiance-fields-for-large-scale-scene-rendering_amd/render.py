@@ -1,0 +1,60 @@
+"""Fused fast path: one launch per HashGrid.render_batch_rays (hashgrid/__init__.py:512-596)."""
+import ctypes
+
+import torch
+
+from . import _capi
+from ._capi import RAY_OUT, RenderCfg, check, dev_ptr, feat_dtype_code, lib, stream
+
+_f32 = torch.float32
+FORE, BG = 0, 1
+
+# columns of out_ray [B,16]
+RGB, DEPTH, T_LEFT, DIFFUSE, SPECULAR, TINT, W_SPEC2 = slice(0, 3), 3, 4, slice(5, 8), slice(8, 11), slice(11, 14), 14
+
+
+class PackedDecoder:
+    """Device workspace holding the decoder in the layout the fused kernels stage into LDS.
+    Re-pack after every optimiser step on the decoder or when weight_feature changes."""
+
+    def __init__(self, device):
+        self.workspace = torch.empty(lib().scanerf_render_workspace_floats(), dtype=_f32, device=device)
+
+    def pack(self, blob, weight_feature):
+        if blob.numel() != _capi.PARAMSIZE or weight_feature.numel() != 32:
+            raise RuntimeError(f"scanerf: blob must hold {_capi.PARAMSIZE} floats and weight_feature 32")
+        check(lib().scanerf_pack_decoder(dev_ptr(blob, _f32, "mlp_blob"), dev_ptr(weight_feature, _f32, "weight_feature"),
+                                         dev_ptr(self.workspace, _f32, "workspace"), stream()), "pack_decoder")
+        return self
+
+
+def _cfg(min_bbox, bbox_size, contract_mode, infinity):
+    c = RenderCfg()
+    c.contract_mode, c.infinity = int(contract_mode), int(bool(infinity))
+    for k in range(3):
+        c.min_bbox[k] = float(min_bbox[k])
+        c.bbox_size[k] = float(bbox_size[k])
+    return c
+
+
+def render_forward(rays_o, rays_d, z_vals, dists, features, resolutions, packed, min_bbox, bbox_size, contract_mode,
+                   infinity, ray_valid=None, want_weights=True, out_ray=None, weights=None):
+    """-> out_ray [B,16] (see column constants), weights [B,S] or None.
+    min_bbox / bbox_size: host sequences of 3 floats (the HashGrid 2x box)."""
+    B, S = z_vals.shape
+    if features.shape[0] != 16 or features.shape[2] != 2:
+        raise RuntimeError("scanerf: fused path needs a [16,T,2] table (the reference hard-codes 16 levels)")
+    if out_ray is None:
+        out_ray = torch.empty((B, RAY_OUT), dtype=_f32, device=z_vals.device)
+    if weights is None and want_weights:
+        weights = torch.empty((B, S), dtype=_f32, device=z_vals.device)
+    cfg = _cfg(min_bbox, bbox_size, contract_mode, infinity)
+    check(lib().scanerf_render_forward_packed(
+        dev_ptr(rays_o, _f32, "rays_o"), dev_ptr(rays_d, _f32, "rays_d"), dev_ptr(z_vals, _f32, "z_vals"),
+        dev_ptr(dists, _f32, "dists"), dev_ptr(features, (torch.float32, torch.float16, torch.bfloat16), "features"),
+        ctypes.c_int(feat_dtype_code(features)), dev_ptr(resolutions, torch.int32, "resolutions"),
+        dev_ptr(packed.workspace, _f32, "workspace"), ctypes.byref(cfg),
+        dev_ptr(ray_valid, (torch.bool, torch.uint8), "ray_valid", allow_none=True), dev_ptr(out_ray, _f32, "out_ray"),
+        dev_ptr(weights, _f32, "weights", allow_none=True), ctypes.c_int(B), ctypes.c_int(S),
+        ctypes.c_int(features.shape[1]), stream()), "render_forward")
+    return out_ray, weights

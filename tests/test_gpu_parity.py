@@ -1,0 +1,336 @@
+"""GPU parity: every HIP op, called through the reference's binding names (-> C ABI),
+against the CPU oracle on the same seeded inputs.  Needs an MI355X: `pytest -m gpu`.
+
+Tolerances: bit-exact for the sampler / box clipping / ray generation / Adam (built with the
+same IEEE sequence as the oracle); 1e-5 relative for the encoder (FMA contraction differs);
+1e-4 relative (north_star) for rendered rgb / depth / weights.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def S():
+    import scanerf_amd  # noqa: F401
+    from scanerf_amd import _capi
+    _capi.lib()  # fail loudly if the HIP library is missing
+    return scanerf_amd
+
+
+def g(a, dtype=None):
+    t = torch.as_tensor(np.ascontiguousarray(a))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.to(DEV).contiguous()
+
+
+def rays(rng, B, scale=4.0):
+    o = rng.uniform(-scale, scale, (B, 3)).astype(np.float32)
+    d = rng.normal(size=(B, 3)).astype(np.float32)
+    d = d / np.linalg.norm(d, axis=1, keepdims=True) * rng.uniform(0.5, 1.5, (B, 1)).astype(np.float32)
+    return o, d.astype(np.float32)
+
+
+# ------------------------------------------------------------------ a1 / a2
+def test_compute_ray_forward_backward(S):
+    from scanerf_amd.cuda import compute_ray_backward, compute_ray_forward
+    rng = np.random.default_rng(0)
+    C, B = 7, 5000
+    Ks = np.tile(np.float32([500, 0, 320.3, 0, 510, 239.6, 0, 0, 1]), (C, 1))
+    M = rng.normal(size=(C, 12)).astype(np.float32)
+    locs = np.stack([np.sort(rng.integers(0, C, B)), rng.integers(0, 640, B), rng.integers(0, 480, B)], 1).astype(np.int32)
+    o_ref, d_ref = O.compute_ray_forward(locs, Ks, M)
+    ro, rd = torch.zeros(B, 3, device=DEV), torch.zeros(B, 3, device=DEV)
+    compute_ray_forward(ro, rd, g(Ks), g(M), g(locs))
+    assert np.array_equal(ro.cpu().numpy(), o_ref) and np.array_equal(rd.cpu().numpy(), d_ref)
+    go, gd = rng.normal(size=(B, 3)).astype(np.float32), rng.normal(size=(B, 3)).astype(np.float32)
+    gref = O.compute_ray_backward(go, gd, Ks, locs, C)
+    gC = torch.zeros(C, 12, device=DEV)
+    compute_ray_backward(g(go), g(gd), g(Ks), gC, g(locs))
+    np.testing.assert_allclose(gC.cpu().numpy(), gref, rtol=2e-4, atol=2e-3)
+    # unsorted views exercise the per-view segmented reduction
+    rng.shuffle(locs)
+    gref = O.compute_ray_backward(go, gd, Ks, locs, C)
+    gC.zero_()
+    compute_ray_backward(g(go), g(gd), g(Ks), gC, g(locs))
+    np.testing.assert_allclose(gC.cpu().numpy(), gref, rtol=2e-4, atol=2e-3)
+
+
+# ------------------------------------------------------------------ a3
+def test_ray_aabb_bit_exact(S):
+    from scanerf_amd.cuda import ray_aabb_intersection, ray_aabb_intersection_v2
+    rng = np.random.default_rng(1)
+    o, d = rays(rng, 4099, 12.0)
+    d[::17, 0] = 0.0  # exercises safe_divide
+    c, s = np.float32([0.5, -1, 2]), np.float32([8, 6, 10])
+    b = torch.full((o.shape[0], 2), -1.0, device=DEV)
+    ray_aabb_intersection(g(o), g(d), g(c), g(s), b)
+    assert np.array_equal(b.cpu().numpy(), O.ray_aabb_intersection(o, d, c, s))
+    cs = rng.uniform(-5, 5, (6, 3)).astype(np.float32)
+    ss = rng.uniform(2, 9, (6, 3)).astype(np.float32)
+    b2 = torch.full((o.shape[0], 6, 2), -1.0, device=DEV)
+    ray_aabb_intersection_v2(g(o), g(d), g(cs), g(ss), b2)
+    assert np.array_equal(b2.cpu().numpy(), O.ray_aabb_intersection(o, d, cs, ss))
+
+
+# ------------------------------------------------------------------ a4
+@pytest.mark.parametrize("l2d,S_,fill", [((4, 4, 4), 64, 1.0), ((5, 4, 6), 128, 0.3), ((7, 7, 7), 128, 0.12),
+                                         ((3, 3, 3), 7, 0.5)])
+def test_sample_points_grid_bit_exact(S, l2d, S_, fill):
+    from scanerf_amd.cuda import sample_points_grid
+    rng = np.random.default_rng(2)
+    B = 6000
+    o, d = rays(rng, B, 5.0)
+    corner, size = np.float32([-4, -4, -4]), np.float32([8, 8, 8])
+    occ = rng.random(tuple(2 ** k for k in l2d)) < fill
+    z_ref, d_ref = O.sample_points_grid(o, d, corner, size, occ, np.int32(l2d), S_)
+    z = torch.full((B, S_), -1.0, device=DEV)
+    dist = torch.full((B, S_), -1.0, device=DEV)
+    sample_points_grid(g(o), g(d), z, dist, g(corner), g(size), g(occ), g(np.int32(l2d)))
+    assert np.array_equal(z.cpu().numpy(), z_ref)
+    assert np.array_equal(dist.cpu().numpy(), d_ref)
+    assert (z_ref[:, 0] != -1).sum() > B // 10
+
+
+def test_sample_points_grid_edges(S):
+    from scanerf_amd.cuda import sample_points_grid
+    corner, size, l2d = g(np.float32([-4, -4, -4])), g(np.float32([8, 8, 8])), g(np.int32([4, 4, 4]))
+    occ = torch.zeros(16, 16, 16, dtype=torch.bool, device=DEV)
+    z = torch.full((3, 16), -1.0, device=DEV)
+    dd = torch.full((3, 16), -1.0, device=DEV)
+    o, d = g(np.float32([[-10, 0, 0]] * 3)), g(np.float32([[1, 0, 0]] * 3))
+    sample_points_grid(o, d, z, dd, corner, size, occ, l2d)  # empty grid keeps the sentinel
+    assert torch.all(z == -1) and torch.all(dd == -1)
+    e = torch.zeros(0, 3, device=DEV)
+    sample_points_grid(e, e, torch.zeros(0, 16, device=DEV), torch.zeros(0, 16, device=DEV), corner, size, occ, l2d)
+    with pytest.raises(RuntimeError):  # no CPU path
+        sample_points_grid(o.cpu(), d, z, dd, corner, size, occ, l2d)
+    with pytest.raises(RuntimeError):  # int64 log2dim would be reinterpreted by the reference
+        sample_points_grid(o, d, z, dd, corner, size, occ, l2d.long())
+    with pytest.raises(RuntimeError):  # non-contiguous output
+        sample_points_grid(o, d, torch.full((16, 3), -1.0, device=DEV).t(), dd, corner, size, occ, l2d)
+
+
+# ------------------------------------------------------------------ a5
+def test_other_samplers_bit_exact(S):
+    from scanerf_amd.cuda import background_sampling_cuda, sample_insideout_block
+    rng = np.random.default_rng(3)
+    B = 3000
+    o = rng.uniform(-1, 1, (B, 3)).astype(np.float32)  # inside the box: every ray hits
+    _, d = rays(rng, B)
+    c, s = np.float32([0, 0, 0]), np.float32([4, 4, 4])
+    z_ref, zb_ref, missed = O.sample_insideout_block(o, d, 64, 32, c, s, 200.0)
+    assert missed == 0
+    z, zb = torch.zeros(B, 64, device=DEV), torch.zeros(B, 32, device=DEV)
+    sample_insideout_block(g(o), g(d), 64, 32, g(c), g(s), 200.0, z, zb)
+    assert np.array_equal(z.cpu().numpy(), z_ref) and np.array_equal(zb.cpu().numpy(), zb_ref)
+    st, bd = rng.uniform(0, 3, B).astype(np.float32), rng.uniform(1, 20, B).astype(np.float32)
+    zz = torch.zeros(B, 48, device=DEV)
+    background_sampling_cuda(g(o), g(d), g(st), g(bd), zz, 48, 1.6)
+    assert np.array_equal(zz.cpu().numpy(), O.background_sampling(st, bd, 48, 1.6))
+
+
+# ------------------------------------------------------------------ a6 / a7 / a8
+def _table(rng, L, T):
+    return (rng.normal(size=(L, T, 2)) * 0.5).astype(np.float32)
+
+
+@pytest.mark.parametrize("N", [1, 777, 70001])
+def test_embedding_bg_forward(S, N):
+    from scanerf_amd.hashgrid import embedding_bg_forward_cuda
+    rng = np.random.default_rng(4)
+    L, T = 16, 2 ** 14
+    res = O.level_resolutions(torch.tensor([32, 48, 32]), torch.tensor([2048, 3072, 2048])).numpy()
+    pts = rng.uniform(-2, 2, (N, 3)).astype(np.float32)
+    pts[0] = [2.0, -2.0, 0.0]  # box faces
+    feat = _table(rng, L, T)
+    ref = O.embedding_forward(pts, feat, res)
+    out = torch.zeros(N, L, 2, device=DEV)
+    embedding_bg_forward_cuda(g(pts), out, g(feat), g(res))
+    np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=1e-5, atol=2e-6)
+
+
+def test_embedding_bg_forward_variants_and_dtypes(S):
+    import ctypes
+    from scanerf_amd._capi import check, lib, stream
+    rng = np.random.default_rng(5)
+    N, L, T = 40000, 16, 2 ** 12
+    res = O.level_resolutions(torch.tensor([32, 32, 32]), torch.tensor([2048, 2048, 2048])).numpy()
+    pts = rng.uniform(-2, 2, (N, 3)).astype(np.float32)
+    feat = _table(rng, L, T)
+    ref = O.embedding_forward(pts, feat, res)
+    P, R = g(pts), g(res)
+    for dt, code, tol in ((torch.float32, 0, 2e-6), (torch.float16, 1, 0), (torch.bfloat16, 2, 0)):
+        F = g(feat).to(dt).contiguous()
+        refd = ref if code == 0 else O.embedding_forward(pts, F.float().cpu().numpy(), res)
+        for variant in (1, 2):
+            for lm in (0, 1):
+                if lm and variant == 2:
+                    continue
+                out = torch.zeros((L, N, 2) if lm else (N, L, 2), device=DEV)
+                check(lib().scanerf_embedding_bg_forward_ex(
+                    ctypes.c_void_p(P.data_ptr()), ctypes.c_void_p(out.data_ptr()), ctypes.c_void_p(F.data_ptr()),
+                    ctypes.c_void_p(R.data_ptr()), N, L, T, code, variant, lm, stream()), "embed_ex")
+                got = out.permute(1, 0, 2).cpu().numpy() if lm else out.cpu().numpy()
+                np.testing.assert_allclose(got, refd, rtol=1e-5, atol=max(tol, 2e-6), err_msg=f"{dt} v{variant} lm{lm}")
+
+
+def test_embedding_bg_backward(S):
+    from scanerf_amd.hashgrid import embedding_bg_backward_cuda
+    rng = np.random.default_rng(6)
+    N, L, T = 20011, 16, 2 ** 12
+    res = O.level_resolutions(torch.tensor([32, 32, 32]), torch.tensor([2048, 2048, 2048])).numpy()
+    pts = rng.uniform(-2, 2, (N, 3)).astype(np.float32)
+    feat, gin = _table(rng, L, T), rng.normal(size=(N, L, 2)).astype(np.float32)
+    gp_ref, gf_ref = O.embedding_backward(pts, gin, feat, res)
+    gp, gf = torch.zeros(N, 3, device=DEV), torch.zeros(L, T, 2, device=DEV)
+    embedding_bg_backward_cuda(g(pts), g(gin), gp, gf, g(feat), g(res))
+    # table gradients: ~N*8/T adds per entry in a different order than the sequential oracle
+    np.testing.assert_allclose(gf.cpu().numpy(), gf_ref, rtol=1e-3, atol=2e-4)
+    scale = np.abs(gp_ref).max()
+    np.testing.assert_allclose(gp.cpu().numpy() / scale, gp_ref / scale, rtol=1e-4, atol=2e-6)
+
+
+def test_embedding_box_variant_and_autograd_modules(S):
+    from scanerf_amd.hashgrid import HashEmbedding, HashEmbeddingBG
+    rng = np.random.default_rng(7)
+    N, L, T = 5000, 8, 2 ** 10
+    res = O.level_resolutions(torch.tensor([16, 16, 16]), torch.tensor([256, 256, 256]), L).numpy()
+    corner, size = np.float32([-1, 0, 2]), np.float32([4, 6, 5])
+    pts = (rng.uniform(-0.05, 1.05, (N, 3)) * size + corner).astype(np.float32)  # some outside: clamped
+    feat, gin = _table(rng, L, T), rng.normal(size=(N, L, 2)).astype(np.float32)
+    P, F = g(pts).requires_grad_(True), g(feat).requires_grad_(True)
+    out = HashEmbedding(P, F, g(corner), g(size), g(res))
+    np.testing.assert_allclose(out.detach().cpu().numpy(), O.embedding_forward(pts, feat, res, corner, size), rtol=1e-5, atol=2e-6)
+    out.backward(g(gin))
+    gp_ref, gf_ref = O.embedding_backward(pts, gin, feat, res, corner, size)
+    np.testing.assert_allclose(F.grad.cpu().numpy(), gf_ref, rtol=1e-3, atol=2e-4)
+    sc = np.abs(gp_ref).max()
+    np.testing.assert_allclose(P.grad.cpu().numpy() / sc, gp_ref / sc, rtol=1e-4, atol=2e-6)
+    # L=8 contracted-space module path (config 1 uses 8 levels)
+    p2 = rng.uniform(-2, 2, (N, 3)).astype(np.float32)
+    P2, F2 = g(p2).requires_grad_(True), g(feat).requires_grad_(True)
+    o2 = HashEmbeddingBG(P2, F2, g(res))
+    np.testing.assert_allclose(o2.detach().cpu().numpy(), O.embedding_forward(p2, feat, res), rtol=1e-5, atol=2e-6)
+    o2.backward(g(gin))
+    _, gf2 = O.embedding_backward(p2, gin, feat, res)
+    np.testing.assert_allclose(F2.grad.cpu().numpy(), gf2, rtol=1e-3, atol=2e-4)
+
+
+# ------------------------------------------------------------------ a14
+@pytest.mark.parametrize("fp16", [False, True])
+def test_sparse_adam_bit_exact(S, fp16):
+    from scanerf_amd.cuda import adam_step_cuda, adam_step_cuda_fp16
+    rng = np.random.default_rng(8)
+    K = 4099
+    p = rng.normal(size=(K, 8)).astype(np.float32)
+    gr = (rng.normal(size=(K, 8)) * 1e-3).astype(np.float32)
+    gr[rng.random((K, 8)) < 0.7] = 0.0  # sparse: untouched entries keep params AND moments
+    mdt = np.float16 if fp16 else np.float32
+    m = (rng.normal(size=(K, 8)) * 1e-2).astype(mdt)
+    v = (np.abs(rng.normal(size=(K, 8))) * 1e-3).astype(mdt)
+    P, M, V = g(p), g(m), g(v)
+    pr, mr, vr = p.copy(), m.copy(), v.copy()
+    for step in (0, 1, 7):
+        (adam_step_cuda_fp16 if fp16 else adam_step_cuda)(P, g(gr), M, V, 1e-3, 0.9, 0.99, 1e-15, step)
+        O.adam_step(pr, gr, mr.view(np.uint16) if fp16 else mr, vr.view(np.uint16) if fp16 else vr, 1e-3, 0.9, 0.99,
+                    1e-15, step, fp16=fp16)
+    assert np.array_equal(P.cpu().numpy(), pr)
+    assert np.array_equal(M.cpu().numpy().view(np.uint16 if fp16 else np.uint32), mr.view(np.uint16 if fp16 else np.uint32))
+    assert np.array_equal(V.cpu().numpy().view(np.uint16 if fp16 else np.uint32), vr.view(np.uint16 if fp16 else np.uint32))
+
+
+# ------------------------------------------------------------------ fused forward (a9-a12)
+def _render_inputs(rng, B, S_, T, bg):
+    o = rng.uniform(-3, 3, (B, 3)).astype(np.float32)
+    d = rng.normal(size=(B, 3)).astype(np.float32) * rng.uniform(0.5, 1.5, (B, 1)).astype(np.float32)
+    if bg:
+        z = np.sort(rng.uniform(9, 70, (B, S_)), 1).astype(np.float32)
+        dist = np.concatenate([np.diff(z, axis=1), np.full((B, 1), 1e-6, np.float32)], 1).astype(np.float32)
+    else:
+        z = np.sort(rng.uniform(0.2, 3.2, (B, S_)), 1).astype(np.float32)
+        dist = np.concatenate([np.diff(z, axis=1), np.full((B, 1), 0.05, np.float32)], 1).astype(np.float32)
+    feat = (rng.normal(size=(16, T, 2)) * 0.5).astype(np.float32)
+    return o, d.astype(np.float32), z, dist, feat
+
+
+def _check_render(out, w, ref, tag):
+    from scanerf_amd import render as R
+    o = out.cpu().numpy()
+    for name, col, key in (("rgb", R.RGB, "rgb"), ("diffuse", R.DIFFUSE, "diffuse"), ("specular", R.SPECULAR, "specular"),
+                           ("tint", R.TINT, "tint")):
+        np.testing.assert_allclose(o[:, col], ref[key].numpy(), rtol=1e-4, atol=1e-6, err_msg=f"{tag} {name}")
+    np.testing.assert_allclose(o[:, R.DEPTH], ref["depth"][:, 0].numpy(), rtol=1e-4, atol=1e-6, err_msg=f"{tag} depth")
+    np.testing.assert_allclose(o[:, R.T_LEFT], ref["T_left"].numpy(), rtol=1e-4, atol=1e-7, err_msg=f"{tag} T_left")
+    np.testing.assert_allclose(w.cpu().numpy(), ref["weights"][..., 0].numpy(), rtol=1e-4, atol=1e-7, err_msg=f"{tag} weights")
+    if "l2_reg_specular" in ref:
+        np.testing.assert_allclose(o[:, R.W_SPEC2].mean() / 3.0, ref["l2_reg_specular"].numpy(), rtol=1e-4, err_msg=f"{tag} l2")  # mean over [B,3]
+
+
+@pytest.mark.parametrize("bg", [False, True])
+@pytest.mark.parametrize("S_", [24, 128, 33])
+def test_render_forward_vs_oracle(S, bg, S_):
+    from scanerf_amd import network, render
+    rng = np.random.default_rng(9)
+    B, T = 300, 2 ** 13
+    o, d, z, dist, feat = _render_inputs(rng, B, S_, T, bg)
+    sd = O.init_mlp(seed=3, bias_scale=0.05)
+    res = O.level_resolutions(torch.tensor([32, 32, 32]), torch.tensor([2048, 2048, 2048]))
+    mn, sz = torch.tensor([-8.0, -8.0, -8.0]), torch.tensor([16.0, 16.0, 16.0])
+    fn = (lambda x: O.contract_bg(x, mn, sz)) if bg else (lambda x: O.contract_fore(x, mn, sz))
+    step = 2500
+    with torch.no_grad():
+        ref = O.render_batch_rays(torch.from_numpy(o), torch.from_numpy(d), torch.from_numpy(z), torch.from_numpy(dist),
+                                  torch.from_numpy(feat), res, sd, O.TRAIN, fn, step, infinity=bg)
+    pk = render.PackedDecoder(DEV).pack(O.pack_blob(sd).to(DEV), network.weight_feature(step, DEV))
+    out, w = render.render_forward(g(o), g(d), g(z), g(dist), g(feat), g(res.numpy()), pk, mn.tolist(), sz.tolist(),
+                                   render.BG if bg else render.FORE, infinity=bg)
+    _check_render(out, w, ref, f"bg={bg} S={S_}")
+
+
+def test_render_forward_golden_g6(S, golden):
+    """The fused kernel against outputs of the REFERENCE's render_batch_rays (fixture G6)."""
+    from scanerf_amd import network, render
+    g6, g1 = golden("g6_render_batch"), golden("g1_mlp")
+    sd = {k[3:]: torch.from_numpy(v) for k, v in g1.items() if k.startswith("sd.")}
+    step = int(g6["global_step"])
+    pk = render.PackedDecoder(DEV).pack(O.pack_blob(sd).to(DEV), network.weight_feature(step, DEV))
+    for tag, mode, inf in (("fg", render.FORE, False), ("bg", render.BG, True)):
+        out, w = render.render_forward(g(g6["rays_o"]), g(g6["rays_d"]), g(g6["z_" + tag]), g(g6["d_" + tag]),
+                                       g(g6["features"]), g(g6["res"]), pk, [-8.0] * 3, [16.0] * 3, mode, infinity=inf)
+        ref = {k: torch.from_numpy(g6[f"{tag}_m0_{k}"]) for k in ("rgb", "depth", "T_left", "weights", "diffuse",
+                                                                 "specular", "tint", "l2_reg_specular")}
+        _check_render(out, w, ref, "golden " + tag)
+
+
+def test_render_forward_invalid_rays_and_table_dtypes(S):
+    from scanerf_amd import network, render
+    rng = np.random.default_rng(10)
+    B, S_, T = 257, 64, 2 ** 12
+    o, d, z, dist, feat = _render_inputs(rng, B, S_, T, False)
+    sd = O.init_mlp(seed=4)
+    res = O.level_resolutions(torch.tensor([32, 32, 32]), torch.tensor([2048, 2048, 2048]))
+    pk = render.PackedDecoder(DEV).pack(O.pack_blob(sd).to(DEV), network.weight_feature(40000, DEV))
+    valid = torch.from_numpy(rng.random(B) < 0.6).to(DEV)
+    args = (g(o), g(d), g(z), g(dist))
+    full, wf = render.render_forward(*args, g(feat), g(res.numpy()), pk, [-8.0] * 3, [16.0] * 3, render.FORE, False)
+    out, w = render.render_forward(*args, g(feat), g(res.numpy()), pk, [-8.0] * 3, [16.0] * 3, render.FORE, False,
+                                   ray_valid=valid)
+    assert torch.equal(out[valid], full[valid]) and torch.equal(w[valid], wf[valid])
+    inv = out[~valid]
+    assert torch.all(inv[:, render.T_LEFT] == 1) and torch.all(inv[:, :4] == 0) and torch.all(w[~valid] == 0)
+    for dt in (torch.float16, torch.bfloat16):  # config 3: half-width tables, fp32 accumulate
+        F = g(feat).to(dt).contiguous()
+        mn, sz = torch.tensor([-8.0] * 3), torch.tensor([16.0] * 3)
+        with torch.no_grad():
+            ref = O.render_batch_rays(torch.from_numpy(o), torch.from_numpy(d), torch.from_numpy(z), torch.from_numpy(dist),
+                                      F.float().cpu(), res, sd, O.INFERENCE, lambda x: O.contract_fore(x, mn, sz), 40000)
+        out, w = render.render_forward(*args, F, g(res.numpy()), pk, mn.tolist(), sz.tolist(), render.FORE, False)
+        _check_render(out, w, ref, str(dt))
