@@ -1,0 +1,195 @@
+#!/usr/bin/env python3
+"""bench.py -- training rays/s of the per-tile volume-rendering hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--path fused|ops] [--rays B]
+
+One "step" = one full training iteration of one tile on a synthetic ray batch
+(BASELINE.json configs[1]: L=16, T=2^19 fp32 table, 2-hidden x 64 decoder, 65 536 rays x
+128 samples): occupancy-grid sampling -> hash encode -> decoder -> compositing -> MSE +
+0.01*l2_reg_specular -> backward -> fused sparse Adam on the table + Adam on the decoder.
+Inputs (rays, targets, parameters) are resident in HBM before the timed region.
+
+N > 1: one process per GPU (torchrun), one independent tile per rank (tiles shard one per GPU:
+admm_trainer.py:74-83) -> weak scaling, no data-path collective; the ADMM camera-consensus
+exchange (RCCL all-reduce) runs every SYN_ITERS=100 steps and is also timed on its own.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+BYTES_FWD_PER_RAY = 24 + 20 + 128 * 16 * 8 * 2 * 4        # 131 116 B (fp32, S=128, L=16)
+BYTES_BWD_PER_RAY = 128 * 16 * (8 + 64 + 16 * 8)          # 409 600 B
+SYN_ITERS = 100                                           # config/default.yaml:5
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--path", default=os.environ.get("SCANERF_BENCH_PATH", "auto"), choices=["auto", "fused", "ops"])
+    ap.add_argument("--rays", type=int, default=65536)
+    ap.add_argument("--samples", type=int, default=128)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(samples, seconds_budget=15.0):
+    """The oracle (CPU port of the same training iteration) on this box's host cores, on a bounded
+    sample of the workload.  Only this leg of bench.py touches oracle/."""
+    import numpy as np
+
+    from oracle import oracle as O
+
+    # the GPU box gives one GPU a 16-core share of the host: more threads only oversubscribe
+    cores = min(os.cpu_count() or 1, 16)
+    os.environ["OMP_NUM_THREADS"] = str(cores)  # the C oracle's OpenMP loops (set before it is loaded)
+    torch.set_num_threads(cores)
+    rng = np.random.default_rng(0)
+    B = 256
+    tile = O.Tile([-4, -4, -4], [8, 8, 8], log2_T=19)
+    o = rng.uniform(-4, 4, (B, 3)).astype(np.float32)
+    d = rng.normal(size=(B, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    feats = torch.randn(16, tile.T, 2) * 1e-3
+    feats.requires_grad_(True)
+    sd = {k: v.requires_grad_(True) for k, v in O.init_mlp(0).items()}
+    tgt = torch.rand(B, 3)
+    m = np.zeros((16 * tile.T * 2 // 8, 8), np.float32)
+    v = np.zeros_like(m)
+
+    def step(i):
+        z, dd = O.sample_points_grid(o, d, tile.occ_corner, tile.occ_size, tile.occ, tile.log2dim, samples)
+        valid = torch.from_numpy((z != -1).all(1))
+        out = O.render_batch_rays(torch.from_numpy(o)[valid], torch.from_numpy(d)[valid], torch.from_numpy(z)[valid],
+                                  torch.from_numpy(dd)[valid], feats, tile.res, sd, O.TRAIN,
+                                  lambda x: O.contract_fore(x, tile.min_bbox, tile.bbox_size), 1000 + i)
+        loss = torch.nn.functional.mse_loss(out["rgb"], tgt[valid]) + 0.01 * out["l2_reg_specular"]
+        feats.grad = None
+        loss.backward()
+        p = feats.detach().numpy().reshape(-1, 8)
+        O.adam_step(p, feats.grad.numpy().reshape(-1, 8), m, v, 1e-2, 0.9, 0.99, 1e-15, i)
+
+    step(0)
+    t0 = time.time()
+    n = 0
+    while n < 2 or (time.time() - t0 < seconds_budget and n < 50):
+        step(n + 1)
+        n += 1
+    dt = (time.time() - t0) / n
+    return {"value": B / dt, "unit": "rays/s", "cores": cores, "kind": "port",
+            "sample": f"{n} training iterations of {B} rays x {samples} samples (same tile config, T=2^19), oracle/ on {cores} host threads"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    torch.cuda.set_device(local)
+    dev = f"cuda:{local}"
+
+    import scanerf_amd  # noqa: F401  (fails loudly if the HIP library is missing)
+    from scanerf_amd import consensus as cons
+    from scanerf_amd import tile_model as tm
+
+    B, S = args.rays, args.samples
+    torch.manual_seed(rank)
+    model = tm.TileModel([-4.0 + 8.0 * rank, -4, -4], [8, 8, 8], dev, log2_T=19, seed=rank)
+    dec_opt = torch.optim.Adam(model.decoder.parameters(), lr=1e-3, betas=(0.9, 0.99), eps=1e-15)
+    corner = torch.tensor([-4.0 + 8.0 * rank, -4, -4], device=dev)
+    rays_o = torch.rand(B, 3, device=dev) * 8 + corner
+    rays_d = torch.nn.functional.normalize(torch.randn(B, 3, device=dev), dim=-1) * (0.5 + torch.rand(B, 1, device=dev))
+    target = torch.rand(B, 3, device=dev)
+
+    path = args.path
+    if path == "auto":
+        path = "fused" if hasattr(tm, "train_step_fused") else "ops"
+    step_fn = tm.train_step_fused if path == "fused" else tm.train_step_ops
+    timer = tm.KernelTimer() if hasattr(tm, "KernelTimer") else None
+
+    # ADMM consensus state: N_cam cameras, each tile sees M of them, 20 % shared with the next tile
+    n_cam_per, overlap = 120, 24
+    n_cam = (n_cam_per - overlap) * world + overlap
+    cam_idx = torch.arange(n_cam_per, device=dev) + rank * (n_cam_per - overlap)
+    admm = cons.ConsensusState(n_cam, cam_idx, dev)
+    se3 = torch.randn(n_cam_per, 6, device=dev) * 1e-3
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step_fn(model, dec_opt, rays_o, rays_d, target, S, i)
+    admm.exchange(se3)
+    sync()
+    if timer:
+        timer.reset()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step_fn(model, dec_opt, rays_o, rays_d, target, S, args.warmup + i, timer=timer) if timer else \
+            step_fn(model, dec_opt, rays_o, rays_d, target, S, args.warmup + i)
+        if (i + 1) % SYN_ITERS == 0:
+            admm.exchange(se3)
+    sync()
+    elapsed = time.perf_counter() - t0
+    # consensus exchange timed on its own (it runs once per SYN_ITERS steps)
+    sync()
+    c0 = time.perf_counter()
+    for _ in range(10):
+        admm.exchange(se3)
+    sync()
+    consensus_ms = (time.perf_counter() - c0) / 10 * 1e3
+
+    t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    ms_per_step = elapsed / args.steps * 1e3
+
+    if rank == 0:
+        value = world * B * args.steps / elapsed
+        line = {
+            "metric": "training rays/s per GPU (128 samples, L=16 hash)" if world == 1 else
+                      "training rays/s, whole job (128 samples, L=16 hash)",
+            "value": value, "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"configs[1]: single 8m^3 tile per GPU, L=16 T=2^19 fp32 hash grid, 2-hidden x 64 "
+                                   f"decoder, {B} rays x {S} samples, full training iteration "
+                                   f"(sample+encode+decode+composite fwd, bwd, sparse Adam); foreground branch",
+                       "path": path, "rays_per_step": B, "samples": S, "tiles_per_gpu": 1,
+                       "parallelism": f"tile-per-gpu x{world}", "syn_iters": SYN_ITERS},
+            "consensus_ms": consensus_ms,
+            "consensus_frac_of_iteration": consensus_ms / (SYN_ITERS * ms_per_step),
+        }
+        if timer and timer.count:
+            name, avg_ms, alg_bytes = timer.dominant(B, BYTES_FWD_PER_RAY, BYTES_BWD_PER_RAY)
+            ach = alg_bytes / (avg_ms * 1e-3) / 1e9
+            line["roofline"] = {"bound": "hbm", "kernel": name, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                "frac": ach / HBM_PEAK_GBS, "traffic": None, "avg_launch_ms": avg_ms,
+                                "algorithmic_bytes_per_launch": alg_bytes, "all_kernels_ms": timer.summary()}
+        if not args.no_cpu_baseline and world == 1:
+            line["cpu_baseline"] = cpu_baseline(S)
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

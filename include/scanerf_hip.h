@@ -19,6 +19,7 @@
 #ifndef SCANERF_HIP_H_
 #define SCANERF_HIP_H_
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -94,6 +95,16 @@ int scanerf_embedding_bg_forward(const float *points, float *outputs, const void
 int scanerf_embedding_bg_backward(const float *points, const float *grad_in, float *grad_points,
                                   float *grad_features, const float *features, const int32_t *resolutions,
                                   int N, int L, int T, scanerf_stream_t stream);
+/* The same table gradient without global atomics: radix partition of the contributions by
+ * 2048-entry table bucket + LDS accumulation (csrc/scatter.hip).  grad_layout 0: grad_in is
+ * [N][L][2] (binding surface), 1: [L][N][2].  workspace: caller-owned scratch of at least
+ * scanerf_embedding_bwd_workspace_bytes(N,L,T) bytes, 16-byte aligned (0 => shape not
+ * supported by the binned path; use scanerf_embedding_bg_backward).  Does not compute
+ * grad_points (call scanerf_embedding_bg_backward with grad_features = NULL for that). */
+size_t scanerf_embedding_bwd_workspace_bytes(int N, int L, int T);
+int scanerf_embedding_bg_backward_binned(const float *points, const float *grad_in, float *grad_features,
+                                         const int32_t *resolutions, int N, int L, int T, int grad_layout,
+                                         void *workspace, size_t workspace_bytes, scanerf_stream_t stream);
 /* hashgrid/src/hashgrid_kernel.cu:246-270 / :272-300 (world-space box variant) */
 int scanerf_embedding_forward(const float *points, float *outputs, const float *features,
                               const float *block_corner, const float *block_size,

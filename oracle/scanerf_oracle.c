@@ -478,12 +478,13 @@ ORC_API void orc_adam_step(float *params, const float *grad, float *m, float *v,
                            float beta1, float beta2, float eps, int step, int64_t K, int param_dim)
 {
     float t = (float)(step + 1);
+    /* the reference evaluates powf per element (adam_kernel.cu:53-54); same value for all, hoisted */
+    const float bc1 = 1.0f - powf(beta1, t), bc2 = 1.0f - powf(beta2, t);
     for (int64_t r = 0; r < K; ++r)
         for (int dcol = 0; dcol < param_dim; ++dcol) {
             int64_t i = r * 8 + dcol;
             float g = grad[i];
             if (g == 0.0f) continue;
-            float bc1 = 1.0f - powf(beta1, t), bc2 = 1.0f - powf(beta2, t);
             float mi = beta1 * m[i] + (1.0f - beta1) * g;
             float vi = beta2 * v[i] + (1.0f - beta2) * g * g;
             float denom = sqrtf(vi / bc2) + eps;
@@ -500,12 +501,12 @@ ORC_API void orc_adam_step_fp16(float *params, const float *grad, uint16_t *m, u
 {
     const float LS = 128.0f;
     float t = (float)(step + 1);
+    const float bc1 = 1.0f - powf(beta1, t), bc2 = 1.0f - powf(beta2, t);
     for (int64_t r = 0; r < K; ++r)
         for (int dcol = 0; dcol < param_dim; ++dcol) {
             int64_t i = r * 8 + dcol;
             float g = grad[i] * LS;
             if (g == 0.0f) continue;
-            float bc1 = 1.0f - powf(beta1, t), bc2 = 1.0f - powf(beta2, t);
             float mi = beta1 * h2f(m[i]) + (1.0f - beta1) * g;
             float vi = beta2 * h2f(v[i]) + (1.0f - beta2) * g * g;
             float denom = sqrtf(vi / (bc2 * LS * LS)) + eps;

@@ -24,7 +24,8 @@ SYMBOLS = [
     "scanerf_background_sampling", "scanerf_adam_step", "scanerf_adam_step_fp16", "scanerf_embedding_bg_forward",
     "scanerf_embedding_bg_backward", "scanerf_embedding_forward", "scanerf_embedding_backward",
     "scanerf_render_workspace_floats", "scanerf_pack_decoder", "scanerf_render_forward_packed",
-    "scanerf_embedding_bg_forward_ex",
+    "scanerf_embedding_bg_forward_ex", "scanerf_embedding_bwd_workspace_bytes",
+    "scanerf_embedding_bg_backward_binned",
 ]
 
 
@@ -43,6 +44,7 @@ def lib():
                 "Run `python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc, gfx950).")
         l = ctypes.CDLL(LIB_PATH)
         l.scanerf_last_error.restype = ctypes.c_char_p
+        l.scanerf_embedding_bwd_workspace_bytes.restype = ctypes.c_size_t
         for name in SYMBOLS:
             if not hasattr(l, name):
                 raise RuntimeError(f"scanerf: {LIB_PATH} does not export {name}")
@@ -87,3 +89,19 @@ def dev_ptr(t, dtypes, name, allow_none=False):
 
 def feat_dtype_code(t):
     return {torch.float32: F32, torch.float16: F16, torch.bfloat16: BF16}[t.dtype]
+
+
+_workspaces = {}
+
+
+def workspace(device, nbytes):
+    """Grow-only scratch buffer per device (torch caching allocator owns the memory; the C ABI
+    never allocates)."""
+    key = str(device)
+    buf = _workspaces.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = None
+        _workspaces.pop(key, None)
+        buf = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+        _workspaces[key] = buf
+    return buf

@@ -6,20 +6,39 @@ import torch.nn as nn
 from .lib.HASHGRID import embedding_bg_backward_cuda, embedding_bg_forward_cuda
 
 
+TIMER = None  # optional tile_model.KernelTimer: per-kernel HIP-event timing for bench.py
+
+
+class _Null:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+
+def _sec(name, alg_bytes):
+    return TIMER.section(name, alg_bytes) if TIMER is not None else _Null()
+
+
 class _EncodeBG(torch.autograd.Function):
     @staticmethod
     def forward(ctx, points, features, resolution):
-        out = points.new_zeros((points.shape[0], features.shape[0], 2))
-        embedding_bg_forward_cuda(points, out, features, resolution)
+        N, L = points.shape[0], features.shape[0]
+        out = points.new_zeros((N, L, 2))
+        with _sec("embedding_bg_forward", N * L * 8 * features.shape[2] * features.element_size()):
+            embedding_bg_forward_cuda(points, out, features, resolution)
         ctx.save_for_backward(points, features, resolution)
         return out
 
     @staticmethod
     def backward(ctx, grad_out):
         points, features, resolution = ctx.saved_tensors
-        g_pts = torch.zeros_like(points)
+        N, L = points.shape[0], features.shape[0]
+        g_pts = torch.zeros_like(points) if ctx.needs_input_grad[0] else None
         g_feat = torch.zeros_like(features)
-        embedding_bg_backward_cuda(points, grad_out.contiguous(), g_pts, g_feat, features, resolution)
+        with _sec("embedding_bg_backward", N * L * (8 + 64 + 16 * 8)):  # SURVEY.md 8(d) bytes_bwd
+            embedding_bg_backward_cuda(points, grad_out.contiguous(), g_pts, g_feat, features, resolution)
         return g_pts, g_feat, None
 
 

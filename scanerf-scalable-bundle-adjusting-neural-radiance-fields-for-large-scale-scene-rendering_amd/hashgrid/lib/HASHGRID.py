@@ -4,10 +4,11 @@ Same names / positional order / in-place outputs as hashgrid/include/hashgrid.h:
 The render-time ops of the module (rendering.h) are listed in DESIGN.md as the next rows.
 """
 import ctypes
+import os
 
 import torch
 
-from ..._capi import check, dev_ptr, feat_dtype_code, lib, stream
+from ..._capi import check, dev_ptr, feat_dtype_code, lib, stream, workspace
 
 _f32, _i32 = torch.float32, torch.int32
 _feat = (torch.float32, torch.float16, torch.bfloat16)
@@ -31,11 +32,26 @@ def embedding_bg_forward_cuda(points, outputs, features, resolutions):
 
 
 def embedding_bg_backward_cuda(points, grad_in, grad_points, grad_features, features, resolutions):
-    """hashgrid.h:45-51: accumulates into grad_points [N,3] and grad_features [L,T,2]."""
+    """hashgrid.h:45-51: accumulates into grad_points [N,3] and grad_features [L,T,2].
+    The table gradient goes through the atomic-free binned scatter (csrc/scatter.hip) when the
+    shape allows; SCANERF_SCATTER=atomics forces the reference-style atomic kernel."""
     N, (L, T) = points.shape[0], features.shape[:2]
+    need = 0
+    if grad_features is not None and N >= 4096 and os.environ.get("SCANERF_SCATTER", "binned") != "atomics":
+        need = lib().scanerf_embedding_bwd_workspace_bytes(ctypes.c_int(N), ctypes.c_int(L), ctypes.c_int(T))
+    if need:
+        ws = workspace(points.device, need)
+        check(lib().scanerf_embedding_bg_backward_binned(
+            dev_ptr(points, _f32, "points"), dev_ptr(grad_in, _f32, "grad_in"),
+            dev_ptr(grad_features, _f32, "grad_features"), _res(resolutions), ctypes.c_int(N), ctypes.c_int(L),
+            ctypes.c_int(T), ctypes.c_int(0), ctypes.c_void_p(ws.data_ptr()), ctypes.c_size_t(ws.numel()), stream()),
+            "embedding_bg_backward_cuda(binned)")
+        if grad_points is None:
+            return
+        grad_features = None  # the point gradient still needs the corner features: gather kernel
     check(lib().scanerf_embedding_bg_backward(dev_ptr(points, _f32, "points"), dev_ptr(grad_in, _f32, "grad_in"),
-                                              dev_ptr(grad_points, _f32, "grad_points"),
-                                              dev_ptr(grad_features, _f32, "grad_features"),
+                                              dev_ptr(grad_points, _f32, "grad_points", allow_none=True),
+                                              dev_ptr(grad_features, _f32, "grad_features", allow_none=True),
                                               dev_ptr(features, _f32, "features"), _res(resolutions),
                                               ctypes.c_int(N), ctypes.c_int(L), ctypes.c_int(T), stream()),
           "embedding_bg_backward_cuda")
@@ -57,7 +73,7 @@ def embedding_backward_cuda(points, grad_in, grad_points, grad_features, feature
     """hashgrid.h:27-35"""
     N, (L, T) = points.shape[0], features.shape[:2]
     check(lib().scanerf_embedding_backward(dev_ptr(points, _f32, "points"), dev_ptr(grad_in, _f32, "grad_in"),
-                                           dev_ptr(grad_points, _f32, "grad_points"),
+                                           dev_ptr(grad_points, _f32, "grad_points", allow_none=True),
                                            dev_ptr(grad_features, _f32, "grad_features"),
                                            dev_ptr(features, _f32, "features"),
                                            dev_ptr(block_corner, _f32, "block_corner"),

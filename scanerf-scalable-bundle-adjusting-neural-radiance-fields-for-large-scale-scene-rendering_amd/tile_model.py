@@ -1,0 +1,234 @@
+"""Per-tile model and training step: the build's counterpart of the slice of tile.py /
+hashgrid/__init__.py that turns the hot-path kernels into a training iteration
+(tile.py:639-692 render_rays, :880-1015 train_one_step; hashgrid/__init__.py:413-596).
+
+Two execution paths over the same parameters:
+
+  * "ops":   the reference's own structure -- HIP sampler + HIP hash encoder behind the
+             binding-surface names, decoder and compositing in torch (autograd), dense torch
+             gradient of the table, fused sparse Adam kernel on the table;
+  * "fused": one HIP launch for render forward and one for backward (render.py).
+
+Scope is the foreground branch on synthetic rays; data loading, warp/mono losses, pose
+refinement and pruning schedules belong to the trainer.
+"""
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import network, render
+from .cuda import adam_step_cuda, sample_points_grid
+from .hashgrid import HashEmbeddingBG, level_resolutions
+
+_C1 = 0.4886025119029199
+_C2 = (1.0925484305920792, -1.0925484305920792, 0.31539156525252005, -1.0925484305920792, 0.5462742152960396)
+_C3 = (-0.5900435899266435, 2.890611442640554, -0.4570457994644658, 0.3731763325901154, -0.4570457994644658,
+       1.445305721320277, -0.5900435899266435)
+
+
+def sh3(v):
+    """Real spherical harmonics up to degree 3 of unit vectors (16 values, network.py:38-77 ordering)."""
+    x, y, z = v.unbind(-1)
+    xx, yy, zz, xy, yz, xz = x * x, y * y, z * z, x * y, y * z, x * z
+    return torch.stack([torch.full_like(x, 0.28209479177387814), _C1 * y, _C1 * z, _C1 * x, _C2[0] * xy, _C2[1] * yz,
+                        _C2[2] * (2.0 * zz - xx - yy), _C2[3] * xz, _C2[4] * (xx - yy), _C3[0] * y * (3 * xx - yy),
+                        _C3[1] * xy * z, _C3[2] * y * (4 * zz - xx - yy), _C3[3] * z * (2 * zz - 3 * xx - 3 * yy),
+                        _C3[4] * x * (4 * zz - xx - yy), _C3[5] * z * (xx - yy), _C3[6] * x * (xx - 3 * yy)], -1)
+
+
+class Decoder(nn.Module):
+    """sigma / diffuse / tint / SH-conditioned specular decoder with the parameter names of the
+    reference's ShallowMLP (network.py:151-190), so state dicts and blobs are interchangeable."""
+
+    def __init__(self, seed=0):
+        super().__init__()
+        g = torch.Generator().manual_seed(seed)
+        for name, o, i in network.LAYERS:
+            w = torch.randn(o, i, generator=g) * math.sqrt(2.0 / (i + o))
+            self.register_parameter(name.replace(".", "_") + "_weight", nn.Parameter(w))
+            self.register_parameter(name.replace(".", "_") + "_bias", nn.Parameter(torch.zeros(o)))
+
+    def ref_state_dict(self):
+        return {f"{n}.{k}": getattr(self, n.replace(".", "_") + "_" + k) for n, _, _ in network.LAYERS
+                for k in ("weight", "bias")}
+
+    def blob(self):
+        return network.blob_from_state_dict(self.ref_state_dict())
+
+    def _lin(self, name, x):
+        n = name.replace(".", "_")
+        return F.linear(x, getattr(self, n + "_weight"), getattr(self, n + "_bias"))
+
+    def forward(self, feats, dirs, weight_feature):
+        act = lambda u: torch.exp(u * u * -50.0)
+        v = dirs / (dirs.norm(2, dim=-1, keepdim=True) + 1e-8)
+        H = self._lin("Spatial_MLP.mlp.2", act(self._lin("Spatial_MLP.mlp.0", feats * weight_feature)))
+        sigma = F.softplus(self._lin("sigma_layer.mlp.0", H[..., :32]))
+        tint = torch.sigmoid(self._lin("tint_layer.mlp.0", H[..., :32]))
+        dif = torch.sigmoid(self._lin("diffuse_layer.mlp.0", H[..., :32]))
+        h = act(self._lin("Directional_MLP.mlp.0", torch.cat([H[..., 32:], sh3(v)], -1)))
+        h = act(self._lin("Directional_MLP.mlp.2", h))
+        spec = torch.sigmoid(self._lin("Directional_MLP.mlp.4", h))
+        return sigma, dif, spec, tint
+
+
+class TileModel(nn.Module):
+    """Geometry + parameters of one tile (hashgrid/__init__.py:33-92 with model_path == ""):
+    `corner`/`size` describe the tile; the hash grid covers the 2x box around it."""
+
+    def __init__(self, corner, size, device, log2_T=19, grid_resolution=(32, 2048), sampler_log2dim=4, seed=0,
+                 table_dtype=torch.float32):
+        super().__init__()
+        corner = torch.as_tensor(corner, dtype=torch.float32)
+        size = torch.as_tensor(size, dtype=torch.float32)
+        self.device = device
+        self.bbox_center = corner + size / 2.0
+        self.bbox_size = size * 2
+        self.min_bbox = self.bbox_center - self.bbox_size / 2.0
+        fin = (self.bbox_size / self.bbox_size.min() * grid_resolution[1]).int()
+        base = (self.bbox_size / self.bbox_size.min() * grid_resolution[0]).int()
+        self.resolution = level_resolutions(base, fin, 16).to(device).contiguous()
+        g = torch.Generator().manual_seed(seed)
+        T = 2 ** log2_T
+        std = math.sqrt(2.0 / (T * 2 + 16 * 2))  # xavier_normal_ on [16,T,2] (PyHashGridBG.py:72-73)
+        self.features = nn.Parameter((torch.randn(16, T, 2, generator=g) * std).to(device))
+        self.table_dtype = table_dtype
+        self.decoder = Decoder(seed).to(device)
+        self.log2dim = (sampler_log2dim - torch.log2(self.bbox_size.max() / self.bbox_size).int()).int().to(device)
+        self.occupied_grid = torch.ones(tuple(int(2 ** k) for k in self.log2dim), dtype=torch.bool, device=device)
+        self.occ_corner = (self.min_bbox + self.bbox_size / 4.0).to(device).contiguous()
+        self.occ_size = (self.bbox_size / 2.0).to(device).contiguous()
+        self._min_dev = self.min_bbox.to(device)
+        self._size_dev = self.bbox_size.to(device)
+        self.packed = render.PackedDecoder(device)
+        # fused sparse Adam state for the table (cuda/adam_kernel.cu semantics)
+        self.exp_avg = torch.zeros_like(self.features)
+        self.exp_avg_sq = torch.zeros_like(self.features)
+        self.adam_step = 0
+
+    # ---- sampling (no grad: hashgrid/__init__.py:278-285) -------------------------------
+    @torch.no_grad()
+    def sample(self, rays_o, rays_d, S):
+        z = torch.full((rays_o.shape[0], S), -1.0, device=self.device)
+        d = torch.full((rays_o.shape[0], S), -1.0, device=self.device)
+        sample_points_grid(rays_o, rays_d, z, d, self.occ_corner, self.occ_size, self.occupied_grid, self.log2dim)
+        return z, d
+
+    # ---- "ops" path: binding-surface kernels + torch decoder / compositing --------------
+    def render_fore_ops(self, rays_o, rays_d, S, global_step, train=True):
+        z, dist = self.sample(rays_o, rays_d, S)
+        valid = torch.all(z != -1, dim=-1)
+        o, d, z, dist = rays_o[valid], rays_d[valid], z[valid], dist[valid]
+        B = o.shape[0]
+        pts = o[:, None, :] + z[..., None] * d[:, None, :]
+        x = (pts.reshape(-1, 3) - self._min_dev) / self._size_dev * 4.0 - 2.0
+        feats = HashEmbeddingBG(x.contiguous(), self.features, self.resolution).reshape(B, S, 32)
+        wf = network.weight_feature(global_step, self.device)
+        sigma, dif, spec, tint = self.decoder(feats, d[:, None, :].expand(B, S, 3), wf)
+        delta = dist * d.norm(dim=-1, keepdim=True)
+        alpha = 1.0 - torch.exp(-sigma[..., 0] * delta)
+        T = torch.cumprod(torch.cat([torch.ones_like(alpha[:, :1]), 1.0 - alpha + 1e-6], 1), 1)[:, :-1]
+        w = (alpha * T)[..., None]
+        out = {"valid": valid, "depth": (w[..., 0] * z).sum(1), "diffuse": (w * dif).sum(1),
+               "specular": (w * tint * spec).sum(1), "T_left": T[:, -1], "weights": w[..., 0]}
+        out["rgb"] = torch.clamp(out["diffuse"] + out["specular"], 0, 1)
+        if train:
+            out["l2_reg_specular"] = (w.detach() * spec ** 2).sum(1).mean()
+        return out
+
+    # ---- "fused" path -----------------------------------------------------------------------
+    @torch.no_grad()
+    def render_fore_fused(self, rays_o, rays_d, S, global_step):
+        z, dist = self.sample(rays_o, rays_d, S)
+        valid = torch.all(z != -1, dim=-1)
+        self.packed.pack(self.decoder.blob(), network.weight_feature(global_step, self.device))
+        table = self.features if self.table_dtype == torch.float32 else self.features.to(self.table_dtype)
+        out, w = render.render_forward(rays_o, rays_d, z, dist, table, self.resolution, self.packed,
+                                       self.min_bbox.tolist(), self.bbox_size.tolist(), render.FORE, False,
+                                       ray_valid=valid)
+        return out, w, valid
+
+    # ---- optimiser on the table: fused sparse Adam (only touched entries move) --------------
+    @torch.no_grad()
+    def table_adam(self, lr, betas=(0.9, 0.99), eps=1e-15):
+        g = self.features.grad
+        K = self.features.numel() // 8
+        adam_step_cuda(self.features.data.view(K, 8), g.view(K, 8), self.exp_avg.view(K, 8),
+                       self.exp_avg_sq.view(K, 8), lr, betas[0], betas[1], eps, self.adam_step)
+        self.adam_step += 1
+
+
+class KernelTimer:
+    """HIP-event timing of named sections on torch's current stream (the stream every scanerf
+    kernel is launched on).  bench.py uses it for the live per-kernel durations behind
+    `roofline`; alg_bytes = algorithmic bytes of ONE launch of that section."""
+
+    def __init__(self):
+        self.reset()
+
+    def reset(self):
+        self.events = {}
+        self.bytes = {}
+        self.count = 0
+
+    class _Section:
+        def __init__(self, timer, name, alg_bytes):
+            self.t, self.name, self.alg = timer, name, alg_bytes
+
+        def __enter__(self):
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e1 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+
+        def __exit__(self, *exc):
+            self.e1.record()
+            self.t.events.setdefault(self.name, []).append((self.e0, self.e1))
+            self.t.bytes[self.name] = self.alg
+            self.t.count += 1
+
+    def section(self, name, alg_bytes=0):
+        return KernelTimer._Section(self, name, alg_bytes)
+
+    def summary(self):
+        torch.cuda.synchronize()
+        return {k: sum(a.elapsed_time(b) for a, b in v) / len(v) for k, v in self.events.items()}
+
+    def dominant(self, *_):
+        s = self.summary()
+        cand = {k: v for k, v in s.items() if self.bytes.get(k, 0) > 0}
+        name = max(cand, key=cand.get)
+        return name, cand[name], self.bytes[name]
+
+
+class _Null:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+
+def _sec(timer, name, alg_bytes=0):
+    return timer.section(name, alg_bytes) if timer is not None else _Null()
+
+
+def train_step_ops(model, dec_opt, rays_o, rays_d, target, S, global_step, table_lr=1e-2, timer=None):
+    """One iteration of tile.py:880-1015 on the foreground branch: MSE + 0.01*l2_reg_specular
+    (criterions.py:142-144, tile.py:999), decoder by torch Adam, table by the fused sparse Adam."""
+    import sys
+    _enc = sys.modules[__package__ + ".hashgrid.PyHashGridBG"]  # the module (the package re-exports the class)
+    _enc.TIMER = timer
+    model.features.grad = None
+    dec_opt.zero_grad(set_to_none=True)
+    with _sec(timer, "forward_total"):
+        out = model.render_fore_ops(rays_o, rays_d, S, global_step, train=True)
+        loss = F.mse_loss(out["rgb"], target[out["valid"]]) + 0.01 * out["l2_reg_specular"]
+    with _sec(timer, "backward_total"):
+        loss.backward()
+    with _sec(timer, "sparse_adam", model.features.numel() * 32):
+        model.table_adam(table_lr)
+    dec_opt.step()
+    _enc.TIMER = None
+    return loss.detach()

@@ -334,3 +334,29 @@ def test_render_forward_invalid_rays_and_table_dtypes(S):
                                       F.float().cpu(), res, sd, O.INFERENCE, lambda x: O.contract_fore(x, mn, sz), 40000)
         out, w = render.render_forward(*args, F, g(res.numpy()), pk, mn.tolist(), sz.tolist(), render.FORE, False)
         _check_render(out, w, ref, str(dt))
+
+
+@pytest.mark.parametrize("layout", [0, 1])
+def test_binned_scatter_matches_oracle_and_atomics(S, layout):
+    """csrc/scatter.hip: the atomic-free table gradient == the oracle's sequential sum."""
+    import ctypes
+    from scanerf_amd._capi import check, lib, stream, workspace
+    rng = np.random.default_rng(11)
+    N, L, T = 30011, 16, 2 ** 13
+    res = O.level_resolutions(torch.tensor([32, 32, 32]), torch.tensor([2048, 2048, 2048])).numpy()
+    pts = rng.uniform(-2, 2, (N, 3)).astype(np.float32)
+    pts[:50] = 2.0  # upper faces: x0+1 crosses the bucket boundary at the finest level (2048)
+    feat, gin = _table(rng, L, T), rng.normal(size=(N, L, 2)).astype(np.float32)
+    _, gf_ref = O.embedding_backward(pts, gin, feat, res)
+    need = lib().scanerf_embedding_bwd_workspace_bytes(N, L, T)
+    assert need > 0
+    gi = g(gin if layout == 0 else np.ascontiguousarray(gin.transpose(1, 0, 2)))
+    P, R = g(pts), g(res)  # keep alive: raw pointers are handed to the C ABI
+    for ws_bytes in (need, 1 << 20):  # second run: workspace too small -> overflow records take the direct path
+        ws = workspace(DEV, need)
+        gf = torch.zeros(L, T, 2, device=DEV)
+        check(lib().scanerf_embedding_bg_backward_binned(
+            ctypes.c_void_p(P.data_ptr()), ctypes.c_void_p(gi.data_ptr()), ctypes.c_void_p(gf.data_ptr()),
+            ctypes.c_void_p(R.data_ptr()), N, L, T, layout, ctypes.c_void_p(ws.data_ptr()),
+            ctypes.c_size_t(ws_bytes), stream()), "binned")
+        np.testing.assert_allclose(gf.cpu().numpy(), gf_ref, rtol=1e-3, atol=3e-4)
