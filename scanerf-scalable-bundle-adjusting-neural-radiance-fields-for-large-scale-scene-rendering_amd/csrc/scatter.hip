@@ -14,10 +14,13 @@
 //   * scan:             exclusive offsets per (bin, workgroup); bins are contiguous in HBM.
 //   * pass 2 (scatter): same walk, LDS cursors, one 16-B store per record.  A workgroup's
 //                       records of one bin are contiguous, so lines fill up in L2.
-//   * accumulate:       one workgroup per bin streams its records (coalesced 16-B loads),
-//                       ds_add_f32 into a 16 KB LDS image of the bucket, then adds the image
-//                       to grad_features with plain stores.  No global atomics anywhere.
+//   * accumulate:       one workgroup per bin streams its records (coalesced 16-B loads) and adds
+//                       them into a 64-bit fixed-point LDS image of the bucket (integer LDS
+//                       atomics; see k_bin_accumulate), then adds the image to grad_features
+//                       with plain stores.  No global atomics anywhere; bit-reproducible.
 // HBM traffic: 64 B written + 64 B read per (point, level) instead of 16 memory-side atomics.
+#include <stdlib.h>
+
 #include "hashgrid_common.h"
 
 using namespace scanerf;
@@ -72,9 +75,10 @@ __device__ __forceinline__ void make_pairs(const float p[3], const int32_t *res,
 // ---- pass 1: count ---------------------------------------------------------------------
 __global__ void __launch_bounds__(kThreads) k_bin_count(const float *__restrict__ points,
                                                         const int32_t *__restrict__ resolutions, BinGeom g,
-                                                        uint32_t *__restrict__ counts)
+                                                        uint32_t *__restrict__ counts, uint32_t *__restrict__ maxbits)
 {
     extern __shared__ uint32_t hist[];  // [L*NB]
+    if (blockIdx.x == 0 && threadIdx.x == 0) *maxbits = 0;
     const int nbins = g.L * g.NB;
     for (int i = threadIdx.x; i < nbins; i += kThreads) hist[i] = 0;
     __syncthreads();
@@ -158,9 +162,11 @@ __global__ void __launch_bounds__(kThreads) k_bin_scatter(const float *__restric
                                                           const int32_t *__restrict__ resolutions, BinGeom g,
                                                           const uint32_t *__restrict__ rowprefix,
                                                           const uint32_t *__restrict__ starts, Rec *__restrict__ recs,
-                                                          float *__restrict__ grad_features)
+                                                          float *__restrict__ grad_features,
+                                                          uint32_t *__restrict__ maxbits)
 {
     extern __shared__ uint32_t cursor[];  // [L*NB]
+    float gmax = 0.0f;
     const int nbins = g.L * g.NB;
     for (int i = threadIdx.x; i < nbins; i += kThreads)
         cursor[i] = starts[i] + rowprefix[(size_t)i * g.W + blockIdx.x];
@@ -171,6 +177,7 @@ __global__ void __launch_bounds__(kThreads) k_bin_scatter(const float *__restric
         const float p[3] = { points[3 * i], points[3 * i + 1], points[3 * i + 2] };
         for (int l = 0; l < g.L; ++l) {
             const float2 gi = LEVEL_MAJOR_GRAD ? grad_in[(size_t)l * g.N + i] : grad_in[(size_t)i * g.L + l];
+            gmax = fmaxf(gmax, fmaxf(fabsf(gi.x), fabsf(gi.y)));
             Pairs pr;
             make_pairs(p, resolutions + 3 * l, mask, pr);
 #pragma unroll
@@ -200,37 +207,73 @@ __global__ void __launch_bounds__(kThreads) k_bin_scatter(const float *__restric
             }
         }
     }
+    // launch-wide max |dL/dout| for the fixed-point scale of the accumulate pass
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) gmax = fmaxf(gmax, __shfl_xor(gmax, off, 64));
+    if ((threadIdx.x & 63) == 0 && gmax > 0.0f) atomicMax(maxbits, __float_as_uint(gmax));
 }
 
 // ---- accumulate: one workgroup per bin -------------------------------------------------------
+// One workgroup per bin.  The bucket image is accumulated in 64-bit FIXED POINT with integer
+// LDS atomics: on gfx950 ds_add_f32 is ~12x slower than ds_add_u32/u64 (measured: 2.1e9 float
+// adds 9.5 ms, the same adds as u64 1.7 ms).  With M = max|dL/dout| of the launch (found by the
+// scatter pass) and n records in the bin, every partial sum is < n*M, so values are scaled by
+// 2^k, k = 62 - ceil(log2 M) - ceil(log2(n+1)): no overflow, resolution n*M*2^-62.  Integer
+// addition is associative, so the table gradient is bit-reproducible run to run (the
+// reference's atomics are not) and closer to the exact sum than an fp32 running sum.
 __global__ void __launch_bounds__(kThreads) k_bin_accumulate(const Rec *__restrict__ recs,
-                                                             const uint32_t *__restrict__ starts, BinGeom g,
+                                                             const uint32_t *__restrict__ starts,
+                                                             const uint32_t *__restrict__ maxbits, BinGeom g,
                                                              float *__restrict__ grad_features)
 {
-    extern __shared__ float acc[];  // [2 << bucket_log]
+    extern __shared__ long long acc64[];  // [2 << bucket_log]
     const int bs = 1 << g.bucket_log;
-    for (int i = threadIdx.x; i < 2 * bs; i += kThreads) acc[i] = 0.0f;
-    __syncthreads();
     const uint32_t lo = min(starts[blockIdx.x], g.capacity), hi = min(starts[blockIdx.x + 1], g.capacity);
+    const float M = __uint_as_float(*maxbits);
+    if (hi == lo || !(M > 0.0f)) return;  // nothing to add (uniform per workgroup)
+    for (int i = threadIdx.x; i < 2 * bs; i += kThreads) acc64[i] = 0;
+    __syncthreads();
+    int eM;
+    frexpf(M, &eM);  // M < 2^eM
+    const int k = 62 - eM - (32 - __clz(hi - lo));
     const float4 *r4 = reinterpret_cast<const float4 *>(recs);
-    for (uint32_t i = lo + threadIdx.x; i < hi; i += kThreads) {
-        const float4 r = r4[i];
+    auto fx = [&](float v) { return (long long)rintf(ldexpf(v, k)); };
+    auto apply = [&](const float4 &r) {
         const uint32_t hdr = __float_as_uint(r.x);
         const uint32_t e0 = hdr & 0xffffu, e1 = hdr >> 16;
         const float w1 = r.y, w0 = 1.0f - w1;
-        atomicAdd(&acc[2 * e0], w0 * r.z);
-        atomicAdd(&acc[2 * e0 + 1], w0 * r.w);
-        atomicAdd(&acc[2 * e1], w1 * r.z);
-        atomicAdd(&acc[2 * e1 + 1], w1 * r.w);
+        unsigned long long *a = reinterpret_cast<unsigned long long *>(acc64);
+        atomicAdd(&a[2 * e0], (unsigned long long)fx(w0 * r.z));
+        atomicAdd(&a[2 * e0 + 1], (unsigned long long)fx(w0 * r.w));
+        atomicAdd(&a[2 * e1], (unsigned long long)fx(w1 * r.z));
+        atomicAdd(&a[2 * e1 + 1], (unsigned long long)fx(w1 * r.w));
+    };
+    // 8 independent 16-B loads in flight per lane (the records are read once, from HBM)
+    constexpr int U = 8;
+    uint32_t i = lo + threadIdx.x;
+    for (; i + (U - 1) * kThreads < hi; i += U * kThreads) {
+        float4 r[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            typedef float v4f __attribute__((ext_vector_type(4)));
+            v4f t = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(r4 + i + u * kThreads));
+            r[u] = make_float4(t.x, t.y, t.z, t.w);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) apply(r[u]);
     }
+    for (; i < hi; i += kThreads) apply(r4[i]);
     __syncthreads();
     const int level = blockIdx.x / g.NB, bucket = blockIdx.x % g.NB;
     float2 *dst = reinterpret_cast<float2 *>(grad_features) + (size_t)level * g.T + ((size_t)bucket << g.bucket_log);
-    for (int i = threadIdx.x; i < bs; i += kThreads) {
-        float2 v = dst[i];
-        v.x += acc[2 * i];
-        v.y += acc[2 * i + 1];
-        dst[i] = v;
+    for (int j = threadIdx.x; j < bs; j += kThreads) {
+        const long long qx = acc64[2 * j], qy = acc64[2 * j + 1];
+        if (qx | qy) {
+            float2 v = dst[j];
+            v.x += (float)ldexp((double)qx, -k);
+            v.y += (float)ldexp((double)qy, -k);
+            dst[j] = v;
+        }
     }
 }
 
@@ -283,6 +326,7 @@ SCANERF_API int scanerf_embedding_bg_backward_binned(const float *points, const 
     uint32_t *counts = reinterpret_cast<uint32_t *>(workspace);
     uint32_t *totals = counts + (size_t)nbins * g.W;
     uint32_t *starts = totals + nbins;
+    uint32_t *maxbits = starts + nbins + 1;
     size_t head = ((size_t)nbins * g.W + 2 * (size_t)nbins + 2) * 4;
     head = (head + 255) & ~(size_t)255;
     SCANERF_REQUIRE(workspace_bytes > head + sizeof(Rec), "embedding_bg_backward_binned: workspace too small (%zu B)",
@@ -292,17 +336,17 @@ SCANERF_API int scanerf_embedding_bg_backward_binned(const float *points, const 
     g.capacity = cap > 0xfffffff0u ? 0xfffffff0u : (uint32_t)cap;
 
     const size_t lds_bins = (size_t)nbins * 4;
-    hipLaunchKernelGGL(k_bin_count, dim3(g.W), dim3(kThreads), lds_bins, st, points, resolutions, g, counts);
+    hipLaunchKernelGGL(k_bin_count, dim3(g.W), dim3(kThreads), lds_bins, st, points, resolutions, g, counts, maxbits);
     hipLaunchKernelGGL(k_bin_rowscan, dim3(nbins), dim3(kThreads), 0, st, counts, totals, g.W);
     hipLaunchKernelGGL(k_bin_starts, dim3(1), dim3(1024), 0, st, totals, starts, nbins);
     const float2 *gi = reinterpret_cast<const float2 *>(grad_in);
     if (grad_layout == 0)
         hipLaunchKernelGGL((k_bin_scatter<false>), dim3(g.W), dim3(kThreads), lds_bins, st, points, gi, resolutions, g,
-                           counts, starts, recs, grad_features);
+                           counts, starts, recs, grad_features, maxbits);
     else
         hipLaunchKernelGGL((k_bin_scatter<true>), dim3(g.W), dim3(kThreads), lds_bins, st, points, gi, resolutions, g,
-                           counts, starts, recs, grad_features);
-    hipLaunchKernelGGL(k_bin_accumulate, dim3(nbins), dim3(kThreads), (size_t)(2 << g.bucket_log) * 4, st, recs, starts, g,
-                       grad_features);
+                           counts, starts, recs, grad_features, maxbits);
+    hipLaunchKernelGGL(k_bin_accumulate, dim3(nbins), dim3(kThreads), (size_t)(2 << g.bucket_log) * 8, st, recs, starts,
+                       maxbits, g, grad_features);
     return check_launch("embedding_bg_backward_binned");
 }
