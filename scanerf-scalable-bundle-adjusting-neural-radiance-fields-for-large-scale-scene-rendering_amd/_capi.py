@@ -25,7 +25,7 @@ SYMBOLS = [
     "scanerf_embedding_bg_backward", "scanerf_embedding_forward", "scanerf_embedding_backward",
     "scanerf_render_workspace_floats", "scanerf_pack_decoder", "scanerf_render_forward_packed",
     "scanerf_embedding_bg_forward_ex", "scanerf_embedding_bwd_workspace_bytes",
-    "scanerf_embedding_bg_backward_binned",
+    "scanerf_embedding_bg_backward_binned", "scanerf_render_backward_grid", "scanerf_render_backward",
 ]
 
 

@@ -1,0 +1,243 @@
+// render_device.h -- device code shared by the fused render kernels (forward: render.hip,
+// backward: render_bwd.hip): decoder helpers on fp32 MFMA, hash encode of a tile, contraction.
+// See render_common.h for the register / LDS layouts.
+#pragma once
+#include "hashgrid_common.h"
+#include "render_common.h"
+
+typedef float v16f __attribute__((ext_vector_type(16)));
+
+namespace scanerf {
+
+// ------------------------------------------------------------------ device helpers
+__device__ __forceinline__ float gauss_act(float x) { return __expf(x * x * -50.0f); }  // exp(-x^2/(2*0.1^2))
+__device__ __forceinline__ float sigmoid_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float softplus_(float x) { return x > 20.0f ? x : log1pf(__expf(x)); }
+
+__device__ __forceinline__ v16f load_bias(const float *lds, int layer, int blk, int h)
+{
+    const float4 *p = reinterpret_cast<const float4 *>(lds + PK_BIAS + ((layer * 2 + blk) * 2 + h) * 16);
+    float4 a = p[0], b = p[1], c = p[2], d = p[3];
+    v16f r = { a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w, d.x, d.y, d.z, d.w };
+    return r;
+}
+
+// acc += W_img[blk] (32 x 2*NG*4... ) * B, with B supplied 4 steps at a time
+#define MFMA4(acc, a4, b0, b1, b2, b3)                                          \
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32((a4).x, (b0), acc, 0, 0, 0);     \
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32((a4).y, (b1), acc, 0, 0, 0);     \
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32((a4).z, (b2), acc, 0, 0, 0);     \
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32((a4).w, (b3), acc, 0, 0, 0);
+
+// one 32-row output block over a 16-register (32-input) B tile: 4 groups of 4 steps
+__device__ __forceinline__ void mma_block16(v16f &acc, const float *img, int grp0, int lane, const v16f &b)
+{
+    const float4 *A = reinterpret_cast<const float4 *>(img) + lane;
+    float4 a0 = A[(grp0 + 0) * 64], a1 = A[(grp0 + 1) * 64], a2 = A[(grp0 + 2) * 64], a3 = A[(grp0 + 3) * 64];
+    MFMA4(acc, a0, b[0], b[1], b[2], b[3])
+    MFMA4(acc, a1, b[4], b[5], b[6], b[7])
+    MFMA4(acc, a2, b[8], b[9], b[10], b[11])
+    MFMA4(acc, a3, b[12], b[13], b[14], b[15])
+    __builtin_amdgcn_sched_barrier(0);  // keep the scheduler from hoisting every layer's LDS reads
+}
+
+__device__ __forceinline__ v16f act16(const v16f &x)
+{
+    v16f r;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) r[g] = gauss_act(x[g]);
+    return r;
+}
+
+__device__ __forceinline__ float half_sum(float v)  // sum over the 32 lanes of a half
+{
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off, 32);
+    return v;
+}
+
+struct RayConst {
+    float o[3], d[3], dnorm;
+    float sh[16];
+};
+
+// SH deg-3 of the normalised direction (network.py:38-77, viewdirs/(norm+1e-8): :177)
+__device__ __forceinline__ void ray_sh(const float d[3], float dnorm, float sh[16])
+{
+    const float inv = 1.0f / (dnorm + 1e-8f);
+    const float x = d[0] * inv, y = d[1] * inv, z = d[2] * inv;
+    const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+    sh[0] = 0.28209479177387814f;
+    sh[1] = 0.4886025119029199f * y;
+    sh[2] = 0.4886025119029199f * z;
+    sh[3] = 0.4886025119029199f * x;
+    sh[4] = 1.0925484305920792f * xy;
+    sh[5] = -1.0925484305920792f * yz;
+    sh[6] = 0.31539156525252005f * (2.0f * zz - xx - yy);
+    sh[7] = -1.0925484305920792f * xz;
+    sh[8] = 0.5462742152960396f * (xx - yy);
+    sh[9] = -0.5900435899266435f * y * (3 * xx - yy);
+    sh[10] = 2.890611442640554f * xy * z;
+    sh[11] = -0.4570457994644658f * y * (4 * zz - xx - yy);
+    sh[12] = 0.3731763325901154f * z * (2 * zz - 3 * xx - 3 * yy);
+    sh[13] = -0.4570457994644658f * x * (4 * zz - xx - yy);
+    sh[14] = 1.445305721320277f * z * (xx - yy);
+    sh[15] = -0.5900435899266435f * x * (xx - 3 * yy);
+}
+
+struct RenderArgs {
+    const float *rays_o, *rays_d, *z_vals, *dists;
+    const void *features;
+    const int32_t *resolutions;
+    const float *packed;      // PK_TOTAL floats
+    const uint8_t *ray_valid; // optional
+    float *out_ray, *weights;
+    float *tile_T;            // optional [B, ceil(S/32)]: transmittance entering each tile (for backward)
+    int B, S, T;
+    int contract_mode, infinity;
+    float min_bbox[3], inv_size4[3];  // 4/bbox_size
+    float bbox_size[3];
+};
+
+// hash-encode 8 levels of one sample: register 2j+f of half h holds feature f of level
+// 4(j>>1) + 2h + (j&1), i.e. input unit nmap(2j+f, h) = 2*level + f -- the same register<->unit
+// map as every other layer, and the layout in which the backward pass produces dL/dx.
+template <int DT>
+__device__ __forceinline__ void encode8(const RenderArgs &a, const int *lds_res, int h, const float p[3], v16f &x)
+{
+    const uint32_t mask = (uint32_t)a.T - 1u;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int level = 4 * (j >> 1) + 2 * h + (j & 1);
+        const int4 res = reinterpret_cast<const int4 *>(lds_res)[level];
+        int b[3];
+        float t[3], sc;
+        locate_bg(p[0], res.x, b[0], t[0], sc);
+        locate_bg(p[1], res.y, b[1], t[1], sc);
+        locate_bg(p[2], res.z, b[2], t[2], sc);
+        uint32_t idx[8];
+        float w[8];
+        corner_indices(idx, b[0], b[1], b[2], mask);
+        trilinear_weights(w, t[0], t[1], t[2]);
+        const char *slice = (const char *)a.features + (size_t)level * a.T * TableElem<DT>::bytes;
+        float2 f[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) f[c] = TableElem<DT>::load(slice, idx[c]);
+        float ax = 0.0f, ay = 0.0f;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            ax = fmaf(w[c], f[c].x, ax);
+            ay = fmaf(w[c], f[c].y, ay);
+        }
+        x[2 * j] = ax;
+        x[2 * j + 1] = ay;
+        if (j & 1) __builtin_amdgcn_sched_barrier(0);  // at most 2 levels (16 gathers) in flight per lane
+    }
+}
+
+__device__ __forceinline__ void contract_point(const RenderArgs &a, const float o[3], const float d[3], float z,
+                                               float p[3])
+{
+#pragma clang fp contract(off)  // torch evaluates these as separate ops (hashgrid/__init__.py:394-411,519)
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        float w = o[k] + z * d[k];
+        p[k] = (w - a.min_bbox[k]) / a.bbox_size[k] * 4.0f - 2.0f;
+    }
+    if (a.contract_mode == 1) {
+        float linf = fmaxf(fabsf(p[0]), fmaxf(fabsf(p[1]), fabsf(p[2])));
+        float ratio = (2.0f - 1.0f / linf) / linf;
+        p[0] *= ratio;
+        p[1] *= ratio;
+        p[2] *= ratio;
+    }
+}
+
+// per-sample decoder outputs (identical in both halves of the wave)
+struct SampleOut {
+    float sigma, dif[3], tint[3], spec[3];
+};
+
+// Decoder on one tile: x = 32 inputs per sample (16 registers x 2 halves) -> SampleOut.
+// dinit = Dir layer-0 accumulator start (bias + SH part), constant per ray.
+__device__ __forceinline__ SampleOut decode_tile(const float *lds, int lane, const v16f &x, const v16f dinit[2])
+{
+    const int h = lane >> 5;
+    // Spatial_MLP.mlp.0 (32 -> 64) + Gaussian
+    v16f a0 = load_bias(lds, 0, 0, h), a1 = load_bias(lds, 0, 1, h);
+    mma_block16(a0, lds + PK_L0, 0, lane, x);
+    mma_block16(a1, lds + PK_L0, 4, lane, x);
+    a0 = act16(a0);
+    a1 = act16(a1);
+    // Spatial_MLP.mlp.2 (64 -> 64), linear
+    v16f h0 = load_bias(lds, 1, 0, h), h1 = load_bias(lds, 1, 1, h);
+    mma_block16(h0, lds + PK_L1, 0, lane, a0);
+    mma_block16(h0, lds + PK_L1, 4, lane, a1);
+    mma_block16(h1, lds + PK_L1, 8, lane, a0);
+    mma_block16(h1, lds + PK_L1, 12, lane, a1);
+    // heads on H[:32] = h0: per-lane partial dot over its 16 units, partner half adds the rest
+    float hd[7] = { 0, 0, 0, 0, 0, 0, 0 };
+    {
+        const float4 *W = reinterpret_cast<const float4 *>(lds + PK_HEAD + h * 128);
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+            float4 wa = W[2 * g], wb = W[2 * g + 1];
+            float v = h0[g];
+            hd[0] = fmaf(v, wa.x, hd[0]);
+            hd[1] = fmaf(v, wa.y, hd[1]);
+            hd[2] = fmaf(v, wa.z, hd[2]);
+            hd[3] = fmaf(v, wa.w, hd[3]);
+            hd[4] = fmaf(v, wb.x, hd[4]);
+            hd[5] = fmaf(v, wb.y, hd[5]);
+            hd[6] = fmaf(v, wb.z, hd[6]);
+        }
+    }
+    SampleOut so;
+    {
+        const float *hb = lds + PK_HB;
+#pragma unroll
+        for (int c = 0; c < 7; ++c) hd[c] = hd[c] + __shfl_xor(hd[c], 32, 64) + hb[c];
+        so.sigma = softplus_(hd[0]);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            so.dif[c] = sigmoid_(hd[1 + c]);
+            so.tint[c] = sigmoid_(hd[4 + c]);
+        }
+    }
+    // Directional_MLP.mlp.0 (48 -> 64): SH part + bias pre-accumulated in dinit
+    v16f d0 = dinit[0], d1 = dinit[1];
+    mma_block16(d0, lds + PK_D0H, 0, lane, h1);
+    mma_block16(d1, lds + PK_D0H, 4, lane, h1);
+    d0 = act16(d0);
+    d1 = act16(d1);
+    // Directional_MLP.mlp.2 (64 -> 64) + Gaussian
+    v16f e0 = load_bias(lds, 3, 0, h), e1 = load_bias(lds, 3, 1, h);
+    mma_block16(e0, lds + PK_D1, 0, lane, d0);
+    mma_block16(e0, lds + PK_D1, 4, lane, d1);
+    mma_block16(e1, lds + PK_D1, 8, lane, d0);
+    mma_block16(e1, lds + PK_D1, 12, lane, d1);
+    e0 = act16(e0);
+    e1 = act16(e1);
+    // Directional_MLP.mlp.4 (64 -> 3) + sigmoid, on the VALU
+    float c3[3] = { 0, 0, 0 };
+    {
+        const float4 *W = reinterpret_cast<const float4 *>(lds + PK_D2 + h * 128);
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+            float4 w0 = W[g], w1 = W[16 + g];
+            c3[0] = fmaf(e0[g], w0.x, c3[0]);
+            c3[1] = fmaf(e0[g], w0.y, c3[1]);
+            c3[2] = fmaf(e0[g], w0.z, c3[2]);
+            c3[0] = fmaf(e1[g], w1.x, c3[0]);
+            c3[1] = fmaf(e1[g], w1.y, c3[1]);
+            c3[2] = fmaf(e1[g], w1.z, c3[2]);
+        }
+        const float *hb = lds + PK_HB + 8;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) so.spec[c] = sigmoid_(c3[c] + __shfl_xor(c3[c], 32, 64) + hb[c]);
+    }
+    return so;
+}
+
+
+}  // namespace scanerf

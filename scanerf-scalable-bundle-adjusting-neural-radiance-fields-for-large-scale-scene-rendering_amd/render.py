@@ -38,7 +38,7 @@ def _cfg(min_bbox, bbox_size, contract_mode, infinity):
 
 
 def render_forward(rays_o, rays_d, z_vals, dists, features, resolutions, packed, min_bbox, bbox_size, contract_mode,
-                   infinity, ray_valid=None, want_weights=True, out_ray=None, weights=None):
+                   infinity, ray_valid=None, want_weights=True, out_ray=None, weights=None, tile_T=None):
     """-> out_ray [B,16] (see column constants), weights [B,S] or None.
     min_bbox / bbox_size: host sequences of 3 floats (the HashGrid 2x box)."""
     B, S = z_vals.shape
@@ -55,6 +55,44 @@ def render_forward(rays_o, rays_d, z_vals, dists, features, resolutions, packed,
         ctypes.c_int(feat_dtype_code(features)), dev_ptr(resolutions, torch.int32, "resolutions"),
         dev_ptr(packed.workspace, _f32, "workspace"), ctypes.byref(cfg),
         dev_ptr(ray_valid, (torch.bool, torch.uint8), "ray_valid", allow_none=True), dev_ptr(out_ray, _f32, "out_ray"),
-        dev_ptr(weights, _f32, "weights", allow_none=True), ctypes.c_int(B), ctypes.c_int(S),
+        dev_ptr(weights, _f32, "weights", allow_none=True), dev_ptr(tile_T, _f32, "tile_T", allow_none=True),
+        ctypes.c_int(B), ctypes.c_int(S),
         ctypes.c_int(features.shape[1]), stream()), "render_forward")
     return out_ray, weights
+
+
+def render_backward(rays_o, rays_d, z_vals, dists, features, resolutions, packed, weight_feature, min_bbox, bbox_size,
+                    contract_mode, infinity, out_ray, tile_T, grad_out, ray_valid=None, grad_blob=None):
+    """Adjoint of render_forward -> (dfeat [16, B*S, 2] level-major, grad_blob [13994])."""
+    B, S = z_vals.shape
+    dev = z_vals.device
+    dfeat = torch.empty((16, B * S, 2), dtype=_f32, device=dev)
+    nblk = lib().scanerf_render_backward_grid(ctypes.c_int(B))
+    dw_partial = torch.empty((4 * nblk, _capi.PARAMSIZE), dtype=_f32, device=dev)
+    if grad_blob is None:
+        grad_blob = torch.zeros(_capi.PARAMSIZE, dtype=_f32, device=dev)
+    cfg = _cfg(min_bbox, bbox_size, contract_mode, infinity)
+    check(lib().scanerf_render_backward(
+        dev_ptr(rays_o, _f32, "rays_o"), dev_ptr(rays_d, _f32, "rays_d"), dev_ptr(z_vals, _f32, "z_vals"),
+        dev_ptr(dists, _f32, "dists"), dev_ptr(features, (torch.float32, torch.float16, torch.bfloat16), "features"),
+        ctypes.c_int(feat_dtype_code(features)), dev_ptr(resolutions, torch.int32, "resolutions"),
+        dev_ptr(packed.workspace, _f32, "workspace"), dev_ptr(weight_feature, _f32, "weight_feature"),
+        ctypes.byref(cfg), dev_ptr(ray_valid, (torch.bool, torch.uint8), "ray_valid", allow_none=True),
+        dev_ptr(out_ray, _f32, "out_ray"), dev_ptr(tile_T, _f32, "tile_T"), dev_ptr(grad_out, _f32, "grad_out"),
+        dev_ptr(dfeat, _f32, "dfeat"), dev_ptr(dw_partial, _f32, "dw_partial"), dev_ptr(grad_blob, _f32, "grad_blob"),
+        ctypes.c_int(B), ctypes.c_int(S), ctypes.c_int(features.shape[1]), stream()), "render_backward")
+    return dfeat, grad_blob
+
+
+def scatter_table_grad(points, dfeat, grad_features, resolutions):
+    """grad_features [16,T,2] += binned scatter of level-major dfeat at contracted `points` [N,3]."""
+    N, (L, T) = points.shape[0], grad_features.shape[:2]
+    need = lib().scanerf_embedding_bwd_workspace_bytes(ctypes.c_int(N), ctypes.c_int(L), ctypes.c_int(T))
+    if not need:
+        raise RuntimeError("scanerf: shape not supported by the binned scatter")
+    ws = _capi.workspace(points.device, need)
+    check(lib().scanerf_embedding_bg_backward_binned(
+        dev_ptr(points, _f32, "points"), dev_ptr(dfeat, _f32, "dfeat"), dev_ptr(grad_features, _f32, "grad_features"),
+        dev_ptr(resolutions, torch.int32, "resolutions"), ctypes.c_int(N), ctypes.c_int(L), ctypes.c_int(T),
+        ctypes.c_int(1), ctypes.c_void_p(ws.data_ptr()), ctypes.c_size_t(ws.numel()), stream()), "scatter_table_grad")
+    return grad_features

@@ -360,3 +360,50 @@ def test_binned_scatter_matches_oracle_and_atomics(S, layout):
             ctypes.c_void_p(R.data_ptr()), N, L, T, layout, ctypes.c_void_p(ws.data_ptr()),
             ctypes.c_size_t(ws_bytes), stream()), "binned")
         np.testing.assert_allclose(gf.cpu().numpy(), gf_ref, rtol=1e-3, atol=3e-4)
+
+
+@pytest.mark.parametrize("bg,S_", [(False, 64), (True, 40), (False, 128)])
+def test_render_backward_vs_oracle_autograd(S, bg, S_):
+    """Fused backward: dL/d(table) and dL/d(decoder blob) against torch autograd through the oracle
+    (tile.py's loss shape: random upstream gradients on rgb / depth / T_left / l2_reg numerator)."""
+    from scanerf_amd import network, render
+    rng = np.random.default_rng(12)
+    B, T = 200, 2 ** 12
+    o, d, z, dist, feat = _render_inputs(rng, B, S_, T, bg)
+    sd = {k: v.clone().requires_grad_(True) for k, v in O.init_mlp(seed=5, bias_scale=0.05).items()}
+    res = O.level_resolutions(torch.tensor([32, 32, 32]), torch.tensor([2048, 2048, 2048]))
+    mn, sz = torch.tensor([-8.0, -8.0, -8.0]), torch.tensor([16.0, 16.0, 16.0])
+    fn = (lambda x: O.contract_bg(x, mn, sz)) if bg else (lambda x: O.contract_fore(x, mn, sz))
+    step = 4000
+    F = torch.from_numpy(feat).requires_grad_(True)
+    to, td, tz, tdist = (torch.from_numpy(v) for v in (o, d, z, dist))
+    ref = O.render_batch_rays(to, td, tz, tdist, F, res, sd, O.TRAIN, fn, step, infinity=bg)
+    g_rgb, g_depth, g_T = (torch.from_numpy(rng.normal(size=s).astype(np.float32)) for s in ((B, 3), (B, 1), (B,)))
+    g_l2 = 0.37
+    loss = (ref["rgb"] * g_rgb).sum() + (ref["depth"] * g_depth).sum() + (ref["T_left"] * g_T).sum() + \
+        g_l2 * ref["l2_reg_specular"] * (3 * B)   # = g_l2 * sum_rays sum_w_spec2
+    loss.backward()
+    gblob_ref = O.pack_blob({k: v.grad for k, v in sd.items()}).numpy()
+
+    blob = O.pack_blob({k: v.detach() for k, v in sd.items()}).to(DEV)
+    wf = network.weight_feature(step, DEV)
+    pk = render.PackedDecoder(DEV).pack(blob, wf)
+    R = g(res.numpy())
+    ntile = (S_ + 31) // 32
+    tile_T = torch.empty(B, ntile, device=DEV)
+    args = (g(o), g(d), g(z), g(dist), g(feat), R, pk)
+    box = (mn.tolist(), sz.tolist(), render.BG if bg else render.FORE, bg)
+    out, w = render.render_forward(*args, *box, tile_T=tile_T)
+    gout = torch.zeros(B, 16, device=DEV)
+    gout[:, 0:3], gout[:, 3], gout[:, 4], gout[:, 14] = g(g_rgb.numpy()), g(g_depth.numpy()[:, 0]), g(g_T.numpy()), g_l2
+    dfeat, gblob = render.render_backward(g(o), g(d), g(z), g(dist), g(feat), R, pk, wf, *box, out, tile_T, gout)
+    # decoder gradient
+    gb = gblob.cpu().numpy()
+    scale = np.abs(gblob_ref).max()
+    np.testing.assert_allclose(gb / scale, gblob_ref / scale, rtol=2e-3, atol=2e-5)
+    # table gradient through the binned scatter at the contracted sample points
+    pts = fn((to[:, None, :] + tz[..., None] * td[:, None, :]).reshape(-1, 3)).numpy()
+    gF = render.scatter_table_grad(g(pts), dfeat, torch.zeros(16, T, 2, device=DEV), R).cpu().numpy()
+    gF_ref = F.grad.numpy()
+    fs = np.abs(gF_ref).max()
+    np.testing.assert_allclose(gF / fs, gF_ref / fs, rtol=2e-3, atol=2e-5)
