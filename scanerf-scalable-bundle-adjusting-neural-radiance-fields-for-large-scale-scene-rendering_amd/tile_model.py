@@ -232,3 +232,45 @@ def train_step_ops(model, dec_opt, rays_o, rays_d, target, S, global_step, table
     dec_opt.step()
     _enc.TIMER = None
     return loss.detach()
+
+
+def train_step_fused(model, dec_opt, rays_o, rays_d, target, S, global_step, table_lr=1e-2, timer=None):
+    """The same iteration as train_step_ops on the fused kernels: one launch for the render forward,
+    one for its adjoint, the atomic-free binned scatter for the table gradient, fused sparse Adam."""
+    B = rays_o.shape[0]
+    dev = model.device
+    with torch.no_grad():
+        with _sec(timer, "sample_points_grid", B * (24 + 2 * 4 * S)):
+            z, dist = model.sample(rays_o, rays_d, S)
+        valid = torch.all(z != -1, dim=-1)
+        wf = network.weight_feature(global_step, dev)
+        blob = model.decoder.blob()
+        model.packed.pack(blob, wf)
+        ntile = (S + 31) // 32
+        tile_T = torch.empty((B, ntile), device=dev)
+        box = (model.min_bbox.tolist(), model.bbox_size.tolist(), render.FORE, False)
+        with _sec(timer, "render_forward", B * (24 + 20 + S * 16 * 8 * 2 * model.features.element_size())):
+            out, _ = render.render_forward(rays_o, rays_d, z, dist, model.features, model.resolution, model.packed, *box,
+                                           ray_valid=valid, want_weights=False, tile_T=tile_T)
+    # loss on the per-ray outputs (tiny torch graph on [B,16])
+    leaf = out.detach().requires_grad_(True)
+    nv = valid.sum()
+    loss = F.mse_loss(leaf[:, 0:3][valid], target[valid]) + 0.01 * leaf[:, 14][valid].sum() / (3 * nv)
+    loss.backward()
+    with torch.no_grad():
+        with _sec(timer, "render_backward", B * (24 + 20 + S * 16 * 8 * 2 * 4 + S * 16 * 8)):
+            dfeat, gblob = render.render_backward(rays_o, rays_d, z, dist, model.features, model.resolution, model.packed,
+                                                  wf, *box, out, tile_T, leaf.grad, ray_valid=valid)
+        pts = ((rays_o[:, None, :] + z[..., None] * rays_d[:, None, :]).reshape(-1, 3) - model._min_dev) \
+            / model._size_dev * 4.0 - 2.0
+        gtab = torch.zeros_like(model.features)
+        with _sec(timer, "table_grad_scatter", B * S * 16 * (8 + 16 * 8)):
+            render.scatter_table_grad(pts.contiguous(), dfeat, gtab, model.resolution)
+        model.features.grad = gtab
+        with _sec(timer, "sparse_adam", model.features.numel() * 28):
+            model.table_adam(table_lr)
+        for k, v in network.state_dict_from_blob(gblob).items():
+            name, kind = k.rsplit(".", 1)
+            getattr(model.decoder, name.replace(".", "_") + "_" + kind).grad = v.contiguous()
+        dec_opt.step()
+    return loss.detach()
