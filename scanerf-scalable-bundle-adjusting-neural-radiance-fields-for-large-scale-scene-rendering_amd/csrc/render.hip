@@ -29,7 +29,7 @@ __device__ __forceinline__ float blob_w(const float *blob, int base, int n_out, 
 }
 
 __global__ void __launch_bounds__(256) k_pack_decoder(const float *__restrict__ blob, const float *__restrict__ wf,
-                                                      float *__restrict__ pk, float *__restrict__ pkt)
+                                                      float *__restrict__ pk)
 {
     for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < PK_TOTAL; e += gridDim.x * blockDim.x) {
         float v = 0.0f;
@@ -40,10 +40,15 @@ __global__ void __launch_bounds__(256) k_pack_decoder(const float *__restrict__ 
             else if (e < PK_D0S) { base = PK_D0H; layer = 2; ngrp = 4; }
             else if (e < PK_D1) { base = PK_D0S; layer = 3; ngrp = 2; }
             else { base = PK_D1; layer = 4; ngrp = 8; }
-            int t = e - base;
-            int q = t & 3, lane = (t >> 2) & 63, grp = (t >> 8) % ngrp, blk = (t >> 8) / ngrp;
-            int r = grp * 4 + q, h = lane >> 5, n = (lane & 31) + 32 * blk;
-            if (layer == 0) {
+            const int t = e - base;
+            const int gall = t / PK_GRP, rem = t % PK_GRP, slot = rem >> 2, q = rem & 3;
+            const int grp = gall % ngrp, blk = gall / ngrp;
+            const bool pad = slot == 32 || slot > 64;  // the upper half-wave sits one slot higher
+            const int lane = slot < 32 ? slot : slot - 1;
+            const int r = grp * 4 + q, h = lane >> 5, n = (lane & 31) + 32 * blk;
+            if (pad) {
+                v = 0.0f;
+            } else if (layer == 0) {
                 int k = nmap(r, h);
                 v = blob_w(blob, BLOB_S0, 64, n, k) * wf[k];
             } else if (layer == 1) {
@@ -81,25 +86,6 @@ __global__ void __launch_bounds__(256) k_pack_decoder(const float *__restrict__ 
             else if (t >= 8 && t < 11) v = blob[BLOB_D2 + t - 8];
         }
         pk[e] = v;
-    }
-    if (!pkt) return;
-    // transposed images for the backward pass: A[i = input unit][step r, half h -> output n]
-    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < PKT_TOTAL; e += gridDim.x * blockDim.x) {
-        int base, layer;
-        if (e < PKT_D0H) { base = PKT_L1; layer = 1; }
-        else if (e < PKT_D1) { base = PKT_D0H; layer = 2; }
-        else if (e < PKT_L0) { base = PKT_D1; layer = 4; }
-        else { base = PKT_L0; layer = 0; }
-        int t = e - base;
-        int q = t & 3, lane = (t >> 2) & 63, grp = (t >> 8) & 7, blk = t >> 11;
-        int r = grp * 4 + q, h = lane >> 5, i = (lane & 31) + 32 * blk;
-        int n = 32 * (r >> 4) + nmap(r & 15, h);  // output unit whose gradient sits in step r
-        float v;
-        if (layer == 1) v = blob_w(blob, BLOB_S1, 64, n, i);
-        else if (layer == 2) v = blob_w(blob, BLOB_D0, 64, n, i);  // i in 0..31: the H[32:64] inputs
-        else if (layer == 4) v = blob_w(blob, BLOB_D1, 64, n, i);
-        else v = blob_w(blob, BLOB_S0, 64, n, i) * wf[i];
-        pkt[e] = v;
     }
 }
 
@@ -151,8 +137,10 @@ __global__ void __launch_bounds__(kRenderThreads, 2) k_render_fwd(RenderArgs a)
             for (int r = 0; r < 8; ++r) shb[r] = h ? sh[2 * r + 1] : sh[2 * r];
             dinit[0] = load_bias(lds, 2, 0, h);
             dinit[1] = load_bias(lds, 2, 1, h);
-            const float4 *A = reinterpret_cast<const float4 *>(lds + PK_D0S) + lane;
-            float4 a00 = A[0], a01 = A[64], a10 = A[128], a11 = A[192];
+            const float *A = lds + PK_D0S + (lane + (lane >> 5)) * 4;
+            const float4 a00 = *reinterpret_cast<const float4 *>(A), a01 = *reinterpret_cast<const float4 *>(A + PK_GRP),
+                         a10 = *reinterpret_cast<const float4 *>(A + 2 * PK_GRP),
+                         a11 = *reinterpret_cast<const float4 *>(A + 3 * PK_GRP);
             MFMA4(dinit[0], a00, shb[0], shb[1], shb[2], shb[3])
             MFMA4(dinit[0], a01, shb[4], shb[5], shb[6], shb[7])
             MFMA4(dinit[1], a10, shb[0], shb[1], shb[2], shb[3])
@@ -221,14 +209,14 @@ __global__ void __launch_bounds__(kRenderThreads, 2) k_render_fwd(RenderArgs a)
 }  // namespace
 
 // ---------------------------------------------------------------------------- C ABI
-SCANERF_API int scanerf_render_workspace_floats(void) { return PK_TOTAL + PKT_TOTAL; }
+SCANERF_API int scanerf_render_workspace_floats(void) { return PK_TOTAL; }
 
 SCANERF_API int scanerf_pack_decoder(const float *mlp_blob, const float *weight_feature, float *workspace,
                                      scanerf_stream_t stream)
 {
     SCANERF_REQUIRE(mlp_blob && weight_feature && workspace, "pack_decoder: null pointer");
     hipLaunchKernelGGL(k_pack_decoder, dim3(32), dim3(256), 0, (hipStream_t)stream, mlp_blob, weight_feature,
-                       workspace, workspace + PK_TOTAL);
+                       workspace);
     return check_launch("pack_decoder");
 }
 

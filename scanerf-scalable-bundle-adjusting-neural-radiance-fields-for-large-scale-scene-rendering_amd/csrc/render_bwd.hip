@@ -6,18 +6,23 @@
 //   * dL/d(decoder blob) as per-wave partial sums (reduced by k_reduce_dw, deterministic),
 // recomputing the forward per 32-sample tile instead of storing per-sample activations.
 //
-// One wave per ray, 4 waves per workgroup, ONE wave per SIMD: the wave owns the whole
-// 512-register file -- ~235 registers hold its private weight-gradient accumulators
-// (MFMA C/D operands), the rest the tile's activations.  Three kinds of MFMA work per tile:
-//   forward recompute      H^T   = W   X^T      A = weights (LDS),    B = activations (regs)
-//   activation gradients   dX^T  = W^T dY^T     A = W^T image (LDS),  B = dY (regs)
+// One WORKGROUP per ray: its 4 waves take 4 consecutive 32-sample tiles (S=128: the whole ray).
+// Three kinds of MFMA work per tile:
+//   forward recompute      H^T   = W   X^T      A = weight image (LDS), B = activations (regs)
+//   activation gradients   dX^T  = W^T dY^T     A = the SAME image walked transposed (chain16)
 //   weight gradients       dW    = dY  X^T      reduction over SAMPLES: both operands need the
-//                                               unit on the lane and samples across steps, the
-//                                               transpose of the register layout -> one trip
-//                                               through a wave-private 9 KB LDS scratch each.
-// Compositing backward walks the tiles LAST to FIRST with the tile-entry transmittances saved
-// by the forward, so suffix sums are formed directly (a prefix-minus-total form divides
-// rounding noise by f_i = 1-alpha_i+1e-6 and loses opaque samples).
+//                                               unit on the lane and samples across the steps --
+//                                               the transpose of the register layout.
+// The transposes go through an LDS stage buffer, and that buffer doubles as the exchange that
+// lets the waves SPLIT the weight-gradient blocks: every wave writes its tile's (dY, X) rows,
+// then accumulates only the blocks it owns over all 4 tiles.  A wave therefore holds 64
+// accumulator registers instead of the 192 a one-wave-per-ray design needs (which spilled
+// ~500 registers per lane: 47 GB of scratch traffic per launch, profiles/r01_fused_v1*).
+//
+// Compositing backward needs sum_{j>i} a_j w_j: tile totals are exchanged through LDS and the
+// tile groups are walked LAST to FIRST with the tile-entry transmittances saved by the forward,
+// so suffix sums are formed directly (a prefix-minus-total form divides rounding noise by
+// f_i = 1-alpha_i+1e-6 and loses opaque samples).
 #include "render_device.h"
 
 using namespace scanerf;
@@ -25,34 +30,33 @@ using namespace scanerf;
 namespace {
 
 constexpr int kBwdThreads = 256;
-constexpr int kScrStride = 36;                 // floats per scratch row (32 samples + pad: conflict-free b128 reads)
-constexpr int kScrFloats = 64 * kScrStride;    // per wave
-constexpr int kBwdLdsFloats = PK_TOTAL + PKT_TOTAL + 64 + 4 * kScrFloats;
+constexpr int kScrStride = 36;                   // floats per stage row (32 samples + pad: conflict-free b128 reads)
+constexpr int kSlotRows = 128;                   // per wave: rows 0..63 dY (or private scratch), 64..127 X
+constexpr int kSlotFloats = kSlotRows * kScrStride;
+constexpr int kBwdLdsFloats = PK_TOTAL + 64 + 4 * kSlotFloats + 16;
 
 struct BwdArgs {
     RenderArgs f;              // forward inputs (out_ray = forward outputs, read-only here)
     const float *grad_out;     // [B,16] dL/d(out_ray)
     const float *tile_T;       // [B, ntiles] from the forward
-    const float *packed_t;     // PKT_TOTAL floats (transposed images)
     float *dfeat;              // [16][B*S][2]
-    float *dw_partial;         // [nwaves][SCANERF_PARAMSIZE]
+    float *dw_partial;         // [nwaves][SCANERF_PARAMSIZE], zero-filled by the host wrapper
 };
 
 __device__ __forceinline__ float dgauss(float u, float a) { return -100.0f * u * a; }  // d/du exp(-50 u^2)
 
-// ---- wave-private transposes through LDS ------------------------------------------------------
-// registers (lane = sample s, half h, reg g = unit nmap(g,h))  ->  scratch[row = unit][col = sample]
-__device__ __forceinline__ void scr_put(float *scr, int lane, int rowbase, const v16f &v)
+// registers (lane = sample s, half h, reg g = unit nmap(g,h))  ->  rows[unit][sample]
+__device__ __forceinline__ void rows_put(float *rows, int lane, int rowbase, const v16f &v)
 {
     const int sl = lane & 31, h = lane >> 5;
 #pragma unroll
-    for (int g = 0; g < 16; ++g) scr[(rowbase + nmap(g, h)) * kScrStride + sl] = v[g];
+    for (int g = 0; g < 16; ++g) rows[(rowbase + nmap(g, h)) * kScrStride + sl] = v[g];
 }
-// scratch -> registers (lane = unit n, half h, reg t = sample 16h + t): the operand layout of an
-// MFMA whose reduction index is the sample
-__device__ __forceinline__ v16f scr_get(const float *scr, int lane, int rowbase)
+// rows -> registers (lane = unit n, half h, reg t = sample 16h + t): operand layout of an MFMA
+// whose reduction index is the sample
+__device__ __forceinline__ v16f rows_get(const float *rows, int lane, int rowbase)
 {
-    const float4 *p = reinterpret_cast<const float4 *>(scr + (rowbase + (lane & 31)) * kScrStride + 16 * (lane >> 5));
+    const float4 *p = reinterpret_cast<const float4 *>(rows + (rowbase + (lane & 31)) * kScrStride + 16 * (lane >> 5));
     float4 a = p[0], b = p[1], c = p[2], d = p[3];
     v16f r = { a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w, d.x, d.y, d.z, d.w };
     return r;
@@ -63,8 +67,7 @@ __device__ __forceinline__ void wave_lds_fence()
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
-
-// acc[n][k] += sum_s dY[n][s] X[k][s]   (both operands in the sample-on-steps layout)
+// acc[n][k] += sum_s dY[n][s] X[k][s]
 __device__ __forceinline__ void mma_ws(v16f &acc, const v16f &dy, const v16f &x)
 {
 #pragma unroll
@@ -78,20 +81,37 @@ __device__ __forceinline__ float sum16(const v16f &v)
     for (int t = 0; t < 16; ++t) s += v[t];
     return s;
 }
+// VALU weight gradient of a narrow layer: acc[c] += sum_s g[c][s] x[s], g rows at `grow` (broadcast reads)
+template <int NC>
+__device__ __forceinline__ void narrow_wgrad(float *acc, const float *grow, int h, const v16f &xo)
+{
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const float4 *gp = reinterpret_cast<const float4 *>(grow + c * kScrStride + 16 * h);
+        float a = 0.0f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 gq = gp[q];
+            a = fmaf(gq.x, xo[4 * q + 0], a);
+            a = fmaf(gq.y, xo[4 * q + 1], a);
+            a = fmaf(gq.z, xo[4 * q + 2], a);
+            a = fmaf(gq.w, xo[4 * q + 3], a);
+        }
+        acc[c] += a;
+    }
+}
 
 template <int DT>
 __global__ void __launch_bounds__(kBwdThreads, 1) k_render_bwd(BwdArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float *ldt = lds + PK_TOTAL;                       // transposed images
-    int *lres = reinterpret_cast<int *>(lds + PK_TOTAL + PKT_TOTAL);
+    int *lres = reinterpret_cast<int *>(lds + PK_TOTAL);
+    float *stage = lds + PK_TOTAL + 64;
+    float *totals = stage + 4 * kSlotFloats;  // [4] tile totals of a_j w_j
     {
         const float4 *src = reinterpret_cast<const float4 *>(a.f.packed);
-        const float4 *srct = reinterpret_cast<const float4 *>(a.packed_t);
         float4 *dst = reinterpret_cast<float4 *>(lds);
         for (int i = threadIdx.x; i < PK_TOTAL / 4; i += kBwdThreads) dst[i] = src[i];
-        float4 *dstt = reinterpret_cast<float4 *>(ldt);
-        for (int i = threadIdx.x; i < PKT_TOTAL / 4; i += kBwdThreads) dstt[i] = srct[i];
         if (threadIdx.x < 64) {
             int lv = threadIdx.x >> 2, c = threadIdx.x & 3;
             lres[threadIdx.x] = c < 3 ? a.f.resolutions[3 * lv + c] : 0;
@@ -99,36 +119,32 @@ __global__ void __launch_bounds__(kBwdThreads, 1) k_render_bwd(BwdArgs a)
     }
     __syncthreads();
     const int lane = threadIdx.x & 63, sl = lane & 31, h = lane >> 5, wv = threadIdx.x >> 6;
-    float *scr = lds + PK_TOTAL + PKT_TOTAL + 64 + wv * kScrFloats;
-    const int wave0 = blockIdx.x * (kBwdThreads / 64) + wv, nwaves = gridDim.x * (kBwdThreads / 64);
-    const int S = a.f.S, ntiles = (S + 31) >> 5;
+    float *slot = stage + wv * kSlotFloats;  // this wave's rows
+    const int S = a.f.S, ntiles = (S + 31) >> 5, ngroups = (ntiles + 3) >> 2;
+    // ownership of the weight-gradient blocks: 64x64 layers -> block (rb, cb) over all 4 tiles;
+    // 64x32 layers -> row block rb2 over a PAIR of tiles
+    const int rb = wv >> 1, cb = wv & 1;        // D1 / L1
+    const int rb2 = wv & 1, tp = wv >> 1;       // D0H / L0: tiles 2*tp, 2*tp+1
 
-    // ---- weight-gradient accumulators (live for the whole kernel) --------------------------------
     const v16f zero16 = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
-    v16f gW_L0[2] = { zero16, zero16 };
-    v16f gW_L1[2][2] = { { zero16, zero16 }, { zero16, zero16 } };
-    v16f gW_D0H[2] = { zero16, zero16 };
-    v16f gW_D1[2][2] = { { zero16, zero16 }, { zero16, zero16 } };
-    float gW_D0S[2][8], gW_head[7], gW_D2[2][3], gB[4][2], gB_head[7], gB_d2[3];
+    v16f gW_D1 = zero16, gW_L1 = zero16, gW_D0H = zero16, gW_L0 = zero16;
+    float gW_D0S[8], gW_head[7], gW_D2[2][3], gB_head[7], gB_d2[3];
+    float gB_D1 = 0.0f, gB_L1 = 0.0f, gB_D0 = 0.0f, gB_L0 = 0.0f;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) gW_D0S[0][i] = gW_D0S[1][i] = 0.0f;
+    for (int i = 0; i < 8; ++i) gW_D0S[i] = 0.0f;
 #pragma unroll
     for (int i = 0; i < 7; ++i) gW_head[i] = gB_head[i] = 0.0f;
 #pragma unroll
     for (int i = 0; i < 3; ++i) gW_D2[0][i] = gW_D2[1][i] = gB_d2[i] = 0.0f;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) gB[i][0] = gB[i][1] = 0.0f;
 
-    for (int ray = wave0; ray < a.f.B; ray += nwaves) {
-        const bool rvalid = !(a.f.ray_valid && !a.f.ray_valid[ray]);
-        if (!rvalid) {
+    for (int ray = blockIdx.x; ray < a.f.B; ray += gridDim.x) {
+        if (a.f.ray_valid && !a.f.ray_valid[ray]) {  // block-uniform
             // invalid rays contribute nothing; their feature gradients are zero
-            for (int s = sl; s < S; s += 32)
+            for (int s = threadIdx.x >> 1; s < S; s += kBwdThreads / 2)
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int level = 4 * (j >> 1) + 2 * h + (j & 1);
-                    reinterpret_cast<float2 *>(a.dfeat)[(size_t)level * a.f.B * S + (size_t)ray * S + s] = make_float2(0, 0);
-                }
+                for (int j = 0; j < 8; ++j)
+                    reinterpret_cast<float2 *>(a.dfeat)[(size_t)(2 * j + (threadIdx.x & 1)) * a.f.B * S + (size_t)ray * S + s] =
+                        make_float2(0, 0);
             continue;
         }
         float o[3], d[3];
@@ -138,55 +154,29 @@ __global__ void __launch_bounds__(kBwdThreads, 1) k_render_bwd(BwdArgs a)
             d[k] = a.f.rays_d[3 * ray + k];
         }
         const float dnorm = sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
-        float sh[16];
-        ray_sh(d, dnorm, sh);
-        v16f dinit[2];
-        {
-            v16f shb;
-#pragma unroll
-            for (int r = 0; r < 8; ++r) shb[r] = h ? sh[2 * r + 1] : sh[2 * r];
-            dinit[0] = load_bias(lds, 2, 0, h);
-            dinit[1] = load_bias(lds, 2, 1, h);
-            const float4 *A = reinterpret_cast<const float4 *>(lds + PK_D0S) + lane;
-            float4 a00 = A[0], a01 = A[64], a10 = A[128], a11 = A[192];
-            MFMA4(dinit[0], a00, shb[0], shb[1], shb[2], shb[3])
-            MFMA4(dinit[0], a01, shb[4], shb[5], shb[6], shb[7])
-            MFMA4(dinit[1], a10, shb[0], shb[1], shb[2], shb[3])
-            MFMA4(dinit[1], a11, shb[4], shb[5], shb[6], shb[7])
-        }
-        // upstream gradients of this ray and the forward outputs they refer to
-        const float *go = a.grad_out + (size_t)ray * SCANERF_RAY_OUT;
-        const float *fo = a.f.out_ray + (size_t)ray * SCANERF_RAY_OUT;
-        float gD[3], gS[3], gTi[3];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const float pre = fo[5 + c] + fo[8 + c];  // diffuse + specular before the clamp
-            const float grgb = (pre >= 0.0f && pre <= 1.0f) ? go[c] : 0.0f;
-            gD[c] = go[5 + c] + grgb;
-            gS[c] = go[8 + c] + grgb;
-            gTi[c] = go[11 + c];
-        }
-        const float gDepth = go[3], gTl = go[4], gW2 = go[14], Tl = fo[4];
-        float Rsuf = 0.0f;  // sum_{j in later tiles} a_j w_j
+        const float *go = a.grad_out + (size_t)ray * SCANERF_RAY_OUT;  // dL/d(out_ray) of this ray
+        const float *fo = a.f.out_ray + (size_t)ray * SCANERF_RAY_OUT;   // the forward outputs
+        float Rcarry = 0.0f;  // sum of a_j w_j over all later tile groups
 
-        for (int tile = ntiles - 1; tile >= 0; --tile) {
+        for (int grp = ngroups - 1; grp >= 0; --grp) {
+            const int tile = 4 * grp + wv;
             const int s = tile * 32 + sl;
-            const bool live = s < S;
+            const bool live = (tile < ntiles) && (s < S);
             const float z = live ? a.f.z_vals[(size_t)ray * S + s] : 0.0f;
             float delta = live ? a.f.dists[(size_t)ray * S + s] * dnorm : 0.0f;
             if (a.f.infinity && s == S - 1) delta = 1e10f;
             float p[3];
             contract_point(a.f, o, d, z, p);
 
-            // ================= forward recompute =================
+            // ================= P0: forward recompute of this wave's tile =================
             v16f x;
             encode8<DT>(a.f, lres, h, p, x);
-            v16f u0[2] = { load_bias(lds, 0, 0, h), load_bias(lds, 0, 1, h) };
-            mma_block16(u0[0], lds + PK_L0, 0, lane, x);
-            mma_block16(u0[1], lds + PK_L0, 4, lane, x);
             v16f H[2] = { load_bias(lds, 1, 0, h), load_bias(lds, 1, 1, h) };
             {
-                v16f a0 = act16(u0[0]), a1 = act16(u0[1]);
+                v16f u0a = load_bias(lds, 0, 0, h), u0b = load_bias(lds, 0, 1, h);
+                mma_block16(u0a, lds + PK_L0, 0, lane, x);
+                mma_block16(u0b, lds + PK_L0, 4, lane, x);
+                v16f a0 = act16(u0a), a1 = act16(u0b);
                 mma_block16(H[0], lds + PK_L1, 0, lane, a0);
                 mma_block16(H[0], lds + PK_L1, 4, lane, a1);
                 mma_block16(H[1], lds + PK_L1, 8, lane, a0);
@@ -215,7 +205,23 @@ __global__ void __launch_bounds__(kBwdThreads, 1) k_render_bwd(BwdArgs a)
                 dif[c] = sigmoid_(hd[1 + c]);
                 tint[c] = sigmoid_(hd[4 + c]);
             }
-            v16f v0[2] = { dinit[0], dinit[1] };
+            v16f v0[2] = { load_bias(lds, 2, 0, h), load_bias(lds, 2, 1, h) };
+            {   // SH part of the 48 inputs
+                float shl[16];
+                ray_sh(d, dnorm, shl);
+                float shb[8];  // MFMA B operand: step r, half h -> SH[2r+h]
+#pragma unroll
+                for (int r = 0; r < 8; ++r) shb[r] = h ? shl[2 * r + 1] : shl[2 * r];
+                const float *A = lds + PK_D0S + (lane + (lane >> 5)) * 4;
+                const float4 a00 = *reinterpret_cast<const float4 *>(A), a01 = *reinterpret_cast<const float4 *>(A + PK_GRP),
+                             a10 = *reinterpret_cast<const float4 *>(A + 2 * PK_GRP),
+                             a11 = *reinterpret_cast<const float4 *>(A + 3 * PK_GRP);
+                MFMA4(v0[0], a00, shb[0], shb[1], shb[2], shb[3])
+                MFMA4(v0[0], a01, shb[4], shb[5], shb[6], shb[7])
+                MFMA4(v0[1], a10, shb[0], shb[1], shb[2], shb[3])
+                MFMA4(v0[1], a11, shb[4], shb[5], shb[6], shb[7])
+                __builtin_amdgcn_sched_barrier(0);
+            }
             mma_block16(v0[0], lds + PK_D0H, 0, lane, H[1]);
             mma_block16(v0[1], lds + PK_D0H, 4, lane, H[1]);
             v16f v1[2] = { load_bias(lds, 3, 0, h), load_bias(lds, 3, 1, h) };
@@ -240,8 +246,7 @@ __global__ void __launch_bounds__(kBwdThreads, 1) k_render_bwd(BwdArgs a)
 #pragma unroll
                 for (int c = 0; c < 3; ++c) spec[c] = sigmoid_(c3[c] + __shfl_xor(c3[c], 32, 64) + hb[c]);
             }
-
-            // ================= compositing: recompute, then adjoint =================
+            // compositing recompute (identical arithmetic to the forward)
             const float ex = live ? expf(-sigma * delta) : 1.0f;  // 1 - alpha
             const float alpha = 1.0f - ex;
             const float fi = 1.0f - alpha + 1e-6f;
@@ -253,9 +258,19 @@ __global__ void __launch_bounds__(kBwdThreads, 1) k_render_bwd(BwdArgs a)
             }
             float excl = __shfl_up(incl, 1, 32);
             if (sl == 0) excl = 1.0f;
-            const float Ti = a.tile_T[(size_t)ray * ntiles + tile] * excl;
+            const float Ti = (tile < ntiles ? a.tile_T[(size_t)ray * ntiles + tile] : 0.0f) * excl;
             const float w = alpha * Ti;
-
+            // upstream gradients (uniform per ray; read through the scalar cache)
+            float gD[3], gS[3], gTi[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float pre = fo[5 + c] + fo[8 + c];  // diffuse + specular before the clamp
+                const float grgb = (pre >= 0.0f && pre <= 1.0f) ? go[c] : 0.0f;
+                gD[c] = go[5 + c] + grgb;
+                gS[c] = go[8 + c] + grgb;
+                gTi[c] = go[11 + c];
+            }
+            const float gDepth = go[3], gTl = go[4], gW2 = go[14], Tl = fo[4];
             float ai = gDepth * z;
 #pragma unroll
             for (int c = 0; c < 3; ++c) ai += gD[c] * dif[c] + gS[c] * tint[c] * spec[c] + gTi[c] * tint[c];
@@ -266,8 +281,14 @@ __global__ void __launch_bounds__(kBwdThreads, 1) k_render_bwd(BwdArgs a)
                 float t = __shfl_down(rs, off, 32);
                 if (sl + off < 32) rs += t;
             }
-            const float suffix = Rsuf + rs - aw;
-            Rsuf += __shfl(rs, 0, 32);
+            if (lane == 0) totals[wv] = rs;  // lane 0: the whole tile
+            __syncthreads();  // ---- B1: tile totals visible; every wave is done with last group's stage rows
+
+            // ================= P1: compositing adjoint, narrow layers, D1 operands =================
+            const float t0_ = totals[0], t1_ = totals[1], t2_ = totals[2], t3_ = totals[3];
+            const float later = (wv < 1 ? t1_ : 0.0f) + (wv < 2 ? t2_ : 0.0f) + (wv < 3 ? t3_ : 0.0f);
+            const float suffix = Rcarry + later + rs - aw;
+            Rcarry += t0_ + t1_ + t2_ + t3_;
             float dalpha = Ti * ai - (suffix + ((s < S - 1) ? gTl * Tl : 0.0f)) / fi;
             if (!live) dalpha = 0.0f;
             const float dsigma = dalpha * delta * ex;
@@ -284,120 +305,97 @@ __global__ void __launch_bounds__(kBwdThreads, 1) k_render_bwd(BwdArgs a)
 #pragma unroll
             for (int c = 0; c < 3; ++c) gB_d2[c] += gs3[c];
 
-            // small per-sample rows (head / rgb pre-activation gradients) for the VALU weight grads:
-            // scratch rows [c][sample]; read back as broadcasts
-            auto put_rows = [&](const float *vals, int n) {
-                if (h == 0)
-                    for (int c = 0; c < n; ++c) scr[c * kScrStride + sl] = vals[c];
-            };
-
-            // ================= decoder adjoint =================
-            // ---- Directional_MLP.mlp.4 (64 -> 3): dc1 = W^T g ; weight grads on the VALU
+            // Directional_MLP.mlp.4 (64 -> 3): dv1 = (W^T g) * G'(v1)
             v16f dv1[2];
             {
                 const float4 *W = reinterpret_cast<const float4 *>(lds + PK_D2 + h * 128);
 #pragma unroll
                 for (int g = 0; g < 16; ++g) {
                     float4 w0 = W[g], w1 = W[16 + g];
-                    const float c10 = gauss_act(v1[0][g]), c11 = gauss_act(v1[1][g]);
                     const float dc0 = w0.x * gs3[0] + w0.y * gs3[1] + w0.z * gs3[2];
                     const float dc1 = w1.x * gs3[0] + w1.y * gs3[1] + w1.z * gs3[2];
-                    dv1[0][g] = dc0 * dgauss(v1[0][g], c10);
-                    dv1[1][g] = dc1 * dgauss(v1[1][g], c11);
+                    dv1[0][g] = dc0 * dgauss(v1[0][g], gauss_act(v1[0][g]));
+                    dv1[1][g] = dc1 * dgauss(v1[1][g], gauss_act(v1[1][g]));
                 }
             }
-            {   // dW_D2[c][k] += sum_s g[c][s] c1[k][s]
-                put_rows(gs3, 3);
-                v16f t0 = act16(v1[0]), t1 = act16(v1[1]);
-                wave_lds_fence();
-                float4 gr[3][4];
+            // narrow-layer weight gradients on the VALU, own rows as private scratch:
+            // rows 0..9 = head / rgb pre-activation gradients [c][sample]; rows 64.. = the layer inputs
+            if (h == 0) {
 #pragma unroll
-                for (int c = 0; c < 3; ++c)
+                for (int c = 0; c < 7; ++c) slot[c * kScrStride + sl] = gh[c];
 #pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        gr[c][q] = reinterpret_cast<const float4 *>(scr + c * kScrStride + 16 * h)[q];
-                wave_lds_fence();
-                scr_put(scr, lane, 0, t0);
-                scr_put(scr, lane, 32, t1);
-                wave_lds_fence();
-#pragma unroll
-                for (int b = 0; b < 2; ++b) {
-                    v16f xo = scr_get(scr, lane, 32 * b);
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) {
-                        float acc = 0.0f;
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            acc = fmaf(gr[c][q].x, xo[4 * q + 0], acc);
-                            acc = fmaf(gr[c][q].y, xo[4 * q + 1], acc);
-                            acc = fmaf(gr[c][q].z, xo[4 * q + 2], acc);
-                            acc = fmaf(gr[c][q].w, xo[4 * q + 3], acc);
-                        }
-                        gW_D2[b][c] += acc;
-                    }
-                }
-                wave_lds_fence();
+                for (int c = 0; c < 3; ++c) slot[(7 + c) * kScrStride + sl] = gs3[c];
             }
-            // ---- Directional_MLP.mlp.2 (64 -> 64): weight grads dv1 x c0, then dc0 = W^T dv1
             {
-                scr_put(scr, lane, 0, dv1[0]);
-                scr_put(scr, lane, 32, dv1[1]);
+                v16f c1a = act16(v1[0]), c1b = act16(v1[1]);
+                rows_put(slot, lane, 64, c1a);
+                rows_put(slot, lane, 96, c1b);
                 wave_lds_fence();
-                v16f dy0 = scr_get(scr, lane, 0), dy1 = scr_get(scr, lane, 32);
+                v16f xo = rows_get(slot, lane, 64);
+                narrow_wgrad<3>(gW_D2[0], slot + 7 * kScrStride, h, xo);
+                xo = rows_get(slot, lane, 96);
+                narrow_wgrad<3>(gW_D2[1], slot + 7 * kScrStride, h, xo);
                 wave_lds_fence();
-                gB[3][0] += sum16(dy0);
-                gB[3][1] += sum16(dy1);
-                v16f t0 = act16(v0[0]), t1 = act16(v0[1]);
-                scr_put(scr, lane, 0, t0);
-                scr_put(scr, lane, 32, t1);
+                rows_put(slot, lane, 64, H[0]);
                 wave_lds_fence();
-                v16f x0 = scr_get(scr, lane, 0), x1 = scr_get(scr, lane, 32);
+                xo = rows_get(slot, lane, 64);
+                narrow_wgrad<7>(gW_head, slot, h, xo);
                 wave_lds_fence();
-                mma_ws(gW_D1[0][0], dy0, x0);
-                mma_ws(gW_D1[0][1], dy0, x1);
-                mma_ws(gW_D1[1][0], dy1, x0);
-                mma_ws(gW_D1[1][1], dy1, x1);
+            }
+            // stage D1: dY = dv1, X = c0 = G(v0)
+            rows_put(slot, lane, 0, dv1[0]);
+            rows_put(slot, lane, 32, dv1[1]);
+            {
+                v16f c0a = act16(v0[0]), c0b = act16(v0[1]);
+                rows_put(slot, lane, 64, c0a);
+                rows_put(slot, lane, 96, c0b);
+            }
+            __syncthreads();  // ---- B2
+            // ================= P2: owned D1 block; chain to dv0 =================
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const float *ts = stage + t * kSlotFloats;
+                v16f dy = rows_get(ts, lane, 32 * rb), xx = rows_get(ts, lane, 64 + 32 * cb);
+                if (cb == 0) gB_D1 += sum16(dy);
+                mma_ws(gW_D1, dy, xx);
             }
             v16f dv0[2] = { zero16, zero16 };
-            mma_block16(dv0[0], ldt + PKT_D1, 0, lane, dv1[0]);
-            mma_block16(dv0[0], ldt + PKT_D1, 4, lane, dv1[1]);
-            mma_block16(dv0[1], ldt + PKT_D1, 8, lane, dv1[0]);
-            mma_block16(dv0[1], ldt + PKT_D1, 12, lane, dv1[1]);
+            chain16(dv0[0], lds + PK_D1, 8, lane, 0, 0, dv1[0]);
+            chain16(dv0[0], lds + PK_D1, 8, lane, 0, 1, dv1[1]);
+            chain16(dv0[1], lds + PK_D1, 8, lane, 1, 0, dv1[0]);
+            chain16(dv0[1], lds + PK_D1, 8, lane, 1, 1, dv1[1]);
 #pragma unroll
             for (int g = 0; g < 16; ++g) {
                 dv0[0][g] *= dgauss(v0[0][g], gauss_act(v0[0][g]));
                 dv0[1][g] *= dgauss(v0[1][g], gauss_act(v0[1][g]));
             }
-            // ---- Directional_MLP.mlp.0 (48 -> 64): weight grads dv0 x [H1, SH], dH1 = W[:, :32]^T dv0
+            __syncthreads();  // ---- B3: D1 operands consumed
+            // stage D0: dY = dv0, X = H[32:64]
+            rows_put(slot, lane, 0, dv0[0]);
+            rows_put(slot, lane, 32, dv0[1]);
+            rows_put(slot, lane, 64, H[1]);
+            __syncthreads();  // ---- B4
+            // ================= P4: owned D0H half-block (+ SH part, bias); chain to dH =================
             {
-                scr_put(scr, lane, 0, dv0[0]);
-                scr_put(scr, lane, 32, dv0[1]);
-                wave_lds_fence();
-                v16f dy0 = scr_get(scr, lane, 0), dy1 = scr_get(scr, lane, 32);
-                wave_lds_fence();
-                float r0 = sum16(dy0), r1 = sum16(dy1);
-                gB[2][0] += r0;
-                gB[2][1] += r1;
-                r0 += __shfl_xor(r0, 32, 64);  // full row sums (both halves of the tile)
-                r1 += __shfl_xor(r1, 32, 64);
+                float rsum = 0.0f;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const float shv = h ? sh[8 + j] : sh[j];
-                    gW_D0S[0][j] = fmaf(r0, shv, gW_D0S[0][j]);
-                    gW_D0S[1][j] = fmaf(r1, shv, gW_D0S[1][j]);
+                for (int t = 0; t < 2; ++t) {
+                    const float *ts = stage + (2 * tp + t) * kSlotFloats;
+                    v16f dy = rows_get(ts, lane, 32 * rb2), xx = rows_get(ts, lane, 64);
+                    rsum += sum16(dy);
+                    mma_ws(gW_D0H, dy, xx);
                 }
-                scr_put(scr, lane, 0, H[1]);
-                wave_lds_fence();
-                v16f x0 = scr_get(scr, lane, 0);
-                wave_lds_fence();
-                mma_ws(gW_D0H[0], dy0, x0);
-                mma_ws(gW_D0H[1], dy1, x0);
+                gB_D0 += rsum;
+                rsum += __shfl_xor(rsum, 32, 64);  // both halves of the samples
+                float shl[16];
+                ray_sh(d, dnorm, shl);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) gW_D0S[j] = fmaf(rsum, h ? shl[8 + j] : shl[j], gW_D0S[j]);
             }
             v16f dH[2] = { zero16, zero16 };
-            mma_block16(dH[1], ldt + PKT_D0H, 0, lane, dv0[0]);
-            mma_block16(dH[1], ldt + PKT_D0H, 4, lane, dv0[1]);
-            // ---- heads (32 -> 1+3+3): dH0 = W^T g ; weight grads on the VALU
-            {
+            chain16(dH[1], lds + PK_D0H, 4, lane, 0, 0, dv0[0]);
+            chain16(dH[1], lds + PK_D0H, 4, lane, 0, 1, dv0[1]);
+            {   // heads (32 -> 1+3+3): dH[:32] = W^T g
                 const float4 *W = reinterpret_cast<const float4 *>(lds + PK_HEAD + h * 128);
 #pragma unroll
                 for (int g = 0; g < 16; ++g) {
@@ -405,82 +403,61 @@ __global__ void __launch_bounds__(kBwdThreads, 1) k_render_bwd(BwdArgs a)
                     dH[0][g] = wa.x * gh[0] + wa.y * gh[1] + wa.z * gh[2] + wa.w * gh[3] + wb.x * gh[4] + wb.y * gh[5] +
                                wb.z * gh[6];
                 }
-                put_rows(gh, 7);
-                wave_lds_fence();
-                float4 gr[7][4];
-#pragma unroll
-                for (int c = 0; c < 7; ++c)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        gr[c][q] = reinterpret_cast<const float4 *>(scr + c * kScrStride + 16 * h)[q];
-                wave_lds_fence();
-                scr_put(scr, lane, 0, H[0]);
-                wave_lds_fence();
-                v16f xo = scr_get(scr, lane, 0);
-                wave_lds_fence();
-#pragma unroll
-                for (int c = 0; c < 7; ++c) {
-                    float acc = 0.0f;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        acc = fmaf(gr[c][q].x, xo[4 * q + 0], acc);
-                        acc = fmaf(gr[c][q].y, xo[4 * q + 1], acc);
-                        acc = fmaf(gr[c][q].z, xo[4 * q + 2], acc);
-                        acc = fmaf(gr[c][q].w, xo[4 * q + 3], acc);
-                    }
-                    gW_head[c] += acc;
-                }
             }
-            // ---- Spatial_MLP.mlp.2 (64 -> 64): weight grads dH x a0, da0 = W^T dH
+            // u0 recomputed (32 MFMAs) instead of held across the directional stage
+            v16f u0[2] = { load_bias(lds, 0, 0, h), load_bias(lds, 0, 1, h) };
+            mma_block16(u0[0], lds + PK_L0, 0, lane, x);
+            mma_block16(u0[1], lds + PK_L0, 4, lane, x);
+            __syncthreads();  // ---- B5: D0 operands consumed
+            // stage L1: dY = dH, X = a0 = G(u0)
+            rows_put(slot, lane, 0, dH[0]);
+            rows_put(slot, lane, 32, dH[1]);
             {
-                scr_put(scr, lane, 0, dH[0]);
-                scr_put(scr, lane, 32, dH[1]);
-                wave_lds_fence();
-                v16f dy0 = scr_get(scr, lane, 0), dy1 = scr_get(scr, lane, 32);
-                wave_lds_fence();
-                gB[1][0] += sum16(dy0);
-                gB[1][1] += sum16(dy1);
-                v16f t0 = act16(u0[0]), t1 = act16(u0[1]);
-                scr_put(scr, lane, 0, t0);
-                scr_put(scr, lane, 32, t1);
-                wave_lds_fence();
-                v16f x0 = scr_get(scr, lane, 0), x1 = scr_get(scr, lane, 32);
-                wave_lds_fence();
-                mma_ws(gW_L1[0][0], dy0, x0);
-                mma_ws(gW_L1[0][1], dy0, x1);
-                mma_ws(gW_L1[1][0], dy1, x0);
-                mma_ws(gW_L1[1][1], dy1, x1);
+                v16f a0 = act16(u0[0]), a1 = act16(u0[1]);
+                rows_put(slot, lane, 64, a0);
+                rows_put(slot, lane, 96, a1);
+            }
+            __syncthreads();  // ---- B6
+            // ================= P6: owned L1 block; chain to du0 =================
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const float *ts = stage + t * kSlotFloats;
+                v16f dy = rows_get(ts, lane, 32 * rb), xx = rows_get(ts, lane, 64 + 32 * cb);
+                if (cb == 0) gB_L1 += sum16(dy);
+                mma_ws(gW_L1, dy, xx);
             }
             v16f du0[2] = { zero16, zero16 };
-            mma_block16(du0[0], ldt + PKT_L1, 0, lane, dH[0]);
-            mma_block16(du0[0], ldt + PKT_L1, 4, lane, dH[1]);
-            mma_block16(du0[1], ldt + PKT_L1, 8, lane, dH[0]);
-            mma_block16(du0[1], ldt + PKT_L1, 12, lane, dH[1]);
+            chain16(du0[0], lds + PK_L1, 8, lane, 0, 0, dH[0]);
+            chain16(du0[0], lds + PK_L1, 8, lane, 0, 1, dH[1]);
+            chain16(du0[1], lds + PK_L1, 8, lane, 1, 0, dH[0]);
+            chain16(du0[1], lds + PK_L1, 8, lane, 1, 1, dH[1]);
 #pragma unroll
             for (int g = 0; g < 16; ++g) {
                 du0[0][g] *= dgauss(u0[0][g], gauss_act(u0[0][g]));
                 du0[1][g] *= dgauss(u0[1][g], gauss_act(u0[1][g]));
             }
-            // ---- Spatial_MLP.mlp.0 (32 -> 64): weight grads du0 x x, dx = W'^T du0
+            __syncthreads();  // ---- B7: L1 operands consumed
+            // stage L0: dY = du0, X = x (32 input rows)
+            rows_put(slot, lane, 0, du0[0]);
+            rows_put(slot, lane, 32, du0[1]);
+            rows_put(slot, lane, 64, x);
+            __syncthreads();  // ---- B8
+            // ================= P8: owned L0 half-block; dx =================
             {
-                scr_put(scr, lane, 0, du0[0]);
-                scr_put(scr, lane, 32, du0[1]);
-                wave_lds_fence();
-                v16f dy0 = scr_get(scr, lane, 0), dy1 = scr_get(scr, lane, 32);
-                wave_lds_fence();
-                gB[0][0] += sum16(dy0);
-                gB[0][1] += sum16(dy1);
-                scr_put(scr, lane, 0, x);
-                wave_lds_fence();
-                v16f x0 = scr_get(scr, lane, 0);
-                wave_lds_fence();
-                mma_ws(gW_L0[0], dy0, x0);
-                mma_ws(gW_L0[1], dy1, x0);
+                float rsum = 0.0f;
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const float *ts = stage + (2 * tp + t) * kSlotFloats;
+                    v16f dy = rows_get(ts, lane, 32 * rb2), xx = rows_get(ts, lane, 64);
+                    rsum += sum16(dy);
+                    mma_ws(gW_L0, dy, xx);
+                }
+                gB_L0 += rsum;
             }
             v16f dx = zero16;
-            mma_block16(dx, ldt + PKT_L0, 0, lane, du0[0]);
-            mma_block16(dx, ldt + PKT_L0, 4, lane, du0[1]);
-            // ---- feature gradients, level-major (register 2j+f of half h = level 4(j>>1)+2h+(j&1))
+            chain16(dx, lds + PK_L0, 4, lane, 0, 0, du0[0]);
+            chain16(dx, lds + PK_L0, 4, lane, 0, 1, du0[1]);
+            // feature gradients, level-major (register 2j+f of half h = level 4(j>>1)+2h+(j&1))
             if (live) {
                 const size_t n = (size_t)ray * S + s, NS = (size_t)a.f.B * S;
 #pragma unroll
@@ -489,39 +466,34 @@ __global__ void __launch_bounds__(kBwdThreads, 1) k_render_bwd(BwdArgs a)
                     reinterpret_cast<float2 *>(a.dfeat)[(size_t)level * NS + n] = make_float2(dx[2 * j], dx[2 * j + 1]);
                 }
             }
+            // (the next group's B1 orders this group's stage reads before the next writes)
         }
     }
 
-    // ---- flush this wave's weight-gradient partial sums in blob order -------------------------------
-    float *out = a.dw_partial + (size_t)wave0 * SCANERF_PARAMSIZE;
+    // ---- flush this wave's partial sums in blob order (dw_partial is zero-filled: only owned entries are written)
+    float *out = a.dw_partial + (size_t)(blockIdx.x * 4 + wv) * SCANERF_PARAMSIZE;
     const int k = lane & 31;
-    auto put_w = [&](const v16f &acc, int base, int rb, int cb) {
+    auto put_w = [&](const v16f &acc, int base, int rbk, int cbk) {
 #pragma unroll
-        for (int g = 0; g < 16; ++g) out[base + 64 + (32 * cb + k) * 64 + 32 * rb + nmap(g, h)] = acc[g];
+        for (int g = 0; g < 16; ++g) out[base + 64 + (32 * cbk + k) * 64 + 32 * rbk + nmap(g, h)] = acc[g];
     };
-    put_w(gW_L0[0], BLOB_S0, 0, 0);
-    put_w(gW_L0[1], BLOB_S0, 1, 0);
-    put_w(gW_D0H[0], BLOB_D0, 0, 0);
-    put_w(gW_D0H[1], BLOB_D0, 1, 0);
+    put_w(gW_D1, BLOB_D1, rb, cb);
+    put_w(gW_L1, BLOB_S1, rb, cb);
+    put_w(gW_D0H, BLOB_D0, rb2, 0);
+    put_w(gW_L0, BLOB_S0, rb2, 0);
 #pragma unroll
-    for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-        for (int cb = 0; cb < 2; ++cb) {
-            put_w(gW_L1[rb][cb], BLOB_S1, rb, cb);
-            put_w(gW_D1[rb][cb], BLOB_D1, rb, cb);
-        }
-#pragma unroll
-    for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) out[BLOB_D0 + 64 + (32 + 8 * h + j) * 64 + 32 * rb + k] = gW_D0S[rb][j];
-    const int bases[4] = { BLOB_S0, BLOB_S1, BLOB_D0, BLOB_D1 };
-#pragma unroll
-    for (int l = 0; l < 4; ++l)
-#pragma unroll
-        for (int rb = 0; rb < 2; ++rb) {
-            float v = gB[l][rb] + __shfl_xor(gB[l][rb], 32, 64);
-            if (h == 0) out[bases[l] + 32 * rb + k] = v;
-        }
+    for (int j = 0; j < 8; ++j) out[BLOB_D0 + 64 + (32 + 8 * h + j) * 64 + 32 * rb2 + k] = gW_D0S[j];
+    {
+        float v;
+        v = gB_D1 + __shfl_xor(gB_D1, 32, 64);
+        if (h == 0 && cb == 0) out[BLOB_D1 + 32 * rb + k] = v;
+        v = gB_L1 + __shfl_xor(gB_L1, 32, 64);
+        if (h == 0 && cb == 0) out[BLOB_S1 + 32 * rb + k] = v;
+        v = gB_D0 + __shfl_xor(gB_D0, 32, 64);
+        if (h == 0) out[BLOB_D0 + 32 * rb2 + k] = v;
+        v = gB_L0 + __shfl_xor(gB_L0, 32, 64);
+        if (h == 0) out[BLOB_S0 + 32 * rb2 + k] = v;
+    }
 #pragma unroll
     for (int c = 0; c < 7; ++c) {
         float v = gW_head[c] + __shfl_xor(gW_head[c], 32, 64);
@@ -564,7 +536,7 @@ __global__ void __launch_bounds__(256) k_reduce_dw(const float *__restrict__ par
 }  // namespace
 
 // ---------------------------------------------------------------------------- C ABI
-SCANERF_API int scanerf_render_backward_grid(int B) { int blocks = ceil_div(B, 4); return blocks > kNumCU ? kNumCU : blocks; }
+SCANERF_API int scanerf_render_backward_grid(int B) { return B > kNumCU ? kNumCU : (B < 1 ? 1 : B); }
 
 // dw_partial: [4 * scanerf_render_backward_grid(B)][13994] f32 scratch; grad_blob [13994] is accumulated into.
 SCANERF_API int scanerf_render_backward(const float *rays_o, const float *rays_d, const float *z_vals, const float *dists,
@@ -593,11 +565,12 @@ SCANERF_API int scanerf_render_backward(const float *rays_o, const float *rays_d
         a.f.bbox_size[k] = cfg->bbox_size[k];
         a.f.inv_size4[k] = 4.0f / cfg->bbox_size[k];
     }
-    a.grad_out = grad_out; a.tile_T = tile_T; a.packed_t = workspace + PK_TOTAL; a.dfeat = dfeat;
-    a.dw_partial = dw_partial;
+    a.grad_out = grad_out; a.tile_T = tile_T; a.dfeat = dfeat; a.dw_partial = dw_partial;
     const int blocks = scanerf_render_backward_grid(B);
     const size_t lds_bytes = (size_t)kBwdLdsFloats * sizeof(float);
     hipStream_t st = (hipStream_t)stream;
+    hipError_t me = hipMemsetAsync(dw_partial, 0, (size_t)blocks * 4 * SCANERF_PARAMSIZE * sizeof(float), st);
+    SCANERF_REQUIRE(me == hipSuccess, "render_backward: memset failed: %s", hipGetErrorString(me));
 #define SCANERF_LAUNCH_BWD(DT)                                                                                     \
     {                                                                                                              \
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_render_bwd<DT>),                      \

@@ -32,26 +32,29 @@ constexpr int BLOB_D1 = 9639;    // 64 + 64x64
 constexpr int BLOB_D2 = 13799;   // 3 + 64x3
 static_assert(BLOB_D2 + 3 + 192 == SCANERF_PARAMSIZE, "blob layout");
 
-// packed image offsets (floats).  A-images are [block][group of 4 steps][lane][4].
-constexpr int PK_L0 = 0;        // 2 x 4 x 256   (K=32; weight_feature folded in)
-constexpr int PK_L1 = 2048;     // 2 x 8 x 256   (K=64)
-constexpr int PK_D0H = 6144;    // 2 x 4 x 256   (K=32: the H[32:64] half of the 48 inputs)
-constexpr int PK_D0S = 8192;    // 2 x 2 x 256   (K=16: the SH half)
-constexpr int PK_D1 = 9216;     // 2 x 8 x 256   (K=64)
-constexpr int PK_BIAS = 13312;  // [layer 4][block 2][half 2][16]
-constexpr int PK_HEAD = 13568;  // [half 2][g 16][8]: sigma, diffuse xyz, tint xyz, 0
-constexpr int PK_D2 = 13824;    // [half 2][block 2][g 16][4]: rgb rows of Directional_MLP.mlp.4, 0
-constexpr int PK_HB = 14080;    // head biases: sigma, dif3, tint3, 0, d2 xyz, 0...
-constexpr int PK_TOTAL = 14096;
+// packed image offsets (floats).  A-images are [block][group of 4 steps][lane slot][4] with a
+// group stride of 264 floats and the upper half-wave shifted by one 16-byte slot
+// (slot = lane + (lane >> 5)).  The forward reads one float4 per lane per group (conflict-free
+// either way); the padding makes the TRANSPOSED walk of the same image -- lane = input unit,
+// step = output unit, one ds_read_b32 per MFMA, used by the backward chain dX^T = W^T dY^T --
+// hit 32 distinct banks, so no second (transposed) copy of the weights is needed in LDS.
+constexpr int PK_GRP = 264;
+constexpr int PK_L0 = 0;                      // 2 x 4 groups (K=32; weight_feature folded in)
+constexpr int PK_L1 = PK_L0 + 8 * PK_GRP;     // 2 x 8 groups (K=64)
+constexpr int PK_D0H = PK_L1 + 16 * PK_GRP;   // 2 x 4 groups (K=32: the H[32:64] half of the 48 inputs)
+constexpr int PK_D0S = PK_D0H + 8 * PK_GRP;   // 2 x 2 groups (K=16: the SH half)
+constexpr int PK_D1 = PK_D0S + 4 * PK_GRP;    // 2 x 8 groups (K=64)
+constexpr int PK_BIAS = PK_D1 + 16 * PK_GRP;  // [layer 4][block 2][half 2][16]
+constexpr int PK_HEAD = PK_BIAS + 256;        // [half 2][g 16][8]: sigma, diffuse xyz, tint xyz, 0
+constexpr int PK_D2 = PK_HEAD + 256;          // [half 2][block 2][g 16][4]: rgb rows of Directional_MLP.mlp.4, 0
+constexpr int PK_HB = PK_D2 + 256;            // head biases: sigma, dif3, tint3, 0, d2 xyz, 0...
+constexpr int PK_TOTAL = PK_HB + 16;
+static_assert(PK_TOTAL % 4 == 0, "image is copied as float4");
 
 __host__ __device__ constexpr int nmap(int g, int h) { return (g & 3) + 8 * (g >> 2) + 4 * h; }
 
-// Transposed A-images for the backward pass (dX^T = W^T dY^T): same scheme with the roles
-// of input and output swapped.  [block of 32 INPUT units][group][lane][4]
-constexpr int PKT_L1 = 0;       // 2 x 8 x 256: A[i = input k][step -> output n]
-constexpr int PKT_D0H = 4096;   // 1 x 8 x 256: inputs = H[32:64] (32 rows), K = 64 outputs
-constexpr int PKT_D1 = 6144;    // 2 x 8 x 256
-constexpr int PKT_L0 = 10240;   // 1 x 8 x 256: inputs = 32 features (weight_feature folded), K = 64
-constexpr int PKT_TOTAL = 12288;
+// inverse of nmap within a 32-unit block: unit i5 -> (register g, half h)
+__host__ __device__ constexpr int nmap_g(int i5) { return (i5 & 3) + 4 * (i5 >> 3); }
+__host__ __device__ constexpr int nmap_h(int i5) { return (i5 >> 2) & 1; }
 
 }  // namespace scanerf

@@ -32,13 +32,29 @@ __device__ __forceinline__ v16f load_bias(const float *lds, int layer, int blk, 
 // one 32-row output block over a 16-register (32-input) B tile: 4 groups of 4 steps
 __device__ __forceinline__ void mma_block16(v16f &acc, const float *img, int grp0, int lane, const v16f &b)
 {
-    const float4 *A = reinterpret_cast<const float4 *>(img) + lane;
-    float4 a0 = A[(grp0 + 0) * 64], a1 = A[(grp0 + 1) * 64], a2 = A[(grp0 + 2) * 64], a3 = A[(grp0 + 3) * 64];
+    const float *A = img + (lane + (lane >> 5)) * 4;
+    const float4 a0 = *reinterpret_cast<const float4 *>(A + (grp0 + 0) * PK_GRP),
+                 a1 = *reinterpret_cast<const float4 *>(A + (grp0 + 1) * PK_GRP),
+                 a2 = *reinterpret_cast<const float4 *>(A + (grp0 + 2) * PK_GRP),
+                 a3 = *reinterpret_cast<const float4 *>(A + (grp0 + 3) * PK_GRP);
     MFMA4(acc, a0, b[0], b[1], b[2], b[3])
     MFMA4(acc, a1, b[4], b[5], b[6], b[7])
     MFMA4(acc, a2, b[8], b[9], b[10], b[11])
     MFMA4(acc, a3, b[12], b[13], b[14], b[15])
     __builtin_amdgcn_sched_barrier(0);  // keep the scheduler from hoisting every layer's LDS reads
+}
+
+// Backward chain through the SAME image: acc[i][s] += sum_n W[n][i] dY[n][s] for the 16 output
+// units n held in dy (output block nb), i = this lane's input unit of input block ib.
+// One conflict-free ds_read_b32 per MFMA (see PK_GRP in render_common.h).
+__device__ __forceinline__ void chain16(v16f &acc, const float *img, int ngrp, int lane, int ib, int nb, const v16f &dy)
+{
+    const int i5 = lane & 31, hp = lane >> 5;
+    const int ri = 16 * ib + nmap_g(i5), hi = nmap_h(i5);
+    const float *A = img + (nb * ngrp + (ri >> 2)) * PK_GRP + (4 * hp + 33 * hi) * 4 + (ri & 3);
+#pragma unroll
+    for (int g = 0; g < 16; ++g) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A[nmap(g, 0) * 4], dy[g], acc, 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
 }
 
 __device__ __forceinline__ v16f act16(const v16f &x)

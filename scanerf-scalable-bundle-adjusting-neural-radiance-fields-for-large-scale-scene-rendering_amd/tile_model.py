@@ -171,11 +171,12 @@ class KernelTimer:
     def reset(self):
         self.events = {}
         self.bytes = {}
+        self.flops = {}
         self.count = 0
 
     class _Section:
-        def __init__(self, timer, name, alg_bytes):
-            self.t, self.name, self.alg = timer, name, alg_bytes
+        def __init__(self, timer, name, alg_bytes, alg_flops=0):
+            self.t, self.name, self.alg, self.flp = timer, name, alg_bytes, alg_flops
 
         def __enter__(self):
             self.e0 = torch.cuda.Event(enable_timing=True)
@@ -186,20 +187,22 @@ class KernelTimer:
             self.e1.record()
             self.t.events.setdefault(self.name, []).append((self.e0, self.e1))
             self.t.bytes[self.name] = self.alg
+            self.t.flops[self.name] = self.flp
             self.t.count += 1
 
-    def section(self, name, alg_bytes=0):
-        return KernelTimer._Section(self, name, alg_bytes)
+    def section(self, name, alg_bytes=0, alg_flops=0):
+        return KernelTimer._Section(self, name, alg_bytes, alg_flops)
 
     def summary(self):
         torch.cuda.synchronize()
         return {k: sum(a.elapsed_time(b) for a, b in v) / len(v) for k, v in self.events.items()}
 
     def dominant(self, *_):
+        """(name, avg ms, algorithmic bytes, algorithmic flops) of the section with the largest time."""
         s = self.summary()
         cand = {k: v for k, v in s.items() if self.bytes.get(k, 0) > 0}
         name = max(cand, key=cand.get)
-        return name, cand[name], self.bytes[name]
+        return name, cand[name], self.bytes[name], self.flops.get(name, 0)
 
 
 class _Null:
@@ -210,8 +213,11 @@ class _Null:
         return False
 
 
-def _sec(timer, name, alg_bytes=0):
-    return timer.section(name, alg_bytes) if timer is not None else _Null()
+def _sec(timer, name, alg_bytes=0, alg_flops=0):
+    return timer.section(name, alg_bytes, alg_flops) if timer is not None else _Null()
+
+
+MLP_FLOPS_PER_SAMPLE = 2 * 13728  # 27 456 FLOP per sample forward
 
 
 def train_step_ops(model, dec_opt, rays_o, rays_d, target, S, global_step, table_lr=1e-2, timer=None):
@@ -249,7 +255,8 @@ def train_step_fused(model, dec_opt, rays_o, rays_d, target, S, global_step, tab
         ntile = (S + 31) // 32
         tile_T = torch.empty((B, ntile), device=dev)
         box = (model.min_bbox.tolist(), model.bbox_size.tolist(), render.FORE, False)
-        with _sec(timer, "render_forward", B * (24 + 20 + S * 16 * 8 * 2 * model.features.element_size())):
+        with _sec(timer, "render_forward", B * (24 + 20 + S * 16 * 8 * 2 * model.features.element_size()),
+                  B * S * MLP_FLOPS_PER_SAMPLE):
             out, _ = render.render_forward(rays_o, rays_d, z, dist, model.features, model.resolution, model.packed, *box,
                                            ray_valid=valid, want_weights=False, tile_T=tile_T)
     # loss on the per-ray outputs (tiny torch graph on [B,16])
@@ -258,7 +265,8 @@ def train_step_fused(model, dec_opt, rays_o, rays_d, target, S, global_step, tab
     loss = F.mse_loss(leaf[:, 0:3][valid], target[valid]) + 0.01 * leaf[:, 14][valid].sum() / (3 * nv)
     loss.backward()
     with torch.no_grad():
-        with _sec(timer, "render_backward", B * (24 + 20 + S * 16 * 8 * 2 * 4 + S * 16 * 8)):
+        # forward recompute + activation gradients + weight gradients = 3x the forward MLP FLOPs
+        with _sec(timer, "render_backward", B * (24 + 20 + S * 16 * 8 * 2 * 4 + S * 16 * 8), 3 * B * S * MLP_FLOPS_PER_SAMPLE):
             dfeat, gblob = render.render_backward(rays_o, rays_d, z, dist, model.features, model.resolution, model.packed,
                                                   wf, *box, out, tile_T, leaf.grad, ray_valid=valid)
         pts = ((rays_o[:, None, :] + z[..., None] * rays_d[:, None, :]).reshape(-1, 3) - model._min_dev) \
