@@ -45,6 +45,21 @@ struct BwdArgs {
 
 __device__ __forceinline__ float dgauss(float u, float a) { return -100.0f * u * a; }  // d/du exp(-50 u^2)
 
+// Hide a value's provenance from the optimiser.  The kernel RECOMPUTES cheap activations
+// (exp(-50 u^2), SH of the ray) at each use instead of holding them; without this the compiler
+// common-subexpression-eliminates the recomputation and keeps 32-64 extra registers alive across
+// the phases, which is what pushes the wave into scratch.
+__device__ __forceinline__ v16f opaque16(v16f v)
+{
+    asm volatile("" : "+v"(v));
+    return v;
+}
+__device__ __forceinline__ float opaque1(float v)
+{
+    asm volatile("" : "+v"(v));
+    return v;
+}
+
 // registers (lane = sample s, half h, reg g = unit nmap(g,h))  ->  rows[unit][sample]
 __device__ __forceinline__ void rows_put(float *rows, int lane, int rowbase, const v16f &v)
 {
@@ -118,8 +133,7 @@ __global__ void __launch_bounds__(kBwdThreads, 1) k_render_bwd(BwdArgs a)
         }
     }
     __syncthreads();
-    const int lane = threadIdx.x & 63, sl = lane & 31, h = lane >> 5, wv = threadIdx.x >> 6;
-    float *slot = stage + wv * kSlotFloats;  // this wave's rows
+    const int lane_k = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int S = a.f.S, ntiles = (S + 31) >> 5, ngroups = (ntiles + 3) >> 2;
     // ownership of the weight-gradient blocks: 64x64 layers -> block (rb, cb) over all 4 tiles;
     // 64x32 layers -> row block rb2 over a PAIR of tiles
@@ -159,6 +173,12 @@ __global__ void __launch_bounds__(kBwdThreads, 1) k_render_bwd(BwdArgs a)
         float Rcarry = 0.0f;  // sum of a_j w_j over all later tile groups
 
         for (int grp = ngroups - 1; grp >= 0; --grp) {
+            // Lane-derived LDS / global addresses are recomputed per tile group: hoisted to kernel entry
+            // they are hundreds of lane-constant registers that end up spilled and reloaded from scratch.
+            int lane = lane_k;
+            asm volatile("" : "+v"(lane));
+            const int sl = lane & 31, h = lane >> 5;
+            float *slot = stage + wv * kSlotFloats;  // this wave's rows
             const int tile = 4 * grp + wv;
             const int s = tile * 32 + sl;
             const bool live = (tile < ntiles) && (s < S);
@@ -314,8 +334,9 @@ __global__ void __launch_bounds__(kBwdThreads, 1) k_render_bwd(BwdArgs a)
                     float4 w0 = W[g], w1 = W[16 + g];
                     const float dc0 = w0.x * gs3[0] + w0.y * gs3[1] + w0.z * gs3[2];
                     const float dc1 = w1.x * gs3[0] + w1.y * gs3[1] + w1.z * gs3[2];
-                    dv1[0][g] = dc0 * dgauss(v1[0][g], gauss_act(v1[0][g]));
-                    dv1[1][g] = dc1 * dgauss(v1[1][g], gauss_act(v1[1][g]));
+                    const float q0 = opaque1(v1[0][g]), q1 = opaque1(v1[1][g]);
+                    dv1[0][g] = dc0 * dgauss(q0, gauss_act(q0));
+                    dv1[1][g] = dc1 * dgauss(q1, gauss_act(q1));
                 }
             }
             // narrow-layer weight gradients on the VALU, own rows as private scratch:
@@ -327,7 +348,7 @@ __global__ void __launch_bounds__(kBwdThreads, 1) k_render_bwd(BwdArgs a)
                 for (int c = 0; c < 3; ++c) slot[(7 + c) * kScrStride + sl] = gs3[c];
             }
             {
-                v16f c1a = act16(v1[0]), c1b = act16(v1[1]);
+                v16f c1a = act16(opaque16(v1[0])), c1b = act16(opaque16(v1[1]));
                 rows_put(slot, lane, 64, c1a);
                 rows_put(slot, lane, 96, c1b);
                 wave_lds_fence();
@@ -346,7 +367,7 @@ __global__ void __launch_bounds__(kBwdThreads, 1) k_render_bwd(BwdArgs a)
             rows_put(slot, lane, 0, dv1[0]);
             rows_put(slot, lane, 32, dv1[1]);
             {
-                v16f c0a = act16(v0[0]), c0b = act16(v0[1]);
+                v16f c0a = act16(opaque16(v0[0])), c0b = act16(opaque16(v0[1]));
                 rows_put(slot, lane, 64, c0a);
                 rows_put(slot, lane, 96, c0b);
             }
@@ -366,8 +387,9 @@ __global__ void __launch_bounds__(kBwdThreads, 1) k_render_bwd(BwdArgs a)
             chain16(dv0[1], lds + PK_D1, 8, lane, 1, 1, dv1[1]);
 #pragma unroll
             for (int g = 0; g < 16; ++g) {
-                dv0[0][g] *= dgauss(v0[0][g], gauss_act(v0[0][g]));
-                dv0[1][g] *= dgauss(v0[1][g], gauss_act(v0[1][g]));
+                const float q0 = opaque1(v0[0][g]), q1 = opaque1(v0[1][g]);
+                dv0[0][g] *= dgauss(q0, gauss_act(q0));
+                dv0[1][g] *= dgauss(q1, gauss_act(q1));
             }
             __syncthreads();  // ---- B3: D1 operands consumed
             // stage D0: dY = dv0, X = H[32:64]
@@ -388,7 +410,7 @@ __global__ void __launch_bounds__(kBwdThreads, 1) k_render_bwd(BwdArgs a)
                 gB_D0 += rsum;
                 rsum += __shfl_xor(rsum, 32, 64);  // both halves of the samples
                 float shl[16];
-                ray_sh(d, dnorm, shl);
+                ray_sh(d, opaque1(dnorm), shl);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) gW_D0S[j] = fmaf(rsum, h ? shl[8 + j] : shl[j], gW_D0S[j]);
             }
@@ -413,7 +435,7 @@ __global__ void __launch_bounds__(kBwdThreads, 1) k_render_bwd(BwdArgs a)
             rows_put(slot, lane, 0, dH[0]);
             rows_put(slot, lane, 32, dH[1]);
             {
-                v16f a0 = act16(u0[0]), a1 = act16(u0[1]);
+                v16f a0 = act16(opaque16(u0[0])), a1 = act16(opaque16(u0[1]));
                 rows_put(slot, lane, 64, a0);
                 rows_put(slot, lane, 96, a1);
             }
@@ -433,8 +455,9 @@ __global__ void __launch_bounds__(kBwdThreads, 1) k_render_bwd(BwdArgs a)
             chain16(du0[1], lds + PK_L1, 8, lane, 1, 1, dH[1]);
 #pragma unroll
             for (int g = 0; g < 16; ++g) {
-                du0[0][g] *= dgauss(u0[0][g], gauss_act(u0[0][g]));
-                du0[1][g] *= dgauss(u0[1][g], gauss_act(u0[1][g]));
+                const float q0 = opaque1(u0[0][g]), q1 = opaque1(u0[1][g]);
+                du0[0][g] *= dgauss(q0, gauss_act(q0));
+                du0[1][g] *= dgauss(q1, gauss_act(q1));
             }
             __syncthreads();  // ---- B7: L1 operands consumed
             // stage L0: dY = du0, X = x (32 input rows)
@@ -472,6 +495,7 @@ __global__ void __launch_bounds__(kBwdThreads, 1) k_render_bwd(BwdArgs a)
 
     // ---- flush this wave's partial sums in blob order (dw_partial is zero-filled: only owned entries are written)
     float *out = a.dw_partial + (size_t)(blockIdx.x * 4 + wv) * SCANERF_PARAMSIZE;
+    const int lane = lane_k, h = lane >> 5;
     const int k = lane & 31;
     auto put_w = [&](const v16f &acc, int base, int rbk, int cbk) {
 #pragma unroll

@@ -173,38 +173,51 @@ __global__ void __launch_bounds__(kThreads) k_bin_scatter(const float *__restric
     __syncthreads();
     const uint32_t mask = (uint32_t)g.T - 1u, lmask = (1u << g.bucket_log) - 1u;
     const int lo = blockIdx.x * g.per_wg, hi = min(g.N, lo + g.per_wg);
-    for (int i = lo + threadIdx.x; i < hi; i += kThreads) {
-        const float p[3] = { points[3 * i], points[3 * i + 1], points[3 * i + 2] };
-        for (int l = 0; l < g.L; ++l) {
-            const float2 gi = LEVEL_MAJOR_GRAD ? grad_in[(size_t)l * g.N + i] : grad_in[(size_t)i * g.L + l];
-            gmax = fmaxf(gmax, fmaxf(fabsf(gi.x), fabsf(gi.y)));
-            Pairs pr;
-            make_pairs(p, resolutions + 3 * l, mask, pr);
+    // One (sample, level): 4 records.
+    auto one = [&](int i, int l, const float p[3]) {
+        const float2 gi = LEVEL_MAJOR_GRAD ? grad_in[(size_t)l * g.N + i] : grad_in[(size_t)i * g.L + l];
+        gmax = fmaxf(gmax, fmaxf(fabsf(gi.x), fabsf(gi.y)));
+        Pairs pr;
+        make_pairs(p, resolutions + 3 * l, mask, pr);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const uint32_t b0 = pr.idx0[q] >> g.bucket_log, b1 = pr.idx1[q] >> g.bucket_log;
-                const float gx = pr.wyz[q] * gi.x, gy = pr.wyz[q] * gi.y;
-                auto emit = [&](uint32_t bkt, uint32_t hdr, float tx, float ax, float ay) {
-                    const uint32_t pos = atomicAdd(&cursor[l * g.NB + bkt], 1u);
-                    if (pos < g.capacity) {
-                        reinterpret_cast<float4 *>(recs)[pos] = make_float4(__uint_as_float(hdr), tx, ax, ay);
-                    } else {  // workspace too small: apply directly (slow path, correctness only)
-                        float *gs = grad_features + ((size_t)l * g.T + ((size_t)bkt << g.bucket_log)) * 2;
-                        const uint32_t e0 = hdr & 0xffffu, e1 = hdr >> 16;
-                        unsafeAtomicAdd(gs + 2 * e0, (1.0f - tx) * ax);
-                        unsafeAtomicAdd(gs + 2 * e0 + 1, (1.0f - tx) * ay);
-                        unsafeAtomicAdd(gs + 2 * e1, tx * ax);
-                        unsafeAtomicAdd(gs + 2 * e1 + 1, tx * ay);
-                    }
-                };
-                if (b1 == b0) {
-                    emit(b0, (pr.idx0[q] & lmask) | ((pr.idx1[q] & lmask) << 16), pr.tx, gx, gy);
-                } else {  // x-neighbours straddle a bucket boundary (only when x+1 reaches 2^bucket_log)
-                    const float a = 1.0f - pr.tx;
-                    emit(b0, (pr.idx0[q] & lmask) * 0x10001u, 0.0f, a * gx, a * gy);
-                    emit(b1, (pr.idx1[q] & lmask) * 0x10001u, 0.0f, pr.tx * gx, pr.tx * gy);
+        for (int q = 0; q < 4; ++q) {
+            const uint32_t b0 = pr.idx0[q] >> g.bucket_log, b1 = pr.idx1[q] >> g.bucket_log;
+            const float gx = pr.wyz[q] * gi.x, gy = pr.wyz[q] * gi.y;
+            auto emit = [&](uint32_t bkt, uint32_t hdr, float tx, float ax, float ay) {
+                const uint32_t pos = atomicAdd(&cursor[l * g.NB + bkt], 1u);
+                if (pos < g.capacity) {
+                    reinterpret_cast<float4 *>(recs)[pos] = make_float4(__uint_as_float(hdr), tx, ax, ay);
+                } else {  // workspace too small: apply directly (slow path, correctness only)
+                    float *gs = grad_features + ((size_t)l * g.T + ((size_t)bkt << g.bucket_log)) * 2;
+                    const uint32_t e0 = hdr & 0xffffu, e1 = hdr >> 16;
+                    unsafeAtomicAdd(gs + 2 * e0, (1.0f - tx) * ax);
+                    unsafeAtomicAdd(gs + 2 * e0 + 1, (1.0f - tx) * ay);
+                    unsafeAtomicAdd(gs + 2 * e1, tx * ax);
+                    unsafeAtomicAdd(gs + 2 * e1 + 1, tx * ay);
                 }
+            };
+            if (b1 == b0) {
+                emit(b0, (pr.idx0[q] & lmask) | ((pr.idx1[q] & lmask) << 16), pr.tx, gx, gy);
+            } else {  // x-neighbours straddle a bucket boundary (only when x+1 reaches 2^bucket_log)
+                const float a = 1.0f - pr.tx;
+                emit(b0, (pr.idx0[q] & lmask) * 0x10001u, 0.0f, a * gx, a * gy);
+                emit(b1, (pr.idx1[q] & lmask) * 0x10001u, 0.0f, pr.tx * gx, pr.tx * gy);
             }
+        }
+    };
+    if (LEVEL_MAJOR_GRAD) {
+        // level-major walk: a workgroup appends to only NB bins at a time, so the partially written
+        // lines of its ranges (one per bin) stay in L2 until complete (full-line write-backs); the
+        // gradient reads are contiguous per level and the points are re-read from L2.
+        for (int l = 0; l < g.L; ++l)
+            for (int i = lo + threadIdx.x; i < hi; i += kThreads) {
+                const float p[3] = { points[3 * i], points[3 * i + 1], points[3 * i + 2] };
+                one(i, l, p);
+            }
+    } else {
+        for (int i = lo + threadIdx.x; i < hi; i += kThreads) {
+            const float p[3] = { points[3 * i], points[3 * i + 1], points[3 * i + 2] };
+            for (int l = 0; l < g.L; ++l) one(i, l, p);
         }
     }
     // launch-wide max |dL/dout| for the fixed-point scale of the accumulate pass
