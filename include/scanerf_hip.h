@@ -176,6 +176,58 @@ int scanerf_embedding_bg_forward_ex(const float *points, float *outputs, const v
                                     const int32_t *resolutions, int N, int L, int T, int feat_dtype,
                                     int variant, int level_major_out, scanerf_stream_t stream);
 
+/* ---- HASHGRID surface, render-time ops (hashgrid/include/rendering.h:20-182;
+ *      hashgrid/src/rendering_kernel.cu, file:line per function) --------------------------------
+ * Tile set: corners/sizes [nb,3] f32; occ = concatenated bool grids; grid_starts [nb] i64;
+ * log2dim [nb,3] i32; intersections [B,nb,2] f32 (1e7 = miss); tracing_blocks [B,nb] i32
+ * (argsort of near); block indices are int16, 4 slots, -1 = none. */
+int scanerf_ray_block_intersection(const float *rays_o, const float *rays_d, const float *corners,
+                                   const float *sizes, float *intersections, int B, int nb,
+                                   scanerf_stream_t stream);                                   /* :126-174 */
+int scanerf_render_sample_points(const float *rays_o, const float *rays_d, const float *corners,
+                                 const float *sizes, const uint8_t *occ, const int64_t *grid_starts,
+                                 const int32_t *log2dim, const int32_t *tracing_blocks,
+                                 const float *intersections, int32_t *tracing_idx, float *z_start,
+                                 float *z_vals, float *dists, int B, int S, int nb,
+                                 scanerf_stream_t stream);                                     /* :179-382 */
+int scanerf_prepare_points(const float *z_vals, const uint8_t *running_mask, const float *intersections,
+                           int16_t *block_idxs, int B, int S, int nb, scanerf_stream_t stream); /* :391-449 */
+/* images [nb][scanerf_render_workspace_floats()]: each tile's decoder blob packed by
+ * scanerf_pack_decoder with weight_feature == 1; tables [nb,16,T,2] f16; resolution [nb,16,3] i32 */
+int scanerf_pts_inference(const float *rays_o, const float *rays_d, const float *z_vals, const float *dists,
+                          const int16_t *block_idxs, const void *tables_f16, const float *images,
+                          const int32_t *resolution, const uint8_t *occ, const int64_t *grid_starts,
+                          const int32_t *log2dim, const float *corners, const float *sizes, float *diffuse,
+                          float *specular, float *alpha, int B, int S, int T, int nb,
+                          scanerf_stream_t stream);                                            /* :467-621 */
+int scanerf_accumulate_color(const float *pts_diffuse, const float *pts_specular, const float *pts_alpha,
+                             float *transparency, const float *z_vals, float *diffuse, float *specular,
+                             float *depth, int B, int S, scanerf_stream_t stream);             /* :624-702 */
+int scanerf_render_inverse_z_sampling(const float *intersections, const int16_t *related_bidx, float *z_vals,
+                                      float sample_range, int B, int S, int nb,
+                                      scanerf_stream_t stream);                                /* :816-868 */
+int scanerf_bg_pts_inference_v2(const float *rays_o, const float *rays_d, const float *z_vals,
+                                const int16_t *bg_idxs, int step, const float *corners, const float *sizes,
+                                const int32_t *resolution, const void *tables_f16, const float *images,
+                                float *diffuse, float *specular, float *alpha, int B, int S, int T, int nb,
+                                scanerf_stream_t stream);                                      /* :1012-1171 */
+int scanerf_update_outgoing_bidx(const float *rays_o, const float *rays_d, const float *corners,
+                                 const float *sizes, const int32_t *tracing_blocks, const float *intersections,
+                                 int16_t *outgoing_bidxs, float *blend_weights, float ratio, int skip, int B,
+                                 int nb, scanerf_stream_t stream);                             /* :1263-1401 */
+int scanerf_update_outgoing_bidx_v2(const float *rays_o, const float *corners, const float *sizes,
+                                    int16_t *inside_bidxs, float *blend_weights, int B, int nb,
+                                    scanerf_stream_t stream);                                  /* :1406-1474 */
+int scanerf_get_last_block(const int32_t *tracing_blocks, int32_t *bidxs, const float *intersections, int B,
+                           int nb, scanerf_stream_t stream);                                   /* :1212-1260 */
+int scanerf_ray_firsthit_block(const float *rays_o, const float *rays_d, const float *corners, const float *sizes,
+                               const uint8_t *occ, const int64_t *grid_starts, const int32_t *log2dim,
+                               const int32_t *tracing_blocks, const float *intersections, int16_t *hit_blockIdxs,
+                               int B, int nb, scanerf_stream_t stream);                        /* :705-813 */
+int scanerf_process_occupied_grid(int bidx, int total_grid, const float *corners, const float *sizes,
+                                  const uint8_t *occ, const int64_t *grid_starts, const int32_t *log2dim,
+                                  uint8_t *tgt_occ, int nb, scanerf_stream_t stream);          /* :1479-1564 */
+
 #define SCANERF_RAY_OUT 16
 
 #ifdef __cplusplus

@@ -194,6 +194,121 @@ def decoder_inference(params, feat, dirs):
     return sigma, diff, spec, tint
 
 
+# ---- a16: render-time kernels (hashgrid/src/rendering_kernel.cu) -------------------------------
+def _u8(a):
+    return np.ascontiguousarray(_np(a).astype(np.uint8))
+
+
+def _i16(a):
+    return np.ascontiguousarray(np.asarray(_np(a), dtype=np.int16))
+
+
+def _i64(a):
+    return np.ascontiguousarray(np.asarray(_np(a), dtype=np.int64))
+
+
+def ray_block_intersection(rays_o, rays_d, corners, sizes):
+    o, d, c, s = _f32(_np(rays_o)), _f32(_np(rays_d)), _f32(_np(corners)), _f32(_np(sizes))
+    out = np.full((o.shape[0], c.shape[0], 2), 1e7, np.float32)
+    lib().orc_ray_block_intersection(_p(o), _p(d), _p(c), _p(s), _p(out), _ci(o.shape[0]), _ci(c.shape[0]))
+    return out
+
+
+def render_sample_points(rays_o, rays_d, corners, sizes, occ, grid_starts, log2dim, S, tracing_blocks, inter,
+                         tracing_idx, z_start):
+    """One tracing step; tracing_idx / z_start are updated in place (numpy int32 / float32 arrays)."""
+    o, d = _f32(_np(rays_o)), _f32(_np(rays_d))
+    B, nb = o.shape[0], np.asarray(corners).shape[0]
+    z = np.full((B, S), -1, np.float32)
+    dd = np.full((B, S), -1, np.float32)
+    lib().orc_render_sample_points(_p(o), _p(d), _p(_f32(_np(corners))), _p(_f32(_np(sizes))), _p(_u8(occ)),
+                                   _p(_i64(grid_starts)), _p(_i32(_np(log2dim))), _ci(S), _ci(nb),
+                                   _p(_i32(_np(tracing_blocks))), _p(_f32(_np(inter))), _p(tracing_idx), _p(z_start),
+                                   _p(z), _p(dd), _ci(B))
+    return z, dd
+
+
+def prepare_points(z_vals, running, inter):
+    z = _f32(_np(z_vals))
+    B, S = z.shape
+    nb = np.asarray(inter).shape[1]
+    out = np.full((B, S, 4), -1, np.int16)
+    lib().orc_prepare_points(_p(z), _p(_u8(running)), _p(out), _p(_f32(_np(inter))), _ci(S), _ci(nb), _ci(B))
+    return out
+
+
+def pts_inference(rays_o, rays_d, z_vals, dists, block_idxs, tables_f16, params, res, occ, grid_starts, log2dim,
+                  corners, sizes):
+    o, d, z, dd = _f32(_np(rays_o)), _f32(_np(rays_d)), _f32(_np(z_vals)), _f32(_np(dists))
+    B, S = z.shape
+    tb = np.ascontiguousarray(_np(tables_f16).view(np.uint16)) if _np(tables_f16).dtype == np.float16 else _np(tables_f16)
+    T = tb.shape[2]
+    dif, spec, al = np.zeros((B, S, 3), np.float32), np.zeros((B, S, 3), np.float32), np.zeros((B, S, 1), np.float32)
+    lib().orc_pts_inference(_p(o), _p(d), _p(z), _p(dd), _p(_i16(block_idxs)), _p(tb), _p(_f32(_np(params))),
+                            _p(_i32(_np(res))), _p(_u8(occ)), _p(_i64(grid_starts)), _p(_i32(_np(log2dim))), _ci(T),
+                            _p(_f32(_np(corners))), _p(_f32(_np(sizes))), _p(dif), _p(spec), _p(al), _ci(B), _ci(S))
+    return dif, spec, al
+
+
+def accumulate_color(pts_dif, pts_spec, pts_alpha, transp, z_vals, dif, spec, depth):
+    """In place on transp [B,1], dif/spec [B,3], depth [B,1] (numpy float32)."""
+    z = _f32(_np(z_vals))
+    lib().orc_accumulate_color(_p(_f32(pts_dif)), _p(_f32(pts_spec)), _p(_f32(pts_alpha)), _p(transp), _p(z), _p(dif),
+                               _p(spec), _p(depth), _ci(z.shape[0]), _ci(z.shape[1]))
+
+
+def render_inverse_z_sampling(inter, related, S, sample_range):
+    it = _f32(_np(inter))
+    B, nb = it.shape[:2]
+    z = np.full((B, S), -1, np.float32)
+    lib().orc_render_inverse_z_sampling(_p(it), _p(_i16(related)), _ci(S), _ci(nb), _cf(sample_range), _p(z), _ci(B))
+    return z
+
+
+def bg_pts_inference_v2(rays_o, rays_d, z_vals, bg_idxs, step, corners, sizes, res, tables_f16, params):
+    o, d, z = _f32(_np(rays_o)), _f32(_np(rays_d)), _f32(_np(z_vals))
+    B, S = z.shape
+    tb = np.ascontiguousarray(_np(tables_f16).view(np.uint16))
+    T = tb.shape[2]
+    dif, spec, al = np.zeros((B, S, 3), np.float32), np.zeros((B, S, 3), np.float32), np.zeros((B, S, 1), np.float32)
+    lib().orc_bg_pts_inference_v2(_p(o), _p(d), _p(z), _p(tb), _p(_f32(_np(params))), _p(_f32(_np(corners))),
+                                  _p(_f32(_np(sizes))), _p(_i32(_np(res))), _p(_i16(bg_idxs)), _ci(step), _p(dif), _p(spec),
+                                  _p(al), _ci(T), _ci(B), _ci(S))
+    return dif, spec, al
+
+
+def update_outgoing_bidx(rays_o, rays_d, corners, sizes, tracing_blocks, inter, ratio, skip):
+    o, d = _f32(_np(rays_o)), _f32(_np(rays_d))
+    B, nb = o.shape[0], np.asarray(corners).shape[0]
+    ob = np.full((B, 4), -1, np.int16)
+    bw = np.zeros((B, 4), np.float32)
+    lib().orc_update_outgoing_bidx(_p(o), _p(d), _p(_f32(_np(corners))), _p(_f32(_np(sizes))), _p(_i32(_np(tracing_blocks))),
+                                   _p(_f32(_np(inter))), _p(ob), _p(bw), _cf(ratio), _ci(int(skip)), _ci(nb), _ci(B))
+    return ob, bw
+
+
+def update_outgoing_bidx_v2(rays_o, corners, sizes):
+    o = _f32(_np(rays_o))
+    B, nb = o.shape[0], np.asarray(corners).shape[0]
+    ob = np.full((B, 4), -1, np.int16)
+    bw = np.zeros((B, 4), np.float32)
+    lib().orc_update_outgoing_bidx_v2(_p(o), _p(_f32(_np(corners))), _p(_f32(_np(sizes))), _p(ob), _p(bw), _ci(nb), _ci(B))
+    return ob, bw
+
+
+def get_last_block(tracing_blocks, inter):
+    tb = _i32(_np(tracing_blocks))
+    out = np.full((tb.shape[0],), -1, np.int32)
+    lib().orc_get_last_block(_p(tb), _p(out), _p(_f32(_np(inter))), _ci(tb.shape[1]), _ci(tb.shape[0]))
+    return out
+
+
+def process_occupied_grid(bidx, total_grid, corners, sizes, occ, grid_starts, log2dim, tgt):
+    """In place on tgt (numpy uint8, concatenated grids)."""
+    lib().orc_process_occupied_grid(_ci(bidx), _ci(total_grid), _p(_f32(_np(corners))), _p(_f32(_np(sizes))), _p(_u8(occ)),
+                                    _p(_i64(grid_starts)), _p(_i32(_np(log2dim))), _p(tgt), _ci(np.asarray(corners).shape[0]))
+
+
 class _EncodeBG(torch.autograd.Function):
     """hashgrid/PyHashGridBG.py:9-30 with the C oracle underneath (CPU tensors)."""
 

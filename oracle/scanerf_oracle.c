@@ -552,40 +552,434 @@ static inline float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-1.0f * x));
 
 #define ORC_PARAMSIZE 13994
 
-/* decoder.h:169-218 Decoder::inference for n samples.
- * feat [n,32], dirs [n,3] (un-normalised), params [13994] ->
+/* decoder.h:169-218 Decoder::inference, one sample.  specular is returned tinted (tint * sigmoid). */
+static void decoder_one(const float *params, const float *feat, const float *d, float *sigma, float *diffuse,
+                        float *specular, float *tint_out)
+{
+    float h0[64], h1[64], in48[48], d0[64], d1[64], o3[3], o1[1], tint[3];
+    const float *p = params;
+    p = linear(p, feat, 32, h0, 64);
+    for (int j = 0; j < 64; ++j) h0[j] = gauss(h0[j]);
+    p = linear(p, h0, 64, h1, 64);
+    p = linear(p, h1, 32, o1, 1);
+    *sigma = softplus_raw(o1[0]);
+    p = linear(p, h1, 32, o3, 3);
+    for (int k = 0; k < 3; ++k) diffuse[k] = sigmoidf_(o3[k]);
+    p = linear(p, h1, 32, o3, 3);
+    for (int k = 0; k < 3; ++k) tint[k] = sigmoidf_(o3[k]);
+    float inv = 1.0f / sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]); /* normalize(): rsqrt, no eps */
+    float dn[3] = { d[0] * inv, d[1] * inv, d[2] * inv };
+    for (int j = 0; j < 32; ++j) in48[j] = h1[32 + j];
+    sh_deg3(dn, in48 + 32);
+    p = linear(p, in48, 48, d0, 64);
+    for (int j = 0; j < 64; ++j) d0[j] = gauss(d0[j]);
+    p = linear(p, d0, 64, d1, 64);
+    for (int j = 0; j < 64; ++j) d1[j] = gauss(d1[j]);
+    p = linear(p, d1, 64, o3, 3);
+    for (int k = 0; k < 3; ++k) {
+        specular[k] = tint[k] * sigmoidf_(o3[k]);
+        if (tint_out) tint_out[k] = tint[k];
+    }
+}
+
+/* feat [n,32], dirs [n,3] (un-normalised), params [13994] ->
  * sigma[n], diffuse[n,3], specular[n,3] (= tint*sigmoid(...)), tint[n,3] (extra output) */
 ORC_API void orc_decoder_inference(const float *params, const float *feat, const float *dirs,
                                    float *sigma, float *diffuse, float *specular, float *tint_out, int n)
 {
 #pragma omp parallel for schedule(static)
-    for (int s = 0; s < n; ++s) {
-        float h0[64], h1[64], in48[48], d0[64], d1[64], o3[3], o1[1], tint[3];
-        const float *p = params;
-        p = linear(p, feat + 32 * (size_t)s, 32, h0, 64);
-        for (int j = 0; j < 64; ++j) h0[j] = gauss(h0[j]);
-        p = linear(p, h0, 64, h1, 64);
-        p = linear(p, h1, 32, o1, 1);
-        sigma[s] = softplus_raw(o1[0]);
-        p = linear(p, h1, 32, o3, 3);
-        for (int k = 0; k < 3; ++k) diffuse[3 * s + k] = sigmoidf_(o3[k]);
-        p = linear(p, h1, 32, o3, 3);
-        for (int k = 0; k < 3; ++k) tint[k] = sigmoidf_(o3[k]);
-        const float *d = dirs + 3 * (size_t)s;
-        float inv = 1.0f / sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]); /* normalize(): rsqrt, no eps */
-        float dn[3] = { d[0] * inv, d[1] * inv, d[2] * inv };
-        for (int j = 0; j < 32; ++j) in48[j] = h1[32 + j];
-        sh_deg3(dn, in48 + 32);
-        p = linear(p, in48, 48, d0, 64);
-        for (int j = 0; j < 64; ++j) d0[j] = gauss(d0[j]);
-        p = linear(p, d0, 64, d1, 64);
-        for (int j = 0; j < 64; ++j) d1[j] = gauss(d1[j]);
-        p = linear(p, d1, 64, o3, 3);
-        for (int k = 0; k < 3; ++k) {
-            specular[3 * s + k] = tint[k] * sigmoidf_(o3[k]);
-            if (tint_out) tint_out[3 * s + k] = tint[k];
+    for (int s = 0; s < n; ++s)
+        decoder_one(params, feat + 32 * (size_t)s, dirs + 3 * (size_t)s, sigma + s, diffuse + 3 * s, specular + 3 * s,
+                    tint_out ? tint_out + 3 * s : NULL);
+}
+
+ORC_API int orc_param_size(void) { return ORC_PARAMSIZE; }
+
+
+/* ===================================================================================
+ * a16: render-time kernels, hashgrid/src/rendering_kernel.cu (multi-tile novel-view render)
+ * =================================================================================== */
+#define ORC_MAX_PTS_BLOCKS 4
+#define ORC_INF_INTERSECTION 10000000.0f
+
+/* rendering_kernel.cu:126-174 */
+ORC_API void orc_ray_block_intersection(const float *rays_o, const float *rays_d, const float *corners,
+                                        const float *sizes, float *inter, int B, int nb)
+{
+    for (int i = 0; i < B; ++i)
+        for (int b = 0; b < nb; ++b) {
+            float h[3], c[3];
+            for (int k = 0; k < 3; ++k) { h[k] = sizes[3 * b + k] / 2.0f; c[k] = corners[3 * b + k] + h[k]; }
+            f2 r = ray_aabb(rays_o + 3 * i, rays_d + 3 * i, c, h);
+            if (r.x == -1.0f) { r.x = ORC_INF_INTERSECTION; r.y = ORC_INF_INTERSECTION; }
+            inter[2 * ((size_t)i * nb + b)] = r.x;
+            inter[2 * ((size_t)i * nb + b) + 1] = r.y;
+        }
+}
+
+static inline uint32_t cell_offset(const int t[3], const int l2d[3])
+{
+    return ((uint32_t)t[0] << (l2d[1] + l2d[2])) | ((uint32_t)t[1] << l2d[2]) | (uint32_t)t[2];
+}
+
+/* rendering_kernel.cu:179-344: one tracing step of samplepoints_kernel for one ray */
+ORC_API void orc_render_sample_points(const float *rays_o, const float *rays_d, const float *corners,
+                                      const float *sizes, const uint8_t *occ, const int64_t *grid_starts,
+                                      const int32_t *log2dim, int S, int nb, const int32_t *tracing_blocks,
+                                      const float *inter, int32_t *tracing_idx, float *z_start, float *z_vals,
+                                      float *dists, int B)
+{
+    for (int i = 0; i < B; ++i) {
+        const float *o = rays_o + 3 * i, *d = rays_d + 3 * i;
+        const int32_t *tb = tracing_blocks + (size_t)i * nb;
+        const float *ci = inter + 2 * (size_t)i * nb;
+        float *cz = z_vals + (size_t)i * S, *cd = dists + (size_t)i * S;
+        int step = tracing_idx[i];
+        float tsx = z_start[i];
+        while (step < nb) {
+            int b = tb[step];
+            float bx = ci[2 * b], by = ci[2 * b + 1];
+            if (bx == ORC_INF_INTERSECTION) break;
+            if (tsx >= by) { step++; continue; }
+            if (step == 0) tsx = bx;
+            int l2d[3] = { log2dim[3 * b], log2dim[3 * b + 1], log2dim[3 * b + 2] };
+            int side[3]; float tsize[3], og[3];
+            for (int k = 0; k < 3; ++k) {
+                side[k] = 1 << l2d[k];
+                tsize[k] = sizes[3 * b + k] / (float)side[k];
+                og[k] = o[k] - corners[3 * b + k];
+            }
+            const uint8_t *g = occ + grid_starts[b];
+            f2 ts = { tsx, 0.0f };
+            dda_t s;
+            dda_init(&s, og, d, ts, side, tsize);
+            int num_seg = 0; float total = 0.0f;
+            while (!dda_terminate(&s)) {
+                dda_next(&s);
+                if (g[cell_offset(s.tile, l2d)]) {
+                    float len = s.ty - s.tx;
+                    if (len > 0) { total += len; num_seg++; }
+                }
+                dda_step(&s);
+            }
+            if (num_seg == 0) { tsx = by; step++; continue; }
+            int num = 0, count = 0;
+            dda_init(&s, og, d, ts, side, tsize);
+            while (!dda_terminate(&s)) {
+                dda_next(&s);
+                if (g[cell_offset(s.tile, l2d)]) {
+                    float len = s.ty - s.tx;
+                    if (len > 0) {
+                        int n = (int)(len / total * (float)S);
+                        if (n < 1) n = 1;
+                        if (n > S - num) n = S - num;
+                        if (count == num_seg - 1) n = S - num;
+                        if (n > 0) {
+                            float interval = (s.ty - s.tx) / (float)n;
+                            for (int k = 0; k < n; ++k) { cz[num + k] = s.tx + (float)k * interval; cd[num + k] = interval; }
+                        }
+                        num += n;
+                        count++;
+                    }
+                }
+                dda_step(&s);
+            }
+            tsx = by;
+            step++;
+            break;
+        }
+        tracing_idx[i] = step;
+        z_start[i] = tsx;
+    }
+}
+
+/* rendering_kernel.cu:391-449 (the reference can overrun the 4 slots when >4 tiles overlap; clamped here) */
+ORC_API void orc_prepare_points(const float *z_vals, const uint8_t *running, int16_t *block_idxs, const float *inter,
+                                int S, int nb, int B)
+{
+    for (int i = 0; i < B; ++i) {
+        if (!running[i]) continue;
+        for (int s = 0; s < S; ++s) {
+            float z = z_vals[(size_t)i * S + s];
+            if (z == -1.0f) continue;
+            int16_t *bi = block_idxs + ((size_t)i * S + s) * ORC_MAX_PTS_BLOCKS;
+            int idx = 0;
+            for (int b = 0; b < nb && idx < ORC_MAX_PTS_BLOCKS; ++b) {
+                float bx = inter[2 * ((size_t)i * nb + b)], by = inter[2 * ((size_t)i * nb + b) + 1];
+                if (z >= bx && z <= by) bi[idx++] = (int16_t)b;
+            }
         }
     }
 }
 
-ORC_API int orc_param_size(void) { return ORC_PARAMSIZE; }
+/* rendering_kernel.cu:79-114 get_multilevel_features: p01 in [0,1] directly, fp16 tables */
+static void multilevel_features_h(const float p01[3], const int32_t *res, const uint16_t *tables, int T, float *feat)
+{
+    for (int l = 0; l < 16; ++l) {
+        int b[3]; float t[3], w[8]; uint32_t idx[8];
+        for (int k = 0; k < 3; ++k) {
+            float v = p01[k] * (float)(res[3 * l + k] - 1);
+            b[k] = (int)v;
+            t[k] = v - (float)b[k];
+        }
+        linear_weight(w, t);
+        corner_indices(idx, b, T);
+        const uint16_t *lf = tables + (size_t)l * T * 2;
+        float ax = 0.0f, ay = 0.0f;
+        for (int c = 0; c < 8; ++c) {
+            ax += w[c] * h2f(lf[2 * idx[c]]);
+            ay += w[c] * h2f(lf[2 * idx[c] + 1]);
+        }
+        feat[2 * l] = ax;
+        feat[2 * l + 1] = ay;
+    }
+}
+
+/* xz-distance blend weight, rendering_kernel.cu:523-537 / :1335-1351 */
+static float xz_weight(float dx, float dz)
+{
+    if (dx != 0 && dz != 0) return dx * dz;
+    if (dx != 0) return dx;
+    if (dz != 0) return dz;
+    return 0.0f;
+}
+
+/* rendering_kernel.cu:467-621 */
+ORC_API void orc_pts_inference(const float *rays_o, const float *rays_d, const float *z_vals, const float *dists,
+                               const int16_t *block_idxs, const uint16_t *tables, const float *params,
+                               const int32_t *res, const uint8_t *occ, const int64_t *grid_starts,
+                               const int32_t *log2dim, int T, const float *corners, const float *sizes,
+                               float *out_dif, float *out_spec, float *out_alpha, int B, int S)
+{
+#pragma omp parallel for schedule(dynamic, 64)
+    for (int64_t t = 0; t < (int64_t)B * S; ++t) {
+        int i = (int)(t / S);
+        const int16_t *bi = block_idxs + t * ORC_MAX_PTS_BLOCKS;
+        float dif[3] = { 0, 0, 0 }, spc[3] = { 0, 0, 0 }, alpha = 0.0f, weight = 0.0f;
+        for (int k = 0; k < ORC_MAX_PTS_BLOCKS; ++k) {
+            int b = bi[k];
+            if (b == -1) break;
+            const float *o = rays_o + 3 * i, *d = rays_d + 3 * i;
+            float z = z_vals[t], dist = dists[t];
+            int l2d[3] = { log2dim[3 * b], log2dim[3 * b + 1], log2dim[3 * b + 2] };
+            float pts[3], dis[3];
+            int loc[3];
+            for (int a = 0; a < 3; ++a) {
+                float w_ = o[a] + z * d[a];
+                pts[a] = (w_ - corners[3 * b + a]) / sizes[3 * b + a];
+                dis[a] = (0.5f - fabsf(pts[a] - 0.5f)) * sizes[3 * b + a];
+                int r = 1 << l2d[a];
+                int c = (int)(pts[a] * (float)r);
+                loc[a] = c < 0 ? 0 : (c > r - 1 ? r - 1 : c);
+            }
+            float w = xz_weight(dis[0], dis[2]);
+            if (occ[grid_starts[b] + cell_offset(loc, l2d)]) {
+                float p01[3] = { pts[0] / 2.0f + 0.25f, pts[1] / 2.0f + 0.25f, pts[2] / 2.0f + 0.25f };
+                float feat[32], sg, pd[3], ps[3];
+                multilevel_features_h(p01, res + (size_t)b * 48, tables + (size_t)b * 16 * T * 2, T, feat);
+                decoder_one(params + (size_t)b * ORC_PARAMSIZE, feat, d, &sg, pd, ps, NULL);
+                float nrm = sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+                float pa = 1.0f - expf(-1.0f * sg * dist * nrm);
+                for (int a = 0; a < 3; ++a) { dif[a] += w * pa * pd[a]; spc[a] += w * pa * ps[a]; }
+                alpha += w * pa;
+            }
+            weight += w;
+        }
+        if (weight > 0) {
+            for (int a = 0; a < 3; ++a) { dif[a] /= weight; spc[a] /= weight; }
+            alpha /= weight;
+        }
+        for (int a = 0; a < 3; ++a) { out_dif[3 * t + a] = dif[a]; out_spec[3 * t + a] = spc[a]; }
+        out_alpha[t] = alpha;
+    }
+}
+
+/* rendering_kernel.cu:624-702 */
+ORC_API void orc_accumulate_color(const float *pts_dif, const float *pts_spec, const float *pts_alpha, float *transp,
+                                  const float *z_vals, float *dif, float *spec, float *depth, int B, int S)
+{
+    for (int i = 0; i < B; ++i) {
+        float T = transp[i];
+        if (T < 0.00001f) continue;
+        for (int s = 0; s < S; ++s) {
+            size_t t = (size_t)i * S + s;
+            for (int a = 0; a < 3; ++a) { dif[3 * i + a] += T * pts_dif[3 * t + a]; spec[3 * i + a] += T * pts_spec[3 * t + a]; }
+            depth[i] += T * pts_alpha[t] * z_vals[t];
+            T = T * (1 - pts_alpha[t]);
+        }
+        transp[i] = T;
+    }
+}
+
+/* rendering_kernel.cu:816-868 */
+ORC_API void orc_render_inverse_z_sampling(const float *inter, const int16_t *related, int S, int nb, float range,
+                                           float *z_vals, int B)
+{
+    for (int i = 0; i < B; ++i) {
+        int b = related[i];
+        if (b == -1) continue;
+        float bx = inter[2 * ((size_t)i * nb + b)], by = inter[2 * ((size_t)i * nb + b) + 1];
+        if (bx == ORC_INF_INTERSECTION) continue;
+        float near_ = by, far_ = near_ + range;
+        float inv_near = 1.0f / near_, inv_far = 1.0f / far_, inv_bound = inv_far - inv_near;
+        float step = 1.0f / (float)(S - 1);
+        for (int k = 0; k < S; ++k) z_vals[(size_t)i * S + k] = 1.0f / (step * (float)k * inv_bound + inv_near);
+    }
+}
+
+/* rendering_kernel.cu:1012-1171 */
+ORC_API void orc_bg_pts_inference_v2(const float *rays_o, const float *rays_d, const float *z_vals,
+                                     const uint16_t *tables, const float *params, const float *corners,
+                                     const float *sizes, const int32_t *res, const int16_t *bg_idxs, int step,
+                                     float *out_dif, float *out_spec, float *out_alpha, int T, int B, int S)
+{
+#pragma omp parallel for schedule(dynamic, 64)
+    for (int64_t t = 0; t < (int64_t)B * S; ++t) {
+        int i = (int)(t / S), s = (int)(t % S);
+        int b = bg_idxs[i * ORC_MAX_PTS_BLOCKS + step];
+        if (b == -1) continue;
+        const float *o = rays_o + 3 * i, *d = rays_d + 3 * i;
+        float z = z_vals[t];
+        float sample_step = (s == S - 1) ? 10000000.0f : z_vals[t + 1] - z;
+        float pts[3], inf_norm = 0.0f;
+        for (int a = 0; a < 3; ++a) {
+            float w_ = o[a] + z * d[a];
+            pts[a] = 2.0f * (w_ - corners[3 * b + a]) / sizes[3 * b + a] - 1.0f;
+        }
+        inf_norm = fabsf(pts[0]);
+        for (int a = 1; a < 3; ++a) if (fabsf(pts[a]) > inf_norm) inf_norm = fabsf(pts[a]);
+        float temp = 2.0f - 1.0f / inf_norm;
+        float ratio = temp / inf_norm;
+        float p01[3];
+        for (int a = 0; a < 3; ++a) { pts[a] *= ratio; p01[a] = (pts[a] + 2.0f) / 4.0f; }
+        float feat[32], sg, pd[3], ps[3];
+        multilevel_features_h(p01, res + (size_t)b * 48, tables + (size_t)b * 16 * T * 2, T, feat);
+        decoder_one(params + (size_t)b * ORC_PARAMSIZE, feat, d, &sg, pd, ps, NULL);
+        float pa = 1.0f - expf(-1.0f * sg * sample_step);
+        for (int a = 0; a < 3; ++a) { out_dif[3 * t + a] = pa * pd[a]; out_spec[3 * t + a] = pa * ps[a]; }
+        out_alpha[t] = pa;
+    }
+}
+
+/* rendering_kernel.cu:1263-1401 */
+ORC_API void orc_update_outgoing_bidx(const float *rays_o, const float *rays_d, const float *corners, const float *sizes,
+                                      const int32_t *tracing_blocks, const float *inter, int16_t *out_bidx,
+                                      float *blend, float ratio, int skip, int nb, int B)
+{
+    (void)ratio;
+    for (int i = 0; i < B; ++i) {
+        const int32_t *tb = tracing_blocks + (size_t)i * nb;
+        const float *ci = inter + 2 * (size_t)i * nb;
+        float far_ = -1.0f;
+        int index = 0;
+        int16_t outb[ORC_MAX_PTS_BLOCKS] = { -1, -1, -1, -1 };
+        for (int k = 0; k < nb; ++k) {
+            int b = tb[k];
+            float bx = ci[2 * b], by = ci[2 * b + 1];
+            if (bx == ORC_INF_INTERSECTION) break;
+            if (!skip && (bx > far_ && far_ != -1.0f)) break;
+            if (by > far_) {
+                far_ = by;
+                for (int j = 0; j < ORC_MAX_PTS_BLOCKS; ++j) outb[j] = -1;
+                index = 0;
+                outb[index++] = (int16_t)b;
+            } else if (by == far_) {
+                if (index < ORC_MAX_PTS_BLOCKS) outb[index++] = (int16_t)b; /* reference: unchecked */
+            }
+        }
+        if (far_ == -1.0f) continue;
+        if (index == 1) {
+            blend[i * ORC_MAX_PTS_BLOCKS] = 1.0f;
+            out_bidx[i * ORC_MAX_PTS_BLOCKS] = outb[0];
+            continue;
+        }
+        for (int k = 0; k < ORC_MAX_PTS_BLOCKS; ++k) {
+            int b = outb[k];
+            if (b == -1) break;
+            float dis[3];
+            for (int a = 0; a < 3; ++a) {
+                float pw = rays_o[3 * i + a] + far_ * rays_d[3 * i + a];
+                float p = (pw - corners[3 * b + a]) / sizes[3 * b + a];
+                p = p < 0.0f ? 0.0f : (p > 1.0f ? 1.0f : p);
+                dis[a] = (0.5f - fabsf(p - 0.5f)) * sizes[3 * b + a];
+            }
+            blend[i * ORC_MAX_PTS_BLOCKS + k] = xz_weight(dis[0], dis[2]);
+            out_bidx[i * ORC_MAX_PTS_BLOCKS + k] = (int16_t)b;
+        }
+    }
+}
+
+/* rendering_kernel.cu:1406-1447 */
+ORC_API void orc_update_outgoing_bidx_v2(const float *rays_o, const float *corners, const float *sizes,
+                                         int16_t *inside, float *blend, int nb, int B)
+{
+    for (int i = 0; i < B; ++i) {
+        int index = 0;
+        for (int b = 0; b < nb && index < ORC_MAX_PTS_BLOCKS; ++b) {
+            float loc[3], dis[3];
+            int in = 1;
+            for (int a = 0; a < 3; ++a) {
+                loc[a] = (rays_o[3 * i + a] - corners[3 * b + a]) / sizes[3 * b + a];
+                if (!(loc[a] >= 0 && loc[a] <= 1)) in = 0;
+                dis[a] = (0.5f - fabsf(loc[a] - 0.5f)) * sizes[3 * b + a];
+            }
+            if (in) {
+                inside[i * ORC_MAX_PTS_BLOCKS + index] = (int16_t)b;
+                blend[i * ORC_MAX_PTS_BLOCKS + index] = dis[0] * dis[1] * dis[2];
+                index++;
+            }
+        }
+    }
+}
+
+/* rendering_kernel.cu:1212-1260 */
+ORC_API void orc_get_last_block(const int32_t *tracing_blocks, int32_t *bidxs, const float *inter, int nb, int B)
+{
+    for (int i = 0; i < B; ++i) {
+        int idx = -1;
+        for (int k = 0; k < nb; ++k) {
+            int b = tracing_blocks[(size_t)i * nb + k];
+            if (inter[2 * ((size_t)i * nb + b)] == ORC_INF_INTERSECTION) break;
+            idx = b;
+        }
+        bidxs[i] = idx;
+    }
+}
+
+/* rendering_kernel.cu:1479-1564: dilate tile bidx's occupancy into the grids of the tiles it overlaps */
+ORC_API void orc_process_occupied_grid(int bidx, int total_grid, const float *corners, const float *sizes,
+                                       const uint8_t *occ, const int64_t *grid_starts, const int32_t *log2dim,
+                                       uint8_t *tgt, int nb)
+{
+    const int l0[3] = { log2dim[3 * bidx], log2dim[3 * bidx + 1], log2dim[3 * bidx + 2] };
+    const int r0[3] = { 1 << l0[0], 1 << l0[1], 1 << l0[2] };
+    float gs[3];
+    for (int a = 0; a < 3; ++a) gs[a] = sizes[3 * bidx + a] / (float)r0[a];
+    static const float vtx[8][3] = { {0,0,0},{0,0,1},{0,1,0},{1,0,0},{0,1,1},{1,0,1},{1,1,0},{1,1,1} };
+    for (int t = 0; t < total_grid; ++t) {
+        if (!occ[grid_starts[bidx] + t]) continue;
+        int x = t / (r0[1] * r0[2]);
+        int y = (t - x * (r0[1] * r0[2])) / r0[2];
+        int z = (t - x * (r0[1] * r0[2])) % r0[2];
+        int loc[3] = { x, y, z };
+        float pts[3];
+        for (int a = 0; a < 3; ++a) pts[a] = (float)loc[a] * gs[a] + corners[3 * bidx + a];
+        for (int b = 0; b < nb; ++b) {
+            if (b == bidx) continue;
+            for (int j = 0; j < 8; ++j) {
+                float p[3];
+                int in = 1;
+                for (int a = 0; a < 3; ++a) {
+                    p[a] = (pts[a] + vtx[j][a] * gs[a] - corners[3 * b + a]) / sizes[3 * b + a];
+                    if (!(p[a] >= 0 && p[a] < 1)) in = 0;
+                }
+                if (in) {
+                    int l2d[3] = { log2dim[3 * b], log2dim[3 * b + 1], log2dim[3 * b + 2] };
+                    int ijk[3];
+                    for (int a = 0; a < 3; ++a) ijk[a] = (int)(p[a] * (float)(1 << l2d[a]));
+                    tgt[grid_starts[b] + cell_offset(ijk, l2d)] = 1;
+                }
+            }
+        }
+    }
+}

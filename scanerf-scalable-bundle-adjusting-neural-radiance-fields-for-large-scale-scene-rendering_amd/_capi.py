@@ -26,6 +26,10 @@ SYMBOLS = [
     "scanerf_render_workspace_floats", "scanerf_pack_decoder", "scanerf_render_forward_packed",
     "scanerf_embedding_bg_forward_ex", "scanerf_embedding_bwd_workspace_bytes",
     "scanerf_embedding_bg_backward_binned", "scanerf_render_backward_grid", "scanerf_render_backward",
+    "scanerf_ray_block_intersection", "scanerf_render_sample_points", "scanerf_prepare_points", "scanerf_pts_inference",
+    "scanerf_accumulate_color", "scanerf_render_inverse_z_sampling", "scanerf_bg_pts_inference_v2",
+    "scanerf_update_outgoing_bidx", "scanerf_update_outgoing_bidx_v2", "scanerf_get_last_block",
+    "scanerf_ray_firsthit_block", "scanerf_process_occupied_grid",
 ]
 
 

@@ -78,9 +78,10 @@ struct RayConst {
 };
 
 // SH deg-3 of the normalised direction (network.py:38-77, viewdirs/(norm+1e-8): :177)
-__device__ __forceinline__ void ray_sh(const float d[3], float dnorm, float sh[16])
+__device__ __forceinline__ void ray_sh(const float d[3], float dnorm, float sh[16], float eps = 1e-8f)
 {
-    const float inv = 1.0f / (dnorm + 1e-8f);
+    // training decoder: d/(|d|+1e-8) (network.py:177); render-time decoder: normalize(d), eps = 0 (decoder.h:201)
+    const float inv = 1.0f / (dnorm + eps);
     const float x = d[0] * inv, y = d[1] * inv, z = d[2] * inv;
     const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
     sh[0] = 0.28209479177387814f;
@@ -255,5 +256,72 @@ __device__ __forceinline__ SampleOut decode_tile(const float *lds, int lane, con
     return so;
 }
 
+
+// ---- render-time variants (hashgrid/src/rendering_kernel.cu): any tile's decoder image and
+// table, read through generic pointers (the images of all tiles stay L2-resident) ----------------
+
+// hash-encode 8 levels at p01 in [0,1]^3 (rendering_kernel.cu:79-114: v = p01*(res-1), no (p+2)/4 step);
+// same register<->level map as encode8.  Lanes with active == false issue no loads.
+template <int DT>
+__device__ __forceinline__ void encode8_01(const void *table, const int32_t *res, int T, int h, const float p01[3],
+                                           bool active, v16f &x)
+{
+    const uint32_t mask = (uint32_t)T - 1u;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int level = 4 * (j >> 1) + 2 * h + (j & 1);
+        float ax = 0.0f, ay = 0.0f;
+        if (active) {
+#pragma clang fp contract(off)
+            int b[3];
+            float t[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const float v = p01[k] * (float)(res[3 * level + k] - 1);
+                b[k] = (int)v;
+                t[k] = v - (float)b[k];
+            }
+            uint32_t idx[8];
+            float w[8];
+            corner_indices(idx, b[0], b[1], b[2], mask);
+            trilinear_weights(w, t[0], t[1], t[2]);
+            const char *slice = (const char *)table + (size_t)level * T * TableElem<DT>::bytes;
+            float2 f[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) f[c] = TableElem<DT>::load(slice, idx[c]);
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                ax = fmaf(w[c], f[c].x, ax);
+                ay = fmaf(w[c], f[c].y, ay);
+            }
+        }
+        x[2 * j] = ax;
+        x[2 * j + 1] = ay;
+        if (j & 1) __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// decode_tile with the SH part of the directional layer computed inline (per-lane direction):
+// img may point to global memory (one packed image per tile).
+__device__ __forceinline__ SampleOut decode_tile_dir(const float *img, int lane, const v16f &x, const float d[3],
+                                                     float dnorm, float eps)
+{
+    const int h = lane >> 5;
+    float sh[16];
+    ray_sh(d, dnorm, sh, eps);
+    v16f dinit[2] = { load_bias(img, 2, 0, h), load_bias(img, 2, 1, h) };
+    const float *A = img + PK_D0S + (lane + (lane >> 5)) * 4;
+    const float4 a00 = *reinterpret_cast<const float4 *>(A), a01 = *reinterpret_cast<const float4 *>(A + PK_GRP),
+                 a10 = *reinterpret_cast<const float4 *>(A + 2 * PK_GRP), a11 = *reinterpret_cast<const float4 *>(A + 3 * PK_GRP);
+    float shb[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) shb[r] = h ? sh[2 * r + 1] : sh[2 * r];
+    MFMA4(dinit[0], a00, shb[0], shb[1], shb[2], shb[3])
+    MFMA4(dinit[0], a01, shb[4], shb[5], shb[6], shb[7])
+    MFMA4(dinit[1], a10, shb[0], shb[1], shb[2], shb[3])
+    MFMA4(dinit[1], a11, shb[4], shb[5], shb[6], shb[7])
+    __builtin_amdgcn_sched_barrier(0);
+    return decode_tile(img, lane, x, dinit);
+}
 
 }  // namespace scanerf

@@ -1,0 +1,731 @@
+// render_time.hip -- the multi-tile novel-view render kernels (gfx950).
+//
+// Reference behaviour: hashgrid/src/rendering_kernel.cu (file:line per kernel below), driven by
+// RenderingHashGrid.render_rays_base (rendering.py:286-544):
+//   ray_block_intersection -> argsort(near) -> per tracing step { sample_points -> prepare_points ->
+//   pts_inference -> accumulate_color } -> update_outgoing_bidx -> per blended background
+//   { inverse_z_sampling -> bg_pts_inference_v2 -> accumulate_color }.
+//
+// Built with -ffp-contract=off (the samplers and box tests are bit-exact against the oracle).
+//
+// pts_inference / bg_pts_inference_v2 are the render hot loop.  The reference runs the whole
+// 13 994-MAC decoder serially in one thread per sample, weights from global memory.  Here a wave
+// takes 32 consecutive samples and runs the decoder on the fp32 matrix cores (render_device.h):
+// the packed weight image of whichever tile the samples reference is read through L2 (all tiles'
+// images stay resident: 58 KB each); samples that overlap several tiles loop over the distinct
+// tiles of the wave.
+#include <hip/hip_fp16.h>
+
+#include "dda_device.h"
+#include "render_device.h"
+
+using namespace scanerf;
+
+namespace {
+
+constexpr int kMaxPtsBlocks = 4;          // MAX_PTS_BLOCKS, rendering_kernel.cu:25
+constexpr float kInf = 10000000.0f;       // INF_INTERSECTION, :26
+
+struct Tiles {
+    const float *corners, *sizes;         // [nb,3]
+    const uint8_t *occ;                   // concatenated bool grids
+    const int64_t *grid_starts;           // [nb]
+    const int32_t *log2dim;               // [nb,3]
+    int nb;
+};
+
+__device__ __forceinline__ uint32_t cell_offset(const int c[3], int ly, int lz)
+{
+    return ((uint32_t)c[0] << (ly + lz)) | ((uint32_t)c[1] << lz) | (uint32_t)c[2];
+}
+
+// ---- rendering_kernel.cu:126-174 ---------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_ray_block_intersection(const float *__restrict__ rays_o,
+                                                                const float *__restrict__ rays_d, Tiles t,
+                                                                float *__restrict__ inter, int B)
+{
+    const int64_t total = (int64_t)B * t.nb;
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int i = (int)(e / t.nb), b = (int)(e % t.nb);
+        float o[3], d[3], c[3], h[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            o[k] = rays_o[3 * i + k];
+            d[k] = rays_d[3 * i + k];
+            h[k] = t.sizes[3 * b + k] / 2.0f;
+            c[k] = t.corners[3 * b + k] + h[k];
+        }
+        F2 r = clip_box(o, d, c, h);
+        if (r.x == -1.0f) r.x = r.y = kInf;
+        reinterpret_cast<float2 *>(inter)[e] = make_float2(r.x, r.y);
+    }
+}
+
+// ---- rendering_kernel.cu:179-382: one tracing step per ray ---------------------------------------
+__global__ void __launch_bounds__(64) k_render_sample_points(const float *__restrict__ rays_o,
+                                                             const float *__restrict__ rays_d, Tiles t, int S,
+                                                             const int32_t *__restrict__ tracing_blocks,
+                                                             const float *__restrict__ inter,
+                                                             int32_t *__restrict__ tracing_idx, float *__restrict__ z_start,
+                                                             float *__restrict__ z_vals, float *__restrict__ dists, int B)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < B; i += gridDim.x * blockDim.x) {
+        const float o[3] = { rays_o[3 * i], rays_o[3 * i + 1], rays_o[3 * i + 2] };
+        const float d[3] = { rays_d[3 * i], rays_d[3 * i + 1], rays_d[3 * i + 2] };
+        const int32_t *tb = tracing_blocks + (size_t)i * t.nb;
+        const float2 *ci = reinterpret_cast<const float2 *>(inter) + (size_t)i * t.nb;
+        float *cz = z_vals + (size_t)i * S, *cd = dists + (size_t)i * S;
+        int step = tracing_idx[i];
+        float tsx = z_start[i];
+        while (step < t.nb) {
+            const int b = tb[step];
+            const float2 bound = ci[b];
+            if (bound.x == kInf) break;
+            if (tsx >= bound.y) { ++step; continue; }
+            if (step == 0) tsx = bound.x;
+            const int l2d[3] = { t.log2dim[3 * b], t.log2dim[3 * b + 1], t.log2dim[3 * b + 2] };
+            int side[3];
+            float cs[3], og[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                side[k] = 1 << l2d[k];
+                cs[k] = t.sizes[3 * b + k] / (float)side[k];
+                og[k] = o[k] - t.corners[3 * b + k];
+            }
+            const uint8_t *g = t.occ + t.grid_starts[b];
+            F2 ts;
+            ts.x = tsx;
+            ts.y = 0.0f;
+            Walker w;
+            w.start(og, d, ts, side, cs);
+            int num_seg = 0;
+            float total = 0.0f;
+            while (!w.done()) {
+                w.pick();
+                if (g[cell_offset(w.cell, l2d[1], l2d[2])]) {
+                    const float len = w.t1 - w.t0;
+                    if (len > 0) { total += len; ++num_seg; }
+                }
+                w.advance();
+            }
+            if (num_seg == 0) { tsx = bound.y; ++step; continue; }
+            int num = 0, count = 0;
+            w.start(og, d, ts, side, cs);
+            while (!w.done()) {
+                w.pick();
+                if (g[cell_offset(w.cell, l2d[1], l2d[2])]) {
+                    const float len = w.t1 - w.t0;
+                    if (len > 0) {
+                        int n = (int)(len / total * (float)S);
+                        n = n < 1 ? 1 : n;
+                        n = n > S - num ? S - num : n;
+                        if (count == num_seg - 1) n = S - num;
+                        if (n > 0) {
+                            const float interval = (w.t1 - w.t0) / (float)n;
+                            for (int k = 0; k < n; ++k) {
+                                cz[num + k] = w.t0 + (float)k * interval;
+                                cd[num + k] = interval;
+                            }
+                        }
+                        num += n;
+                        ++count;
+                    }
+                }
+                w.advance();
+            }
+            tsx = bound.y;
+            ++step;
+            break;
+        }
+        tracing_idx[i] = step;
+        z_start[i] = tsx;
+    }
+}
+
+// ---- rendering_kernel.cu:391-449 (the reference overruns its 4 slots when >4 tiles overlap; clamped) --
+__global__ void __launch_bounds__(256) k_prepare_points(const float *__restrict__ z_vals,
+                                                        const uint8_t *__restrict__ running,
+                                                        int16_t *__restrict__ block_idxs,
+                                                        const float *__restrict__ inter, int S, int nb, int B)
+{
+    const int64_t total = (int64_t)B * S;
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int i = (int)(e / S);
+        if (!running[i]) continue;
+        const float z = z_vals[e];
+        if (z == -1.0f) continue;
+        const float2 *ci = reinterpret_cast<const float2 *>(inter) + (size_t)i * nb;
+        int16_t out[kMaxPtsBlocks] = { -1, -1, -1, -1 };
+        int idx = 0;
+        bool any = false;
+        for (int b = 0; b < nb && idx < kMaxPtsBlocks; ++b) {
+            const float2 bd = ci[b];
+            if (z >= bd.x && z <= bd.y) { out[idx++] = (int16_t)b; any = true; }
+        }
+        if (any) {  // the reference leaves untouched slots as the caller filled them (-1)
+            int16_t *dst = block_idxs + e * kMaxPtsBlocks;
+            for (int k = 0; k < idx; ++k) dst[k] = out[k];
+        }
+    }
+}
+
+// xz-distance blend weight (rendering_kernel.cu:523-537, :1335-1351)
+__device__ __forceinline__ float xz_weight(float dx, float dz)
+{
+    if (dx != 0 && dz != 0) return dx * dz;
+    if (dx != 0) return dx;
+    if (dz != 0) return dz;
+    return 0.0f;
+}
+
+struct InferArgs {
+    const float *rays_o, *rays_d, *z_vals, *dists;
+    const int16_t *block_idxs;    // fg: [B,S,4]; bg: [B,4] (+ step)
+    const void *tables;           // [nb,16,T,2] f16
+    const float *images;          // [nb, PK_TOTAL] packed decoders (weight_feature == 1)
+    const int32_t *res;           // [nb,16,3]
+    Tiles t;
+    float *out_dif, *out_spec, *out_alpha;
+    int T, B, S, step;
+};
+
+// ---- rendering_kernel.cu:467-621 (BG == false) and :1012-1171 (BG == true) -------------------------
+template <bool BG>
+__global__ void __launch_bounds__(256, 2) k_pts_inference(InferArgs a)
+{
+    const int lane = threadIdx.x & 63, sl = lane & 31, h = lane >> 5;
+    const int64_t total = (int64_t)a.B * a.S;
+    const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+    for (int64_t base = ((int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 32; base < total; base += nwaves * 32) {
+        const int64_t e = base + sl;
+        const bool in_range = e < total;
+        const int64_t ec = in_range ? e : total - 1;
+        const int i = (int)(ec / a.S), s = (int)(ec % a.S);
+        float o[3], d[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            o[k] = a.rays_o[3 * i + k];
+            d[k] = a.rays_d[3 * i + k];
+        }
+        const float dnorm = sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+        const float z = a.z_vals[ec];
+        float delta;  // what multiplies sigma in alpha = 1 - exp(-sigma*delta)
+        if (BG) delta = (s == a.S - 1) ? 10000000.0f : a.z_vals[ec + 1] - z;   // :1045-1047: raw depth step
+        else delta = a.dists[ec] * dnorm;                                       // :557
+        float dif[3] = { 0, 0, 0 }, spc[3] = { 0, 0, 0 }, alpha = 0.0f, weight = 0.0f;
+
+        const int nslots = BG ? 1 : kMaxPtsBlocks;
+        bool ended = !in_range;  // fg: the slot list stops at the first -1 (:499)
+        for (int k = 0; k < nslots; ++k) {
+            int b_lane = -1;
+            if (!ended) b_lane = BG ? a.block_idxs[i * kMaxPtsBlocks + a.step] : a.block_idxs[ec * kMaxPtsBlocks + k];
+            if (b_lane == -1) ended = true;
+            unsigned long long pending = __ballot(b_lane != -1);
+            while (pending) {
+                const int leader = __ffsll((long long)pending) - 1;
+                const int b = __shfl(b_lane, leader, 64);  // wave-uniform tile
+                const bool mine = b_lane == b;
+                pending &= ~__ballot(mine);
+                // tile-space position, blend weight, occupancy
+                float p01[3], w = 0.0f;
+                bool run = mine;
+                if (BG) {
+                    // L-infinity contraction of the 2x-box coordinates (:1056-1096), then [-2,2] -> [0,1]
+                    float q[3];
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) q[c] = 2.0f * ((o[c] + z * d[c]) - a.t.corners[3 * b + c]) / a.t.sizes[3 * b + c] - 1.0f;
+                    const float linf = fmaxf(fabsf(q[0]), fmaxf(fabsf(q[1]), fabsf(q[2])));
+                    const float ratio = (2.0f - 1.0f / linf) / linf;
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) p01[c] = (q[c] * ratio + 2.0f) / 4.0f;
+                } else {
+                    float pt[3], dis[3];
+                    int loc[3];
+                    const int l2d[3] = { a.t.log2dim[3 * b], a.t.log2dim[3 * b + 1], a.t.log2dim[3 * b + 2] };
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        pt[c] = ((o[c] + z * d[c]) - a.t.corners[3 * b + c]) / a.t.sizes[3 * b + c];
+                        dis[c] = (0.5f - fabsf(pt[c] - 0.5f)) * a.t.sizes[3 * b + c];
+                        const int r = 1 << l2d[c];
+                        int cc = (int)(pt[c] * (float)r);
+                        loc[c] = cc < 0 ? 0 : (cc > r - 1 ? r - 1 : cc);
+                        p01[c] = pt[c] / 2.0f + 0.25f;  // tile -> the middle half of the 2x box (:548)
+                    }
+                    w = xz_weight(dis[0], dis[2]);
+                    if (mine) {
+                        weight += w;
+                        run = a.t.occ[a.t.grid_starts[b] + cell_offset(loc, l2d[1], l2d[2])] != 0;
+                    }
+                }
+                if (!__any(run)) continue;  // wave-uniform
+                v16f x;
+                encode8_01<SCANERF_F16>((const char *)a.tables + (size_t)b * 16 * a.T * 4, a.res + (size_t)b * 48, a.T, h, p01,
+                                        run, x);
+                SampleOut so = decode_tile_dir(a.images + (size_t)b * PK_TOTAL, lane, x, d, dnorm, 0.0f);
+                if (run) {
+                    const float pa = 1.0f - expf(-1.0f * so.sigma * delta);
+                    if (BG) {
+                        alpha = pa;
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) {
+                            dif[c] = pa * so.dif[c];
+                            spc[c] = pa * (so.tint[c] * so.spec[c]);
+                        }
+                    } else {
+                        alpha += w * pa;
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) {
+                            dif[c] += w * pa * so.dif[c];
+                            spc[c] += w * pa * (so.tint[c] * so.spec[c]);
+                        }
+                    }
+                }
+            }
+        }
+        if (!BG && weight > 0) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { dif[c] /= weight; spc[c] /= weight; }
+            alpha /= weight;
+        }
+        // fg writes every sample (zeros when no tile applies, :569-571); bg only rays with a tile (:1032-1036)
+        const bool wr = in_range && h == 0 && (!BG || a.block_idxs[i * kMaxPtsBlocks + a.step] != -1);
+        if (wr) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                a.out_dif[3 * e + c] = dif[c];
+                a.out_spec[3 * e + c] = spc[c];
+            }
+            a.out_alpha[e] = alpha;
+        }
+    }
+}
+
+// ---- rendering_kernel.cu:624-702: front-to-back accumulation, one wave per ray ------------------------
+__global__ void __launch_bounds__(256) k_accumulate_color(const float *__restrict__ pts_dif,
+                                                          const float *__restrict__ pts_spec,
+                                                          const float *__restrict__ pts_alpha, float *__restrict__ transp,
+                                                          const float *__restrict__ z_vals, float *__restrict__ dif,
+                                                          float *__restrict__ spec, float *__restrict__ depth, int B, int S)
+{
+    const int lane = threadIdx.x & 63;
+    const int nw = gridDim.x * (blockDim.x >> 6);
+    for (int i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); i < B; i += nw) {
+        float T = transp[i];
+        if (T < 0.00001f) continue;  // wave-uniform
+        float acc[7] = { 0, 0, 0, 0, 0, 0, 0 };
+        for (int s0 = 0; s0 < S; s0 += 64) {
+            const int s = s0 + lane;
+            const bool live = s < S;
+            const size_t e = (size_t)i * S + (live ? s : 0);
+            const float al = live ? pts_alpha[e] : 0.0f;
+            float incl = 1.0f - al;  // T_k = T * prod_{j<k} (1 - alpha_j)
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                float t = __shfl_up(incl, off, 64);
+                if (lane >= off) incl *= t;
+            }
+            float excl = __shfl_up(incl, 1, 64);
+            if (lane == 0) excl = 1.0f;
+            const float Tk = T * excl;
+            if (live) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    acc[c] += Tk * pts_dif[3 * e + c];
+                    acc[3 + c] += Tk * pts_spec[3 * e + c];
+                }
+                acc[6] += Tk * al * z_vals[e];
+            }
+            T *= __shfl(incl, 63, 64);
+        }
+#pragma unroll
+        for (int c = 0; c < 7; ++c)
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) acc[c] += __shfl_xor(acc[c], off, 64);
+        if (lane == 0) {
+            transp[i] = T;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                dif[3 * i + c] += acc[c];
+                spec[3 * i + c] += acc[3 + c];
+            }
+            depth[i] += acc[6];
+        }
+    }
+}
+
+// ---- rendering_kernel.cu:816-868 -------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_render_inverse_z(const float *__restrict__ inter, const int16_t *__restrict__ related,
+                                                          int S, int nb, float range, float *__restrict__ z_vals, int B)
+{
+    const int64_t total = (int64_t)B * S;
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int i = (int)(e / S), k = (int)(e % S);
+        const int b = related[i];
+        if (b == -1) continue;
+        const float2 bd = reinterpret_cast<const float2 *>(inter)[(size_t)i * nb + b];
+        if (bd.x == kInf) continue;
+        const float near_ = bd.y, far_ = near_ + range;
+        const float inv_near = 1.0f / near_, inv_far = 1.0f / far_, inv_bound = inv_far - inv_near;
+        const float stp = 1.0f / (float)(S - 1);
+        z_vals[e] = 1.0f / (stp * (float)k * inv_bound + inv_near);
+    }
+}
+
+// ---- rendering_kernel.cu:1263-1401 -------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_update_outgoing(const float *__restrict__ rays_o, const float *__restrict__ rays_d,
+                                                         Tiles t, const int32_t *__restrict__ tracing_blocks,
+                                                         const float *__restrict__ inter, int16_t *__restrict__ out_bidx,
+                                                         float *__restrict__ blend, int skip, int B)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < B; i += gridDim.x * blockDim.x) {
+        const int32_t *tb = tracing_blocks + (size_t)i * t.nb;
+        const float2 *ci = reinterpret_cast<const float2 *>(inter) + (size_t)i * t.nb;
+        float far_ = -1.0f;
+        int index = 0;
+        int outb[kMaxPtsBlocks] = { -1, -1, -1, -1 };
+        for (int k = 0; k < t.nb; ++k) {
+            const int b = tb[k];
+            const float2 bd = ci[b];
+            if (bd.x == kInf) break;
+            if (!skip && (bd.x > far_ && far_ != -1.0f)) break;
+            if (bd.y > far_) {
+                far_ = bd.y;
+                outb[0] = b; outb[1] = outb[2] = outb[3] = -1;
+                index = 1;
+            } else if (bd.y == far_) {
+                if (index < kMaxPtsBlocks) {  // the reference writes unchecked
+                    if (index == 1) outb[1] = b; else if (index == 2) outb[2] = b; else outb[3] = b;
+                    ++index;
+                }
+            }
+        }
+        if (far_ == -1.0f) continue;
+        if (index == 1) {
+            blend[i * kMaxPtsBlocks] = 1.0f;
+            out_bidx[i * kMaxPtsBlocks] = (int16_t)outb[0];
+            continue;
+        }
+#pragma unroll
+        for (int k = 0; k < kMaxPtsBlocks; ++k) {
+            const int b = outb[k];
+            if (b == -1) break;
+            float dis[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float pw = rays_o[3 * i + c] + far_ * rays_d[3 * i + c];
+                float p = (pw - t.corners[3 * b + c]) / t.sizes[3 * b + c];
+                p = p < 0.0f ? 0.0f : (p > 1.0f ? 1.0f : p);
+                dis[c] = (0.5f - fabsf(p - 0.5f)) * t.sizes[3 * b + c];
+            }
+            blend[i * kMaxPtsBlocks + k] = xz_weight(dis[0], dis[2]);
+            out_bidx[i * kMaxPtsBlocks + k] = (int16_t)b;
+        }
+    }
+}
+
+// ---- rendering_kernel.cu:1406-1447 -----------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_update_outgoing_v2(const float *__restrict__ rays_o, Tiles t,
+                                                            int16_t *__restrict__ inside, float *__restrict__ blend, int B)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < B; i += gridDim.x * blockDim.x) {
+        int index = 0;
+        for (int b = 0; b < t.nb && index < kMaxPtsBlocks; ++b) {
+            float loc[3], dis[3];
+            bool in = true;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                loc[c] = (rays_o[3 * i + c] - t.corners[3 * b + c]) / t.sizes[3 * b + c];
+                in = in && (loc[c] >= 0 && loc[c] <= 1);
+                dis[c] = (0.5f - fabsf(loc[c] - 0.5f)) * t.sizes[3 * b + c];
+            }
+            if (in) {
+                inside[i * kMaxPtsBlocks + index] = (int16_t)b;
+                blend[i * kMaxPtsBlocks + index] = dis[0] * dis[1] * dis[2];
+                ++index;
+            }
+        }
+    }
+}
+
+// ---- rendering_kernel.cu:1212-1260 -------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_get_last_block(const int32_t *__restrict__ tracing_blocks, int32_t *__restrict__ bidxs,
+                                                        const float *__restrict__ inter, int nb, int B)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < B; i += gridDim.x * blockDim.x) {
+        int idx = -1;
+        for (int k = 0; k < nb; ++k) {
+            const int b = tracing_blocks[(size_t)i * nb + k];
+            if (inter[2 * ((size_t)i * nb + b)] == kInf) break;
+            idx = b;
+        }
+        bidxs[i] = idx;
+    }
+}
+
+// ---- rendering_kernel.cu:705-813: first tile along the ray whose occupancy the ray touches ----------------
+__global__ void __launch_bounds__(64) k_ray_firsthit_block(const float *__restrict__ rays_o, const float *__restrict__ rays_d,
+                                                           Tiles t, const int32_t *__restrict__ tracing_blocks,
+                                                           const float *__restrict__ inter, int16_t *__restrict__ hit, int B)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < B; i += gridDim.x * blockDim.x) {
+        const float o[3] = { rays_o[3 * i], rays_o[3 * i + 1], rays_o[3 * i + 2] };
+        const float d[3] = { rays_d[3 * i], rays_d[3 * i + 1], rays_d[3 * i + 2] };
+        float dis = 10000000.0f;
+        int last = -1;
+        for (int k = 0; k < t.nb; ++k) {
+            const int b = tracing_blocks[(size_t)i * t.nb + k];
+            const float2 bd = reinterpret_cast<const float2 *>(inter)[(size_t)i * t.nb + b];
+            if (bd.x == kInf) break;
+            const int l2d[3] = { t.log2dim[3 * b], t.log2dim[3 * b + 1], t.log2dim[3 * b + 2] };
+            int side[3];
+            float cs[3], og[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                side[c] = 1 << l2d[c];
+                cs[c] = t.sizes[3 * b + c] / (float)side[c];
+                og[c] = o[c] - t.corners[3 * b + c];
+            }
+            const uint8_t *g = t.occ + t.grid_starts[b];
+            F2 ts;
+            ts.x = bd.x;
+            ts.y = bd.y;
+            Walker w;
+            w.start(og, d, ts, side, cs);
+            bool found = false;
+            while (!w.done()) {
+                w.pick();
+                if (g[cell_offset(w.cell, l2d[1], l2d[2])]) { found = true; break; }
+                w.advance();
+            }
+            if (found && dis > bd.y) {
+                hit[i] = (int16_t)b;
+                dis = bd.y;
+            }
+            last = b;
+        }
+        if (last != -1 && hit[i] == -1) hit[i] = (int16_t)last;
+    }
+}
+
+// ---- rendering_kernel.cu:1479-1564: dilate tile `bidx`'s occupancy into the tiles it overlaps ------------------
+__global__ void __launch_bounds__(256) k_process_occupied_grid(int bidx, Tiles t, uint8_t *__restrict__ tgt, int total_grid)
+{
+    const int l0[3] = { t.log2dim[3 * bidx], t.log2dim[3 * bidx + 1], t.log2dim[3 * bidx + 2] };
+    const int r0[3] = { 1 << l0[0], 1 << l0[1], 1 << l0[2] };
+    float gs[3], c0[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        gs[c] = t.sizes[3 * bidx + c] / (float)r0[c];
+        c0[c] = t.corners[3 * bidx + c];
+    }
+    const uint8_t *g = t.occ + t.grid_starts[bidx];
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total_grid; e += gridDim.x * blockDim.x) {
+        if (!g[e]) continue;
+        const int x = e / (r0[1] * r0[2]);
+        const int y = (e - x * (r0[1] * r0[2])) / r0[2];
+        const int z = (e - x * (r0[1] * r0[2])) % r0[2];
+        const float pts[3] = { (float)x * gs[0] + c0[0], (float)y * gs[1] + c0[1], (float)z * gs[2] + c0[2] };
+        for (int b = 0; b < t.nb; ++b) {
+            if (b == bidx) continue;
+            const int l2d[3] = { t.log2dim[3 * b], t.log2dim[3 * b + 1], t.log2dim[3 * b + 2] };
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                // vertex order of the reference: 000 001 010 100 011 101 110 111
+                const int vx = (j == 3 || j == 5 || j == 6 || j == 7), vy = (j == 2 || j == 4 || j == 6 || j == 7),
+                          vz = (j == 1 || j == 4 || j == 5 || j == 7);
+                const float v[3] = { (float)vx, (float)vy, (float)vz };
+                float p[3];
+                bool in = true;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    p[c] = (pts[c] + v[c] * gs[c] - t.corners[3 * b + c]) / t.sizes[3 * b + c];
+                    in = in && (p[c] >= 0 && p[c] < 1);
+                }
+                if (in) {
+                    int ijk[3];
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) ijk[c] = (int)(p[c] * (float)(1 << l2d[c]));
+                    tgt[t.grid_starts[b] + cell_offset(ijk, l2d[1], l2d[2])] = 1;
+                }
+            }
+        }
+    }
+}
+
+Tiles make_tiles(const float *corners, const float *sizes, const uint8_t *occ, const int64_t *gst, const int32_t *l2d, int nb)
+{
+    Tiles t;
+    t.corners = corners; t.sizes = sizes; t.occ = occ; t.grid_starts = gst; t.log2dim = l2d; t.nb = nb;
+    return t;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------- C ABI
+#define RT_REQ(cond, name) SCANERF_REQUIRE(cond, name ": bad argument (null pointer or negative size)")
+
+SCANERF_API int scanerf_ray_block_intersection(const float *rays_o, const float *rays_d, const float *corners,
+                                               const float *sizes, float *inter, int B, int nb, scanerf_stream_t stream)
+{
+    RT_REQ(B >= 0 && nb >= 1, "ray_block_intersection");
+    if (B == 0) return 0;
+    RT_REQ(rays_o && rays_d && corners && sizes && inter, "ray_block_intersection");
+    hipLaunchKernelGGL(k_ray_block_intersection, dim3(stream_grid((int64_t)B * nb, 256)), dim3(256), 0, (hipStream_t)stream,
+                       rays_o, rays_d, make_tiles(corners, sizes, nullptr, nullptr, nullptr, nb), inter, B);
+    return check_launch("ray_block_intersection");
+}
+
+SCANERF_API int scanerf_render_sample_points(const float *rays_o, const float *rays_d, const float *corners,
+                                             const float *sizes, const uint8_t *occ, const int64_t *grid_starts,
+                                             const int32_t *log2dim, const int32_t *tracing_blocks, const float *inter,
+                                             int32_t *tracing_idx, float *z_start, float *z_vals, float *dists, int B, int S,
+                                             int nb, scanerf_stream_t stream)
+{
+    RT_REQ(B >= 0 && S >= 1 && nb >= 1, "sample_points");
+    if (B == 0) return 0;
+    RT_REQ(rays_o && rays_d && corners && sizes && occ && grid_starts && log2dim && tracing_blocks && inter && tracing_idx &&
+               z_start && z_vals && dists, "sample_points");
+    hipLaunchKernelGGL(k_render_sample_points, dim3(stream_grid(B, 64, kNumCU * 64)), dim3(64), 0, (hipStream_t)stream, rays_o,
+                       rays_d, make_tiles(corners, sizes, occ, grid_starts, log2dim, nb), S, tracing_blocks, inter, tracing_idx,
+                       z_start, z_vals, dists, B);
+    return check_launch("sample_points");
+}
+
+SCANERF_API int scanerf_prepare_points(const float *z_vals, const uint8_t *running_mask, const float *inter,
+                                       int16_t *block_idxs, int B, int S, int nb, scanerf_stream_t stream)
+{
+    RT_REQ(B >= 0 && S >= 1 && nb >= 1, "prepare_points");
+    if (B == 0) return 0;
+    RT_REQ(z_vals && running_mask && inter && block_idxs, "prepare_points");
+    hipLaunchKernelGGL(k_prepare_points, dim3(stream_grid((int64_t)B * S, 256)), dim3(256), 0, (hipStream_t)stream, z_vals,
+                       running_mask, block_idxs, inter, S, nb, B);
+    return check_launch("prepare_points");
+}
+
+// images: [nb][scanerf_render_workspace_floats()] decoders packed by scanerf_pack_decoder with weight_feature == 1
+SCANERF_API int scanerf_pts_inference(const float *rays_o, const float *rays_d, const float *z_vals, const float *dists,
+                                      const int16_t *block_idxs, const void *tables_f16, const float *images,
+                                      const int32_t *res, const uint8_t *occ, const int64_t *grid_starts,
+                                      const int32_t *log2dim, const float *corners, const float *sizes, float *out_dif,
+                                      float *out_spec, float *out_alpha, int B, int S, int T, int nb, scanerf_stream_t stream)
+{
+    RT_REQ(B >= 0 && S >= 1 && nb >= 1, "pts_inference");
+    SCANERF_REQUIRE(T >= 2 && (T & (T - 1)) == 0, "pts_inference: T=%d must be a power of two", T);
+    if (B == 0) return 0;
+    RT_REQ(rays_o && rays_d && z_vals && dists && block_idxs && tables_f16 && images && res && occ && grid_starts && log2dim &&
+               corners && sizes && out_dif && out_spec && out_alpha, "pts_inference");
+    InferArgs a;
+    a.rays_o = rays_o; a.rays_d = rays_d; a.z_vals = z_vals; a.dists = dists; a.block_idxs = block_idxs;
+    a.tables = tables_f16; a.images = images; a.res = res; a.t = make_tiles(corners, sizes, occ, grid_starts, log2dim, nb);
+    a.out_dif = out_dif; a.out_spec = out_spec; a.out_alpha = out_alpha; a.T = T; a.B = B; a.S = S; a.step = 0;
+    const int64_t tiles32 = ((int64_t)B * S + 31) / 32;
+    int blocks = (int)((tiles32 + 3) / 4 < kNumCU * 4 ? (tiles32 + 3) / 4 : kNumCU * 4);
+    hipLaunchKernelGGL((k_pts_inference<false>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+    return check_launch("pts_inference");
+}
+
+SCANERF_API int scanerf_bg_pts_inference_v2(const float *rays_o, const float *rays_d, const float *z_vals,
+                                            const int16_t *bg_idxs, int step, const float *corners, const float *sizes,
+                                            const int32_t *res, const void *tables_f16, const float *images, float *out_dif,
+                                            float *out_spec, float *out_alpha, int B, int S, int T, int nb,
+                                            scanerf_stream_t stream)
+{
+    RT_REQ(B >= 0 && S >= 1 && nb >= 1 && step >= 0 && step < kMaxPtsBlocks, "bg_pts_inference_v2");
+    SCANERF_REQUIRE(T >= 2 && (T & (T - 1)) == 0, "bg_pts_inference_v2: T=%d must be a power of two", T);
+    if (B == 0) return 0;
+    RT_REQ(rays_o && rays_d && z_vals && bg_idxs && tables_f16 && images && res && corners && sizes && out_dif && out_spec &&
+               out_alpha, "bg_pts_inference_v2");
+    InferArgs a;
+    a.rays_o = rays_o; a.rays_d = rays_d; a.z_vals = z_vals; a.dists = nullptr; a.block_idxs = bg_idxs;
+    a.tables = tables_f16; a.images = images; a.res = res; a.t = make_tiles(corners, sizes, nullptr, nullptr, nullptr, nb);
+    a.out_dif = out_dif; a.out_spec = out_spec; a.out_alpha = out_alpha; a.T = T; a.B = B; a.S = S; a.step = step;
+    const int64_t tiles32 = ((int64_t)B * S + 31) / 32;
+    int blocks = (int)((tiles32 + 3) / 4 < kNumCU * 4 ? (tiles32 + 3) / 4 : kNumCU * 4);
+    hipLaunchKernelGGL((k_pts_inference<true>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+    return check_launch("bg_pts_inference_v2");
+}
+
+SCANERF_API int scanerf_accumulate_color(const float *pts_dif, const float *pts_spec, const float *pts_alpha, float *transp,
+                                         const float *z_vals, float *dif, float *spec, float *depth, int B, int S,
+                                         scanerf_stream_t stream)
+{
+    RT_REQ(B >= 0 && S >= 1, "accumulate_color");
+    if (B == 0) return 0;
+    RT_REQ(pts_dif && pts_spec && pts_alpha && transp && z_vals && dif && spec && depth, "accumulate_color");
+    hipLaunchKernelGGL(k_accumulate_color, dim3(stream_grid((int64_t)B * 64, 256)), dim3(256), 0, (hipStream_t)stream, pts_dif,
+                       pts_spec, pts_alpha, transp, z_vals, dif, spec, depth, B, S);
+    return check_launch("accumulate_color");
+}
+
+SCANERF_API int scanerf_render_inverse_z_sampling(const float *inter, const int16_t *related_bidx, float *z_vals,
+                                                  float sample_range, int B, int S, int nb, scanerf_stream_t stream)
+{
+    RT_REQ(B >= 0 && S >= 2 && nb >= 1, "inverse_z_sampling");
+    if (B == 0) return 0;
+    RT_REQ(inter && related_bidx && z_vals, "inverse_z_sampling");
+    hipLaunchKernelGGL(k_render_inverse_z, dim3(stream_grid((int64_t)B * S, 256)), dim3(256), 0, (hipStream_t)stream, inter,
+                       related_bidx, S, nb, sample_range, z_vals, B);
+    return check_launch("inverse_z_sampling");
+}
+
+SCANERF_API int scanerf_update_outgoing_bidx(const float *rays_o, const float *rays_d, const float *corners,
+                                             const float *sizes, const int32_t *tracing_blocks, const float *inter,
+                                             int16_t *out_bidx, float *blend, float ratio, int skip, int B, int nb,
+                                             scanerf_stream_t stream)
+{
+    (void)ratio;  // unused by the reference kernel as well (its only use is commented out, :1323-1331)
+    RT_REQ(B >= 0 && nb >= 1, "update_outgoing_bidx");
+    if (B == 0) return 0;
+    RT_REQ(rays_o && rays_d && corners && sizes && tracing_blocks && inter && out_bidx && blend, "update_outgoing_bidx");
+    hipLaunchKernelGGL(k_update_outgoing, dim3(stream_grid(B, 256)), dim3(256), 0, (hipStream_t)stream, rays_o, rays_d,
+                       make_tiles(corners, sizes, nullptr, nullptr, nullptr, nb), tracing_blocks, inter, out_bidx, blend, skip, B);
+    return check_launch("update_outgoing_bidx");
+}
+
+SCANERF_API int scanerf_update_outgoing_bidx_v2(const float *rays_o, const float *corners, const float *sizes,
+                                                int16_t *inside_bidx, float *blend, int B, int nb, scanerf_stream_t stream)
+{
+    RT_REQ(B >= 0 && nb >= 1, "update_outgoing_bidx_v2");
+    if (B == 0) return 0;
+    RT_REQ(rays_o && corners && sizes && inside_bidx && blend, "update_outgoing_bidx_v2");
+    hipLaunchKernelGGL(k_update_outgoing_v2, dim3(stream_grid(B, 256)), dim3(256), 0, (hipStream_t)stream, rays_o,
+                       make_tiles(corners, sizes, nullptr, nullptr, nullptr, nb), inside_bidx, blend, B);
+    return check_launch("update_outgoing_bidx_v2");
+}
+
+SCANERF_API int scanerf_get_last_block(const int32_t *tracing_blocks, int32_t *bidxs, const float *inter, int B, int nb,
+                                       scanerf_stream_t stream)
+{
+    RT_REQ(B >= 0 && nb >= 1, "get_last_block");
+    if (B == 0) return 0;
+    RT_REQ(tracing_blocks && bidxs && inter, "get_last_block");
+    hipLaunchKernelGGL(k_get_last_block, dim3(stream_grid(B, 256)), dim3(256), 0, (hipStream_t)stream, tracing_blocks, bidxs,
+                       inter, nb, B);
+    return check_launch("get_last_block");
+}
+
+SCANERF_API int scanerf_ray_firsthit_block(const float *rays_o, const float *rays_d, const float *corners, const float *sizes,
+                                           const uint8_t *occ, const int64_t *grid_starts, const int32_t *log2dim,
+                                           const int32_t *tracing_blocks, const float *inter, int16_t *hit, int B, int nb,
+                                           scanerf_stream_t stream)
+{
+    RT_REQ(B >= 0 && nb >= 1, "ray_firsthit_block");
+    if (B == 0) return 0;
+    RT_REQ(rays_o && rays_d && corners && sizes && occ && grid_starts && log2dim && tracing_blocks && inter && hit,
+           "ray_firsthit_block");
+    hipLaunchKernelGGL(k_ray_firsthit_block, dim3(stream_grid(B, 64, kNumCU * 64)), dim3(64), 0, (hipStream_t)stream, rays_o,
+                       rays_d, make_tiles(corners, sizes, occ, grid_starts, log2dim, nb), tracing_blocks, inter, hit, B);
+    return check_launch("ray_firsthit_block");
+}
+
+SCANERF_API int scanerf_process_occupied_grid(int bidx, int total_grid, const float *corners, const float *sizes,
+                                              const uint8_t *occ, const int64_t *grid_starts, const int32_t *log2dim,
+                                              uint8_t *tgt_occ, int nb, scanerf_stream_t stream)
+{
+    RT_REQ(total_grid >= 0 && nb >= 1 && bidx >= 0 && bidx < nb, "process_occupied_grid");
+    if (total_grid == 0) return 0;
+    RT_REQ(corners && sizes && occ && grid_starts && log2dim && tgt_occ, "process_occupied_grid");
+    hipLaunchKernelGGL(k_process_occupied_grid, dim3(stream_grid(total_grid, 256)), dim3(256), 0, (hipStream_t)stream, bidx,
+                       make_tiles(corners, sizes, occ, grid_starts, log2dim, nb), tgt_occ, total_grid);
+    return check_launch("process_occupied_grid");
+}

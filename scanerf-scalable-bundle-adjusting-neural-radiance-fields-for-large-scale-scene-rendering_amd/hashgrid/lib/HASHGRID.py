@@ -82,6 +82,168 @@ def embedding_backward_cuda(points, grad_in, grad_points, grad_features, feature
           "embedding_backward_cuda")
 
 
+# ------------------------------------------------------------------ render-time ops (rendering.h:20-182)
+_i16, _i64, _bool = torch.int16, torch.int64, (torch.bool, torch.uint8)
+_I = ctypes.c_int
+_images = {}
+
+
+def _packed_images(params):
+    """[nb, 13994] decoder blobs -> [nb, image] packed for the MFMA decoder (weight_feature == 1: the
+    render-time decoder has no coarse-to-fine mask, decoder.h:169-218).  Cached per params version."""
+    key = (params.data_ptr(), tuple(params.shape), params._version)
+    hit = _images.get("k")
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    nb = params.shape[0]
+    n = lib().scanerf_render_workspace_floats()
+    img = torch.empty((nb, n), dtype=_f32, device=params.device)
+    ones = torch.ones(32, dtype=_f32, device=params.device)
+    p = params.contiguous()
+    for b in range(nb):
+        check(lib().scanerf_pack_decoder(ctypes.c_void_p(p[b].data_ptr()), dev_ptr(ones, _f32, "wf"),
+                                         ctypes.c_void_p(img[b].data_ptr()), stream()), "pack_decoder")
+    _images["k"] = (key, img)
+    return img
+
+
+def ray_block_intersection(rays_o, rays_d, block_corners, block_sizes, intersections):
+    """rendering.h: intersections [B,nb,2] pre-filled with 1e7 (rendering.py:299)."""
+    check(lib().scanerf_ray_block_intersection(dev_ptr(rays_o, _f32, "rays_o"), dev_ptr(rays_d, _f32, "rays_d"),
+                                               dev_ptr(block_corners, _f32, "block_corners"),
+                                               dev_ptr(block_sizes, _f32, "block_sizes"),
+                                               dev_ptr(intersections, _f32, "intersections"), _I(rays_d.shape[0]),
+                                               _I(block_corners.shape[0]), stream()), "ray_block_intersection")
+
+
+def sample_points(rays_o, rays_d, block_corners, block_sizes, grid_occupied, grid_starts, grid_log2dim, tracing_blocks,
+                  intersections, tracing_idx, z_start, z_vals, dists):
+    check(lib().scanerf_render_sample_points(
+        dev_ptr(rays_o, _f32, "rays_o"), dev_ptr(rays_d, _f32, "rays_d"), dev_ptr(block_corners, _f32, "block_corners"),
+        dev_ptr(block_sizes, _f32, "block_sizes"), dev_ptr(grid_occupied, _bool, "grid_occupied"),
+        dev_ptr(grid_starts, _i64, "grid_starts"), dev_ptr(grid_log2dim, _i32, "grid_log2dim"),
+        dev_ptr(tracing_blocks, _i32, "tracing_blocks"), dev_ptr(intersections, _f32, "intersections"),
+        dev_ptr(tracing_idx, _i32, "tracing_idx"), dev_ptr(z_start, _f32, "z_start"), dev_ptr(z_vals, _f32, "z_vals"),
+        dev_ptr(dists, _f32, "dists"), _I(rays_d.shape[0]), _I(z_vals.shape[1]), _I(block_corners.shape[0]), stream()),
+        "sample_points")
+
+
+def prepare_points(z_vals, runing_mask, intersections, block_idxs):
+    check(lib().scanerf_prepare_points(dev_ptr(z_vals, _f32, "z_vals"), dev_ptr(runing_mask, _bool, "runing_mask"),
+                                       dev_ptr(intersections, _f32, "intersections"),
+                                       dev_ptr(block_idxs, _i16, "block_idxs"), _I(z_vals.shape[0]), _I(z_vals.shape[1]),
+                                       _I(intersections.shape[1]), stream()), "prepare_points")
+
+
+def pts_inference(rays_o, rays_d, z_vals, dists, block_idxs, features_tables, params, resolution, grid_occupied,
+                  grid_starts, grid_log2dim, block_corners, block_sizes, diffuse, specular, alpha):
+    img = _packed_images(params)
+    check(lib().scanerf_pts_inference(
+        dev_ptr(rays_o, _f32, "rays_o"), dev_ptr(rays_d, _f32, "rays_d"), dev_ptr(z_vals, _f32, "z_vals"),
+        dev_ptr(dists, _f32, "dists"), dev_ptr(block_idxs, _i16, "block_idxs"),
+        dev_ptr(features_tables, torch.float16, "features_tables"), dev_ptr(img, _f32, "images"),
+        dev_ptr(resolution, _i32, "resolution"), dev_ptr(grid_occupied, _bool, "grid_occupied"),
+        dev_ptr(grid_starts, _i64, "grid_starts"), dev_ptr(grid_log2dim, _i32, "grid_log2dim"),
+        dev_ptr(block_corners, _f32, "block_corners"), dev_ptr(block_sizes, _f32, "block_sizes"),
+        dev_ptr(diffuse, _f32, "diffuse"), dev_ptr(specular, _f32, "specular"), dev_ptr(alpha, _f32, "alpha"),
+        _I(rays_d.shape[0]), _I(z_vals.shape[1]), _I(features_tables.shape[2]), _I(block_corners.shape[0]), stream()),
+        "pts_inference")
+
+
+def accumulate_color(pts_diffuse, pts_specular, pts_alpha, transparency, z_vals, diffuse, specular, depth):
+    check(lib().scanerf_accumulate_color(
+        dev_ptr(pts_diffuse, _f32, "pts_diffuse"), dev_ptr(pts_specular, _f32, "pts_specular"),
+        dev_ptr(pts_alpha, _f32, "pts_alpha"), dev_ptr(transparency, _f32, "transparency"), dev_ptr(z_vals, _f32, "z_vals"),
+        dev_ptr(diffuse, _f32, "diffuse"), dev_ptr(specular, _f32, "specular"), dev_ptr(depth, _f32, "depth"),
+        _I(z_vals.shape[0]), _I(z_vals.shape[1]), stream()), "accumulate_color")
+
+
+def inverse_z_sampling(intersections, related_bidx, z_vals, sample_range):
+    check(lib().scanerf_render_inverse_z_sampling(dev_ptr(intersections, _f32, "intersections"),
+                                                  dev_ptr(related_bidx, _i16, "related_bidx"),
+                                                  dev_ptr(z_vals, _f32, "z_vals"), ctypes.c_float(sample_range),
+                                                  _I(intersections.shape[0]), _I(z_vals.shape[1]),
+                                                  _I(intersections.shape[1]), stream()), "inverse_z_sampling")
+
+
+def bg_pts_inference_v2(rays_o, rays_d, z_vals, bg_idxs, step, block_corners, block_sizes, resolution, features_tables,
+                        params, diffuse, specular, alpha):
+    img = _packed_images(params)
+    check(lib().scanerf_bg_pts_inference_v2(
+        dev_ptr(rays_o, _f32, "rays_o"), dev_ptr(rays_d, _f32, "rays_d"), dev_ptr(z_vals, _f32, "z_vals"),
+        dev_ptr(bg_idxs, _i16, "bg_idxs"), _I(step), dev_ptr(block_corners, _f32, "block_corners"),
+        dev_ptr(block_sizes, _f32, "block_sizes"), dev_ptr(resolution, _i32, "resolution"),
+        dev_ptr(features_tables, torch.float16, "features_tables"), dev_ptr(img, _f32, "images"),
+        dev_ptr(diffuse, _f32, "diffuse"), dev_ptr(specular, _f32, "specular"), dev_ptr(alpha, _f32, "alpha"),
+        _I(rays_d.shape[0]), _I(z_vals.shape[1]), _I(features_tables.shape[2]), _I(block_corners.shape[0]), stream()),
+        "bg_pts_inference_v2")
+
+
+def bg_pts_inference(*args, **kwargs):
+    """hashgrid/binding.cpp:31 (v1): superseded by bg_pts_inference_v2 in rendering.py:497; no caller."""
+    raise NotImplementedError("bg_pts_inference (v1) has no caller in the reference; use bg_pts_inference_v2")
+
+
+def update_outgoing_bidx(rays_o, rays_d, block_corners, block_sizes, tracing_blocks, intersections, outgoing_bidxs,
+                         blend_weights, ratio, skip):
+    check(lib().scanerf_update_outgoing_bidx(
+        dev_ptr(rays_o, _f32, "rays_o"), dev_ptr(rays_d, _f32, "rays_d"), dev_ptr(block_corners, _f32, "block_corners"),
+        dev_ptr(block_sizes, _f32, "block_sizes"), dev_ptr(tracing_blocks, _i32, "tracing_blocks"),
+        dev_ptr(intersections, _f32, "intersections"), dev_ptr(outgoing_bidxs, _i16, "outgoing_bidxs"),
+        dev_ptr(blend_weights, _f32, "blend_weights"), ctypes.c_float(ratio), _I(int(bool(skip))),
+        _I(tracing_blocks.shape[0]), _I(tracing_blocks.shape[1]), stream()), "update_outgoing_bidx")
+
+
+def update_outgoing_bidx_v2(rays_o, rays_d, block_corners, block_sizes, tracing_blocks, intersections, inside_bidxs,
+                            blend_weights):
+    check(lib().scanerf_update_outgoing_bidx_v2(
+        dev_ptr(rays_o, _f32, "rays_o"), dev_ptr(block_corners, _f32, "block_corners"),
+        dev_ptr(block_sizes, _f32, "block_sizes"), dev_ptr(inside_bidxs, _i16, "inside_bidxs"),
+        dev_ptr(blend_weights, _f32, "blend_weights"), _I(tracing_blocks.shape[0]), _I(tracing_blocks.shape[1]), stream()),
+        "update_outgoing_bidx_v2")
+
+
+def get_last_block(tracing_blocks, bidxs, intersections):
+    check(lib().scanerf_get_last_block(dev_ptr(tracing_blocks, _i32, "tracing_blocks"), dev_ptr(bidxs, _i32, "bidxs"),
+                                       dev_ptr(intersections, _f32, "intersections"), _I(intersections.shape[0]),
+                                       _I(intersections.shape[1]), stream()), "get_last_block")
+
+
+def ray_firsthit_block(rays_o, rays_d, block_corners, block_sizes, grid_occupied, grid_starts, grid_log2dim,
+                       tracing_blocks, intersections, hit_blockIdxs):
+    check(lib().scanerf_ray_firsthit_block(
+        dev_ptr(rays_o, _f32, "rays_o"), dev_ptr(rays_d, _f32, "rays_d"), dev_ptr(block_corners, _f32, "block_corners"),
+        dev_ptr(block_sizes, _f32, "block_sizes"), dev_ptr(grid_occupied, _bool, "grid_occupied"),
+        dev_ptr(grid_starts, _i64, "grid_starts"), dev_ptr(grid_log2dim, _i32, "grid_log2dim"),
+        dev_ptr(tracing_blocks, _i32, "tracing_blocks"), dev_ptr(intersections, _f32, "intersections"),
+        dev_ptr(hit_blockIdxs, _i16, "hit_blockIdxs"), _I(rays_d.shape[0]), _I(block_corners.shape[0]), stream()),
+        "ray_firsthit_block")
+
+
+def process_occupied_grid(bidx, total_grid, block_corners, block_sizes, grid_occupied, grid_starts, grid_log2dim,
+                          tgt_grid_occupied):
+    check(lib().scanerf_process_occupied_grid(
+        _I(bidx), _I(total_grid), dev_ptr(block_corners, _f32, "block_corners"), dev_ptr(block_sizes, _f32, "block_sizes"),
+        dev_ptr(grid_occupied, _bool, "grid_occupied"), dev_ptr(grid_starts, _i64, "grid_starts"),
+        dev_ptr(grid_log2dim, _i32, "grid_log2dim"), dev_ptr(tgt_grid_occupied, _bool, "tgt_grid_occupied"),
+        _I(block_corners.shape[0]), stream()), "process_occupied_grid")
+
+
+def sort_by_key(keys_tensor, values_tensor, starts_tensor):
+    """rendering_kernel.cu:452-463 (thrust sort_by_key + unique_by_key; no caller in the reference).
+    In-place on keys / values; unique keys and the first `starts` of each run are compacted to the
+    front; returns the number of unique keys.  Host-side torch ops: not on the hot path."""
+    k, order = torch.sort(keys_tensor, stable=True)
+    keys_tensor.copy_(k)
+    values_tensor.copy_(values_tensor[order])
+    first = torch.ones_like(k, dtype=torch.bool)
+    first[1:] = k[1:] != k[:-1]
+    n = int(first.sum())
+    keys_tensor[:n] = k[first]
+    starts_tensor[:n] = starts_tensor[first]
+    return n
+
+
 def rendering_cuda(*args, **kwargs):
     """hashgrid/binding.cpp:22.  The reference's device body is commented out
     (hashgrid/src/rendering/renderbase_kernel.cu:72-177): dead code, exported as a stub."""

@@ -102,6 +102,8 @@ class TileModel(nn.Module):
         self.occ_size = (self.bbox_size / 2.0).to(device).contiguous()
         self._min_dev = self.min_bbox.to(device)
         self._size_dev = self.bbox_size.to(device)
+        self._center_dev = self.bbox_center.to(device).contiguous()
+        self._half_dev = (self.bbox_size / 2.0).to(device).contiguous()
         self.packed = render.PackedDecoder(device)
         # fused sparse Adam state for the table (cuda/adam_kernel.cu semantics)
         self.exp_avg = torch.zeros_like(self.features)
@@ -149,6 +151,48 @@ class TileModel(nn.Module):
                                        self.min_bbox.tolist(), self.bbox_size.tolist(), render.FORE, False,
                                        ray_valid=valid)
         return out, w, valid
+
+    # ---- background branch: inverse-depth sampling beyond the 2x box (hashgrid/__init__.py:306-337) ----
+    @torch.no_grad()
+    def inverse_z_sampling(self, rays_o, rays_d, S, invalid_underground=False):
+        """z = 1/((1-t)/(far+1e-6) + t/1e6), t = linspace(0,1,S); far = exit of the HashGrid box
+        (0.1 for rays that miss it); dists = diff, last = 1e-6; optional under-ground mask (:287-293)."""
+        from .cuda import ray_aabb_intersection
+        B = rays_o.shape[0]
+        bounds = torch.full((B, 2), -1.0, device=self.device)
+        ray_aabb_intersection(rays_o, rays_d, self._center_dev, self._half_dev, bounds)
+        if invalid_underground:
+            out_pt = rays_o + bounds[:, 1:] * rays_d
+            valid = ~(torch.abs(out_pt[:, 1] - (self._center_dev - self._size_dev / 4.0)[1]) < 0.0001)
+        else:
+            valid = torch.ones(B, dtype=torch.bool, device=self.device)
+        far = torch.where(torch.any(bounds == -1, dim=-1, keepdim=True), torch.full_like(bounds[:, 1:], 0.1), bounds[:, 1:])
+        t = torch.linspace(0.0, 1.0, steps=S, device=self.device)[None, :]
+        z = (1.0 / (1.0 / (far + 1e-6) * (1.0 - t) + 1.0 / 1e6 * t)).contiguous()
+        d = torch.cat([z[:, 1:] - z[:, :-1], torch.full((B, 1), 1e-6, device=self.device)], -1).contiguous()
+        return z, d, valid
+
+    @torch.no_grad()
+    def render_rays_fused(self, rays_o, rays_d, S_fg, S_bg, global_step, invalid_underground=False):
+        """tile.py:639-692 on the fused kernels: foreground (occupancy-sampled, contract_fore) and
+        background (inverse-z, contract_bg, infinity) renders, merged with the foreground's T_left."""
+        self.packed.pack(self.decoder.blob(), network.weight_feature(global_step, self.device))
+        table = self.features if self.table_dtype == torch.float32 else self.features.to(self.table_dtype)
+        box = (self.min_bbox.tolist(), self.bbox_size.tolist())
+        z, dist = self.sample(rays_o, rays_d, S_fg)
+        vf = torch.all(z != -1, dim=-1)
+        fg, wfg = render.render_forward(rays_o, rays_d, z, dist, table, self.resolution, self.packed, *box, render.FORE,
+                                        False, ray_valid=vf)
+        zb, db, vb = self.inverse_z_sampling(rays_o, rays_d, S_bg, invalid_underground)
+        bg, wbg = render.render_forward(rays_o, rays_d, zb, db, table, self.resolution, self.packed, *box, render.BG,
+                                        True, ray_valid=vb)
+        T = fg[:, render.T_LEFT, None]
+        return {"fore_valid": vf, "bg_valid": vb, "T_left": T,
+                "pred_color": fg[:, render.RGB] + T * bg[:, render.RGB],
+                "pred_depth": fg[:, render.DEPTH, None] + T * bg[:, render.DEPTH, None],
+                "pred_specular": fg[:, render.SPECULAR] + T * bg[:, render.SPECULAR],
+                "pred_diffuse": fg[:, render.DIFFUSE] + T * bg[:, render.DIFFUSE],
+                "fg": fg, "bg": bg, "fg_weights": wfg, "bg_weights": wbg}
 
     # ---- optimiser on the table: fused sparse Adam (only touched entries move) --------------
     @torch.no_grad()

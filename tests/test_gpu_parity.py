@@ -407,3 +407,30 @@ def test_render_backward_vs_oracle_autograd(S, bg, S_):
     gF_ref = F.grad.numpy()
     fs = np.abs(gF_ref).max()
     np.testing.assert_allclose(gF / fs, gF_ref / fs, rtol=2e-3, atol=2e-5)
+
+
+def test_render_rays_fg_bg_merge_vs_oracle(S):
+    """a5 (inverse-z background sampling) + a13 (fg/bg merge with T_left): the fused tile render against
+    the oracle's restatement of tile.py:639-692 / hashgrid/__init__.py:413-509."""
+    from scanerf_amd.tile_model import TileModel
+    rng = np.random.default_rng(13)
+    B, Sf, Sb = 300, 64, 48
+    m = TileModel([-4, -4, -4], [8, 8, 8], DEV, log2_T=12, seed=3)
+    occ = rng.random((16, 16, 16)) < 0.5
+    m.occupied_grid = g(occ)
+    o = rng.uniform(-3.9, 3.9, (B, 3)).astype(np.float32)
+    o[:20] += 30.0  # some rays start far outside: fg misses, bg still renders
+    d = rng.normal(size=(B, 3)).astype(np.float32)
+    with torch.no_grad():
+        m.features.mul_(40.0)  # visible densities
+    out = m.render_rays_fused(g(o), g(d), Sf, Sb, 3000, invalid_underground=True)
+    tile = O.Tile([-4, -4, -4], [8, 8, 8], log2_T=12)
+    tile.occ = torch.from_numpy(occ)
+    sd = {k: v.detach().cpu() for k, v in m.decoder.ref_state_dict().items()}
+    with torch.no_grad():
+        ref = O.render_rays(tile, m.features.detach().cpu(), sd, torch.from_numpy(o), torch.from_numpy(d), Sf, Sb,
+                            O.INFERENCE, 3000, invalid_underground=True)
+    assert torch.equal(out["fore_valid"].cpu(), ref["fore_valid"]) and torch.equal(out["bg_valid"].cpu(), ref["bg_valid"])
+    assert 0 < int(ref["fore_valid"].sum()) < B
+    for k in ("pred_color", "pred_depth", "pred_specular", "pred_diffuse", "T_left"):
+        np.testing.assert_allclose(out[k].cpu().numpy(), ref[k].numpy(), rtol=1e-4, atol=2e-6, err_msg=k)
