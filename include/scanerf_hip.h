@@ -145,13 +145,14 @@ int scanerf_pack_decoder(const float *mlp_blob, const float *weight_feature, flo
 
 /* ray_valid [B] u8 (may be NULL): rays with 0 render as zeros with T_left = 1
  * (hashgrid/__init__.py:427-431) and are skipped.  tile_T [B, ceil(S/32)] (may be NULL): the
- * transmittance entering each 32-sample tile, saved for scanerf_render_backward. */
+ * transmittance entering each 32-sample tile, saved for scanerf_render_backward.  xstash [B*S,32] f32
+ * (may be NULL): the encoder outputs in register order, so the backward can skip the re-gather. */
 int scanerf_render_forward_packed(const float *rays_o, const float *rays_d, const float *z_vals,
                                   const float *dists, const void *features, int feat_dtype,
                                   const int32_t *resolutions, const float *workspace,
                                   const scanerf_render_cfg *cfg /*[host]*/, const uint8_t *ray_valid,
-                                  float *out_ray, float *weights, float *tile_T, int B, int S, int T,
-                                  scanerf_stream_t stream);
+                                  float *out_ray, float *weights, float *tile_T, float *xstash, int B, int S,
+                                  int T, scanerf_stream_t stream);
 
 /* Adjoint of scanerf_render_forward_packed (hashgrid/__init__.py:512-596 under autograd).
  *   out_ray, tile_T: the forward's outputs;  grad_out [B,16]: dL/d(out_ray) (columns as out_ray;
@@ -166,8 +167,9 @@ int scanerf_render_backward(const float *rays_o, const float *rays_d, const floa
                             const void *features, int feat_dtype, const int32_t *resolutions,
                             const float *workspace, const float *weight_feature,
                             const scanerf_render_cfg *cfg /*[host]*/, const uint8_t *ray_valid,
-                            const float *out_ray, const float *tile_T, const float *grad_out, float *dfeat,
-                            float *dw_partial, float *grad_blob, int B, int S, int T, scanerf_stream_t stream);
+                            const float *out_ray, const float *tile_T, const float *grad_out,
+                            const float *xstash /* forward's, or NULL */, float *dfeat, float *dw_partial,
+                            float *grad_blob, int B, int S, int T, scanerf_stream_t stream);
 
 /* Encoder with an explicit mapping (for benchmarks and the two-kernel path):
  * variant 0 auto / 1 XCD-partitioned by level / 2 level-fastest; level_major_out != 0 writes

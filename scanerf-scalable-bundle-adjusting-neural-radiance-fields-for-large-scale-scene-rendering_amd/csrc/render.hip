@@ -163,6 +163,13 @@ __global__ void __launch_bounds__(kRenderThreads, 2) k_render_fwd(RenderArgs a)
             contract_point(a, o, d, z, p);
             v16f x;
             encode8<DT>(a, lds_res, h, p, x);
+            if (a.xstash && live) {
+                float4 *xs = reinterpret_cast<float4 *>(a.xstash + ((size_t)ray * S + s) * 32 + 16 * h);
+                xs[0] = make_float4(x[0], x[1], x[2], x[3]);
+                xs[1] = make_float4(x[4], x[5], x[6], x[7]);
+                xs[2] = make_float4(x[8], x[9], x[10], x[11]);
+                xs[3] = make_float4(x[12], x[13], x[14], x[15]);
+            }
             SampleOut so = decode_tile(lds, lane, x, dinit);
 
             // compositing (hashgrid/__init__.py:344-360): alpha, T = cumprod(1 - alpha + 1e-6)
@@ -224,8 +231,8 @@ SCANERF_API int scanerf_render_forward_packed(const float *rays_o, const float *
                                               const float *dists, const void *features, int feat_dtype,
                                               const int32_t *resolutions, const float *packed,
                                               const scanerf_render_cfg *cfg, const uint8_t *ray_valid,
-                                              float *out_ray, float *weights, float *tile_T, int B, int S, int T,
-                                              scanerf_stream_t stream)
+                                              float *out_ray, float *weights, float *tile_T, float *xstash, int B, int S,
+                                              int T, scanerf_stream_t stream)
 {
     SCANERF_REQUIRE(B >= 0 && S >= 1, "render_forward: B=%d S=%d", B, S);
     SCANERF_REQUIRE(T >= 2 && (T & (T - 1)) == 0, "render_forward: T=%d must be a power of two", T);
@@ -239,7 +246,7 @@ SCANERF_API int scanerf_render_forward_packed(const float *rays_o, const float *
     RenderArgs a;
     a.rays_o = rays_o; a.rays_d = rays_d; a.z_vals = z_vals; a.dists = dists;
     a.features = features; a.resolutions = resolutions; a.packed = packed; a.ray_valid = ray_valid;
-    a.out_ray = out_ray; a.weights = weights; a.tile_T = tile_T;
+    a.out_ray = out_ray; a.weights = weights; a.tile_T = tile_T; a.xstash = xstash;
     a.B = B; a.S = S; a.T = T;
     a.contract_mode = cfg->contract_mode; a.infinity = cfg->infinity;
     for (int k = 0; k < 3; ++k) {

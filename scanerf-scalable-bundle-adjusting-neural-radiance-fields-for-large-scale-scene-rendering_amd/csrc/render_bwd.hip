@@ -23,6 +23,8 @@
 // tile groups are walked LAST to FIRST with the tile-entry transmittances saved by the forward,
 // so suffix sums are formed directly (a prefix-minus-total form divides rounding noise by
 // f_i = 1-alpha_i+1e-6 and loses opaque samples).
+#include <stdlib.h>
+
 #include "render_device.h"
 
 using namespace scanerf;
@@ -41,6 +43,8 @@ struct BwdArgs {
     const float *tile_T;       // [B, ntiles] from the forward
     float *dfeat;              // [16][B*S][2]
     float *dw_partial;         // [nwaves][SCANERF_PARAMSIZE], zero-filled by the host wrapper
+    const float *xstash;       // optional [B*S][2][16]: the forward's encoder outputs (skips the re-gather)
+    int dbg;                   // timing experiments only (SCANERF_DEBUG_BWD): 1 = forward recompute only, 2 = no dW
 };
 
 __device__ __forceinline__ float dgauss(float u, float a) { return -100.0f * u * a; }  // d/du exp(-50 u^2)
@@ -190,7 +194,14 @@ __global__ void __launch_bounds__(kBwdThreads, 1) k_render_bwd(BwdArgs a)
 
             // ================= P0: forward recompute of this wave's tile =================
             v16f x;
-            encode8<DT>(a.f, lres, h, p, x);
+            if (a.xstash) {
+                // the forward saved this lane's 16 encoder outputs: 64 contiguous bytes per lane
+                const float4 *xs = reinterpret_cast<const float4 *>(a.xstash + ((size_t)ray * S + (live ? s : 0)) * 32 + 16 * h);
+                const float4 q0 = xs[0], q1 = xs[1], q2 = xs[2], q3 = xs[3];
+                x = v16f{ q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w };
+            } else {
+                encode8<DT>(a.f, lres, h, p, x);
+            }
             v16f H[2] = { load_bias(lds, 1, 0, h), load_bias(lds, 1, 1, h) };
             {
                 v16f u0a = load_bias(lds, 0, 0, h), u0b = load_bias(lds, 0, 1, h);
@@ -302,6 +313,7 @@ __global__ void __launch_bounds__(kBwdThreads, 1) k_render_bwd(BwdArgs a)
                 if (sl + off < 32) rs += t;
             }
             if (lane == 0) totals[wv] = rs;  // lane 0: the whole tile
+            if (a.dbg == 1) { if (live) a.dfeat[(size_t)ray * S + s] = x[0] + H[0][0] + v0[0][0] + v1[0][0] + rs; continue; }
             __syncthreads();  // ---- B1: tile totals visible; every wave is done with last group's stage rows
 
             // ================= P1: compositing adjoint, narrow layers, D1 operands =================
@@ -567,8 +579,8 @@ SCANERF_API int scanerf_render_backward(const float *rays_o, const float *rays_d
                                         const void *features, int feat_dtype, const int32_t *resolutions,
                                         const float *workspace, const float *weight_feature,
                                         const scanerf_render_cfg *cfg, const uint8_t *ray_valid, const float *out_ray,
-                                        const float *tile_T, const float *grad_out, float *dfeat, float *dw_partial,
-                                        float *grad_blob, int B, int S, int T, scanerf_stream_t stream)
+                                        const float *tile_T, const float *grad_out, const float *xstash, float *dfeat,
+                                        float *dw_partial, float *grad_blob, int B, int S, int T, scanerf_stream_t stream)
 {
     SCANERF_REQUIRE(B >= 0 && S >= 1, "render_backward: B=%d S=%d", B, S);
     SCANERF_REQUIRE(T >= 2 && (T & (T - 1)) == 0, "render_backward: T=%d must be a power of two", T);
@@ -581,7 +593,7 @@ SCANERF_API int scanerf_render_backward(const float *rays_o, const float *rays_d
     BwdArgs a;
     a.f.rays_o = rays_o; a.f.rays_d = rays_d; a.f.z_vals = z_vals; a.f.dists = dists;
     a.f.features = features; a.f.resolutions = resolutions; a.f.packed = workspace; a.f.ray_valid = ray_valid;
-    a.f.out_ray = const_cast<float *>(out_ray); a.f.weights = nullptr; a.f.tile_T = nullptr;
+    a.f.out_ray = const_cast<float *>(out_ray); a.f.weights = nullptr; a.f.tile_T = nullptr; a.f.xstash = nullptr;
     a.f.B = B; a.f.S = S; a.f.T = T;
     a.f.contract_mode = cfg->contract_mode; a.f.infinity = cfg->infinity;
     for (int k = 0; k < 3; ++k) {
@@ -589,7 +601,8 @@ SCANERF_API int scanerf_render_backward(const float *rays_o, const float *rays_d
         a.f.bbox_size[k] = cfg->bbox_size[k];
         a.f.inv_size4[k] = 4.0f / cfg->bbox_size[k];
     }
-    a.grad_out = grad_out; a.tile_T = tile_T; a.dfeat = dfeat; a.dw_partial = dw_partial;
+    a.grad_out = grad_out; a.tile_T = tile_T; a.dfeat = dfeat; a.dw_partial = dw_partial; a.xstash = xstash;
+    { const char *e = getenv("SCANERF_DEBUG_BWD"); a.dbg = e ? atoi(e) : 0; }
     const int blocks = scanerf_render_backward_grid(B);
     const size_t lds_bytes = (size_t)kBwdLdsFloats * sizeof(float);
     hipStream_t st = (hipStream_t)stream;

@@ -110,6 +110,7 @@ struct RenderArgs {
     const uint8_t *ray_valid; // optional
     float *out_ray, *weights;
     float *tile_T;            // optional [B, ceil(S/32)]: transmittance entering each tile (for backward)
+    float *xstash;            // optional [B*S][2][16]: encoder outputs per (sample, half-wave) (for backward)
     int B, S, T;
     int contract_mode, infinity;
     float min_bbox[3], inv_size4[3];  // 4/bbox_size
@@ -119,7 +120,10 @@ struct RenderArgs {
 // hash-encode 8 levels of one sample: register 2j+f of half h holds feature f of level
 // 4(j>>1) + 2h + (j&1), i.e. input unit nmap(2j+f, h) = 2*level + f -- the same register<->unit
 // map as every other layer, and the layout in which the backward pass produces dL/dx.
-template <int DT>
+// GATHER_BATCH = levels whose 8 gathers each are in flight together: 2 keeps the forward kernel at
+// two waves per SIMD (128-register budget); 8 issues all 64 gathers of the lane at once -- one
+// memory latency instead of four -- for the one-wave-per-SIMD backward kernel.
+template <int DT, int GATHER_BATCH = 2>
 __device__ __forceinline__ void encode8(const RenderArgs &a, const int *lds_res, int h, const float p[3], v16f &x)
 {
     const uint32_t mask = (uint32_t)a.T - 1u;
@@ -148,7 +152,7 @@ __device__ __forceinline__ void encode8(const RenderArgs &a, const int *lds_res,
         }
         x[2 * j] = ax;
         x[2 * j + 1] = ay;
-        if (j & 1) __builtin_amdgcn_sched_barrier(0);  // at most 2 levels (16 gathers) in flight per lane
+        if ((j + 1) % GATHER_BATCH == 0) __builtin_amdgcn_sched_barrier(0);  // bound the gathers in flight per lane
     }
 }
 

@@ -38,7 +38,7 @@ def _cfg(min_bbox, bbox_size, contract_mode, infinity):
 
 
 def render_forward(rays_o, rays_d, z_vals, dists, features, resolutions, packed, min_bbox, bbox_size, contract_mode,
-                   infinity, ray_valid=None, want_weights=True, out_ray=None, weights=None, tile_T=None):
+                   infinity, ray_valid=None, want_weights=True, out_ray=None, weights=None, tile_T=None, xstash=None):
     """-> out_ray [B,16] (see column constants), weights [B,S] or None.
     min_bbox / bbox_size: host sequences of 3 floats (the HashGrid 2x box)."""
     B, S = z_vals.shape
@@ -56,13 +56,13 @@ def render_forward(rays_o, rays_d, z_vals, dists, features, resolutions, packed,
         dev_ptr(packed.workspace, _f32, "workspace"), ctypes.byref(cfg),
         dev_ptr(ray_valid, (torch.bool, torch.uint8), "ray_valid", allow_none=True), dev_ptr(out_ray, _f32, "out_ray"),
         dev_ptr(weights, _f32, "weights", allow_none=True), dev_ptr(tile_T, _f32, "tile_T", allow_none=True),
-        ctypes.c_int(B), ctypes.c_int(S),
+        dev_ptr(xstash, _f32, "xstash", allow_none=True), ctypes.c_int(B), ctypes.c_int(S),
         ctypes.c_int(features.shape[1]), stream()), "render_forward")
     return out_ray, weights
 
 
 def render_backward(rays_o, rays_d, z_vals, dists, features, resolutions, packed, weight_feature, min_bbox, bbox_size,
-                    contract_mode, infinity, out_ray, tile_T, grad_out, ray_valid=None, grad_blob=None):
+                    contract_mode, infinity, out_ray, tile_T, grad_out, ray_valid=None, grad_blob=None, xstash=None):
     """Adjoint of render_forward -> (dfeat [16, B*S, 2] level-major, grad_blob [13994])."""
     B, S = z_vals.shape
     dev = z_vals.device
@@ -79,7 +79,7 @@ def render_backward(rays_o, rays_d, z_vals, dists, features, resolutions, packed
         dev_ptr(packed.workspace, _f32, "workspace"), dev_ptr(weight_feature, _f32, "weight_feature"),
         ctypes.byref(cfg), dev_ptr(ray_valid, (torch.bool, torch.uint8), "ray_valid", allow_none=True),
         dev_ptr(out_ray, _f32, "out_ray"), dev_ptr(tile_T, _f32, "tile_T"), dev_ptr(grad_out, _f32, "grad_out"),
-        dev_ptr(dfeat, _f32, "dfeat"), dev_ptr(dw_partial, _f32, "dw_partial"), dev_ptr(grad_blob, _f32, "grad_blob"),
+        dev_ptr(xstash, _f32, "xstash", allow_none=True), dev_ptr(dfeat, _f32, "dfeat"), dev_ptr(dw_partial, _f32, "dw_partial"), dev_ptr(grad_blob, _f32, "grad_blob"),
         ctypes.c_int(B), ctypes.c_int(S), ctypes.c_int(features.shape[1]), stream()), "render_backward")
     return dfeat, grad_blob
 

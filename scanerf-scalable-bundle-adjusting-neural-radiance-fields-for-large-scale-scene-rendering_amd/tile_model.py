@@ -298,11 +298,12 @@ def train_step_fused(model, dec_opt, rays_o, rays_d, target, S, global_step, tab
         model.packed.pack(blob, wf)
         ntile = (S + 31) // 32
         tile_T = torch.empty((B, ntile), device=dev)
+        xstash = torch.empty((B * S, 32), device=dev)  # encoder outputs: 1 GB at 65 536 x 128, saves the re-gather
         box = (model.min_bbox.tolist(), model.bbox_size.tolist(), render.FORE, False)
         with _sec(timer, "render_forward", B * (24 + 20 + S * 16 * 8 * 2 * model.features.element_size()),
                   B * S * MLP_FLOPS_PER_SAMPLE):
             out, _ = render.render_forward(rays_o, rays_d, z, dist, model.features, model.resolution, model.packed, *box,
-                                           ray_valid=valid, want_weights=False, tile_T=tile_T)
+                                           ray_valid=valid, want_weights=False, tile_T=tile_T, xstash=xstash)
     # loss on the per-ray outputs (tiny torch graph on [B,16])
     leaf = out.detach().requires_grad_(True)
     nv = valid.sum()
@@ -312,7 +313,7 @@ def train_step_fused(model, dec_opt, rays_o, rays_d, target, S, global_step, tab
         # forward recompute + activation gradients + weight gradients = 3x the forward MLP FLOPs
         with _sec(timer, "render_backward", B * (24 + 20 + S * 16 * 8 * 2 * 4 + S * 16 * 8), 3 * B * S * MLP_FLOPS_PER_SAMPLE):
             dfeat, gblob = render.render_backward(rays_o, rays_d, z, dist, model.features, model.resolution, model.packed,
-                                                  wf, *box, out, tile_T, leaf.grad, ray_valid=valid)
+                                                  wf, *box, out, tile_T, leaf.grad, ray_valid=valid, xstash=xstash)
         pts = ((rays_o[:, None, :] + z[..., None] * rays_d[:, None, :]).reshape(-1, 3) - model._min_dev) \
             / model._size_dev * 4.0 - 2.0
         gtab = torch.zeros_like(model.features)

@@ -397,6 +397,11 @@ def test_render_backward_vs_oracle_autograd(S, bg, S_):
     gout = torch.zeros(B, 16, device=DEV)
     gout[:, 0:3], gout[:, 3], gout[:, 4], gout[:, 14] = g(g_rgb.numpy()), g(g_depth.numpy()[:, 0]), g(g_T.numpy()), g_l2
     dfeat, gblob = render.render_backward(g(o), g(d), g(z), g(dist), g(feat), R, pk, wf, *box, out, tile_T, gout)
+    # the x-stash variant (forward saves the encoder outputs, backward skips the re-gather) is bit-identical
+    xs = torch.empty(B * S_, 32, device=DEV)
+    out2, _ = render.render_forward(*args, *box, tile_T=tile_T, xstash=xs)
+    dfeat2, gblob2 = render.render_backward(g(o), g(d), g(z), g(dist), g(feat), R, pk, wf, *box, out2, tile_T, gout, xstash=xs)
+    assert torch.equal(out2, out) and torch.equal(dfeat2, dfeat) and torch.equal(gblob2, gblob)
     # decoder gradient
     gb = gblob.cpu().numpy()
     scale = np.abs(gblob_ref).max()

@@ -15,14 +15,15 @@ wf = network.weight_feature(5000, dev)
 m.packed.pack(m.decoder.blob(), wf)
 tile_T = torch.empty(B, 4, device=dev)
 box = (m.min_bbox.tolist(), m.bbox_size.tolist(), render.FORE, False)
-out, _ = render.render_forward(o, d, z, dist, m.features, m.resolution, m.packed, *box, want_weights=False, tile_T=tile_T)
+XS = torch.empty(B * S, 32, device=dev) if os.environ.get("XS", "1") == "1" else None
+out, _ = render.render_forward(o, d, z, dist, m.features, m.resolution, m.packed, *box, want_weights=False, tile_T=tile_T, xstash=XS)
 g = torch.randn(B, 16, device=dev)
 for _ in range(int(os.environ.get("N", 3))):
-    render.render_backward(o, d, z, dist, m.features, m.resolution, m.packed, wf, *box, out, tile_T, g)
+    render.render_backward(o, d, z, dist, m.features, m.resolution, m.packed, wf, *box, out, tile_T, g, xstash=XS)
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
 for _ in range(3):
-    render.render_backward(o, d, z, dist, m.features, m.resolution, m.packed, wf, *box, out, tile_T, g)
+    render.render_backward(o, d, z, dist, m.features, m.resolution, m.packed, wf, *box, out, tile_T, g, xstash=XS)
 e1.record(); torch.cuda.synchronize()
 print(f"render_backward {e0.elapsed_time(e1)/3:.2f} ms")
