@@ -13,6 +13,7 @@ Scope is the foreground branch on synthetic rays; data loading, warp/mono losses
 refinement and pruning schedules belong to the trainer.
 """
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -105,6 +106,7 @@ class TileModel(nn.Module):
         self._center_dev = self.bbox_center.to(device).contiguous()
         self._half_dev = (self.bbox_size / 2.0).to(device).contiguous()
         self.packed = render.PackedDecoder(device)
+        self._side_stream = torch.cuda.Stream(device=device) if str(device).startswith("cuda") else None
         # fused sparse Adam state for the table (cuda/adam_kernel.cu semantics)
         self.exp_avg = torch.zeros_like(self.features)
         self.exp_avg_sq = torch.zeros_like(self.features)
@@ -310,15 +312,41 @@ def train_step_fused(model, dec_opt, rays_o, rays_d, target, S, global_step, tab
     loss = F.mse_loss(leaf[:, 0:3][valid], target[valid]) + 0.01 * leaf[:, 14][valid].sum() / (3 * nv)
     loss.backward()
     with torch.no_grad():
-        # forward recompute + activation gradients + weight gradients = 3x the forward MLP FLOPs
-        with _sec(timer, "render_backward", B * (24 + 20 + S * 16 * 8 * 2 * 4 + S * 16 * 8), 3 * B * S * MLP_FLOPS_PER_SAMPLE):
-            dfeat, gblob = render.render_backward(rays_o, rays_d, z, dist, model.features, model.resolution, model.packed,
-                                                  wf, *box, out, tile_T, leaf.grad, ray_valid=valid, xstash=xstash)
-        pts = ((rays_o[:, None, :] + z[..., None] * rays_d[:, None, :]).reshape(-1, 3) - model._min_dev) \
-            / model._size_dev * 4.0 - 2.0
+        # Optional chunking (SCANERF_BWD_CHUNKS > 1): scatter of chunk c on a side stream underneath the
+        # backward of chunk c+1.  Measured on MI355X: no gain (24.2 vs 24.5 ms/step) -- the persistent
+        # backward workgroups hold 132 KB of LDS per CU, so the 32 KB accumulate workgroups cannot
+        # co-reside; default is one chunk.
+        chunks = max(1, min(int(os.environ.get("SCANERF_BWD_CHUNKS", "1")), B // 4096)) if B >= 8192 else 1
+        edges = [B * c // chunks for c in range(chunks + 1)]
+        main = torch.cuda.current_stream()
+        side = model._side_stream if chunks > 1 else main
         gtab = torch.zeros_like(model.features)
-        with _sec(timer, "table_grad_scatter", B * S * 16 * (8 + 16 * 8)):
-            render.scatter_table_grad(pts.contiguous(), dfeat, gtab, model.resolution)
+        gblob = torch.zeros(network.PARAMSIZE, device=dev)
+        keep = []
+        if chunks > 1:
+            side.wait_stream(main)
+        for c in range(chunks):
+            lo, hi = edges[c], edges[c + 1]
+            sl = slice(lo, hi)
+            n = hi - lo
+            # forward recompute + activation gradients + weight gradients = 3x the forward MLP FLOPs
+            with _sec(timer, "render_backward", n * (24 + 20 + S * 16 * 8 * 2 * 4 + S * 16 * 8), 3 * n * S * MLP_FLOPS_PER_SAMPLE):
+                dfeat, _ = render.render_backward(rays_o[sl], rays_d[sl], z[sl], dist[sl], model.features, model.resolution,
+                                                  model.packed, wf, *box, out[sl], tile_T[sl], leaf.grad[sl],
+                                                  ray_valid=valid[sl], grad_blob=gblob, xstash=xstash[lo * S:hi * S])
+            pts = ((rays_o[sl, None, :] + z[sl, :, None] * rays_d[sl, None, :]).reshape(-1, 3) - model._min_dev) \
+                / model._size_dev * 4.0 - 2.0
+            pts = pts.contiguous()
+            keep += [dfeat, pts]
+            if chunks > 1:
+                ev = torch.cuda.Event()
+                ev.record(main)
+                side.wait_event(ev)
+            with torch.cuda.stream(side):
+                with _sec(timer, "table_grad_scatter", n * S * 16 * (8 + 16 * 8)):
+                    render.scatter_table_grad(pts, dfeat, gtab, model.resolution)
+        if chunks > 1:
+            main.wait_stream(side)
         model.features.grad = gtab
         with _sec(timer, "sparse_adam", model.features.numel() * 28):
             model.table_adam(table_lr)
