@@ -1,0 +1,129 @@
+"""Multi-tile novel-view renderer: the build's counterpart of RenderingHashGrid's render path
+(rendering.py:93-174 parse_blocks, :286-544 render_rays_base) on the HIP render-time ops, plus the
+tile export / load formats it consumes (hashgrid/__init__.py:248-257 feature.npz, tile.py:516-529).
+
+Per view: compute_ray_forward -> ray_block_intersection -> argsort(near) -> per tracing step
+{sample_points -> prepare_points -> pts_inference -> accumulate_color} -> update_outgoing_bidx ->
+per blended background {inverse_z_sampling -> bg_pts_inference_v2 -> accumulate_color} -> merge.
+"""
+import os
+
+import numpy as np
+import torch
+
+from . import network
+from .cuda import compute_ray_forward
+from .hashgrid import (accumulate_color, bg_pts_inference_v2, inverse_z_sampling, prepare_points, process_occupied_grid,
+                       pts_inference, ray_block_intersection, sample_points, update_outgoing_bidx)
+
+
+def export_tile(path, model):
+    """feature.npz (fp16 table, occupancy, 2x-box corner/size, log2dim, resolution) + decoder.pth
+    (state dict with the reference's ShallowMLP key names)."""
+    os.makedirs(path, exist_ok=True)
+    np.savez(os.path.join(path, "feature.npz"), features=model.features.detach().cpu().numpy().astype(np.float16),
+             occupied_grid=model.occupied_grid.cpu().numpy(), block_corner=model.min_bbox.cpu().numpy(),
+             block_size=model.bbox_size.cpu().numpy(), grid_log2dim=model.log2dim.cpu().numpy(),
+             resolution=model.resolution.cpu().numpy())
+    torch.save({k: v.detach().cpu() for k, v in model.decoder.ref_state_dict().items()}, os.path.join(path, "decoder.pth"))
+
+
+def load_tile(path):
+    f = np.load(os.path.join(path, "feature.npz"))
+    sd = torch.load(os.path.join(path, "decoder.pth"), map_location="cpu")
+    return {"features": f["features"], "occupied_grid": f["occupied_grid"], "block_corner": f["block_corner"],
+            "block_size": f["block_size"], "grid_log2dim": f["grid_log2dim"], "resolution": f["resolution"],
+            "blob": network.blob_from_state_dict(sd).numpy()}
+
+
+class TileSetRenderer:
+    def __init__(self, device, tiles):
+        """tiles: dicts as returned by load_tile (block_corner / block_size describe the 2x HashGrid box;
+        the renderer works on the inner tile box: rendering.py:164-165)."""
+        self.device = device
+        t = lambda a, dt: torch.as_tensor(np.ascontiguousarray(a), dtype=dt).to(device).contiguous()
+        self.feature_tables = t(np.stack([x["features"] for x in tiles]), torch.float16)
+        self.params = t(np.stack([x["blob"] for x in tiles]), torch.float32)
+        self.resolution = t(np.stack([x["resolution"] for x in tiles]), torch.int32)
+        self.grid_log2dim = t(np.stack([x["grid_log2dim"] for x in tiles]), torch.int32)
+        grids = [np.asarray(x["occupied_grid"]).reshape(-1) for x in tiles]
+        self.grid_starts = t(np.cumsum([0] + [g.size for g in grids[:-1]]), torch.int64)
+        self.occupied_grid = t(np.concatenate(grids), torch.bool)
+        corner = t(np.stack([x["block_corner"] for x in tiles]), torch.float32)
+        size = t(np.stack([x["block_size"] for x in tiles]), torch.float32)
+        self.block_corner = (corner + size / 4.0).contiguous()
+        self.block_size = (size / 2.0).contiguous()
+        # sampling grid: each tile's occupancy dilated into the tiles it overlaps (rendering.py:168-173)
+        self.fake_occupied_grid = self.occupied_grid.clone()
+        for i in range(len(tiles)):
+            process_occupied_grid(i, int(torch.prod(2 ** self.grid_log2dim[i]).cpu()), self.block_corner, self.block_size,
+                                  self.occupied_grid, self.grid_starts, self.grid_log2dim, self.fake_occupied_grid)
+
+    def compute_rays(self, H, W, K, c2w):
+        """Pixel-centre rays of one view (rendering.py:272-284) through the HIP ray kernel."""
+        dev = self.device
+        j, i = torch.meshgrid(torch.arange(H, device=dev), torch.arange(W, device=dev), indexing="ij")
+        locs = torch.stack([torch.zeros_like(i), i, j], -1).reshape(-1, 3).int().contiguous()
+        o = torch.empty(H * W, 3, device=dev)
+        d = torch.empty(H * W, 3, device=dev)
+        compute_ray_forward(o, d, torch.as_tensor(K, dtype=torch.float32, device=dev).reshape(1, 9).contiguous(),
+                            torch.as_tensor(c2w, dtype=torch.float32, device=dev)[:3, :4].reshape(1, 12).contiguous(), locs)
+        return o, d
+
+    @torch.no_grad()
+    def render_rays(self, rays_o, rays_d, num_sample=128, num_bg_sample=128, sample_range=1e6):
+        dev, B, nb = self.device, rays_o.shape[0], self.block_corner.shape[0]
+        inter = torch.full((B, nb, 2), 1e7, device=dev)
+        ray_block_intersection(rays_o, rays_d, self.block_corner, self.block_size, inter)
+        tracing_blocks = torch.argsort(inter[..., 0], dim=-1, stable=True).int().contiguous()
+        max_tracing = int(torch.mean((inter != 1e7).float(), dim=-1).sum(dim=-1).max().cpu())
+        transp = torch.ones(B, 1, device=dev)
+        dif, spec, depth = torch.zeros(B, 3, device=dev), torch.zeros(B, 3, device=dev), torch.zeros(B, 1, device=dev)
+        tracing_idx = torch.zeros(B, 1, dtype=torch.int32, device=dev)
+        z_start = torch.zeros(B, 1, device=dev)
+        pd = torch.empty(B, num_sample, 3, device=dev)
+        ps = torch.empty(B, num_sample, 3, device=dev)
+        pa = torch.empty(B, num_sample, 1, device=dev)
+        for _ in range(max_tracing):
+            running = ((tracing_idx < max_tracing) & (transp > 1e-5))[:, 0].contiguous()
+            if running.sum() == 0:
+                break
+            z = torch.full((B, num_sample), -1.0, device=dev)
+            dd = torch.full((B, num_sample), -1.0, device=dev)
+            sample_points(rays_o, rays_d, self.block_corner, self.block_size, self.fake_occupied_grid, self.grid_starts,
+                          self.grid_log2dim, tracing_blocks, inter, tracing_idx, z_start, z, dd)
+            bi = torch.full((B, num_sample, 4), -1, dtype=torch.int16, device=dev)
+            prepare_points(z, running, inter, bi)
+            pts_inference(rays_o, rays_d, z, dd, bi, self.feature_tables, self.params, self.resolution, self.occupied_grid,
+                          self.grid_starts, self.grid_log2dim, self.block_corner, self.block_size, pd, ps, pa)
+            accumulate_color(pd, ps, pa, transp, z, dif, spec, depth)
+        # blended backgrounds of the exit tile(s)
+        bg_b = torch.full((B, 4), -1, dtype=torch.int16, device=dev)
+        bg_w = torch.zeros(B, 4, device=dev)
+        update_outgoing_bidx(rays_o, rays_d, self.block_corner, self.block_size, tracing_blocks, inter, bg_b, bg_w, 0.12, False)
+        bg_w = bg_w / torch.sum(bg_w, dim=-1, keepdim=True)
+        n_blend = int((bg_w > 0).sum(dim=-1).max().cpu())
+        bgd, bgs, bgz = torch.zeros(B, 3, device=dev), torch.zeros(B, 3, device=dev), torch.zeros(B, 1, device=dev)
+        if num_bg_sample != num_sample:
+            pd = torch.empty(B, num_bg_sample, 3, device=dev)
+            ps = torch.empty(B, num_bg_sample, 3, device=dev)
+            pa = torch.empty(B, num_bg_sample, 1, device=dev)
+        for i in range(n_blend):
+            zb = torch.full((B, num_bg_sample), -1.0, device=dev)
+            inverse_z_sampling(inter, bg_b[:, i].contiguous(), zb, sample_range)
+            pd.zero_(), ps.zero_(), pa.zero_()
+            bg_pts_inference_v2(rays_o, rays_d, zb, bg_b, i, self.block_corner, self.block_size, self.resolution,
+                                self.feature_tables, self.params, pd, ps, pa)
+            t1 = torch.ones(B, 1, device=dev)
+            td, ts, tz = torch.zeros(B, 3, device=dev), torch.zeros(B, 3, device=dev), torch.zeros(B, 1, device=dev)
+            accumulate_color(pd, ps, pa, t1, zb, td, ts, tz)
+            w = torch.nan_to_num(bg_w[:, i:i + 1])  # rays with no exit tile: 0/0 in the reference's normalisation
+            bgd += td * w
+            bgs += ts * w
+            bgz += tz * w
+        return dif + transp * bgd, spec + transp * bgs, depth + transp * bgz, transp
+
+    def render(self, H, W, K, c2w, **kw):
+        o, d = self.compute_rays(H, W, K, c2w)
+        dif, spec, depth, transp = self.render_rays(o, d, **kw)
+        return dif.reshape(H, W, 3), spec.reshape(H, W, 3), depth.reshape(H, W, 1), transp.reshape(H, W, 1)

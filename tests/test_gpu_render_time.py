@@ -158,3 +158,69 @@ def test_process_occupied_grid_and_firsthit_and_sort():
     starts = torch.arange(6, dtype=torch.int32, device=DEV)
     n = H.sort_by_key(keys, vals, starts)
     assert n == 3 and keys[:3].tolist() == [1, 2, 3] and starts[:3].tolist() == [0, 3, 4]
+
+
+def test_renderer_end_to_end_and_tile_formats(tmp_path):
+    """f2/f3: export two trained-tile directories (feature.npz + decoder.pth), load them into the multi-tile
+    renderer, render a small view and compare the image with the oracle driven through the same loop."""
+    import scanerf_amd  # noqa
+    from scanerf_amd import renderer as R
+    from scanerf_amd.tile_model import TileModel
+    rng = np.random.default_rng(23)
+    tiles = []
+    for b, cx in enumerate((-4.0, 2.0)):  # tiles [-4,4]x.. and [2,10]x..: 2 m overlap in x
+        m = TileModel([cx, -4, -4], [8, 8, 8], DEV, log2_T=10, seed=30 + b, sampler_log2dim=4)
+        with torch.no_grad():
+            m.features.mul_(60.0)
+            m.decoder.sigma_layer_mlp_0_bias.add_(3.0)
+        m.occupied_grid = g(rng.random((16, 16, 16)) < 0.4)
+        R.export_tile(str(tmp_path / f"tile{b}"), m)
+        tiles.append(R.load_tile(str(tmp_path / f"tile{b}")))
+    assert tiles[0]["features"].dtype == np.float16 and tiles[0]["blob"].shape == (13994,)
+    rnd = R.TileSetRenderer(DEV, tiles)
+    H, W = 20, 28
+    K = np.float32([[30, 0, 14], [0, 30, 10], [0, 0, 1]])
+    c2w = np.float32([[0, 0, 1, -9], [0, 1, 0, 0.3], [-1, 0, 0, 0.2]])  # looking down +x from x = -9
+    dif, spec, depth, transp = rnd.render(H, W, K, c2w, num_sample=64, num_bg_sample=32)
+    # ---- the same loop on the oracle
+    o, d = (t.cpu().numpy() for t in rnd.compute_rays(H, W, K, c2w))
+    o_ref, d_ref = O.compute_ray_forward(np.stack([np.zeros(H * W), np.tile(np.arange(W), H), np.repeat(np.arange(H), W)], 1),
+                                         K.reshape(1, 9), c2w.reshape(1, 12))
+    assert np.array_equal(o, o_ref) and np.array_equal(d, d_ref)
+    corners, sizes = rnd.block_corner.cpu().numpy(), rnd.block_size.cpu().numpy()
+    occ, fake = rnd.occupied_grid.cpu().numpy(), rnd.fake_occupied_grid.cpu().numpy()
+    starts, l2d = rnd.grid_starts.cpu().numpy(), rnd.grid_log2dim.cpu().numpy()
+    tabs, par, res = rnd.feature_tables.cpu().numpy(), rnd.params.cpu().numpy(), rnd.resolution.cpu().numpy()
+    B = H * W
+    inter = O.ray_block_intersection(o, d, corners, sizes)
+    tb = np.argsort(inter[..., 0], axis=-1, kind="stable").astype(np.int32)
+    max_tracing = int((inter != 1e7).astype(np.float32).mean(-1).sum(-1).max())
+    T_, dF, sF, zF = np.ones((B, 1), np.float32), np.zeros((B, 3), np.float32), np.zeros((B, 3), np.float32), np.zeros((B, 1), np.float32)
+    ti, zs = np.zeros(B, np.int32), np.zeros(B, np.float32)
+    for _ in range(max_tracing):
+        running = (ti < max_tracing) & (T_[:, 0] > 1e-5)
+        if running.sum() == 0:
+            break
+        z, dd = O.render_sample_points(o, d, corners, sizes, fake, starts, l2d, 64, tb, inter, ti, zs)
+        bi = O.prepare_points(z, running, inter)
+        pd, ps, pa = O.pts_inference(o, d, z, dd, bi, tabs, par, res, occ, starts, l2d, corners, sizes)
+        O.accumulate_color(pd, ps, pa, T_, z, dF, sF, zF)
+    ob, bw = O.update_outgoing_bidx(o, d, corners, sizes, tb, inter, 0.12, False)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        bwn = np.nan_to_num(bw / bw.sum(-1, keepdims=True))
+    bd, bs, bz = np.zeros((B, 3), np.float32), np.zeros((B, 3), np.float32), np.zeros((B, 1), np.float32)
+    for i in range(int((bwn > 0).sum(-1).max())):
+        zb = O.render_inverse_z_sampling(inter, ob[:, i], 32, 1e6)
+        pd, ps, pa = O.bg_pts_inference_v2(o, d, zb, ob, i, corners, sizes, res, tabs, par)
+        t1, td, ts, tz = np.ones((B, 1), np.float32), np.zeros((B, 3), np.float32), np.zeros((B, 3), np.float32), np.zeros((B, 1), np.float32)
+        O.accumulate_color(pd, ps, pa, t1, zb, td, ts, tz)
+        bd += td * bwn[:, i:i + 1]; bs += ts * bwn[:, i:i + 1]; bz += tz * bwn[:, i:i + 1]
+    ref = {"dif": dF + T_ * bd, "spec": sF + T_ * bs, "depth": zF + T_ * bz, "T": T_}
+    assert ref["T"].min() < 0.5 < ref["T"].max(), "view must contain both opaque and empty pixels"
+    np.testing.assert_allclose(transp.cpu().numpy().reshape(B, 1), ref["T"], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(dif.cpu().numpy().reshape(B, 3), ref["dif"], rtol=1e-4, atol=3e-6)
+    np.testing.assert_allclose(spec.cpu().numpy().reshape(B, 3), ref["spec"], rtol=1e-4, atol=3e-6)
+    np.testing.assert_allclose(depth.cpu().numpy().reshape(B, 1), ref["depth"], rtol=1e-4, atol=1e-3)
+    img_a = np.clip((dif + spec).cpu().numpy(), 0, 1) * 255
+    img_b = np.clip(ref["dif"] + ref["spec"], 0, 1).reshape(H, W, 3) * 255
+    assert O.psnr(img_a, img_b) > 80.0  # tools/utils.py:53-55 PSNR of the HIP render vs the oracle render
