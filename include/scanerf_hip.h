@@ -169,7 +169,15 @@ int scanerf_render_backward(const float *rays_o, const float *rays_d, const floa
                             const scanerf_render_cfg *cfg /*[host]*/, const uint8_t *ray_valid,
                             const float *out_ray, const float *tile_T, const float *grad_out,
                             const float *xstash /* forward's, or NULL */, float *dfeat, float *dw_partial,
-                            float *grad_blob, int B, int S, int T, scanerf_stream_t stream);
+                            float *grad_blob, float *g_dnorm /* [B,ceil(S/32)] or NULL */,
+                            float *g_rowsum /* [B,2,64] or NULL */, int B, int S, int T, scanerf_stream_t stream);
+/* For pose refinement (gradients w.r.t. the rays): g_dnorm = per-tile partials of dL/d|rays_d| through
+ * delta = dist*|d| (hashgrid/__init__.py:347); g_rowsum = per-ray sums of dL/d(Directional_MLP.mlp.0
+ * pre-activation) in two partial rows (their sum times W[:,32:48] is dL/dSH(viewdir)).  The gradient
+ * through the sample positions comes from scanerf_embedding_bg_point_grad on dfeat. */
+int scanerf_embedding_bg_point_grad(const float *points, const float *dfeat_level_major, float *grad_points,
+                                    const float *features, const int32_t *resolutions, int N, int L, int T,
+                                    scanerf_stream_t stream);
 
 /* Encoder with an explicit mapping (for benchmarks and the two-kernel path):
  * variant 0 auto / 1 XCD-partitioned by level / 2 level-fastest; level_major_out != 0 writes

@@ -122,7 +122,7 @@ __global__ void __launch_bounds__(256) k_embed_fwd_lf(const float *__restrict__ 
 
 // ---- backward, level-fastest ----------------------------------------------------------
 // LP = L rounded up to a power of two (<= 64): the lanes of one point form an aligned group.
-template <bool BOX, int LP>
+template <bool BOX, int LP, bool GRAD_LM = false>
 __global__ void __launch_bounds__(256) k_embed_bwd(const float *__restrict__ points, const float2 *__restrict__ grad_in,
                                                    float *__restrict__ grad_points, float *__restrict__ grad_features,
                                                    const float *__restrict__ features,
@@ -152,7 +152,7 @@ __global__ void __launch_bounds__(256) k_embed_bwd(const float *__restrict__ poi
             float w[8];
             corner_indices(idx, b[0], b[1], b[2], mask);
             trilinear_weights(w, t[0], t[1], t[2]);
-            const float2 g = grad_in[(size_t)i * L + level];
+            const float2 g = GRAD_LM ? grad_in[(size_t)level * N + i] : grad_in[(size_t)i * L + level];
             if (grad_features) {
                 float *gs = grad_features + (size_t)level * T * 2;
 #pragma unroll
@@ -301,6 +301,22 @@ SCANERF_API int scanerf_embedding_bg_backward(const float *points, const float *
     SCANERF_REQUIRE(points && grad_in && features && resolutions, "embedding_bg_backward: null pointer");
     return launch_bwd<false>(points, grad_in, grad_points, grad_features, features, resolutions,
                              BoxArgs{ nullptr, nullptr }, N, L, T, (hipStream_t)stream);
+}
+
+// dL/d(points) only, from a LEVEL-MAJOR feature gradient [L][N][2] (the fused backward's dfeat).
+SCANERF_API int scanerf_embedding_bg_point_grad(const float *points, const float *dfeat_level_major, float *grad_points,
+                                                const float *features, const int32_t *resolutions, int N, int L, int T,
+                                                scanerf_stream_t stream)
+{
+    if (int e = check_common("embedding_bg_point_grad", N, L, T)) return e;
+    if (N == 0) return 0;
+    SCANERF_REQUIRE(points && dfeat_level_major && grad_points && features && resolutions, "embedding_bg_point_grad: null pointer");
+    SCANERF_REQUIRE(L == 16, "embedding_bg_point_grad: L=%d (the fused path has 16 levels)", L);
+    dim3 grid(stream_grid((int64_t)N * 16, 256)), block(256);
+    hipLaunchKernelGGL((k_embed_bwd<false, 16, true>), grid, block, 0, (hipStream_t)stream, points,
+                       reinterpret_cast<const float2 *>(dfeat_level_major), grad_points, (float *)nullptr, features,
+                       resolutions, BoxArgs{ nullptr, nullptr }, N, L, T);
+    return check_launch("embedding_bg_point_grad");
 }
 
 SCANERF_API int scanerf_embedding_forward(const float *points, float *outputs, const float *features,

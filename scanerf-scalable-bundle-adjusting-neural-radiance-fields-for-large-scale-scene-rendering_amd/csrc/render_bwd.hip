@@ -44,6 +44,8 @@ struct BwdArgs {
     float *dfeat;              // [16][B*S][2]
     float *dw_partial;         // [nwaves][SCANERF_PARAMSIZE], zero-filled by the host wrapper
     const float *xstash;       // optional [B*S][2][16]: the forward's encoder outputs (skips the re-gather)
+    float *g_dnorm;            // optional [B, ntiles]: dL/d|d| partials (through delta = dist*|d|)
+    float *g_rowsum;           // optional [B, 2, 64]: sum_s dL/d(dir layer-0 pre-activation), for dL/dSH
     int dbg;                   // timing experiments only (SCANERF_DEBUG_BWD): 1 = forward recompute only, 2 = no dW
 };
 
@@ -175,6 +177,7 @@ __global__ void __launch_bounds__(kBwdThreads, 1) k_render_bwd(BwdArgs a)
         const float *go = a.grad_out + (size_t)ray * SCANERF_RAY_OUT;  // dL/d(out_ray) of this ray
         const float *fo = a.f.out_ray + (size_t)ray * SCANERF_RAY_OUT;   // the forward outputs
         float Rcarry = 0.0f;  // sum of a_j w_j over all later tile groups
+        float ray_rowsum = 0.0f;  // this wave's rows (32*rb2 + lane) of sum_s dv0, over its tile pair, all groups
 
         for (int grp = ngroups - 1; grp >= 0; --grp) {
             // Lane-derived LDS / global addresses are recomputed per tile group: hoisted to kernel entry
@@ -324,6 +327,12 @@ __global__ void __launch_bounds__(kBwdThreads, 1) k_render_bwd(BwdArgs a)
             float dalpha = Ti * ai - (suffix + ((s < S - 1) ? gTl * Tl : 0.0f)) / fi;
             if (!live) dalpha = 0.0f;
             const float dsigma = dalpha * delta * ex;
+            if (a.g_dnorm && tile < ntiles) {
+                // d(delta)/d|d| = dist (the infinity sample's delta is the constant 1e10)
+                const float dist_i = (live && !(a.f.infinity && s == S - 1)) ? a.f.dists[(size_t)ray * S + s] : 0.0f;
+                const float gd = half_sum(dalpha * sigma * ex * dist_i);
+                if (lane == 0) a.g_dnorm[(size_t)ray * ntiles + tile] = gd;
+            }
             float gh[7], gs3[3];  // gradients w.r.t. the head pre-activations
             gh[0] = dsigma * dsig_dpre;
 #pragma unroll
@@ -421,6 +430,7 @@ __global__ void __launch_bounds__(kBwdThreads, 1) k_render_bwd(BwdArgs a)
                 }
                 gB_D0 += rsum;
                 rsum += __shfl_xor(rsum, 32, 64);  // both halves of the samples
+                ray_rowsum += rsum;
                 float shl[16];
                 ray_sh(d, opaque1(dnorm), shl);
 #pragma unroll
@@ -503,6 +513,7 @@ __global__ void __launch_bounds__(kBwdThreads, 1) k_render_bwd(BwdArgs a)
             }
             // (the next group's B1 orders this group's stage reads before the next writes)
         }
+        if (a.g_rowsum && (lane_k >> 5) == 0) a.g_rowsum[((size_t)ray * 2 + tp) * 64 + 32 * rb2 + (lane_k & 31)] = ray_rowsum;
     }
 
     // ---- flush this wave's partial sums in blob order (dw_partial is zero-filled: only owned entries are written)
@@ -580,7 +591,8 @@ SCANERF_API int scanerf_render_backward(const float *rays_o, const float *rays_d
                                         const float *workspace, const float *weight_feature,
                                         const scanerf_render_cfg *cfg, const uint8_t *ray_valid, const float *out_ray,
                                         const float *tile_T, const float *grad_out, const float *xstash, float *dfeat,
-                                        float *dw_partial, float *grad_blob, int B, int S, int T, scanerf_stream_t stream)
+                                        float *dw_partial, float *grad_blob, float *g_dnorm, float *g_rowsum, int B, int S,
+                                        int T, scanerf_stream_t stream)
 {
     SCANERF_REQUIRE(B >= 0 && S >= 1, "render_backward: B=%d S=%d", B, S);
     SCANERF_REQUIRE(T >= 2 && (T & (T - 1)) == 0, "render_backward: T=%d must be a power of two", T);
@@ -602,6 +614,7 @@ SCANERF_API int scanerf_render_backward(const float *rays_o, const float *rays_d
         a.f.inv_size4[k] = 4.0f / cfg->bbox_size[k];
     }
     a.grad_out = grad_out; a.tile_T = tile_T; a.dfeat = dfeat; a.dw_partial = dw_partial; a.xstash = xstash;
+    a.g_dnorm = g_dnorm; a.g_rowsum = g_rowsum;
     { const char *e = getenv("SCANERF_DEBUG_BWD"); a.dbg = e ? atoi(e) : 0; }
     const int blocks = scanerf_render_backward_grid(B);
     const size_t lds_bytes = (size_t)kBwdLdsFloats * sizeof(float);

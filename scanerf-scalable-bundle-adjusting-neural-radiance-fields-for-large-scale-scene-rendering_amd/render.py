@@ -62,7 +62,8 @@ def render_forward(rays_o, rays_d, z_vals, dists, features, resolutions, packed,
 
 
 def render_backward(rays_o, rays_d, z_vals, dists, features, resolutions, packed, weight_feature, min_bbox, bbox_size,
-                    contract_mode, infinity, out_ray, tile_T, grad_out, ray_valid=None, grad_blob=None, xstash=None):
+                    contract_mode, infinity, out_ray, tile_T, grad_out, ray_valid=None, grad_blob=None, xstash=None,
+                    ray_grad_buffers=None):
     """Adjoint of render_forward -> (dfeat [16, B*S, 2] level-major, grad_blob [13994])."""
     B, S = z_vals.shape
     dev = z_vals.device
@@ -80,6 +81,8 @@ def render_backward(rays_o, rays_d, z_vals, dists, features, resolutions, packed
         ctypes.byref(cfg), dev_ptr(ray_valid, (torch.bool, torch.uint8), "ray_valid", allow_none=True),
         dev_ptr(out_ray, _f32, "out_ray"), dev_ptr(tile_T, _f32, "tile_T"), dev_ptr(grad_out, _f32, "grad_out"),
         dev_ptr(xstash, _f32, "xstash", allow_none=True), dev_ptr(dfeat, _f32, "dfeat"), dev_ptr(dw_partial, _f32, "dw_partial"), dev_ptr(grad_blob, _f32, "grad_blob"),
+        dev_ptr(ray_grad_buffers[0] if ray_grad_buffers else None, _f32, "g_dnorm", allow_none=True),
+        dev_ptr(ray_grad_buffers[1] if ray_grad_buffers else None, _f32, "g_rowsum", allow_none=True),
         ctypes.c_int(B), ctypes.c_int(S), ctypes.c_int(features.shape[1]), stream()), "render_backward")
     return dfeat, grad_blob
 
@@ -96,3 +99,40 @@ def scatter_table_grad(points, dfeat, grad_features, resolutions):
         dev_ptr(resolutions, torch.int32, "resolutions"), ctypes.c_int(N), ctypes.c_int(L), ctypes.c_int(T),
         ctypes.c_int(1), ctypes.c_void_p(ws.data_ptr()), ctypes.c_size_t(ws.numel()), stream()), "scatter_table_grad")
     return grad_features
+
+
+def ray_gradients(rays_o, rays_d, z_vals, features, resolutions, blob, min_bbox, bbox_size, contract_mode, dfeat,
+                  g_dnorm, g_rowsum, ray_valid=None):
+    """dL/d(rays_o), dL/d(rays_d) of a fused render (for pose refinement: tile.py trains se3_refine through
+    the rays).  Three paths: the sample positions (hash-encoder point gradient kernel on dfeat, then the
+    contraction's Jacobian by torch autograd), |d| through delta = dist*|d|, and SH(d/|d|) of the decoder."""
+    from . import tile_model
+    B, S = z_vals.shape
+    dev = z_vals.device
+    mn = torch.as_tensor(min_bbox, dtype=_f32, device=dev)
+    sz = torch.as_tensor(bbox_size, dtype=_f32, device=dev)
+    o = rays_o.detach().clone().requires_grad_(True)
+    d = rays_d.detach().clone().requires_grad_(True)
+    with torch.enable_grad():
+        x = ((o[:, None, :] + z_vals[..., None] * d[:, None, :]).reshape(-1, 3) - mn) / sz * 4.0 - 2.0
+        if contract_mode == BG:
+            linf = torch.max(torch.abs(x), dim=-1, keepdim=True)[0]
+            x = x * ((2 - 1.0 / linf) / linf)
+        dn = d.norm(2, dim=-1, keepdim=True)
+        sh = tile_model.sh3(d / (dn + 1e-8))
+    gp = torch.zeros(B * S, 3, dtype=_f32, device=dev)
+    xd = x.detach().contiguous()
+    check(lib().scanerf_embedding_bg_point_grad(dev_ptr(xd, _f32, "points"), dev_ptr(dfeat, _f32, "dfeat"),
+                                                dev_ptr(gp, _f32, "grad_points"), dev_ptr(features, _f32, "features"),
+                                                dev_ptr(resolutions, torch.int32, "resolutions"), ctypes.c_int(B * S),
+                                                ctypes.c_int(16), ctypes.c_int(features.shape[1]), stream()),
+          "embedding_bg_point_grad")
+    w_sh = blob[6503 + 64 + 32 * 64: 6503 + 64 + 48 * 64].reshape(16, 64)  # Directional_MLP.mlp.0 weight^T rows 32..47
+    g_sh = g_rowsum.sum(1) @ w_sh.t()
+    g_dn = g_dnorm.sum(1, keepdim=True)
+    if ray_valid is not None:
+        keep = ray_valid[:, None].to(_f32)
+        gp = gp * keep.repeat_interleave(S, dim=0)
+        g_sh, g_dn = g_sh * keep, g_dn * keep
+    torch.autograd.backward([x, sh, dn], [gp, g_sh, g_dn])
+    return o.grad, d.grad

@@ -286,9 +286,12 @@ def train_step_ops(model, dec_opt, rays_o, rays_d, target, S, global_step, table
     return loss.detach()
 
 
-def train_step_fused(model, dec_opt, rays_o, rays_d, target, S, global_step, table_lr=1e-2, timer=None):
+def train_step_fused(model, dec_opt, rays_o, rays_d, target, S, global_step, table_lr=1e-2, timer=None,
+                     pose_grads=False):
     """The same iteration as train_step_ops on the fused kernels: one launch for the render forward,
-    one for its adjoint, the atomic-free binned scatter for the table gradient, fused sparse Adam."""
+    one for its adjoint, the atomic-free binned scatter for the table gradient, fused sparse Adam.
+    pose_grads=True also returns dL/d(rays_o), dL/d(rays_d) (feed them to the pose graph:
+    torch.autograd.backward([rays_o, rays_d], [g_o, g_d]) -- camera_utils.py:65-84 in the reference)."""
     B = rays_o.shape[0]
     dev = model.device
     with torch.no_grad():
@@ -322,6 +325,8 @@ def train_step_fused(model, dec_opt, rays_o, rays_d, target, S, global_step, tab
         side = model._side_stream if chunks > 1 else main
         gtab = torch.zeros_like(model.features)
         gblob = torch.zeros(network.PARAMSIZE, device=dev)
+        ray_bufs = (torch.zeros(B, ntile, device=dev), torch.zeros(B, 2, 64, device=dev)) if pose_grads else None
+        g_o = g_d = None
         keep = []
         if chunks > 1:
             side.wait_stream(main)
@@ -333,7 +338,14 @@ def train_step_fused(model, dec_opt, rays_o, rays_d, target, S, global_step, tab
             with _sec(timer, "render_backward", n * (24 + 20 + S * 16 * 8 * 2 * 4 + S * 16 * 8), 3 * n * S * MLP_FLOPS_PER_SAMPLE):
                 dfeat, _ = render.render_backward(rays_o[sl], rays_d[sl], z[sl], dist[sl], model.features, model.resolution,
                                                   model.packed, wf, *box, out[sl], tile_T[sl], leaf.grad[sl],
-                                                  ray_valid=valid[sl], grad_blob=gblob, xstash=xstash[lo * S:hi * S])
+                                                  ray_valid=valid[sl], grad_blob=gblob, xstash=xstash[lo * S:hi * S],
+                                                  ray_grad_buffers=(ray_bufs[0][sl], ray_bufs[1][sl]) if pose_grads else None)
+            if pose_grads:
+                go_c, gd_c = render.ray_gradients(rays_o[sl], rays_d[sl], z[sl], model.features, model.resolution, blob,
+                                                  box[0], box[1], box[2], dfeat, ray_bufs[0][sl], ray_bufs[1][sl],
+                                                  ray_valid=valid[sl])
+                g_o = go_c if g_o is None else torch.cat([g_o, go_c])
+                g_d = gd_c if g_d is None else torch.cat([g_d, gd_c])
             pts = ((rays_o[sl, None, :] + z[sl, :, None] * rays_d[sl, None, :]).reshape(-1, 3) - model._min_dev) \
                 / model._size_dev * 4.0 - 2.0
             pts = pts.contiguous()
@@ -354,4 +366,4 @@ def train_step_fused(model, dec_opt, rays_o, rays_d, target, S, global_step, tab
             name, kind = k.rsplit(".", 1)
             getattr(model.decoder, name.replace(".", "_") + "_" + kind).grad = v.contiguous()
         dec_opt.step()
-    return loss.detach()
+    return (loss.detach(), g_o, g_d) if pose_grads else loss.detach()
