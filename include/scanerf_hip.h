@@ -159,7 +159,15 @@ int scanerf_render_forward_packed(const float *rays_o, const float *rays_d, cons
  *   the sum_w_spec2 column is differentiated with the weights detached, as the reference's
  *   l2_reg_specular, hashgrid/__init__.py:593);
  *   dfeat [16][B*S][2] f32 (out): dL/d(hash features), level-major -> feed to
- *   scanerf_embedding_bg_backward_binned(grad_layout = 1) with the contracted sample points;
+ *   scanerf_embedding_bg_backward_binned(grad_layout = 1) with the contracted sample points; may be
+ *   NULL when scatter_ws is given;
+ *   scatter_ws / scatter_ws_bytes / grad_features (may be NULL/0/NULL): FUSED table-gradient path.  The
+ *   kernel then appends the scatter records itself (no dfeat round trip, no separate producer pass):
+ *     scanerf_render_scatter_plan(...)        -- before: reserves each workgroup's record ranges
+ *     scanerf_render_backward(..., ws, ...)   -- emits
+ *     scanerf_render_scatter_accumulate(...)  -- after: grad_features [16][T][2] += records
+ *   all three on the same (B, S, T), rays, z_vals, cfg, ray_valid and stream; grad_features is written
+ *   by the backward only if the workspace overflows;
  *   dw_partial [4*scanerf_render_backward_grid(B)][13994] f32 scratch;
  *   grad_blob [13994] f32: dL/d(decoder blob), ACCUMULATED into (deterministic reduction). */
 int scanerf_render_backward_grid(int B);
@@ -170,7 +178,17 @@ int scanerf_render_backward(const float *rays_o, const float *rays_d, const floa
                             const float *out_ray, const float *tile_T, const float *grad_out,
                             const float *xstash /* forward's, or NULL */, float *dfeat, float *dw_partial,
                             float *grad_blob, float *g_dnorm /* [B,ceil(S/32)] or NULL */,
-                            float *g_rowsum /* [B,2,64] or NULL */, int B, int S, int T, scanerf_stream_t stream);
+                            float *g_rowsum /* [B,2,64] or NULL */, void *scatter_ws, size_t scatter_ws_bytes,
+                            float *grad_features, int B, int S, int T, scanerf_stream_t stream);
+/* Fused table-gradient path (replaces the atomicAdd scatter of hashgrid_bg_kernel.cu:196-201 for the
+ * samples of a render batch).  workspace_bytes == 0 => shape unsupported, use dfeat + the binned op. */
+size_t scanerf_render_scatter_workspace_bytes(int B, int S, int T);
+int scanerf_render_scatter_plan(const float *rays_o, const float *rays_d, const float *z_vals,
+                                const int32_t *resolutions, const scanerf_render_cfg *cfg /*[host]*/,
+                                const uint8_t *ray_valid, int B, int S, int T, void *workspace,
+                                size_t workspace_bytes, scanerf_stream_t stream);
+int scanerf_render_scatter_accumulate(float *grad_features, int B, int S, int T, void *workspace,
+                                      size_t workspace_bytes, scanerf_stream_t stream);
 /* For pose refinement (gradients w.r.t. the rays): g_dnorm = per-tile partials of dL/d|rays_d| through
  * delta = dist*|d| (hashgrid/__init__.py:347); g_rowsum = per-ray sums of dL/d(Directional_MLP.mlp.0
  * pre-activation) in two partial rows (their sum times W[:,32:48] is dL/dSH(viewdir)).  The gradient

@@ -26,6 +26,7 @@
 #include <stdlib.h>
 
 #include "render_device.h"
+#include "scatter_common.h"
 
 using namespace scanerf;
 
@@ -41,12 +42,18 @@ struct BwdArgs {
     RenderArgs f;              // forward inputs (out_ray = forward outputs, read-only here)
     const float *grad_out;     // [B,16] dL/d(out_ray)
     const float *tile_T;       // [B, ntiles] from the forward
-    float *dfeat;              // [16][B*S][2]
+    float *dfeat;              // [16][B*S][2]; may be null when recs != nullptr
     float *dw_partial;         // [nwaves][SCANERF_PARAMSIZE], zero-filled by the host wrapper
     const float *xstash;       // optional [B*S][2][16]: the forward's encoder outputs (skips the re-gather)
     float *g_dnorm;            // optional [B, ntiles]: dL/d|d| partials (through delta = dist*|d|)
     float *g_rowsum;           // optional [B, 2, 64]: sum_s dL/d(dir layer-0 pre-activation), for dL/dSH
-    int dbg;                   // timing experiments only (SCANERF_DEBUG_BWD): 1 = forward recompute only, 2 = no dW
+    // fused table-gradient producer (scatter.hip): when recs != nullptr the kernel appends the scatter
+    // records itself (the stores hide under the MFMA work) and dfeat becomes optional
+    BinGeom bins;
+    const uint32_t *bin_rowprefix, *bin_starts;
+    Rec *recs;
+    uint32_t *maxbits;
+    float *grad_features;      // only touched if the record workspace overflows
 };
 
 __device__ __forceinline__ float dgauss(float u, float a) { return -100.0f * u * a; }  // d/du exp(-50 u^2)
@@ -129,6 +136,13 @@ __global__ void __launch_bounds__(kBwdThreads, 1) k_render_bwd(BwdArgs a)
     int *lres = reinterpret_cast<int *>(lds + PK_TOTAL);
     float *stage = lds + PK_TOTAL + 64;
     float *totals = stage + 4 * kSlotFloats;  // [4] tile totals of a_j w_j
+    uint32_t *cursor = reinterpret_cast<uint32_t *>(totals + 16);  // [16*NB] record cursors (fused producer only)
+    float gmax = 0.0f;
+    if (a.recs) {
+        const int nbins = 16 * a.bins.NB;
+        for (int i = threadIdx.x; i < nbins; i += kBwdThreads)
+            cursor[i] = a.bin_starts[i] + a.bin_rowprefix[(size_t)i * a.bins.W + blockIdx.x];
+    }
     {
         const float4 *src = reinterpret_cast<const float4 *>(a.f.packed);
         float4 *dst = reinterpret_cast<float4 *>(lds);
@@ -160,6 +174,7 @@ __global__ void __launch_bounds__(kBwdThreads, 1) k_render_bwd(BwdArgs a)
     for (int ray = blockIdx.x; ray < a.f.B; ray += gridDim.x) {
         if (a.f.ray_valid && !a.f.ray_valid[ray]) {  // block-uniform
             // invalid rays contribute nothing; their feature gradients are zero
+            if (a.dfeat)
             for (int s = threadIdx.x >> 1; s < S; s += kBwdThreads / 2)
 #pragma unroll
                 for (int j = 0; j < 8; ++j)
@@ -316,7 +331,6 @@ __global__ void __launch_bounds__(kBwdThreads, 1) k_render_bwd(BwdArgs a)
                 if (sl + off < 32) rs += t;
             }
             if (lane == 0) totals[wv] = rs;  // lane 0: the whole tile
-            if (a.dbg == 1) { if (live) a.dfeat[(size_t)ray * S + s] = x[0] + H[0][0] + v0[0][0] + v1[0][0] + rs; continue; }
             __syncthreads();  // ---- B1: tile totals visible; every wave is done with last group's stage rows
 
             // ================= P1: compositing adjoint, narrow layers, D1 operands =================
@@ -503,7 +517,7 @@ __global__ void __launch_bounds__(kBwdThreads, 1) k_render_bwd(BwdArgs a)
             chain16(dx, lds + PK_L0, 4, lane, 0, 0, du0[0]);
             chain16(dx, lds + PK_L0, 4, lane, 0, 1, du0[1]);
             // feature gradients, level-major (register 2j+f of half h = level 4(j>>1)+2h+(j&1))
-            if (live) {
+            if (live && a.dfeat) {
                 const size_t n = (size_t)ray * S + s, NS = (size_t)a.f.B * S;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
@@ -511,11 +525,32 @@ __global__ void __launch_bounds__(kBwdThreads, 1) k_render_bwd(BwdArgs a)
                     reinterpret_cast<float2 *>(a.dfeat)[(size_t)level * NS + n] = make_float2(dx[2 * j], dx[2 * j + 1]);
                 }
             }
+            // fused scatter producer: this lane's 8 levels x 4 corner pairs -> 16-byte records appended to
+            // the ranges k_bin_count_rays reserved for this workgroup (same point, same pairs)
+            if (live && a.recs) {
+                float pe[3];
+                contract_point(a.f, o, d, opaque1(z), pe);
+                const uint32_t mask = (uint32_t)a.f.T - 1u;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int level = 4 * (j >> 1) + 2 * h + (j & 1);
+                    gmax = fmaxf(gmax, fmaxf(fabsf(dx[2 * j]), fabsf(dx[2 * j + 1])));
+                    Pairs pr;
+                    make_pairs(pe, lres + 4 * level, mask, pr);
+                    emit_pairs(pr, dx[2 * j], dx[2 * j + 1], cursor + level * a.bins.NB, a.bins.bucket_log,
+                               a.bins.capacity, a.recs, a.grad_features + (size_t)level * a.f.T * 2);
+                }
+            }
             // (the next group's B1 orders this group's stage reads before the next writes)
         }
         if (a.g_rowsum && (lane_k >> 5) == 0) a.g_rowsum[((size_t)ray * 2 + tp) * 64 + 32 * rb2 + (lane_k & 31)] = ray_rowsum;
     }
 
+    if (a.recs) {  // launch-wide max |dL/dfeature| for the fixed-point scale of the accumulate pass
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) gmax = fmaxf(gmax, __shfl_xor(gmax, off, 64));
+        if (lane_k == 0 && gmax > 0.0f) atomicMax(a.maxbits, __float_as_uint(gmax));
+    }
     // ---- flush this wave's partial sums in blob order (dw_partial is zero-filled: only owned entries are written)
     float *out = a.dw_partial + (size_t)(blockIdx.x * 4 + wv) * SCANERF_PARAMSIZE;
     const int lane = lane_k, h = lane >> 5;
@@ -591,7 +626,8 @@ SCANERF_API int scanerf_render_backward(const float *rays_o, const float *rays_d
                                         const float *workspace, const float *weight_feature,
                                         const scanerf_render_cfg *cfg, const uint8_t *ray_valid, const float *out_ray,
                                         const float *tile_T, const float *grad_out, const float *xstash, float *dfeat,
-                                        float *dw_partial, float *grad_blob, float *g_dnorm, float *g_rowsum, int B, int S,
+                                        float *dw_partial, float *grad_blob, float *g_dnorm, float *g_rowsum,
+                                        void *scatter_ws, size_t scatter_ws_bytes, float *grad_features, int B, int S,
                                         int T, scanerf_stream_t stream)
 {
     SCANERF_REQUIRE(B >= 0 && S >= 1, "render_backward: B=%d S=%d", B, S);
@@ -600,8 +636,9 @@ SCANERF_API int scanerf_render_backward(const float *rays_o, const float *rays_d
     SCANERF_REQUIRE(cfg, "render_backward: cfg is null");
     if (B == 0) return 0;
     SCANERF_REQUIRE(rays_o && rays_d && z_vals && dists && features && resolutions && workspace && weight_feature &&
-                        out_ray && tile_T && grad_out && dfeat && dw_partial && grad_blob,
+                        out_ray && tile_T && grad_out && dw_partial && grad_blob,
                     "render_backward: null pointer");
+    SCANERF_REQUIRE(dfeat || scatter_ws, "render_backward: need dfeat or a planned scatter workspace");
     BwdArgs a;
     a.f.rays_o = rays_o; a.f.rays_d = rays_d; a.f.z_vals = z_vals; a.f.dists = dists;
     a.f.features = features; a.f.resolutions = resolutions; a.f.packed = workspace; a.f.ray_valid = ray_valid;
@@ -615,9 +652,27 @@ SCANERF_API int scanerf_render_backward(const float *rays_o, const float *rays_d
     }
     a.grad_out = grad_out; a.tile_T = tile_T; a.dfeat = dfeat; a.dw_partial = dw_partial; a.xstash = xstash;
     a.g_dnorm = g_dnorm; a.g_rowsum = g_rowsum;
-    { const char *e = getenv("SCANERF_DEBUG_BWD"); a.dbg = e ? atoi(e) : 0; }
     const int blocks = scanerf_render_backward_grid(B);
-    const size_t lds_bytes = (size_t)kBwdLdsFloats * sizeof(float);
+    size_t lds_bytes = (size_t)kBwdLdsFloats * sizeof(float);
+    a.recs = nullptr;
+    if (scatter_ws) {  // planned by scanerf_render_scatter_plan on the same (B, S, T) and inputs
+        SCANERF_REQUIRE(grad_features, "render_backward: grad_features is required with a scatter workspace");
+        SCANERF_REQUIRE(scanerf_render_scatter_workspace_bytes(B, S, T) != 0,
+                        "render_backward: fused scatter does not support B=%d S=%d T=%d", B, S, T);
+        const int lt = bin_ilog2(T);
+        a.bins.bucket_log = lt < kBucketLog ? lt : (lt - 8 > kBucketLog ? lt - 8 : kBucketLog);
+        a.bins.N = B * S; a.bins.L = 16; a.bins.T = T;
+        a.bins.NB = T >> a.bins.bucket_log;
+        a.bins.W = blocks;
+        a.bins.per_wg = 0;
+        BinWorkspace w;
+        SCANERF_REQUIRE(bin_workspace_carve(scatter_ws, scatter_ws_bytes, 16 * a.bins.NB, blocks, w),
+                        "render_backward: scatter workspace too small (%zu B)", scatter_ws_bytes);
+        a.bins.capacity = w.capacity;
+        a.bin_rowprefix = w.counts; a.bin_starts = w.starts; a.recs = w.recs; a.maxbits = w.maxbits;
+        a.grad_features = grad_features;
+        lds_bytes += (size_t)16 * a.bins.NB * sizeof(uint32_t);
+    }
     hipStream_t st = (hipStream_t)stream;
     hipError_t me = hipMemsetAsync(dw_partial, 0, (size_t)blocks * 4 * SCANERF_PARAMSIZE * sizeof(float), st);
     SCANERF_REQUIRE(me == hipSuccess, "render_backward: memset failed: %s", hipGetErrorString(me));

@@ -21,56 +21,14 @@
 // HBM traffic: 64 B written + 64 B read per (point, level) instead of 16 memory-side atomics.
 #include <stdlib.h>
 
-#include "hashgrid_common.h"
+#include "render_device.h"
+#include "scatter_common.h"
 
 using namespace scanerf;
 
 namespace {
 
-constexpr int kBucketLog = 11;  // 2048 entries (16 KB of fp32 pairs) per bucket
 constexpr int kThreads = 256;
-
-struct BinGeom {
-    int N, L, T;
-    int bucket_log;   // min(kBucketLog, log2 T)
-    int NB;           // buckets per level = T >> bucket_log
-    int W;            // producer workgroups
-    int per_wg;       // samples per producer workgroup
-    uint32_t capacity;  // records that fit the workspace
-};
-
-struct Rec {
-    uint32_t hdr;
-    float tx, gx, gy;
-};
-
-// the 4 (y,z) corner pairs of one (point, level): bucket, locals, weights
-struct Pairs {
-    uint32_t idx0[4], idx1[4];
-    float wyz[4], tx;
-};
-
-__device__ __forceinline__ void make_pairs(const float p[3], const int32_t *res, uint32_t mask, Pairs &pr)
-{
-    int b[3];
-    float t[3], sc;
-    locate_bg(p[0], res[0], b[0], t[0], sc);
-    locate_bg(p[1], res[1], b[1], t[1], sc);
-    locate_bg(p[2], res[2], b[2], t[2], sc);
-    const uint32_t hx0 = (uint32_t)b[0], hx1 = (uint32_t)(b[0] + 1);
-    const uint32_t hy[2] = { (uint32_t)b[1] * 2654435761u, (uint32_t)(b[1] + 1) * 2654435761u };
-    const uint32_t hz[2] = { (uint32_t)b[2] * 805459861u, (uint32_t)(b[2] + 1) * 805459861u };
-    const float wy[2] = { 1 - t[1], t[1] }, wz[2] = { 1 - t[2], t[2] };
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int dy = q >> 1, dz = q & 1;
-        const uint32_t c = hy[dy] ^ hz[dz];
-        pr.idx0[q] = (hx0 ^ c) & mask;
-        pr.idx1[q] = (hx1 ^ c) & mask;
-        pr.wyz[q] = wy[dy] * wz[dz];
-    }
-    pr.tx = t[0];
-}
 
 // ---- pass 1: count ---------------------------------------------------------------------
 __global__ void __launch_bounds__(kThreads) k_bin_count(const float *__restrict__ points,
@@ -89,12 +47,7 @@ __global__ void __launch_bounds__(kThreads) k_bin_count(const float *__restrict_
         for (int l = 0; l < g.L; ++l) {
             Pairs pr;
             make_pairs(p, resolutions + 3 * l, mask, pr);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const uint32_t b0 = pr.idx0[q] >> g.bucket_log, b1 = pr.idx1[q] >> g.bucket_log;
-                atomicAdd(&hist[l * g.NB + b0], 1u);
-                if (b1 != b0) atomicAdd(&hist[l * g.NB + b1], 1u);
-            }
+            count_pairs(pr, hist + l * g.NB, g.bucket_log);
         }
     }
     __syncthreads();
@@ -171,7 +124,7 @@ __global__ void __launch_bounds__(kThreads) k_bin_scatter(const float *__restric
     for (int i = threadIdx.x; i < nbins; i += kThreads)
         cursor[i] = starts[i] + rowprefix[(size_t)i * g.W + blockIdx.x];
     __syncthreads();
-    const uint32_t mask = (uint32_t)g.T - 1u, lmask = (1u << g.bucket_log) - 1u;
+    const uint32_t mask = (uint32_t)g.T - 1u;
     const int lo = blockIdx.x * g.per_wg, hi = min(g.N, lo + g.per_wg);
     // One (sample, level): 4 records.
     auto one = [&](int i, int l, const float p[3]) {
@@ -179,31 +132,7 @@ __global__ void __launch_bounds__(kThreads) k_bin_scatter(const float *__restric
         gmax = fmaxf(gmax, fmaxf(fabsf(gi.x), fabsf(gi.y)));
         Pairs pr;
         make_pairs(p, resolutions + 3 * l, mask, pr);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const uint32_t b0 = pr.idx0[q] >> g.bucket_log, b1 = pr.idx1[q] >> g.bucket_log;
-            const float gx = pr.wyz[q] * gi.x, gy = pr.wyz[q] * gi.y;
-            auto emit = [&](uint32_t bkt, uint32_t hdr, float tx, float ax, float ay) {
-                const uint32_t pos = atomicAdd(&cursor[l * g.NB + bkt], 1u);
-                if (pos < g.capacity) {
-                    reinterpret_cast<float4 *>(recs)[pos] = make_float4(__uint_as_float(hdr), tx, ax, ay);
-                } else {  // workspace too small: apply directly (slow path, correctness only)
-                    float *gs = grad_features + ((size_t)l * g.T + ((size_t)bkt << g.bucket_log)) * 2;
-                    const uint32_t e0 = hdr & 0xffffu, e1 = hdr >> 16;
-                    unsafeAtomicAdd(gs + 2 * e0, (1.0f - tx) * ax);
-                    unsafeAtomicAdd(gs + 2 * e0 + 1, (1.0f - tx) * ay);
-                    unsafeAtomicAdd(gs + 2 * e1, tx * ax);
-                    unsafeAtomicAdd(gs + 2 * e1 + 1, tx * ay);
-                }
-            };
-            if (b1 == b0) {
-                emit(b0, (pr.idx0[q] & lmask) | ((pr.idx1[q] & lmask) << 16), pr.tx, gx, gy);
-            } else {  // x-neighbours straddle a bucket boundary (only when x+1 reaches 2^bucket_log)
-                const float a = 1.0f - pr.tx;
-                emit(b0, (pr.idx0[q] & lmask) * 0x10001u, 0.0f, a * gx, a * gy);
-                emit(b1, (pr.idx1[q] & lmask) * 0x10001u, 0.0f, pr.tx * gx, pr.tx * gy);
-            }
-        }
+        emit_pairs(pr, gi.x, gi.y, cursor + l * g.NB, g.bucket_log, g.capacity, recs, grad_features + (size_t)l * g.T * 2);
     };
     if (LEVEL_MAJOR_GRAD) {
         // level-major walk: a workgroup appends to only NB bins at a time, so the partially written
@@ -231,7 +160,7 @@ __global__ void __launch_bounds__(kThreads) k_bin_scatter(const float *__restric
 // LDS atomics: on gfx950 ds_add_f32 is ~12x slower than ds_add_u32/u64 (measured: 2.1e9 float
 // adds 9.5 ms, the same adds as u64 1.7 ms).  With M = max|dL/dout| of the launch (found by the
 // scatter pass) and n records in the bin, every partial sum is < n*M, so values are scaled by
-// 2^k, k = 62 - ceil(log2 M) - ceil(log2(n+1)): no overflow, resolution n*M*2^-62.  Integer
+// 2^k, k = 50 - ceil(log2 M) - ceil(log2(n+1)): no overflow, resolution n*M*2^-50.  Integer
 // addition is associative, so the table gradient is bit-reproducible run to run (the
 // reference's atomics are not) and closer to the exact sum than an fp32 running sum.
 __global__ void __launch_bounds__(kThreads) k_bin_accumulate(const Rec *__restrict__ recs,
@@ -248,18 +177,24 @@ __global__ void __launch_bounds__(kThreads) k_bin_accumulate(const Rec *__restri
     __syncthreads();
     int eM;
     frexpf(M, &eM);  // M < 2^eM
-    const int k = 62 - eM - (32 - __clz(hi - lo));
+    // float -> fixed point through the double "magic number": d = v*2^k + 1.5*2^52 holds round(v*2^k) in
+    // its low mantissa bits for |v*2^k| < 2^51, so bits(d) - bits(magic) is the integer (one cvt, one
+    // fma, one 64-bit subtract instead of the ~20-instruction f32 -> i64 software conversion).
+    const int k = 50 - eM - (32 - __clz(hi - lo));
+    const double scale = ldexp(1.0, k), magic = 6755399441055744.0;  // 1.5 * 2^52
     const float4 *r4 = reinterpret_cast<const float4 *>(recs);
-    auto fx = [&](float v) { return (long long)rintf(ldexpf(v, k)); };
+    auto fx = [&](float v) {
+        return (unsigned long long)(__double_as_longlong(fma((double)v, scale, magic)) - __double_as_longlong(magic));
+    };
     auto apply = [&](const float4 &r) {
         const uint32_t hdr = __float_as_uint(r.x);
         const uint32_t e0 = hdr & 0xffffu, e1 = hdr >> 16;
         const float w1 = r.y, w0 = 1.0f - w1;
         unsigned long long *a = reinterpret_cast<unsigned long long *>(acc64);
-        atomicAdd(&a[2 * e0], (unsigned long long)fx(w0 * r.z));
-        atomicAdd(&a[2 * e0 + 1], (unsigned long long)fx(w0 * r.w));
-        atomicAdd(&a[2 * e1], (unsigned long long)fx(w1 * r.z));
-        atomicAdd(&a[2 * e1 + 1], (unsigned long long)fx(w1 * r.w));
+        atomicAdd(&a[2 * e0], fx(w0 * r.z));
+        atomicAdd(&a[2 * e0 + 1], fx(w0 * r.w));
+        atomicAdd(&a[2 * e1], fx(w1 * r.z));
+        atomicAdd(&a[2 * e1 + 1], fx(w1 * r.w));
     };
     // 8 independent 16-B loads in flight per lane (the records are read once, from HBM)
     constexpr int U = 8;
@@ -290,11 +225,56 @@ __global__ void __launch_bounds__(kThreads) k_bin_accumulate(const Rec *__restri
     }
 }
 
-int ilog2(int v)
+// ---- count for the FUSED producer (k_render_bwd emits the records) ------------------------------
+// Same ray -> workgroup map as k_render_bwd (ray = blockIdx.x + i * gridDim.x), same point arithmetic
+// (contract_point) and the same make_pairs/count_pairs as its emit_pairs, so the ranges it reserves
+// are exactly the ones the backward kernel fills.
+__global__ void __launch_bounds__(1024) k_bin_count_rays(RenderArgs f, BinGeom g, uint32_t *__restrict__ counts,
+                                                         uint32_t *__restrict__ maxbits)
 {
-    int l = 0;
-    while ((1 << l) < v) ++l;
-    return l;
+    extern __shared__ uint32_t hist[];  // [16*NB]
+    if (blockIdx.x == 0 && threadIdx.x == 0) *maxbits = 0;
+    const int nbins = 16 * g.NB;
+    for (int i = threadIdx.x; i < nbins; i += 1024) hist[i] = 0;
+    __syncthreads();
+    const uint32_t mask = (uint32_t)f.T - 1u;
+    const int G = gridDim.x, w = blockIdx.x;
+    const int nrays = w < f.B ? (f.B - w + G - 1) / G : 0;
+    for (int idx = threadIdx.x; idx < nrays * f.S; idx += 1024) {
+        const int ray = w + (idx / f.S) * G, s = idx % f.S;
+        if (f.ray_valid && !f.ray_valid[ray]) continue;
+        float o[3], d[3], p[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            o[k] = f.rays_o[3 * ray + k];
+            d[k] = f.rays_d[3 * ray + k];
+        }
+        contract_point(f, o, d, f.z_vals[(size_t)ray * f.S + s], p);
+        for (int l = 0; l < 16; ++l) {
+            Pairs pr;
+            make_pairs(p, f.resolutions + 3 * l, mask, pr);
+            count_pairs(pr, hist + l * g.NB, g.bucket_log);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < nbins; i += 1024) counts[(size_t)i * g.W + blockIdx.x] = hist[i];
+}
+
+// bin geometry of the fused producer: W = the backward kernel's grid, buckets sized so that the
+// 16*NB cursors fit next to the backward kernel's LDS image (NB <= 256)
+bool fused_geom(int B, int S, int T, BinGeom &g)
+{
+    if (B < 1 || S < 1 || T < 2 || (T & (T - 1))) return false;
+    const int lt = bin_ilog2(T);
+    g.bucket_log = lt < kBucketLog ? lt : (lt - 8 > kBucketLog ? lt - 8 : kBucketLog);
+    if (g.bucket_log > 13) return false;  // 64-bit LDS image of a bucket: 128 KB at 2^13 entries
+    if ((int64_t)B * S * 16 * 4 + (1 << 20) >= (int64_t)1 << 31) return false;  // 32-bit record offsets
+    g.N = B * S; g.L = 16; g.T = T;
+    g.NB = T >> g.bucket_log;
+    g.W = scanerf_render_backward_grid(B);
+    g.per_wg = 0;
+    g.capacity = 0;
+    return true;
 }
 
 }  // namespace
@@ -304,7 +284,7 @@ int ilog2(int v)
 SCANERF_API size_t scanerf_embedding_bwd_workspace_bytes(int N, int L, int T)
 {
     if (N <= 0 || L < 1 || T < 2 || (T & (T - 1))) return 0;
-    const int bl = ilog2(T) < kBucketLog ? ilog2(T) : kBucketLog;
+    const int bl = bin_ilog2(T) < kBucketLog ? bin_ilog2(T) : kBucketLog;
     const int64_t nbins = (int64_t)L * (T >> bl);
     if (nbins * 4 > 64 * 1024) return 0;                       // LDS histogram of all bins
     if ((int64_t)N * L * 4 + (1 << 20) >= (int64_t)1 << 31) return 0;  // 32-bit record offsets
@@ -329,24 +309,18 @@ SCANERF_API int scanerf_embedding_bg_backward_binned(const float *points, const 
     hipStream_t st = (hipStream_t)stream;
     BinGeom g;
     g.N = N; g.L = L; g.T = T;
-    g.bucket_log = ilog2(T) < kBucketLog ? ilog2(T) : kBucketLog;
+    g.bucket_log = bin_ilog2(T) < kBucketLog ? bin_ilog2(T) : kBucketLog;
     g.NB = T >> g.bucket_log;
     g.W = 1024;
     if (g.W > (N + kThreads - 1) / kThreads) g.W = (N + kThreads - 1) / kThreads;
     g.per_wg = (N + g.W - 1) / g.W;
     const int nbins = L * g.NB;
-    // carve: [counts nbins*W][totals nbins][starts nbins+1][pad][records]
-    uint32_t *counts = reinterpret_cast<uint32_t *>(workspace);
-    uint32_t *totals = counts + (size_t)nbins * g.W;
-    uint32_t *starts = totals + nbins;
-    uint32_t *maxbits = starts + nbins + 1;
-    size_t head = ((size_t)nbins * g.W + 2 * (size_t)nbins + 2) * 4;
-    head = (head + 255) & ~(size_t)255;
-    SCANERF_REQUIRE(workspace_bytes > head + sizeof(Rec), "embedding_bg_backward_binned: workspace too small (%zu B)",
-                    workspace_bytes);
-    Rec *recs = reinterpret_cast<Rec *>(reinterpret_cast<char *>(workspace) + head);
-    size_t cap = (workspace_bytes - head) / sizeof(Rec);
-    g.capacity = cap > 0xfffffff0u ? 0xfffffff0u : (uint32_t)cap;
+    BinWorkspace w;
+    SCANERF_REQUIRE(bin_workspace_carve(workspace, workspace_bytes, nbins, g.W, w),
+                    "embedding_bg_backward_binned: workspace too small (%zu B)", workspace_bytes);
+    g.capacity = w.capacity;
+    uint32_t *counts = w.counts, *totals = w.totals, *starts = w.starts, *maxbits = w.maxbits;
+    Rec *recs = w.recs;
 
     const size_t lds_bins = (size_t)nbins * 4;
     hipLaunchKernelGGL(k_bin_count, dim3(g.W), dim3(kThreads), lds_bins, st, points, resolutions, g, counts, maxbits);
@@ -362,4 +336,69 @@ SCANERF_API int scanerf_embedding_bg_backward_binned(const float *points, const 
     hipLaunchKernelGGL(k_bin_accumulate, dim3(nbins), dim3(kThreads), (size_t)(2 << g.bucket_log) * 8, st, recs, starts,
                        maxbits, g, grad_features);
     return check_launch("embedding_bg_backward_binned");
+}
+
+// ---- fused producer: plan (count + scan) before k_render_bwd, accumulate after it ---------------
+// Workspace bytes of the fused table-gradient path of scanerf_render_backward; 0 => shape unsupported
+// (use dfeat + scanerf_embedding_bg_backward_binned instead).
+SCANERF_API size_t scanerf_render_scatter_workspace_bytes(int B, int S, int T)
+{
+    BinGeom g;
+    if (!fused_geom(B, S, T, g)) return 0;
+    const size_t n = (size_t)B * S * 16;
+    return bin_workspace_head(16 * g.NB, g.W) + (n * 4 + n / 8 + 4096) * sizeof(Rec);
+}
+
+SCANERF_API int scanerf_render_scatter_plan(const float *rays_o, const float *rays_d, const float *z_vals,
+                                            const int32_t *resolutions, const scanerf_render_cfg *cfg,
+                                            const uint8_t *ray_valid, int B, int S, int T, void *workspace,
+                                            size_t workspace_bytes, scanerf_stream_t stream)
+{
+    SCANERF_REQUIRE(B >= 0 && S >= 1, "render_scatter_plan: B=%d S=%d", B, S);
+    if (B == 0) return 0;
+    BinGeom g;
+    SCANERF_REQUIRE(fused_geom(B, S, T, g), "render_scatter_plan: shape B=%d S=%d T=%d not supported", B, S, T);
+    SCANERF_REQUIRE(rays_o && rays_d && z_vals && resolutions && cfg && workspace, "render_scatter_plan: null pointer");
+    SCANERF_REQUIRE(((uintptr_t)workspace & 15) == 0, "render_scatter_plan: workspace must be 16-byte aligned");
+    const int nbins = 16 * g.NB;
+    BinWorkspace w;
+    SCANERF_REQUIRE(bin_workspace_carve(workspace, workspace_bytes, nbins, g.W, w),
+                    "render_scatter_plan: workspace too small (%zu B)", workspace_bytes);
+    RenderArgs f = {};
+    f.rays_o = rays_o; f.rays_d = rays_d; f.z_vals = z_vals; f.resolutions = resolutions; f.ray_valid = ray_valid;
+    f.B = B; f.S = S; f.T = T;
+    f.contract_mode = cfg->contract_mode; f.infinity = cfg->infinity;
+    for (int k = 0; k < 3; ++k) {
+        f.min_bbox[k] = cfg->min_bbox[k];
+        f.bbox_size[k] = cfg->bbox_size[k];
+        f.inv_size4[k] = 4.0f / cfg->bbox_size[k];
+    }
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_bin_count_rays, dim3(g.W), dim3(1024), (size_t)nbins * 4, st, f, g, w.counts, w.maxbits);
+    hipLaunchKernelGGL(k_bin_rowscan, dim3(nbins), dim3(kThreads), 0, st, w.counts, w.totals, g.W);
+    hipLaunchKernelGGL(k_bin_starts, dim3(1), dim3(1024), 0, st, w.totals, w.starts, nbins);
+    return check_launch("render_scatter_plan");
+}
+
+// grad_features [16][T][2] += the records scanerf_render_backward emitted into `workspace`.
+SCANERF_API int scanerf_render_scatter_accumulate(float *grad_features, int B, int S, int T, void *workspace,
+                                                  size_t workspace_bytes, scanerf_stream_t stream)
+{
+    if (B == 0) return 0;
+    BinGeom g;
+    SCANERF_REQUIRE(fused_geom(B, S, T, g), "render_scatter_accumulate: shape B=%d S=%d T=%d not supported", B, S, T);
+    SCANERF_REQUIRE(grad_features && workspace, "render_scatter_accumulate: null pointer");
+    const int nbins = 16 * g.NB;
+    BinWorkspace w;
+    SCANERF_REQUIRE(bin_workspace_carve(workspace, workspace_bytes, nbins, g.W, w),
+                    "render_scatter_accumulate: workspace too small (%zu B)", workspace_bytes);
+    g.capacity = w.capacity;
+    const size_t lds_bytes = (size_t)(2 << g.bucket_log) * 8;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bin_accumulate),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    SCANERF_REQUIRE(e == hipSuccess, "render_scatter_accumulate: cannot reserve %zu B of LDS: %s", lds_bytes,
+                    hipGetErrorString(e));
+    hipLaunchKernelGGL(k_bin_accumulate, dim3(nbins), dim3(kThreads), lds_bytes, (hipStream_t)stream, w.recs, w.starts,
+                       w.maxbits, g, grad_features);
+    return check_launch("render_scatter_accumulate");
 }

@@ -1,0 +1,129 @@
+// scatter_common.h -- record format, bin geometry and workspace layout of the atomic-free table-gradient
+// scatter, shared by scatter.hip (count / scan / accumulate, stand-alone producer) and render_bwd.hip
+// (which emits the records straight from the fused backward kernel).
+#pragma once
+#include "hashgrid_common.h"
+
+namespace scanerf {
+
+constexpr int kBucketLog = 11;  // 2048 entries (16 KB of fp32 pairs) per bucket
+
+struct BinGeom {
+    int N, L, T;
+    int bucket_log;   // min(kBucketLog, log2 T)
+    int NB;           // buckets per level = T >> bucket_log
+    int W;            // producer workgroups
+    int per_wg;       // samples per producer workgroup
+    uint32_t capacity;  // records that fit the workspace
+};
+
+struct Rec {
+    uint32_t hdr;
+    float tx, gx, gy;
+};
+
+// the 4 (y,z) corner pairs of one (point, level): bucket, locals, weights
+struct Pairs {
+    uint32_t idx0[4], idx1[4];
+    float wyz[4], tx;
+};
+
+__device__ __forceinline__ void make_pairs(const float p[3], const int32_t *res, uint32_t mask, Pairs &pr)
+{
+    int b[3];
+    float t[3], sc;
+    locate_bg(p[0], res[0], b[0], t[0], sc);
+    locate_bg(p[1], res[1], b[1], t[1], sc);
+    locate_bg(p[2], res[2], b[2], t[2], sc);
+    const uint32_t hx0 = (uint32_t)b[0], hx1 = (uint32_t)(b[0] + 1);
+    const uint32_t hy[2] = { (uint32_t)b[1] * 2654435761u, (uint32_t)(b[1] + 1) * 2654435761u };
+    const uint32_t hz[2] = { (uint32_t)b[2] * 805459861u, (uint32_t)(b[2] + 1) * 805459861u };
+    const float wy[2] = { 1 - t[1], t[1] }, wz[2] = { 1 - t[2], t[2] };
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int dy = q >> 1, dz = q & 1;
+        const uint32_t c = hy[dy] ^ hz[dz];
+        pr.idx0[q] = (hx0 ^ c) & mask;
+        pr.idx1[q] = (hx1 ^ c) & mask;
+        pr.wyz[q] = wy[dy] * wz[dz];
+    }
+    pr.tx = t[0];
+}
+
+
+// Append the (up to 5) records of one (sample, level) with upstream gradient (gix, giy).
+// cursor_level: this workgroup's LDS cursors of the level's NB bins; grad_level: the level's slice of
+// grad_features, touched only when the workspace is too small (slow path, correctness only).
+__device__ __forceinline__ void emit_pairs(const Pairs &pr, float gix, float giy, uint32_t *cursor_level, int bucket_log,
+                                           uint32_t capacity, Rec *recs, float *grad_level)
+{
+    const uint32_t lmask = (1u << bucket_log) - 1u;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const uint32_t b0 = pr.idx0[q] >> bucket_log, b1 = pr.idx1[q] >> bucket_log;
+        const float gx = pr.wyz[q] * gix, gy = pr.wyz[q] * giy;
+        auto emit = [&](uint32_t bkt, uint32_t hdr, float tx, float ax, float ay) {
+            const uint32_t pos = atomicAdd(&cursor_level[bkt], 1u);
+            if (pos < capacity) {
+                reinterpret_cast<float4 *>(recs)[pos] = make_float4(__uint_as_float(hdr), tx, ax, ay);
+            } else {
+                float *gs = grad_level + ((size_t)bkt << bucket_log) * 2;
+                const uint32_t e0 = hdr & 0xffffu, e1 = hdr >> 16;
+                unsafeAtomicAdd(gs + 2 * e0, (1.0f - tx) * ax);
+                unsafeAtomicAdd(gs + 2 * e0 + 1, (1.0f - tx) * ay);
+                unsafeAtomicAdd(gs + 2 * e1, tx * ax);
+                unsafeAtomicAdd(gs + 2 * e1 + 1, tx * ay);
+            }
+        };
+        if (b1 == b0) {
+            emit(b0, (pr.idx0[q] & lmask) | ((pr.idx1[q] & lmask) << 16), pr.tx, gx, gy);
+        } else {  // x-neighbours straddle a bucket boundary (only when x+1 reaches 2^bucket_log)
+            const float a = 1.0f - pr.tx;
+            emit(b0, (pr.idx0[q] & lmask) * 0x10001u, 0.0f, a * gx, a * gy);
+            emit(b1, (pr.idx1[q] & lmask) * 0x10001u, 0.0f, pr.tx * gx, pr.tx * gy);
+        }
+    }
+}
+// histogram counterpart of emit_pairs (must stay in lock-step with it)
+__device__ __forceinline__ void count_pairs(const Pairs &pr, uint32_t *hist_level, int bucket_log)
+{
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const uint32_t b0 = pr.idx0[q] >> bucket_log, b1 = pr.idx1[q] >> bucket_log;
+        atomicAdd(&hist_level[b0], 1u);
+        if (b1 != b0) atomicAdd(&hist_level[b1], 1u);
+    }
+}
+
+// workspace carve: [counts nbins*W][totals nbins][starts nbins+1][maxbits][pad to 256 B][records]
+struct BinWorkspace {
+    uint32_t *counts, *totals, *starts, *maxbits;
+    Rec *recs;
+    uint32_t capacity;
+};
+inline size_t bin_workspace_head(int nbins, int W)
+{
+    size_t head = ((size_t)nbins * W + 2 * (size_t)nbins + 2) * 4;
+    return (head + 255) & ~(size_t)255;
+}
+inline bool bin_workspace_carve(void *workspace, size_t bytes, int nbins, int W, BinWorkspace &w)
+{
+    const size_t head = bin_workspace_head(nbins, W);
+    if (bytes < head + sizeof(Rec)) return false;
+    w.counts = reinterpret_cast<uint32_t *>(workspace);
+    w.totals = w.counts + (size_t)nbins * W;
+    w.starts = w.totals + nbins;
+    w.maxbits = w.starts + nbins + 1;
+    w.recs = reinterpret_cast<Rec *>(reinterpret_cast<char *>(workspace) + head);
+    const size_t cap = (bytes - head) / sizeof(Rec);
+    w.capacity = cap > 0xfffffff0u ? 0xfffffff0u : (uint32_t)cap;
+    return true;
+}
+inline int bin_ilog2(int v)
+{
+    int l = 0;
+    while ((1 << l) < v) ++l;
+    return l;
+}
+
+}  // namespace scanerf

@@ -63,11 +63,15 @@ def render_forward(rays_o, rays_d, z_vals, dists, features, resolutions, packed,
 
 def render_backward(rays_o, rays_d, z_vals, dists, features, resolutions, packed, weight_feature, min_bbox, bbox_size,
                     contract_mode, infinity, out_ray, tile_T, grad_out, ray_valid=None, grad_blob=None, xstash=None,
-                    ray_grad_buffers=None):
-    """Adjoint of render_forward -> (dfeat [16, B*S, 2] level-major, grad_blob [13994])."""
+                    ray_grad_buffers=None, scatter=None, want_dfeat=True):
+    """Adjoint of render_forward -> (dfeat [16, B*S, 2] level-major, grad_blob [13994]).
+    scatter = (workspace, grad_features) from scatter_plan(): the kernel emits the table-gradient records
+    itself; finish with scatter_accumulate().  dfeat is then only produced if want_dfeat."""
     B, S = z_vals.shape
     dev = z_vals.device
-    dfeat = torch.empty((16, B * S, 2), dtype=_f32, device=dev)
+    if scatter is None and not want_dfeat:
+        raise ValueError("render_backward: nothing would receive the feature gradients")
+    dfeat = torch.empty((16, B * S, 2), dtype=_f32, device=dev) if want_dfeat else None
     nblk = lib().scanerf_render_backward_grid(ctypes.c_int(B))
     dw_partial = torch.empty((4 * nblk, _capi.PARAMSIZE), dtype=_f32, device=dev)
     if grad_blob is None:
@@ -80,11 +84,44 @@ def render_backward(rays_o, rays_d, z_vals, dists, features, resolutions, packed
         dev_ptr(packed.workspace, _f32, "workspace"), dev_ptr(weight_feature, _f32, "weight_feature"),
         ctypes.byref(cfg), dev_ptr(ray_valid, (torch.bool, torch.uint8), "ray_valid", allow_none=True),
         dev_ptr(out_ray, _f32, "out_ray"), dev_ptr(tile_T, _f32, "tile_T"), dev_ptr(grad_out, _f32, "grad_out"),
-        dev_ptr(xstash, _f32, "xstash", allow_none=True), dev_ptr(dfeat, _f32, "dfeat"), dev_ptr(dw_partial, _f32, "dw_partial"), dev_ptr(grad_blob, _f32, "grad_blob"),
+        dev_ptr(xstash, _f32, "xstash", allow_none=True), dev_ptr(dfeat, _f32, "dfeat", allow_none=True), dev_ptr(dw_partial, _f32, "dw_partial"), dev_ptr(grad_blob, _f32, "grad_blob"),
         dev_ptr(ray_grad_buffers[0] if ray_grad_buffers else None, _f32, "g_dnorm", allow_none=True),
         dev_ptr(ray_grad_buffers[1] if ray_grad_buffers else None, _f32, "g_rowsum", allow_none=True),
+        ctypes.c_void_p(scatter[0].data_ptr() if scatter else None), ctypes.c_size_t(scatter[0].numel() if scatter else 0),
+        dev_ptr(scatter[1] if scatter else None, _f32, "grad_features", allow_none=True),
         ctypes.c_int(B), ctypes.c_int(S), ctypes.c_int(features.shape[1]), stream()), "render_backward")
     return dfeat, grad_blob
+
+
+def scatter_supported(B, S, T):
+    return lib().scanerf_render_scatter_workspace_bytes(ctypes.c_int(B), ctypes.c_int(S), ctypes.c_int(T)) != 0
+
+
+def scatter_plan(rays_o, rays_d, z_vals, resolutions, T, min_bbox, bbox_size, contract_mode, infinity, ray_valid=None):
+    """Reserve the record ranges of the fused table-gradient path for this batch (count + scan).
+    Returns the workspace tensor to hand to render_backward(scatter=(ws, grad_features)) and scatter_accumulate.
+    The workspace is a per-device cache: one plan/backward/accumulate sequence at a time."""
+    B, S = z_vals.shape
+    need = lib().scanerf_render_scatter_workspace_bytes(ctypes.c_int(B), ctypes.c_int(S), ctypes.c_int(T))
+    if not need:
+        raise RuntimeError(f"scanerf: fused scatter does not support B={B} S={S} T={T}")
+    ws = _capi.workspace(z_vals.device, need)
+    cfg = _cfg(min_bbox, bbox_size, contract_mode, infinity)
+    check(lib().scanerf_render_scatter_plan(
+        dev_ptr(rays_o, _f32, "rays_o"), dev_ptr(rays_d, _f32, "rays_d"), dev_ptr(z_vals, _f32, "z_vals"),
+        dev_ptr(resolutions, torch.int32, "resolutions"), ctypes.byref(cfg),
+        dev_ptr(ray_valid, (torch.bool, torch.uint8), "ray_valid", allow_none=True), ctypes.c_int(B), ctypes.c_int(S),
+        ctypes.c_int(T), ctypes.c_void_p(ws.data_ptr()), ctypes.c_size_t(ws.numel()), stream()), "scatter_plan")
+    return ws
+
+
+def scatter_accumulate(ws, grad_features, B, S):
+    """grad_features [16,T,2] += the records the fused backward emitted into ws."""
+    check(lib().scanerf_render_scatter_accumulate(
+        dev_ptr(grad_features, _f32, "grad_features"), ctypes.c_int(B), ctypes.c_int(S),
+        ctypes.c_int(grad_features.shape[1]), ctypes.c_void_p(ws.data_ptr()), ctypes.c_size_t(ws.numel()), stream()),
+        "scatter_accumulate")
+    return grad_features
 
 
 def scatter_table_grad(points, dfeat, grad_features, resolutions):

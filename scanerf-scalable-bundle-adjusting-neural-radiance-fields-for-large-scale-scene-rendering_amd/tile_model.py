@@ -287,7 +287,7 @@ def train_step_ops(model, dec_opt, rays_o, rays_d, target, S, global_step, table
 
 
 def train_step_fused(model, dec_opt, rays_o, rays_d, target, S, global_step, table_lr=1e-2, timer=None,
-                     pose_grads=False):
+                     pose_grads=False, fused_scatter=True):
     """The same iteration as train_step_ops on the fused kernels: one launch for the render forward,
     one for its adjoint, the atomic-free binned scatter for the table gradient, fused sparse Adam.
     pose_grads=True also returns dL/d(rays_o), dL/d(rays_d) (feed them to the pose graph:
@@ -315,50 +315,34 @@ def train_step_fused(model, dec_opt, rays_o, rays_d, target, S, global_step, tab
     loss = F.mse_loss(leaf[:, 0:3][valid], target[valid]) + 0.01 * leaf[:, 14][valid].sum() / (3 * nv)
     loss.backward()
     with torch.no_grad():
-        # Optional chunking (SCANERF_BWD_CHUNKS > 1): scatter of chunk c on a side stream underneath the
-        # backward of chunk c+1.  Measured on MI355X: no gain (24.2 vs 24.5 ms/step) -- the persistent
-        # backward workgroups hold 132 KB of LDS per CU, so the 32 KB accumulate workgroups cannot
-        # co-reside; default is one chunk.
-        chunks = max(1, min(int(os.environ.get("SCANERF_BWD_CHUNKS", "1")), B // 4096)) if B >= 8192 else 1
-        edges = [B * c // chunks for c in range(chunks + 1)]
-        main = torch.cuda.current_stream()
-        side = model._side_stream if chunks > 1 else main
         gtab = torch.zeros_like(model.features)
         gblob = torch.zeros(network.PARAMSIZE, device=dev)
         ray_bufs = (torch.zeros(B, ntile, device=dev), torch.zeros(B, 2, 64, device=dev)) if pose_grads else None
         g_o = g_d = None
-        keep = []
-        if chunks > 1:
-            side.wait_stream(main)
-        for c in range(chunks):
-            lo, hi = edges[c], edges[c + 1]
-            sl = slice(lo, hi)
-            n = hi - lo
-            # forward recompute + activation gradients + weight gradients = 3x the forward MLP FLOPs
-            with _sec(timer, "render_backward", n * (24 + 20 + S * 16 * 8 * 2 * 4 + S * 16 * 8), 3 * n * S * MLP_FLOPS_PER_SAMPLE):
-                dfeat, _ = render.render_backward(rays_o[sl], rays_d[sl], z[sl], dist[sl], model.features, model.resolution,
-                                                  model.packed, wf, *box, out[sl], tile_T[sl], leaf.grad[sl],
-                                                  ray_valid=valid[sl], grad_blob=gblob, xstash=xstash[lo * S:hi * S],
-                                                  ray_grad_buffers=(ray_bufs[0][sl], ray_bufs[1][sl]) if pose_grads else None)
-            if pose_grads:
-                go_c, gd_c = render.ray_gradients(rays_o[sl], rays_d[sl], z[sl], model.features, model.resolution, blob,
-                                                  box[0], box[1], box[2], dfeat, ray_bufs[0][sl], ray_bufs[1][sl],
-                                                  ray_valid=valid[sl])
-                g_o = go_c if g_o is None else torch.cat([g_o, go_c])
-                g_d = gd_c if g_d is None else torch.cat([g_d, gd_c])
-            pts = ((rays_o[sl, None, :] + z[sl, :, None] * rays_d[sl, None, :]).reshape(-1, 3) - model._min_dev) \
+        T = model.features.shape[1]
+        fused = fused_scatter and render.scatter_supported(B, S, T)
+        ws = None
+        if fused:
+            # count + scan of the scatter records (depends on the sample positions only)
+            with _sec(timer, "scatter_plan", B * S * 4):
+                ws = render.scatter_plan(rays_o, rays_d, z, model.resolution, T, *box, ray_valid=valid)
+        # forward recompute + activation gradients + weight gradients = 3x the forward MLP FLOPs
+        with _sec(timer, "render_backward", B * (24 + 20 + S * 16 * 8 * 2 * 4 + S * 16 * 8), 3 * B * S * MLP_FLOPS_PER_SAMPLE):
+            dfeat, _ = render.render_backward(rays_o, rays_d, z, dist, model.features, model.resolution, model.packed, wf,
+                                              *box, out, tile_T, leaf.grad, ray_valid=valid, grad_blob=gblob, xstash=xstash,
+                                              ray_grad_buffers=ray_bufs, scatter=(ws, gtab) if fused else None,
+                                              want_dfeat=pose_grads or not fused)
+        if pose_grads:
+            g_o, g_d = render.ray_gradients(rays_o, rays_d, z, model.features, model.resolution, blob, box[0], box[1],
+                                            box[2], dfeat, ray_bufs[0], ray_bufs[1], ray_valid=valid)
+        if fused:
+            with _sec(timer, "table_grad_accumulate", B * S * 16 * 64):
+                render.scatter_accumulate(ws, gtab, B, S)
+        else:
+            pts = ((rays_o[:, None, :] + z[:, :, None] * rays_d[:, None, :]).reshape(-1, 3) - model._min_dev) \
                 / model._size_dev * 4.0 - 2.0
-            pts = pts.contiguous()
-            keep += [dfeat, pts]
-            if chunks > 1:
-                ev = torch.cuda.Event()
-                ev.record(main)
-                side.wait_event(ev)
-            with torch.cuda.stream(side):
-                with _sec(timer, "table_grad_scatter", n * S * 16 * (8 + 16 * 8)):
-                    render.scatter_table_grad(pts, dfeat, gtab, model.resolution)
-        if chunks > 1:
-            main.wait_stream(side)
+            with _sec(timer, "table_grad_scatter", B * S * 16 * (8 + 16 * 8)):
+                render.scatter_table_grad(pts.contiguous(), dfeat, gtab, model.resolution)
         model.features.grad = gtab
         with _sec(timer, "sparse_adam", model.features.numel() * 28):
             model.table_adam(table_lr)
