@@ -134,7 +134,11 @@ typedef struct {
     int infinity;      /* dists[:, -1] = 1e10 (hashgrid/__init__.py:349-350) */
     float min_bbox[3];
     float bbox_size[3];
+    int arith; /* decoder arithmetic: SCANERF_ARITH_F32 (f32-input MFMA, exact f32) or SCANERF_ARITH_H3 (f16 MFMA
+                  on hi/lo-split operands, three products per term: f32-equivalent results, csrc/render_h3.h) */
 } scanerf_render_cfg;
+#define SCANERF_ARITH_F32 0
+#define SCANERF_ARITH_H3 1
 
 /* Packs the decoder blob (+ weight_feature folded into the first layer) into the LDS image
  * the fused kernels stage (csrc/render_common.h).  workspace: scanerf_render_workspace_floats()

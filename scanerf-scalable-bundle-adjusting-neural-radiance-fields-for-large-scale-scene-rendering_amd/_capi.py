@@ -9,7 +9,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libscanerf_hip.so")
+LIB_PATH = os.environ.get("SCANERF_LIB") or os.path.join(_HERE, "lib", "libscanerf_hip.so")
 
 F32, F16, BF16 = 0, 1, 2
 RAY_OUT = 16
@@ -36,7 +36,10 @@ SYMBOLS = [
 
 class RenderCfg(ctypes.Structure):
     _fields_ = [("contract_mode", ctypes.c_int), ("infinity", ctypes.c_int),
-                ("min_bbox", ctypes.c_float * 3), ("bbox_size", ctypes.c_float * 3)]
+                ("min_bbox", ctypes.c_float * 3), ("bbox_size", ctypes.c_float * 3), ("arith", ctypes.c_int)]
+
+
+ARITH_F32, ARITH_H3 = 0, 1
 
 
 def lib():

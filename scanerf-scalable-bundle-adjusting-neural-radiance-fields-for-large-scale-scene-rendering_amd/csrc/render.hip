@@ -13,7 +13,9 @@
 // (render_common.h).  Compositing is a 32-lane prefix product per tile with the
 // transmittance carried across tiles.  Per ray 48 B are read and 64 B + S*4 B written;
 // everything else is table gathers.
-#include "render_device.h"
+#include <stdlib.h>
+
+#include "render_h3.h"
 
 using namespace scanerf;
 
@@ -213,17 +215,207 @@ __global__ void __launch_bounds__(kRenderThreads, 2) k_render_fwd(RenderArgs a)
     }
 }
 
+
+// ------------------------------------------------------------------ h3 (f16 split) pack + forward
+// One thread per (sub-image pair, lane, element): W in f32 -> hi / lo f16 at the two parts.
+__global__ void __launch_bounds__(256) k_pack_decoder_h3(const float *__restrict__ blob, const float *__restrict__ wf,
+                                                         char *__restrict__ out)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < 32 * 512) {
+        const int pair = e >> 9, lane = (e >> 3) & 63, j = e & 7;
+        const int r = lane & 31, h = lane >> 5;
+        int base, ks, q = pair, layer;
+        if (q < 4) { layer = 0; base = H3_L0; ks = 2; }
+        else if ((q -= 4) < 8) { layer = 1; base = H3_L1; ks = 4; }
+        else if ((q -= 8) < 2) { layer = 2; base = H3_HEAD; ks = 2; }
+        else if ((q -= 2) < 6) { layer = 3; base = H3_D0; ks = 3; }
+        else if ((q -= 6) < 8) { layer = 4; base = H3_D1; ks = 4; }
+        else { q -= 8; layer = 5; base = H3_D2; ks = 4; }
+        const int b = q / ks, s = q % ks;
+        const int n = 32 * b + r, k = 16 * s + 8 * (j >> 2) + 4 * h + (j & 3);
+        float w = 0.0f;
+        if (layer == 0) w = blob_w(blob, BLOB_S0, 64, n, k) * wf[k];
+        else if (layer == 1) w = blob_w(blob, BLOB_S1, 64, n, k);
+        else if (layer == 2) {
+            // rows 0-3: sigma, dif xyz; rows 8-10: tint xyz; replicas 4 rows higher (for the upper half-wave)
+            const int rr = r & ~4;
+            if (r < 16) {
+                if (rr == 0) w = blob_w(blob, BLOB_SIG, 1, 0, k);
+                else if (rr < 4) w = blob_w(blob, BLOB_DIF, 3, rr - 1, k);
+                else if (rr >= 8 && rr < 11) w = blob_w(blob, BLOB_TINT, 3, rr - 8, k);
+            }
+        } else if (layer == 3) {
+            w = s < 2 ? blob_w(blob, BLOB_D0, 64, n, k) : blob_w(blob, BLOB_D0, 64, n, 32 + 8 * h + j);
+        } else if (layer == 4) w = blob_w(blob, BLOB_D1, 64, n, k);
+        else {
+            const int rr = r & ~4;
+            if (r < 8 && rr < 3) w = blob_w(blob, BLOB_D2, 3, rr, k);
+        }
+        const _Float16 hi = (_Float16)w, lo = (_Float16)(w - (float)hi);
+        char *p = out + base + ((b * ks + s) * 2) * H3_SUB + r * 16 + h * 576 + j * 2;
+        *reinterpret_cast<_Float16 *>(p) = hi;
+        *reinterpret_cast<_Float16 *>(p + H3_SUB) = lo;
+    } else if (e < 32 * 512 + 64) {  // the 64-byte gaps between the half-waves and after the upper one
+        const int sub = e - 32 * 512;  // 64 sub-images: zero the 64-B gap between their half-waves
+        float4 *g0 = reinterpret_cast<float4 *>(out + sub * H3_SUB + 512);
+        for (int i = 0; i < 4; ++i) g0[i] = make_float4(0, 0, 0, 0);
+    } else if (e < 32 * 512 + 64 + 288) {
+        const int t = e - 32 * 512 - 64;
+        float v = 0.0f;
+        if (t < 256) {
+            const int g = t & 15, h = (t >> 4) & 1, blk = (t >> 5) & 1, layer = t >> 6;
+            const int bases[4] = { BLOB_S0, BLOB_S1, BLOB_D0, BLOB_D1 };
+            v = blob[bases[layer] + 32 * blk + nmap(g, h)];
+        } else if (t < 272) {
+            const int g = t - 256;
+            if (g == 0) v = blob[BLOB_SIG];
+            else if (g < 4) v = blob[BLOB_DIF + g - 1];
+            else if (g < 7) v = blob[BLOB_TINT + g - 4];
+        } else {
+            const int g = t - 272;
+            if (g < 3) v = blob[BLOB_D2 + g];
+        }
+        reinterpret_cast<float *>(out + H3_BIAS)[t] = v;
+    }
+}
+
+constexpr int kH3LdsBytes = H3_BYTES + 64 * 4;  // + resolutions [16][4] i32
+
+template <int DT>
+__global__ void __launch_bounds__(kRenderThreads, 2) k_render_fwd_h3(RenderArgs a)
+{
+    __shared__ __attribute__((aligned(16))) char lds[kH3LdsBytes];
+    {
+        const float4 *src = reinterpret_cast<const float4 *>(a.packed + PK_TOTAL);
+        float4 *dst = reinterpret_cast<float4 *>(lds);
+        for (int i = threadIdx.x; i < H3_BYTES / 16; i += kRenderThreads) dst[i] = src[i];
+        int *lres = reinterpret_cast<int *>(lds + H3_BYTES);
+        if (threadIdx.x < 64) {
+            int lv = threadIdx.x >> 2, c = threadIdx.x & 3;
+            lres[threadIdx.x] = c < 3 ? a.resolutions[3 * lv + c] : 0;
+        }
+    }
+    __syncthreads();
+    const int *lds_res = reinterpret_cast<const int *>(lds + H3_BYTES);
+    const int lane = threadIdx.x & 63, sl = lane & 31, h = lane >> 5;
+    const int waves_per_block = kRenderThreads / 64;
+    const int wave0 = blockIdx.x * waves_per_block + (threadIdx.x >> 6);
+    const int nwaves = gridDim.x * waves_per_block;
+    const int S = a.S, ntiles = (S + 31) >> 5;
+
+    for (int ray = wave0; ray < a.B; ray += nwaves) {
+        float *outp = a.out_ray + (size_t)ray * SCANERF_RAY_OUT;
+        if (a.ray_valid && !a.ray_valid[ray]) {
+            if (lane < 16) outp[lane] = (lane == 4) ? 1.0f : 0.0f;
+            if (a.weights)
+                for (int s = lane; s < S; s += 64) a.weights[(size_t)ray * S + s] = 0.0f;
+            continue;
+        }
+        float o[3], d[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            o[k] = a.rays_o[3 * ray + k];
+            d[k] = a.rays_d[3 * ray + k];
+        }
+        const float dnorm = sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+        v16f dinit[2];
+        {
+            float sh[16];
+            ray_sh(d, dnorm, sh);
+            h3_dinit(lds, lane, sh, dinit);
+        }
+        float T_run = 1.0f, T_left = 1.0f;
+        float acc[11];
+#pragma unroll
+        for (int k = 0; k < 11; ++k) acc[k] = 0.0f;
+
+        for (int tile = 0; tile < ntiles; ++tile) {
+            const int s = tile * 32 + sl;
+            const bool live = s < S;
+            const float z = live ? a.z_vals[(size_t)ray * S + s] : 0.0f;
+            float delta = live ? a.dists[(size_t)ray * S + s] * dnorm : 0.0f;
+            if (a.infinity && s == S - 1) delta = 1e10f;
+            float p[3];
+            contract_point(a, o, d, z, p);
+            v16f x;
+            if (a.dbg == 2) {
+#pragma unroll
+                for (int g = 0; g < 16; ++g) x[g] = p[g % 3] * (0.01f * g);
+            } else {
+                encode8<DT>(a, lds_res, h, p, x);
+            }
+            if (a.xstash && live) {
+                float4 *xs = reinterpret_cast<float4 *>(a.xstash + ((size_t)ray * S + s) * 32 + 16 * h);
+                xs[0] = make_float4(x[0], x[1], x[2], x[3]);
+                xs[1] = make_float4(x[4], x[5], x[6], x[7]);
+                xs[2] = make_float4(x[8], x[9], x[10], x[11]);
+                xs[3] = make_float4(x[12], x[13], x[14], x[15]);
+            }
+            SampleOut so;
+            if (a.dbg == 1) {
+                so.sigma = x[0] + x[5] + x[10] + x[15];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) { so.dif[c] = x[1 + c] + x[12 + c]; so.tint[c] = x[4 + c] + x[9 + c]; so.spec[c] = x[7 + c] + x[6 + c]; }
+            } else {
+                so = decode_tile_h3(lds, lane, x, dinit);
+            }
+
+            const float alpha = live ? 1.0f - expf(-so.sigma * delta) : 0.0f;
+            float incl = 1.0f - alpha + 1e-6f;
+#pragma unroll
+            for (int off = 1; off < 32; off <<= 1) {
+                float t = __shfl_up(incl, off, 32);
+                if (sl >= off) incl *= t;
+            }
+            float excl = __shfl_up(incl, 1, 32);
+            if (sl == 0) excl = 1.0f;
+            if (a.tile_T && lane == 0) a.tile_T[(size_t)ray * ntiles + tile] = T_run;
+            const float Ti = T_run * excl;
+            const float w = alpha * Ti;
+            T_run *= __shfl(incl, 31, 32);
+            if (tile == ntiles - 1) T_left = __shfl(Ti, (S - 1) & 31, 32);
+            if (a.weights && live && h == 0) a.weights[(size_t)ray * S + s] = w;
+
+            acc[0] = fmaf(w, z, acc[0]);
+            float s2 = 0.0f;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                acc[1 + c] = fmaf(w, so.dif[c], acc[1 + c]);
+                acc[4 + c] = fmaf(w, so.tint[c] * so.spec[c], acc[4 + c]);
+                acc[7 + c] = fmaf(w, so.tint[c], acc[7 + c]);
+                s2 = fmaf(so.spec[c], so.spec[c], s2);
+            }
+            acc[10] = fmaf(w, s2, acc[10]);
+        }
+#pragma unroll
+        for (int k = 0; k < 11; ++k) acc[k] = half_sum(acc[k]);
+        if (lane == 0) {
+            float4 *o4 = reinterpret_cast<float4 *>(outp);
+            auto clamp01 = [](float v) { return fminf(fmaxf(v, 0.0f), 1.0f); };
+            o4[0] = make_float4(clamp01(acc[1] + acc[4]), clamp01(acc[2] + acc[5]), clamp01(acc[3] + acc[6]), acc[0]);
+            o4[1] = make_float4(T_left, acc[1], acc[2], acc[3]);
+            o4[2] = make_float4(acc[4], acc[5], acc[6], acc[7]);
+            o4[3] = make_float4(acc[8], acc[9], acc[10], 0.0f);
+        }
+    }
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------- C ABI
-SCANERF_API int scanerf_render_workspace_floats(void) { return PK_TOTAL; }
+SCANERF_API int scanerf_render_workspace_floats(void) { return WS_FLOATS; }
 
 SCANERF_API int scanerf_pack_decoder(const float *mlp_blob, const float *weight_feature, float *workspace,
                                      scanerf_stream_t stream)
 {
     SCANERF_REQUIRE(mlp_blob && weight_feature && workspace, "pack_decoder: null pointer");
+    SCANERF_REQUIRE(((uintptr_t)workspace & 15) == 0, "pack_decoder: workspace must be 16-byte aligned");
     hipLaunchKernelGGL(k_pack_decoder, dim3(32), dim3(256), 0, (hipStream_t)stream, mlp_blob, weight_feature,
                        workspace);
+    // the same decoder as f16 hi/lo operand pairs for the split-precision kernels (render_h3.h)
+    hipLaunchKernelGGL(k_pack_decoder_h3, dim3((32 * 512 + 64 + 288 + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                       mlp_blob, weight_feature, reinterpret_cast<char *>(workspace + PK_TOTAL));
     return check_launch("pack_decoder");
 }
 
@@ -254,12 +446,18 @@ SCANERF_API int scanerf_render_forward_packed(const float *rays_o, const float *
         a.bbox_size[k] = cfg->bbox_size[k];
         a.inv_size4[k] = 4.0f / cfg->bbox_size[k];
     }
+    { const char *e = getenv("SCANERF_DEBUG_FWD"); a.dbg = e ? atoi(e) : 0; }
     const int waves_per_block = kRenderThreads / 64;
     int blocks = ceil_div(B, waves_per_block);
     if (blocks > kNumCU) blocks = kNumCU;  // one resident 512-thread workgroup per CU (VGPR-bound), persistent
     dim3 grid(blocks), block(kRenderThreads);
     hipStream_t st = (hipStream_t)stream;
-    if (feat_dtype == SCANERF_F32) hipLaunchKernelGGL((k_render_fwd<SCANERF_F32>), grid, block, 0, st, a);
+    SCANERF_REQUIRE(cfg->arith == SCANERF_ARITH_F32 || cfg->arith == SCANERF_ARITH_H3, "render_forward: arith=%d", cfg->arith);
+    if (cfg->arith == SCANERF_ARITH_H3) {
+        if (feat_dtype == SCANERF_F32) hipLaunchKernelGGL((k_render_fwd_h3<SCANERF_F32>), grid, block, 0, st, a);
+        else if (feat_dtype == SCANERF_F16) hipLaunchKernelGGL((k_render_fwd_h3<SCANERF_F16>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((k_render_fwd_h3<SCANERF_BF16>), grid, block, 0, st, a);
+    } else if (feat_dtype == SCANERF_F32) hipLaunchKernelGGL((k_render_fwd<SCANERF_F32>), grid, block, 0, st, a);
     else if (feat_dtype == SCANERF_F16) hipLaunchKernelGGL((k_render_fwd<SCANERF_F16>), grid, block, 0, st, a);
     else hipLaunchKernelGGL((k_render_fwd<SCANERF_BF16>), grid, block, 0, st, a);
     return check_launch("render_forward");

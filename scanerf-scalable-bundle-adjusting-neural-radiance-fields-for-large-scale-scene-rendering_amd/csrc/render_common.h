@@ -51,6 +51,26 @@ constexpr int PK_HB = PK_D2 + 256;            // head biases: sigma, dif3, tint3
 constexpr int PK_TOTAL = PK_HB + 16;
 static_assert(PK_TOTAL % 4 == 0, "image is copied as float4");
 
+// ---- f16 split ("h3") image, see render_h3.h (bytes from the start of the h3 part of the workspace / LDS copy)
+constexpr int H3_SUB = 1088;
+constexpr int H3_L0 = 0;                       // 2 blocks x 2 k-steps (weight_feature folded in)
+constexpr int H3_L1 = H3_L0 + 8 * H3_SUB;      // 2 x 4
+constexpr int H3_HEAD = H3_L1 + 16 * H3_SUB;   // 1 x 2: rows 0-3 sigma,dif; 8-10 tint; replicas at +4
+constexpr int H3_D0 = H3_HEAD + 4 * H3_SUB;    // 2 x 3: k-steps 0,1 = H[32:64], k-step 2 = SH (slot 8h+j = SH[8h+j])
+constexpr int H3_D1 = H3_D0 + 12 * H3_SUB;     // 2 x 4
+constexpr int H3_D2 = H3_D1 + 16 * H3_SUB;     // 1 x 4: rows 0-2 rgb; replicas at +4
+constexpr int H3_IMG_BYTES = H3_D2 + 8 * H3_SUB;
+// f32 tail: accumulator start values
+constexpr int H3_BIAS = H3_IMG_BYTES;          // [layer 4][block 2][half 2][16] f32, as PK_BIAS
+constexpr int H3_HB = H3_BIAS + 256 * 4;       // head accumulator start [16]: regs 0-3 sigma,dif; 4-6 tint
+constexpr int H3_D2B = H3_HB + 16 * 4;         // rgb accumulator start [16]: regs 0-2
+constexpr int H3_BYTES = H3_D2B + 16 * 4;
+static_assert(H3_BYTES % 16 == 0 && H3_IMG_BYTES % 256 == 0, "h3 image is copied as float4");
+constexpr int H3_FLOATS = H3_BYTES / 4;
+
+// packed workspace = [fp32 image PK_TOTAL floats][h3 image H3_FLOATS floats]
+constexpr int WS_FLOATS = PK_TOTAL + H3_FLOATS;
+
 __host__ __device__ constexpr int nmap(int g, int h) { return (g & 3) + 8 * (g >> 2) + 4 * h; }
 
 // inverse of nmap within a 32-unit block: unit i5 -> (register g, half h)

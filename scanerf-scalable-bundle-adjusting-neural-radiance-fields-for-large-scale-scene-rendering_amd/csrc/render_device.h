@@ -115,6 +115,7 @@ struct RenderArgs {
     int contract_mode, infinity;
     float min_bbox[3], inv_size4[3];  // 4/bbox_size
     float bbox_size[3];
+    int dbg;                  // timing experiments only (SCANERF_DEBUG_FWD): 1 = encode only, 2 = decode only
 };
 
 // hash-encode 8 levels of one sample: register 2j+f of half h holds feature f of level

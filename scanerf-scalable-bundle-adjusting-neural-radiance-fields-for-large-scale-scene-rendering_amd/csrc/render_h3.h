@@ -1,0 +1,236 @@
+// render_h3.h -- the decoder on f16 matrix cores with split operands ("h3" arithmetic).
+//
+// v_mfma_f32_32x32x16_f16 runs at 16x the rate of the f32-input MFMA on gfx950, but one f16 operand
+// carries 11 significant bits.  Every operand is therefore split into two f16 parts
+//     v = hi + lo,   hi = f16(v),   lo = f16(v - hi)            (22 significant bits together)
+// and every product is evaluated as  lo_a*hi_b + hi_a*lo_b + hi_a*hi_b  (three MFMAs, f32 accumulate,
+// small terms first); the dropped lo*lo term is 2^-22 relative.  Measured against an fp64 evaluation of
+// network.ShallowMLP the outputs are as close as the fp32 evaluation is (a few 1e-6 relative; the bf16
+// analogue is 30x worse and a single f16 product 1000x) at 3/16 of the fp32 MFMA time.
+//
+// Register / lane maps are those of render_common.h: lane l = (sample s = l & 31, half h = l >> 5),
+// accumulator register g of a 32-unit block = unit nmap(g, h).  A 32x32x16 MFMA consumes per lane 8 values
+// of the reduction index: k-slot 8h + j (j = 0..7).  Feeding registers 8t .. 8t+7 of a block as the B operand
+// of k-step t puts unit  ku(t, h, j) = 16t + 8(j >> 2) + 4h + (j & 3)  at slot 8h + j, so the weight image
+// stores W[n][ku(...)] at that slot and activations never move between lanes (MI355X guide, "An accumulator
+// tile as the next MFMA's operand").
+//
+// Image: one sub-image per (layer, 32-row block b, k-step s, part hi|lo): 64 lanes x 16 B, the upper
+// half-wave shifted by 64 B (H3_SUB = 1088 B), sub-images consecutive in the order [b][s][part].  The forward
+// reads it with one ds_read_b128 per lane (conflict-free).  The backward products dX = W^T dY read the SAME
+// image through ds_read_b64_tr_b16 (a 4-row x 16-column block delivered column-major): with this stride the
+// 32 8-byte pieces a half-wave touches fall on 32 distinct bank pairs, so no transposed copy is kept.
+#pragma once
+#include "render_device.h"
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+typedef float f2v __attribute__((ext_vector_type(2)));
+
+namespace scanerf {
+
+__host__ __device__ constexpr int h3_ku(int t, int h, int j) { return 16 * t + 8 * (j >> 2) + 4 * h + (j & 3); }
+__device__ __forceinline__ int h3_lane_off(int lane) { return (lane & 31) * 16 + (lane >> 5) * 576; }
+
+// ---- operand split
+struct HL {
+    h8 hi, lo;
+};
+// registers 8t .. 8t+7 of an accumulator block -> B operand of k-step t
+__device__ __forceinline__ HL split8(const v16f &v, int t)
+{
+    HL o;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const f2v x = { v[8 * t + 2 * q], v[8 * t + 2 * q + 1] };
+        const h2v hi = __builtin_convertvector(x, h2v);
+        const f2v back = __builtin_convertvector(hi, f2v);
+        const f2v r = { x[0] - back[0], x[1] - back[1] };
+        const h2v lo = __builtin_convertvector(r, h2v);
+        o.hi[2 * q] = hi[0];
+        o.hi[2 * q + 1] = hi[1];
+        o.lo[2 * q] = lo[0];
+        o.lo[2 * q + 1] = lo[1];
+    }
+    return o;
+}
+struct HL2 {
+    HL t[2];
+};
+__device__ __forceinline__ HL2 split16(const v16f &v)
+{
+    HL2 o;
+    o.t[0] = split8(v, 0);
+    o.t[1] = split8(v, 1);
+    return o;
+}
+
+// ---- MFMA regions.
+// Measured on MI355X (ROCm 7.2 hipcc): with the f16 MFMAs scheduled freely among the VALU code that produces and
+// recycles their 4-register A/B operands, about 3e-4 of the 32-sample tiles came out wrong in lanes 16-31, differently
+// on every launch (tools/h3_debug.py); fencing the MFMAs off removes it.  The listing shows VALU writes to an MFMA's
+// A/B registers one or two issue slots behind it, which the hazard recogniser does not pad (it pads the producer ->
+// MFMA direction).  So every group of MFMAs is a closed scheduling region: operands are complete before it, nothing
+// else is inside it, and two wait states follow it.  The A operands of the NEXT group are loaded in front of the region
+// (their LDS latency hides under the MFMAs); VALU work overlaps through the other waves of the SIMD.
+struct A2 {
+    h8 hi, lo;
+};
+__device__ __forceinline__ A2 h3_lda(const char *sub)  // `sub` = address of this lane's 16 B of the hi part
+{
+    A2 a;
+    a.hi = *reinterpret_cast<const h8 *>(sub);
+    a.lo = *reinterpret_cast<const h8 *>(sub + H3_SUB);
+    return a;
+}
+#define H3_REGION_BEGIN() __builtin_amdgcn_sched_barrier(0)
+#define H3_REGION_END()          \
+    asm volatile("s_nop 1");     \
+    __builtin_amdgcn_sched_barrier(0)
+// acc += W * B with the three-term split (small terms first); call between H3_REGION_BEGIN / END
+__device__ __forceinline__ void mma3(v16f &acc, const A2 &a, const HL &b)
+{
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.lo, b.hi, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.hi, b.lo, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.hi, b.hi, acc, 0, 0, 0);
+}
+// Two row blocks of one layer over KS k-steps: u[b] += W[b] * B.  The two accumulators are independent, so their
+// MFMAs alternate (no dependent-issue stall); one region per k-step, next k-step's A operands prefetched.
+template <int KS>
+__device__ __forceinline__ void h3_layer2(v16f u[2], const char *img, int base, int ksb, int lo, const HL *const B[KS])
+{
+    A2 a0 = h3_lda(img + base + ((0 * ksb + 0) * 2) * H3_SUB + lo), a1 = h3_lda(img + base + ((1 * ksb + 0) * 2) * H3_SUB + lo);
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        A2 n0 = a0, n1 = a1;
+        if (s + 1 < KS) {
+            n0 = h3_lda(img + base + ((0 * ksb + s + 1) * 2) * H3_SUB + lo);
+            n1 = h3_lda(img + base + ((1 * ksb + s + 1) * 2) * H3_SUB + lo);
+        }
+        H3_REGION_BEGIN();
+        u[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0.lo, B[s]->hi, u[0], 0, 0, 0);
+        u[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1.lo, B[s]->hi, u[1], 0, 0, 0);
+        u[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0.hi, B[s]->lo, u[0], 0, 0, 0);
+        u[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1.hi, B[s]->lo, u[1], 0, 0, 0);
+        u[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0.hi, B[s]->hi, u[0], 0, 0, 0);
+        u[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1.hi, B[s]->hi, u[1], 0, 0, 0);
+        H3_REGION_END();
+        a0 = n0;
+        a1 = n1;
+    }
+}
+// One row block over KS k-steps (heads, rgb layer)
+template <int KS>
+__device__ __forceinline__ void h3_layer1(v16f &u, const char *img, int base, int lo, const HL *const B[KS])
+{
+    A2 a = h3_lda(img + base + lo);
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        A2 n = a;
+        if (s + 1 < KS) n = h3_lda(img + base + ((s + 1) * 2) * H3_SUB + lo);
+        H3_REGION_BEGIN();
+        mma3(u, a, *B[s]);
+        H3_REGION_END();
+        a = n;
+    }
+}
+// sub-image address of (layer base, k-steps per block, block b, k-step s) for this lane
+__device__ __forceinline__ const char *h3_sub(const char *img, int base, int ks, int b, int s, int lane_off)
+{
+    return img + base + ((b * ks + s) * 2) * H3_SUB + lane_off;
+}
+__device__ __forceinline__ v16f h3_ld16(const char *img, int byte_off)  // 16 f32 accumulator start values
+{
+    const float4 *p = reinterpret_cast<const float4 *>(img + byte_off);
+    const float4 a = p[0], b = p[1], c = p[2], d = p[3];
+    return v16f{ a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w, d.x, d.y, d.z, d.w };
+}
+__device__ __forceinline__ v16f h3_bias(const char *img, int layer, int blk, int h)
+{
+    return h3_ld16(img, H3_BIAS + (((layer * 2 + blk) * 2 + h) * 16) * 4);
+}
+
+// Dir layer-0 accumulator start of one ray: bias + W[:, 32:48] SH(dir)   (one k-step per block)
+__device__ __forceinline__ void h3_dinit(const char *img, int lane, const float sh[16], v16f dinit[2])
+{
+    const int h = lane >> 5, lo = h3_lane_off(lane);
+    v16f s16;  // registers 0..7 = this half's 8 SH values (slot 8h + j = SH[8h + j])
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s16[j] = h ? sh[8 + j] : sh[j];
+#pragma unroll
+    for (int j = 8; j < 16; ++j) s16[j] = 0.0f;
+    const HL b = split8(s16, 0);
+    dinit[0] = h3_bias(img, 2, 0, h);
+    dinit[1] = h3_bias(img, 2, 1, h);
+    const A2 a0 = h3_lda(h3_sub(img, H3_D0, 3, 0, 2, lo)), a1 = h3_lda(h3_sub(img, H3_D0, 3, 1, 2, lo));
+    H3_REGION_BEGIN();
+    mma3(dinit[0], a0, b);
+    mma3(dinit[1], a1, b);
+    H3_REGION_END();
+}
+
+// Decoder forward on one 32-sample tile (same contract as decode_tile in render_device.h)
+__device__ __forceinline__ SampleOut decode_tile_h3(const char *img, int lane, const v16f &x, const v16f dinit[2])
+{
+    const int h = lane >> 5, lo = h3_lane_off(lane);
+    // Spatial_MLP.mlp.0 (32 -> 64) + Gaussian
+    HL2 a[2];
+    {
+        const HL2 xs = split16(x);
+        v16f u[2] = { h3_bias(img, 0, 0, h), h3_bias(img, 0, 1, h) };
+        const HL *const B[2] = { &xs.t[0], &xs.t[1] };
+        h3_layer2<2>(u, img, H3_L0, 2, lo, B);
+        a[0] = split16(act16(u[0]));
+        a[1] = split16(act16(u[1]));
+    }
+    // Spatial_MLP.mlp.2 (64 -> 64), linear
+    HL2 H[2];
+    {
+        v16f u[2] = { h3_bias(img, 1, 0, h), h3_bias(img, 1, 1, h) };
+        const HL *const B[4] = { &a[0].t[0], &a[0].t[1], &a[1].t[0], &a[1].t[1] };
+        h3_layer2<4>(u, img, H3_L1, 4, lo, B);
+        H[0] = split16(u[0]);
+        H[1] = split16(u[1]);
+    }
+    SampleOut so;
+    {   // heads on H[:32]: one 32-row block, rows replicated so both halves hold all 7 outputs
+        v16f u = h3_ld16(img, H3_HB);
+        const HL *const B[2] = { &H[0].t[0], &H[0].t[1] };
+        h3_layer1<2>(u, img, H3_HEAD, lo, B);
+        so.sigma = softplus_(u[0]);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            so.dif[c] = sigmoid_(u[1 + c]);
+            so.tint[c] = sigmoid_(u[4 + c]);
+        }
+    }
+    // Directional_MLP.mlp.0 (48 -> 64): SH part + bias pre-accumulated in dinit
+    HL2 c0[2];
+    {
+        v16f u[2] = { dinit[0], dinit[1] };
+        const HL *const B[2] = { &H[1].t[0], &H[1].t[1] };
+        h3_layer2<2>(u, img, H3_D0, 3, lo, B);
+        c0[0] = split16(act16(u[0]));
+        c0[1] = split16(act16(u[1]));
+    }
+    // Directional_MLP.mlp.2 (64 -> 64) + Gaussian
+    HL2 c1[2];
+    {
+        v16f u[2] = { h3_bias(img, 3, 0, h), h3_bias(img, 3, 1, h) };
+        const HL *const B[4] = { &c0[0].t[0], &c0[0].t[1], &c0[1].t[0], &c0[1].t[1] };
+        h3_layer2<4>(u, img, H3_D1, 4, lo, B);
+        c1[0] = split16(act16(u[0]));
+        c1[1] = split16(act16(u[1]));
+    }
+    {   // Directional_MLP.mlp.4 (64 -> 3) + sigmoid
+        v16f u = h3_ld16(img, H3_D2B);
+        const HL *const B[4] = { &c1[0].t[0], &c1[0].t[1], &c1[1].t[0], &c1[1].t[1] };
+        h3_layer1<4>(u, img, H3_D2, lo, B);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) so.spec[c] = sigmoid_(u[c]);
+    }
+    return so;
+}
+
+}  // namespace scanerf

@@ -261,7 +261,7 @@ __global__ void __launch_bounds__(256, 2) k_pts_inference(InferArgs a)
                 v16f x;
                 encode8_01<SCANERF_F16>((const char *)a.tables + (size_t)b * 16 * a.T * 4, a.res + (size_t)b * 48, a.T, h, p01,
                                         run, x);
-                SampleOut so = decode_tile_dir(a.images + (size_t)b * PK_TOTAL, lane, x, d, dnorm, 0.0f);
+                SampleOut so = decode_tile_dir(a.images + (size_t)b * WS_FLOATS, lane, x, d, dnorm, 0.0f);
                 if (run) {
                     const float pa = 1.0f - expf(-1.0f * so.sigma * delta);
                     if (BG) {

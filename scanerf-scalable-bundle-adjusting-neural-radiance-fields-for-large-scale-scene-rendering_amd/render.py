@@ -9,6 +9,17 @@ from ._capi import RAY_OUT, RenderCfg, check, dev_ptr, feat_dtype_code, lib, str
 _f32 = torch.float32
 FORE, BG = 0, 1
 
+# Decoder arithmetic of the fused kernels: "h3" = f16 matrix cores on hi/lo-split operands (three products
+# per term, f32 accumulate: results as close to fp64 as the f32 evaluation, csrc/render_h3.h), "f32" = the
+# f32-input MFMA.  Module-level switch (also SCANERF_ARITH=f32|h3 in the environment).
+import os as _os
+ARITH = {"f32": _capi.ARITH_F32, "h3": _capi.ARITH_H3}[_os.environ.get("SCANERF_ARITH", "h3")]
+
+
+def set_arith(name):
+    global ARITH
+    ARITH = {"f32": _capi.ARITH_F32, "h3": _capi.ARITH_H3}[name]
+
 # columns of out_ray [B,16]
 RGB, DEPTH, T_LEFT, DIFFUSE, SPECULAR, TINT, W_SPEC2 = slice(0, 3), 3, 4, slice(5, 8), slice(8, 11), slice(11, 14), 14
 
@@ -31,6 +42,7 @@ class PackedDecoder:
 def _cfg(min_bbox, bbox_size, contract_mode, infinity):
     c = RenderCfg()
     c.contract_mode, c.infinity = int(contract_mode), int(bool(infinity))
+    c.arith = ARITH
     for k in range(3):
         c.min_bbox[k] = float(min_bbox[k])
         c.bbox_size[k] = float(bbox_size[k])

@@ -1,0 +1,36 @@
+"""Fused forward only, both decoder arithmetics, at BASELINE config 2 (65 536 rays x 128 samples, T=2^19)."""
+import os, sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import scanerf_amd
+from scanerf_amd import network, render
+from scanerf_amd.tile_model import TileModel
+dev = "cuda:0"
+B, S = int(os.environ.get("B", 65536)), 128
+torch.manual_seed(0)
+m = TileModel([-4, -4, -4], [8, 8, 8], dev, log2_T=int(os.environ.get("LOG2T", 19)))
+o = torch.rand(B, 3, device=dev) * 8 - 4
+d = torch.nn.functional.normalize(torch.randn(B, 3, device=dev), dim=-1)
+z, dist = m.sample(o, d, S)
+m.packed.pack(m.decoder.blob(), network.weight_feature(40000, dev))
+box = (m.min_bbox.tolist(), m.bbox_size.tolist(), render.FORE, False)
+outs = {}
+for ar in os.environ.get("ARITH", "f32,h3").split(","):
+    render.set_arith(ar)
+    for dt in (torch.float32, torch.bfloat16):
+        F = m.features.detach().to(dt).contiguous()
+        for xs in (None, torch.empty(B * S, 32, device=dev)):
+            f = lambda: render.render_forward(o, d, z, dist, F, m.resolution, m.packed, *box, want_weights=False, xstash=xs)
+            for _ in range(3): out, _ = f()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10): f()
+            e1.record(); torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / 10
+            print(f"render_forward arith={ar} table={dt} xstash={xs is not None}: {ms:.3f} ms  {B/ms*1e3:.3e} rays/s", flush=True)
+        outs[(ar, dt)] = out.clone()
+if ("f32", torch.float32) in outs and ("h3", torch.float32) in outs:
+    a, b = outs[("f32", torch.float32)], outs[("h3", torch.float32)]
+    e = ((a - b).abs() / (1e-6 + 1e-4 * a.abs()))[:, :15]
+    print("h3 vs f32 (allclose units, <=1 passes): max", e.max().item(), " n>1:", int((e > 1).sum()))
