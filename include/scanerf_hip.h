@@ -193,6 +193,12 @@ int scanerf_render_scatter_plan(const float *rays_o, const float *rays_d, const 
                                 size_t workspace_bytes, scanerf_stream_t stream);
 int scanerf_render_scatter_accumulate(float *grad_features, int B, int S, int T, void *workspace,
                                       size_t workspace_bytes, scanerf_stream_t stream);
+/* Device self-test of the split-f16 backward primitives (csrc/render_h3.h; test infrastructure, one wave):
+ * workspace from scanerf_pack_decoder; dy, x [64][32] f32 -> out_dx [2][64][32] (W^T dy of Spatial_MLP.mlp.2, and
+ * of the H part of Directional_MLP.mlp.0 in rows 0..31 of the second slab), out_dw [64][64] = dy x^T, out_rs [64]
+ * = row sums of dy. */
+int scanerf_h3_selftest(const float *workspace, const float *dy, const float *x, float *out_dx, float *out_dw,
+                        float *out_rs, scanerf_stream_t stream);
 /* For pose refinement (gradients w.r.t. the rays): g_dnorm = per-tile partials of dL/d|rays_d| through
  * delta = dist*|d| (hashgrid/__init__.py:347); g_rowsum = per-ray sums of dL/d(Directional_MLP.mlp.0
  * pre-activation) in two partial rows (their sum times W[:,32:48] is dL/dSH(viewdir)).  The gradient

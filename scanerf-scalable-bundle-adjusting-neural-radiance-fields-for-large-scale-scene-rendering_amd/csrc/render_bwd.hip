@@ -25,8 +25,7 @@
 // f_i = 1-alpha_i+1e-6 and loses opaque samples).
 #include <stdlib.h>
 
-#include "render_device.h"
-#include "scatter_common.h"
+#include "render_bwd_common.h"
 
 using namespace scanerf;
 
@@ -37,41 +36,6 @@ constexpr int kScrStride = 36;                   // floats per stage row (32 sam
 constexpr int kSlotRows = 128;                   // per wave: rows 0..63 dY (or private scratch), 64..127 X
 constexpr int kSlotFloats = kSlotRows * kScrStride;
 constexpr int kBwdLdsFloats = PK_TOTAL + 64 + 4 * kSlotFloats + 16;
-
-struct BwdArgs {
-    RenderArgs f;              // forward inputs (out_ray = forward outputs, read-only here)
-    const float *grad_out;     // [B,16] dL/d(out_ray)
-    const float *tile_T;       // [B, ntiles] from the forward
-    float *dfeat;              // [16][B*S][2]; may be null when recs != nullptr
-    float *dw_partial;         // [nwaves][SCANERF_PARAMSIZE], zero-filled by the host wrapper
-    const float *xstash;       // optional [B*S][2][16]: the forward's encoder outputs (skips the re-gather)
-    float *g_dnorm;            // optional [B, ntiles]: dL/d|d| partials (through delta = dist*|d|)
-    float *g_rowsum;           // optional [B, 2, 64]: sum_s dL/d(dir layer-0 pre-activation), for dL/dSH
-    // fused table-gradient producer (scatter.hip): when recs != nullptr the kernel appends the scatter
-    // records itself (the stores hide under the MFMA work) and dfeat becomes optional
-    BinGeom bins;
-    const uint32_t *bin_rowprefix, *bin_starts;
-    Rec *recs;
-    uint32_t *maxbits;
-    float *grad_features;      // only touched if the record workspace overflows
-};
-
-__device__ __forceinline__ float dgauss(float u, float a) { return -100.0f * u * a; }  // d/du exp(-50 u^2)
-
-// Hide a value's provenance from the optimiser.  The kernel RECOMPUTES cheap activations
-// (exp(-50 u^2), SH of the ray) at each use instead of holding them; without this the compiler
-// common-subexpression-eliminates the recomputation and keeps 32-64 extra registers alive across
-// the phases, which is what pushes the wave into scratch.
-__device__ __forceinline__ v16f opaque16(v16f v)
-{
-    asm volatile("" : "+v"(v));
-    return v;
-}
-__device__ __forceinline__ float opaque1(float v)
-{
-    asm volatile("" : "+v"(v));
-    return v;
-}
 
 // registers (lane = sample s, half h, reg g = unit nmap(g,h))  ->  rows[unit][sample]
 __device__ __forceinline__ void rows_put(float *rows, int lane, int rowbase, const v16f &v)
@@ -617,6 +581,26 @@ __global__ void __launch_bounds__(256) k_reduce_dw(const float *__restrict__ par
 
 }  // namespace
 
+namespace scanerf {
+int launch_render_bwd_f32(const BwdArgs &a, int feat_dtype, int blocks, size_t lds_extra, hipStream_t st)
+{
+    const size_t lds_bytes = (size_t)kBwdLdsFloats * sizeof(float) + lds_extra;
+#define SCANERF_LAUNCH_BWD(DT)                                                                                     \
+    {                                                                                                              \
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_render_bwd<DT>),                      \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);            \
+        SCANERF_REQUIRE(e == hipSuccess, "render_backward: cannot reserve %zu B of LDS: %s", lds_bytes,             \
+                        hipGetErrorString(e));                                                                     \
+        hipLaunchKernelGGL((k_render_bwd<DT>), dim3(blocks), dim3(kBwdThreads), lds_bytes, st, a);                  \
+    }
+    if (feat_dtype == SCANERF_F32) SCANERF_LAUNCH_BWD(SCANERF_F32)
+    else if (feat_dtype == SCANERF_F16) SCANERF_LAUNCH_BWD(SCANERF_F16)
+    else SCANERF_LAUNCH_BWD(SCANERF_BF16)
+#undef SCANERF_LAUNCH_BWD
+    return 0;
+}
+}  // namespace scanerf
+
 // ---------------------------------------------------------------------------- C ABI
 SCANERF_API int scanerf_render_backward_grid(int B) { return B > kNumCU ? kNumCU : (B < 1 ? 1 : B); }
 
@@ -652,10 +636,12 @@ SCANERF_API int scanerf_render_backward(const float *rays_o, const float *rays_d
     }
     a.grad_out = grad_out; a.tile_T = tile_T; a.dfeat = dfeat; a.dw_partial = dw_partial; a.xstash = xstash;
     a.g_dnorm = g_dnorm; a.g_rowsum = g_rowsum;
+    SCANERF_REQUIRE(cfg->arith == SCANERF_ARITH_F32 || cfg->arith == SCANERF_ARITH_H3, "render_backward: arith=%d", cfg->arith);
+    const bool h3 = cfg->arith == SCANERF_ARITH_H3;
     const int blocks = scanerf_render_backward_grid(B);
-    size_t lds_bytes = (size_t)kBwdLdsFloats * sizeof(float);
+    size_t lds_extra = 0;
     a.recs = nullptr;
-    if (scatter_ws) {  // planned by scanerf_render_scatter_plan on the same (B, S, T) and inputs
+    if (scatter_ws) {  // planned by scanerf_render_scatter_plan on the same (B, S, T), cfg and inputs
         SCANERF_REQUIRE(grad_features, "render_backward: grad_features is required with a scatter workspace");
         SCANERF_REQUIRE(scanerf_render_scatter_workspace_bytes(B, S, T) != 0,
                         "render_backward: fused scatter does not support B=%d S=%d T=%d", B, S, T);
@@ -665,29 +651,21 @@ SCANERF_API int scanerf_render_backward(const float *rays_o, const float *rays_d
         a.bins.NB = T >> a.bins.bucket_log;
         a.bins.W = blocks;
         a.bins.per_wg = 0;
+        a.bins.rpg = h3 ? 4 : 1;
         BinWorkspace w;
         SCANERF_REQUIRE(bin_workspace_carve(scatter_ws, scatter_ws_bytes, 16 * a.bins.NB, blocks, w),
                         "render_backward: scatter workspace too small (%zu B)", scatter_ws_bytes);
         a.bins.capacity = w.capacity;
         a.bin_rowprefix = w.counts; a.bin_starts = w.starts; a.recs = w.recs; a.maxbits = w.maxbits;
         a.grad_features = grad_features;
-        lds_bytes += (size_t)16 * a.bins.NB * sizeof(uint32_t);
+        lds_extra = (size_t)16 * a.bins.NB * sizeof(uint32_t);
     }
     hipStream_t st = (hipStream_t)stream;
     hipError_t me = hipMemsetAsync(dw_partial, 0, (size_t)blocks * 4 * SCANERF_PARAMSIZE * sizeof(float), st);
     SCANERF_REQUIRE(me == hipSuccess, "render_backward: memset failed: %s", hipGetErrorString(me));
-#define SCANERF_LAUNCH_BWD(DT)                                                                                     \
-    {                                                                                                              \
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_render_bwd<DT>),                      \
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);            \
-        SCANERF_REQUIRE(e == hipSuccess, "render_backward: cannot reserve %zu B of LDS: %s", lds_bytes,             \
-                        hipGetErrorString(e));                                                                     \
-        hipLaunchKernelGGL((k_render_bwd<DT>), dim3(blocks), dim3(kBwdThreads), lds_bytes, st, a);                  \
-    }
-    if (feat_dtype == SCANERF_F32) SCANERF_LAUNCH_BWD(SCANERF_F32)
-    else if (feat_dtype == SCANERF_F16) SCANERF_LAUNCH_BWD(SCANERF_F16)
-    else SCANERF_LAUNCH_BWD(SCANERF_BF16)
-#undef SCANERF_LAUNCH_BWD
+    if (int e = h3 ? launch_render_bwd_h3(a, feat_dtype, blocks, lds_extra, st)
+                   : launch_render_bwd_f32(a, feat_dtype, blocks, lds_extra, st))
+        return e;
     if (int e = check_launch("render_backward")) return e;
     hipLaunchKernelGGL(k_reduce_dw, dim3(ceil_div(SCANERF_PARAMSIZE, 256)), dim3(256), 0, st, dw_partial, blocks * 4,
                        weight_feature, grad_blob);

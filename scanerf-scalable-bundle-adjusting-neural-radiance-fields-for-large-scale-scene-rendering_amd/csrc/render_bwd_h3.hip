@@ -1,0 +1,636 @@
+// render_bwd_h3.hip -- fused per-ray volume rendering, backward, on split-f16 matrix cores (gfx950).
+//
+// Same adjoint as render_bwd.hip (hashgrid/__init__.py:512-596 under autograd in the reference) with the decoder
+// products in the h3 arithmetic of render_h3.h (three f16 MFMAs per term, f32 accumulate: 3/16 of the f32-MFMA time
+// at f32-equivalent accuracy).  With the matrix work that cheap the kernel is organised around what remains:
+//
+//   * ONE WAVE PER RAY, its 32-sample tiles walked last -> first, so the compositing adjoint's suffix sums are a
+//     register carry and NOTHING is exchanged between waves: no workgroup barrier after the prologue.
+//   * Every wave owns a full set of weight-gradient accumulators (240 registers; one wave per SIMD, 512-register
+//     budget) and flushes them once; k_reduce_dw adds the per-wave partials in a fixed order (deterministic).
+//   * Products that reduce over units  (forward recompute H = W X, activation gradients dX = W^T dY) take their B
+//     operand straight from accumulator registers; W^T comes from the SAME LDS image as W through transposed reads
+//     (h3_lda_T), so one 69 KB image serves both directions.
+//   * Products that reduce over samples (weight gradients dW = dY X^T) need the transposed register layout: the wave
+//     writes the already split f16 operands to a private 16 KB staging image and reads them back with
+//     ds_read_b64_tr_b16 (h3_stage_put / h3_stage_get, conflict-free both ways); bias gradients are row sums of the
+//     same operands (v_dot2_f32_f16).
+//   * G'(u) = -100 u G(u) is kept from the recompute (one multiply) instead of being re-derived per use.
+//   * GRADIENT RANGE.  Upstream gradients of a mean loss are ~1/(3B) and are multiplied by compositing weights down
+//     to 1e-8: far below f16's normal range (6e-5).  Every wave therefore carries a power-of-two scale 2^K: the
+//     pre-activation gradients of a tile are multiplied by it before they enter any f16 operand, so that the tile's
+//     largest one lies in [2^-8, 2^6]; K moves only when a tile leaves that window, and then all accumulators of the
+//     wave are rescaled by the (exact) power of two.  Feature gradients are unscaled per tile, the weight-gradient
+//     partials once at the flush.  MODE.FP16_OVFL clamps f32 -> f16 conversions at +-65504 instead of producing
+//     infinities, as a safety net for pathological amplification through the layers.
+#include <stdlib.h>
+
+#include "render_bwd_common.h"
+#include "render_h3.h"
+
+using namespace scanerf;
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kLdsRes = H3_BYTES;                          // resolutions [16][4] i32
+constexpr int kLdsStage = kLdsRes + 256;                   // 4 waves x {Y, X} staging matrices
+constexpr int kLdsCursor = kLdsStage + 4 * 2 * H3_STAGE_MAT;  // record cursors (fused scatter producer only)
+
+__device__ __forceinline__ void wave_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// G(u) and G'(u) of a block: u <- G(u), d <- -100 u G(u)
+__device__ __forceinline__ void act_and_deriv(v16f &u, v16f &d)
+{
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+        const float q = gauss_act(u[g]);
+        d[g] = -100.0f * u[g] * q;
+        u[g] = q;
+    }
+}
+__device__ __forceinline__ v16f mul16(const v16f &a, const v16f &b)
+{
+    v16f r;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) r[g] = a[g] * b[g];
+    return r;
+}
+
+// dX (rows 32ib..32ib+31 of the layer's input) = W^T dY over the 64 output units (row blocks 0,1 x k-steps 0,1)
+template <int NIB>
+__device__ __forceinline__ void chain64(v16f dx[NIB], const char *img, int base, int ksb, int lane, const HL2 dy[2])
+{
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+        for (int tq = 0; tq < 2; ++tq) {
+            HL a[NIB];
+#pragma unroll
+            for (int ib = 0; ib < NIB; ++ib) a[ib] = h3_lda_T(img, base, ksb, nb, tq, ib, lane);
+            H3_REGION_BEGIN();
+#pragma unroll
+            for (int ib = 0; ib < NIB; ++ib) dx[ib] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[ib].lo, dy[nb].t[tq].hi, dx[ib], 0, 0, 0);
+#pragma unroll
+            for (int ib = 0; ib < NIB; ++ib) dx[ib] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[ib].hi, dy[nb].t[tq].lo, dx[ib], 0, 0, 0);
+#pragma unroll
+            for (int ib = 0; ib < NIB; ++ib) dx[ib] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[ib].hi, dy[nb].t[tq].hi, dx[ib], 0, 0, 0);
+            H3_REGION_END();
+        }
+}
+// dX (NIB row blocks) = W^T dY for a layer with ONE 32-row output block whose live rows sit in k-step 0 (heads, rgb)
+template <int NIB>
+__device__ __forceinline__ void chain_narrow(v16f dx[NIB], const char *img, int base, int ksb, int lane, const HL &dy)
+{
+    HL a[NIB];
+#pragma unroll
+    for (int ib = 0; ib < NIB; ++ib) a[ib] = h3_lda_T(img, base, ksb, 0, 0, ib, lane);
+    H3_REGION_BEGIN();
+#pragma unroll
+    for (int ib = 0; ib < NIB; ++ib) mma3(dx[ib], a[ib], dy);
+    H3_REGION_END();
+}
+
+// Weight gradient of a layer from the staged operands: acc[nb][kb] += dY[nb] X[kb]^T (NKB = 1 or 2 input blocks);
+// rowsum[nb] += sum_s dY[nb][.][s] over this half-wave's samples (lane = unit).
+template <int NKB>
+__device__ __forceinline__ void wgrad64(v16f acc[2][NKB], float rowsum[2], const char *stY, const char *stX, int lane)
+{
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        HL a[2], b[NKB];
+        a[0] = h3_stage_get(stY, lane, 0, t);
+        a[1] = h3_stage_get(stY, lane, 1, t);
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb) b[kb] = h3_stage_get(stX, lane, kb, t);
+        rowsum[0] = h3_sum8(a[0], rowsum[0]);
+        rowsum[1] = h3_sum8(a[1], rowsum[1]);
+        H3_REGION_BEGIN();
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+            for (int kb = 0; kb < NKB; ++kb)
+                acc[nb][kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[nb].lo, b[kb].hi, acc[nb][kb], 0, 0, 0);
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+            for (int kb = 0; kb < NKB; ++kb)
+                acc[nb][kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[nb].hi, b[kb].lo, acc[nb][kb], 0, 0, 0);
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+            for (int kb = 0; kb < NKB; ++kb)
+                acc[nb][kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[nb].hi, b[kb].hi, acc[nb][kb], 0, 0, 0);
+        H3_REGION_END();
+    }
+}
+
+template <int DT>
+__global__ void __launch_bounds__(kThreads, 1) k_render_bwd_h3(BwdArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    int *lres = reinterpret_cast<int *>(lds + kLdsRes);
+    uint32_t *cursor = reinterpret_cast<uint32_t *>(lds + kLdsCursor);
+    {
+        const float4 *src = reinterpret_cast<const float4 *>(a.f.packed + PK_TOTAL);
+        float4 *dst = reinterpret_cast<float4 *>(lds);
+        for (int i = threadIdx.x; i < H3_BYTES / 16; i += kThreads) dst[i] = src[i];
+        if (threadIdx.x < 64) {
+            const int lv = threadIdx.x >> 2, c = threadIdx.x & 3;
+            lres[threadIdx.x] = c < 3 ? a.f.resolutions[3 * lv + c] : 0;
+        }
+        float4 *stz = reinterpret_cast<float4 *>(lds + kLdsStage);  // finite contents for the unused rows of narrow blocks
+        for (int i = threadIdx.x; i < 4 * 2 * H3_STAGE_MAT / 16; i += kThreads) stz[i] = make_float4(0, 0, 0, 0);
+        if (a.recs) {
+            const int nbins = 16 * a.bins.NB;
+            for (int i = threadIdx.x; i < nbins; i += kThreads)
+                cursor[i] = a.bin_starts[i] + a.bin_rowprefix[(size_t)i * a.bins.W + blockIdx.x];
+        }
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, sl = lane & 31, h = lane >> 5;
+    const int lo = h3_lane_off(lane);
+    char *stY = lds + kLdsStage + wv * 2 * H3_STAGE_MAT, *stX = stY + H3_STAGE_MAT;
+    const int S = a.f.S, ntiles = (S + 31) >> 5;
+    const v16f zero16 = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+    __builtin_amdgcn_s_setreg(1 | (23 << 6), 1);  // hwreg(HW_REG_MODE, 23, 1) = FP16_OVFL: f16 conversions saturate
+    int K = 0;                    // this wave's gradient scale 2^K (wave-uniform)
+    float sc = 1.0f, isc = 1.0f;
+
+    // ---- weight-gradient accumulators of this wave (row = output unit nmap(g,h) of block nb, column = input unit)
+    v16f gW_L0[2][1] = { { zero16 }, { zero16 } }, gW_D0H[2][1] = { { zero16 }, { zero16 } };
+    v16f gW_L1[2][2] = { { zero16, zero16 }, { zero16, zero16 } }, gW_D1[2][2] = { { zero16, zero16 }, { zero16, zero16 } };
+    v16f gW_head = zero16, gW_D2[2] = { zero16, zero16 };  // rows 0-6: heads; rows 8-10: rgb layer
+    float gW_D0S[2][8];                                    // [row block][j]: unit 32nb + sl, SH index 8h + j
+    float gB_L0[2] = { 0, 0 }, gB_L1[2] = { 0, 0 }, gB_D0[2] = { 0, 0 }, gB_D1[2] = { 0, 0 };  // lane = unit, this half's samples
+    float gB_head[7], gB_d2[3];                            // lane = sample
+    float gmax = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) gW_D0S[0][i] = gW_D0S[1][i] = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 7; ++i) gB_head[i] = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) gB_d2[i] = 0.0f;
+
+    const int ngroups_all = (a.f.B + 3) >> 2;
+    for (int grp = blockIdx.x; grp < ngroups_all; grp += gridDim.x) {
+        const int ray = 4 * grp + wv;
+        if (ray >= a.f.B) continue;
+        if (a.f.ray_valid && !a.f.ray_valid[ray]) {  // wave-uniform: zero feature gradients, nothing else
+            if (a.dfeat)
+                for (int s = lane >> 1; s < S; s += 32)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        reinterpret_cast<float2 *>(a.dfeat)[(size_t)(2 * j + (lane & 1)) * a.f.B * S + (size_t)ray * S + s] =
+                            make_float2(0, 0);
+            continue;
+        }
+        float o[3], d[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            o[k] = a.f.rays_o[3 * ray + k];
+            d[k] = a.f.rays_d[3 * ray + k];
+        }
+        const float dnorm = sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+        const float *go = a.grad_out + (size_t)ray * SCANERF_RAY_OUT;
+        const float *fo = a.f.out_ray + (size_t)ray * SCANERF_RAY_OUT;
+        float sh[16];
+        ray_sh(d, dnorm, sh);
+        v16f dinit[2];
+        h3_dinit(lds, lane, sh, dinit);
+        float Rcarry = 0.0f;           // sum of a_j w_j over all later tiles
+        float ray_rs[2] = { 0, 0 };    // sum over the ray's samples (this half) of dL/d(dir layer-0 pre-activation)
+
+        for (int tile = ntiles - 1; tile >= 0; --tile) {
+            const int s = tile * 32 + sl;
+            const bool live = s < S;
+            const float z = live ? a.f.z_vals[(size_t)ray * S + s] : 0.0f;
+            const float dist_i = live ? a.f.dists[(size_t)ray * S + s] : 0.0f;
+            float delta = dist_i * dnorm;
+            if (a.f.infinity && s == S - 1) delta = 1e10f;
+
+            // ================= forward recompute =================
+            v16f x;
+            if (a.xstash) {
+                const float4 *xs = reinterpret_cast<const float4 *>(a.xstash + ((size_t)ray * S + (live ? s : 0)) * 32 + 16 * h);
+                const float4 q0 = xs[0], q1 = xs[1], q2 = xs[2], q3 = xs[3];
+                x = v16f{ q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w };
+            } else {
+                float p[3];
+                contract_point(a.f, o, d, z, p);
+                encode8<DT, 8>(a.f, lres, h, p, x);
+            }
+            const HL2 xs2 = split16(x);
+            HL2 a0s[2], Hs[2], c0s[2], c1s[2];
+            v16f du0f[2], dv0f[2], dv1f[2];   // G' of the three Gaussian layers
+            {
+                v16f u[2] = { h3_bias(lds, 0, 0, h), h3_bias(lds, 0, 1, h) };
+                const HL *const B[2] = { &xs2.t[0], &xs2.t[1] };
+                h3_layer2<2>(u, lds, H3_L0, 2, lo, B);
+                act_and_deriv(u[0], du0f[0]);
+                act_and_deriv(u[1], du0f[1]);
+                a0s[0] = split16(u[0]);
+                a0s[1] = split16(u[1]);
+            }
+            {
+                v16f u[2] = { h3_bias(lds, 1, 0, h), h3_bias(lds, 1, 1, h) };
+                const HL *const B[4] = { &a0s[0].t[0], &a0s[0].t[1], &a0s[1].t[0], &a0s[1].t[1] };
+                h3_layer2<4>(u, lds, H3_L1, 4, lo, B);
+                Hs[0] = split16(u[0]);
+                Hs[1] = split16(u[1]);
+            }
+            float sigma, dsig_dpre, dif[3], tint[3], spec[3];
+            {
+                v16f u = h3_ld16(lds, H3_HB);
+                const HL *const B[2] = { &Hs[0].t[0], &Hs[0].t[1] };
+                h3_layer1<2>(u, lds, H3_HEAD, lo, B);
+                sigma = softplus_(u[0]);
+                dsig_dpre = u[0] > 20.0f ? 1.0f : sigmoid_(u[0]);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    dif[c] = sigmoid_(u[1 + c]);
+                    tint[c] = sigmoid_(u[4 + c]);
+                }
+            }
+            {
+                v16f u[2] = { dinit[0], dinit[1] };
+                const HL *const B[2] = { &Hs[1].t[0], &Hs[1].t[1] };
+                h3_layer2<2>(u, lds, H3_D0, 3, lo, B);
+                act_and_deriv(u[0], dv0f[0]);
+                act_and_deriv(u[1], dv0f[1]);
+                c0s[0] = split16(u[0]);
+                c0s[1] = split16(u[1]);
+            }
+            {
+                v16f u[2] = { h3_bias(lds, 3, 0, h), h3_bias(lds, 3, 1, h) };
+                const HL *const B[4] = { &c0s[0].t[0], &c0s[0].t[1], &c0s[1].t[0], &c0s[1].t[1] };
+                h3_layer2<4>(u, lds, H3_D1, 4, lo, B);
+                act_and_deriv(u[0], dv1f[0]);
+                act_and_deriv(u[1], dv1f[1]);
+                c1s[0] = split16(u[0]);
+                c1s[1] = split16(u[1]);
+            }
+            {
+                v16f u = h3_ld16(lds, H3_D2B);
+                const HL *const B[4] = { &c1s[0].t[0], &c1s[0].t[1], &c1s[1].t[0], &c1s[1].t[1] };
+                h3_layer1<4>(u, lds, H3_D2, lo, B);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) spec[c] = sigmoid_(u[c]);
+            }
+
+            // ================= compositing: recompute and adjoint =================
+            const float ex = live ? expf(-sigma * delta) : 1.0f;  // 1 - alpha
+            const float alpha = 1.0f - ex;
+            const float fi = 1.0f - alpha + 1e-6f;
+            float incl = fi;
+#pragma unroll
+            for (int off = 1; off < 32; off <<= 1) {
+                const float t = __shfl_up(incl, off, 32);
+                if (sl >= off) incl *= t;
+            }
+            float excl = __shfl_up(incl, 1, 32);
+            if (sl == 0) excl = 1.0f;
+            const float Ti = a.tile_T[(size_t)ray * ntiles + tile] * excl;
+            const float w = alpha * Ti;
+            float gD[3], gS[3], gTi[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float pre = fo[5 + c] + fo[8 + c];  // diffuse + specular before the clamp
+                const float grgb = (pre >= 0.0f && pre <= 1.0f) ? go[c] : 0.0f;
+                gD[c] = go[5 + c] + grgb;
+                gS[c] = go[8 + c] + grgb;
+                gTi[c] = go[11 + c];
+            }
+            const float gDepth = go[3], gTl = go[4], gW2 = go[14], Tl = fo[4];
+            float ai = gDepth * z;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) ai += gD[c] * dif[c] + gS[c] * tint[c] * spec[c] + gTi[c] * tint[c];
+            const float aw = live ? ai * w : 0.0f;
+            float rs = aw;  // inclusive suffix sum inside the tile
+#pragma unroll
+            for (int off = 1; off < 32; off <<= 1) {
+                const float t = __shfl_down(rs, off, 32);
+                if (sl + off < 32) rs += t;
+            }
+            const float suffix = Rcarry + rs - aw;
+            Rcarry += __shfl(rs, 0, 32);
+            float dalpha = Ti * ai - (suffix + ((s < S - 1) ? gTl * Tl : 0.0f)) / fi;
+            if (!live) dalpha = 0.0f;
+            const float dsigma = dalpha * delta * ex;
+            if (a.g_dnorm) {
+                const float dd = (a.f.infinity && s == S - 1) ? 0.0f : dist_i;  // the infinity sample's delta is a constant
+                const float gd = half_sum(dalpha * sigma * ex * dd);
+                if (lane == 0) a.g_dnorm[(size_t)ray * ntiles + tile] = gd;
+            }
+            float gh[7], gs3[3];  // gradients w.r.t. the head / rgb pre-activations
+            gh[0] = dsigma * dsig_dpre;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                gh[1 + c] = w * gD[c] * dif[c] * (1.0f - dif[c]);
+                gh[4 + c] = w * (gS[c] * spec[c] + gTi[c]) * tint[c] * (1.0f - tint[c]);
+                gs3[c] = (w * gS[c] * tint[c] + gW2 * w * 2.0f * spec[c]) * spec[c] * (1.0f - spec[c]);
+            }
+            {   // gradient scale of the wave (see the header): keep the tile's largest |gradient| * 2^K in [2^-8, 2^6]
+                float mx = 0.0f;
+#pragma unroll
+                for (int c = 0; c < 7; ++c) mx = fmaxf(mx, fabsf(gh[c]));
+#pragma unroll
+                for (int c = 0; c < 3; ++c) mx = fmaxf(mx, fabsf(gs3[c]));
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+                mx = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, mx)));
+                const float ms = mx * sc;
+                if (mx > 0.0f && mx < 3.0e38f && (ms > 64.0f || ms < 0.00390625f)) {
+                    int e;
+                    frexpf(mx, &e);  // mx = f * 2^e, f in [0.5, 1)
+                    int Kn = -e;
+                    Kn = Kn > K + 100 ? K + 100 : (Kn < K - 100 ? K - 100 : Kn);  // rescale factor stays an f32 power of two
+                    Kn = Kn > 100 ? 100 : (Kn < -100 ? -100 : Kn);
+                    const float r = ldexpf(1.0f, Kn - K);
+                    K = Kn;
+                    sc = ldexpf(1.0f, K);
+                    isc = ldexpf(1.0f, -K);
+#pragma unroll
+                    for (int nb = 0; nb < 2; ++nb) {
+                        gW_L0[nb][0] *= r; gW_D0H[nb][0] *= r; gW_D2[nb] *= r;
+                        gW_L1[nb][0] *= r; gW_L1[nb][1] *= r; gW_D1[nb][0] *= r; gW_D1[nb][1] *= r;
+                        gB_L0[nb] *= r; gB_L1[nb] *= r; gB_D0[nb] *= r; gB_D1[nb] *= r; ray_rs[nb] *= r;
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) gW_D0S[nb][j] *= r;
+                    }
+                    gW_head *= r;
+#pragma unroll
+                    for (int c = 0; c < 7; ++c) gB_head[c] *= r;
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) gB_d2[c] *= r;
+                }
+#pragma unroll
+                for (int c = 0; c < 7; ++c) gh[c] *= sc;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) gs3[c] *= sc;
+            }
+#pragma unroll
+            for (int c = 0; c < 7; ++c) gB_head[c] += gh[c];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) gB_d2[c] += gs3[c];
+
+            // ================= narrow layers: rgb (64 -> 3) and heads (32 -> 7) =================
+            // one staged 32-row block: rows 0-3 sigma,dif; 4-6 tint; 8-10 rgb (k-slot <-> row as the weight images)
+            HL nar;      // B operand of the transposed products: half 0 carries the rows, half 1 zeros (its rows are replicas)
+            HL narrgb;
+            {
+                v16f t16 = zero16, r16 = zero16;
+                if (h == 0) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) t16[c] = gh[c];
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        t16[4 + c] = gh[4 + c];  // slot j = 4..6 of half 0 <-> image rows 8..10
+                        r16[c] = gs3[c];
+                    }
+                }
+                nar = split8(t16, 0);
+                narrgb = split8(r16, 0);
+                // staging: unit u of the block = row u: chunk uq0 = rows 0-3, uq1 = rows 4-7, uq2 = rows 8-11
+                v16f st = zero16;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) st[c] = h == 0 ? gh[c] : (c < 3 ? gh[4 + c] : 0.0f);
+                const HL stq = split8(st, 0);
+                v16f st2 = zero16;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) st2[c] = h == 0 ? gs3[c] : 0.0f;
+                const HL stq2 = split8(st2, 0);
+                const int o0 = h3_stage_off(sl, h), o1 = h3_stage_off(sl, 2 + h);
+                *reinterpret_cast<h4 *>(stY + o0) = h4{ stq.hi[0], stq.hi[1], stq.hi[2], stq.hi[3] };
+                *reinterpret_cast<h4 *>(stY + H3_STAGE_PART + o0) = h4{ stq.lo[0], stq.lo[1], stq.lo[2], stq.lo[3] };
+                *reinterpret_cast<h4 *>(stY + o1) = h4{ stq2.hi[0], stq2.hi[1], stq2.hi[2], stq2.hi[3] };
+                *reinterpret_cast<h4 *>(stY + H3_STAGE_PART + o1) = h4{ stq2.lo[0], stq2.lo[1], stq2.lo[2], stq2.lo[3] };
+            }
+            h3_stage_put(stX, lane, 0, c1s[0]);
+            h3_stage_put(stX, lane, 1, c1s[1]);
+            wave_lds_sync();
+            HL na[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                na[t] = h3_stage_get(stY, lane, 0, t);
+                const HL b0 = h3_stage_get(stX, lane, 0, t), b1 = h3_stage_get(stX, lane, 1, t);
+                H3_REGION_BEGIN();
+                mma3(gW_D2[0], na[t], b0);
+                mma3(gW_D2[1], na[t], b1);
+                H3_REGION_END();
+            }
+            wave_lds_sync();
+            h3_stage_put(stX, lane, 0, Hs[0]);
+            wave_lds_sync();
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const HL b0 = h3_stage_get(stX, lane, 0, t);
+                H3_REGION_BEGIN();
+                mma3(gW_head, na[t], b0);
+                H3_REGION_END();
+            }
+            // dv1 = (W_rgb^T gs3) * G'(v1)
+            HL2 dys[2];
+            {
+                v16f dc[2] = { zero16, zero16 };
+                chain_narrow<2>(dc, lds, H3_D2, 4, lane, narrgb);
+                dys[0] = split16(mul16(dc[0], dv1f[0]));
+                dys[1] = split16(mul16(dc[1], dv1f[1]));
+            }
+            // ================= Directional_MLP.mlp.2 (64 -> 64) =================
+            wave_lds_sync();
+            h3_stage_put(stY, lane, 0, dys[0]);
+            h3_stage_put(stY, lane, 1, dys[1]);
+            h3_stage_put(stX, lane, 0, c0s[0]);
+            h3_stage_put(stX, lane, 1, c0s[1]);
+            wave_lds_sync();
+            wgrad64<2>(gW_D1, gB_D1, stY, stX, lane);
+            {
+                v16f dc[2] = { zero16, zero16 };
+                chain64<2>(dc, lds, H3_D1, 4, lane, dys);
+                dys[0] = split16(mul16(dc[0], dv0f[0]));   // dv0
+                dys[1] = split16(mul16(dc[1], dv0f[1]));
+            }
+            // ================= Directional_MLP.mlp.0 (32 of its 48 inputs; the SH part per ray) =================
+            wave_lds_sync();
+            h3_stage_put(stY, lane, 0, dys[0]);
+            h3_stage_put(stY, lane, 1, dys[1]);
+            h3_stage_put(stX, lane, 0, Hs[1]);
+            wave_lds_sync();
+            {
+                float rsum[2] = { 0, 0 };
+                wgrad64<1>(gW_D0H, rsum, stY, stX, lane);
+                gB_D0[0] += rsum[0];
+                gB_D0[1] += rsum[1];
+                ray_rs[0] += rsum[0];
+                ray_rs[1] += rsum[1];
+            }
+            v16f dH[2] = { zero16, zero16 };
+            {
+                v16f dc[1] = { zero16 };
+                chain64<1>(dc, lds, H3_D0, 3, lane, dys);
+                dH[1] = dc[0];
+                v16f dh0[1] = { zero16 };
+                chain_narrow<1>(dh0, lds, H3_HEAD, 2, lane, nar);
+                dH[0] = dh0[0];
+            }
+            // ================= Spatial_MLP.mlp.2 (64 -> 64, linear) =================
+            dys[0] = split16(dH[0]);
+            dys[1] = split16(dH[1]);
+            wave_lds_sync();
+            h3_stage_put(stY, lane, 0, dys[0]);
+            h3_stage_put(stY, lane, 1, dys[1]);
+            h3_stage_put(stX, lane, 0, a0s[0]);
+            h3_stage_put(stX, lane, 1, a0s[1]);
+            wave_lds_sync();
+            wgrad64<2>(gW_L1, gB_L1, stY, stX, lane);
+            {
+                v16f dc[2] = { zero16, zero16 };
+                chain64<2>(dc, lds, H3_L1, 4, lane, dys);
+                dys[0] = split16(mul16(dc[0], du0f[0]));   // du0
+                dys[1] = split16(mul16(dc[1], du0f[1]));
+            }
+            // ================= Spatial_MLP.mlp.0 (32 -> 64) =================
+            wave_lds_sync();
+            h3_stage_put(stY, lane, 0, dys[0]);
+            h3_stage_put(stY, lane, 1, dys[1]);
+            h3_stage_put(stX, lane, 0, xs2);
+            wave_lds_sync();
+            wgrad64<1>(gW_L0, gB_L0, stY, stX, lane);
+            v16f dxa[1] = { zero16 };
+            chain64<1>(dxa, lds, H3_L0, 2, lane, dys);
+            const v16f dx = dxa[0] * isc;
+            wave_lds_sync();  // the next tile's staging writes come after this tile's reads
+
+            // ================= feature gradients =================
+            // register 2j+f of half h = level 4(j>>1)+2h+(j&1), feature f
+            if (live && a.dfeat) {
+                const size_t n = (size_t)ray * S + s, NS = (size_t)a.f.B * S;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int level = 4 * (j >> 1) + 2 * h + (j & 1);
+                    reinterpret_cast<float2 *>(a.dfeat)[(size_t)level * NS + n] = make_float2(dx[2 * j], dx[2 * j + 1]);
+                }
+            }
+            if (live && a.recs) {  // fused scatter producer (scatter.hip): records into the ranges the plan reserved
+                float pe[3];
+                contract_point(a.f, o, d, z, pe);
+                const uint32_t mask = (uint32_t)a.f.T - 1u;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int level = 4 * (j >> 1) + 2 * h + (j & 1);
+                    gmax = fmaxf(gmax, fmaxf(fabsf(dx[2 * j]), fabsf(dx[2 * j + 1])));
+                    Pairs pr;
+                    make_pairs(pe, lres + 4 * level, mask, pr);
+                    emit_pairs(pr, dx[2 * j], dx[2 * j + 1], cursor + level * a.bins.NB, a.bins.bucket_log,
+                               a.bins.capacity, a.recs, a.grad_features + (size_t)level * a.f.T * 2);
+                }
+            }
+        }
+        // ---- per-ray: SH part of Directional_MLP.mlp.0's weight gradient, pose-gradient row sums
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+            const float r = ray_rs[nb] + __shfl_xor(ray_rs[nb], 32, 64);  // all 32 samples x all tiles, lane = unit 32nb + sl
+#pragma unroll
+            for (int j = 0; j < 8; ++j) gW_D0S[nb][j] = fmaf(r, h ? sh[8 + j] : sh[j], gW_D0S[nb][j]);
+            if (a.g_rowsum && h == 0) {
+                a.g_rowsum[((size_t)ray * 2 + 0) * 64 + 32 * nb + sl] = r * isc;
+                a.g_rowsum[((size_t)ray * 2 + 1) * 64 + 32 * nb + sl] = 0.0f;
+            }
+        }
+    }
+
+    if (a.recs) {  // launch-wide max |dL/dfeature| for the fixed-point scale of the accumulate pass
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) gmax = fmaxf(gmax, __shfl_xor(gmax, off, 64));
+        if (lane == 0 && gmax > 0.0f) atomicMax(a.maxbits, __float_as_uint(gmax));
+    }
+    // ---- flush this wave's partial sums in blob order
+    float *out = a.dw_partial + (size_t)(blockIdx.x * 4 + wv) * SCANERF_PARAMSIZE;
+    const int k = sl;
+    auto put_w = [&](const v16f &acc, int base, int nb, int kb) {
+#pragma unroll
+        for (int g = 0; g < 16; ++g) out[base + 64 + (32 * kb + k) * 64 + 32 * nb + nmap(g, h)] = acc[g] * isc;
+    };
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+        put_w(gW_L0[nb][0], BLOB_S0, nb, 0);
+        put_w(gW_D0H[nb][0], BLOB_D0, nb, 0);
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            put_w(gW_L1[nb][kb], BLOB_S1, nb, kb);
+            put_w(gW_D1[nb][kb], BLOB_D1, nb, kb);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) out[BLOB_D0 + 64 + (32 + 8 * h + j) * 64 + 32 * nb + k] = gW_D0S[nb][j] * isc;
+        float v;
+        v = (gB_L0[nb] + __shfl_xor(gB_L0[nb], 32, 64)) * isc;
+        if (h == 0) out[BLOB_S0 + 32 * nb + k] = v;
+        v = (gB_L1[nb] + __shfl_xor(gB_L1[nb], 32, 64)) * isc;
+        if (h == 0) out[BLOB_S1 + 32 * nb + k] = v;
+        v = (gB_D0[nb] + __shfl_xor(gB_D0[nb], 32, 64)) * isc;
+        if (h == 0) out[BLOB_D0 + 32 * nb + k] = v;
+        v = (gB_D1[nb] + __shfl_xor(gB_D1[nb], 32, 64)) * isc;
+        if (h == 0) out[BLOB_D1 + 32 * nb + k] = v;
+    }
+    // heads: rows 0-3 (half 0, registers 0-3) sigma,dif; rows 4-6 (half 1, registers 0-2) tint; column = H unit k
+    if (h == 0) {
+        out[BLOB_SIG + 1 + k] = gW_head[0] * isc;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) out[BLOB_DIF + 3 + k * 3 + c] = gW_head[1 + c] * isc;
+    } else {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) out[BLOB_TINT + 3 + k * 3 + c] = gW_head[c] * isc;
+    }
+    // rgb layer: rows 8-10 = half 0, registers 4-6; column = unit 32kb + k
+    if (h == 0) {
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) out[BLOB_D2 + 3 + (32 * kb + k) * 3 + c] = gW_D2[kb][4 + c] * isc;
+    }
+#pragma unroll
+    for (int c = 0; c < 7; ++c) {
+        const float b = half_sum(gB_head[c]) * isc;
+        if (lane == 0) {
+            if (c == 0) out[BLOB_SIG] = b;
+            else if (c < 4) out[BLOB_DIF + c - 1] = b;
+            else out[BLOB_TINT + c - 4] = b;
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float b = half_sum(gB_d2[c]) * isc;
+        if (lane == 0) out[BLOB_D2 + c] = b;
+    }
+}
+
+}  // namespace
+
+namespace scanerf {
+
+int launch_render_bwd_h3(const BwdArgs &a, int feat_dtype, int blocks, size_t lds_extra, hipStream_t st)
+{
+    const size_t lds_bytes = (size_t)kLdsCursor + lds_extra;
+    SCANERF_REQUIRE(lds_bytes <= 160 * 1024, "render_backward(h3): %zu B of LDS needed (table too large for the fused scatter)", lds_bytes);
+#define SCANERF_LAUNCH_BWD(DT)                                                                                     \
+    {                                                                                                              \
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_render_bwd_h3<DT>),                   \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);            \
+        SCANERF_REQUIRE(e == hipSuccess, "render_backward(h3): cannot reserve %zu B of LDS: %s", lds_bytes,         \
+                        hipGetErrorString(e));                                                                     \
+        hipLaunchKernelGGL((k_render_bwd_h3<DT>), dim3(blocks), dim3(kThreads), lds_bytes, st, a);                  \
+    }
+    if (feat_dtype == SCANERF_F32) SCANERF_LAUNCH_BWD(SCANERF_F32)
+    else if (feat_dtype == SCANERF_F16) SCANERF_LAUNCH_BWD(SCANERF_F16)
+    else SCANERF_LAUNCH_BWD(SCANERF_BF16)
+#undef SCANERF_LAUNCH_BWD
+    return 0;
+}
+
+}  // namespace scanerf

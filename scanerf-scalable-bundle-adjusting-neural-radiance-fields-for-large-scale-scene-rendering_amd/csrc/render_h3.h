@@ -74,9 +74,7 @@ __device__ __forceinline__ HL2 split16(const v16f &v)
 // MFMA direction).  So every group of MFMAs is a closed scheduling region: operands are complete before it, nothing
 // else is inside it, and two wait states follow it.  The A operands of the NEXT group are loaded in front of the region
 // (their LDS latency hides under the MFMAs); VALU work overlaps through the other waves of the SIMD.
-struct A2 {
-    h8 hi, lo;
-};
+typedef HL A2;  // an A operand (weights): the same pair of parts
 __device__ __forceinline__ A2 h3_lda(const char *sub)  // `sub` = address of this lane's 16 B of the hi part
 {
     A2 a;
@@ -149,6 +147,82 @@ __device__ __forceinline__ v16f h3_ld16(const char *img, int byte_off)  // 16 f3
 __device__ __forceinline__ v16f h3_bias(const char *img, int layer, int blk, int h)
 {
     return h3_ld16(img, H3_BIAS + (((layer * 2 + blk) * 2 + h) * 16) * 4);
+}
+
+// ------------------------------------------------------------------ backward primitives
+typedef short s4v __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) s4v lds_s4v;
+
+// ds_read_b64_tr_b16: per 16-lane group a block of 4 rows x 16 columns of 16-bit elements, delivered column-major.
+// Lane 4q+p of the group supplies the address of row q, columns 4p..4p+3 (8 bytes); lane i receives column i,
+// row q in element q.  EXEC must be all ones.
+__device__ __forceinline__ h4 ds_tr4(const char *p)
+{
+    const s4v v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4v *)(p));
+    return __builtin_bit_cast(h4, v);
+}
+__device__ __forceinline__ h8 cat44(h4 a, h4 b) { return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7); }
+
+// A operand of a TRANSPOSED product dX = W^T dY from the forward image of a layer (ksb k-steps per row block):
+// reduction over the layer's output units n of row block nb, k-step tq (slot 8h'+j' <-> n = 32nb + ku(tq, h', j'),
+// i.e. the same slot<->unit map as B operands made from accumulator registers), output rows = input units
+// 32ib + (lane & 31).  Two transposed reads per part; conflict-free (see the header comment).
+__device__ __forceinline__ A2 h3_lda_T(const char *img, int base, int ksb, int nb, int tq, int ib, int lane)
+{
+    const int hq = lane >> 5, ti = (lane >> 4) & 1, q = (lane >> 2) & 3, p = lane & 3;
+    const int ai = p >> 1, hi = p & 1;
+    const char *a = img + base + ((nb * ksb + 2 * ib + ti) * 2) * H3_SUB + (16 * tq + 4 * hq + q) * 16 + hi * 576 + ai * 8;
+    A2 r;
+    r.hi = cat44(ds_tr4(a), ds_tr4(a + 8 * 16));
+    r.lo = cat44(ds_tr4(a + H3_SUB), ds_tr4(a + H3_SUB + 8 * 16));
+    return r;
+}
+
+// ---- per-wave staging image for products that reduce over SAMPLES (weight gradients dW = dY X^T): both operands
+// need the unit on the lane and 8 samples per k-slot group, the transpose of the register layout.  A matrix part
+// (hi or lo) of up to 64 units x 32 samples is kept as 8-byte chunks (sample s, unit quad uq) at
+//     s*128 + ((uq ^ g(s)) * 8),   g(s) = ((s >> 1) & 7) | (((s >> 1) & 1) << 3)
+// so that the writes (16 consecutive samples, one quad) and the transposed reads (4 consecutive samples x 8
+// consecutive quads) both touch 32 distinct bank pairs.
+constexpr int H3_STAGE_PART = 32 * 128;            // bytes per matrix part
+constexpr int H3_STAGE_MAT = 2 * H3_STAGE_PART;    // hi + lo
+__device__ __forceinline__ int h3_stage_off(int s, int uq) { return s * 128 + ((uq ^ (((s >> 1) & 7) | (((s >> 1) & 1) << 3))) << 3); }
+
+// registers of one 32-unit block (lane = sample) -> chunks of units 32b .. 32b+31
+__device__ __forceinline__ void h3_stage_put(char *mat, int lane, int b, const HL2 &v)
+{
+    const int s = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            const int off = h3_stage_off(s, 8 * b + 4 * t + 2 * a + h);
+            const h8 &hi = v.t[t].hi, &lo = v.t[t].lo;
+            *reinterpret_cast<h4 *>(mat + off) = h4{ hi[4 * a], hi[4 * a + 1], hi[4 * a + 2], hi[4 * a + 3] };
+            *reinterpret_cast<h4 *>(mat + H3_STAGE_PART + off) = h4{ lo[4 * a], lo[4 * a + 1], lo[4 * a + 2], lo[4 * a + 3] };
+        }
+}
+// operand (A or B alike) of k-step t for units 32b + (lane & 31): slot 8h + j <-> sample 16t + 8h + j
+__device__ __forceinline__ HL h3_stage_get(const char *mat, int lane, int b, int t)
+{
+    const int h = lane >> 5, g16 = (lane >> 4) & 1, q = (lane >> 2) & 3, p = lane & 3;
+    const int uq = 8 * b + 4 * g16 + p, s0 = 16 * t + 8 * h + q;
+    const int o0 = h3_stage_off(s0, uq), o1 = h3_stage_off(s0 + 4, uq);
+    HL r;
+    r.hi = cat44(ds_tr4(mat + o0), ds_tr4(mat + o1));
+    r.lo = cat44(ds_tr4(mat + H3_STAGE_PART + o0), ds_tr4(mat + H3_STAGE_PART + o1));
+    return r;
+}
+// sum of the 8 slots of an operand (for bias gradients): hi and lo parts, f32 accumulate
+__device__ __forceinline__ float h3_sum8(const HL &v, float acc)
+{
+    const h2v one = { (_Float16)1.0f, (_Float16)1.0f };
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        acc = __builtin_amdgcn_fdot2(h2v{ v.lo[2 * q], v.lo[2 * q + 1] }, one, acc, false);
+        acc = __builtin_amdgcn_fdot2(h2v{ v.hi[2 * q], v.hi[2 * q + 1] }, one, acc, false);
+    }
+    return acc;
 }
 
 // Dir layer-0 accumulator start of one ray: bias + W[:, 32:48] SH(dir)   (one k-step per block)

@@ -238,10 +238,13 @@ __global__ void __launch_bounds__(1024) k_bin_count_rays(RenderArgs f, BinGeom g
     for (int i = threadIdx.x; i < nbins; i += 1024) hist[i] = 0;
     __syncthreads();
     const uint32_t mask = (uint32_t)f.T - 1u;
-    const int G = gridDim.x, w = blockIdx.x;
-    const int nrays = w < f.B ? (f.B - w + G - 1) / G : 0;
-    for (int idx = threadIdx.x; idx < nrays * f.S; idx += 1024) {
-        const int ray = w + (idx / f.S) * G, s = idx % f.S;
+    const int G = gridDim.x, w = blockIdx.x, R = g.rpg;
+    const int ngroups_all = (f.B + R - 1) / R;                          // ray groups of the launch
+    const int ngroups = w < ngroups_all ? (ngroups_all - w + G - 1) / G : 0;  // ... visited by this workgroup
+    for (int idx = threadIdx.x; idx < ngroups * R * f.S; idx += 1024) {
+        const int lr = idx / f.S, s = idx % f.S;
+        const int ray = (w + (lr / R) * G) * R + lr % R;
+        if (ray >= f.B) continue;
         if (f.ray_valid && !f.ray_valid[ray]) continue;
         float o[3], d[3], p[3];
 #pragma unroll
@@ -262,7 +265,7 @@ __global__ void __launch_bounds__(1024) k_bin_count_rays(RenderArgs f, BinGeom g
 
 // bin geometry of the fused producer: W = the backward kernel's grid, buckets sized so that the
 // 16*NB cursors fit next to the backward kernel's LDS image (NB <= 256)
-bool fused_geom(int B, int S, int T, BinGeom &g)
+bool fused_geom(int B, int S, int T, BinGeom &g, int arith = SCANERF_ARITH_F32)
 {
     if (B < 1 || S < 1 || T < 2 || (T & (T - 1))) return false;
     const int lt = bin_ilog2(T);
@@ -273,6 +276,7 @@ bool fused_geom(int B, int S, int T, BinGeom &g)
     g.NB = T >> g.bucket_log;
     g.W = scanerf_render_backward_grid(B);
     g.per_wg = 0;
+    g.rpg = arith == SCANERF_ARITH_H3 ? 4 : 1;
     g.capacity = 0;
     return true;
 }
@@ -357,8 +361,9 @@ SCANERF_API int scanerf_render_scatter_plan(const float *rays_o, const float *ra
     SCANERF_REQUIRE(B >= 0 && S >= 1, "render_scatter_plan: B=%d S=%d", B, S);
     if (B == 0) return 0;
     BinGeom g;
-    SCANERF_REQUIRE(fused_geom(B, S, T, g), "render_scatter_plan: shape B=%d S=%d T=%d not supported", B, S, T);
-    SCANERF_REQUIRE(rays_o && rays_d && z_vals && resolutions && cfg && workspace, "render_scatter_plan: null pointer");
+    SCANERF_REQUIRE(cfg, "render_scatter_plan: cfg is null");
+    SCANERF_REQUIRE(fused_geom(B, S, T, g, cfg->arith), "render_scatter_plan: shape B=%d S=%d T=%d not supported", B, S, T);
+    SCANERF_REQUIRE(rays_o && rays_d && z_vals && resolutions && workspace, "render_scatter_plan: null pointer");
     SCANERF_REQUIRE(((uintptr_t)workspace & 15) == 0, "render_scatter_plan: workspace must be 16-byte aligned");
     const int nbins = 16 * g.NB;
     BinWorkspace w;

@@ -14,6 +14,7 @@ struct BinGeom {
     int NB;           // buckets per level = T >> bucket_log
     int W;            // producer workgroups
     int per_wg;       // samples per producer workgroup
+    int rpg;          // fused producer: rays per workgroup visit (ray = (wg + i*W)*rpg + r): 1 f32 kernel, 4 h3 kernel
     uint32_t capacity;  // records that fit the workspace
 };
 

@@ -295,6 +295,30 @@ def test_render_forward_vs_oracle(S, bg, S_):
     _check_render(out, w, ref, f"bg={bg} S={S_}")
 
 
+def test_h3_backward_primitives(S):
+    """csrc/render_h3.h: transposed image reads (dX = W^T dY) and staged sample-reduction products (dW = dY X^T)
+    of the split-f16 arithmetic against float64."""
+    import ctypes
+    from scanerf_amd import network, render
+    from scanerf_amd._capi import check, lib, stream
+    rng = np.random.default_rng(21)
+    sd = O.init_mlp(seed=5, bias_scale=0.05)
+    pk = render.PackedDecoder(DEV).pack(O.pack_blob(sd).to(DEV), torch.ones(32, device=DEV))
+    dy = rng.normal(size=(64, 32)).astype(np.float32)
+    x = (rng.normal(size=(64, 32)) * rng.uniform(0.01, 2.0, (64, 1))).astype(np.float32)
+    dx, dw, rs = torch.zeros(2, 64, 32, device=DEV), torch.zeros(64, 64, device=DEV), torch.zeros(64, device=DEV)
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    DY, X = g(dy), g(x)
+    check(lib().scanerf_h3_selftest(p(pk.workspace), p(DY), p(X), p(dx), p(dw), p(rs), stream()), "h3_selftest")
+    W1 = sd["Spatial_MLP.mlp.2.weight"].double().numpy()
+    Wd0 = sd["Directional_MLP.mlp.0.weight"].double().numpy()[:, :32]
+    d64 = dy.astype(np.float64)
+    np.testing.assert_allclose(dx[0].cpu().numpy(), W1.T @ d64, rtol=2e-6, atol=2e-6)
+    np.testing.assert_allclose(dx[1, :32].cpu().numpy(), Wd0.T @ d64, rtol=2e-6, atol=2e-6)
+    np.testing.assert_allclose(dw.cpu().numpy(), d64 @ x.astype(np.float64).T, rtol=2e-6, atol=1e-5)
+    np.testing.assert_allclose(rs.cpu().numpy(), d64.sum(1), rtol=1e-5, atol=1e-5)
+
+
 def test_render_forward_golden_g6(S, golden):
     """The fused kernel against outputs of the REFERENCE's render_batch_rays (fixture G6)."""
     from scanerf_amd import network, render
@@ -412,6 +436,52 @@ def test_render_backward_vs_oracle_autograd(S, bg, S_):
     gF_ref = F.grad.numpy()
     fs = np.abs(gF_ref).max()
     np.testing.assert_allclose(gF / fs, gF_ref / fs, rtol=2e-3, atol=2e-5)
+
+
+@pytest.mark.parametrize("arith", ["f32", "h3"])
+@pytest.mark.parametrize("B,S_", [(1000, 64), (37, 128), (4099, 40)])
+def test_fused_scatter_equals_dfeat_scatter(S, arith, B, S_):
+    """Fused table-gradient path (scatter_plan -> render_backward emits the records -> scatter_accumulate) against
+    the dfeat round trip through the stand-alone binned scatter, same backward kernel, both decoder arithmetics."""
+    from scanerf_amd import network, render
+    from scanerf_amd.tile_model import TileModel
+    render.set_arith(arith)
+    try:
+        torch.manual_seed(5)
+        m = TileModel([-4, -4, -4], [8, 8, 8], DEV, log2_T=14, seed=2)
+        with torch.no_grad():
+            m.features.mul_(30.0)
+        o = torch.rand(B, 3, device=DEV) * 8 - 4
+        d = torch.nn.functional.normalize(torch.randn(B, 3, device=DEV), dim=-1) * (0.5 + torch.rand(B, 1, device=DEV))
+        z, dist = m.sample(o, d, S_)
+        valid = torch.all(z != -1, dim=-1)
+        valid[::7] = False
+        wf = network.weight_feature(3000, DEV)
+        m.packed.pack(m.decoder.blob(), wf)
+        box = (m.min_bbox.tolist(), m.bbox_size.tolist(), render.FORE, False)
+        ntile = (S_ + 31) // 32
+        tile_T = torch.empty(B, ntile, device=DEV)
+        xs = torch.empty(B * S_, 32, device=DEV)
+        out, _ = render.render_forward(o, d, z, dist, m.features, m.resolution, m.packed, *box, ray_valid=valid,
+                                       want_weights=False, tile_T=tile_T, xstash=xs)
+        gout = torch.randn(B, 16, device=DEV)
+        T = m.features.shape[1]
+        args = (o, d, z, dist, m.features, m.resolution, m.packed, wf, *box, out, tile_T, gout)
+        dfeat, gb1 = render.render_backward(*args, ray_valid=valid, xstash=xs)
+        pts = ((o[:, None, :] + z[:, :, None] * d[:, None, :]).reshape(-1, 3) - m._min_dev) / m._size_dev * 4.0 - 2.0
+        g1 = render.scatter_table_grad(pts.contiguous(), dfeat, torch.zeros_like(m.features), m.resolution)
+        assert render.scatter_supported(B, S_, T)
+        ws = render.scatter_plan(o, d, z, m.resolution, T, *box, ray_valid=valid)
+        g2 = torch.zeros_like(m.features)
+        _, gb2 = render.render_backward(*args, ray_valid=valid, xstash=xs, scatter=(ws, g2), want_dfeat=False)
+        render.scatter_accumulate(ws, g2, B, S_)
+        torch.cuda.synchronize()
+        assert torch.equal(gb1, gb2)
+        sc = float(g1.abs().max())
+        assert sc > 0
+        np.testing.assert_allclose(g2.cpu().numpy() / sc, g1.cpu().numpy() / sc, rtol=1e-4, atol=1e-6)
+    finally:
+        render.set_arith("h3")
 
 
 def test_render_rays_fg_bg_merge_vs_oracle(S):
