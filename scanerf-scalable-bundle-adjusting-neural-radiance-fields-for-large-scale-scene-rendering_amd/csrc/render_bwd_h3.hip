@@ -59,7 +59,7 @@ __device__ __forceinline__ void act_and_deriv(v16f &u, v16f &d)
 {
 #pragma unroll
     for (int g = 0; g < 16; ++g) {
-        const float q = gauss_act(u[g]);
+        const float q = gauss_fast(u[g]);
         d[g] = -100.0f * u[g] * q;
         u[g] = q;
     }
@@ -109,9 +109,9 @@ __device__ __forceinline__ void chain_narrow(v16f dx[NIB], const char *img, int 
 // Weight-gradient block owned by this wave: acc += sum over slots [slot0, slot0+NS) of dY_slot[yb] X_slot[xb]^T, the
 // operands read back (transposed) from the staging images of the NS waves' tiles; rowsum += row sums of dY (lane = unit,
 // this half-wave's samples).  x_in_y: the X operand sits in the Y matrix (heads: H[:32] is parked beside the narrow block).
-template <int NS>
+template <int NS, int ROWSUM_FROM = 0, int ROWSUM_TO = 2 * NS>
 __device__ __forceinline__ void wgrad_block(v16f &acc, float &rowsum, const char *stage, int slot0, int yb, bool x_in_y,
-                                            int xb, int lane)
+                                            int xb, int lane, int rs_shift = 0)
 {
     const char *m0 = stage + slot0 * 2 * H3_STAGE_MAT;
     HL a = h3_stage_get(m0, lane, yb, 0), b = h3_stage_get(m0 + (x_in_y ? 0 : H3_STAGE_MAT), lane, xb, 0);
@@ -123,7 +123,9 @@ __device__ __forceinline__ void wgrad_block(v16f &acc, float &rowsum, const char
             an = h3_stage_get(m, lane, yb, (i + 1) & 1);
             bn = h3_stage_get(m + (x_in_y ? 0 : H3_STAGE_MAT), lane, xb, (i + 1) & 1);
         }
-        rowsum = h3_sum8(a, rowsum);
+        // row sums (bias gradients) only over steps [ROWSUM_FROM, ROWSUM_TO) + rs_shift: the two owners of a row
+        // block share that work
+        if (ROWSUM_TO > ROWSUM_FROM && i >= ROWSUM_FROM + rs_shift && i < ROWSUM_TO + rs_shift) rowsum = h3_sum8(a, rowsum);
         H3_REGION_BEGIN();
         mma3(acc, a, b);
         H3_REGION_END();
@@ -247,6 +249,11 @@ __global__ void __launch_bounds__(kThreads, 1) k_render_bwd_h3(BwdArgs a)
                 contract_point(a.f, o, d, z, p);
                 encode8<DT, 2>(a.f, lres, h, p, x);
             }
+            // warm the caches with the NEXT tile's stashed inputs (one line per lane): at one wave per SIMD the miss
+            // at the top of every tile is otherwise fully exposed
+            float warm = 0.0f;
+            if (active && a.xstash && tile > 0 && live)
+                warm = a.xstash[((size_t)ray * S + s - 32) * 32 + 16 * h];
             const HL2 xs2 = split16(x);
             // Only H, G'(v1) and the inputs x are held across the backward steps; the two other Gaussian layers are
             // recomputed where their gradients are formed (12 MFMAs each) -- holding them spills (see the header).
@@ -258,8 +265,8 @@ __global__ void __launch_bounds__(kThreads, 1) k_render_bwd_h3(BwdArgs a)
                     v16f u[2] = { h3_bias(lds, 0, 0, fresh(lane) >> 5), h3_bias(lds, 0, 1, fresh(lane) >> 5) };
                     const HL *const B[2] = { &xs2.t[0], &xs2.t[1] };
                     h3_layer2<2>(u, lds, H3_L0, 2, h3_lane_off(fresh(lane)), B);
-                    a0s[0] = split16(act16(u[0]));
-                    a0s[1] = split16(act16(u[1]));
+                    a0s[0] = split16(act16_fast(u[0]));
+                    a0s[1] = split16(act16_fast(u[1]));
                 }
                 v16f u[2] = { h3_bias(lds, 1, 0, fresh(lane) >> 5), h3_bias(lds, 1, 1, fresh(lane) >> 5) };
                 const HL *const B[4] = { &a0s[0].t[0], &a0s[0].t[1], &a0s[1].t[0], &a0s[1].t[1] };
@@ -273,11 +280,11 @@ __global__ void __launch_bounds__(kThreads, 1) k_render_bwd_h3(BwdArgs a)
                 const HL *const B[2] = { &Hs[0].t[0], &Hs[0].t[1] };
                 h3_layer1<2>(u, lds, H3_HEAD, h3_lane_off(fresh(lane)), B);
                 sigma = softplus_(u[0]);
-                dsig_dpre = u[0] > 20.0f ? 1.0f : sigmoid_(u[0]);
+                dsig_dpre = u[0] > 20.0f ? 1.0f : sigmoid_fast(u[0]);
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
-                    dif[c] = sigmoid_(u[1 + c]);
-                    tint[c] = sigmoid_(u[4 + c]);
+                    dif[c] = sigmoid_fast(u[1 + c]);
+                    tint[c] = sigmoid_fast(u[4 + c]);
                 }
             }
             h3_stage_put(stY, fresh(lane), 1, Hs[0]);  // X operand of the heads' weight gradient: upper half of this wave's Y image
@@ -287,8 +294,8 @@ __global__ void __launch_bounds__(kThreads, 1) k_render_bwd_h3(BwdArgs a)
                     v16f u[2] = { h3_ld16(lds, kLdsDinit + wv * 256 + (fresh(lane) >> 5) * 64), h3_ld16(lds, kLdsDinit + wv * 256 + 128 + (fresh(lane) >> 5) * 64) };
                     const HL *const B[2] = { &Hs[1].t[0], &Hs[1].t[1] };
                     h3_layer2<2>(u, lds, H3_D0, 3, h3_lane_off(fresh(lane)), B);
-                    c0s[0] = split16(act16(u[0]));
-                    c0s[1] = split16(act16(u[1]));
+                    c0s[0] = split16(act16_fast(u[0]));
+                    c0s[1] = split16(act16_fast(u[1]));
                 }
                 {
                     v16f u[2] = { h3_bias(lds, 3, 0, fresh(lane) >> 5), h3_bias(lds, 3, 1, fresh(lane) >> 5) };
@@ -303,7 +310,7 @@ __global__ void __launch_bounds__(kThreads, 1) k_render_bwd_h3(BwdArgs a)
                 const HL *const B[4] = { &c1s[0].t[0], &c1s[0].t[1], &c1s[1].t[0], &c1s[1].t[1] };
                 h3_layer1<4>(u, lds, H3_D2, h3_lane_off(fresh(lane)), B);
 #pragma unroll
-                for (int c = 0; c < 3; ++c) spec[c] = sigmoid_(u[c]);
+                for (int c = 0; c < 3; ++c) spec[c] = sigmoid_fast(u[c]);
                 h3_stage_put(stX, fresh(lane), 0, c1s[0]);  // X operand of the rgb layer's weight gradient
                 h3_stage_put(stX, fresh(lane), 1, c1s[1]);
             }
@@ -443,8 +450,8 @@ __global__ void __launch_bounds__(kThreads, 1) k_render_bwd_h3(BwdArgs a)
             __syncthreads();  // ---- A1
             {
                 float dummy = 0.0f;
-                if (wv == 0) wgrad_block<4>(gW_nar, dummy, stage, 0, 0, true, 1, fresh(lane));        // heads: x = H[:32]
-                else if (wv < 3) wgrad_block<4>(gW_nar, dummy, stage, 0, 0, false, wv - 1, fresh(lane));  // rgb: x = c1 block wv-1
+                if (wv == 0) wgrad_block<4, 0, 0>(gW_nar, dummy, stage, 0, 0, true, 1, fresh(lane));        // heads: x = H[:32]
+                else if (wv < 3) wgrad_block<4, 0, 0>(gW_nar, dummy, stage, 0, 0, false, wv - 1, fresh(lane));  // rgb: x = c1 block wv-1
             }
             // dv1 = (W_rgb^T gs3) * G'(v1)
             HL2 dys[2];
@@ -469,7 +476,7 @@ __global__ void __launch_bounds__(kThreads, 1) k_render_bwd_h3(BwdArgs a)
                 h3_stage_put(stX, fresh(lane), 1, split16(u[1]));
             }
             __syncthreads();  // ---- A2
-            wgrad_block<4>(gW_D1, gB_D1, stage, 0, rb, false, cb, fresh(lane));
+            wgrad_block<4, 0, 4>(gW_D1, gB_D1, stage, 0, rb, false, cb, fresh(lane), 4 * cb);
             {
                 v16f dc[2] = { zero16, zero16 };
                 chain64<2>(dc, lds, H3_D1, 4, fresh(lane), dys);
@@ -522,7 +529,7 @@ __global__ void __launch_bounds__(kThreads, 1) k_render_bwd_h3(BwdArgs a)
                 h3_stage_put(stX, fresh(lane), 1, split16(u[1]));
             }
             __syncthreads();  // ---- A4
-            wgrad_block<4>(gW_L1, gB_L1, stage, 0, rb, false, cb, fresh(lane));
+            wgrad_block<4, 0, 4>(gW_L1, gB_L1, stage, 0, rb, false, cb, fresh(lane), 4 * cb);
             {
                 v16f dc[2] = { zero16, zero16 };
                 chain64<2>(dc, lds, H3_L1, 4, fresh(lane), dys);
@@ -541,6 +548,7 @@ __global__ void __launch_bounds__(kThreads, 1) k_render_bwd_h3(BwdArgs a)
             const v16f dx = dxa[0] * isc;
             __syncthreads();  // ---- B5: this tile's staging reads are complete
 
+            asm volatile("" ::"v"(warm));
             // ================= feature gradients =================
             // register 2j+f of half h = level 4(j>>1)+2h+(j&1), feature f
             if (live && active && a.dfeat) {
@@ -610,9 +618,9 @@ __global__ void __launch_bounds__(kThreads, 1) k_render_bwd_h3(BwdArgs a)
     {
         float v;
         v = (gB_D1 + __shfl_xor(gB_D1, 32, 64)) * isc;
-        if (h == 0 && cb == 0) out[BLOB_D1 + 32 * rb + k] = v;
+        if (h == 0) out[BLOB_D1 + 32 * rb + k] = v;
         v = (gB_L1 + __shfl_xor(gB_L1, 32, 64)) * isc;
-        if (h == 0 && cb == 0) out[BLOB_S1 + 32 * rb + k] = v;
+        if (h == 0) out[BLOB_S1 + 32 * rb + k] = v;
         v = (gB_D0 + __shfl_xor(gB_D0, 32, 64)) * isc;
         if (h == 0) out[BLOB_D0 + 32 * rb + k] = v;
         v = (gB_L0 + __shfl_xor(gB_L0, 32, 64)) * isc;

@@ -12,6 +12,13 @@ namespace scanerf {
 // ------------------------------------------------------------------ device helpers
 __device__ __forceinline__ float gauss_act(float x) { return __expf(x * x * -50.0f); }  // exp(-x^2/(2*0.1^2))
 __device__ __forceinline__ float sigmoid_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+// the same two functions at hardware-instruction cost for the split-f16 kernels, whose time is VALU issue:
+// exp2 with the constants folded (3 instructions instead of 4) and v_rcp_f32 (1 ulp) instead of an IEEE division
+__device__ __forceinline__ float gauss_fast(float x) { return __builtin_amdgcn_exp2f(x * x * -72.13475204444817f); }
+__device__ __forceinline__ float sigmoid_fast(float x)
+{
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.4426950408889634f));
+}
 __device__ __forceinline__ float softplus_(float x) { return x > 20.0f ? x : log1pf(__expf(x)); }
 
 __device__ __forceinline__ v16f load_bias(const float *lds, int layer, int blk, int h)

@@ -53,6 +53,9 @@ __device__ __forceinline__ HL split8(const v16f &v, int t)
         o.lo[2 * q] = lo[0];
         o.lo[2 * q + 1] = lo[1];
     }
+#if !(defined(H3_REGIONS) && H3_REGIONS)
+    asm volatile("s_nop 1" : "+v"(o.hi), "+v"(o.lo));  // operand guard, see "operand hazard" below
+#endif
     return o;
 }
 struct HL2 {
@@ -66,14 +69,15 @@ __device__ __forceinline__ HL2 split16(const v16f &v)
     return o;
 }
 
-// ---- MFMA regions.
-// Measured on MI355X (ROCm 7.2 hipcc): with the f16 MFMAs scheduled freely among the VALU code that produces and
-// recycles their 4-register A/B operands, about 3e-4 of the 32-sample tiles came out wrong in lanes 16-31, differently
-// on every launch (tools/h3_debug.py); fencing the MFMAs off removes it.  The listing shows VALU writes to an MFMA's
-// A/B registers one or two issue slots behind it, which the hazard recogniser does not pad (it pads the producer ->
-// MFMA direction).  So every group of MFMAs is a closed scheduling region: operands are complete before it, nothing
-// else is inside it, and two wait states follow it.  The A operands of the NEXT group are loaded in front of the region
-// (their LDS latency hides under the MFMAs); VALU work overlaps through the other waves of the SIMD.
+// ---- operand hazard.
+// Measured on MI355X (ROCm 7.2 hipcc): with the f16 MFMAs scheduled freely among the VALU code that produces their
+// B operands, about 3e-4 of the 32-sample tiles came out wrong in lanes 16-31, differently on every launch
+// (tools/h3_debug.py: ~10 wrong tiles per 16 384).  The listing shows the hazard recogniser leaving two wait states
+// between the last v_cvt_pk_f16_f32 of an operand and the MFMA that reads it; that is not enough for this producer.
+// Every VALU-made operand therefore passes through a guard where it is produced (split8: two more wait states, and
+// the MFMAs depend on the guard's outputs): 0 wrong tiles in 393 216.  Operands that come from LDS (weights,
+// transposed reads) need nothing.  H3_REGIONS=1 instead fences every MFMA group off as a closed scheduling region
+// (equally clean, but a lone wave per SIMD then cannot overlap its own VALU and matrix work).
 typedef HL A2;  // an A operand (weights): the same pair of parts
 __device__ __forceinline__ A2 h3_lda(const char *sub)  // `sub` = address of this lane's 16 B of the hi part
 {
@@ -82,10 +86,15 @@ __device__ __forceinline__ A2 h3_lda(const char *sub)  // `sub` = address of thi
     a.lo = *reinterpret_cast<const h8 *>(sub + H3_SUB);
     return a;
 }
+#if defined(H3_REGIONS) && H3_REGIONS
 #define H3_REGION_BEGIN() __builtin_amdgcn_sched_barrier(0)
 #define H3_REGION_END()          \
     asm volatile("s_nop 1");     \
     __builtin_amdgcn_sched_barrier(0)
+#else
+#define H3_REGION_BEGIN()
+#define H3_REGION_END()
+#endif
 // acc += W * B with the three-term split (small terms first); call between H3_REGION_BEGIN / END
 __device__ __forceinline__ void mma3(v16f &acc, const A2 &a, const HL &b)
 {
@@ -244,6 +253,14 @@ __device__ __forceinline__ void h3_dinit(const char *img, int lane, const float 
     H3_REGION_END();
 }
 
+__device__ __forceinline__ v16f act16_fast(const v16f &x)
+{
+    v16f r;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) r[g] = gauss_fast(x[g]);
+    return r;
+}
+
 // Decoder forward on one 32-sample tile (same contract as decode_tile in render_device.h)
 __device__ __forceinline__ SampleOut decode_tile_h3(const char *img, int lane, const v16f &x, const v16f dinit[2])
 {
@@ -255,8 +272,8 @@ __device__ __forceinline__ SampleOut decode_tile_h3(const char *img, int lane, c
         v16f u[2] = { h3_bias(img, 0, 0, h), h3_bias(img, 0, 1, h) };
         const HL *const B[2] = { &xs.t[0], &xs.t[1] };
         h3_layer2<2>(u, img, H3_L0, 2, lo, B);
-        a[0] = split16(act16(u[0]));
-        a[1] = split16(act16(u[1]));
+        a[0] = split16(act16_fast(u[0]));
+        a[1] = split16(act16_fast(u[1]));
     }
     // Spatial_MLP.mlp.2 (64 -> 64), linear
     HL2 H[2];
@@ -275,8 +292,8 @@ __device__ __forceinline__ SampleOut decode_tile_h3(const char *img, int lane, c
         so.sigma = softplus_(u[0]);
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            so.dif[c] = sigmoid_(u[1 + c]);
-            so.tint[c] = sigmoid_(u[4 + c]);
+            so.dif[c] = sigmoid_fast(u[1 + c]);
+            so.tint[c] = sigmoid_fast(u[4 + c]);
         }
     }
     // Directional_MLP.mlp.0 (48 -> 64): SH part + bias pre-accumulated in dinit
@@ -285,8 +302,8 @@ __device__ __forceinline__ SampleOut decode_tile_h3(const char *img, int lane, c
         v16f u[2] = { dinit[0], dinit[1] };
         const HL *const B[2] = { &H[1].t[0], &H[1].t[1] };
         h3_layer2<2>(u, img, H3_D0, 3, lo, B);
-        c0[0] = split16(act16(u[0]));
-        c0[1] = split16(act16(u[1]));
+        c0[0] = split16(act16_fast(u[0]));
+        c0[1] = split16(act16_fast(u[1]));
     }
     // Directional_MLP.mlp.2 (64 -> 64) + Gaussian
     HL2 c1[2];
@@ -294,15 +311,15 @@ __device__ __forceinline__ SampleOut decode_tile_h3(const char *img, int lane, c
         v16f u[2] = { h3_bias(img, 3, 0, h), h3_bias(img, 3, 1, h) };
         const HL *const B[4] = { &c0[0].t[0], &c0[0].t[1], &c0[1].t[0], &c0[1].t[1] };
         h3_layer2<4>(u, img, H3_D1, 4, lo, B);
-        c1[0] = split16(act16(u[0]));
-        c1[1] = split16(act16(u[1]));
+        c1[0] = split16(act16_fast(u[0]));
+        c1[1] = split16(act16_fast(u[1]));
     }
     {   // Directional_MLP.mlp.4 (64 -> 3) + sigmoid
         v16f u = h3_ld16(img, H3_D2B);
         const HL *const B[4] = { &c1[0].t[0], &c1[0].t[1], &c1[1].t[0], &c1[1].t[1] };
         h3_layer1<4>(u, img, H3_D2, lo, B);
 #pragma unroll
-        for (int c = 0; c < 3; ++c) so.spec[c] = sigmoid_(u[c]);
+        for (int c = 0; c < 3; ++c) so.spec[c] = sigmoid_fast(u[c]);
     }
     return so;
 }
