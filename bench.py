@@ -29,6 +29,7 @@ import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 MFMA_F32_PEAK_TFLOPS = 157.3  # fp32-input MFMA = fp32 vector peak (MI355X_MICROARCH.md, Matrix cores)
+MFMA_F16_PEAK_TFLOPS = 2500.0  # dense f16/bf16 MFMA (MI355X_MICROARCH.md); the h3 arithmetic issues 3 f16 products per term
 BYTES_FWD_PER_RAY = 24 + 20 + 128 * 16 * 8 * 2 * 4        # 131 116 B (fp32, S=128, L=16)
 BYTES_BWD_PER_RAY = 128 * 16 * (8 + 64 + 16 * 8)          # 409 600 B
 SYN_ITERS = 100                                           # config/default.yaml:5
@@ -183,11 +184,16 @@ def main():
         }
         if timer and timer.count:
             name, avg_ms, alg_bytes, alg_flops = timer.dominant()
-            t_hbm, t_mfma = alg_bytes / (HBM_PEAK_GBS * 1e9), alg_flops / (MFMA_F32_PEAK_TFLOPS * 1e12)
-            if t_mfma > t_hbm:  # the kernel's floor is set by the fp32 matrix pipe, not by HBM
+            from scanerf_amd import render as _render
+            h3 = _render.ARITH == 1 and path == "fused"
+            # matrix-pipe floor of the launch: f32-input MFMA, or 3 f16 MFMAs per term for the split arithmetic
+            mfma_peak = MFMA_F16_PEAK_TFLOPS if h3 else MFMA_F32_PEAK_TFLOPS
+            t_hbm, t_mfma = alg_bytes / (HBM_PEAK_GBS * 1e9), (3 if h3 else 1) * alg_flops / (mfma_peak * 1e12)
+            line["config"]["decoder_arith"] = "split f16 x3 MFMA, f32 accumulate (csrc/render_h3.h)" if h3 else "f32 MFMA"
+            if t_mfma > t_hbm:  # the kernel's floor is set by the matrix pipe, not by HBM
                 ach = alg_flops / (avg_ms * 1e-3) / 1e12
-                roof = {"bound": "mfma", "achieved": ach, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                        "frac": ach / MFMA_F32_PEAK_TFLOPS, "algorithmic_flops_per_launch": alg_flops}
+                roof = {"bound": "mfma", "achieved": ach, "peak": mfma_peak, "unit": "TFLOP/s",
+                        "frac": ach / mfma_peak, "algorithmic_flops_per_launch": alg_flops}
             else:
                 ach = alg_bytes / (avg_ms * 1e-3) / 1e9
                 roof = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS}

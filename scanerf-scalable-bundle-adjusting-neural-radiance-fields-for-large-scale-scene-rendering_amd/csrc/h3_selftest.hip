@@ -22,6 +22,7 @@ __global__ void __launch_bounds__(64) k_h3_selftest(const float *packed, const f
     }
     __syncthreads();
     const int lane = threadIdx.x, sl = lane & 31, h = lane >> 5;
+    const H3Lane L = h3_lane(lane);
     char *stY = lds + H3_BYTES, *stX = stY + H3_STAGE_MAT;
     // registers in accumulator layout: block b, register g = unit 32b + nmap(g,h), column = sample sl
     v16f Y[2], X[2];
@@ -43,7 +44,7 @@ __global__ void __launch_bounds__(64) k_h3_selftest(const float *packed, const f
             for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
                 for (int tq = 0; tq < 2; ++tq) {
-                    const A2 a = h3_lda_T(lds, base, ksb, nb, tq, ib, lane);
+                    const A2 a = h3_lda_T(lds, base, ksb, nb, tq, ib, L);
                     H3_REGION_BEGIN();
                     mma3(acc, a, ys[nb].t[tq]);
                     H3_REGION_END();
@@ -53,10 +54,10 @@ __global__ void __launch_bounds__(64) k_h3_selftest(const float *packed, const f
         }
     }
     // ---- staged products
-    h3_stage_put(stY, lane, 0, ys[0]);
-    h3_stage_put(stY, lane, 1, ys[1]);
-    h3_stage_put(stX, lane, 0, xs[0]);
-    h3_stage_put(stX, lane, 1, xs[1]);
+    h3_stage_put(stY, L, 0, ys[0]);
+    h3_stage_put(stY, L, 1, ys[1]);
+    h3_stage_put(stX, L, 0, xs[0]);
+    h3_stage_put(stX, L, 1, xs[1]);
     __syncthreads();
     for (int nb = 0; nb < 2; ++nb) {
         float rs = 0.0f;
@@ -64,7 +65,7 @@ __global__ void __launch_bounds__(64) k_h3_selftest(const float *packed, const f
             v16f acc = zero;
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
-                const HL a = h3_stage_get(stY, lane, nb, t), b = h3_stage_get(stX, lane, kb, t);
+                const HL a = h3_stage_get(stY, L.g0[nb], L.g1[nb], t), b = h3_stage_get(stX, L.g0[kb], L.g1[kb], t);
                 if (kb == 0) rs = h3_sum8(a, rs);
                 H3_REGION_BEGIN();
                 mma3(acc, a, b);

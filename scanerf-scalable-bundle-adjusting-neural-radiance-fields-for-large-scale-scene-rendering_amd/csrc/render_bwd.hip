@@ -567,16 +567,27 @@ __global__ void __launch_bounds__(kBwdThreads, 1) k_render_bwd(BwdArgs a)
     }
 }
 
-// grad_blob[e] += sum over waves of the partials; first-layer weights carry the folded weight_feature
-__global__ void __launch_bounds__(256) k_reduce_dw(const float *__restrict__ partial, int nwaves,
-                                                   const float *__restrict__ wf, float *__restrict__ grad_blob)
+// grad_blob[e] += sum over waves of the partials; first-layer weights carry the folded weight_feature.
+// 64 columns x 16 row chunks per workgroup: every thread sums a fixed subset of the rows, the 16 partial sums are
+// added in a fixed order -- deterministic, and enough workgroups (219) to stream the 57 MB of partials.
+__global__ void __launch_bounds__(1024) k_reduce_dw(const float *__restrict__ partial, int nwaves,
+                                                    const float *__restrict__ wf, float *__restrict__ grad_blob)
 {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= SCANERF_PARAMSIZE) return;
+    __shared__ float part[16][64];
+    const int c = threadIdx.x & 63, r = threadIdx.x >> 6;
+    const int e = blockIdx.x * 64 + c;
     float s = 0.0f;
-    for (int w = 0; w < nwaves; ++w) s += partial[(size_t)w * SCANERF_PARAMSIZE + e];
-    if (e >= BLOB_S0 + 64 && e < BLOB_S1) s *= wf[(e - 64) / 64];
-    grad_blob[e] += s;
+    if (e < SCANERF_PARAMSIZE)
+        for (int w = r; w < nwaves; w += 16) s += partial[(size_t)w * SCANERF_PARAMSIZE + e];
+    part[r][c] = s;
+    __syncthreads();
+    if (r == 0 && e < SCANERF_PARAMSIZE) {
+        float t = 0.0f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) t += part[q][c];
+        if (e >= BLOB_S0 + 64 && e < BLOB_S1) t *= wf[(e - 64) / 64];
+        grad_blob[e] += t;
+    }
 }
 
 }  // namespace
@@ -667,7 +678,7 @@ SCANERF_API int scanerf_render_backward(const float *rays_o, const float *rays_d
                    : launch_render_bwd_f32(a, feat_dtype, blocks, lds_extra, st))
         return e;
     if (int e = check_launch("render_backward")) return e;
-    hipLaunchKernelGGL(k_reduce_dw, dim3(ceil_div(SCANERF_PARAMSIZE, 256)), dim3(256), 0, st, dw_partial, blocks * 4,
+    hipLaunchKernelGGL(k_reduce_dw, dim3(ceil_div(SCANERF_PARAMSIZE, 64)), dim3(1024), 0, st, dw_partial, blocks * 4,
                        weight_feature, grad_blob);
     return check_launch("render_backward(reduce)");
 }

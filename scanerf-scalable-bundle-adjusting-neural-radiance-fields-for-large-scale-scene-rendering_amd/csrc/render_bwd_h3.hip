@@ -74,7 +74,7 @@ __device__ __forceinline__ v16f mul16(const v16f &a, const v16f &b)
 
 // dX (rows 32ib..32ib+31 of the layer's input) = W^T dY over the 64 output units (row blocks 0,1 x k-steps 0,1)
 template <int NIB>
-__device__ __forceinline__ void chain64(v16f dx[NIB], const char *img, int base, int ksb, int lane, const HL2 dy[2])
+__device__ __forceinline__ void chain64(v16f dx[NIB], const char *img, int base, int ksb, const H3Lane &L, const HL2 dy[2])
 {
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb)
@@ -82,7 +82,7 @@ __device__ __forceinline__ void chain64(v16f dx[NIB], const char *img, int base,
         for (int tq = 0; tq < 2; ++tq) {
             HL a[NIB];
 #pragma unroll
-            for (int ib = 0; ib < NIB; ++ib) a[ib] = h3_lda_T(img, base, ksb, nb, tq, ib, lane);
+            for (int ib = 0; ib < NIB; ++ib) a[ib] = h3_lda_T(img, base, ksb, nb, tq, ib, L);
             H3_REGION_BEGIN();
 #pragma unroll
             for (int ib = 0; ib < NIB; ++ib) dx[ib] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[ib].lo, dy[nb].t[tq].hi, dx[ib], 0, 0, 0);
@@ -95,11 +95,11 @@ __device__ __forceinline__ void chain64(v16f dx[NIB], const char *img, int base,
 }
 // dX (NIB row blocks) = W^T dY for a layer with ONE 32-row output block whose live rows sit in k-step 0 (heads, rgb)
 template <int NIB>
-__device__ __forceinline__ void chain_narrow(v16f dx[NIB], const char *img, int base, int ksb, int lane, const HL &dy)
+__device__ __forceinline__ void chain_narrow(v16f dx[NIB], const char *img, int base, int ksb, const H3Lane &L, const HL &dy)
 {
     HL a[NIB];
 #pragma unroll
-    for (int ib = 0; ib < NIB; ++ib) a[ib] = h3_lda_T(img, base, ksb, 0, 0, ib, lane);
+    for (int ib = 0; ib < NIB; ++ib) a[ib] = h3_lda_T(img, base, ksb, 0, 0, ib, L);
     H3_REGION_BEGIN();
 #pragma unroll
     for (int ib = 0; ib < NIB; ++ib) mma3(dx[ib], a[ib], dy);
@@ -110,18 +110,21 @@ __device__ __forceinline__ void chain_narrow(v16f dx[NIB], const char *img, int 
 // operands read back (transposed) from the staging images of the NS waves' tiles; rowsum += row sums of dY (lane = unit,
 // this half-wave's samples).  x_in_y: the X operand sits in the Y matrix (heads: H[:32] is parked beside the narrow block).
 template <int NS, int ROWSUM_FROM = 0, int ROWSUM_TO = 2 * NS>
-__device__ __forceinline__ void wgrad_block(v16f &acc, float &rowsum, const char *stage, int slot0, int yb, bool x_in_y,
-                                            int xb, int lane, int rs_shift = 0)
+__device__ __forceinline__ void wgrad_block(v16f &acc, float &rowsum, const char *stage, int slot0, const H3Lane &L, int yb,
+                                            bool x_in_y, int xb, int rs_shift = 0)
 {
+    // block selection is wave-uniform at run time: pick the lane terms once
+    const int yo0 = yb ? L.g0[1] : L.g0[0], yo1 = yb ? L.g1[1] : L.g1[0];
+    const int xo0 = (xb ? L.g0[1] : L.g0[0]) + (x_in_y ? 0 : H3_STAGE_MAT), xo1 = (xb ? L.g1[1] : L.g1[0]) + (x_in_y ? 0 : H3_STAGE_MAT);
     const char *m0 = stage + slot0 * 2 * H3_STAGE_MAT;
-    HL a = h3_stage_get(m0, lane, yb, 0), b = h3_stage_get(m0 + (x_in_y ? 0 : H3_STAGE_MAT), lane, xb, 0);
+    HL a = h3_stage_get(m0, yo0, yo1, 0), b = h3_stage_get(m0, xo0, xo1, 0);
 #pragma unroll
     for (int i = 0; i < 2 * NS; ++i) {
         HL an = a, bn = b;
         if (i + 1 < 2 * NS) {
-            const char *m = stage + (slot0 + ((i + 1) >> 1)) * 2 * H3_STAGE_MAT;
-            an = h3_stage_get(m, lane, yb, (i + 1) & 1);
-            bn = h3_stage_get(m + (x_in_y ? 0 : H3_STAGE_MAT), lane, xb, (i + 1) & 1);
+            const char *m = m0 + ((i + 1) >> 1) * 2 * H3_STAGE_MAT;
+            an = h3_stage_get(m, yo0, yo1, (i + 1) & 1);
+            bn = h3_stage_get(m, xo0, xo1, (i + 1) & 1);
         }
         // row sums (bias gradients) only over steps [ROWSUM_FROM, ROWSUM_TO) + rs_shift: the two owners of a row
         // block share that work
@@ -236,6 +239,8 @@ __global__ void __launch_bounds__(kThreads, 1) k_render_bwd_h3(BwdArgs a)
             float delta = dist_i * dnorm;
             if (a.f.infinity && s == S - 1) delta = 1e10f;
 
+            const H3Lane L = h3_lane(fresh(lane));  // this tile's lane address terms (not loop invariants: see fresh())
+            const int hf = L.fwd >= 576;             // = lane >> 5, derived from the opaque index
             // ================= forward recompute =================
             v16f x;
             if (!active) {
@@ -262,15 +267,15 @@ __global__ void __launch_bounds__(kThreads, 1) k_render_bwd_h3(BwdArgs a)
             {
                 HL2 a0s[2];
                 {
-                    v16f u[2] = { h3_bias(lds, 0, 0, fresh(lane) >> 5), h3_bias(lds, 0, 1, fresh(lane) >> 5) };
+                    v16f u[2] = { h3_bias(lds, 0, 0, hf), h3_bias(lds, 0, 1, hf) };
                     const HL *const B[2] = { &xs2.t[0], &xs2.t[1] };
-                    h3_layer2<2>(u, lds, H3_L0, 2, h3_lane_off(fresh(lane)), B);
+                    h3_layer2<2>(u, lds, H3_L0, 2, L.fwd, B);
                     a0s[0] = split16(act16_fast(u[0]));
                     a0s[1] = split16(act16_fast(u[1]));
                 }
-                v16f u[2] = { h3_bias(lds, 1, 0, fresh(lane) >> 5), h3_bias(lds, 1, 1, fresh(lane) >> 5) };
+                v16f u[2] = { h3_bias(lds, 1, 0, hf), h3_bias(lds, 1, 1, hf) };
                 const HL *const B[4] = { &a0s[0].t[0], &a0s[0].t[1], &a0s[1].t[0], &a0s[1].t[1] };
-                h3_layer2<4>(u, lds, H3_L1, 4, h3_lane_off(fresh(lane)), B);
+                h3_layer2<4>(u, lds, H3_L1, 4, L.fwd, B);
                 Hs[0] = split16(u[0]);
                 Hs[1] = split16(u[1]);
             }
@@ -278,7 +283,7 @@ __global__ void __launch_bounds__(kThreads, 1) k_render_bwd_h3(BwdArgs a)
             {
                 v16f u = h3_ld16(lds, H3_HB);
                 const HL *const B[2] = { &Hs[0].t[0], &Hs[0].t[1] };
-                h3_layer1<2>(u, lds, H3_HEAD, h3_lane_off(fresh(lane)), B);
+                h3_layer1<2>(u, lds, H3_HEAD, L.fwd, B);
                 sigma = softplus_(u[0]);
                 dsig_dpre = u[0] > 20.0f ? 1.0f : sigmoid_fast(u[0]);
 #pragma unroll
@@ -287,20 +292,20 @@ __global__ void __launch_bounds__(kThreads, 1) k_render_bwd_h3(BwdArgs a)
                     tint[c] = sigmoid_fast(u[4 + c]);
                 }
             }
-            h3_stage_put(stY, fresh(lane), 1, Hs[0]);  // X operand of the heads' weight gradient: upper half of this wave's Y image
+            h3_stage_put(stY, L, 1, Hs[0]);  // X operand of the heads' weight gradient: upper half of this wave's Y image
             {
                 HL2 c0s[2], c1s[2];
                 {
-                    v16f u[2] = { h3_ld16(lds, kLdsDinit + wv * 256 + (fresh(lane) >> 5) * 64), h3_ld16(lds, kLdsDinit + wv * 256 + 128 + (fresh(lane) >> 5) * 64) };
+                    v16f u[2] = { h3_ld16(lds, kLdsDinit + wv * 256 + (hf) * 64), h3_ld16(lds, kLdsDinit + wv * 256 + 128 + (hf) * 64) };
                     const HL *const B[2] = { &Hs[1].t[0], &Hs[1].t[1] };
-                    h3_layer2<2>(u, lds, H3_D0, 3, h3_lane_off(fresh(lane)), B);
+                    h3_layer2<2>(u, lds, H3_D0, 3, L.fwd, B);
                     c0s[0] = split16(act16_fast(u[0]));
                     c0s[1] = split16(act16_fast(u[1]));
                 }
                 {
-                    v16f u[2] = { h3_bias(lds, 3, 0, fresh(lane) >> 5), h3_bias(lds, 3, 1, fresh(lane) >> 5) };
+                    v16f u[2] = { h3_bias(lds, 3, 0, hf), h3_bias(lds, 3, 1, hf) };
                     const HL *const B[4] = { &c0s[0].t[0], &c0s[0].t[1], &c0s[1].t[0], &c0s[1].t[1] };
-                    h3_layer2<4>(u, lds, H3_D1, 4, h3_lane_off(fresh(lane)), B);
+                    h3_layer2<4>(u, lds, H3_D1, 4, L.fwd, B);
                     act_and_deriv(u[0], dv1f[0]);
                     act_and_deriv(u[1], dv1f[1]);
                     c1s[0] = split16(u[0]);
@@ -308,11 +313,11 @@ __global__ void __launch_bounds__(kThreads, 1) k_render_bwd_h3(BwdArgs a)
                 }
                 v16f u = h3_ld16(lds, H3_D2B);
                 const HL *const B[4] = { &c1s[0].t[0], &c1s[0].t[1], &c1s[1].t[0], &c1s[1].t[1] };
-                h3_layer1<4>(u, lds, H3_D2, h3_lane_off(fresh(lane)), B);
+                h3_layer1<4>(u, lds, H3_D2, L.fwd, B);
 #pragma unroll
                 for (int c = 0; c < 3; ++c) spec[c] = sigmoid_fast(u[c]);
-                h3_stage_put(stX, fresh(lane), 0, c1s[0]);  // X operand of the rgb layer's weight gradient
-                h3_stage_put(stX, fresh(lane), 1, c1s[1]);
+                h3_stage_put(stX, L, 0, c1s[0]);  // X operand of the rgb layer's weight gradient
+                h3_stage_put(stX, L, 1, c1s[1]);
             }
 
             // ================= compositing: recompute and adjoint =================
@@ -450,49 +455,49 @@ __global__ void __launch_bounds__(kThreads, 1) k_render_bwd_h3(BwdArgs a)
             __syncthreads();  // ---- A1
             {
                 float dummy = 0.0f;
-                if (wv == 0) wgrad_block<4, 0, 0>(gW_nar, dummy, stage, 0, 0, true, 1, fresh(lane));        // heads: x = H[:32]
-                else if (wv < 3) wgrad_block<4, 0, 0>(gW_nar, dummy, stage, 0, 0, false, wv - 1, fresh(lane));  // rgb: x = c1 block wv-1
+                if (wv == 0) wgrad_block<4, 0, 0>(gW_nar, dummy, stage, 0, L, 0, true, 1);        // heads: x = H[:32]
+                else if (wv < 3) wgrad_block<4, 0, 0>(gW_nar, dummy, stage, 0, L, 0, false, wv - 1);  // rgb: x = c1 block wv-1
             }
             // dv1 = (W_rgb^T gs3) * G'(v1)
             HL2 dys[2];
             {
                 v16f dc[2] = { zero16, zero16 };
-                chain_narrow<2>(dc, lds, H3_D2, 4, fresh(lane), narrgb);
+                chain_narrow<2>(dc, lds, H3_D2, 4, L, narrgb);
                 dys[0] = split16(mul16(dc[0], dv1f[0]));
                 dys[1] = split16(mul16(dc[1], dv1f[1]));
             }
             __syncthreads();  // ---- B1
             // ================= Directional_MLP.mlp.2 (64 -> 64) =================
-            h3_stage_put(stY, fresh(lane), 0, dys[0]);
-            h3_stage_put(stY, fresh(lane), 1, dys[1]);
+            h3_stage_put(stY, L, 0, dys[0]);
+            h3_stage_put(stY, L, 1, dys[1]);
             v16f dv0f[2];
             {   // c0 = G(v0), G'(v0) recomputed from H[32:]
-                v16f u[2] = { h3_ld16(lds, kLdsDinit + wv * 256 + (fresh(lane) >> 5) * 64), h3_ld16(lds, kLdsDinit + wv * 256 + 128 + (fresh(lane) >> 5) * 64) };
+                v16f u[2] = { h3_ld16(lds, kLdsDinit + wv * 256 + (hf) * 64), h3_ld16(lds, kLdsDinit + wv * 256 + 128 + (hf) * 64) };
                 const HL *const B[2] = { &Hs[1].t[0], &Hs[1].t[1] };
-                h3_layer2<2>(u, lds, H3_D0, 3, h3_lane_off(fresh(lane)), B);
+                h3_layer2<2>(u, lds, H3_D0, 3, L.fwd, B);
                 act_and_deriv(u[0], dv0f[0]);
                 act_and_deriv(u[1], dv0f[1]);
-                h3_stage_put(stX, fresh(lane), 0, split16(u[0]));
-                h3_stage_put(stX, fresh(lane), 1, split16(u[1]));
+                h3_stage_put(stX, L, 0, split16(u[0]));
+                h3_stage_put(stX, L, 1, split16(u[1]));
             }
             __syncthreads();  // ---- A2
-            wgrad_block<4, 0, 4>(gW_D1, gB_D1, stage, 0, rb, false, cb, fresh(lane), 4 * cb);
+            wgrad_block<4, 0, 4>(gW_D1, gB_D1, stage, 0, L, rb, false, cb, 4 * cb);
             {
                 v16f dc[2] = { zero16, zero16 };
-                chain64<2>(dc, lds, H3_D1, 4, fresh(lane), dys);
+                chain64<2>(dc, lds, H3_D1, 4, L, dys);
                 dys[0] = split16(mul16(dc[0], dv0f[0]));   // dv0
                 dys[1] = split16(mul16(dc[1], dv0f[1]));
             }
             __syncthreads();  // ---- B2
             // ================= Directional_MLP.mlp.0 (32 of its 48 inputs; the SH part per ray) =================
-            h3_stage_put(stY, fresh(lane), 0, dys[0]);
-            h3_stage_put(stY, fresh(lane), 1, dys[1]);
-            h3_stage_put(stX, fresh(lane), 0, Hs[1]);
+            h3_stage_put(stY, L, 0, dys[0]);
+            h3_stage_put(stY, L, 1, dys[1]);
+            h3_stage_put(stX, L, 0, Hs[1]);
             __syncthreads();  // ---- A3
 #pragma unroll
             for (int i = 0; i < 2; ++i) {   // own slots one at a time: their row sums meet different rays' SH
                 float rsum = 0.0f;
-                wgrad_block<1>(gW_D0H, rsum, stage, s2 + i, rb, false, 0, fresh(lane));
+                wgrad_block<1>(gW_D0H, rsum, stage, s2 + i, L, rb, false, 0);
                 gB_D0 += rsum;
                 rsum += __shfl_xor(rsum, 32, 64);  // all 32 samples of the tile, lane = unit 32rb + sl
                 slot_rs[i] += rsum;
@@ -506,45 +511,45 @@ __global__ void __launch_bounds__(kThreads, 1) k_render_bwd_h3(BwdArgs a)
             v16f dH[2] = { zero16, zero16 };
             {
                 v16f dc[1] = { zero16 };
-                chain64<1>(dc, lds, H3_D0, 3, fresh(lane), dys);
+                chain64<1>(dc, lds, H3_D0, 3, L, dys);
                 dH[1] = dc[0];
                 v16f dh0[1] = { zero16 };
-                chain_narrow<1>(dh0, lds, H3_HEAD, 2, fresh(lane), nar);
+                chain_narrow<1>(dh0, lds, H3_HEAD, 2, L, nar);
                 dH[0] = dh0[0];
             }
             dys[0] = split16(dH[0]);
             dys[1] = split16(dH[1]);
             __syncthreads();  // ---- B3
             // ================= Spatial_MLP.mlp.2 (64 -> 64, linear) =================
-            h3_stage_put(stY, fresh(lane), 0, dys[0]);
-            h3_stage_put(stY, fresh(lane), 1, dys[1]);
+            h3_stage_put(stY, L, 0, dys[0]);
+            h3_stage_put(stY, L, 1, dys[1]);
             v16f du0f[2];
             {   // a0 = G(u0), G'(u0) recomputed from x
-                v16f u[2] = { h3_bias(lds, 0, 0, fresh(lane) >> 5), h3_bias(lds, 0, 1, fresh(lane) >> 5) };
+                v16f u[2] = { h3_bias(lds, 0, 0, hf), h3_bias(lds, 0, 1, hf) };
                 const HL *const B[2] = { &xs2.t[0], &xs2.t[1] };
-                h3_layer2<2>(u, lds, H3_L0, 2, h3_lane_off(fresh(lane)), B);
+                h3_layer2<2>(u, lds, H3_L0, 2, L.fwd, B);
                 act_and_deriv(u[0], du0f[0]);
                 act_and_deriv(u[1], du0f[1]);
-                h3_stage_put(stX, fresh(lane), 0, split16(u[0]));
-                h3_stage_put(stX, fresh(lane), 1, split16(u[1]));
+                h3_stage_put(stX, L, 0, split16(u[0]));
+                h3_stage_put(stX, L, 1, split16(u[1]));
             }
             __syncthreads();  // ---- A4
-            wgrad_block<4, 0, 4>(gW_L1, gB_L1, stage, 0, rb, false, cb, fresh(lane), 4 * cb);
+            wgrad_block<4, 0, 4>(gW_L1, gB_L1, stage, 0, L, rb, false, cb, 4 * cb);
             {
                 v16f dc[2] = { zero16, zero16 };
-                chain64<2>(dc, lds, H3_L1, 4, fresh(lane), dys);
+                chain64<2>(dc, lds, H3_L1, 4, L, dys);
                 dys[0] = split16(mul16(dc[0], du0f[0]));   // du0
                 dys[1] = split16(mul16(dc[1], du0f[1]));
             }
             __syncthreads();  // ---- B4
             // ================= Spatial_MLP.mlp.0 (32 -> 64) =================
-            h3_stage_put(stY, fresh(lane), 0, dys[0]);
-            h3_stage_put(stY, fresh(lane), 1, dys[1]);
-            h3_stage_put(stX, fresh(lane), 0, xs2);
+            h3_stage_put(stY, L, 0, dys[0]);
+            h3_stage_put(stY, L, 1, dys[1]);
+            h3_stage_put(stX, L, 0, xs2);
             __syncthreads();  // ---- A5
-            wgrad_block<2>(gW_L0, gB_L0, stage, s2, rb, false, 0, fresh(lane));
+            wgrad_block<2>(gW_L0, gB_L0, stage, s2, L, rb, false, 0);
             v16f dxa[1] = { zero16 };
-            chain64<1>(dxa, lds, H3_L0, 2, fresh(lane), dys);
+            chain64<1>(dxa, lds, H3_L0, 2, L, dys);
             const v16f dx = dxa[0] * isc;
             __syncthreads();  // ---- B5: this tile's staging reads are complete
 

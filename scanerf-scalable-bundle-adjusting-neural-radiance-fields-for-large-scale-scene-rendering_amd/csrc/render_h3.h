@@ -172,15 +172,39 @@ __device__ __forceinline__ h4 ds_tr4(const char *p)
 }
 __device__ __forceinline__ h8 cat44(h4 a, h4 b) { return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7); }
 
+// Lane-dependent address terms of the backward primitives, computed once per tile from an opaque lane index
+// (8 registers): every LDS access below is then one base register plus an immediate offset.
+struct H3Lane {
+    int fwd;           // forward image: this lane's 16 B of a sub-image (h3_lane_off)
+    int lT;            // transposed image reads (h3_lda_T)
+    int pv, pb;        // staging writes: chunk (t, a) of block b at pb + (((8b + 4t + 2a) ^ pv) << 3)
+    int g0[2], g1[2];  // staging reads of block b: samples 8h..8h+3 / 8h+4..8h+7 of k-step 0 (k-step 1: + 2048)
+};
+__device__ __forceinline__ H3Lane h3_lane(int lane)
+{
+    H3Lane L;
+    const int h = lane >> 5, g16 = (lane >> 4) & 1, q = (lane >> 2) & 3, p = lane & 3, s = lane & 31;
+    L.fwd = h3_lane_off(lane);
+    L.lT = (4 * h + q) * 16 + (p & 1) * 576 + (p >> 1) * 8 + g16 * 2 * H3_SUB;
+    L.pv = (((s >> 1) & 7) | (((s >> 1) & 1) << 3)) ^ h;
+    L.pb = s * 128;
+    const int gq = (4 * h + (q >> 1)) | (((q >> 1) & 1) << 3);  // g(s) of the first four samples (independent of the k-step)
+    const int gv = (4 * g16 + p) ^ gq;
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        L.g0[b] = (8 * h + q) * 128 + ((gv ^ (8 * b)) << 3);
+        L.g1[b] = (8 * h + q + 4) * 128 + ((gv ^ (8 * b) ^ 2) << 3);
+    }
+    return L;
+}
+
 // A operand of a TRANSPOSED product dX = W^T dY from the forward image of a layer (ksb k-steps per row block):
 // reduction over the layer's output units n of row block nb, k-step tq (slot 8h'+j' <-> n = 32nb + ku(tq, h', j'),
 // i.e. the same slot<->unit map as B operands made from accumulator registers), output rows = input units
 // 32ib + (lane & 31).  Two transposed reads per part; conflict-free (see the header comment).
-__device__ __forceinline__ A2 h3_lda_T(const char *img, int base, int ksb, int nb, int tq, int ib, int lane)
+__device__ __forceinline__ A2 h3_lda_T(const char *img, int base, int ksb, int nb, int tq, int ib, const H3Lane &L)
 {
-    const int hq = lane >> 5, ti = (lane >> 4) & 1, q = (lane >> 2) & 3, p = lane & 3;
-    const int ai = p >> 1, hi = p & 1;
-    const char *a = img + base + ((nb * ksb + 2 * ib + ti) * 2) * H3_SUB + (16 * tq + 4 * hq + q) * 16 + hi * 576 + ai * 8;
+    const char *a = img + L.lT + (base + ((nb * ksb + 2 * ib) * 2) * H3_SUB + tq * 256);
     A2 r;
     r.hi = cat44(ds_tr4(a), ds_tr4(a + 8 * 16));
     r.lo = cat44(ds_tr4(a + H3_SUB), ds_tr4(a + H3_SUB + 8 * 16));
@@ -198,28 +222,25 @@ constexpr int H3_STAGE_MAT = 2 * H3_STAGE_PART;    // hi + lo
 __device__ __forceinline__ int h3_stage_off(int s, int uq) { return s * 128 + ((uq ^ (((s >> 1) & 7) | (((s >> 1) & 1) << 3))) << 3); }
 
 // registers of one 32-unit block (lane = sample) -> chunks of units 32b .. 32b+31
-__device__ __forceinline__ void h3_stage_put(char *mat, int lane, int b, const HL2 &v)
+__device__ __forceinline__ void h3_stage_put(char *mat, const H3Lane &L, int b, const HL2 &v)
 {
-    const int s = lane & 31, h = lane >> 5;
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int a = 0; a < 2; ++a) {
-            const int off = h3_stage_off(s, 8 * b + 4 * t + 2 * a + h);
+            const int off = L.pb + (((8 * b + 4 * t + 2 * a) ^ L.pv) << 3);
             const h8 &hi = v.t[t].hi, &lo = v.t[t].lo;
             *reinterpret_cast<h4 *>(mat + off) = h4{ hi[4 * a], hi[4 * a + 1], hi[4 * a + 2], hi[4 * a + 3] };
             *reinterpret_cast<h4 *>(mat + H3_STAGE_PART + off) = h4{ lo[4 * a], lo[4 * a + 1], lo[4 * a + 2], lo[4 * a + 3] };
         }
 }
-// operand (A or B alike) of k-step t for units 32b + (lane & 31): slot 8h + j <-> sample 16t + 8h + j
-__device__ __forceinline__ HL h3_stage_get(const char *mat, int lane, int b, int t)
+// operand (A or B alike) of k-step t for units 32b + (lane & 31): slot 8h + j <-> sample 16t + 8h + j;
+// o0 / o1 = L.g0[b] / L.g1[b]
+__device__ __forceinline__ HL h3_stage_get(const char *mat, int o0, int o1, int t)
 {
-    const int h = lane >> 5, g16 = (lane >> 4) & 1, q = (lane >> 2) & 3, p = lane & 3;
-    const int uq = 8 * b + 4 * g16 + p, s0 = 16 * t + 8 * h + q;
-    const int o0 = h3_stage_off(s0, uq), o1 = h3_stage_off(s0 + 4, uq);
     HL r;
-    r.hi = cat44(ds_tr4(mat + o0), ds_tr4(mat + o1));
-    r.lo = cat44(ds_tr4(mat + H3_STAGE_PART + o0), ds_tr4(mat + H3_STAGE_PART + o1));
+    r.hi = cat44(ds_tr4(mat + o0 + 2048 * t), ds_tr4(mat + o1 + 2048 * t));
+    r.lo = cat44(ds_tr4(mat + o0 + (H3_STAGE_PART + 2048 * t)), ds_tr4(mat + o1 + (H3_STAGE_PART + 2048 * t)));
     return r;
 }
 // sum of the 8 slots of an operand (for bias gradients): hi and lo parts, f32 accumulate

@@ -163,6 +163,7 @@ __global__ void __launch_bounds__(kThreads) k_bin_scatter(const float *__restric
 // 2^k, k = 50 - ceil(log2 M) - ceil(log2(n+1)): no overflow, resolution n*M*2^-50.  Integer
 // addition is associative, so the table gradient is bit-reproducible run to run (the
 // reference's atomics are not) and closer to the exact sum than an fp32 running sum.
+template <int kThreads, int U>
 __global__ void __launch_bounds__(kThreads) k_bin_accumulate(const Rec *__restrict__ recs,
                                                              const uint32_t *__restrict__ starts,
                                                              const uint32_t *__restrict__ maxbits, BinGeom g,
@@ -196,8 +197,7 @@ __global__ void __launch_bounds__(kThreads) k_bin_accumulate(const Rec *__restri
         atomicAdd(&a[2 * e1], fx(w1 * r.z));
         atomicAdd(&a[2 * e1 + 1], fx(w1 * r.w));
     };
-    // 8 independent 16-B loads in flight per lane (the records are read once, from HBM)
-    constexpr int U = 8;
+    // U independent 16-B loads in flight per lane (the records are read once, from HBM)
     uint32_t i = lo + threadIdx.x;
     for (; i + (U - 1) * kThreads < hi; i += U * kThreads) {
         float4 r[U];
@@ -337,7 +337,7 @@ SCANERF_API int scanerf_embedding_bg_backward_binned(const float *points, const 
     else
         hipLaunchKernelGGL((k_bin_scatter<true>), dim3(g.W), dim3(kThreads), lds_bins, st, points, gi, resolutions, g,
                            counts, starts, recs, grad_features, maxbits);
-    hipLaunchKernelGGL(k_bin_accumulate, dim3(nbins), dim3(kThreads), (size_t)(2 << g.bucket_log) * 8, st, recs, starts,
+    hipLaunchKernelGGL((k_bin_accumulate<256, 8>), dim3(nbins), dim3(256), (size_t)(2 << g.bucket_log) * 8, st, recs, starts,
                        maxbits, g, grad_features);
     return check_launch("embedding_bg_backward_binned");
 }
@@ -399,11 +399,22 @@ SCANERF_API int scanerf_render_scatter_accumulate(float *grad_features, int B, i
                     "render_scatter_accumulate: workspace too small (%zu B)", workspace_bytes);
     g.capacity = w.capacity;
     const size_t lds_bytes = (size_t)(2 << g.bucket_log) * 8;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bin_accumulate),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    SCANERF_REQUIRE(e == hipSuccess, "render_scatter_accumulate: cannot reserve %zu B of LDS: %s", lds_bytes,
-                    hipGetErrorString(e));
-    hipLaunchKernelGGL(k_bin_accumulate, dim3(nbins), dim3(kThreads), lds_bytes, (hipStream_t)stream, w.recs, w.starts,
-                       w.maxbits, g, grad_features);
+    const char *ve = getenv("SCANERF_ACC_VARIANT");  // tuning experiments only
+    const int variant = ve ? atoi(ve) : 0;
+#define SCANERF_LAUNCH_ACC(TH, UU)                                                                                  \
+    {                                                                                                               \
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bin_accumulate<TH, UU>),               \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);             \
+        SCANERF_REQUIRE(e == hipSuccess, "render_scatter_accumulate: cannot reserve %zu B of LDS: %s", lds_bytes,    \
+                        hipGetErrorString(e));                                                                      \
+        hipLaunchKernelGGL((k_bin_accumulate<TH, UU>), dim3(nbins), dim3(TH), lds_bytes, (hipStream_t)stream, w.recs, \
+                           w.starts, w.maxbits, g, grad_features);                                                  \
+    }
+    // measured on MI355X (tools/bench_accum.py, 5.4e8 records): 256x8 3.61 ms, 512x8 3.38, 1024x4 3.33, 256x16 3.36 --
+    // the pass is bound by the LDS atomic rate (2.1e9 64-bit adds), not by occupancy or loads in flight
+    if (variant == 1) SCANERF_LAUNCH_ACC(256, 8)
+    else if (variant == 2) SCANERF_LAUNCH_ACC(512, 8)
+    else SCANERF_LAUNCH_ACC(1024, 4)
+#undef SCANERF_LAUNCH_ACC
     return check_launch("render_scatter_accumulate");
 }
