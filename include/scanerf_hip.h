@@ -193,6 +193,15 @@ int scanerf_render_scatter_plan(const float *rays_o, const float *rays_d, const 
                                 size_t workspace_bytes, scanerf_stream_t stream);
 int scanerf_render_scatter_accumulate(float *grad_features, int B, int S, int T, void *workspace,
                                       size_t workspace_bytes, scanerf_stream_t stream);
+/* Photometric loss of the training step and dL/d(out_ray) in two launches (criterions.py:90,142-144 MSE over the valid
+ * rays' rgb + tile.py:999 reg_weight * l2_reg_specular = mean over valid rays x 3 of out_ray[:,14]):
+ *   loss [1] = (sum_valid |rgb - target|^2 + reg_weight * sum_valid out_ray[:,14]) / (3 * n_valid)
+ *   grad_out [B,16] = its gradient w.r.t. out_ray (all 16 columns written; invalid rays zero)
+ * scratch: scanerf_photometric_loss_scratch_floats() f32.  Deterministic (fixed reduction order). */
+int scanerf_photometric_loss_scratch_floats(void);
+int scanerf_photometric_loss_grad(const float *out_ray, const float *target /*[B,3]*/, const uint8_t *ray_valid,
+                                  float reg_weight, float *grad_out, float *loss, float *scratch, int B,
+                                  scanerf_stream_t stream);
 /* Device self-test of the split-f16 backward primitives (csrc/render_h3.h; test infrastructure, one wave):
  * workspace from scanerf_pack_decoder; dy, x [64][32] f32 -> out_dx [2][64][32] (W^T dy of Spatial_MLP.mlp.2, and
  * of the H part of Directional_MLP.mlp.0 in rows 0..31 of the second slab), out_dw [64][64] = dy x^T, out_rs [64]

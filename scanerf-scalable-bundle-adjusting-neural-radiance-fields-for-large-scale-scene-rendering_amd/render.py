@@ -105,6 +105,23 @@ def render_backward(rays_o, rays_d, z_vals, dists, features, resolutions, packed
     return dfeat, grad_blob
 
 
+def photometric_loss_grad(out_ray, target, ray_valid=None, reg_weight=0.01, grad_out=None):
+    """MSE over the valid rays' rgb + reg_weight * l2_reg_specular (criterions.py:142-144, tile.py:999) and its gradient
+    w.r.t. out_ray, without a torch graph -> (loss [1] device tensor, grad_out [B,16])."""
+    B = out_ray.shape[0]
+    dev = out_ray.device
+    if grad_out is None:
+        grad_out = torch.empty((B, RAY_OUT), dtype=_f32, device=dev)
+    loss = torch.empty(1, dtype=_f32, device=dev)
+    scratch = torch.empty(lib().scanerf_photometric_loss_scratch_floats(), dtype=_f32, device=dev)
+    check(lib().scanerf_photometric_loss_grad(
+        dev_ptr(out_ray, _f32, "out_ray"), dev_ptr(target, _f32, "target"),
+        dev_ptr(ray_valid, (torch.bool, torch.uint8), "ray_valid", allow_none=True), ctypes.c_float(reg_weight),
+        dev_ptr(grad_out, _f32, "grad_out"), dev_ptr(loss, _f32, "loss"), dev_ptr(scratch, _f32, "scratch"), ctypes.c_int(B),
+        stream()), "photometric_loss_grad")
+    return loss, grad_out
+
+
 def scatter_supported(B, S, T):
     return lib().scanerf_render_scatter_workspace_bytes(ctypes.c_int(B), ctypes.c_int(S), ctypes.c_int(T)) != 0
 

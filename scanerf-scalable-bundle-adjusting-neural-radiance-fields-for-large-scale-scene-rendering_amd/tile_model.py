@@ -40,27 +40,44 @@ def sh3(v):
 
 
 class Decoder(nn.Module):
-    """sigma / diffuse / tint / SH-conditioned specular decoder with the parameter names of the
-    reference's ShallowMLP (network.py:151-190), so state dicts and blobs are interchangeable."""
+    """sigma / diffuse / tint / SH-conditioned specular decoder of the reference's ShallowMLP (network.py:151-190).
+    The parameters ARE the render-time blob (rendering.py:101-112: per layer [bias, W^T]), one flat tensor: the fused
+    kernels read it as it is, their gradient is its .grad, and the optimiser steps one tensor instead of sixteen
+    (Adam is element-wise, so the update is the same).  Per-layer views carry the reference's parameter names."""
 
     def __init__(self, seed=0):
         super().__init__()
-        g = torch.Generator().manual_seed(seed)
-        for name, o, i in network.LAYERS:
-            w = torch.randn(o, i, generator=g) * math.sqrt(2.0 / (i + o))
-            self.register_parameter(name.replace(".", "_") + "_weight", nn.Parameter(w))
-            self.register_parameter(name.replace(".", "_") + "_bias", nn.Parameter(torch.zeros(o)))
+        self.params = nn.Parameter(network.xavier_blob(seed))
+        self._views = {}
+
+    def _view(self, name, kind):
+        """weight [out,in] / bias [out] of a layer as a (differentiable) view of the blob"""
+        k = 0
+        for n, o, i in network.LAYERS:
+            if n == name:
+                return self.params[k:k + o] if kind == "bias" else self.params[k + o:k + o + i * o].reshape(i, o).t()
+            k += o + i * o
+        raise KeyError(name)
+
+    def __getattr__(self, attr):  # e.g. sigma_layer_mlp_0_bias -> view (the names tile.py's optimiser groups use)
+        for n, _, _ in network.LAYERS:
+            for kind in ("weight", "bias"):
+                if attr == n.replace(".", "_") + "_" + kind:
+                    return self._view(n, kind)
+        return super().__getattr__(attr)
 
     def ref_state_dict(self):
-        return {f"{n}.{k}": getattr(self, n.replace(".", "_") + "_" + k) for n, _, _ in network.LAYERS
-                for k in ("weight", "bias")}
+        return {f"{n}.{k}": self._view(n, k) for n, _, _ in network.LAYERS for k in ("weight", "bias")}
+
+    def load_ref_state_dict(self, sd):
+        with torch.no_grad():
+            self.params.copy_(network.blob_from_state_dict(sd).to(self.params.device))
 
     def blob(self):
-        return network.blob_from_state_dict(self.ref_state_dict())
+        return self.params
 
     def _lin(self, name, x):
-        n = name.replace(".", "_")
-        return F.linear(x, getattr(self, n + "_weight"), getattr(self, n + "_bias"))
+        return F.linear(x, self._view(name, "weight"), self._view(name, "bias"))
 
     def forward(self, feats, dirs, weight_feature):
         act = lambda u: torch.exp(u * u * -50.0)
@@ -111,6 +128,13 @@ class TileModel(nn.Module):
         self.exp_avg = torch.zeros_like(self.features)
         self.exp_avg_sq = torch.zeros_like(self.features)
         self.adam_step = 0
+
+    def weight_feature(self, global_step):
+        """Coarse-to-fine mask on the device, cached: it is constant once global_step >= 10 000."""
+        key = min(int(global_step), 10000)
+        if getattr(self, "_wf_key", None) != key:
+            self._wf_key, self._wf = key, network.weight_feature(global_step, self.device)
+        return self._wf
 
     # ---- sampling (no grad: hashgrid/__init__.py:278-285) -------------------------------
     @torch.no_grad()
@@ -298,7 +322,7 @@ def train_step_fused(model, dec_opt, rays_o, rays_d, target, S, global_step, tab
         with _sec(timer, "sample_points_grid", B * (24 + 2 * 4 * S)):
             z, dist = model.sample(rays_o, rays_d, S)
         valid = torch.all(z != -1, dim=-1)
-        wf = network.weight_feature(global_step, dev)
+        wf = model.weight_feature(global_step)
         blob = model.decoder.blob()
         model.packed.pack(blob, wf)
         ntile = (S + 31) // 32
@@ -309,11 +333,8 @@ def train_step_fused(model, dec_opt, rays_o, rays_d, target, S, global_step, tab
                   B * S * MLP_FLOPS_PER_SAMPLE):
             out, _ = render.render_forward(rays_o, rays_d, z, dist, model.features, model.resolution, model.packed, *box,
                                            ray_valid=valid, want_weights=False, tile_T=tile_T, xstash=xstash)
-    # loss on the per-ray outputs (tiny torch graph on [B,16])
-    leaf = out.detach().requires_grad_(True)
-    nv = valid.sum()
-    loss = F.mse_loss(leaf[:, 0:3][valid], target[valid]) + 0.01 * leaf[:, 14][valid].sum() / (3 * nv)
-    loss.backward()
+    # loss and dL/d(out_ray) in two launches (the torch graph for it was ~60 tiny kernels with host-bound gaps)
+    loss, grad_out = render.photometric_loss_grad(out, target, valid, 0.01)
     with torch.no_grad():
         gtab = torch.zeros_like(model.features)
         gblob = torch.zeros(network.PARAMSIZE, device=dev)
@@ -329,7 +350,7 @@ def train_step_fused(model, dec_opt, rays_o, rays_d, target, S, global_step, tab
         # forward recompute + activation gradients + weight gradients = 3x the forward MLP FLOPs
         with _sec(timer, "render_backward", B * (24 + 20 + S * 16 * 8 * 2 * 4 + S * 16 * 8), 3 * B * S * MLP_FLOPS_PER_SAMPLE):
             dfeat, _ = render.render_backward(rays_o, rays_d, z, dist, model.features, model.resolution, model.packed, wf,
-                                              *box, out, tile_T, leaf.grad, ray_valid=valid, grad_blob=gblob, xstash=xstash,
+                                              *box, out, tile_T, grad_out, ray_valid=valid, grad_blob=gblob, xstash=xstash,
                                               ray_grad_buffers=ray_bufs, scatter=(ws, gtab) if fused else None,
                                               want_dfeat=pose_grads or not fused)
         if pose_grads:
@@ -346,8 +367,6 @@ def train_step_fused(model, dec_opt, rays_o, rays_d, target, S, global_step, tab
         model.features.grad = gtab
         with _sec(timer, "sparse_adam", model.features.numel() * 28):
             model.table_adam(table_lr)
-        for k, v in network.state_dict_from_blob(gblob).items():
-            name, kind = k.rsplit(".", 1)
-            getattr(model.decoder, name.replace(".", "_") + "_" + kind).grad = v.contiguous()
+        model.decoder.params.grad = gblob
         dec_opt.step()
-    return (loss.detach(), g_o, g_d) if pose_grads else loss.detach()
+    return (loss[0], g_o, g_d) if pose_grads else loss[0]

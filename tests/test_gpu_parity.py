@@ -484,6 +484,24 @@ def test_fused_scatter_equals_dfeat_scatter(S, arith, B, S_):
         render.set_arith("h3")
 
 
+def test_photometric_loss_grad_vs_autograd(S):
+    """csrc/loss.hip against the torch graph it replaces (criterions.py:142-144 MSE + tile.py:999 0.01 * l2_reg)."""
+    from scanerf_amd import render
+    torch.manual_seed(11)
+    for B in (1, 777, 70000):
+        out = torch.rand(B, 16, device=DEV)
+        tgt = torch.rand(B, 3, device=DEV)
+        valid = torch.rand(B, device=DEV) < 0.8
+        valid[0] = True
+        leaf = out.clone().requires_grad_(True)
+        nv = valid.sum()
+        ref = torch.nn.functional.mse_loss(leaf[:, 0:3][valid], tgt[valid]) + 0.01 * leaf[:, 14][valid].sum() / (3 * nv)
+        ref.backward()
+        loss, g_out = render.photometric_loss_grad(out, tgt, valid, 0.01)
+        np.testing.assert_allclose(loss.item(), ref.item(), rtol=2e-6)
+        np.testing.assert_allclose(g_out.cpu().numpy(), leaf.grad.cpu().numpy(), rtol=1e-6, atol=1e-12)
+
+
 def test_render_rays_fg_bg_merge_vs_oracle(S):
     """a5 (inverse-z background sampling) + a13 (fg/bg merge with T_left): the fused tile render against
     the oracle's restatement of tile.py:639-692 / hashgrid/__init__.py:413-509."""
