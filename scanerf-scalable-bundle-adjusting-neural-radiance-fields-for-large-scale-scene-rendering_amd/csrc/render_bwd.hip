@@ -656,8 +656,7 @@ SCANERF_API int scanerf_render_backward(const float *rays_o, const float *rays_d
         SCANERF_REQUIRE(grad_features, "render_backward: grad_features is required with a scatter workspace");
         SCANERF_REQUIRE(scanerf_render_scatter_workspace_bytes(B, S, T) != 0,
                         "render_backward: fused scatter does not support B=%d S=%d T=%d", B, S, T);
-        const int lt = bin_ilog2(T);
-        a.bins.bucket_log = lt < kBucketLog ? lt : (lt - 8 > kBucketLog ? lt - 8 : kBucketLog);
+        a.bins.bucket_log = fused_bucket_log(T);
         a.bins.N = B * S; a.bins.L = 16; a.bins.T = T;
         a.bins.NB = T >> a.bins.bucket_log;
         a.bins.W = blocks;

@@ -268,8 +268,7 @@ __global__ void __launch_bounds__(1024) k_bin_count_rays(RenderArgs f, BinGeom g
 bool fused_geom(int B, int S, int T, BinGeom &g, int arith = SCANERF_ARITH_F32)
 {
     if (B < 1 || S < 1 || T < 2 || (T & (T - 1))) return false;
-    const int lt = bin_ilog2(T);
-    g.bucket_log = lt < kBucketLog ? lt : (lt - 8 > kBucketLog ? lt - 8 : kBucketLog);
+    g.bucket_log = fused_bucket_log(T);
     if (g.bucket_log > 13) return false;  // 64-bit LDS image of a bucket: 128 KB at 2^13 entries
     if ((int64_t)B * S * 16 * 4 + (1 << 20) >= (int64_t)1 << 31) return false;  // 32-bit record offsets
     g.N = B * S; g.L = 16; g.T = T;

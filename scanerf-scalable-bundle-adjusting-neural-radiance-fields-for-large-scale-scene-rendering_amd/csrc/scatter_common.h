@@ -2,11 +2,13 @@
 // scatter, shared by scatter.hip (count / scan / accumulate, stand-alone producer) and render_bwd.hip
 // (which emits the records straight from the fused backward kernel).
 #pragma once
+#include <stdlib.h>
 #include "hashgrid_common.h"
 
 namespace scanerf {
 
 constexpr int kBucketLog = 11;  // 2048 entries (16 KB of fp32 pairs) per bucket
+constexpr int kFusedBucketLog = 11;
 
 struct BinGeom {
     int N, L, T;
@@ -120,11 +122,23 @@ inline bool bin_workspace_carve(void *workspace, size_t bytes, int nbins, int W,
     w.capacity = cap > 0xfffffff0u ? 0xfffffff0u : (uint32_t)cap;
     return true;
 }
+// bucket size of the FUSED producer (k_render_bwd* emits, scanerf_render_scatter_accumulate consumes): log2 entries
+inline int fused_bucket_log(int T);
 inline int bin_ilog2(int v)
 {
     int l = 0;
     while ((1 << l) < v) ++l;
     return l;
+}
+
+inline int fused_bucket_log(int T)
+{
+    const int lt = bin_ilog2(T);
+    int want = kFusedBucketLog;
+    if (const char *e = getenv("SCANERF_FUSED_BUCKET_LOG")) want = atoi(e);  // tuning experiments only
+    // at most 256 buckets per level (16 KB of cursors in the producer's LDS), at least `want` entries per bucket
+    const int bl = lt - 8 > want ? lt - 8 : want;
+    return lt < bl ? lt : bl;
 }
 
 }  // namespace scanerf
