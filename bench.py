@@ -197,7 +197,16 @@ def main():
             else:
                 ach = alg_bytes / (avg_ms * 1e-3) / 1e9
                 roof = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS}
-            roof.update({"kernel": name, "traffic": None, "avg_launch_ms": avg_ms,
+            # HBM-side bytes of that kernel per launch: rocprofv3 PMC passes of this same command, committed under profiles/
+            traffic = None
+            try:
+                pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+                if h3 and name in pm:
+                    traffic = pm[name]["fetch_bytes"] + pm[name]["write_bytes"]
+                    roof["traffic_source"] = "profiles/r01_pmc_traffic.json (FETCH_SIZE + WRITE_SIZE of " + pm[name]["kernel"] + ")"
+            except (OSError, ValueError, KeyError):
+                pass
+            roof.update({"kernel": name, "traffic": traffic, "avg_launch_ms": avg_ms,
                          "algorithmic_bytes_per_launch": alg_bytes, "all_kernels_ms": timer.summary()})
             line["roofline"] = roof
         if not args.no_cpu_baseline and world == 1:
