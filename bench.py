@@ -43,6 +43,7 @@ def parse():
     ap.add_argument("--path", default=os.environ.get("SCANERF_BENCH_PATH", "auto"), choices=["auto", "fused", "ops"])
     ap.add_argument("--rays", type=int, default=65536)
     ap.add_argument("--samples", type=int, default=128)
+    ap.add_argument("--log2-T", type=int, default=19, help="hash-table entries per level (configs[1]: 19; the reference's default.yaml: 24)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     return ap.parse_args()
 
@@ -111,7 +112,7 @@ def main():
 
     B, S = args.rays, args.samples
     torch.manual_seed(rank)
-    model = tm.TileModel([-4.0 + 8.0 * rank, -4, -4], [8, 8, 8], dev, log2_T=19, seed=rank)
+    model = tm.TileModel([-4.0 + 8.0 * rank, -4, -4], [8, 8, 8], dev, log2_T=args.log2_T, seed=rank)
     dec_opt = torch.optim.Adam(model.decoder.parameters(), lr=1e-3, betas=(0.9, 0.99), eps=1e-15)
     corner = torch.tensor([-4.0 + 8.0 * rank, -4, -4], device=dev)
     rays_o = torch.rand(B, 3, device=dev) * 8 + corner
@@ -174,7 +175,7 @@ def main():
             "value": value, "value_is": "whole-job aggregate over n_gpus (one tile per GPU)", "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"configs[1]: single 8m^3 tile per GPU, L=16 T=2^19 fp32 hash grid, 2-hidden x 64 "
+            "config": {"workload": f"configs[1]: single 8m^3 tile per GPU, L=16 T=2^{args.log2_T} fp32 hash grid, 2-hidden x 64 "
                                    f"decoder, {B} rays x {S} samples, full training iteration "
                                    f"(sample+encode+decode+composite fwd, bwd, sparse Adam); foreground branch",
                        "path": path, "rays_per_step": B, "samples": S, "tiles_per_gpu": 1,

@@ -169,13 +169,14 @@ __global__ void __launch_bounds__(kThreads) k_bin_accumulate(const Rec *__restri
                                                              const uint32_t *__restrict__ maxbits, BinGeom g,
                                                              float *__restrict__ grad_features)
 {
-    extern __shared__ long long acc64[];  // [2 << bucket_log]
-    const int bs = 1 << g.bucket_log;
+    extern __shared__ long long acc64[];  // [2 << window_log]
+    // Buckets larger than the LDS image (tables above 2^21 entries: bucket = T/256 so that the producer's cursors fit its
+    // LDS) are accumulated in windows of 2^13 entries: every window pass re-reads the bucket's records -- about 2 MB,
+    // they stay in L2 -- and applies the entries that fall inside it.
+    const int wl = g.bucket_log < 13 ? g.bucket_log : 13, ws = 1 << wl;
     const uint32_t lo = min(starts[blockIdx.x], g.capacity), hi = min(starts[blockIdx.x + 1], g.capacity);
     const float M = __uint_as_float(*maxbits);
     if (hi == lo || !(M > 0.0f)) return;  // nothing to add (uniform per workgroup)
-    for (int i = threadIdx.x; i < 2 * bs; i += kThreads) acc64[i] = 0;
-    __syncthreads();
     int eM;
     frexpf(M, &eM);  // M < 2^eM
     // float -> fixed point through the double "magic number": d = v*2^k + 1.5*2^52 holds round(v*2^k) in
@@ -187,41 +188,52 @@ __global__ void __launch_bounds__(kThreads) k_bin_accumulate(const Rec *__restri
     auto fx = [&](float v) {
         return (unsigned long long)(__double_as_longlong(fma((double)v, scale, magic)) - __double_as_longlong(magic));
     };
-    auto apply = [&](const float4 &r) {
-        const uint32_t hdr = __float_as_uint(r.x);
-        const uint32_t e0 = hdr & 0xffffu, e1 = hdr >> 16;
-        const float w1 = r.y, w0 = 1.0f - w1;
-        unsigned long long *a = reinterpret_cast<unsigned long long *>(acc64);
-        atomicAdd(&a[2 * e0], fx(w0 * r.z));
-        atomicAdd(&a[2 * e0 + 1], fx(w0 * r.w));
-        atomicAdd(&a[2 * e1], fx(w1 * r.z));
-        atomicAdd(&a[2 * e1 + 1], fx(w1 * r.w));
-    };
-    // U independent 16-B loads in flight per lane (the records are read once, from HBM)
-    uint32_t i = lo + threadIdx.x;
-    for (; i + (U - 1) * kThreads < hi; i += U * kThreads) {
-        float4 r[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            typedef float v4f __attribute__((ext_vector_type(4)));
-            v4f t = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(r4 + i + u * kThreads));
-            r[u] = make_float4(t.x, t.y, t.z, t.w);
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) apply(r[u]);
-    }
-    for (; i < hi; i += kThreads) apply(r4[i]);
-    __syncthreads();
     const int level = blockIdx.x / g.NB, bucket = blockIdx.x % g.NB;
-    float2 *dst = reinterpret_cast<float2 *>(grad_features) + (size_t)level * g.T + ((size_t)bucket << g.bucket_log);
-    for (int j = threadIdx.x; j < bs; j += kThreads) {
-        const long long qx = acc64[2 * j], qy = acc64[2 * j + 1];
-        if (qx | qy) {
-            float2 v = dst[j];
-            v.x += (float)ldexp((double)qx, -k);
-            v.y += (float)ldexp((double)qy, -k);
-            dst[j] = v;
+    for (int win = 0; win < (1 << (g.bucket_log - wl)); ++win) {
+        for (int i = threadIdx.x; i < 2 * ws; i += kThreads) acc64[i] = 0;
+        __syncthreads();
+        const uint32_t wbase = (uint32_t)win << wl;
+        auto apply = [&](const float4 &r) {
+            const uint32_t hdr = __float_as_uint(r.x);
+            const uint32_t e0 = (hdr & 0xffffu) - wbase, e1 = (hdr >> 16) - wbase;  // unsigned: outside the window = huge
+            const float w1 = r.y, w0 = 1.0f - w1;
+            unsigned long long *a = reinterpret_cast<unsigned long long *>(acc64);
+            if (e0 < (uint32_t)ws) {
+                atomicAdd(&a[2 * e0], fx(w0 * r.z));
+                atomicAdd(&a[2 * e0 + 1], fx(w0 * r.w));
+            }
+            if (e1 < (uint32_t)ws) {
+                atomicAdd(&a[2 * e1], fx(w1 * r.z));
+                atomicAdd(&a[2 * e1 + 1], fx(w1 * r.w));
+            }
+        };
+        // U independent 16-B loads in flight per lane (the records are read once from HBM; window passes re-read them from L2)
+        uint32_t i = lo + threadIdx.x;
+        for (; i + (U - 1) * kThreads < hi; i += U * kThreads) {
+            float4 r[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                typedef float v4f __attribute__((ext_vector_type(4)));
+                const v4f *src = reinterpret_cast<const v4f *>(r4 + i + u * kThreads);
+                const v4f t = g.bucket_log <= 13 ? __builtin_nontemporal_load(src) : *src;  // windowed: keep them cached
+                r[u] = make_float4(t.x, t.y, t.z, t.w);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) apply(r[u]);
         }
+        for (; i < hi; i += kThreads) apply(r4[i]);
+        __syncthreads();
+        float2 *dst = reinterpret_cast<float2 *>(grad_features) + (size_t)level * g.T + ((size_t)bucket << g.bucket_log) + wbase;
+        for (int j = threadIdx.x; j < ws; j += kThreads) {
+            const long long qx = acc64[2 * j], qy = acc64[2 * j + 1];
+            if (qx | qy) {
+                float2 v = dst[j];
+                v.x += (float)ldexp((double)qx, -k);
+                v.y += (float)ldexp((double)qy, -k);
+                dst[j] = v;
+            }
+        }
+        __syncthreads();
     }
 }
 
@@ -269,7 +281,7 @@ bool fused_geom(int B, int S, int T, BinGeom &g, int arith = SCANERF_ARITH_F32)
 {
     if (B < 1 || S < 1 || T < 2 || (T & (T - 1))) return false;
     g.bucket_log = fused_bucket_log(T);
-    if (g.bucket_log > 13) return false;  // 64-bit LDS image of a bucket: 128 KB at 2^13 entries
+    if (g.bucket_log > 16) return false;  // local entry indices are 16-bit; buckets above 2^13 entries are accumulated in windows
     if ((int64_t)B * S * 16 * 4 + (1 << 20) >= (int64_t)1 << 31) return false;  // 32-bit record offsets
     g.N = B * S; g.L = 16; g.T = T;
     g.NB = T >> g.bucket_log;
@@ -397,7 +409,7 @@ SCANERF_API int scanerf_render_scatter_accumulate(float *grad_features, int B, i
     SCANERF_REQUIRE(bin_workspace_carve(workspace, workspace_bytes, nbins, g.W, w),
                     "render_scatter_accumulate: workspace too small (%zu B)", workspace_bytes);
     g.capacity = w.capacity;
-    const size_t lds_bytes = (size_t)(2 << g.bucket_log) * 8;
+    const size_t lds_bytes = (size_t)(2 << (g.bucket_log < 13 ? g.bucket_log : 13)) * 8;
     const char *ve = getenv("SCANERF_ACC_VARIANT");  // tuning experiments only
     const int variant = ve ? atoi(ve) : 0;
 #define SCANERF_LAUNCH_ACC(TH, UU)                                                                                  \

@@ -5,6 +5,8 @@ Tolerances: bit-exact for the sampler / box clipping / ray generation / Adam (bu
 same IEEE sequence as the oracle); 1e-5 relative for the encoder (FMA contraction differs);
 1e-4 relative (north_star) for rendered rgb / depth / weights.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -482,6 +484,49 @@ def test_fused_scatter_equals_dfeat_scatter(S, arith, B, S_):
         np.testing.assert_allclose(g2.cpu().numpy() / sc, g1.cpu().numpy() / sc, rtol=1e-4, atol=1e-6)
     finally:
         render.set_arith("h3")
+
+
+def test_fused_scatter_large_table(S):
+    """Tables above 2^21 entries (the reference's default is 2^24): buckets of T/256 entries are accumulated in LDS
+    windows.  The fused path against the reference-style atomic kernel on the same dfeat."""
+    from scanerf_amd import network, render
+    from scanerf_amd.hashgrid.lib.HASHGRID import embedding_bg_backward_cuda
+    from scanerf_amd.tile_model import TileModel
+    torch.manual_seed(8)
+    B, S_ = 3000, 64
+    m = TileModel([-4, -4, -4], [8, 8, 8], DEV, log2_T=22, seed=2)
+    with torch.no_grad():
+        m.features.mul_(1000.0)
+    o = torch.rand(B, 3, device=DEV) * 8 - 4
+    d = torch.nn.functional.normalize(torch.randn(B, 3, device=DEV), dim=-1)
+    z, dist = m.sample(o, d, S_)
+    valid = torch.all(z != -1, dim=-1)
+    wf = network.weight_feature(20000, DEV)
+    m.packed.pack(m.decoder.blob(), wf)
+    box = (m.min_bbox.tolist(), m.bbox_size.tolist(), render.FORE, False)
+    tile_T = torch.empty(B, 2, device=DEV)
+    xs = torch.empty(B * S_, 32, device=DEV)
+    out, _ = render.render_forward(o, d, z, dist, m.features, m.resolution, m.packed, *box, ray_valid=valid,
+                                   want_weights=False, tile_T=tile_T, xstash=xs)
+    gout = torch.randn(B, 16, device=DEV)
+    T = m.features.shape[1]
+    assert render.scatter_supported(B, S_, T)
+    ws = render.scatter_plan(o, d, z, m.resolution, T, *box, ray_valid=valid)
+    g2 = torch.zeros_like(m.features)
+    dfeat, _ = render.render_backward(o, d, z, dist, m.features, m.resolution, m.packed, wf, *box, out, tile_T, gout,
+                                      ray_valid=valid, xstash=xs, scatter=(ws, g2), want_dfeat=True)
+    render.scatter_accumulate(ws, g2, B, S_)
+    pts = (((o[:, None, :] + z[:, :, None] * d[:, None, :]).reshape(-1, 3) - m._min_dev) / m._size_dev * 4.0 - 2.0).contiguous()
+    g1 = torch.zeros_like(m.features)
+    os.environ["SCANERF_SCATTER"] = "atomics"
+    try:
+        embedding_bg_backward_cuda(pts, dfeat.permute(1, 0, 2).contiguous(), None, g1, m.features, m.resolution)
+    finally:
+        del os.environ["SCANERF_SCATTER"]
+    torch.cuda.synchronize()
+    sc = float(g1.abs().max())
+    assert sc > 0
+    np.testing.assert_allclose(g2.cpu().numpy() / sc, g1.cpu().numpy() / sc, rtol=1e-4, atol=2e-6)
 
 
 def test_photometric_loss_grad_vs_autograd(S):
