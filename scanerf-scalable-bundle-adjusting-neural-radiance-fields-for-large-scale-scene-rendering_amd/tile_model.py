@@ -370,3 +370,71 @@ def train_step_fused(model, dec_opt, rays_o, rays_d, target, S, global_step, tab
         model.decoder.params.grad = gblob
         dec_opt.step()
     return (loss[0], g_o, g_d) if pose_grads else loss[0]
+
+
+def fgbg_gradients(model, rays_o, rays_d, target, S_fg, S_bg, global_step, invalid_underground=False, timer=None):
+    """Loss and parameter gradients of the complete per-tile render of tile.py:639-692 / :880-1015: foreground
+    (occupancy-sampled, contract_fore) + T_left * background (inverse-z, contract_bg, infinity), MSE on the merged colour
+    over all rays + 0.01 * (l2_reg_specular of both branches) -- two fused forward/backward pairs over the same table and
+    decoder.  Returns (loss, grad_table [16,T,2], grad_blob [13994])."""
+    B = rays_o.shape[0]
+    dev = model.device
+    T = model.features.shape[1]
+    with torch.no_grad():
+        wf = model.weight_feature(global_step)
+        model.packed.pack(model.decoder.blob(), wf)
+        box = (model.min_bbox.tolist(), model.bbox_size.tolist())
+        branches = []
+        z, dist = model.sample(rays_o, rays_d, S_fg)
+        branches.append((z, dist, torch.all(z != -1, dim=-1), render.FORE, False))
+        zb, db, vb = model.inverse_z_sampling(rays_o, rays_d, S_bg, invalid_underground)
+        branches.append((zb, db, vb, render.BG, True))
+        outs, state = [], []
+        for z_, d_, v_, mode, inf in branches:
+            S = z_.shape[1]
+            tile_T = torch.empty((B, (S + 31) // 32), device=dev)
+            xs = torch.empty((B * S, 32), device=dev)
+            out, _ = render.render_forward(rays_o, rays_d, z_, d_, model.features, model.resolution, model.packed, *box, mode, inf,
+                                           ray_valid=v_, want_weights=False, tile_T=tile_T, xstash=xs)
+            outs.append(out)
+            state.append((tile_T, xs))
+    # merge and loss on the per-ray outputs (tile.py:666-690; criterions.py:142-144; tile.py:999)
+    fg, bg = (o.detach().requires_grad_(True) for o in outs)
+    vf, vbg = branches[0][2], branches[1][2]
+    pred = fg[:, 0:3] + fg[:, 4:5] * bg[:, 0:3]
+    l2 = sum(leaf[:, 14][v].sum() / (3 * v.sum().clamp(min=1)) for leaf, v in ((fg, vf), (bg, vbg)))
+    loss = F.mse_loss(pred, target) + 0.01 * l2
+    loss.backward()
+    with torch.no_grad():
+        gtab = torch.zeros_like(model.features)
+        gblob = torch.zeros(network.PARAMSIZE, device=dev)
+        for (z_, d_, v_, mode, inf), out, leaf, (tile_T, xs) in zip(branches, outs, (fg, bg), state):
+            S = z_.shape[1]
+            fused = render.scatter_supported(B, S, T)
+            ws = render.scatter_plan(rays_o, rays_d, z_, model.resolution, T, *box, mode, inf, ray_valid=v_) if fused else None
+            with _sec(timer, "render_backward"):
+                dfeat, _ = render.render_backward(rays_o, rays_d, z_, d_, model.features, model.resolution, model.packed, wf, *box,
+                                                  mode, inf, out, tile_T, leaf.grad.contiguous(), ray_valid=v_, grad_blob=gblob,
+                                                  xstash=xs, scatter=(ws, gtab) if fused else None, want_dfeat=not fused)
+            if fused:
+                render.scatter_accumulate(ws, gtab, B, S)
+            else:
+                pts = (rays_o[:, None, :] + z_[:, :, None] * rays_d[:, None, :]).reshape(-1, 3)
+                pts = (pts - model._min_dev) / model._size_dev * 4.0 - 2.0
+                if mode == render.BG:
+                    linf = pts.abs().amax(-1, keepdim=True)
+                    pts = pts * ((2.0 - 1.0 / linf) / linf)
+                render.scatter_table_grad(pts.contiguous(), dfeat, gtab, model.resolution)
+    return loss.detach(), gtab, gblob
+
+
+def train_step_fgbg(model, dec_opt, rays_o, rays_d, target, S_fg, S_bg, global_step, table_lr=1e-2,
+                    invalid_underground=False, timer=None):
+    """One complete training iteration of a tile (foreground + background branch, tile.py:880-1015) on the fused kernels."""
+    loss, gtab, gblob = fgbg_gradients(model, rays_o, rays_d, target, S_fg, S_bg, global_step, invalid_underground, timer)
+    with torch.no_grad():
+        model.features.grad = gtab
+        model.table_adam(table_lr)
+        model.decoder.params.grad = gblob
+        dec_opt.step()
+    return loss

@@ -529,6 +529,41 @@ def test_fused_scatter_large_table(S):
     np.testing.assert_allclose(g2.cpu().numpy() / sc, g1.cpu().numpy() / sc, rtol=1e-4, atol=2e-6)
 
 
+def test_fgbg_training_gradients_vs_oracle(S):
+    """f1: the complete per-tile training render (foreground + T_left * background, tile.py:639-692, loss of :880-1015)
+    on the fused kernels -- loss, table gradient and decoder gradient against autograd through the oracle's render_rays."""
+    from scanerf_amd import network
+    from scanerf_amd.tile_model import TileModel, fgbg_gradients
+    rng = np.random.default_rng(31)
+    B, Sf, Sb = 256, 64, 40
+    m = TileModel([-4, -4, -4], [8, 8, 8], DEV, log2_T=12, seed=4)
+    with torch.no_grad():
+        m.features.mul_(200.0)
+    occ = rng.random((16, 16, 16)) < 0.6
+    m.occupied_grid = g(occ)
+    o = rng.uniform(-3.9, 3.9, (B, 3)).astype(np.float32)
+    d = rng.normal(size=(B, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    tgt = rng.random((B, 3)).astype(np.float32)
+    step = 6000
+    loss, gtab, gblob = fgbg_gradients(m, g(o), g(d), g(tgt), Sf, Sb, step, invalid_underground=True)
+    # oracle
+    tile = O.Tile([-4, -4, -4], [8, 8, 8], log2_T=12)
+    tile.occ = torch.from_numpy(occ)
+    Ft = m.features.detach().cpu().clone().requires_grad_(True)
+    sd = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in m.decoder.ref_state_dict().items()}
+    ref = O.render_rays(tile, Ft, sd, torch.from_numpy(o), torch.from_numpy(d), Sf, Sb, O.TRAIN, step, invalid_underground=True)
+    lref = torch.nn.functional.mse_loss(ref["pred_color"], torch.from_numpy(tgt)) + 0.01 * ref["l2_reg_specular"]
+    lref.backward()
+    np.testing.assert_allclose(loss.item(), lref.item(), rtol=2e-5)
+    gF = Ft.grad.numpy()
+    sc = np.abs(gF).max()
+    np.testing.assert_allclose(gtab.cpu().numpy() / sc, gF / sc, rtol=2e-3, atol=2e-5)
+    gb_ref = O.pack_blob({k: v.grad for k, v in sd.items()}).numpy()
+    sb = np.abs(gb_ref).max()
+    np.testing.assert_allclose(gblob.cpu().numpy() / sb, gb_ref / sb, rtol=2e-3, atol=2e-5)
+
+
 def test_photometric_loss_grad_vs_autograd(S):
     """csrc/loss.hip against the torch graph it replaces (criterions.py:142-144 MSE + tile.py:999 0.01 * l2_reg)."""
     from scanerf_amd import render
