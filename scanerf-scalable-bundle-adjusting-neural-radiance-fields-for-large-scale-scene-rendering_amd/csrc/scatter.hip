@@ -163,7 +163,7 @@ __global__ void __launch_bounds__(kThreads) k_bin_scatter(const float *__restric
 // 2^k, k = 50 - ceil(log2 M) - ceil(log2(n+1)): no overflow, resolution n*M*2^-50.  Integer
 // addition is associative, so the table gradient is bit-reproducible run to run (the
 // reference's atomics are not) and closer to the exact sum than an fp32 running sum.
-template <int kThreads, int U>
+template <int kThreads, int U, bool LANE_OWNS_RUN = false>
 __global__ void __launch_bounds__(kThreads) k_bin_accumulate(const Rec *__restrict__ recs,
                                                              const uint32_t *__restrict__ starts,
                                                              const uint32_t *__restrict__ maxbits, BinGeom g,
@@ -209,6 +209,23 @@ __global__ void __launch_bounds__(kThreads) k_bin_accumulate(const Rec *__restri
         };
         // U independent 16-B loads in flight per lane (the records are read once from HBM; window passes re-read them from L2)
         uint32_t i = lo + threadIdx.x;
+        if (LANE_OWNS_RUN) {
+            // Each lane takes U CONSECUTIVE records.  Records of consecutive samples of a ray that share a cell (coarse
+            // levels: up to ~8 per cell) sit next to each other in the bin; handled by neighbouring lanes they hit the same
+            // LDS address in one instruction, which the LDS serialises at ~6 clocks per duplicate (tools/lds_atomic_bench:
+            // 64 equal addresses 0.15 lane-ops/clk/CU against 5.8 for distinct ones).  Inside one lane they are just
+            // successive instructions.  A lane reads 16*U contiguous bytes, so the wave still consumes whole lines.
+            uint32_t c = lo + threadIdx.x * U;
+            for (; c + U <= hi; c += U * kThreads) {
+                float4 r[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) r[u] = r4[c + u];
+#pragma unroll
+                for (int u = 0; u < U; ++u) apply(r[u]);
+            }
+            for (uint32_t j = c; j < hi && j < c + U; ++j) apply(r4[j]);  // at most one lane has a partial run
+            i = hi;
+        }
         for (; i + (U - 1) * kThreads < hi; i += U * kThreads) {
             float4 r[U];
 #pragma unroll
@@ -253,8 +270,12 @@ __global__ void __launch_bounds__(1024) k_bin_count_rays(RenderArgs f, BinGeom g
     const int G = gridDim.x, w = blockIdx.x, R = g.rpg;
     const int ngroups_all = (f.B + R - 1) / R;                          // ray groups of the launch
     const int ngroups = w < ngroups_all ? (ngroups_all - w + G - 1) / G : 0;  // ... visited by this workgroup
-    for (int idx = threadIdx.x; idx < ngroups * R * f.S; idx += 1024) {
-        const int lr = idx / f.S, s = idx % f.S;
+    // ray-fastest walk: the 64 lanes of a wave count 64 DIFFERENT rays at one sample index.  Sample-fastest, neighbouring
+    // lanes are neighbouring samples of a ray, share cells at the coarse levels and so hit the same histogram word in one
+    // instruction, which the LDS serialises (tools/lds_atomic_bench: ~6 clocks per duplicate address).
+    const int nlr = ngroups * R;
+    for (int idx = threadIdx.x; idx < nlr * f.S; idx += 1024) {
+        const int lr = idx % nlr, s = idx / nlr;
         const int ray = (w + (lr / R) * G) * R + lr % R;
         if (ray >= f.B) continue;
         if (f.ray_valid && !f.ray_valid[ray]) continue;
@@ -421,11 +442,27 @@ SCANERF_API int scanerf_render_scatter_accumulate(float *grad_features, int B, i
         hipLaunchKernelGGL((k_bin_accumulate<TH, UU>), dim3(nbins), dim3(TH), lds_bytes, (hipStream_t)stream, w.recs, \
                            w.starts, w.maxbits, g, grad_features);                                                  \
     }
-    // measured on MI355X (tools/bench_accum.py, 5.4e8 records): 256x8 3.61 ms, 512x8 3.38, 1024x4 3.33, 256x16 3.36 --
-    // the pass is bound by the LDS atomic rate (2.1e9 64-bit adds), not by occupancy or loads in flight
+#define SCANERF_LAUNCH_ACC_RUN(TH, UU)                                                                              \
+    {                                                                                                               \
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bin_accumulate<TH, UU, true>),         \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);             \
+        SCANERF_REQUIRE(e == hipSuccess, "render_scatter_accumulate: cannot reserve %zu B of LDS: %s", lds_bytes,    \
+                        hipGetErrorString(e));                                                                      \
+        hipLaunchKernelGGL((k_bin_accumulate<TH, UU, true>), dim3(nbins), dim3(TH), lds_bytes, (hipStream_t)stream, \
+                           w.recs, w.starts, w.maxbits, g, grad_features);                                          \
+    }
+    // measured on MI355X (tools/bench_accum.py, 5.4e8 records = 8.6 GB): record i -> lane i (lane-interleaved) 256x8 3.61 ms,
+    // 512x8 3.38, 1024x4 3.31; U consecutive records per lane 1024x4 2.21, 512x8 2.34, 1024x8 2.35, 1024x16 2.01.  The
+    // interleaved forms were bound by same-address serialisation in the LDS (coarse levels), not by the atomic rate itself
+    // (5.8 distinct 64-bit adds per clock per CU: tools/lds_atomic_bench.hip); what is left is mostly the record stream.
     if (variant == 1) SCANERF_LAUNCH_ACC(256, 8)
     else if (variant == 2) SCANERF_LAUNCH_ACC(512, 8)
-    else SCANERF_LAUNCH_ACC(1024, 4)
+    else if (variant == 3) SCANERF_LAUNCH_ACC(1024, 4)
+    else if (variant == 4) SCANERF_LAUNCH_ACC_RUN(1024, 4)
+    else if (variant == 5) SCANERF_LAUNCH_ACC_RUN(512, 8)
+    else if (variant == 6) SCANERF_LAUNCH_ACC_RUN(1024, 8)
+    else SCANERF_LAUNCH_ACC_RUN(1024, 16)
 #undef SCANERF_LAUNCH_ACC
+#undef SCANERF_LAUNCH_ACC_RUN
     return check_launch("render_scatter_accumulate");
 }
