@@ -45,6 +45,10 @@ def parse():
     ap.add_argument("--samples", type=int, default=128)
     ap.add_argument("--log2-T", type=int, default=19, help="hash-table entries per level (configs[1]: 19; the reference's default.yaml: 24)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", default="configs1", choices=["configs1", "configs2", "configs4-render"],
+                    help="configs1 (default, the metric's configuration): fp32 table, fully occupied sampler grid; "
+                         "configs2: + sphere-shell occupancy at log2dim 7 and a bf16 table (fp32 master + fused sparse Adam); "
+                         "configs4-render: 4 tiles per GPU + background, one 1920x1080 novel view per step (render rays/s)")
     return ap.parse_args()
 
 
@@ -95,6 +99,58 @@ def cpu_baseline(samples, seconds_budget=15.0):
             "sample": f"{n} training iterations of {B} rays x {samples} samples (same tile config, T=2^19), oracle/ on {cores} host threads"}
 
 
+def bench_render(args, world, rank, dev):
+    """configs[4] render leg: 4 tiles per GPU (admm_trainer.py:74-83 round-robin), background shells, one 1920x1080 view
+    per step through the multi-tile renderer (rendering.py:286-544 counterpart).  value = rendered rays (pixels) per second."""
+    import tempfile
+
+    from scanerf_amd import renderer as R
+    from scanerf_amd import tile_model as tm
+    H, W, ntile = 1080, 1920, 4
+    tiles = []
+    with tempfile.TemporaryDirectory() as tmp:
+        for t in range(ntile):
+            m = tm.TileModel([-16.0 + 8.0 * t, -4, -4], [8, 8, 8], dev, log2_T=args.log2_T, seed=rank * ntile + t, sampler_log2dim=7)
+            m.set_occupancy(tm.sphere_shell_occupancy(m, 3.0, 0.5))
+            with torch.no_grad():
+                m.features.mul_(300.0)  # xavier std of a 2^19-entry table gives sigma ~ softplus(0): make the shell visible
+            R.export_tile(os.path.join(tmp, f"tile{t}"), m)
+            tiles.append(R.load_tile(os.path.join(tmp, f"tile{t}")))
+            del m
+    rend = R.TileSetRenderer(dev, tiles)
+    K = [1600.0, 0, W / 2, 0, 1600.0, H / 2, 0, 0, 1]
+    c2w = torch.tensor([[1.0, 0, 0, 0.0], [0, 1, 0, 0.5], [0, 0, 1, -14.0]])
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        rend.render(H, W, K, c2w, num_sample=args.samples, num_bg_sample=args.samples)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = rend.render(H, W, K, c2w, num_sample=args.samples, num_bg_sample=args.samples)
+    sync()
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    if rank == 0:
+        print(json.dumps({
+            "metric": "novel-view render rays/s per GPU (128 samples, L=16 hash)", "value": world * H * W * args.steps / elapsed,
+            "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32 (f16 tables)", "data": "synthetic",
+            "config": {"workload": f"configs[4] render leg: {ntile} tiles per GPU (f16 tables T=2^{args.log2_T}, shell occupancy) + "
+                                   f"blended backgrounds, one {W}x{H} view per step, {args.samples} fg + {args.samples} bg samples",
+                       "opaque_fraction": float((out[3] < 0.5).float().mean())}}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -112,7 +168,13 @@ def main():
 
     B, S = args.rays, args.samples
     torch.manual_seed(rank)
-    model = tm.TileModel([-4.0 + 8.0 * rank, -4, -4], [8, 8, 8], dev, log2_T=args.log2_T, seed=rank)
+    if args.workload == "configs4-render":
+        return bench_render(args, world, rank, dev)
+    occ = args.workload == "configs2"
+    model = tm.TileModel([-4.0 + 8.0 * rank, -4, -4], [8, 8, 8], dev, log2_T=args.log2_T, seed=rank,
+                         sampler_log2dim=7 if occ else 4, table_dtype=torch.bfloat16 if occ else torch.float32)
+    if occ:  # shell of radius 3 m, thickness 0.5 m around the tile centre
+        model.set_occupancy(tm.sphere_shell_occupancy(model, 3.0, 0.5))
     dec_opt = torch.optim.Adam(model.decoder.parameters(), lr=1e-3, betas=(0.9, 0.99), eps=1e-15)
     corner = torch.tensor([-4.0 + 8.0 * rank, -4, -4], device=dev)
     rays_o = torch.rand(B, 3, device=dev) * 8 + corner
@@ -168,17 +230,22 @@ def main():
     elapsed = float(t.item())
     ms_per_step = elapsed / args.steps * 1e3
 
+    with torch.no_grad():  # rays that meet no occupied cell are skipped by every kernel: they are not counted as work
+        valid_frac = float((model.sample(rays_o, rays_d, S)[0] != -1).all(1).float().mean())
     if rank == 0:
-        value = world * B * args.steps / elapsed
+        value = world * B * valid_frac * args.steps / elapsed
         line = {
             "metric": "training rays/s per GPU (128 samples, L=16 hash)",
             "value": value, "value_is": "whole-job aggregate over n_gpus (one tile per GPU)", "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"configs[1]: single 8m^3 tile per GPU, L=16 T=2^{args.log2_T} fp32 hash grid, 2-hidden x 64 "
-                                   f"decoder, {B} rays x {S} samples, full training iteration "
-                                   f"(sample+encode+decode+composite fwd, bwd, sparse Adam); foreground branch",
-                       "path": path, "rays_per_step": B, "samples": S, "tiles_per_gpu": 1,
+            "config": {"workload": (f"configs[2]: as configs[1] + sphere-shell occupancy (r=3 m, 0.5 m thick, log2dim 7, "
+                                    f"{float(model.occupied_grid.float().mean()):.3f} of cells), bf16 gather table (fp32 master, fp32 accumulate), "
+                                    f"fused sparse Adam; {B} rays x {S} samples" if occ else
+                                    f"configs[1]: single 8m^3 tile per GPU, L=16 T=2^{args.log2_T} fp32 hash grid, 2-hidden x 64 "
+                                    f"decoder, {B} rays x {S} samples, full training iteration "
+                                    f"(sample+encode+decode+composite fwd, bwd, sparse Adam); foreground branch"),
+                       "path": path, "rays_per_step": B, "valid_ray_fraction": valid_frac, "samples": S, "tiles_per_gpu": 1,
                        "parallelism": f"tile-per-gpu x{world}", "syn_iters": SYN_ITERS},
             "consensus_ms": consensus_ms,
             "consensus_frac_of_iteration": consensus_ms / (SYN_ITERS * ms_per_step),
@@ -202,7 +269,7 @@ def main():
             traffic = None
             try:
                 pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-                if h3 and name in pm:
+                if h3 and name in pm and args.workload == "configs1" and B == 65536 and S == 128 and args.log2_T == 19:
                     traffic = pm[name]["fetch_bytes"] + pm[name]["write_bytes"]
                     roof["traffic_source"] = "profiles/r01_pmc_traffic.json (FETCH_SIZE + WRITE_SIZE of " + pm[name]["kernel"] + ")"
             except (OSError, ValueError, KeyError):

@@ -42,7 +42,12 @@ __global__ void __launch_bounds__(kThreads) k_bin_count(const float *__restrict_
     __syncthreads();
     const uint32_t mask = (uint32_t)g.T - 1u;
     const int lo = blockIdx.x * g.per_wg, hi = min(g.N, lo + g.per_wg);
-    for (int i = lo + threadIdx.x; i < hi; i += kThreads) {
+    // lane-owned runs of consecutive points: neighbouring points (samples of one ray) share cells at the coarse levels and
+    // would hit the same LDS word from neighbouring lanes (serialised: tools/lds_atomic_bench.hip)
+    const int run = (hi - lo + kThreads - 1) / kThreads;
+    for (int k = 0; k < run; ++k) {
+        const int i = lo + threadIdx.x * run + k;
+        if (i >= hi) break;
         const float p[3] = { points[3 * i], points[3 * i + 1], points[3 * i + 2] };
         for (int l = 0; l < g.L; ++l) {
             Pairs pr;
@@ -138,13 +143,19 @@ __global__ void __launch_bounds__(kThreads) k_bin_scatter(const float *__restric
         // level-major walk: a workgroup appends to only NB bins at a time, so the partially written
         // lines of its ranges (one per bin) stay in L2 until complete (full-line write-backs); the
         // gradient reads are contiguous per level and the points are re-read from L2.
+        const int run = (hi - lo + kThreads - 1) / kThreads;  // lane-owned runs of consecutive points (see k_bin_count)
         for (int l = 0; l < g.L; ++l)
-            for (int i = lo + threadIdx.x; i < hi; i += kThreads) {
+            for (int k = 0; k < run; ++k) {
+                const int i = lo + threadIdx.x * run + k;
+                if (i >= hi) break;
                 const float p[3] = { points[3 * i], points[3 * i + 1], points[3 * i + 2] };
                 one(i, l, p);
             }
     } else {
-        for (int i = lo + threadIdx.x; i < hi; i += kThreads) {
+        const int run = (hi - lo + kThreads - 1) / kThreads;
+        for (int k = 0; k < run; ++k) {
+            const int i = lo + threadIdx.x * run + k;
+            if (i >= hi) break;
             const float p[3] = { points[3 * i], points[3 * i + 1], points[3 * i + 2] };
             for (int l = 0; l < g.L; ++l) one(i, l, p);
         }
@@ -369,8 +380,8 @@ SCANERF_API int scanerf_embedding_bg_backward_binned(const float *points, const 
     else
         hipLaunchKernelGGL((k_bin_scatter<true>), dim3(g.W), dim3(kThreads), lds_bins, st, points, gi, resolutions, g,
                            counts, starts, recs, grad_features, maxbits);
-    hipLaunchKernelGGL((k_bin_accumulate<256, 8>), dim3(nbins), dim3(256), (size_t)(2 << g.bucket_log) * 8, st, recs, starts,
-                       maxbits, g, grad_features);
+    hipLaunchKernelGGL((k_bin_accumulate<1024, 16, true>), dim3(nbins), dim3(1024), (size_t)(2 << g.bucket_log) * 8, st, recs,
+                       starts, maxbits, g, grad_features);
     return check_launch("embedding_bg_backward_binned");
 }
 

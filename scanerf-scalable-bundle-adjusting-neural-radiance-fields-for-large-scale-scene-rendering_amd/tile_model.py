@@ -116,6 +116,7 @@ class TileModel(nn.Module):
         self.decoder = Decoder(seed).to(device)
         self.log2dim = (sampler_log2dim - torch.log2(self.bbox_size.max() / self.bbox_size).int()).int().to(device)
         self.occupied_grid = torch.ones(tuple(int(2 ** k) for k in self.log2dim), dtype=torch.bool, device=device)
+        self._occ_full = True  # set_occupancy() keeps it in step with the grid
         self.occ_corner = (self.min_bbox + self.bbox_size / 4.0).to(device).contiguous()
         self.occ_size = (self.bbox_size / 2.0).to(device).contiguous()
         self._min_dev = self.min_bbox.to(device)
@@ -128,6 +129,13 @@ class TileModel(nn.Module):
         self.exp_avg = torch.zeros_like(self.features)
         self.exp_avg_sq = torch.zeros_like(self.features)
         self.adam_step = 0
+
+    def set_occupancy(self, grid):
+        """Replace the sampler's occupancy grid (pruning: hashgrid/__init__.py:138-225)."""
+        if tuple(grid.shape) != tuple(self.occupied_grid.shape):
+            raise ValueError(f"occupancy grid must be {tuple(self.occupied_grid.shape)}, got {tuple(grid.shape)}")
+        self.occupied_grid = grid.to(self.device, torch.bool).contiguous()
+        self._occ_full = bool(self.occupied_grid.all())
 
     def weight_feature(self, global_step):
         """Coarse-to-fine mask on the device, cached: it is constant once global_step >= 10 000."""
@@ -230,6 +238,16 @@ class TileModel(nn.Module):
         self.adam_step += 1
 
 
+def sphere_shell_occupancy(model, radius, thickness):
+    """Synthetic sampler occupancy: cells of the tile's sampling grid whose centre lies within
+    thickness/2 of a sphere of `radius` around the tile centre -> bool grid shaped like model.occupied_grid."""
+    dims = [int(2 ** k) for k in model.log2dim.tolist()]
+    corner, size = model.occ_corner.cpu(), model.occ_size.cpu()
+    axes = [corner[a] + (torch.arange(dims[a]) + 0.5) * (size[a] / dims[a]) - model.bbox_center[a] for a in range(3)]
+    r = torch.sqrt(axes[0][:, None, None] ** 2 + axes[1][None, :, None] ** 2 + axes[2][None, None, :] ** 2)
+    return (torch.abs(r - radius) <= thickness / 2.0).to(model.device).contiguous()
+
+
 class KernelTimer:
     """HIP-event timing of named sections on torch's current stream (the stream every scanerf
     kernel is launched on).  bench.py uses it for the live per-kernel durations behind
@@ -311,7 +329,7 @@ def train_step_ops(model, dec_opt, rays_o, rays_d, target, S, global_step, table
 
 
 def train_step_fused(model, dec_opt, rays_o, rays_d, target, S, global_step, table_lr=1e-2, timer=None,
-                     pose_grads=False, fused_scatter=True):
+                     pose_grads=False, fused_scatter=True, compact_rays=None):
     """The same iteration as train_step_ops on the fused kernels: one launch for the render forward,
     one for its adjoint, the atomic-free binned scatter for the table gradient, fused sparse Adam.
     pose_grads=True also returns dL/d(rays_o), dL/d(rays_d) (feed them to the pose graph:
@@ -322,6 +340,19 @@ def train_step_fused(model, dec_opt, rays_o, rays_d, target, S, global_step, tab
         with _sec(timer, "sample_points_grid", B * (24 + 2 * 4 * S)):
             z, dist = model.sample(rays_o, rays_d, S)
         valid = torch.all(z != -1, dim=-1)
+        if compact_rays is None:  # a fully occupied sampler grid cannot produce invalid rays from inside the tile
+            compact_rays = not getattr(model, "_occ_full", False) and not pose_grads
+        if compact_rays:
+            # valid-mask compaction (hashgrid/__init__.py:419-421: the reference renders rays_o[valid] only): the fused
+            # backward runs its 4 waves per workgroup in lock step, so an invalid ray costs as much as a valid one there
+            keep = torch.nonzero(valid)[:, 0]
+            if keep.numel() < B:
+                rays_o, rays_d, target = rays_o[keep].contiguous(), rays_d[keep].contiguous(), target[keep].contiguous()
+                z, dist = z[keep].contiguous(), dist[keep].contiguous()
+                B = keep.numel()
+                valid = None
+            if B == 0:
+                return torch.zeros((), device=dev)
         wf = model.weight_feature(global_step)
         blob = model.decoder.blob()
         model.packed.pack(blob, wf)
@@ -329,9 +360,11 @@ def train_step_fused(model, dec_opt, rays_o, rays_d, target, S, global_step, tab
         tile_T = torch.empty((B, ntile), device=dev)
         xstash = torch.empty((B * S, 32), device=dev)  # encoder outputs: 1 GB at 65 536 x 128, saves the re-gather
         box = (model.min_bbox.tolist(), model.bbox_size.tolist(), render.FORE, False)
-        with _sec(timer, "render_forward", B * (24 + 20 + S * 16 * 8 * 2 * model.features.element_size()),
+        # gather table: the fp32 master itself, or its bf16/f16 image (configs[2]: half the gather bytes, fp32 accumulate)
+        table = model.features if model.table_dtype == torch.float32 else model.features.detach().to(model.table_dtype)
+        with _sec(timer, "render_forward", B * (24 + 20 + S * 16 * 8 * 2 * table.element_size()),
                   B * S * MLP_FLOPS_PER_SAMPLE):
-            out, _ = render.render_forward(rays_o, rays_d, z, dist, model.features, model.resolution, model.packed, *box,
+            out, _ = render.render_forward(rays_o, rays_d, z, dist, table, model.resolution, model.packed, *box,
                                            ray_valid=valid, want_weights=False, tile_T=tile_T, xstash=xstash)
     # loss and dL/d(out_ray) in two launches (the torch graph for it was ~60 tiny kernels with host-bound gaps)
     loss, grad_out = render.photometric_loss_grad(out, target, valid, 0.01)
@@ -349,7 +382,7 @@ def train_step_fused(model, dec_opt, rays_o, rays_d, target, S, global_step, tab
                 ws = render.scatter_plan(rays_o, rays_d, z, model.resolution, T, *box, ray_valid=valid)
         # forward recompute + activation gradients + weight gradients = 3x the forward MLP FLOPs
         with _sec(timer, "render_backward", B * (24 + 20 + S * 16 * 8 * 2 * 4 + S * 16 * 8), 3 * B * S * MLP_FLOPS_PER_SAMPLE):
-            dfeat, _ = render.render_backward(rays_o, rays_d, z, dist, model.features, model.resolution, model.packed, wf,
+            dfeat, _ = render.render_backward(rays_o, rays_d, z, dist, table, model.resolution, model.packed, wf,
                                               *box, out, tile_T, grad_out, ray_valid=valid, grad_blob=gblob, xstash=xstash,
                                               ray_grad_buffers=ray_bufs, scatter=(ws, gtab) if fused else None,
                                               want_dfeat=pose_grads or not fused)

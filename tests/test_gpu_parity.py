@@ -673,3 +673,42 @@ def test_fused_and_ops_training_steps_agree(S):
     assert float(df) < 2e-3 and float(db) < 2e-3, (float(df), float(db))  # Adam normalises: tiny gradient noise -> lr-sized steps
     _, g_o, g_d = res["fused"][3]
     assert g_o.shape == (B, 3) and torch.isfinite(g_o).all() and torch.isfinite(g_d).all() and float(g_d.abs().max()) > 0
+
+
+@pytest.mark.parametrize("table_dtype", [torch.float32, torch.bfloat16])
+def test_training_step_sparse_occupancy_compaction(S, table_dtype):
+    """BASELINE configs[2] shape of the iteration: sphere-shell occupancy (most rays of a random batch miss it), optional
+    bf16 gather table.  Compacting the valid rays before the fused kernels (what the reference does: rays_o[valid]) must give
+    the same loss and updates as masking them inside the kernels, and -- fp32 table -- the same as the op-by-op iteration."""
+    from scanerf_amd.tile_model import TileModel, sphere_shell_occupancy, train_step_fused, train_step_ops
+    torch.manual_seed(5)
+    B, S_ = 4096, 64
+    o = torch.rand(B, 3, device=DEV) * 8 - 4
+    d = torch.nn.functional.normalize(torch.randn(B, 3, device=DEV), dim=-1) * (0.5 + torch.rand(B, 1, device=DEV))
+    tgt = torch.rand(B, 3, device=DEV)
+    res = {}
+    runs = [("compact", train_step_fused, {"compact_rays": True}), ("masked", train_step_fused, {"compact_rays": False})]
+    if table_dtype == torch.float32:
+        runs.append(("ops", train_step_ops, {}))
+    for name, fn, kw in runs:
+        m = TileModel([-4, -4, -4], [8, 8, 8], DEV, log2_T=14, seed=2, sampler_log2dim=6, table_dtype=table_dtype)
+        m.set_occupancy(sphere_shell_occupancy(m, 3.0, 0.6))
+        assert not m._occ_full
+        with torch.no_grad():
+            m.features.mul_(30.0)
+        opt = torch.optim.Adam(m.decoder.parameters(), lr=1e-3, betas=(0.9, 0.99), eps=1e-15)
+        losses = [float(fn(m, opt, o, d, tgt, S_, 20000 + i, **kw)) for i in range(2)]
+        res[name] = (losses, m.features.detach().clone(), m.decoder.blob().detach().clone())
+    z, _ = m.sample(o, d, S_)
+    frac = float((z != -1).all(1).float().mean())
+    assert 0.05 < frac < 0.95, frac  # the batch really mixes valid and invalid rays
+    for other in res:
+        if other == "compact":
+            continue
+        # Adam normalises: tiny gradient noise -> lr-sized steps.  "masked" differs from "compact" only in which rays share a
+        # workgroup (the h3 backward's power-of-two gradient scale is per workgroup), "ops" in the whole arithmetic
+        tol = 2e-4 if other == "masked" else 2e-3
+        np.testing.assert_allclose(res["compact"][0], res[other][0], rtol=2e-5)
+        df = (res["compact"][1] - res[other][1]).abs().max() / res[other][1].abs().max()
+        db = (res["compact"][2] - res[other][2]).abs().max() / res[other][2].abs().max()
+        assert float(df) < tol and float(db) < tol, (other, float(df), float(db))
