@@ -29,6 +29,11 @@ using namespace scanerf;
 namespace {
 
 constexpr int kThreads = 256;
+constexpr int kRun = 8;  // consecutive points per lane in the stand-alone count / scatter walks
+// i over [lo, hi): thread t takes points lo + (j*kThreads + t)*kRun + k, k < kRun
+#define SCANERF_RUN_WALK(i, lo, hi)                                                     \
+    for (int c_ = (lo) + threadIdx.x * kRun; c_ < (hi); c_ += kThreads * kRun)          \
+        for (int i = c_; i < c_ + kRun && i < (hi); ++i)
 
 // ---- pass 1: count ---------------------------------------------------------------------
 __global__ void __launch_bounds__(kThreads) k_bin_count(const float *__restrict__ points,
@@ -42,12 +47,10 @@ __global__ void __launch_bounds__(kThreads) k_bin_count(const float *__restrict_
     __syncthreads();
     const uint32_t mask = (uint32_t)g.T - 1u;
     const int lo = blockIdx.x * g.per_wg, hi = min(g.N, lo + g.per_wg);
-    // lane-owned runs of consecutive points: neighbouring points (samples of one ray) share cells at the coarse levels and
-    // would hit the same LDS word from neighbouring lanes (serialised: tools/lds_atomic_bench.hip)
-    const int run = (hi - lo + kThreads - 1) / kThreads;
-    for (int k = 0; k < run; ++k) {
-        const int i = lo + threadIdx.x * run + k;
-        if (i >= hi) break;
+    // lane-owned runs of kRun consecutive points: neighbouring points (samples of one ray) share cells at the coarse levels
+    // and would hit the same LDS word from neighbouring lanes (serialised: tools/lds_atomic_bench.hip); a wave still walks a
+    // contiguous window of 64*kRun points, so its loads reuse the lines they touch
+    SCANERF_RUN_WALK(i, lo, hi) {
         const float p[3] = { points[3 * i], points[3 * i + 1], points[3 * i + 2] };
         for (int l = 0; l < g.L; ++l) {
             Pairs pr;
@@ -143,19 +146,15 @@ __global__ void __launch_bounds__(kThreads) k_bin_scatter(const float *__restric
         // level-major walk: a workgroup appends to only NB bins at a time, so the partially written
         // lines of its ranges (one per bin) stay in L2 until complete (full-line write-backs); the
         // gradient reads are contiguous per level and the points are re-read from L2.
-        const int run = (hi - lo + kThreads - 1) / kThreads;  // lane-owned runs of consecutive points (see k_bin_count)
+        // (lane-interleaved on purpose: with lane-owned runs as in k_bin_count the cursor conflicts go away but the 8-byte
+        // gradient and 12-byte point loads and the record stores lose their coalescing -- measured 4.7 -> 7.6 ms)
         for (int l = 0; l < g.L; ++l)
-            for (int k = 0; k < run; ++k) {
-                const int i = lo + threadIdx.x * run + k;
-                if (i >= hi) break;
+            for (int i = lo + threadIdx.x; i < hi; i += kThreads) {
                 const float p[3] = { points[3 * i], points[3 * i + 1], points[3 * i + 2] };
                 one(i, l, p);
             }
     } else {
-        const int run = (hi - lo + kThreads - 1) / kThreads;
-        for (int k = 0; k < run; ++k) {
-            const int i = lo + threadIdx.x * run + k;
-            if (i >= hi) break;
+        for (int i = lo + threadIdx.x; i < hi; i += kThreads) {
             const float p[3] = { points[3 * i], points[3 * i + 1], points[3 * i + 2] };
             for (int l = 0; l < g.L; ++l) one(i, l, p);
         }

@@ -28,6 +28,7 @@ struct Rec {
 // the 4 (y,z) corner pairs of one (point, level): bucket, locals, weights
 struct Pairs {
     uint32_t idx0[4], idx1[4];
+    uint32_t xm;  // idx0[q] ^ idx1[q] for every q: (x ^ (x+1)) & mask
     float wyz[4], tx;
 };
 
@@ -51,39 +52,61 @@ __device__ __forceinline__ void make_pairs(const float p[3], const int32_t *res,
         pr.wyz[q] = wy[dy] * wz[dz];
     }
     pr.tx = t[0];
+    pr.xm = (hx0 ^ hx1) & mask;
 }
 
 
-// Append the (up to 5) records of one (sample, level) with upstream gradient (gix, giy).
-// cursor_level: this workgroup's LDS cursors of the level's NB bins; grad_level: the level's slice of
-// grad_features, touched only when the workspace is too small (slow path, correctness only).
+// Append the records of one (sample, level) with upstream gradient (gix, giy): one per (y,z) corner pair, two when the
+// x-neighbours fall into different buckets.
+// cursor_level: this workgroup's LDS cursors of the level's NB bins; grad_level: the level's slice of grad_features, touched
+// only when the workspace is too small (slow path, correctness only).
+// Shape of the code (it runs inside the backward kernel at one wave per SIMD, where every divergent branch is a bubble):
+// idx0 ^ idx1 = (x ^ (x+1)) & mask for all four pairs, so "straddles a bucket boundary" is ONE test per (sample, level);
+// the common case is 4 cursor atomics issued back to back and 4 predicated 16-B stores, no branch; straddling lanes and
+// workspace overflow share one rarely taken, wave-uniform branch.
 __device__ __forceinline__ void emit_pairs(const Pairs &pr, float gix, float giy, uint32_t *cursor_level, int bucket_log,
                                            uint32_t capacity, Rec *recs, float *grad_level)
 {
     const uint32_t lmask = (1u << bucket_log) - 1u;
+    const bool straddle = (pr.xm >> bucket_log) != 0u;
+    const float a0 = 1.0f - pr.tx;
+    auto fallback = [&](uint32_t bkt, uint32_t hdr, float tx, float ax, float ay) {
+        float *gs = grad_level + ((size_t)bkt << bucket_log) * 2;
+        const uint32_t e0 = hdr & 0xffffu, e1 = hdr >> 16;
+        unsafeAtomicAdd(gs + 2 * e0, (1.0f - tx) * ax);
+        unsafeAtomicAdd(gs + 2 * e0 + 1, (1.0f - tx) * ay);
+        unsafeAtomicAdd(gs + 2 * e1, tx * ax);
+        unsafeAtomicAdd(gs + 2 * e1 + 1, tx * ay);
+    };
+    uint32_t pos[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) pos[q] = atomicAdd(&cursor_level[pr.idx0[q] >> bucket_log], 1u);
+    const float txr = straddle ? 0.0f : pr.tx;
+    bool rare = straddle;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        const uint32_t b0 = pr.idx0[q] >> bucket_log, b1 = pr.idx1[q] >> bucket_log;
+        const uint32_t l0 = pr.idx0[q] & lmask;
+        const uint32_t hdr = straddle ? l0 * 0x10001u : (l0 | ((l0 ^ pr.xm) << 16));
         const float gx = pr.wyz[q] * gix, gy = pr.wyz[q] * giy;
-        auto emit = [&](uint32_t bkt, uint32_t hdr, float tx, float ax, float ay) {
-            const uint32_t pos = atomicAdd(&cursor_level[bkt], 1u);
-            if (pos < capacity) {
-                reinterpret_cast<float4 *>(recs)[pos] = make_float4(__uint_as_float(hdr), tx, ax, ay);
-            } else {
-                float *gs = grad_level + ((size_t)bkt << bucket_log) * 2;
-                const uint32_t e0 = hdr & 0xffffu, e1 = hdr >> 16;
-                unsafeAtomicAdd(gs + 2 * e0, (1.0f - tx) * ax);
-                unsafeAtomicAdd(gs + 2 * e0 + 1, (1.0f - tx) * ay);
-                unsafeAtomicAdd(gs + 2 * e1, tx * ax);
-                unsafeAtomicAdd(gs + 2 * e1 + 1, tx * ay);
+        const float ax = straddle ? a0 * gx : gx, ay = straddle ? a0 * gy : gy;
+        if (pos[q] < capacity) reinterpret_cast<float4 *>(recs)[pos[q]] = make_float4(__uint_as_float(hdr), txr, ax, ay);
+        rare |= pos[q] >= capacity;
+    }
+    if (__builtin_expect(__any(rare), 0)) {
+#pragma unroll  // (rolled, pr would be indexed dynamically and live in scratch -- whose stores cost a vmcnt(0) per level)
+        for (int q = 0; q < 4; ++q) {
+            const uint32_t l0 = pr.idx0[q] & lmask, b0 = pr.idx0[q] >> bucket_log;
+            const float gx = pr.wyz[q] * gix, gy = pr.wyz[q] * giy;
+            if (pos[q] >= capacity) {
+                if (straddle) fallback(b0, l0 * 0x10001u, 0.0f, a0 * gx, a0 * gy);
+                else fallback(b0, l0 | ((l0 ^ pr.xm) << 16), pr.tx, gx, gy);
             }
-        };
-        if (b1 == b0) {
-            emit(b0, (pr.idx0[q] & lmask) | ((pr.idx1[q] & lmask) << 16), pr.tx, gx, gy);
-        } else {  // x-neighbours straddle a bucket boundary (only when x+1 reaches 2^bucket_log)
-            const float a = 1.0f - pr.tx;
-            emit(b0, (pr.idx0[q] & lmask) * 0x10001u, 0.0f, a * gx, a * gy);
-            emit(b1, (pr.idx1[q] & lmask) * 0x10001u, 0.0f, pr.tx * gx, pr.tx * gy);
+            if (straddle) {  // second record: the x+1 neighbour in its own bucket
+                const uint32_t i1 = pr.idx0[q] ^ pr.xm, b1 = i1 >> bucket_log, hdr1 = (i1 & lmask) * 0x10001u;
+                const uint32_t p1 = atomicAdd(&cursor_level[b1], 1u);
+                if (p1 < capacity) reinterpret_cast<float4 *>(recs)[p1] = make_float4(__uint_as_float(hdr1), 0.0f, pr.tx * gx, pr.tx * gy);
+                else fallback(b1, hdr1, 0.0f, pr.tx * gx, pr.tx * gy);
+            }
         }
     }
 }
