@@ -275,6 +275,15 @@ int scanerf_process_occupied_grid(int bidx, int total_grid, const float *corners
                                   const uint8_t *occ, const int64_t *grid_starts, const int32_t *log2dim,
                                   uint8_t *tgt_occ, int nb, scanerf_stream_t stream);          /* :1479-1564 */
 
+/* cuda/include/voxelize.h:12-119 (CUDA_EXT.voxelize_mesh after its PLY read: cuda/include/plyIO.h): mark the cells of the
+ * sampler grid that the 1.5x-inflated boxes of the mesh faces overlap; init_out != 0 also marks (vis and outside) every
+ * cell whose centre lies outside the union box of the faces that touch the grid.  vertices [V,3] f32, faces [F,3] i32,
+ * vis / outside bool grids [2^lx,2^ly,2^lz], scratch6 6 x u32 -- device; log2dim [3], block_corner [3], block_size [3] --
+ * HOST (the reference takes them as CPU tensors). */
+int scanerf_voxelize_mesh(const float *vertices, const int32_t *faces, int V, int F, const int32_t *log2dim,
+                          const float *block_corner, const float *block_size, uint8_t *vis, int init_out,
+                          uint8_t *outside, uint32_t *scratch6, scanerf_stream_t stream);
+
 #define SCANERF_RAY_OUT 16
 
 #ifdef __cplusplus

@@ -594,3 +594,68 @@ def psnr(a, b):
     """tools/utils.py:53-55 on 0..255 images"""
     mse = np.mean((np.asarray(a, np.float64) - np.asarray(b, np.float64)) ** 2)
     return 10.0 * math.log10(255.0 ** 2 / (mse + 1e-8))
+
+
+# --------------------------------------------------------------------------- f1 / f4 restatements
+def scheduler_eta(step, start_eta, end_eta, iterations, decay_rate=0.1, start_itr=0, end_itr=100000000):
+    """scheduler.py:15-52 with decay_func2: eta = start * rate^(step / (iterations / log_rate(end/start)))."""
+    if step < start_itr or step >= end_itr:
+        return 0.0
+    decay_steps = iterations / math.log(end_eta / start_eta, decay_rate)
+    return start_eta * decay_rate ** (step / decay_steps)
+
+
+def voxelize_mesh(vertices, faces, log2dim, block_corner, block_size, init_out):
+    """cuda/include/voxelize.h:12-119 on arrays -> (vis, outside) bool grids."""
+    l2d = _i32(log2dim)
+    shape = tuple(1 << int(k) for k in l2d)
+    vis, out = np.zeros(shape, np.uint8), np.zeros(shape, np.uint8)
+    v, f = _f32(vertices).reshape(-1, 3), _i32(faces).reshape(-1, 3)
+    lib().orc_voxelize_mesh(_p(v), _p(f), _ci(f.shape[0]), _p(l2d), _p(_f32(block_corner)), _p(_f32(block_size)), _p(vis),
+                            _ci(int(bool(init_out))), _p(out))
+    return vis.astype(bool), out.astype(bool)
+
+
+def pruning_tile_grid(occupied_grid, log2dim, features, res, sd, bbox_size, global_step, sub_split, pruning_th,
+                      finest_resolution=2048, batch_size=92 ** 3):
+    """hashgrid/__init__.py:138-213 with the CPU encoder: -> (new_grid bool, new_log2dim)."""
+    occ = torch.as_tensor(occupied_grid)
+    log2dim = torch.as_tensor(log2dim).int() + (1 if sub_split else 0)
+    scale = 2 if sub_split else 1
+    grid_resolution = 2 ** log2dim
+    bbox_size = torch.as_tensor(bbox_size, dtype=torch.float32)
+    fin = (bbox_size / bbox_size.min() * finest_resolution).int()
+    total_res = fin / 4.0 if global_step < 10000 else fin / 2.0
+    sample_resolution = ((total_res / 2.0) / grid_resolution).int()
+    xs, ys, zs = torch.where(occ.repeat_interleave(scale, 0).repeat_interleave(scale, 1).repeat_interleave(scale, 2))
+    locs = torch.stack([xs, ys, zs], -1).long()
+    grid_corner = locs / grid_resolution
+    X, Y, Z = torch.meshgrid(torch.arange(0, int(sample_resolution[0])), torch.arange(0, int(sample_resolution[1])),
+                             torch.arange(0, int(sample_resolution[2])), indexing="ij")
+    grid_point = torch.stack([X, Y, Z], -1).reshape(-1, 3) / (sample_resolution * grid_resolution)
+    run = max(int(batch_size / int(torch.prod(sample_resolution))), 1)
+    alpha_res = torch.zeros(locs.shape[0])
+    wf = weight_feature(global_step)[None, :].repeat_interleave(2, dim=-1)
+    for i in range(0, locs.shape[0], run):
+        pts = (grid_corner[i:i + run, None, :] + grid_point[None, ...]) * 2 - 1
+        n = pts.shape[0]
+        feats = encode_bg(pts.reshape(-1, 3).float(), features, res).reshape(-1, 32) * wf
+        alpha = 1 - torch.exp(-1.0 * mlp_sigma(sd, feats))
+        alpha_res[i:i + n] = alpha.reshape(n, -1).max(dim=-1)[0]
+    new = torch.zeros(tuple(int(r) for r in grid_resolution), dtype=torch.bool)
+    keep = locs[alpha_res > pruning_th]
+    new[keep[:, 0], keep[:, 1], keep[:, 2]] = True
+    return new, log2dim
+
+
+def occlusion_mask(rays_o, rays_d, shared_depth_half, bbox_center, bbox_size_half, H, W, kernel_size=91):
+    """tile.py:366-400 for one view: half-resolution shared depth [H/2,W/2,1] upsampled 2x (nearest), compared with
+    the entry depth of the tile box (ray_aabb_intersection with size = bbox_size/2, i.e. half extents bbox_size/4
+    ... as the reference passes it), the un-occluded set dilated by a kernel_size box filter.
+    -> bool [H,W,1]: True = keep the pixel."""
+    depth = torch.as_tensor(shared_depth_half).repeat_interleave(2, 0).repeat_interleave(2, 1).reshape(-1, 1)
+    bounds = torch.from_numpy(ray_aabb_intersection(_np(rays_o), _np(rays_d), _np(bbox_center), _np(bbox_size_half)))
+    occ = ((depth > bounds[..., :1]) & (bounds[..., :1] != -1)).reshape(1, 1, H, W)
+    kernel = torch.ones((1, 1, kernel_size, kernel_size), dtype=torch.float32)
+    occ = 1.0 - torch.nn.functional.conv2d(1.0 - occ.float(), kernel, padding=(kernel_size // 2, kernel_size // 2)).clamp(0, 1)
+    return occ.bool().reshape(H, W, 1)

@@ -983,3 +983,64 @@ ORC_API void orc_process_occupied_grid(int bidx, int total_grid, const float *co
         }
     }
 }
+
+/* ------------------------------------------------------------------ voxelize_mesh
+ * cuda/include/voxelize.h:12-119 after read_plyFile: vertices [V,3], faces [F,3]; vis / outside byte grids
+ * [2^lx,2^ly,2^lz] (caller zero-fills, as hashgrid/__init__.py:71-78 does). */
+ORC_API void orc_voxelize_mesh(const float *vertices, const int32_t *faces, int F, const int32_t *log2dim,
+                               const float *block_corner, const float *block_size, uint8_t *vis, int init_out,
+                               uint8_t *outside)
+{
+    const int res[3] = { 1 << log2dim[0], 1 << log2dim[1], 1 << log2dim[2] };
+    float gs[3], bmax[3];
+    for (int c = 0; c < 3; ++c) {
+        gs[c] = block_size[c] / (float)res[c];            /* :28 */
+        bmax[c] = block_corner[c] + block_size[c];        /* :32 */
+    }
+    float geo_min[3] = { 100000000.0f, 100000000.0f, 100000000.0f };   /* :43-44 */
+    float geo_max[3] = { -1.0f * 100000000.0f, -1.0f * 100000000.0f, -1.0f * 100000000.0f };
+    for (int f = 0; f < F; ++f) {
+        float mn[3], mx[3];
+        int lo[3], hi[3], skip = 0;
+        for (int c = 0; c < 3; ++c) {
+            const float A = vertices[3 * faces[3 * f] + c], B = vertices[3 * faces[3 * f + 1] + c],
+                        C = vertices[3 * faces[3 * f + 2] + c];
+            const float mnc = fminf(fminf(A, B), C), mxc = fmaxf(fmaxf(A, B), C);   /* :52-53 */
+            const float center = (mnc + mxc) / 2.0f;                               /* :55 */
+            const float half = ((mxc - mnc) * 1.5f) / 2.0f;                         /* :56-57 */
+            mn[c] = center - half;                                                  /* :58-59 */
+            mx[c] = center + half;
+            if (mx[c] <= block_corner[c] || mn[c] >= bmax[c]) skip = 1;             /* :61-62 */
+        }
+        if (skip) continue;
+        for (int c = 0; c < 3; ++c) {
+            geo_min[c] = fminf(mn[c], geo_min[c]);                                  /* :64-65 */
+            geo_max[c] = fmaxf(mx[c], geo_max[c]);
+            int l = (int)((mn[c] - block_corner[c]) / gs[c]);                       /* :67-71 */
+            int h = (int)((mx[c] - block_corner[c]) / gs[c]);
+            lo[c] = l < 0 ? 0 : (l > res[c] - 1 ? res[c] - 1 : l);                  /* :73-74 */
+            hi[c] = h < 0 ? 0 : (h > res[c] - 1 ? res[c] - 1 : h);
+        }
+        for (int x = lo[0]; x <= hi[0]; ++x)
+            for (int y = lo[1]; y <= hi[1]; ++y)
+                for (int z = lo[2]; z <= hi[2]; ++z)
+                    vis[((uint32_t)x << (log2dim[1] + log2dim[2])) | ((uint32_t)y << log2dim[2]) | (uint32_t)z] = 1;  /* :82-83 */
+    }
+    if (init_out) {                                                                 /* :89-109 */
+        for (int x = 0; x < res[0]; ++x)
+            for (int y = 0; y < res[1]; ++y)
+                for (int z = 0; z < res[2]; ++z) {
+                    const int idx[3] = { x, y, z };
+                    int out = 0;
+                    for (int c = 0; c < 3; ++c) {
+                        const float loc = block_corner[c] + (float)idx[c] * gs[c] + gs[c] / 2.0f;
+                        if (loc < geo_min[c] || loc > geo_max[c]) out = 1;
+                    }
+                    if (out) {
+                        const uint32_t n = ((uint32_t)x << (log2dim[1] + log2dim[2])) | ((uint32_t)y << log2dim[2]) | (uint32_t)z;
+                        vis[n] = 1;
+                        outside[n] = 1;
+                    }
+                }
+    }
+}

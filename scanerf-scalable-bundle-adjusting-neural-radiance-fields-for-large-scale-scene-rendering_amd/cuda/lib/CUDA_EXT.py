@@ -4,7 +4,7 @@ Same names, positional argument order and in-place output convention as the refe
 C++ prototypes (cuda/include/{compute_ray,sample,helper,adam}.h); every function returns
 None.  Each call forwards to one C-ABI entry point of libscanerf_hip.so on the current
 torch stream.  Ops of the module that are off the hot path (warp-loss, view selection,
-voxelize, BlockBuilder: SURVEY.md section 2.2) are not provided and raise on access.
+BlockBuilder: SURVEY.md section 2.2) are not provided and raise on access.
 """
 import ctypes
 
@@ -115,7 +115,43 @@ def adam_step_cuda_fp16(params, grad_params, exp_avg, exp_avg_sq, lr, beta1, bet
           beta2, eps, step, torch.float16)
 
 
-_OFF_PATH = ("proj2pixel_and_fetch_color", "computeViewcost", "voxelize_mesh", "grid_sample_forward_cuda",
+def voxelize_mesh(_log2dim, block_corner, block_size, model_path, vis, init_out, outside):
+    """cuda/include/voxelize.h:12-119: initialise the sampler's occupancy grid `vis` (and `outside`) from a PLY mesh;
+    model_path == "" marks every cell occupied.  The reference runs this on the host over CPU tensors
+    (hashgrid/__init__.py:71-80); here the faces are marked by a HIP kernel.  `vis` / `outside` are bool grids
+    [2^lx,2^ly,2^lz], updated in place: GPU tensors directly, CPU tensors (what the reference's caller passes) through
+    a device copy.  _log2dim [3] int32, block_corner / block_size [3] float32 (any device)."""
+    from ... import formats
+    if vis.dtype != torch.bool or outside.dtype != torch.bool:
+        raise RuntimeError("scanerf: voxelize_mesh needs bool grids")
+    l2d = [int(v) for v in _log2dim.detach().cpu().reshape(-1).tolist()]
+    if tuple(vis.shape) != tuple(1 << k for k in l2d) or tuple(outside.shape) != tuple(vis.shape):
+        raise RuntimeError(f"scanerf: voxelize_mesh grids must be {tuple(1 << k for k in l2d)}, got {tuple(vis.shape)}")
+    if model_path == "":
+        vis.fill_(True)
+        return
+    dev = vis.device if vis.is_cuda else torch.device("cuda", torch.cuda.current_device())
+    verts, faces = formats.read_ply(model_path)
+    v = torch.from_numpy(verts).to(dev).contiguous()
+    f = torch.from_numpy(faces).to(dev).contiguous()
+    gv = vis if vis.is_cuda else vis.to(dev)
+    go = outside if outside.is_cuda else outside.to(dev)
+    if not (gv.is_contiguous() and go.is_contiguous()):
+        raise RuntimeError("scanerf: voxelize_mesh grids must be contiguous")
+    scratch = torch.empty(6, dtype=torch.int32, device=dev)
+    corner = (ctypes.c_float * 3)(*[float(x) for x in block_corner.detach().cpu().reshape(-1).tolist()])
+    size = (ctypes.c_float * 3)(*[float(x) for x in block_size.detach().cpu().reshape(-1).tolist()])
+    check(lib().scanerf_voxelize_mesh(dev_ptr(v, _f32, "vertices"), dev_ptr(f, _i32, "faces"), ctypes.c_int(v.shape[0]),
+                                      ctypes.c_int(f.shape[0]), (ctypes.c_int32 * 3)(*l2d), corner, size,
+                                      dev_ptr(gv, torch.bool, "vis"), ctypes.c_int(int(bool(init_out))),
+                                      dev_ptr(go, torch.bool, "outside"), dev_ptr(scratch, _i32, "scratch"), stream()),
+          "voxelize_mesh")
+    if gv is not vis:
+        vis.copy_(gv)
+        outside.copy_(go)
+
+
+_OFF_PATH = ("proj2pixel_and_fetch_color", "computeViewcost", "grid_sample_forward_cuda",
              "grid_sample_backward_cuda", "gaussian_grid_sample_forward_cuda", "gaussian_grid_sample_backward_cuda",
              "grid_sample_bool_cuda", "proj2neighbor_forward", "proj2neighbor_backward", "BlockBuilder")
 

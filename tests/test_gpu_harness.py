@@ -1,0 +1,170 @@
+"""GPU parity of the harness pieces around the hot path: mesh voxelisation, occupancy pruning,
+shared-depth occlusion masks and the per-tile training loop with its checkpoint, each against the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _random_mesh(rng, n_faces, lo, hi, edge):
+    c = rng.uniform(lo, hi, (n_faces, 1, 3))
+    v = (c + rng.normal(scale=edge, size=(n_faces, 3, 3))).astype(np.float32).reshape(-1, 3)
+    f = np.arange(3 * n_faces, dtype=np.int32).reshape(-1, 3)
+    return v, f
+
+
+@pytest.mark.parametrize("l2d,init_out", [((4, 4, 4), False), ((6, 5, 7), True), ((7, 7, 7), True)])
+def test_voxelize_mesh_bit_exact(tmp_path, l2d, init_out):
+    """CUDA_EXT.voxelize_mesh through the binding name: PLY on disk -> occupancy / outside grids, identical to the oracle's
+    restatement of voxelize.h; CPU tensors in (what hashgrid/__init__.py:71-80 passes) and GPU tensors in."""
+    import scanerf_amd  # noqa
+    from scanerf_amd import formats
+    from scanerf_amd.cuda import voxelize_mesh
+    rng = np.random.default_rng(sum(l2d))
+    corner, size = np.array([-4, -3, -5], np.float32), np.array([8, 4, 16], np.float32)
+    # faces inside, straddling the faces of the box, and far outside; a few large ones
+    v, f = _random_mesh(rng, 3000, corner - 2, corner + size + 2, 0.15)
+    v2, f2 = _random_mesh(rng, 20, corner + size * 0.3, corner + size * 0.6, 1.5)
+    v, f = np.concatenate([v, v2]), np.concatenate([f, f2 + len(v)])
+    ply = tmp_path / "mesh.ply"
+    formats.write_ply(ply, v, f, binary=True)
+    want_vis, want_out = O.voxelize_mesh(v, f, l2d, corner, size, init_out)
+    assert 0 < want_vis.mean() < 1
+    shape = tuple(1 << k for k in l2d)
+    log2dim, tc, ts = torch.tensor(l2d, dtype=torch.int32), torch.from_numpy(corner), torch.from_numpy(size)
+    vis, out = torch.zeros(shape, dtype=torch.bool), torch.zeros(shape, dtype=torch.bool)
+    voxelize_mesh(log2dim, tc, ts, str(ply), vis, init_out, out)
+    assert np.array_equal(vis.numpy(), want_vis) and np.array_equal(out.numpy(), want_out)
+    gvis, gout = torch.zeros(shape, dtype=torch.bool, device=DEV), torch.zeros(shape, dtype=torch.bool, device=DEV)
+    voxelize_mesh(log2dim.to(DEV), tc.to(DEV), ts.to(DEV), str(ply), gvis, init_out, gout)
+    assert np.array_equal(gvis.cpu().numpy(), want_vis) and np.array_equal(gout.cpu().numpy(), want_out)
+    # no mesh: everything occupied (voxelize.h:111-117)
+    vis.zero_()
+    voxelize_mesh(log2dim, tc, ts, "", vis, False, out)
+    assert bool(vis.all())
+
+
+def test_occupancy_pruning_vs_oracle():
+    """hashgrid/__init__.py:138-225: the pruned grid (same level and one split level) equals the oracle's, up to cells whose
+    peak alpha sits within float noise of the threshold."""
+    import scanerf_amd  # noqa
+    from scanerf_amd import trainer
+    from scanerf_amd.tile_model import TileModel, sphere_shell_occupancy
+    m = TileModel([-4, -4, -4], [8, 8, 8], DEV, log2_T=15, seed=4, sampler_log2dim=4)
+    with torch.no_grad():
+        m.features.mul_(400.0)
+    m.set_occupancy(sphere_shell_occupancy(m, 2.5, 3.0))
+    sd = {k: v.detach().cpu() for k, v in m.decoder.ref_state_dict().items()}
+    feats, res = m.features.detach().cpu(), m.resolution.cpu()
+    occ0, l2d0 = m.occupied_grid.cpu(), m.log2dim.cpu()
+    for sub_split, step in ((False, 4000), (True, 12000)):
+        # threshold = median of what the field produces, so that both outcomes occur
+        probe, _ = O.pruning_tile_grid(occ0, l2d0, feats, res, sd, m.bbox_size, step, sub_split, -1.0, finest_resolution=256)
+        assert probe.any()
+        want, want_l2d = None, None
+        for th in (0.3, 0.5, 0.6):
+            want, want_l2d = O.pruning_tile_grid(occ0, l2d0, feats, res, sd, m.bbox_size, step, sub_split, th, finest_resolution=256)
+            if 0.1 < float(want.float().sum() / probe.float().sum()) < 0.9:
+                break
+        assert 0.02 < float(want.float().sum() / probe.float().sum()) < 0.98, "the test field does not straddle the threshold"
+        m.set_occupancy(occ0.to(DEV))
+        m.log2dim = l2d0.to(DEV)
+        n = trainer.pruning_grid(m, step, int(l2d0.max()) + (1 if sub_split else 0), th, finest_resolution=256)
+        assert m.log2dim.cpu().tolist() == want_l2d.tolist() and tuple(m.occupied_grid.shape) == tuple(want.shape)
+        mism = float((m.occupied_grid.cpu() != want).float().sum())
+        assert mism <= max(2.0, 0.002 * float(want.float().sum())), (mism, float(want.float().sum()))
+        assert n == int(m.occupied_grid.sum())
+
+
+def test_occlusion_mask_vs_oracle():
+    """tile.py:366-400: mask of one outside view against a synthetic half-resolution shared depth."""
+    import scanerf_amd  # noqa
+    from scanerf_amd import occlusion as OC
+    from scanerf_amd.tile_model import TileModel
+    H, W = 96, 128
+    m = TileModel([-4, -4, -4], [8, 8, 8], DEV, log2_T=12, seed=0)
+    g = torch.Generator().manual_seed(1)
+    cam = torch.tensor([0.5, 0.2, -12.0])
+    j, i = torch.meshgrid(torch.arange(H), torch.arange(W), indexing="ij")
+    d = torch.stack([(i + 0.5 - W / 2) / 90.0, (j + 0.5 - H / 2) / 90.0, torch.ones(H, W)], -1).reshape(-1, 3).float()
+    o = cam[None, :].expand_as(d).contiguous()
+    # box entry is at ~8 m on the axis: nearer surface on the left third (pixels explained by the other tile), farther on the
+    # right, plus a few isolated near pixels that the 9 x 9 dilation grows into holes
+    depth_half = torch.where(torch.arange(W // 2)[None, :] < W // 6, 6.0, 12.0).expand(H // 2, W // 2).clone()
+    depth_half[torch.randint(0, H // 2, (5,), generator=g), torch.randint(W // 4, W // 2, (5,), generator=g)] = 5.0
+    want = O.occlusion_mask(o, d, depth_half[..., None], m.bbox_center, m.bbox_size / 2.0, H, W, kernel_size=9)
+    got = OC.occlusion_mask_view(o.to(DEV), d.to(DEV), depth_half.to(DEV), m._center_dev, m._half_dev, H, W, kernel_size=9)
+    assert got.shape == (H, W, 1) and torch.equal(got.cpu(), want)
+    assert 0.02 < float(want.float().mean()) < 0.98
+    # update_occlusion_mask: views without a published depth and views from inside the tile stay fully enabled
+    shared = torch.full((3, H // 2, W // 2), OC.NO_DEPTH, device=DEV)
+    shared[1] = depth_half.to(DEV)
+    shared[2] = depth_half.to(DEV)
+    inside_o = torch.zeros_like(o)
+    rays = {0: (o.to(DEV), d.to(DEV)), 1: (o.to(DEV), d.to(DEV)), 2: (inside_o.to(DEV), d.to(DEV))}
+    occ = OC.update_occlusion_mask(m, lambda v: rays[v], H, W, [0, 1, 2], shared, kernel_size=9)
+    assert occ.shape == (3, H, W, 1) and bool(occ[0].all()) and bool(occ[2].all()) and torch.equal(occ[1].cpu(), want)
+
+
+def test_render_shared_depth_publishes_inside_views_only():
+    """tile.py:436-471: only overlap views whose camera lies inside the tile are rendered (every second pixel) and the map is
+    the merged fg + T*bg depth of the fused renderer."""
+    import scanerf_amd  # noqa
+    from scanerf_amd import occlusion as OC
+    from scanerf_amd.tile_model import TileModel
+    H, W = 32, 48
+    m = TileModel([-4, -4, -4], [8, 8, 8], DEV, log2_T=14, seed=2)
+    with torch.no_grad():
+        m.features.mul_(200.0)
+    j, i = torch.meshgrid(torch.arange(H), torch.arange(W), indexing="ij")
+    d = torch.stack([(i + 0.5 - W / 2) / 40.0, (j + 0.5 - H / 2) / 40.0, torch.ones(H, W)], -1).reshape(-1, 3).float().to(DEV)
+    cams = {0: torch.tensor([0.0, 0.0, -1.0]), 1: torch.tensor([0.0, 0.0, -9.0]), 2: torch.tensor([1.0, 0.5, 0.0])}
+    get = lambda v: (cams[v].to(DEV)[None, :].expand_as(d).contiguous(), d)
+    shared = torch.full((10, H // 2, W // 2), OC.NO_DEPTH, device=DEV)
+    pub = OC.render_shared_depth(m, get, H, W, [4, 7, 9], [0, 1], shared, S_fg=32, S_bg=16, global_step=20000)
+    assert pub == [4]  # view 1 is outside the tile, view 2 is not an overlap view
+    assert bool(torch.isinf(shared[7]).all()) and bool(torch.isinf(shared[9]).all()) and bool(torch.isfinite(shared[4]).all())
+    o0, d0 = get(0)
+    sub = lambda t: t.reshape(H, W, 3)[::2, ::2].reshape(-1, 3).contiguous()
+    want = m.render_rays_fused(sub(o0), sub(d0), 32, 16, 20000)["pred_depth"].reshape(H // 2, W // 2)
+    assert torch.equal(shared[4], want) and float(want.abs().max()) > 0
+
+
+def test_tile_trainer_loop_prunes_and_resumes(tmp_path):
+    """TileTrainer: scheduled learning rates, a pruning event inside the loop, loss going down on a fixed batch, and a
+    checkpoint from which a fresh trainer continues bit-identically."""
+    import scanerf_amd  # noqa
+    from scanerf_amd import trainer
+    from scanerf_amd.tile_model import TileModel
+    torch.manual_seed(0)
+    B = 4096
+    o = torch.rand(B, 3, device=DEV) * 8 - 4
+    d = torch.nn.functional.normalize(torch.randn(B, 3, device=DEV), dim=-1)
+    tgt = torch.rand(1, 3, device=DEV).expand(B, 3).contiguous()
+
+    def make():
+        m = TileModel([-4, -4, -4], [8, 8, 8], DEV, log2_T=14, seed=7, sampler_log2dim=4)
+        with torch.no_grad():
+            m.features.mul_(100.0)
+        return trainer.TileTrainer(m, lambda s: (o, d, tgt), total_step=40, eta_hash=1e-2, eta_decoder=1e-3, grid_log2dim=(4, 5),
+                                   pruning_th=(0.0,), adjust_step=4, num_sample=32, finest_resolution=256)
+
+    tr = make()
+    losses = []
+    tr.train(6, on_step=lambda s, l: losses.append(float(l)))
+    assert tr.global_step == 6 and int(tr.model.log2dim.max()) == 5  # pruned (with a split) at step 4
+    assert tuple(tr.model.occupied_grid.shape) == (32, 32, 32) and bool(tr.model.occupied_grid.any())
+    assert abs(tr.table_lr - O.scheduler_eta(5, 1e-2, 1e-3, 40)) < 1e-12
+    assert abs(tr.dec_opt.param_groups[0]["lr"] - O.scheduler_eta(5, 1e-3, 1e-4, 40)) < 1e-12
+    ck = tr.export_check_point(tmp_path / "checkpoint-6-0.pt")
+    a = [float(tr.train_one_step()) for _ in range(3)]
+    tr2 = make()
+    assert tr2.load_check_point(ck) == 6 and tr2.table_lr == trainer.Scheduler("g", 1e-2, 1e-3, 40).value(5)
+    b = [float(tr2.train_one_step()) for _ in range(3)]
+    assert a == b, (a, b)
+    assert torch.equal(tr.model.features, tr2.model.features) and torch.equal(tr.model.decoder.params, tr2.model.decoder.params)
+    assert np.isfinite(losses).all() and a[-1] < losses[0]
