@@ -10,14 +10,19 @@
 //
 // pts_inference / bg_pts_inference_v2 are the render hot loop.  The reference runs the whole
 // 13 994-MAC decoder serially in one thread per sample, weights from global memory.  Here a wave
-// takes 32 consecutive samples and runs the decoder on the fp32 matrix cores (render_device.h):
-// the packed weight image of whichever tile the samples reference is read through L2 (all tiles'
-// images stay resident: 58 KB each); samples that overlap several tiles loop over the distinct
-// tiles of the wave.
+// takes 32 consecutive samples and runs the decoder on the matrix cores.  Default: one pass per
+// tile with that tile's split-f16 decoder image staged in LDS (k_pts_inference_tile: 2.4e9
+// samples/s, the rate of the training forward -- table gathers bound it).  Kept for comparison
+// (SCANERF_RENDER_ARITH=f32): a single pass on the fp32 matrix pipe that reads the packed image of
+// whichever tile the samples reference through L2 and loops over the distinct tiles of a wave
+// (1.5e9 samples/s).
 #include <hip/hip_fp16.h>
+
+#include <stdlib.h>
 
 #include "dda_device.h"
 #include "render_device.h"
+#include "render_h3.h"
 
 using namespace scanerf;
 
@@ -298,6 +303,144 @@ __global__ void __launch_bounds__(256, 2) k_pts_inference(InferArgs a)
             a.out_alpha[e] = alpha;
         }
     }
+}
+
+// ---- pts_inference / bg_pts_inference_v2, one pass per tile (default) ---------------------------------------------------
+// The kernel above reads every MFMA operand of whichever tile a sample references from global memory and multiplies on
+// the f32 matrix pipe (1.5e9 samples/s).  Here the launch is split into one pass per tile b: a workgroup stages tile b's
+// split-f16 decoder image (render_h3.h, the arithmetic of the training kernels; 70 KB) in LDS once and walks all 32-sample
+// groups, working only on the samples that list b.  A group none of whose samples lists b costs one 8-byte load per lane.
+// Samples in the overlap of several tiles are blended across passes: each pass adds w_b * pa * colour / sum_k w_k into the
+// (zero-filled) outputs; passes are separate launches on one stream, so the read-modify-write is race-free and ordered.
+template <bool BG>
+__global__ void __launch_bounds__(256, 2) k_pts_inference_tile(InferArgs a, int b)
+{
+    __shared__ __attribute__((aligned(16))) char lds[H3_BYTES];
+    {
+        const float4 *src = reinterpret_cast<const float4 *>(a.images + (size_t)b * WS_FLOATS + PK_TOTAL);
+        float4 *dst = reinterpret_cast<float4 *>(lds);
+        for (int i = threadIdx.x; i < H3_BYTES / 16; i += 256) dst[i] = src[i];
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, sl = lane & 31, h = lane >> 5;
+    const int64_t total = (int64_t)a.B * a.S;
+    const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
+    float cb[3], sb[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        cb[c] = a.t.corners[3 * b + c];
+        sb[c] = a.t.sizes[3 * b + c];
+    }
+    for (int64_t base = ((int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 32; base < total; base += nwaves * 32) {
+        const int64_t e = base + sl;
+        const bool in_range = e < total;
+        const int64_t ec = in_range ? e : total - 1;
+        const int i = (int)(ec / a.S), s = (int)(ec % a.S);
+        // does this sample list tile b?  (fg: the slot list stops at the first -1, rendering_kernel.cu:499)
+        int16_t slot[kMaxPtsBlocks] = { -1, -1, -1, -1 };
+        bool mine = false;
+        if (BG) {
+            mine = in_range && a.block_idxs[i * kMaxPtsBlocks + a.step] == b;
+        } else if (in_range) {
+            const uint2 raw = *reinterpret_cast<const uint2 *>(a.block_idxs + ec * kMaxPtsBlocks);
+            slot[0] = (int16_t)(raw.x & 0xffffu); slot[1] = (int16_t)(raw.x >> 16);
+            slot[2] = (int16_t)(raw.y & 0xffffu); slot[3] = (int16_t)(raw.y >> 16);
+            bool ended = false;
+#pragma unroll
+            for (int k = 0; k < kMaxPtsBlocks; ++k) {
+                ended |= slot[k] == -1;
+                if (ended) slot[k] = -1;
+                mine |= slot[k] == b;
+            }
+        }
+        if (!__any(mine)) continue;  // wave-uniform
+        float o[3], d[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            o[k] = a.rays_o[3 * i + k];
+            d[k] = a.rays_d[3 * i + k];
+        }
+        const float dnorm = sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+        const float z = a.z_vals[ec];
+        float delta;
+        if (BG) delta = (s == a.S - 1) ? 10000000.0f : a.z_vals[ec + 1] - z;   // :1045-1047: raw depth step
+        else delta = a.dists[ec] * dnorm;                                       // :557
+        float p01[3], w_b = 0.0f, weight = 0.0f;
+        bool run = mine;
+        if (BG) {
+            float q[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) q[c] = 2.0f * ((o[c] + z * d[c]) - cb[c]) / sb[c] - 1.0f;
+            const float linf = fmaxf(fabsf(q[0]), fmaxf(fabsf(q[1]), fabsf(q[2])));
+            const float ratio = (2.0f - 1.0f / linf) / linf;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) p01[c] = (q[c] * ratio + 2.0f) / 4.0f;
+        } else {
+            // blend weights of every listed tile (occupied or not, :523-541), this tile's cell and position
+#pragma unroll
+            for (int k = 0; k < kMaxPtsBlocks; ++k) {
+                const int bk = slot[k];
+                if (bk == -1) continue;
+                float dis[3];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const float sz = a.t.sizes[3 * bk + c];
+                    const float pt = ((o[c] + z * d[c]) - a.t.corners[3 * bk + c]) / sz;
+                    dis[c] = (0.5f - fabsf(pt - 0.5f)) * sz;
+                }
+                const float w = xz_weight(dis[0], dis[2]);
+                weight += w;
+                if (bk == b) w_b = w;
+            }
+            int loc[3];
+            const int l2d[3] = { a.t.log2dim[3 * b], a.t.log2dim[3 * b + 1], a.t.log2dim[3 * b + 2] };
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float pt = ((o[c] + z * d[c]) - cb[c]) / sb[c];
+                const int r = 1 << l2d[c];
+                const int cc = (int)(pt * (float)r);
+                loc[c] = cc < 0 ? 0 : (cc > r - 1 ? r - 1 : cc);
+                p01[c] = pt / 2.0f + 0.25f;  // tile -> the middle half of the 2x box (:548)
+            }
+            if (mine) run = a.t.occ[a.t.grid_starts[b] + cell_offset(loc, l2d[1], l2d[2])] != 0;
+        }
+        if (!__any(run)) continue;  // wave-uniform: nothing of this group is occupied (the outputs stay as they are)
+        v16f x;
+        encode8_01<SCANERF_F16>((const char *)a.tables + (size_t)b * 16 * a.T * 4, a.res + (size_t)b * 48, a.T, h, p01, run, x);
+        v16f dinit[2];
+        {
+            float sh[16];
+            ray_sh(d, dnorm, sh, 0.0f);
+            h3_dinit(lds, lane, sh, dinit);
+        }
+        const SampleOut so = decode_tile_h3(lds, lane, x, dinit);
+        if (run && h == 0) {
+            const float pa = 1.0f - expf(-1.0f * so.sigma * delta);
+            if (BG) {
+                a.out_alpha[e] = pa;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    a.out_dif[3 * e + c] = pa * so.dif[c];
+                    a.out_spec[3 * e + c] = pa * (so.tint[c] * so.spec[c]);
+                }
+            } else {
+                const float inv = weight > 0 ? 1.0f / weight : 1.0f;
+                a.out_alpha[e] += (w_b * pa) * inv;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    a.out_dif[3 * e + c] += (w_b * pa * so.dif[c]) * inv;
+                    a.out_spec[3 * e + c] += (w_b * pa * (so.tint[c] * so.spec[c])) * inv;
+                }
+            }
+        }
+    }
+}
+
+// f32-MFMA single-pass kernel instead of the per-tile passes (SCANERF_RENDER_ARITH=f32; comparison / debugging)
+inline bool render_single_pass()
+{
+    const char *e = getenv("SCANERF_RENDER_ARITH");
+    return e && e[0] == 'f';
 }
 
 // ---- rendering_kernel.cu:624-702: front-to-back accumulation, one wave per ray ------------------------
@@ -620,7 +763,19 @@ SCANERF_API int scanerf_pts_inference(const float *rays_o, const float *rays_d, 
     a.out_dif = out_dif; a.out_spec = out_spec; a.out_alpha = out_alpha; a.T = T; a.B = B; a.S = S; a.step = 0;
     const int64_t tiles32 = ((int64_t)B * S + 31) / 32;
     int blocks = (int)((tiles32 + 3) / 4 < kNumCU * 4 ? (tiles32 + 3) / 4 : kNumCU * 4);
-    hipLaunchKernelGGL((k_pts_inference<false>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+    if (render_single_pass()) {
+        hipLaunchKernelGGL((k_pts_inference<false>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+        return check_launch("pts_inference");
+    }
+    // every sample is written (zeros where no tile applies, :569-571); the tile passes add into it
+    const size_t n = (size_t)B * S;
+    if (hipMemsetAsync(out_dif, 0, n * 12, (hipStream_t)stream) != hipSuccess ||
+        hipMemsetAsync(out_spec, 0, n * 12, (hipStream_t)stream) != hipSuccess ||
+        hipMemsetAsync(out_alpha, 0, n * 4, (hipStream_t)stream) != hipSuccess)
+        return check_launch("pts_inference (clear)") | 1;
+    blocks = (int)((tiles32 + 3) / 4 < kNumCU * 8 ? (tiles32 + 3) / 4 : kNumCU * 8);
+    for (int b = 0; b < nb; ++b)
+        hipLaunchKernelGGL((k_pts_inference_tile<false>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, a, b);
     return check_launch("pts_inference");
 }
 
@@ -641,7 +796,13 @@ SCANERF_API int scanerf_bg_pts_inference_v2(const float *rays_o, const float *ra
     a.out_dif = out_dif; a.out_spec = out_spec; a.out_alpha = out_alpha; a.T = T; a.B = B; a.S = S; a.step = step;
     const int64_t tiles32 = ((int64_t)B * S + 31) / 32;
     int blocks = (int)((tiles32 + 3) / 4 < kNumCU * 4 ? (tiles32 + 3) / 4 : kNumCU * 4);
-    hipLaunchKernelGGL((k_pts_inference<true>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+    if (render_single_pass()) {
+        hipLaunchKernelGGL((k_pts_inference<true>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+        return check_launch("bg_pts_inference_v2");
+    }
+    blocks = (int)((tiles32 + 3) / 4 < kNumCU * 8 ? (tiles32 + 3) / 4 : kNumCU * 8);
+    for (int b = 0; b < nb; ++b)
+        hipLaunchKernelGGL((k_pts_inference_tile<true>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, a, b);
     return check_launch("bg_pts_inference_v2");
 }
 
