@@ -102,4 +102,34 @@ struct TableElem<SCANERF_BF16> {
     static constexpr int bytes = 4;
 };
 
+// ---- the 8 corner entries of one cell with fewer cache-line requests (half-precision tables) ------------------------
+// Scattered loads on gfx950 cost one request per lane and line whatever their width (tools/gather_bench.hip: 265 G/s from
+// L2, 55-80 G/s beyond it, the same for 8-byte and 16-byte loads).  idx(x+1) = idx(x) ^ ((x ^ (x+1)) & mask): for even x
+// the two x-neighbours of a (y,z) corner are the entries i and i^1 -- one aligned two-entry chunk, one load; only for odd
+// x does the neighbour live elsewhere: 6 requests per cell on average instead of 8.  Two exclusive paths write the same
+// 8 results.  Used for the 4-byte-entry tables only: with 8-byte entries the chunk loads are 16 bytes per lane and the
+// extra registers spill the (register-bound) forward kernel -- measured 3.2 -> 4.3 ms there, against 1.24 -> 1.03 ms
+// (bf16, configs[2]) here.  f[c] in corner_indices order (c = dx<<2 | dy<<1 | dz).
+template <int DT>
+__device__ __forceinline__ void gather_cell(const void *slice, const uint32_t idx[8], bool x_odd, float2 f[8])
+{
+    static_assert(DT == SCANERF_F16 || DT == SCANERF_BF16, "paired gathers are for the half-precision tables");
+    auto unpack = [](uint32_t u) {
+        if (DT == SCANERF_F16) return __half22float2(*reinterpret_cast<const __half2 *>(&u));
+        return make_float2(__uint_as_float(u << 16), __uint_as_float(u & 0xffff0000u));
+    };
+    if (x_odd) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) f[c] = TableElem<DT>::load(slice, idx[c]);
+    } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint2 t = reinterpret_cast<const uint2 *>(slice)[idx[q] >> 1];
+            const bool hi = idx[q] & 1u;
+            f[q] = unpack(hi ? t.y : t.x);
+            f[4 + q] = unpack(hi ? t.x : t.y);
+        }
+    }
+}
+
 }  // namespace scanerf

@@ -343,7 +343,7 @@ __global__ void __launch_bounds__(kRenderThreads, 2) k_render_fwd_h3(RenderArgs 
 #pragma unroll
                 for (int g = 0; g < 16; ++g) x[g] = p[g % 3] * (0.01f * g);
             } else {
-                encode8<DT>(a, lds_res, h, p, x);
+                encode8<DT, 2, true>(a, lds_res, h, p, x);
             }
             if (a.xstash && live) {
                 float4 *xs = reinterpret_cast<float4 *>(a.xstash + ((size_t)ray * S + s) * 32 + 16 * h);

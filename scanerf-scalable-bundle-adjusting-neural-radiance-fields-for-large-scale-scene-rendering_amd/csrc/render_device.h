@@ -131,7 +131,8 @@ struct RenderArgs {
 // GATHER_BATCH = levels whose 8 gathers each are in flight together: 2 keeps the forward kernel at
 // two waves per SIMD (128-register budget); 8 issues all 64 gathers of the lane at once -- one
 // memory latency instead of four -- for the one-wave-per-SIMD backward kernel.
-template <int DT, int GATHER_BATCH = 2>
+// PAIRED: fetch x-neighbour pairs with one load where the hash puts them side by side (gather_cell; half-precision tables)
+template <int DT, int GATHER_BATCH = 2, bool PAIRED = false>
 __device__ __forceinline__ void encode8(const RenderArgs &a, const int *lds_res, int h, const float p[3], v16f &x)
 {
     const uint32_t mask = (uint32_t)a.T - 1u;
@@ -150,8 +151,12 @@ __device__ __forceinline__ void encode8(const RenderArgs &a, const int *lds_res,
         trilinear_weights(w, t[0], t[1], t[2]);
         const char *slice = (const char *)a.features + (size_t)level * a.T * TableElem<DT>::bytes;
         float2 f[8];
+        if constexpr (PAIRED && DT != SCANERF_F32) {
+            gather_cell<DT>(slice, idx, b[0] & 1, f);
+        } else {
 #pragma unroll
-        for (int c = 0; c < 8; ++c) f[c] = TableElem<DT>::load(slice, idx[c]);
+            for (int c = 0; c < 8; ++c) f[c] = TableElem<DT>::load(slice, idx[c]);
+        }
         float ax = 0.0f, ay = 0.0f;
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
@@ -299,8 +304,12 @@ __device__ __forceinline__ void encode8_01(const void *table, const int32_t *res
             trilinear_weights(w, t[0], t[1], t[2]);
             const char *slice = (const char *)table + (size_t)level * T * TableElem<DT>::bytes;
             float2 f[8];
+            if constexpr (DT != SCANERF_F32) {
+                gather_cell<DT>(slice, idx, b[0] & 1, f);
+            } else {
 #pragma unroll
-            for (int c = 0; c < 8; ++c) f[c] = TableElem<DT>::load(slice, idx[c]);
+                for (int c = 0; c < 8; ++c) f[c] = TableElem<DT>::load(slice, idx[c]);
+            }
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
                 ax = fmaf(w[c], f[c].x, ax);
