@@ -379,7 +379,7 @@ SCANERF_API int scanerf_embedding_bg_backward_binned(const float *points, const 
     else
         hipLaunchKernelGGL((k_bin_scatter<true>), dim3(g.W), dim3(kThreads), lds_bins, st, points, gi, resolutions, g,
                            counts, starts, recs, grad_features, maxbits);
-    hipLaunchKernelGGL((k_bin_accumulate<1024, 16, true>), dim3(nbins), dim3(1024), (size_t)(2 << g.bucket_log) * 8, st, recs,
+    hipLaunchKernelGGL((k_bin_accumulate<256, 32, true>), dim3(nbins), dim3(256), (size_t)(2 << g.bucket_log) * 8, st, recs,
                        starts, maxbits, g, grad_features);
     return check_launch("embedding_bg_backward_binned");
 }
@@ -462,7 +462,8 @@ SCANERF_API int scanerf_render_scatter_accumulate(float *grad_features, int B, i
                            w.recs, w.starts, w.maxbits, g, grad_features);                                          \
     }
     // measured on MI355X (tools/bench_accum.py, 5.4e8 records = 8.6 GB): record i -> lane i (lane-interleaved) 256x8 3.61 ms,
-    // 512x8 3.38, 1024x4 3.31; U consecutive records per lane 1024x4 2.21, 512x8 2.34, 1024x8 2.35, 1024x16 2.01.  The
+    // 512x8 3.38, 1024x4 3.31; U consecutive records per lane 1024x4 2.21, 512x8 2.34, 1024x8 2.35, 1024x16 2.01-2.06,
+    // 512x16 1.86, 256x16 1.86, 128x16 1.82, 512x32 1.95, 256x32 1.73-1.79 (default), 128x32 1.73, 64x32 1.78.  The
     // interleaved forms were bound by same-address serialisation in the LDS (coarse levels), not by the atomic rate itself
     // (5.8 distinct 64-bit adds per clock per CU: tools/lds_atomic_bench.hip); what is left is mostly the record stream.
     if (variant == 1) SCANERF_LAUNCH_ACC(256, 8)
@@ -471,7 +472,15 @@ SCANERF_API int scanerf_render_scatter_accumulate(float *grad_features, int B, i
     else if (variant == 4) SCANERF_LAUNCH_ACC_RUN(1024, 4)
     else if (variant == 5) SCANERF_LAUNCH_ACC_RUN(512, 8)
     else if (variant == 6) SCANERF_LAUNCH_ACC_RUN(1024, 8)
-    else SCANERF_LAUNCH_ACC_RUN(1024, 16)
+    else if (variant == 8) SCANERF_LAUNCH_ACC_RUN(512, 16)
+    else if (variant == 9) SCANERF_LAUNCH_ACC_RUN(256, 16)
+    else if (variant == 10) SCANERF_LAUNCH_ACC_RUN(512, 32)
+    else if (variant == 11) SCANERF_LAUNCH_ACC_RUN(256, 32)
+    else if (variant == 12) SCANERF_LAUNCH_ACC_RUN(128, 32)
+    else if (variant == 13) SCANERF_LAUNCH_ACC_RUN(64, 32)
+    else if (variant == 14) SCANERF_LAUNCH_ACC_RUN(128, 16)
+    else if (variant == 7) SCANERF_LAUNCH_ACC_RUN(1024, 16)
+    else SCANERF_LAUNCH_ACC_RUN(256, 32)
 #undef SCANERF_LAUNCH_ACC
 #undef SCANERF_LAUNCH_ACC_RUN
     return check_launch("render_scatter_accumulate");

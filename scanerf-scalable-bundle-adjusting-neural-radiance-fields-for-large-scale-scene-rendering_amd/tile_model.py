@@ -329,7 +329,7 @@ def train_step_ops(model, dec_opt, rays_o, rays_d, target, S, global_step, table
 
 
 def train_step_fused(model, dec_opt, rays_o, rays_d, target, S, global_step, table_lr=1e-2, timer=None,
-                     pose_grads=False, fused_scatter=True, compact_rays=None):
+                     pose_grads=False, fused_scatter=True, compact_rays=None, overlap_plan=False):
     """The same iteration as train_step_ops on the fused kernels: one launch for the render forward,
     one for its adjoint, the atomic-free binned scatter for the table gradient, fused sparse Adam.
     pose_grads=True also returns dL/d(rays_o), dL/d(rays_d) (feed them to the pose graph:
@@ -360,6 +360,19 @@ def train_step_fused(model, dec_opt, rays_o, rays_d, target, S, global_step, tab
         tile_T = torch.empty((B, ntile), device=dev)
         xstash = torch.empty((B * S, 32), device=dev)  # encoder outputs: 1 GB at 65 536 x 128, saves the re-gather
         box = (model.min_bbox.tolist(), model.bbox_size.tolist(), render.FORE, False)
+        T = model.features.shape[1]
+        fused = fused_scatter and render.scatter_supported(B, S, T)
+        ws = plan_done = None
+        side = model._side_stream if overlap_plan else None  # (the plan then has no timer section of its own)
+        if fused and side is not None:
+            # the record plan depends on the sample positions only: count + scan on a side stream, under the forward.
+            # Measured: no gain (the forward slows from 3.14 to 3.6 ms, exactly the 0.25 ms of the plan plus contention),
+            # so it is off by default
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                ws = render.scatter_plan(rays_o, rays_d, z, model.resolution, T, *box, ray_valid=valid)
+                plan_done = torch.cuda.Event()
+                plan_done.record(side)
         # gather table: the fp32 master itself, or its bf16/f16 image (configs[2]: half the gather bytes, fp32 accumulate)
         table = model.features if model.table_dtype == torch.float32 else model.features.detach().to(model.table_dtype)
         with _sec(timer, "render_forward", B * (24 + 20 + S * 16 * 8 * 2 * table.element_size()),
@@ -373,13 +386,12 @@ def train_step_fused(model, dec_opt, rays_o, rays_d, target, S, global_step, tab
         gblob = torch.zeros(network.PARAMSIZE, device=dev)
         ray_bufs = (torch.zeros(B, ntile, device=dev), torch.zeros(B, 2, 64, device=dev)) if pose_grads else None
         g_o = g_d = None
-        T = model.features.shape[1]
-        fused = fused_scatter and render.scatter_supported(B, S, T)
-        ws = None
-        if fused:
+        if fused and ws is None:
             # count + scan of the scatter records (depends on the sample positions only)
             with _sec(timer, "scatter_plan", B * S * 4):
                 ws = render.scatter_plan(rays_o, rays_d, z, model.resolution, T, *box, ray_valid=valid)
+        elif plan_done is not None:
+            torch.cuda.current_stream().wait_event(plan_done)
         # forward recompute + activation gradients + weight gradients = 3x the forward MLP FLOPs
         with _sec(timer, "render_backward", B * (24 + 20 + S * 16 * 8 * 2 * 4 + S * 16 * 8), 3 * B * S * MLP_FLOPS_PER_SAMPLE):
             dfeat, _ = render.render_backward(rays_o, rays_d, z, dist, table, model.resolution, model.packed, wf,
