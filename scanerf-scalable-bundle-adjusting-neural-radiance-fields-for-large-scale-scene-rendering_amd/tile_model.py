@@ -329,7 +329,7 @@ def train_step_ops(model, dec_opt, rays_o, rays_d, target, S, global_step, table
 
 
 def train_step_fused(model, dec_opt, rays_o, rays_d, target, S, global_step, table_lr=1e-2, timer=None,
-                     pose_grads=False, fused_scatter=True, compact_rays=None, overlap_plan=False):
+                     pose_grads=False, fused_scatter=True, compact_rays=None, overlap_plan=False, dec_step=True):
     """The same iteration as train_step_ops on the fused kernels: one launch for the render forward,
     one for its adjoint, the atomic-free binned scatter for the table gradient, fused sparse Adam.
     pose_grads=True also returns dL/d(rays_o), dL/d(rays_d) (feed them to the pose graph:
@@ -413,7 +413,8 @@ def train_step_fused(model, dec_opt, rays_o, rays_d, target, S, global_step, tab
         with _sec(timer, "sparse_adam", model.features.numel() * 28):
             model.table_adam(table_lr)
         model.decoder.params.grad = gblob
-        dec_opt.step()
+        if dec_step:  # False: the caller steps the optimiser itself (it holds more parameter groups: camera poses)
+            dec_opt.step()
     return (loss[0], g_o, g_d) if pose_grads else loss[0]
 
 

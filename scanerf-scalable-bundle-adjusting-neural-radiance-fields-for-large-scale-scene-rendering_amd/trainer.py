@@ -152,11 +152,22 @@ class TileTrainer:
 
     def __init__(self, model, get_batch, total_step=40000, eta_hash=1e-2, eta_decoder=1e-3, grid_log2dim=(4, 5, 6, 7, 8, 9),
                  pruning_th=(0.1, 0.2, 0.3, 0.4), adjust_step=2000, dynamic_start=None, dynamic_end=None, dynamic_step=None,
-                 num_sample=128, num_bg_sample=0, finest_resolution=2048, consensus=None):
+                 num_sample=128, num_bg_sample=0, finest_resolution=2048, consensus=None, cameras=None, eta_cam=1e-3,
+                 cam_start_step=0, admm=False):
+        """cameras (cameras.CameraSet): pose refinement on -- get_batch(step) then returns (locs [B,3] int32 (view, px, py),
+        target [B,3]) and the rays are generated from the current poses; se3_refine is the optimiser's second parameter
+        group with its own schedule (tile.py:316-323).  admm: add the consensus penalty (consensus.py:70-76) to the
+        pose gradient."""
         self.model, self.get_batch = model, get_batch
-        self.dec_opt = torch.optim.Adam([{"params": model.decoder.parameters(), "lr": eta_decoder, "weight_decay": 1e-6}])
+        self.cameras, self.admm = cameras, admm
+        groups = [{"params": model.decoder.parameters(), "lr": eta_decoder, "weight_decay": 1e-6}]
+        sches = [Scheduler("decoder", eta_decoder, 0.1 * eta_decoder, total_step, groups=[0])]
+        if cameras is not None:
+            groups.append({"params": [cameras.se3_refine], "lr": eta_cam})
+            sches.append(Scheduler("cam", eta_cam, 0.1 * eta_cam, total_step, groups=[1], start_itr=cam_start_step, end_itr=total_step))
+        self.dec_opt = torch.optim.Adam(groups)
         self.table_sche = SchedulerManager([Scheduler("featureGrid", eta_hash, 0.1 * eta_hash, total_step)])
-        self.sche = SchedulerManager([Scheduler("decoder", eta_decoder, 0.1 * eta_decoder, total_step, groups=[0])])
+        self.sche = SchedulerManager(sches)
         self.table_lr = eta_hash
         self.total_step, self.global_step = total_step, 0
         self.grid_log2dim, self.pruning_th, self.adjust_step = list(grid_log2dim), list(pruning_th), adjust_step
@@ -176,7 +187,29 @@ class TileTrainer:
         log2dim = max(log2dim, int(self.model.log2dim.max()))
         return pruning_grid(self.model, s, log2dim, th, finest_resolution=self.finest_resolution)
 
+    def _train_one_step_poses(self):
+        """Iteration with pose refinement: rays from the cameras (HIP ray kernel, differentiable), fused render + adjoint with
+        the ray gradients, which the ray kernel's backward reduces to dL/dC2W and torch carries to se3_refine."""
+        locs, target = self.get_batch(self.global_step)
+        cams = self.cameras
+        cams.se3_refine.grad = None
+        rays_o, rays_d = cams.get_rays(locs)
+        loss, g_o, g_d = train_step_fused(self.model, self.dec_opt, rays_o.detach(), rays_d.detach(), target, self.num_sample,
+                                          self.global_step, table_lr=self.table_lr, pose_grads=True, dec_step=False)
+        torch.autograd.backward([rays_o, rays_d], [g_o, g_d])
+        if self.admm and self.consensus is not None and bool(self.consensus.overlap_flags.any()):
+            self.consensus.camera_loss(cams.se3_refine).backward()
+        self.dec_opt.step()
+        return loss
+
     def train_one_step(self):
+        if self.cameras is not None:
+            loss = self._train_one_step_poses()
+            self.table_sche.step(self.global_step)
+            self.table_lr = self.table_sche.scheduler_list[0].eta
+            self.sche.step(self.global_step, self.dec_opt)
+            self.global_step += 1
+            return loss
         rays_o, rays_d, target = self.get_batch(self.global_step)
         if self.num_bg_sample > 0:
             loss = train_step_fgbg(self.model, self.dec_opt, rays_o, rays_d, target, self.num_sample, self.num_bg_sample,

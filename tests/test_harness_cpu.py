@@ -203,3 +203,21 @@ def test_shared_depth_exchange_world2_gloo():
             else:
                 assert np.isinf(buf[cam]).all()
     np.testing.assert_array_equal(res[0][1], res[1][1])
+
+
+def test_camera_algebra_matches_reference_golden_g7(golden):
+    """cameras.py Lie / pose algebra against camera.py (golden G7): se3_to_SE3, invert, compose."""
+    import scanerf_amd  # noqa
+    from scanerf_amd import cameras as CM
+    g = golden("g7_camera")
+    SE3 = CM.se3_to_SE3(torch.from_numpy(g["se3"]))
+    np.testing.assert_allclose(SE3.numpy(), g["SE3"], rtol=1e-6, atol=1e-7)
+    w2c = CM.pose_invert(torch.from_numpy(g["c2w"]))
+    np.testing.assert_allclose(w2c.numpy(), g["w2c"], rtol=1e-6, atol=1e-7)
+    comp = CM.pose_compose([SE3, w2c])
+    np.testing.assert_allclose(comp.numpy(), g["composed"], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(CM.pose_invert(comp).numpy(), g["composed_inv"], rtol=1e-6, atol=1e-7)
+    # small-angle limit and the pixel layout of a batch
+    np.testing.assert_allclose(CM.se3_to_SE3(torch.zeros(2, 6)).numpy(), np.tile(np.eye(3, 4, dtype=np.float32), (2, 1, 1)))
+    locs = CM.pixel_locs(3, torch.tensor([0, 9, 17]), 8, "cpu")
+    assert locs.dtype == torch.int32 and locs.tolist()[:4] == [[0, 0, 0], [0, 1, 1], [0, 1, 2], [1, 0, 0]]
