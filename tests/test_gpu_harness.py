@@ -250,3 +250,58 @@ def test_pose_refinement_descends():
     print("pose refinement: loss %.5f -> %.5f, camera centre error %.4f -> %.4f m" % (losses[0], losses[-1], err0, err1))
     assert losses[-1] < 0.7 * losses[0], (losses[0], losses[-1])
     assert err1 < 0.8 * err0, (err0, err1)
+
+
+def test_admm_driver_with_real_tile_trainers(tmp_path):
+    """Two neighbouring tiles on one GPU, each refining the poses of its 3 views (one view shared), through the ADMM schedule:
+    trainer iterations on the fused kernels, consensus exchanges, shared-depth hooks, refined camera log."""
+    import scanerf_amd  # noqa
+    from scanerf_amd import admm, consensus as C, formats, occlusion as OC, trainer
+    from scanerf_amd import cameras as CM
+    from scanerf_amd.tile_model import TileModel
+    torch.manual_seed(0)
+    H, W, S_ = 24, 32, 32
+    n_cam = 5
+    eye = torch.eye(3)
+    all_c2w = torch.stack([torch.cat([eye, torch.tensor([[x0], [0.0], [-3.0]])], -1) for x0 in (-2.0, 0.0, 3.5, 6.0, 9.0)])
+    all_ks = torch.tensor([[40.0, 0, W / 2, 0, 40.0, H / 2, 0, 0, 1]]).repeat(n_cam, 1).reshape(n_cam, 3, 3)
+    views = [[0, 1, 2], [2, 3, 4]]  # camera 2 is seen by both tiles
+    shared_depth = torch.full((n_cam, H // 2, W // 2), OC.NO_DEPTH, device=DEV)
+    trainers = []
+    for t, vs in enumerate(views):
+        m = TileModel([-4.0 + 8.0 * t, -4, -4], [8, 8, 8], DEV, log2_T=13, seed=t)
+        with torch.no_grad():
+            m.features.mul_(100.0)
+        cams = CM.CameraSet(all_ks[vs], all_c2w[vs], DEV, noise=torch.randn(3, 6) * 0.01)
+        locs = CM.pixel_locs(3, torch.arange(H * W), W, DEV)
+        tgt = torch.rand(locs.shape[0], 3, device=DEV)
+        tr = trainer.TileTrainer(m, lambda s, locs=locs, tgt=tgt: (locs, tgt), total_step=20, num_sample=S_, adjust_step=1000,
+                                 cameras=cams, eta_cam=1e-3, consensus=C.ConsensusState(n_cam, torch.tensor(vs), DEV, rho=1.0))
+        tr.views = vs
+        trainers.append(tr)
+
+    def publish(tr):
+        get = lambda v: tr.cameras.get_rays(CM.pixel_locs(3, torch.arange(H * W), W, DEV)[v * H * W:(v + 1) * H * W])
+        OC.render_shared_depth(tr.model, lambda v: tuple(x.detach() for x in get(v)), H, W, tr.views,
+                               torch.nonzero(tr.consensus.overlap_flags)[:, 0], shared_depth, S_fg=S_, S_bg=16, global_step=tr.global_step)
+
+    masks = {}
+
+    def consume(tr):
+        get = lambda v: tuple(x.detach() for x in tr.cameras.get_rays(CM.pixel_locs(3, torch.arange(H * W), W, DEV)[v * H * W:(v + 1) * H * W]))
+        OC.exchange_shared_depth(shared_depth)
+        masks[id(tr)] = OC.update_occlusion_mask(tr.model, get, H, W, tr.views, shared_depth, kernel_size=5)
+
+    drv = admm.AdmmDriver(trainers, total_step=8, syn_iters=4, log_dir=str(tmp_path), depth_hooks=(publish, consume))
+    hist = drv.run()
+    assert len(hist) == 3 and all(np.isfinite(h).all() for h in hist) and all(tr.global_step == 8 for tr in trainers)
+    for tr in trainers:  # camera 2 is flagged as overlapping in both tiles, the others are not
+        assert tr.consensus.overlap_flags.tolist() == [v == 2 for v in tr.views]
+        assert masks[id(tr)].shape == (3, H, W, 1)
+        assert float(tr.cameras.se3_refine.detach().abs().max()) > 0
+    assert open(tmp_path / "admm_error.txt").read().count("primal_residual") == 3
+    # camera 2 sits inside tile 1 ([4,12) x ...)? no: x = 3.5 is inside tile 0 -> tile 0 publishes its depth
+    assert bool(torch.isfinite(shared_depth[2]).all()) and bool(torch.isinf(shared_depth[0]).all())
+    c2ws = drv.write_refined_cameras(tmp_path / "refined_camera.log", all_ks, all_c2w, H, W)
+    Ks, C2Ws = formats.read_campara(tmp_path / "refined_camera.log")
+    assert C2Ws.shape == (n_cam, 3, 4) and np.allclose(C2Ws, c2ws.numpy(), atol=1e-7)
