@@ -98,8 +98,41 @@ def cpu_baseline(samples, seconds_budget=15.0):
         step(n + 1)
         n += 1
     dt = (time.time() - t0) / n
-    return {"value": B / dt, "unit": "rays/s", "cores": cores, "kind": "port",
+    return {"value": B / dt, "unit": "rays/s", "cores": cores, "kind": "port", "psnr_vs_oracle_db": psnr_vs_oracle(samples),
             "sample": f"{n} training iterations of {B} rays x {samples} samples (same tile config, T=2^19), oracle/ on {cores} host threads"}
+
+
+def psnr_vs_oracle(samples, B=2048, log2_T=15):
+    """PSNR (tools/utils.py:53-55: 10 log10(255^2 / (mse + 1e-8)) on 0..255 values) of the HIP render of B rays against the
+    oracle's render of the same rays, table and decoder -- the metric's "PSNR vs ref" on the reference-equivalent CPU path
+    (the reference ships no dataset and no CUDA build runs here).  Part of the cpu_baseline leg: the oracle is the checker."""
+    import numpy as np
+
+    import scanerf_amd  # noqa: F401
+    from oracle import oracle as O
+    from scanerf_amd import network, render
+    from scanerf_amd.cuda import sample_points_grid
+    dev = "cuda:0"
+    rng = np.random.default_rng(1)
+    tile = O.Tile([-4, -4, -4], [8, 8, 8], log2_T=log2_T)
+    o = rng.uniform(-4, 4, (B, 3)).astype(np.float32)
+    d = rng.normal(size=(B, 3)).astype(np.float32)
+    feat = (rng.normal(size=(16, tile.T, 2)) * 0.5).astype(np.float32)
+    sd = O.init_mlp(seed=2)
+    t = lambda a: torch.as_tensor(a).to(dev).contiguous()
+    z = torch.full((B, samples), -1.0, device=dev)
+    dist_ = torch.full((B, samples), -1.0, device=dev)
+    sample_points_grid(t(o), t(d), z, dist_, t(tile.occ_corner), t(tile.occ_size), t(tile.occ), t(tile.log2dim))
+    valid = torch.all(z != -1, dim=-1)
+    pk = render.PackedDecoder(dev).pack(O.pack_blob(sd).to(dev), network.weight_feature(20000, dev))
+    out, _ = render.render_forward(t(o), t(d), z, dist_, t(feat), t(tile.res), pk, tile.min_bbox.tolist(), tile.bbox_size.tolist(),
+                                   render.FORE, False, ray_valid=valid, want_weights=False)
+    v = valid.cpu()
+    with torch.no_grad():
+        ref = O.render_batch_rays(torch.from_numpy(o)[v], torch.from_numpy(d)[v], z.cpu()[v], dist_.cpu()[v], torch.from_numpy(feat),
+                                  tile.res, sd, O.INFERENCE, lambda x: O.contract_fore(x, tile.min_bbox, tile.bbox_size), 20000)
+    mse = float(((out[valid][:, 0:3].cpu() * 255.0 - ref["rgb"] * 255.0) ** 2).mean())
+    return 10.0 * float(np.log10(255.0 ** 2 / (mse + 1e-8)))
 
 
 def bench_render(args, world, rank, dev):
