@@ -45,7 +45,7 @@ def parse():
     ap.add_argument("--samples", type=int, default=128)
     ap.add_argument("--log2-T", type=int, default=19, help="hash-table entries per level (configs[1]: 19; the reference's default.yaml: 24)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--scatter", default="fused", choices=["fused", "dfeat"],
+    ap.add_argument("--scatter", default="auto", choices=["auto", "fused", "dfeat"],
                     help="table-gradient records emitted by the backward kernel (fused, default) or by the stand-alone "
                          "binned scatter from a level-major dfeat (tuning comparison)")
     ap.add_argument("--workload", default="configs1", choices=["configs1", "configs2", "configs4-render"],
@@ -221,9 +221,9 @@ def main():
     if path == "auto":
         path = "fused" if hasattr(tm, "train_step_fused") else "ops"
     step_fn = tm.train_step_fused if path == "fused" else tm.train_step_ops
-    if path == "fused" and args.scatter == "dfeat":
+    if path == "fused" and args.scatter != "auto":
         import functools
-        step_fn = functools.partial(tm.train_step_fused, fused_scatter=False)
+        step_fn = functools.partial(tm.train_step_fused, fused_scatter=args.scatter == "fused")
     timer = tm.KernelTimer() if hasattr(tm, "KernelTimer") else None
 
     # ADMM consensus state: N_cam cameras, each tile sees M of them, 20 % shared with the next tile

@@ -36,12 +36,33 @@ constexpr int kRun = 8;  // consecutive points per lane in the stand-alone count
         for (int i = c_; i < c_ + kRun && i < (hi); ++i)
 
 // ---- pass 1: count ---------------------------------------------------------------------
+// PER_LEVEL: the LDS holds one level's NB counters at a time (large tables: L*NB counters do not fit); the points are
+// walked once per level (re-read from L2).
+template <bool PER_LEVEL>
 __global__ void __launch_bounds__(kThreads) k_bin_count(const float *__restrict__ points,
                                                         const int32_t *__restrict__ resolutions, BinGeom g,
                                                         uint32_t *__restrict__ counts, uint32_t *__restrict__ maxbits)
 {
-    extern __shared__ uint32_t hist[];  // [L*NB]
+    extern __shared__ uint32_t hist[];  // [L*NB], or [NB] if PER_LEVEL
     if (blockIdx.x == 0 && threadIdx.x == 0) *maxbits = 0;
+    if (PER_LEVEL) {
+        const uint32_t mask = (uint32_t)g.T - 1u;
+        const int lo = blockIdx.x * g.per_wg, hi = min(g.N, lo + g.per_wg);
+        for (int l = 0; l < g.L; ++l) {
+            for (int i = threadIdx.x; i < g.NB; i += kThreads) hist[i] = 0;
+            __syncthreads();
+            SCANERF_RUN_WALK(i, lo, hi) {
+                const float p[3] = { points[3 * i], points[3 * i + 1], points[3 * i + 2] };
+                Pairs pr;
+                make_pairs(p, resolutions + 3 * l, mask, pr);
+                count_pairs(pr, hist, g.bucket_log);
+            }
+            __syncthreads();
+            for (int i = threadIdx.x; i < g.NB; i += kThreads) counts[((size_t)l * g.NB + i) * g.W + blockIdx.x] = hist[i];
+            __syncthreads();
+        }
+        return;
+    }
     const int nbins = g.L * g.NB;
     for (int i = threadIdx.x; i < nbins; i += kThreads) hist[i] = 0;
     __syncthreads();
@@ -117,7 +138,7 @@ __global__ void __launch_bounds__(1024) k_bin_starts(const uint32_t *__restrict_
 
 // ---- pass 2: scatter records ---------------------------------------------------------------
 // LEVEL_MAJOR_GRAD: grad_in is [L][N][2] (two-kernel render path) instead of [N][L][2].
-template <bool LEVEL_MAJOR_GRAD>
+template <bool LEVEL_MAJOR_GRAD, bool PER_LEVEL = false>
 __global__ void __launch_bounds__(kThreads) k_bin_scatter(const float *__restrict__ points,
                                                           const float2 *__restrict__ grad_in,
                                                           const int32_t *__restrict__ resolutions, BinGeom g,
@@ -126,12 +147,14 @@ __global__ void __launch_bounds__(kThreads) k_bin_scatter(const float *__restric
                                                           float *__restrict__ grad_features,
                                                           uint32_t *__restrict__ maxbits)
 {
-    extern __shared__ uint32_t cursor[];  // [L*NB]
+    extern __shared__ uint32_t cursor[];  // [L*NB], or one level's [NB] at a time if PER_LEVEL
     float gmax = 0.0f;
     const int nbins = g.L * g.NB;
-    for (int i = threadIdx.x; i < nbins; i += kThreads)
-        cursor[i] = starts[i] + rowprefix[(size_t)i * g.W + blockIdx.x];
-    __syncthreads();
+    if (!PER_LEVEL) {
+        for (int i = threadIdx.x; i < nbins; i += kThreads)
+            cursor[i] = starts[i] + rowprefix[(size_t)i * g.W + blockIdx.x];
+        __syncthreads();
+    }
     const uint32_t mask = (uint32_t)g.T - 1u;
     const int lo = blockIdx.x * g.per_wg, hi = min(g.N, lo + g.per_wg);
     // One (sample, level): 4 records.
@@ -140,9 +163,23 @@ __global__ void __launch_bounds__(kThreads) k_bin_scatter(const float *__restric
         gmax = fmaxf(gmax, fmaxf(fabsf(gi.x), fabsf(gi.y)));
         Pairs pr;
         make_pairs(p, resolutions + 3 * l, mask, pr);
-        emit_pairs(pr, gi.x, gi.y, cursor + l * g.NB, g.bucket_log, g.capacity, recs, grad_features + (size_t)l * g.T * 2);
+        emit_pairs(pr, gi.x, gi.y, PER_LEVEL ? cursor : cursor + l * g.NB, g.bucket_log, g.capacity, recs,
+                   grad_features + (size_t)l * g.T * 2);
     };
-    if (LEVEL_MAJOR_GRAD) {
+    if (PER_LEVEL) {
+        for (int l = 0; l < g.L; ++l) {
+            for (int i = threadIdx.x; i < g.NB; i += kThreads) {
+                const int bin = l * g.NB + i;
+                cursor[i] = starts[bin] + rowprefix[(size_t)bin * g.W + blockIdx.x];
+            }
+            __syncthreads();
+            for (int i = lo + threadIdx.x; i < hi; i += kThreads) {
+                const float p[3] = { points[3 * i], points[3 * i + 1], points[3 * i + 2] };
+                one(i, l, p);
+            }
+            __syncthreads();
+        }
+    } else if (LEVEL_MAJOR_GRAD) {
         // level-major walk: a workgroup appends to only NB bins at a time, so the partially written
         // lines of its ranges (one per bin) stay in L2 until complete (full-line write-backs); the
         // gradient reads are contiguous per level and the points are re-read from L2.
@@ -325,14 +362,25 @@ bool fused_geom(int B, int S, int T, BinGeom &g, int arith = SCANERF_ARITH_F32)
 
 }  // namespace
 
+// bucket size of the stand-alone path: 2^11 entries, growing to at most 2^13 (the accumulate's LDS image) so that a level
+// has at most 2048 buckets
+static int standalone_bucket_log(int T)
+{
+    const int lt = bin_ilog2(T);
+    int bl = lt - 11 > kBucketLog ? lt - 11 : kBucketLog;
+    if (const char *e = getenv("SCANERF_STANDALONE_BUCKET_LOG")) bl = atoi(e);  // tuning experiments only
+    if (bl > 13) bl = 13;
+    return lt < bl ? lt : bl;
+}
+
 // Workspace bytes for a binned backward of N points.  0 => shape unsupported by the binned path
 // (the atomics kernel is used instead).
 SCANERF_API size_t scanerf_embedding_bwd_workspace_bytes(int N, int L, int T)
 {
     if (N <= 0 || L < 1 || T < 2 || (T & (T - 1))) return 0;
-    const int bl = bin_ilog2(T) < kBucketLog ? bin_ilog2(T) : kBucketLog;
+    const int bl = standalone_bucket_log(T);
     const int64_t nbins = (int64_t)L * (T >> bl);
-    if (nbins * 4 > 64 * 1024) return 0;                       // LDS histogram of all bins
+    if ((T >> bl) * 4 > 64 * 1024) return 0;                   // one level's LDS counters
     if ((int64_t)N * L * 4 + (1 << 20) >= (int64_t)1 << 31) return 0;  // 32-bit record offsets
     const int W = 1024;
     const size_t recs = ((size_t)N * L * 4 + (size_t)N * L / 8 + 4096) * sizeof(Rec);
@@ -355,7 +403,7 @@ SCANERF_API int scanerf_embedding_bg_backward_binned(const float *points, const 
     hipStream_t st = (hipStream_t)stream;
     BinGeom g;
     g.N = N; g.L = L; g.T = T;
-    g.bucket_log = bin_ilog2(T) < kBucketLog ? bin_ilog2(T) : kBucketLog;
+    g.bucket_log = standalone_bucket_log(T);
     g.NB = T >> g.bucket_log;
     g.W = 1024;
     if (g.W > (N + kThreads - 1) / kThreads) g.W = (N + kThreads - 1) / kThreads;
@@ -368,19 +416,39 @@ SCANERF_API int scanerf_embedding_bg_backward_binned(const float *points, const 
     uint32_t *counts = w.counts, *totals = w.totals, *starts = w.starts, *maxbits = w.maxbits;
     Rec *recs = w.recs;
 
-    const size_t lds_bins = (size_t)nbins * 4;
-    hipLaunchKernelGGL(k_bin_count, dim3(g.W), dim3(kThreads), lds_bins, st, points, resolutions, g, counts, maxbits);
+    // all levels' counters in LDS when they fit in 64 KB, else one level's at a time (large tables)
+    const bool per_level = (size_t)nbins * 4 > 64 * 1024;
+    const size_t lds_bins = per_level ? (size_t)g.NB * 4 : (size_t)nbins * 4;
+    const float2 *gi = reinterpret_cast<const float2 *>(grad_in);
+    if (per_level)
+        hipLaunchKernelGGL((k_bin_count<true>), dim3(g.W), dim3(kThreads), lds_bins, st, points, resolutions, g, counts, maxbits);
+    else
+        hipLaunchKernelGGL((k_bin_count<false>), dim3(g.W), dim3(kThreads), lds_bins, st, points, resolutions, g, counts, maxbits);
     hipLaunchKernelGGL(k_bin_rowscan, dim3(nbins), dim3(kThreads), 0, st, counts, totals, g.W);
     hipLaunchKernelGGL(k_bin_starts, dim3(1), dim3(1024), 0, st, totals, starts, nbins);
-    const float2 *gi = reinterpret_cast<const float2 *>(grad_in);
-    if (grad_layout == 0)
+    if (per_level && grad_layout == 0)
+        hipLaunchKernelGGL((k_bin_scatter<false, true>), dim3(g.W), dim3(kThreads), lds_bins, st, points, gi, resolutions, g,
+                           counts, starts, recs, grad_features, maxbits);
+    else if (per_level)
+        hipLaunchKernelGGL((k_bin_scatter<true, true>), dim3(g.W), dim3(kThreads), lds_bins, st, points, gi, resolutions, g,
+                           counts, starts, recs, grad_features, maxbits);
+    else if (grad_layout == 0)
         hipLaunchKernelGGL((k_bin_scatter<false>), dim3(g.W), dim3(kThreads), lds_bins, st, points, gi, resolutions, g,
                            counts, starts, recs, grad_features, maxbits);
     else
         hipLaunchKernelGGL((k_bin_scatter<true>), dim3(g.W), dim3(kThreads), lds_bins, st, points, gi, resolutions, g,
                            counts, starts, recs, grad_features, maxbits);
-    hipLaunchKernelGGL((k_bin_accumulate<256, 32, true>), dim3(nbins), dim3(256), (size_t)(2 << g.bucket_log) * 8, st, recs,
-                       starts, maxbits, g, grad_features);
+    const size_t lds_acc = (size_t)(2 << g.bucket_log) * 8;
+    if (lds_acc > 64 * 1024) {  // one image per CU: give the workgroup all 16 waves
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bin_accumulate<1024, 16, true>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_acc);
+        SCANERF_REQUIRE(e == hipSuccess, "embedding_bg_backward_binned: cannot reserve %zu B of LDS: %s", lds_acc, hipGetErrorString(e));
+        hipLaunchKernelGGL((k_bin_accumulate<1024, 16, true>), dim3(nbins), dim3(1024), lds_acc, st, recs, starts, maxbits, g,
+                           grad_features);
+    } else {
+        hipLaunchKernelGGL((k_bin_accumulate<256, 32, true>), dim3(nbins), dim3(256), lds_acc, st, recs, starts, maxbits, g,
+                           grad_features);
+    }
     return check_launch("embedding_bg_backward_binned");
 }
 

@@ -329,7 +329,7 @@ def train_step_ops(model, dec_opt, rays_o, rays_d, target, S, global_step, table
 
 
 def train_step_fused(model, dec_opt, rays_o, rays_d, target, S, global_step, table_lr=1e-2, timer=None,
-                     pose_grads=False, fused_scatter=True, compact_rays=None, overlap_plan=False, dec_step=True):
+                     pose_grads=False, fused_scatter=None, compact_rays=None, overlap_plan=False, dec_step=True):
     """The same iteration as train_step_ops on the fused kernels: one launch for the render forward,
     one for its adjoint, the atomic-free binned scatter for the table gradient, fused sparse Adam.
     pose_grads=True also returns dL/d(rays_o), dL/d(rays_d) (feed them to the pose graph:
@@ -361,6 +361,11 @@ def train_step_fused(model, dec_opt, rays_o, rays_d, target, S, global_step, tab
         xstash = torch.empty((B * S, 32), device=dev)  # encoder outputs: 1 GB at 65 536 x 128, saves the re-gather
         box = (model.min_bbox.tolist(), model.bbox_size.tolist(), render.FORE, False)
         T = model.features.shape[1]
+        if fused_scatter is None:
+            # records emitted by the backward kernel need the level's cursors in ITS LDS (256 buckets per level): above
+            # 2^21 entries the buckets outgrow the accumulate's LDS image and are accumulated in windows that re-read the
+            # records (T = 2^24: 15.4 ms); there the stand-alone scatter from dfeat (2048 buckets per level) wins (10.6 ms)
+            fused_scatter = T <= (1 << 21)
         fused = fused_scatter and render.scatter_supported(B, S, T)
         ws = plan_done = None
         side = model._side_stream if overlap_plan else None  # (the plan then has no timer section of its own)
@@ -456,7 +461,7 @@ def fgbg_gradients(model, rays_o, rays_d, target, S_fg, S_bg, global_step, inval
         gblob = torch.zeros(network.PARAMSIZE, device=dev)
         for (z_, d_, v_, mode, inf), out, leaf, (tile_T, xs) in zip(branches, outs, (fg, bg), state):
             S = z_.shape[1]
-            fused = render.scatter_supported(B, S, T)
+            fused = T <= (1 << 21) and render.scatter_supported(B, S, T)  # (see train_step_fused)
             ws = render.scatter_plan(rays_o, rays_d, z_, model.resolution, T, *box, mode, inf, ray_valid=v_) if fused else None
             with _sec(timer, "render_backward"):
                 dfeat, _ = render.render_backward(rays_o, rays_d, z_, d_, model.features, model.resolution, model.packed, wf, *box,

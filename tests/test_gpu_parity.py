@@ -362,13 +362,14 @@ def test_render_forward_invalid_rays_and_table_dtypes(S):
         _check_render(out, w, ref, str(dt))
 
 
-@pytest.mark.parametrize("layout", [0, 1])
-def test_binned_scatter_matches_oracle_and_atomics(S, layout):
-    """csrc/scatter.hip: the atomic-free table gradient == the oracle's sequential sum."""
+@pytest.mark.parametrize("layout,log2_T", [(0, 13), (1, 13), (0, 22), (1, 22)])
+def test_binned_scatter_matches_oracle_and_atomics(S, layout, log2_T):
+    """csrc/scatter.hip: the atomic-free table gradient == the oracle's sequential sum.  T = 2^22: large-table form
+    (2^13-entry buckets, one level's cursors in LDS at a time)."""
     import ctypes
     from scanerf_amd._capi import check, lib, stream, workspace
     rng = np.random.default_rng(11)
-    N, L, T = 30011, 16, 2 ** 13
+    N, L, T = (30011 if log2_T == 13 else 6007), 16, 2 ** log2_T
     res = O.level_resolutions(torch.tensor([32, 32, 32]), torch.tensor([2048, 2048, 2048])).numpy()
     pts = rng.uniform(-2, 2, (N, 3)).astype(np.float32)
     pts[:50] = 2.0  # upper faces: x0+1 crosses the bucket boundary at the finest level (2048)
@@ -378,7 +379,8 @@ def test_binned_scatter_matches_oracle_and_atomics(S, layout):
     assert need > 0
     gi = g(gin if layout == 0 else np.ascontiguousarray(gin.transpose(1, 0, 2)))
     P, R = g(pts), g(res)  # keep alive: raw pointers are handed to the C ABI
-    for ws_bytes in (need, 1 << 20):  # second run: workspace too small -> overflow records take the direct path
+    # second run (small table): workspace too small -> overflow records take the direct path
+    for ws_bytes in ((need, 1 << 20) if log2_T == 13 else (need,)):
         ws = workspace(DEV, need)
         gf = torch.zeros(L, T, 2, device=DEV)
         check(lib().scanerf_embedding_bg_backward_binned(
