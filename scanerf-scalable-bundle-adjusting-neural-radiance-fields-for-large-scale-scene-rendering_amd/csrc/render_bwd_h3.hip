@@ -576,15 +576,42 @@ __global__ void __launch_bounds__(kThreads, 1) k_render_bwd_h3(BwdArgs a)
                     float pe[3];
                     contract_point(a.f, o, d, z, pe);
                     const uint32_t mask = (uint32_t)a.f.T - 1u;
-#pragma unroll 1
-                    for (int j = 0; j < 8; ++j) {
-                        const int level = 4 * (j >> 1) + 2 * h + (j & 1);
-                        const float2 gxy = reinterpret_cast<const float2 *>(stY + lane * 64)[j];
+                    // software-pipelined: the cursor round trips of level j+1 are in flight while level j's records are stored.
+                    // Two register sets used alternately (a copy from "next" to "current" would wait for the atomics at the
+                    // top of every trip); LDS operations return in order, so each trip reads its gradient BEFORE issuing
+                    // the next level's atomics.
+                    Pairs prA, prB;
+                    PairSlots slA, slB;
+                    auto lvl = [&](int j) { return 4 * (j >> 1) + 2 * h + (j & 1); };
+                    // the level's resolution comes from LDS too: it is fetched one step ahead, before the atomics in flight
+                    auto res_of = [&](int j) { return *reinterpret_cast<const int4 *>(lres + 4 * lvl(j)); };
+                    auto issue = [&](int j, const int4 &r, Pairs &pr, PairSlots &sl) {
+                        const int32_t rr[3] = { r.x, r.y, r.z };
+                        make_pairs(pe, rr, mask, pr);
+                        reserve_pairs(pr, cursor + lvl(j) * a.bins.NB, a.bins.bucket_log, sl);
+                    };
+                    auto commit = [&](int j, const Pairs &pr, const PairSlots &sl, float2 gxy) {
                         gmax = fmaxf(gmax, fmaxf(fabsf(gxy.x), fabsf(gxy.y)));
-                        Pairs pr;
-                        make_pairs(pe, lres + 4 * level, mask, pr);
-                        emit_pairs(pr, gxy.x, gxy.y, cursor + level * a.bins.NB, a.bins.bucket_log, a.bins.capacity, a.recs,
-                                   a.grad_features + (size_t)level * a.f.T * 2);
+                        commit_pairs(pr, sl, gxy.x, gxy.y, cursor + lvl(j) * a.bins.NB, a.bins.bucket_log, a.bins.capacity, a.recs,
+                                     a.grad_features + (size_t)lvl(j) * a.f.T * 2);
+                    };
+                    const float2 *gpark = reinterpret_cast<const float2 *>(stY + lane * 64);
+                    int4 rA = res_of(0), rB = res_of(1);
+                    issue(0, rA, prA, slA);
+#pragma unroll 1
+                    for (int jj = 0; jj < 4; ++jj) {
+                        const float2 g0 = gpark[2 * jj];
+                        rA = res_of(jj < 3 ? 2 * jj + 2 : 0);
+                        __builtin_amdgcn_sched_barrier(0);
+                        issue(2 * jj + 1, rB, prB, slB);
+                        __builtin_amdgcn_sched_barrier(0);
+                        commit(2 * jj, prA, slA, g0);
+                        const float2 g1 = gpark[2 * jj + 1];
+                        rB = res_of(jj < 3 ? 2 * jj + 3 : 1);
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (jj < 3) issue(2 * jj + 2, rA, prA, slA);
+                        __builtin_amdgcn_sched_barrier(0);
+                        commit(2 * jj + 1, prB, slB, g1);
                     }
                 }
             }

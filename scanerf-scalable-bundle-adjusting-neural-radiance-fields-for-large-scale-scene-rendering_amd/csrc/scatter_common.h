@@ -110,6 +110,60 @@ __device__ __forceinline__ void emit_pairs(const Pairs &pr, float gix, float giy
         }
     }
 }
+// emit_pairs in two halves, so that a caller can have the cursor round trips of one (sample, level) in flight while it
+// stores the records of the previous one: reserve = the four cursor atomics; commit = records + rare paths.
+struct PairSlots {
+    uint32_t pos[4];
+};
+__device__ __forceinline__ void reserve_pairs(const Pairs &pr, uint32_t *cursor_level, int bucket_log, PairSlots &sl)
+{
+#pragma unroll
+    for (int q = 0; q < 4; ++q) sl.pos[q] = atomicAdd(&cursor_level[pr.idx0[q] >> bucket_log], 1u);
+}
+__device__ __forceinline__ void commit_pairs(const Pairs &pr, const PairSlots &sl, float gix, float giy, uint32_t *cursor_level,
+                                             int bucket_log, uint32_t capacity, Rec *recs, float *grad_level)
+{
+    const uint32_t lmask = (1u << bucket_log) - 1u;
+    const bool straddle = (pr.xm >> bucket_log) != 0u;
+    const float a0 = 1.0f - pr.tx;
+    auto fallback = [&](uint32_t bkt, uint32_t hdr, float tx, float ax, float ay) {
+        float *gs = grad_level + ((size_t)bkt << bucket_log) * 2;
+        const uint32_t e0 = hdr & 0xffffu, e1 = hdr >> 16;
+        unsafeAtomicAdd(gs + 2 * e0, (1.0f - tx) * ax);
+        unsafeAtomicAdd(gs + 2 * e0 + 1, (1.0f - tx) * ay);
+        unsafeAtomicAdd(gs + 2 * e1, tx * ax);
+        unsafeAtomicAdd(gs + 2 * e1 + 1, tx * ay);
+    };
+    const float txr = straddle ? 0.0f : pr.tx;
+    bool rare = straddle;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const uint32_t l0 = pr.idx0[q] & lmask;
+        const uint32_t hdr = straddle ? l0 * 0x10001u : (l0 | ((l0 ^ pr.xm) << 16));
+        const float gx = pr.wyz[q] * gix, gy = pr.wyz[q] * giy;
+        const float ax = straddle ? a0 * gx : gx, ay = straddle ? a0 * gy : gy;
+        if (sl.pos[q] < capacity) reinterpret_cast<float4 *>(recs)[sl.pos[q]] = make_float4(__uint_as_float(hdr), txr, ax, ay);
+        rare |= sl.pos[q] >= capacity;
+    }
+    if (__builtin_expect(__any(rare), 0)) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint32_t l0 = pr.idx0[q] & lmask, b0 = pr.idx0[q] >> bucket_log;
+            const float gx = pr.wyz[q] * gix, gy = pr.wyz[q] * giy;
+            if (sl.pos[q] >= capacity) {
+                if (straddle) fallback(b0, l0 * 0x10001u, 0.0f, a0 * gx, a0 * gy);
+                else fallback(b0, l0 | ((l0 ^ pr.xm) << 16), pr.tx, gx, gy);
+            }
+            if (straddle) {
+                const uint32_t i1 = pr.idx0[q] ^ pr.xm, b1 = i1 >> bucket_log, hdr1 = (i1 & lmask) * 0x10001u;
+                const uint32_t p1 = atomicAdd(&cursor_level[b1], 1u);
+                if (p1 < capacity) reinterpret_cast<float4 *>(recs)[p1] = make_float4(__uint_as_float(hdr1), 0.0f, pr.tx * gx, pr.tx * gy);
+                else fallback(b1, hdr1, 0.0f, pr.tx * gx, pr.tx * gy);
+            }
+        }
+    }
+}
+
 // histogram counterpart of emit_pairs (must stay in lock-step with it)
 __device__ __forceinline__ void count_pairs(const Pairs &pr, uint32_t *hist_level, int bucket_log)
 {
