@@ -5,7 +5,7 @@
 // LOSS_SCALE 128), host wrappers :72-94 / :147-169 (the kernel sees step+1).
 //
 // HBM-bound: 4 B/param grad scan + 28 B/param (fp32) for touched entries.  One thread owns
-// one row of 8 parameters = two 16-B vectors per array; untouched rows cost the grad read
+// half a row of 8 parameters = one 16-B vector per array; untouched vectors cost the grad read
 // only.  The bias corrections are the same for every element and are computed once on
 // the host (powf), not per thread.
 #include <hip/hip_fp16.h>
@@ -36,17 +36,16 @@ struct Moments<true> {
     static __device__ __forceinline__ void put(T *p, int64_t i, float v) { p[i] = __float2half(v); }
 };
 
+// one element; returns false when it is untouched (g == 0)
 template <bool HALF_STATE>
-__device__ __forceinline__ void update_one(float *params, typename Moments<HALF_STATE>::T *m,
-                                           typename Moments<HALF_STATE>::T *v, int64_t i, float g_raw,
-                                           const AdamArgs &a)
+__device__ __forceinline__ bool update_one(float &p, float &mi, float &vi, float g_raw, const AdamArgs &a)
 {
     constexpr float LS = 128.0f;
-    float g = HALF_STATE ? g_raw * LS : g_raw;
-    if (g == 0.0f) return;
-    float mi = a.beta1 * Moments<HALF_STATE>::get(m, i) + (1.0f - a.beta1) * g;
-    float vi = a.beta2 * Moments<HALF_STATE>::get(v, i) + (1.0f - a.beta2) * g * g;
-    float step_size = a.lr / a.bc1;
+    const float g = HALF_STATE ? g_raw * LS : g_raw;
+    if (g == 0.0f) return false;
+    mi = a.beta1 * mi + (1.0f - a.beta1) * g;
+    vi = a.beta2 * vi + (1.0f - a.beta2) * g * g;
+    const float step_size = a.lr / a.bc1;
     float denom, upd;
     if (HALF_STATE) {
         denom = sqrtf(vi / (a.bc2 * LS * LS)) + a.eps;
@@ -55,24 +54,60 @@ __device__ __forceinline__ void update_one(float *params, typename Moments<HALF_
         denom = sqrtf(vi / a.bc2) + a.eps;
         upd = step_size * mi / denom;
     }
-    params[i] = params[i] - upd;
-    Moments<HALF_STATE>::put(m, i, mi);
-    Moments<HALF_STATE>::put(v, i, vi);
+    p = p - upd;
+    return true;
 }
 
+// One thread owns HALF a row: 4 consecutive parameters = one 16-B vector of grad / params (and of the fp32 moments; 8 B of
+// fp16 moments), so that every access of a wave is one contiguous 1 KB (the first version walked the 8 elements of a row
+// with predicated 4-byte accesses at a 32-B lane stride: 3.4 TB/s on a 2 GB table against 5+ here).  A vector none of whose
+// gradients is non-zero costs the gradient read only; in a touched vector the untouched elements are written back unchanged.
 template <bool HALF_STATE>
 __global__ void __launch_bounds__(256) k_adam(float *__restrict__ params, const float *__restrict__ grad,
                                               typename Moments<HALF_STATE>::T *__restrict__ m,
                                               typename Moments<HALF_STATE>::T *__restrict__ v, AdamArgs a, int64_t K,
                                               int param_dim)
 {
-    for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < K; r += (int64_t)gridDim.x * blockDim.x) {
-        const float4 *g4 = reinterpret_cast<const float4 *>(grad + r * 8);
-        float4 ga = g4[0], gb = g4[1];
-        float g[8] = { ga.x, ga.y, ga.z, ga.w, gb.x, gb.y, gb.z, gb.w };
+    using MT = typename Moments<HALF_STATE>::T;
+    for (int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; q < 2 * K; q += (int64_t)gridDim.x * blockDim.x) {
+        const int k0 = (int)(q & 1) * 4;  // first element of this half row
+        if (k0 >= param_dim) continue;
+        const float4 g4 = reinterpret_cast<const float4 *>(grad)[q];
+        const float g[4] = { g4.x, g4.y, g4.z, g4.w };
+        bool any = false;
 #pragma unroll
-        for (int k = 0; k < 8; ++k)
-            if (k < param_dim) update_one<HALF_STATE>(params, m, v, r * 8 + k, g[k], a);
+        for (int j = 0; j < 4; ++j) any |= (k0 + j < param_dim) && g[j] != 0.0f;
+        if (!any) continue;
+        float4 p4 = reinterpret_cast<float4 *>(params)[q];
+        float p[4] = { p4.x, p4.y, p4.z, p4.w }, mm[4], vv[4];
+        if (HALF_STATE) {
+            const uint2 mr = reinterpret_cast<const uint2 *>(m)[q], vr = reinterpret_cast<const uint2 *>(v)[q];
+            const __half2 m01 = *reinterpret_cast<const __half2 *>(&mr.x), m23 = *reinterpret_cast<const __half2 *>(&mr.y);
+            const __half2 v01 = *reinterpret_cast<const __half2 *>(&vr.x), v23 = *reinterpret_cast<const __half2 *>(&vr.y);
+            mm[0] = __low2float(m01); mm[1] = __high2float(m01); mm[2] = __low2float(m23); mm[3] = __high2float(m23);
+            vv[0] = __low2float(v01); vv[1] = __high2float(v01); vv[2] = __low2float(v23); vv[3] = __high2float(v23);
+        } else {
+            const float4 m4 = reinterpret_cast<const float4 *>(m)[q], v4 = reinterpret_cast<const float4 *>(v)[q];
+            mm[0] = m4.x; mm[1] = m4.y; mm[2] = m4.z; mm[3] = m4.w;
+            vv[0] = v4.x; vv[1] = v4.y; vv[2] = v4.z; vv[3] = v4.w;
+        }
+        bool touched[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) touched[j] = (k0 + j < param_dim) && update_one<HALF_STATE>(p[j], mm[j], vv[j], g[j], a);
+        reinterpret_cast<float4 *>(params)[q] = make_float4(p[0], p[1], p[2], p[3]);
+        if (HALF_STATE) {
+            // an untouched element keeps its stored bits (a float round trip of a half is exact, so converting back is too)
+            MT *mo = m + q * 4, *vo = v + q * 4;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (touched[j]) {
+                    Moments<HALF_STATE>::put(mo, j, mm[j]);
+                    Moments<HALF_STATE>::put(vo, j, vv[j]);
+                }
+        } else {
+            reinterpret_cast<float4 *>(m)[q] = make_float4(mm[0], mm[1], mm[2], mm[3]);
+            reinterpret_cast<float4 *>(v)[q] = make_float4(vv[0], vv[1], vv[2], vv[3]);
+        }
     }
 }
 
@@ -84,11 +119,12 @@ int launch(float *params, const float *grad, void *m, void *v, float lr, float b
                     (long long)K, param_dim);
     if (K == 0) return 0;
     SCANERF_REQUIRE(params && grad && m && v, "%s: null pointer", what);
-    SCANERF_REQUIRE(((uintptr_t)grad & 15) == 0, "%s: grad must be 16-byte aligned", what);
+    SCANERF_REQUIRE((((uintptr_t)grad | (uintptr_t)params) & 15) == 0 && (((uintptr_t)m | (uintptr_t)v) & (HALF_STATE ? 7 : 15)) == 0,
+                    "%s: params, grad and moments must be 16-byte aligned (8 for fp16 moments)", what);
     float t = (float)(step + 1);
     AdamArgs a{ lr, beta1, beta2, eps, 1.0f - powf(beta1, t), 1.0f - powf(beta2, t) };
     using MT = typename Moments<HALF_STATE>::T;
-    hipLaunchKernelGGL((k_adam<HALF_STATE>), dim3(stream_grid(K, 256)), dim3(256), 0, st, params, grad, (MT *)m,
+    hipLaunchKernelGGL((k_adam<HALF_STATE>), dim3(stream_grid(2 * K, 256)), dim3(256), 0, st, params, grad, (MT *)m,
                        (MT *)v, a, K, param_dim);
     return check_launch(what);
 }
