@@ -405,7 +405,9 @@ SCANERF_API int scanerf_embedding_bg_backward_binned(const float *points, const 
     g.N = N; g.L = L; g.T = T;
     g.bucket_log = standalone_bucket_log(T);
     g.NB = T >> g.bucket_log;
-    g.W = 1024;
+    // producer workgroups: every one of them writes and reads a counter per bin, so with the tens of thousands of bins of a
+    // large table fewer, longer-running workgroups are cheaper (T = 2^24, 2.1 M points: count 0.62 -> see DESIGN.md)
+    g.W = (size_t)L * g.NB * 4 > 64 * 1024 ? 256 : 1024;
     if (g.W > (N + kThreads - 1) / kThreads) g.W = (N + kThreads - 1) / kThreads;
     g.per_wg = (N + g.W - 1) / g.W;
     const int nbins = L * g.NB;
