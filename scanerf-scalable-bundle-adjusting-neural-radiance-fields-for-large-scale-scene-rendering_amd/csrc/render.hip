@@ -345,7 +345,7 @@ __global__ void __launch_bounds__(kRenderThreads, 2) k_render_fwd_h3(RenderArgs 
             } else {
                 encode8<DT, 2, true>(a, lds_res, h, p, x);
             }
-            if (a.xstash && live) {
+            if (a.xstash && live) {  // (plain stores: streaming / nontemporal ones measured 3.16 -> 3.41 ms)
                 float4 *xs = reinterpret_cast<float4 *>(a.xstash + ((size_t)ray * S + s) * 32 + 16 * h);
                 xs[0] = make_float4(x[0], x[1], x[2], x[3]);
                 xs[1] = make_float4(x[4], x[5], x[6], x[7]);
