@@ -769,10 +769,9 @@ SCANERF_API int scanerf_pts_inference(const float *rays_o, const float *rays_d, 
     }
     // every sample is written (zeros where no tile applies, :569-571); the tile passes add into it
     const size_t n = (size_t)B * S;
-    if (hipMemsetAsync(out_dif, 0, n * 12, (hipStream_t)stream) != hipSuccess ||
-        hipMemsetAsync(out_spec, 0, n * 12, (hipStream_t)stream) != hipSuccess ||
-        hipMemsetAsync(out_alpha, 0, n * 4, (hipStream_t)stream) != hipSuccess)
-        return check_launch("pts_inference (clear)") | 1;
+    const hipError_t ce[3] = { hipMemsetAsync(out_dif, 0, n * 12, (hipStream_t)stream), hipMemsetAsync(out_spec, 0, n * 12, (hipStream_t)stream),
+                               hipMemsetAsync(out_alpha, 0, n * 4, (hipStream_t)stream) };
+    for (hipError_t e : ce) SCANERF_REQUIRE(e == hipSuccess, "pts_inference: clearing the outputs failed: %s", hipGetErrorString(e));
     blocks = (int)((tiles32 + 3) / 4 < kNumCU * 8 ? (tiles32 + 3) / 4 : kNumCU * 8);
     for (int b = 0; b < nb; ++b)
         hipLaunchKernelGGL((k_pts_inference_tile<false>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, a, b);

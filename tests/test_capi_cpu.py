@@ -49,7 +49,9 @@ def test_argument_validation_without_a_gpu():
                                  ctypes.c_float(1e-15), 0, ctypes.c_int64(5), 9, null) != 0  # rows are 8 wide
     lib.scanerf_embedding_bwd_workspace_bytes.restype = ctypes.c_size_t
     assert lib.scanerf_embedding_bwd_workspace_bytes(65536 * 128, 16, 2 ** 19) > 8 << 30
-    assert lib.scanerf_embedding_bwd_workspace_bytes(1000, 16, 2 ** 24) == 0  # too many bins for the LDS histogram
+    assert lib.scanerf_embedding_bwd_workspace_bytes(1000, 16, 2 ** 24) > 0   # large tables: one level's cursors at a time
+    assert lib.scanerf_embedding_bwd_workspace_bytes(1000, 16, 2 ** 28) == 0  # too many buckets per level for the LDS
+    assert lib.scanerf_embedding_bwd_workspace_bytes(1000, 16, 1000) == 0     # not a power of two
 
 
 def test_binding_surface_names_match_the_reference():
