@@ -45,6 +45,9 @@ def parse():
     ap.add_argument("--samples", type=int, default=128)
     ap.add_argument("--log2-T", type=int, default=19, help="hash-table entries per level (configs[1]: 19; the reference's default.yaml: 24)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--tiles-per-gpu", type=int, default=1,
+                    help="tiles resident on each GPU and stepped round-robin (configs[4]: 32 tiles on 8 GPUs = 4; the reference "
+                         "swaps them through host memory, tile.py:574-636 -- 288 GB of HBM keeps them resident)")
     ap.add_argument("--scatter", default="auto", choices=["auto", "fused", "dfeat"],
                     help="table-gradient records emitted by the backward kernel (fused, default) or by the stand-alone "
                          "binned scatter from a level-major dfeat (tuning comparison)")
@@ -207,11 +210,16 @@ def main():
     if args.workload == "configs4-render":
         return bench_render(args, world, rank, dev)
     occ = args.workload == "configs2"
-    model = tm.TileModel([-4.0 + 8.0 * rank, -4, -4], [8, 8, 8], dev, log2_T=args.log2_T, seed=rank,
+    ntile = max(1, args.tiles_per_gpu)
+    models, dec_opts = [], []
+    for t in range(ntile):  # the rank's tiles share one footprint (the batch lies in it); weights and state are their own
+        m = tm.TileModel([-4.0 + 8.0 * rank, -4, -4], [8, 8, 8], dev, log2_T=args.log2_T, seed=rank * ntile + t,
                          sampler_log2dim=7 if occ else 4, table_dtype=torch.bfloat16 if occ else torch.float32)
-    if occ:  # shell of radius 3 m, thickness 0.5 m around the tile centre
-        model.set_occupancy(tm.sphere_shell_occupancy(model, 3.0, 0.5))
-    dec_opt = torch.optim.Adam(model.decoder.parameters(), lr=1e-3, betas=(0.9, 0.99), eps=1e-15)
+        if occ:  # shell of radius 3 m, thickness 0.5 m around the tile centre
+            m.set_occupancy(tm.sphere_shell_occupancy(m, 3.0, 0.5))
+        models.append(m)
+        dec_opts.append(torch.optim.Adam(m.decoder.parameters(), lr=1e-3, betas=(0.9, 0.99), eps=1e-15))
+    model, dec_opt = models[0], dec_opts[0]
     corner = torch.tensor([-4.0 + 8.0 * rank, -4, -4], device=dev)
     rays_o = torch.rand(B, 3, device=dev) * 8 + corner
     rays_d = torch.nn.functional.normalize(torch.randn(B, 3, device=dev), dim=-1) * (0.5 + torch.rand(B, 1, device=dev))
@@ -241,16 +249,17 @@ def main():
     # steady-state iteration count: past the coarse-to-fine warm-up (hashgrid/__init__.py:228-235) every one
     # of the 16 levels is active -- the first 10 000 iterations mask fine levels and do less useful work
     step0 = 20000
-    for i in range(args.warmup):
-        step_fn(model, dec_opt, rays_o, rays_d, target, S, step0 + i)
+    for i in range(max(args.warmup, ntile if ntile > 1 else 0)):
+        step_fn(models[i % ntile], dec_opts[i % ntile], rays_o, rays_d, target, S, step0 + i)
     admm.exchange(se3)
     sync()
     if timer:
         timer.reset()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        step_fn(model, dec_opt, rays_o, rays_d, target, S, step0 + args.warmup + i, timer=timer) if timer else \
-            step_fn(model, dec_opt, rays_o, rays_d, target, S, step0 + args.warmup + i)
+        mi, oi = models[i % ntile], dec_opts[i % ntile]
+        step_fn(mi, oi, rays_o, rays_d, target, S, step0 + args.warmup + i, timer=timer) if timer else \
+            step_fn(mi, oi, rays_o, rays_d, target, S, step0 + args.warmup + i)
         if (i + 1) % SYN_ITERS == 0:
             admm.exchange(se3)
     sync()
@@ -284,7 +293,7 @@ def main():
                                     f"configs[1]: single 8m^3 tile per GPU, L=16 T=2^{args.log2_T} fp32 hash grid, 2-hidden x 64 "
                                     f"decoder, {B} rays x {S} samples, full training iteration "
                                     f"(sample+encode+decode+composite fwd, bwd, sparse Adam); foreground branch"),
-                       "path": path, "rays_per_step": B, "valid_ray_fraction": valid_frac, "samples": S, "tiles_per_gpu": 1,
+                       "path": path, "rays_per_step": B, "valid_ray_fraction": valid_frac, "samples": S, "tiles_per_gpu": ntile,
                        "parallelism": f"tile-per-gpu x{world}", "syn_iters": SYN_ITERS},
             "consensus_ms": consensus_ms,
             "consensus_frac_of_iteration": consensus_ms / (SYN_ITERS * ms_per_step),
