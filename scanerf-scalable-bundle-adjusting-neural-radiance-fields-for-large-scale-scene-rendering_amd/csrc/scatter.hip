@@ -30,16 +30,16 @@ namespace {
 
 constexpr int kThreads = 256;
 constexpr int kRun = 8;  // consecutive points per lane in the stand-alone count / scatter walks
-// i over [lo, hi): thread t takes points lo + (j*kThreads + t)*kRun + k, k < kRun
+// i over [lo, hi): thread t takes points lo + (j*blockDim.x + t)*kRun + k, k < kRun
 #define SCANERF_RUN_WALK(i, lo, hi)                                                     \
-    for (int c_ = (lo) + threadIdx.x * kRun; c_ < (hi); c_ += kThreads * kRun)          \
+    for (int c_ = (lo) + threadIdx.x * kRun; c_ < (hi); c_ += (int)blockDim.x * kRun)    \
         for (int i = c_; i < c_ + kRun && i < (hi); ++i)
 
 // ---- pass 1: count ---------------------------------------------------------------------
 // PER_LEVEL: the LDS holds one level's NB counters at a time (large tables: L*NB counters do not fit); the points are
 // walked once per level (re-read from L2).
 template <bool PER_LEVEL>
-__global__ void __launch_bounds__(kThreads) k_bin_count(const float *__restrict__ points,
+__global__ void __launch_bounds__(1024) k_bin_count(const float *__restrict__ points,
                                                         const int32_t *__restrict__ resolutions, BinGeom g,
                                                         uint32_t *__restrict__ counts, uint32_t *__restrict__ maxbits)
 {
@@ -49,7 +49,7 @@ __global__ void __launch_bounds__(kThreads) k_bin_count(const float *__restrict_
         const uint32_t mask = (uint32_t)g.T - 1u;
         const int lo = blockIdx.x * g.per_wg, hi = min(g.N, lo + g.per_wg);
         for (int l = 0; l < g.L; ++l) {
-            for (int i = threadIdx.x; i < g.NB; i += kThreads) hist[i] = 0;
+            for (int i = threadIdx.x; i < g.NB; i += (int)blockDim.x) hist[i] = 0;
             __syncthreads();
             SCANERF_RUN_WALK(i, lo, hi) {
                 const float p[3] = { points[3 * i], points[3 * i + 1], points[3 * i + 2] };
@@ -58,13 +58,13 @@ __global__ void __launch_bounds__(kThreads) k_bin_count(const float *__restrict_
                 count_pairs(pr, hist, g.bucket_log);
             }
             __syncthreads();
-            for (int i = threadIdx.x; i < g.NB; i += kThreads) counts[((size_t)l * g.NB + i) * g.W + blockIdx.x] = hist[i];
+            for (int i = threadIdx.x; i < g.NB; i += (int)blockDim.x) counts[((size_t)l * g.NB + i) * g.W + blockIdx.x] = hist[i];
             __syncthreads();
         }
         return;
     }
     const int nbins = g.L * g.NB;
-    for (int i = threadIdx.x; i < nbins; i += kThreads) hist[i] = 0;
+    for (int i = threadIdx.x; i < nbins; i += (int)blockDim.x) hist[i] = 0;
     __syncthreads();
     const uint32_t mask = (uint32_t)g.T - 1u;
     const int lo = blockIdx.x * g.per_wg, hi = min(g.N, lo + g.per_wg);
@@ -80,7 +80,7 @@ __global__ void __launch_bounds__(kThreads) k_bin_count(const float *__restrict_
         }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < nbins; i += kThreads) counts[(size_t)i * g.W + blockIdx.x] = hist[i];
+    for (int i = threadIdx.x; i < nbins; i += (int)blockDim.x) counts[(size_t)i * g.W + blockIdx.x] = hist[i];
 }
 
 // ---- scan: counts[bin][wg] -> in-row exclusive prefix (in place) + bin totals ------------
@@ -139,7 +139,7 @@ __global__ void __launch_bounds__(1024) k_bin_starts(const uint32_t *__restrict_
 // ---- pass 2: scatter records ---------------------------------------------------------------
 // LEVEL_MAJOR_GRAD: grad_in is [L][N][2] (two-kernel render path) instead of [N][L][2].
 template <bool LEVEL_MAJOR_GRAD, bool PER_LEVEL = false>
-__global__ void __launch_bounds__(kThreads) k_bin_scatter(const float *__restrict__ points,
+__global__ void __launch_bounds__(1024) k_bin_scatter(const float *__restrict__ points,
                                                           const float2 *__restrict__ grad_in,
                                                           const int32_t *__restrict__ resolutions, BinGeom g,
                                                           const uint32_t *__restrict__ rowprefix,
@@ -151,7 +151,7 @@ __global__ void __launch_bounds__(kThreads) k_bin_scatter(const float *__restric
     float gmax = 0.0f;
     const int nbins = g.L * g.NB;
     if (!PER_LEVEL) {
-        for (int i = threadIdx.x; i < nbins; i += kThreads)
+        for (int i = threadIdx.x; i < nbins; i += (int)blockDim.x)
             cursor[i] = starts[i] + rowprefix[(size_t)i * g.W + blockIdx.x];
         __syncthreads();
     }
@@ -168,12 +168,12 @@ __global__ void __launch_bounds__(kThreads) k_bin_scatter(const float *__restric
     };
     if (PER_LEVEL) {
         for (int l = 0; l < g.L; ++l) {
-            for (int i = threadIdx.x; i < g.NB; i += kThreads) {
+            for (int i = threadIdx.x; i < g.NB; i += (int)blockDim.x) {
                 const int bin = l * g.NB + i;
                 cursor[i] = starts[bin] + rowprefix[(size_t)bin * g.W + blockIdx.x];
             }
             __syncthreads();
-            for (int i = lo + threadIdx.x; i < hi; i += kThreads) {
+            for (int i = lo + threadIdx.x; i < hi; i += (int)blockDim.x) {
                 const float p[3] = { points[3 * i], points[3 * i + 1], points[3 * i + 2] };
                 one(i, l, p);
             }
@@ -186,12 +186,12 @@ __global__ void __launch_bounds__(kThreads) k_bin_scatter(const float *__restric
         // (lane-interleaved on purpose: with lane-owned runs as in k_bin_count the cursor conflicts go away but the 8-byte
         // gradient and 12-byte point loads and the record stores lose their coalescing -- measured 4.7 -> 7.6 ms)
         for (int l = 0; l < g.L; ++l)
-            for (int i = lo + threadIdx.x; i < hi; i += kThreads) {
+            for (int i = lo + threadIdx.x; i < hi; i += (int)blockDim.x) {
                 const float p[3] = { points[3 * i], points[3 * i + 1], points[3 * i + 2] };
                 one(i, l, p);
             }
     } else {
-        for (int i = lo + threadIdx.x; i < hi; i += kThreads) {
+        for (int i = lo + threadIdx.x; i < hi; i += (int)blockDim.x) {
             const float p[3] = { points[3 * i], points[3 * i + 1], points[3 * i + 2] };
             for (int l = 0; l < g.L; ++l) one(i, l, p);
         }
@@ -423,16 +423,16 @@ SCANERF_API int scanerf_embedding_bg_backward_binned(const float *points, const 
     const size_t lds_bins = per_level ? (size_t)g.NB * 4 : (size_t)nbins * 4;
     const float2 *gi = reinterpret_cast<const float2 *>(grad_in);
     if (per_level)
-        hipLaunchKernelGGL((k_bin_count<true>), dim3(g.W), dim3(kThreads), lds_bins, st, points, resolutions, g, counts, maxbits);
+        hipLaunchKernelGGL((k_bin_count<true>), dim3(g.W), dim3(1024), lds_bins, st, points, resolutions, g, counts, maxbits);
     else
         hipLaunchKernelGGL((k_bin_count<false>), dim3(g.W), dim3(kThreads), lds_bins, st, points, resolutions, g, counts, maxbits);
     hipLaunchKernelGGL(k_bin_rowscan, dim3(nbins), dim3(kThreads), 0, st, counts, totals, g.W);
     hipLaunchKernelGGL(k_bin_starts, dim3(1), dim3(1024), 0, st, totals, starts, nbins);
     if (per_level && grad_layout == 0)
-        hipLaunchKernelGGL((k_bin_scatter<false, true>), dim3(g.W), dim3(kThreads), lds_bins, st, points, gi, resolutions, g,
+        hipLaunchKernelGGL((k_bin_scatter<false, true>), dim3(g.W), dim3(1024), lds_bins, st, points, gi, resolutions, g,
                            counts, starts, recs, grad_features, maxbits);
     else if (per_level)
-        hipLaunchKernelGGL((k_bin_scatter<true, true>), dim3(g.W), dim3(kThreads), lds_bins, st, points, gi, resolutions, g,
+        hipLaunchKernelGGL((k_bin_scatter<true, true>), dim3(g.W), dim3(1024), lds_bins, st, points, gi, resolutions, g,
                            counts, starts, recs, grad_features, maxbits);
     else if (grad_layout == 0)
         hipLaunchKernelGGL((k_bin_scatter<false>), dim3(g.W), dim3(kThreads), lds_bins, st, points, gi, resolutions, g,
