@@ -145,11 +145,11 @@ def bench_render(args, world, rank, dev):
 
     from scanerf_amd import renderer as R
     from scanerf_amd import tile_model as tm
-    H, W, ntile = 1080, 1920, 4
+    H, W, ntile = 1080, 1920, (args.tiles_per_gpu if args.tiles_per_gpu > 1 else 4)
     tiles = []
     with tempfile.TemporaryDirectory() as tmp:
         for t in range(ntile):
-            m = tm.TileModel([-16.0 + 8.0 * t, -4, -4], [8, 8, 8], dev, log2_T=args.log2_T, seed=rank * ntile + t, sampler_log2dim=7)
+            m = tm.TileModel([-4.0 * ntile + 8.0 * t, -4, -4], [8, 8, 8], dev, log2_T=args.log2_T, seed=rank * ntile + t, sampler_log2dim=7)
             m.set_occupancy(tm.sphere_shell_occupancy(m, 3.0, 0.5))
             with torch.no_grad():
                 m.features.mul_(300.0)  # xavier std of a 2^19-entry table gives sigma ~ softplus(0): make the shell visible

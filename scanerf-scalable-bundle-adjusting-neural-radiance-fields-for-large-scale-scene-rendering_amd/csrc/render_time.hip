@@ -331,11 +331,33 @@ __global__ void __launch_bounds__(256, 2) k_pts_inference_tile(InferArgs a, int 
         cb[c] = a.t.corners[3 * b + c];
         sb[c] = a.t.sizes[3 * b + c];
     }
-    for (int64_t base = ((int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 32; base < total; base += nwaves * 32) {
+    // does the sample at e list tile b?  One small load per lane; the walk below issues kScan of them at once, because most
+    // groups of a pass do not touch the pass's tile and a load -> decide -> next chain is pure latency (2 ms per empty pass)
+    auto lists_tile = [&](int64_t e) {
+        if (e >= total) return false;
+        const uint32_t e32 = (uint32_t)e;
+        if (BG) return a.block_idxs[(e32 / (uint32_t)a.S) * kMaxPtsBlocks + a.step] == b;
+        const uint2 raw = *reinterpret_cast<const uint2 *>(a.block_idxs + (size_t)e32 * kMaxPtsBlocks);
+        const int s0 = (int16_t)(raw.x & 0xffffu), s1 = (int16_t)(raw.x >> 16), s2 = (int16_t)(raw.y & 0xffffu), s3 = (int16_t)(raw.y >> 16);
+        return s0 == b || (s0 != -1 && (s1 == b || (s1 != -1 && (s2 == b || (s2 != -1 && s3 == b)))));
+    };
+    const int64_t stride = nwaves * 32;
+    constexpr int kScan = 16;  // slot loads in flight per lane: at 8 waves per CU four of them stream at only ~1 TB/s
+    for (int64_t base0 = ((int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 32; base0 < total; base0 += kScan * stride) {
+        uint32_t hits = 0;
+#pragma unroll
+        for (int u = 0; u < kScan; ++u) hits |= (uint32_t)lists_tile(base0 + u * stride + sl) << u;
+        if (!__any(hits != 0u)) continue;
+#pragma unroll 1
+      for (int u = 0; u < kScan; ++u) {
+        if (!__any((hits >> u) & 1u)) continue;
+        const int64_t base = base0 + u * stride;
         const int64_t e = base + sl;
         const bool in_range = e < total;
         const int64_t ec = in_range ? e : total - 1;
-        const int i = (int)(ec / a.S), s = (int)(ec % a.S);
+        // (32-bit division: the host keeps B*S below 2^31 for this kernel)
+        const uint32_t ec32 = (uint32_t)ec, S32 = (uint32_t)a.S;
+        const int i = (int)(ec32 / S32), s = (int)(ec32 - (uint32_t)i * S32);
         // does this sample list tile b?  (fg: the slot list stops at the first -1, rendering_kernel.cu:499)
         int16_t slot[kMaxPtsBlocks] = { -1, -1, -1, -1 };
         bool mine = false;
@@ -433,14 +455,15 @@ __global__ void __launch_bounds__(256, 2) k_pts_inference_tile(InferArgs a, int 
                 }
             }
         }
+      }
     }
 }
 
 // f32-MFMA single-pass kernel instead of the per-tile passes (SCANERF_RENDER_ARITH=f32; comparison / debugging)
-inline bool render_single_pass()
+inline bool render_single_pass(int64_t total)
 {
     const char *e = getenv("SCANERF_RENDER_ARITH");
-    return e && e[0] == 'f';
+    return (e && e[0] == 'f') || total >= ((int64_t)1 << 31);  // the per-tile kernel indexes samples in 32 bits
 }
 
 // ---- rendering_kernel.cu:624-702: front-to-back accumulation, one wave per ray ------------------------
@@ -763,7 +786,7 @@ SCANERF_API int scanerf_pts_inference(const float *rays_o, const float *rays_d, 
     a.out_dif = out_dif; a.out_spec = out_spec; a.out_alpha = out_alpha; a.T = T; a.B = B; a.S = S; a.step = 0;
     const int64_t tiles32 = ((int64_t)B * S + 31) / 32;
     int blocks = (int)((tiles32 + 3) / 4 < kNumCU * 4 ? (tiles32 + 3) / 4 : kNumCU * 4);
-    if (render_single_pass()) {
+    if (render_single_pass((int64_t)B * S)) {
         hipLaunchKernelGGL((k_pts_inference<false>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
         return check_launch("pts_inference");
     }
@@ -795,7 +818,7 @@ SCANERF_API int scanerf_bg_pts_inference_v2(const float *rays_o, const float *ra
     a.out_dif = out_dif; a.out_spec = out_spec; a.out_alpha = out_alpha; a.T = T; a.B = B; a.S = S; a.step = step;
     const int64_t tiles32 = ((int64_t)B * S + 31) / 32;
     int blocks = (int)((tiles32 + 3) / 4 < kNumCU * 4 ? (tiles32 + 3) / 4 : kNumCU * 4);
-    if (render_single_pass()) {
+    if (render_single_pass((int64_t)B * S)) {
         hipLaunchKernelGGL((k_pts_inference<true>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
         return check_launch("bg_pts_inference_v2");
     }
