@@ -10,9 +10,9 @@
 //
 // pts_inference / bg_pts_inference_v2 are the render hot loop.  The reference runs the whole
 // 13 994-MAC decoder serially in one thread per sample, weights from global memory.  Here a wave
-// takes 32 consecutive samples and runs the decoder on the matrix cores.  Default: one pass per
-// tile with that tile's split-f16 decoder image staged in LDS (k_pts_inference_tile: 2.4e9
-// samples/s, the rate of the training forward -- table gathers bound it).  Kept for comparison
+// takes 32 consecutive samples and runs the decoder on the matrix cores.  Default: chunk-major
+// with the split-f16 decoder image of each tile a chunk touches staged in LDS
+// (k_pts_inference_chunks: the rate of the training forward -- table gathers bound it).  Kept for comparison
 // (SCANERF_RENDER_ARITH=f32): a single pass on the fp32 matrix pipe that reads the packed image of
 // whichever tile the samples reference through L2 and loops over the distinct tiles of a wave
 // (1.5e9 samples/s).
@@ -305,57 +305,89 @@ __global__ void __launch_bounds__(256, 2) k_pts_inference(InferArgs a)
     }
 }
 
-// ---- pts_inference / bg_pts_inference_v2, one pass per tile (default) ---------------------------------------------------
+// ---- pts_inference / bg_pts_inference_v2, chunk-major with the tile's decoder in LDS (default) ---------------------------
 // The kernel above reads every MFMA operand of whichever tile a sample references from global memory and multiplies on
-// the f32 matrix pipe (1.5e9 samples/s).  Here the launch is split into one pass per tile b: a workgroup stages tile b's
-// split-f16 decoder image (render_h3.h, the arithmetic of the training kernels; 70 KB) in LDS once and walks all 32-sample
-// groups, working only on the samples that list b.  A group none of whose samples lists b costs one 8-byte load per lane.
-// Samples in the overlap of several tiles are blended across passes: each pass adds w_b * pa * colour / sum_k w_k into the
-// (zero-filled) outputs; passes are separate launches on one stream, so the read-modify-write is race-free and ordered.
+// the f32 matrix pipe (1.5e9 samples/s).  Here a workgroup takes a chunk of 64 consecutive 32-sample groups (16 rays at
+// 128 samples), finds the set of tiles its samples list (one 8-byte slot load per lane and group), and for each tile of the
+// set in ascending order stages that tile's split-f16 decoder image (render_h3.h, the arithmetic of the training kernels;
+// 70 KB, from L2) in LDS and runs the groups that list it.  Neighbouring rays see the same one or two tiles, so a chunk
+// stages one or two images for 2048 samples; the cost does not grow with the number of tiles of the scene (a first version
+// made one launch per tile: every pass re-read all slot lists, ~1 ms per tile the view does not even see).  Samples in
+// the overlap of several tiles are blended across the chunk's tile steps: each adds w_b * pa * colour / sum_k w_k into the
+// (zero-filled) outputs; a sample belongs to one workgroup and the steps are sequential, so the read-modify-write is
+// race-free and its order (ascending tile index) is fixed.
 template <bool BG>
-__global__ void __launch_bounds__(256, 2) k_pts_inference_tile(InferArgs a, int b)
+__global__ void __launch_bounds__(256, 2) k_pts_inference_chunks(InferArgs a)
 {
     __shared__ __attribute__((aligned(16))) char lds[H3_BYTES];
-    {
-        const float4 *src = reinterpret_cast<const float4 *>(a.images + (size_t)b * WS_FLOATS + PK_TOTAL);
-        float4 *dst = reinterpret_cast<float4 *>(lds);
-        for (int i = threadIdx.x; i < H3_BYTES / 16; i += 256) dst[i] = src[i];
-    }
-    __syncthreads();
-    const int lane = threadIdx.x & 63, sl = lane & 31, h = lane >> 5;
+    __shared__ uint32_t tileset[2];
+    const int lane = threadIdx.x & 63, sl = lane & 31, h = lane >> 5, wave = threadIdx.x >> 6;
     const int64_t total = (int64_t)a.B * a.S;
-    const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x >> 6);
-    float cb[3], sb[3];
+    constexpr int kWaveGroups = 16, kChunkGroups = 4 * kWaveGroups;
+    const int64_t ngroups = (total + 31) / 32, nchunks = (ngroups + kChunkGroups - 1) / kChunkGroups;
+    for (int64_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+        if (threadIdx.x < 2) tileset[threadIdx.x] = 0;
+        __syncthreads();  // (also: the previous chunk's last tile step is complete)
+        const int64_t wbase = (chunk * kChunkGroups + (int64_t)wave * kWaveGroups) * 32;
+        {   // 1. the tiles this chunk's samples list: all slot loads of the wave in flight together
+            uint32_t mlo = 0, mhi = 0;
+            auto mark = [&](int t) {
+                if (t >= 0) {
+                    if (t < 32) mlo |= 1u << t;
+                    else mhi |= 1u << (t - 32);
+                }
+            };
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        cb[c] = a.t.corners[3 * b + c];
-        sb[c] = a.t.sizes[3 * b + c];
-    }
-    // does the sample at e list tile b?  One small load per lane; the walk below issues kScan of them at once, because most
-    // groups of a pass do not touch the pass's tile and a load -> decide -> next chain is pure latency (2 ms per empty pass)
-    auto lists_tile = [&](int64_t e) {
-        if (e >= total) return false;
-        const uint32_t e32 = (uint32_t)e;
-        if (BG) return a.block_idxs[(e32 / (uint32_t)a.S) * kMaxPtsBlocks + a.step] == b;
-        const uint2 raw = *reinterpret_cast<const uint2 *>(a.block_idxs + (size_t)e32 * kMaxPtsBlocks);
-        const int s0 = (int16_t)(raw.x & 0xffffu), s1 = (int16_t)(raw.x >> 16), s2 = (int16_t)(raw.y & 0xffffu), s3 = (int16_t)(raw.y >> 16);
-        return s0 == b || (s0 != -1 && (s1 == b || (s1 != -1 && (s2 == b || (s2 != -1 && s3 == b)))));
-    };
-    const int64_t stride = nwaves * 32;
-    constexpr int kScan = 16;  // slot loads in flight per lane: at 8 waves per CU four of them stream at only ~1 TB/s
-    for (int64_t base0 = ((int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 32; base0 < total; base0 += kScan * stride) {
-        uint32_t hits = 0;
+            for (int g = 0; g < kWaveGroups; ++g) {
+                const int64_t e = wbase + g * 32 + sl;
+                if (e >= total || h != 0) continue;
+                const uint32_t e32 = (uint32_t)e;
+                if (BG) {
+                    mark(a.block_idxs[(e32 / (uint32_t)a.S) * kMaxPtsBlocks + a.step]);
+                } else {
+                    const uint2 raw = *reinterpret_cast<const uint2 *>(a.block_idxs + (size_t)e32 * kMaxPtsBlocks);
+                    const int s0 = (int16_t)(raw.x & 0xffffu), s1 = (int16_t)(raw.x >> 16), s2 = (int16_t)(raw.y & 0xffffu),
+                              s3 = (int16_t)(raw.y >> 16);
+                    mark(s0);  // the list stops at the first -1 (rendering_kernel.cu:499)
+                    if (s0 != -1) { mark(s1); if (s1 != -1) { mark(s2); if (s2 != -1) mark(s3); } }
+                }
+            }
 #pragma unroll
-        for (int u = 0; u < kScan; ++u) hits |= (uint32_t)lists_tile(base0 + u * stride + sl) << u;
-        if (!__any(hits != 0u)) continue;
+            for (int off = 32; off > 0; off >>= 1) {
+                mlo |= __shfl_xor(mlo, off, 64);
+                mhi |= __shfl_xor(mhi, off, 64);
+            }
+            if (lane == 0) {
+                if (mlo) atomicOr(&tileset[0], mlo);
+                if (mhi) atomicOr(&tileset[1], mhi);
+            }
+        }
+        __syncthreads();
+        uint64_t todo = (uint64_t)tileset[0] | ((uint64_t)tileset[1] << 32);
+      while (todo) {  // 2. one step per listed tile, ascending
+        const int b = __ffsll((long long)todo) - 1;
+        todo &= todo - 1;
+        __syncthreads();  // every wave is done with the previous image
+        {
+            const float4 *src = reinterpret_cast<const float4 *>(a.images + (size_t)b * WS_FLOATS + PK_TOTAL);
+            float4 *dst = reinterpret_cast<float4 *>(lds);
+            for (int i = threadIdx.x; i < H3_BYTES / 16; i += 256) dst[i] = src[i];
+        }
+        __syncthreads();
+        float cb[3], sb[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            cb[c] = a.t.corners[3 * b + c];
+            sb[c] = a.t.sizes[3 * b + c];
+        }
 #pragma unroll 1
-      for (int u = 0; u < kScan; ++u) {
-        if (!__any((hits >> u) & 1u)) continue;
-        const int64_t base = base0 + u * stride;
+      for (int g = 0; g < kWaveGroups; ++g) {
+        const int64_t base = wbase + g * 32;
+        if (base >= total) break;
         const int64_t e = base + sl;
         const bool in_range = e < total;
         const int64_t ec = in_range ? e : total - 1;
-        // (32-bit division: the host keeps B*S below 2^31 for this kernel)
+        // (32-bit division: the host keeps B*S below 2^31 for this kernel; a 64-bit one costs ~100 instructions per group)
         const uint32_t ec32 = (uint32_t)ec, S32 = (uint32_t)a.S;
         const int i = (int)(ec32 / S32), s = (int)(ec32 - (uint32_t)i * S32);
         // does this sample list tile b?  (fg: the slot list stops at the first -1, rendering_kernel.cu:499)
@@ -456,14 +488,16 @@ __global__ void __launch_bounds__(256, 2) k_pts_inference_tile(InferArgs a, int 
             }
         }
       }
+      }
     }
 }
 
-// f32-MFMA single-pass kernel instead of the per-tile passes (SCANERF_RENDER_ARITH=f32; comparison / debugging)
-inline bool render_single_pass(int64_t total)
+// f32-MFMA single-pass kernel instead of the chunk-major one (SCANERF_RENDER_ARITH=f32; comparison / debugging)
+inline bool render_single_pass(int64_t total, int nb)
 {
     const char *e = getenv("SCANERF_RENDER_ARITH");
-    return (e && e[0] == 'f') || total >= ((int64_t)1 << 31);  // the per-tile kernel indexes samples in 32 bits
+    // the chunk-major kernel indexes samples in 32 bits and keeps a chunk's tile set in 64 bits
+    return (e && e[0] == 'f') || total >= ((int64_t)1 << 31) || nb > 64;
 }
 
 // ---- rendering_kernel.cu:624-702: front-to-back accumulation, one wave per ray ------------------------
@@ -786,7 +820,7 @@ SCANERF_API int scanerf_pts_inference(const float *rays_o, const float *rays_d, 
     a.out_dif = out_dif; a.out_spec = out_spec; a.out_alpha = out_alpha; a.T = T; a.B = B; a.S = S; a.step = 0;
     const int64_t tiles32 = ((int64_t)B * S + 31) / 32;
     int blocks = (int)((tiles32 + 3) / 4 < kNumCU * 4 ? (tiles32 + 3) / 4 : kNumCU * 4);
-    if (render_single_pass((int64_t)B * S)) {
+    if (render_single_pass((int64_t)B * S, nb)) {
         hipLaunchKernelGGL((k_pts_inference<false>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
         return check_launch("pts_inference");
     }
@@ -795,9 +829,9 @@ SCANERF_API int scanerf_pts_inference(const float *rays_o, const float *rays_d, 
     const hipError_t ce[3] = { hipMemsetAsync(out_dif, 0, n * 12, (hipStream_t)stream), hipMemsetAsync(out_spec, 0, n * 12, (hipStream_t)stream),
                                hipMemsetAsync(out_alpha, 0, n * 4, (hipStream_t)stream) };
     for (hipError_t e : ce) SCANERF_REQUIRE(e == hipSuccess, "pts_inference: clearing the outputs failed: %s", hipGetErrorString(e));
-    blocks = (int)((tiles32 + 3) / 4 < kNumCU * 8 ? (tiles32 + 3) / 4 : kNumCU * 8);
-    for (int b = 0; b < nb; ++b)
-        hipLaunchKernelGGL((k_pts_inference_tile<false>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, a, b);
+    const int64_t nchunks = (tiles32 + 63) / 64;
+    blocks = (int)(nchunks < kNumCU * 8 ? nchunks : kNumCU * 8);
+    hipLaunchKernelGGL((k_pts_inference_chunks<false>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
     return check_launch("pts_inference");
 }
 
@@ -818,13 +852,13 @@ SCANERF_API int scanerf_bg_pts_inference_v2(const float *rays_o, const float *ra
     a.out_dif = out_dif; a.out_spec = out_spec; a.out_alpha = out_alpha; a.T = T; a.B = B; a.S = S; a.step = step;
     const int64_t tiles32 = ((int64_t)B * S + 31) / 32;
     int blocks = (int)((tiles32 + 3) / 4 < kNumCU * 4 ? (tiles32 + 3) / 4 : kNumCU * 4);
-    if (render_single_pass((int64_t)B * S)) {
+    if (render_single_pass((int64_t)B * S, nb)) {
         hipLaunchKernelGGL((k_pts_inference<true>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
         return check_launch("bg_pts_inference_v2");
     }
-    blocks = (int)((tiles32 + 3) / 4 < kNumCU * 8 ? (tiles32 + 3) / 4 : kNumCU * 8);
-    for (int b = 0; b < nb; ++b)
-        hipLaunchKernelGGL((k_pts_inference_tile<true>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, a, b);
+    const int64_t nchunks = (tiles32 + 63) / 64;
+    blocks = (int)(nchunks < kNumCU * 8 ? nchunks : kNumCU * 8);
+    hipLaunchKernelGGL((k_pts_inference_chunks<true>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
     return check_launch("bg_pts_inference_v2");
 }
 
