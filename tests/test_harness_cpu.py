@@ -221,3 +221,23 @@ def test_camera_algebra_matches_reference_golden_g7(golden):
     np.testing.assert_allclose(CM.se3_to_SE3(torch.zeros(2, 6)).numpy(), np.tile(np.eye(3, 4, dtype=np.float32), (2, 1, 1)))
     locs = CM.pixel_locs(3, torch.tensor([0, 9, 17]), 8, "cpu")
     assert locs.dtype == torch.int32 and locs.tolist()[:4] == [[0, 0, 0], [0, 1, 1], [0, 1, 2], [1, 0, 0]]
+
+
+def test_metrics_match_reference_golden_g11(golden, tmp_path):
+    """metrics.ssim / psnr against the reference's tools/ssim.py and tools/utils.py (golden G11); evaluation log layout."""
+    import scanerf_amd  # noqa
+    from scanerf_amd import metrics as M
+    g = golden("g11_ssim")
+    a, b, sm = (torch.from_numpy(g[k]) for k in ("a", "b", "smooth"))
+    np.testing.assert_allclose(float(M.ssim(a, b)), float(g["ssim_ab"]), rtol=2e-5)
+    np.testing.assert_allclose(float(M.ssim(a, a)), 1.0, rtol=1e-6)
+    np.testing.assert_allclose(float(M.ssim(a, sm)), float(g["ssim_asmooth"]), rtol=1e-4)
+    np.testing.assert_allclose(M.ssim(a, b, size_average=False).numpy(), g["ssim_ab_per_image"], rtol=2e-5)
+    np.testing.assert_allclose(M.psnr(a[0].permute(1, 2, 0) * 255.0, b[0].permute(1, 2, 0) * 255.0), float(g["psnr_ab0"]), rtol=1e-6)
+    views = [(None, None, (a[i].permute(1, 2, 0) * 255.0)) for i in range(2)]
+    order = iter(range(2))
+    mp, ms, rows = M.evaluate_views(lambda H, W, K, c2w: b[next(order)].permute(1, 2, 0), views, tmp_path / "eval.txt")
+    txt = open(tmp_path / "eval.txt").read().split("\n")
+    assert txt[0].startswith("img 0 psnr ") and "\tssim " in txt[0] and txt[2].startswith("mean psnr ")
+    np.testing.assert_allclose(rows[0][1], float(g["psnr_ab0"]), rtol=1e-5)
+    np.testing.assert_allclose(ms, float(g["ssim_ab"]), rtol=1e-3)
