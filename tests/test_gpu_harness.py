@@ -318,3 +318,19 @@ def test_end_to_end_learning_on_procedural_scene():
     spec.loader.exec_module(demo)
     p0, p1, losses = demo.run(steps=150, rays=8192, log2_T=16, samples=64, dev=DEV, verbose=False)
     assert np.isfinite(losses).all() and p1 > p0 + 12.0 and p1 > 18.0, (p0, p1)
+
+
+def test_train_export_render_pipeline_consistent():
+    """f1 -> f3 -> f2: a tile trained on the procedural scene, exported (f16 table, decoder.pth) and rendered through the
+    multi-tile render-time path gives the same novel view as the training-time renderer (PSNR > 45 dB, SSIM > 0.99)."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("train_demo", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                                                              "tools", "train_demo.py"))
+    demo = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(demo)
+    p0, p1, losses, model = demo.run(steps=200, rays=8192, log2_T=16, samples=64, dev=DEV, verbose=False, return_model=True)
+    # step >= 10 000: the coarse-to-fine mask of the training renderer is all ones, as the render-time decoder assumes
+    r = demo.novel_view_check(model, H=60, W=80, samples=64, step=40000, dev=DEV)
+    assert r["psnr_render_vs_train"] > 45.0 and r["ssim_render_vs_train"] > 0.99, r
+    assert r["psnr_render_vs_gt"] > 15.0 and abs(r["psnr_render_vs_gt"] - r["psnr_train_vs_gt"]) < 1.0, r

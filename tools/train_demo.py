@@ -39,7 +39,7 @@ def psnr(a, b):
     return 10.0 * math.log10(255.0 ** 2 / (mse + 1e-8))
 
 
-def run(steps=400, rays=16384, log2_T=19, samples=128, dev="cuda:0", verbose=True):
+def run(steps=400, rays=16384, log2_T=19, samples=128, dev="cuda:0", verbose=True, return_model=False):
     import scanerf_amd  # noqa: F401
     from scanerf_amd import trainer
     from scanerf_amd.tile_model import TileModel
@@ -72,7 +72,35 @@ def run(steps=400, rays=16384, log2_T=19, samples=128, dev="cuda:0", verbose=Tru
               f"held-out PSNR {p0:.2f} -> {p1:.2f} dB, loss {losses[0]:.4f} -> {losses[-1]:.4f}, "
               f"{dt / steps * 1e3:.2f} ms/step ({rays * steps / dt:.3e} rays/s incl. ray generation), "
               f"occupied cells {int(model.occupied_grid.sum())}/{model.occupied_grid.numel()} at log2dim {model.log2dim.tolist()}")
-    return p0, p1, losses
+    return (p0, p1, losses, model) if return_model else (p0, p1, losses)
+
+
+def novel_view_check(model, H=120, W=160, samples=128, step=40000, dev="cuda:0"):
+    """Train-time renderer vs export -> multi-tile render-time renderer on one novel view of the trained tile, and both
+    against the procedural ground truth: -> dict of PSNR / SSIM figures."""
+    import tempfile
+
+    from scanerf_amd import cameras as CM
+    from scanerf_amd import metrics as MT
+    from scanerf_amd import renderer as R
+    c2w = torch.tensor([[1.0, 0, 0, 0.3], [0, 1, 0, -0.2], [0, 0, 1, -3.7]])
+    K = torch.tensor([[110.0, 0, W / 2], [0, 110.0, H / 2], [0, 0, 1]])
+    cams = CM.CameraSet(K[None], c2w[None], dev)
+    locs = CM.pixel_locs(1, torch.arange(H * W), W, dev)
+    with torch.no_grad():
+        o, d = cams.get_rays(locs)
+    gt = sphere_scene(o, d).reshape(H, W, 3)
+    with torch.no_grad():
+        train_img = model.render_rays_fused(o.contiguous(), d.contiguous(), samples, samples, step)["pred_color"].reshape(H, W, 3).clamp(0, 1)
+    with tempfile.TemporaryDirectory() as tmp:
+        R.export_tile(os.path.join(tmp, "tile-0"), model)
+        rend = R.TileSetRenderer(dev, [R.load_tile(os.path.join(tmp, "tile-0"))])
+    dif, spec, depth, transp = rend.render(H, W, K.reshape(-1).tolist(), c2w, num_sample=samples, num_bg_sample=samples)
+    rt_img = (dif + spec).clamp(0, 1)
+    nchw = lambda im: im[None].permute(0, 3, 1, 2)
+    return {"psnr_train_vs_gt": MT.psnr(train_img * 255, gt * 255), "psnr_render_vs_gt": MT.psnr(rt_img * 255, gt * 255),
+            "psnr_render_vs_train": MT.psnr(rt_img * 255, train_img * 255), "ssim_render_vs_gt": float(MT.ssim(nchw(rt_img), nchw(gt))),
+            "ssim_render_vs_train": float(MT.ssim(nchw(rt_img), nchw(train_img)))}
 
 
 if __name__ == "__main__":
@@ -80,5 +108,8 @@ if __name__ == "__main__":
     ap.add_argument("--steps", type=int, default=400)
     ap.add_argument("--rays", type=int, default=16384)
     ap.add_argument("--log2-T", type=int, default=19)
+    ap.add_argument("--render", action="store_true", help="also export the tile and render a novel view through the render-time path")
     a = ap.parse_args()
-    run(a.steps, a.rays, a.log2_T)
+    res = run(a.steps, a.rays, a.log2_T, return_model=a.render)
+    if a.render:
+        print("novel view 160x120:", {k: round(v, 3) for k, v in novel_view_check(res[3], step=max(a.steps, 10000)).items()})
