@@ -72,7 +72,7 @@ __device__ __forceinline__ HL2 split16(const v16f &v)
 // ---- operand hazard.
 // Measured on MI355X (ROCm 7.2 hipcc): with the f16 MFMAs scheduled freely among the VALU code that produces their
 // B operands, about 3e-4 of the 32-sample tiles came out wrong in lanes 16-31, differently on every launch
-// (tools/h3_debug.py: ~10 wrong tiles per 16 384).  The listing shows the hazard recogniser leaving two wait states
+// (tests/debug/h3_debug.py: ~10 wrong tiles per 16 384).  The listing shows the hazard recogniser leaving two wait states
 // between the last v_cvt_pk_f16_f32 of an operand and the MFMA that reads it; that is not enough for this producer.
 // Every VALU-made operand therefore passes through a guard where it is produced (split8: two more wait states, and
 // the MFMAs depend on the guard's outputs): 0 wrong tiles in 393 216.  Operands that come from LDS (weights,

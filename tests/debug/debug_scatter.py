@@ -1,6 +1,6 @@
 import ctypes, os, sys
 import numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))  # repo root
 import scanerf_amd
 from oracle import oracle as O
 from scanerf_amd._capi import check, lib, stream, workspace

@@ -1,11 +1,11 @@
 """Compare the two decoder arithmetics (f32 MFMA vs f16 split) of the fused forward; run h3 twice (determinism)."""
 import os, sys
 import numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))  # repo root
 import scanerf_amd
 from oracle import oracle as O
 from scanerf_amd import network, render
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))  # tests/
 from test_gpu_parity import _render_inputs, g, DEV
 
 junk = torch.randn(64 << 20, device=DEV)  # dirty the allocator's pool
