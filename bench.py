@@ -9,9 +9,15 @@ One "step" = one full training iteration of one tile on a synthetic ray batch
 0.01*l2_reg_specular -> backward -> fused sparse Adam on the table + Adam on the decoder.
 Inputs (rays, targets, parameters) are resident in HBM before the timed region.
 
-N > 1: one process per GPU (torchrun), one independent tile per rank (tiles shard one per GPU:
+N > 1: one process per GPU, one independent tile per rank (tiles shard one per GPU:
 admm_trainer.py:74-83) -> weak scaling, no data-path collective; the ADMM camera-consensus
 exchange (RCCL all-reduce) runs every SYN_ITERS=100 steps and is also timed on its own.
+Started under torchrun (RANK/WORLD_SIZE in the environment) this process IS one rank.  Started
+plainly with --gpus N > 1 it is the launcher: like the reference's admm_trainer.py:312-337 it spawns
+its own workers -- N child processes of this script, one per GPU, with RANK / LOCAL_RANK /
+WORLD_SIZE / MASTER_* set -- BEFORE anything touches the GPU, relays rank 0's JSON line and exits
+non-zero if any rank failed.  --dry-run-cpu runs the same launcher and collectives on gloo/CPU with
+no kernels (the CPU tests use it; its line says "dry_run": true and is not a measurement).
 
 Prints ONE JSON line on rank 0.
 """
@@ -45,6 +51,8 @@ def parse():
     ap.add_argument("--samples", type=int, default=128)
     ap.add_argument("--log2-T", type=int, default=19, help="hash-table entries per level (configs[1]: 19; the reference's default.yaml: 24)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dry-run-cpu", action="store_true",
+                    help="launcher / collective rehearsal on gloo + CPU tensors: no kernels, no measurement")
     ap.add_argument("--tiles-per-gpu", type=int, default=1,
                     help="tiles resident on each GPU and stepped round-robin (configs[4]: 32 tiles on 8 GPUs = 4; the reference "
                          "swaps them through host memory, tile.py:574-636 -- 288 GB of HBM keeps them resident)")
@@ -58,7 +66,67 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(samples, seconds_budget=15.0):
+def launch_ranks(args):
+    """--gpus N without a torchrun environment: this process only launches.  It never calls into torch.cuda (a process
+    that has initialised the GPU must not start others that share it by exec; children are plain subprocesses)."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out0, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    line = None
+    for ln in (out0 or "").splitlines():
+        if ln.startswith("{"):
+            line = ln
+        else:
+            print(ln, file=sys.stderr)
+    if any(codes) or line is None:
+        print(f"bench.py: ranks exited with {codes}" + ("" if line else "; rank 0 printed no JSON line"), file=sys.stderr)
+        sys.exit(next((c for c in codes if c), 1))
+    print(line)
+
+
+def dry_run_cpu(args, world, rank):
+    """The launcher's and the consensus exchange's rehearsal on gloo: same process-group bring-up, barrier, MAX-reduce of
+    the elapsed time and all-reduce consensus as the real run, CPU tensors, no kernels."""
+    from scanerf_amd import consensus as cons
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
+    n_cam_per, overlap = 120, 24
+    n_cam = (n_cam_per - overlap) * world + overlap
+    cam_idx = torch.arange(n_cam_per) + rank * (n_cam_per - overlap)
+    admm = cons.ConsensusState(n_cam, cam_idx, "cpu")
+    se3 = torch.randn(n_cam_per, 6) * 1e-3
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        admm.exchange(se3)
+    if world > 1:
+        dist.barrier()
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        print(json.dumps({"metric": "training rays/s per GPU (128 samples, L=16 hash)", "value": 0.0, "unit": "rays/s",
+                          "n_gpus": world, "rccl_world_size": dist.get_world_size() if world > 1 else 1, "dry_run": True,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": float(t.item()) / args.steps * 1e3,
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "none (dry run)",
+                          "data": "synthetic", "config": {"workload": "launcher + gloo consensus rehearsal, no kernels"}}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(samples):
     """The oracle (CPU port of the same training iteration) on this box's host cores, on a bounded
     sample of the workload.  Only this leg of bench.py touches oracle/."""
     import numpy as np
@@ -82,27 +150,41 @@ def cpu_baseline(samples, seconds_budget=15.0):
     m = np.zeros((16 * tile.T * 2 // 8, 8), np.float32)
     v = np.zeros_like(m)
 
-    def step(i):
+    def forward(i, grad):
         z, dd = O.sample_points_grid(o, d, tile.occ_corner, tile.occ_size, tile.occ, tile.log2dim, samples)
         valid = torch.from_numpy((z != -1).all(1))
-        out = O.render_batch_rays(torch.from_numpy(o)[valid], torch.from_numpy(d)[valid], torch.from_numpy(z)[valid],
-                                  torch.from_numpy(dd)[valid], feats, tile.res, sd, O.TRAIN,
-                                  lambda x: O.contract_fore(x, tile.min_bbox, tile.bbox_size), 1000 + i)
+        with torch.set_grad_enabled(grad):
+            out = O.render_batch_rays(torch.from_numpy(o)[valid], torch.from_numpy(d)[valid], torch.from_numpy(z)[valid],
+                                      torch.from_numpy(dd)[valid], feats, tile.res, sd, O.TRAIN if grad else O.INFERENCE,
+                                      lambda x: O.contract_fore(x, tile.min_bbox, tile.bbox_size), 1000 + i)
+        return out, valid
+
+    def step(i):
+        out, valid = forward(i, True)
         loss = torch.nn.functional.mse_loss(out["rgb"], tgt[valid]) + 0.01 * out["l2_reg_specular"]
         feats.grad = None
         loss.backward()
         p = feats.detach().numpy().reshape(-1, 8)
         O.adam_step(p, feats.grad.numpy().reshape(-1, 8), m, v, 1e-2, 0.9, 0.99, 1e-15, i)
 
-    step(0)
+    # 3 warm-up + 10 timed iterations, forward and forward+backward(+sparse Adam) separately
+    WARM, TIMED = 3, 10
+    for i in range(WARM):
+        step(i)
     t0 = time.time()
-    n = 0
-    while n < 2 or (time.time() - t0 < seconds_budget and n < 50):
-        step(n + 1)
-        n += 1
-    dt = (time.time() - t0) / n
-    return {"value": B / dt, "unit": "rays/s", "cores": cores, "kind": "port", "psnr_vs_oracle_db": psnr_vs_oracle(samples),
-            "sample": f"{n} training iterations of {B} rays x {samples} samples (same tile config, T=2^19), oracle/ on {cores} host threads"}
+    for i in range(TIMED):
+        step(WARM + i)
+    dt = (time.time() - t0) / TIMED
+    for i in range(WARM):
+        forward(i, False)
+    t0 = time.time()
+    for i in range(TIMED):
+        forward(i, False)
+    dt_fwd = (time.time() - t0) / TIMED
+    return {"value": B / dt, "unit": "rays/s", "cores": cores, "kind": "port", "forward_only_rays_per_s": B / dt_fwd,
+            "psnr_vs_oracle_db": psnr_vs_oracle(samples),
+            "sample": f"{WARM} warm-up + {TIMED} timed training iterations (forward + backward + sparse Adam; forward-only timed the "
+                      f"same way) of {B} rays x {samples} samples (same tile config, T=2^19), oracle/ on {cores} host threads"}
 
 
 def psnr_vs_oracle(samples, B=2048, log2_T=15):
@@ -192,9 +274,15 @@ def bench_render(args, world, rank, dev):
 
 def main():
     args = parse()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        return launch_ranks(args)  # the parent never touches the GPU
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and rank == 0:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: running {world} rank(s)", file=sys.stderr)
+    if args.dry_run_cpu:
+        return dry_run_cpu(args, world, rank)
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -278,15 +366,39 @@ def main():
     elapsed = float(t.item())
     ms_per_step = elapsed / args.steps * 1e3
 
+    # the same step with the exact-f32 decoder arithmetic (f32-input MFMA), timed the same way, printed beside the headline
+    from scanerf_amd import render as _render
+    h3_run = path == "fused" and _render.ARITH == 1
+    dtype_label = ("f32 tables/accumulate/compositing; decoder GEMMs split-f16 x3 MFMA, f32 accumulate (22-bit operands)"
+                   if h3_run else "f32")
+    if occ:
+        dtype_label = "bf16 gather table, fp32 master + accumulate; " + dtype_label
+    f32_ms = None
+    if h3_run and not occ:
+        _render.set_arith("f32")
+        try:
+            for i in range(2):
+                step_fn(models[i % ntile], dec_opts[i % ntile], rays_o, rays_d, target, S, step0 + i)
+            sync()
+            f0 = time.perf_counter()
+            for i in range(args.steps):
+                step_fn(models[i % ntile], dec_opts[i % ntile], rays_o, rays_d, target, S, step0 + i)
+            sync()
+            f32_ms = (time.perf_counter() - f0) / args.steps * 1e3
+        finally:
+            _render.set_arith("h3")
+
     with torch.no_grad():  # rays that meet no occupied cell are skipped by every kernel: they are not counted as work
         valid_frac = float((model.sample(rays_o, rays_d, S)[0] != -1).all(1).float().mean())
     if rank == 0:
         value = world * B * valid_frac * args.steps / elapsed
         line = {
             "metric": "training rays/s per GPU (128 samples, L=16 hash)",
-            "value": value, "value_is": "whole-job aggregate over n_gpus (one tile per GPU)", "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": value, "value_is": "whole-job aggregate over n_gpus (one tile per GPU)", "value_per_gpu": value / world,
+            "unit": "rays/s", "n_gpus": world, "rccl_world_size": dist.get_world_size() if world > 1 else 1,
+            "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": dtype_label, "data": "synthetic",
             "config": {"workload": (f"configs[2]: as configs[1] + sphere-shell occupancy (r=3 m, 0.5 m thick, log2dim 7, "
                                     f"{float(model.occupied_grid.float().mean()):.3f} of cells), bf16 gather table (fp32 master, fp32 accumulate), "
                                     f"fused sparse Adam; {B} rays x {S} samples" if occ else
@@ -295,6 +407,7 @@ def main():
                                     f"(sample+encode+decode+composite fwd, bwd, sparse Adam); foreground branch"),
                        "path": path, "rays_per_step": B, "valid_ray_fraction": valid_frac, "samples": S, "tiles_per_gpu": ntile,
                        "parallelism": f"tile-per-gpu x{world}", "syn_iters": SYN_ITERS},
+            "f32_arith_ms_per_step": f32_ms,
             "consensus_ms": consensus_ms,
             "consensus_frac_of_iteration": consensus_ms / (SYN_ITERS * ms_per_step),
         }
@@ -322,6 +435,10 @@ def main():
                     roof["traffic_source"] = "profiles/r01_pmc_traffic.json (FETCH_SIZE + WRITE_SIZE of " + pm[name]["kernel"] + ")"
             except (OSError, ValueError, KeyError):
                 pass
+            # SURVEY.md 8(d) bytes of the WHOLE step (forward + backward per ray) against the step time
+            whole = B * valid_frac * (BYTES_FWD_PER_RAY + BYTES_BWD_PER_RAY) if S == 128 else None
+            if whole:
+                roof["whole_step"] = {"bytes": whole, "ms": ms_per_step, "frac": whole / (ms_per_step * 1e-3) / (HBM_PEAK_GBS * 1e9)}
             roof.update({"kernel": name, "traffic": traffic, "avg_launch_ms": avg_ms,
                          "algorithmic_bytes_per_launch": alg_bytes, "all_kernels_ms": timer.summary()})
             line["roofline"] = roof

@@ -303,6 +303,16 @@ def get_last_block(tracing_blocks, inter):
     return out
 
 
+def ray_firsthit_block(rays_o, rays_d, corners, sizes, occ, grid_starts, log2dim, tracing_blocks, inter):
+    """rendering_kernel.cu:705-813 -> hit_blockIdxs [B] int16 (pre-filled with -1 as the kernel expects)."""
+    tb = _i32(_np(tracing_blocks))
+    hit = np.full((tb.shape[0],), -1, np.int16)
+    lib().orc_ray_firsthit_block(_p(_f32(_np(rays_o))), _p(_f32(_np(rays_d))), _p(_f32(_np(corners))), _p(_f32(_np(sizes))),
+                                 _p(_u8(occ)), _p(_i64(grid_starts)), _p(_i32(_np(log2dim))), _p(tb), _p(_f32(_np(inter))),
+                                 _p(hit), _ci(tb.shape[1]), _ci(tb.shape[0]))
+    return hit
+
+
 def process_occupied_grid(bidx, total_grid, corners, sizes, occ, grid_starts, log2dim, tgt):
     """In place on tgt (numpy uint8, concatenated grids)."""
     lib().orc_process_occupied_grid(_ci(bidx), _ci(total_grid), _p(_f32(_np(corners))), _p(_f32(_np(sizes))), _p(_u8(occ)),
@@ -462,10 +472,11 @@ def render_batch_rays(rays_o, rays_d, z_vals, dists, features, res, sd, mode, co
                       infinity=False):
     """hashgrid/__init__.py:512-596 (out_normal=False).  `contract` is a callable on [N,3]."""
     B, S = z_vals.shape
+    L = int(res.shape[0])  # 16 in the reference (hard-coded, hashgrid/__init__.py:62,233); BASELINE configs[0] uses 8
     samples = rays_o[:, None, :] + z_vals[..., None] * rays_d[:, None, :]
     cx = contract(samples.reshape(-1, 3))
-    feats = encode_bg(cx, features, res).reshape(B, S, 32)
-    wf = weight_feature(global_step)[None, None, :].repeat_interleave(2, dim=-1)
+    feats = encode_bg(cx, features, res).reshape(B, S, 2 * L)
+    wf = weight_feature(global_step)[:L][None, None, :].repeat_interleave(2, dim=-1)
     inputs = torch.cat([feats, rays_d[:, None, :].repeat(1, S, 1)], -1)
     o = mlp_forward(sd, inputs, wf)
     weights, T_left = cal_integrate_weight(o["sigma"], dists, rays_d, infinity=infinity)

@@ -946,6 +946,46 @@ ORC_API void orc_get_last_block(const int32_t *tracing_blocks, int32_t *bidxs, c
     }
 }
 
+/* rendering_kernel.cu:705-782 (`tracing` :705-732 + ray_firsthit_block_kernel :735-782): per ray, walk its tiles in
+ * tracing order until the first untouched one (near == INF); a tile "hits" when the DDA over [near, far] meets an occupied
+ * cell (no length test, unlike the samplers); among hitting tiles the one with the smallest FAR bound wins (`dis > bound.y`,
+ * strict: the earlier tile wins ties); a ray that hits nothing keeps the last tile it crosses; `hit` is read back for the
+ * -1 test, so it must be pre-filled with -1 by the caller. */
+ORC_API void orc_ray_firsthit_block(const float *rays_o, const float *rays_d, const float *corners, const float *sizes,
+                                    const uint8_t *occ, const int64_t *grid_starts, const int32_t *log2dim,
+                                    const int32_t *tracing_blocks, const float *inter, int16_t *hit, int nb, int B)
+{
+    for (int i = 0; i < B; ++i) {
+        const float *o = rays_o + 3 * i, *d = rays_d + 3 * i;
+        float dis = 10000000.0f;
+        int last = -1;
+        for (int k = 0; k < nb; ++k) {
+            const int b = tracing_blocks[(size_t)i * nb + k];
+            const f2 bound = { inter[2 * ((size_t)i * nb + b)], inter[2 * ((size_t)i * nb + b) + 1] };
+            if (bound.x == ORC_INF_INTERSECTION) break;
+            const int l2d[3] = { log2dim[3 * b], log2dim[3 * b + 1], log2dim[3 * b + 2] };
+            int side[3]; float tsize[3], og[3];
+            for (int a = 0; a < 3; ++a) {
+                side[a] = 1 << l2d[a];
+                tsize[a] = sizes[3 * b + a] / (float)side[a];
+                og[a] = o[a] - corners[3 * b + a];
+            }
+            const uint8_t *g = occ + grid_starts[b];
+            dda_t s;
+            dda_init(&s, og, d, bound, side, tsize);
+            int found = 0;
+            while (!dda_terminate(&s)) {
+                dda_next(&s);
+                if (g[cell_offset(s.tile, l2d)]) { found = 1; break; }
+                dda_step(&s);
+            }
+            if (found && dis > bound.y) { hit[i] = (int16_t)b; dis = bound.y; }
+            last = b;
+        }
+        if (last != -1 && hit[i] == -1) hit[i] = (int16_t)last;
+    }
+}
+
 /* rendering_kernel.cu:1479-1564: dilate tile bidx's occupancy into the grids of the tiles it overlaps */
 ORC_API void orc_process_occupied_grid(int bidx, int total_grid, const float *corners, const float *sizes,
                                        const uint8_t *occ, const int64_t *grid_starts, const int32_t *log2dim,

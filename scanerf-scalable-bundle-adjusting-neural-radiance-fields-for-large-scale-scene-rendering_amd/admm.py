@@ -50,7 +50,11 @@ class AdmmDriver:
         self.stretches = syn_schedule(total_step, syn_start, syn_iters)
         self.confidence = confidence
         self.log_dir, self.group = log_dir, group
-        self.depth_hooks = depth_hooks  # optional (publish(trainer), consume(trainer)) around the shared-depth exchange
+        # optional shared-depth exchange: (publish(trainer) -> camera ids it wrote, consume(trainer), shared_depth buffer).
+        # The collective itself is issued HERE, exactly once per stretch on every rank whatever the number of tiles a rank
+        # owns (inside a per-trainer hook, ranks with different tile counts would issue different numbers of collectives
+        # and hang)
+        self.depth_hooks = depth_hooks
         self.history = []
 
     def _rank(self):
@@ -72,16 +76,20 @@ class AdmmDriver:
 
     def run(self, on_stretch=None):
         self.synchronize()  # the reference exchanges once before the first iteration (admm_trainer.py:222-231)
+        from . import occlusion
         for n, iters in enumerate(self.stretches):
+            published = []
             for t in self.trainers:
-                if self.depth_hooks is not None:
+                if self.depth_hooks is not None and n > 0:
                     self.depth_hooks[1](t)  # update_occlusion_mask with what the last exchange delivered
                 t.admm = True
                 for _ in range(iters):
                     t.maybe_prune()
                     t.train_one_step()
                 if self.depth_hooks is not None:
-                    self.depth_hooks[0](t)  # render_shared_depth into the rank's buffer
+                    published += list(self.depth_hooks[0](t) or [])  # render_shared_depth into the rank's buffer
+            if self.depth_hooks is not None:
+                occlusion.exchange_shared_depth(self.depth_hooks[2], published, group=self.group)
             res = self.synchronize()
             if on_stretch is not None:
                 on_stretch(n, res)

@@ -39,23 +39,30 @@ def taylor_C(x):
     return _series(x, (2, 3))   # 2*3, 2*3*4*5, ...
 
 
+# generators of so(3): hat(w) = w_0 E_0 + w_1 E_1 + w_2 E_2
+_SO3_GENERATORS = torch.tensor([[[0.0, 0, 0], [0, 0, -1], [0, 1, 0]],
+                                [[0, 0, 1], [0, 0, 0], [-1, 0, 0]],
+                                [[0, -1, 0], [1, 0, 0], [0, 0, 0]]])
+
+
 def skew_symmetric(w):
-    w0, w1, w2 = w.unbind(dim=-1)
-    O = torch.zeros_like(w0)
-    return torch.stack([torch.stack([O, -w2, w1], dim=-1), torch.stack([w2, O, -w0], dim=-1),
-                        torch.stack([-w1, w0, O], dim=-1)], dim=-2)
+    """hat operator [...,3] -> [...,3,3] (camera.py:110-116) as a contraction with the so(3) generators."""
+    return torch.einsum("...k,kij->...ij", w, _SO3_GENERATORS.to(device=w.device, dtype=w.dtype))
 
 
 def se3_to_SE3(wu):
-    """[...,6] (rotation w, translation u) -> [...,3,4] = [exp(w^) | V u]."""
-    w, u = wu.split([3, 3], dim=-1)
-    wx = skew_symmetric(w)
-    theta = w.norm(dim=-1)[..., None, None]
-    eye = torch.eye(3, device=w.device, dtype=torch.float32)
-    A, B, C = taylor_A(theta), taylor_B(theta), taylor_C(theta)
-    R = eye + A * wx + B * wx @ wx
-    V = eye + B * wx + C * wx @ wx
-    return torch.cat([R, V @ u[..., None]], dim=-1)
+    """Exponential map se(3) -> SE(3), [...,6] = (rotation vector, translation part) -> [...,3,4] = [R | V u] with
+    R = I + A K + B K^2 and V = I + B K + C K^2 for K = hat(w) (Rodrigues; camera.py:84-95), A, B, C the reference's
+    truncated series in the rotation angle."""
+    rot, trans = wu[..., :3], wu[..., 3:]
+    K = skew_symmetric(rot)
+    K2 = K @ K
+    angle = rot.norm(dim=-1)[..., None, None]
+    ident = torch.eye(3, device=wu.device, dtype=torch.float32)
+    b = taylor_B(angle)
+    R = ident + taylor_A(angle) * K + b * K2
+    V = ident + b * K + taylor_C(angle) * K2
+    return torch.cat([R, V @ trans[..., None]], dim=-1)
 
 
 def pose_invert(pose):

@@ -1,7 +1,7 @@
 """Drop-in for the reference's pybind module HASHGRID (hashgrid/binding.cpp:9-44), training-path ops.
 
-Same names / positional order / in-place outputs as hashgrid/include/hashgrid.h:19-51.
-The render-time ops of the module (rendering.h) are listed in DESIGN.md as the next rows.
+Same names / positional order / in-place outputs as hashgrid/include/hashgrid.h:19-51 (encoder ops) and
+hashgrid/include/rendering.h:20-182 (the render-time ops of rendering.py's novel-view loop, second half of this file).
 """
 import ctypes
 import os
@@ -85,26 +85,50 @@ def embedding_backward_cuda(points, grad_in, grad_points, grad_features, feature
 # ------------------------------------------------------------------ render-time ops (rendering.h:20-182)
 _i16, _i64, _bool = torch.int16, torch.int64, (torch.bool, torch.uint8)
 _I = ctypes.c_int
+
+
+class PackedDecoders:
+    """[nb, 13994] render-time decoder blobs packed once into the LDS images of the MFMA decoder (weight_feature == 1:
+    the render-time decoder has no coarse-to-fine mask, decoder.h:169-218).  Owned by whoever owns the blobs
+    (renderer.TileSetRenderer packs once in its constructor) and accepted by pts_inference / bg_pts_inference_v2 in
+    place of the raw `params` tensor; call repack() after changing the blobs."""
+
+    def __init__(self, params):
+        if params.dim() != 2 or params.shape[1] != 13994:
+            raise RuntimeError(f"scanerf: decoder blobs must be [nb, 13994], got {tuple(params.shape)}")
+        self.params = params
+        self.images = torch.empty((params.shape[0], lib().scanerf_render_workspace_floats()), dtype=_f32, device=params.device)
+        self.repack()
+
+    def repack(self):
+        p = self.params.contiguous()
+        ones = torch.ones(32, dtype=_f32, device=p.device)
+        for b in range(p.shape[0]):
+            check(lib().scanerf_pack_decoder(ctypes.c_void_p(p[b].data_ptr()), dev_ptr(ones, _f32, "wf"),
+                                             ctypes.c_void_p(self.images[b].data_ptr()), stream()), "pack_decoder")
+        self.version = self.params._version
+        return self
+
+
+# Raw `params` tensors (the reference's calling convention) are packed on first use and remembered PER TENSOR OBJECT: the
+# entry holds a weak reference, is dropped when the tensor dies, and is only trusted while the reference still points at
+# the very same object and its version counter is unchanged -- an address recycled by the caching allocator for a new
+# tensor can never hit an old entry.  Writes that bypass the version counter (params.data[...] = ...) are not seen: own
+# a PackedDecoders and repack() instead.
 _images = {}
 
 
 def _packed_images(params):
-    """[nb, 13994] decoder blobs -> [nb, image] packed for the MFMA decoder (weight_feature == 1: the
-    render-time decoder has no coarse-to-fine mask, decoder.h:169-218).  Cached per params version."""
-    key = (params.data_ptr(), tuple(params.shape), params._version)
-    hit = _images.get("k")
-    if hit is not None and hit[0] == key:
-        return hit[1]
-    nb = params.shape[0]
-    n = lib().scanerf_render_workspace_floats()
-    img = torch.empty((nb, n), dtype=_f32, device=params.device)
-    ones = torch.ones(32, dtype=_f32, device=params.device)
-    p = params.contiguous()
-    for b in range(nb):
-        check(lib().scanerf_pack_decoder(ctypes.c_void_p(p[b].data_ptr()), dev_ptr(ones, _f32, "wf"),
-                                         ctypes.c_void_p(img[b].data_ptr()), stream()), "pack_decoder")
-    _images["k"] = (key, img)
-    return img
+    if isinstance(params, PackedDecoders):
+        return params.images
+    import weakref
+    key = id(params)
+    hit = _images.get(key)
+    if hit is not None and hit[0]() is params and hit[1].version == params._version:
+        return hit[1].images
+    packed = PackedDecoders(params)
+    _images[key] = (weakref.ref(params, lambda _r, key=key: _images.pop(key, None)), packed)
+    return packed.images
 
 
 def ray_block_intersection(rays_o, rays_d, block_corners, block_sizes, intersections):

@@ -15,14 +15,19 @@ LAYERS = (("Spatial_MLP.mlp.0", 64, 32), ("Spatial_MLP.mlp.2", 64, 64), ("sigma_
           ("Directional_MLP.mlp.2", 64, 64), ("Directional_MLP.mlp.4", 3, 64))
 
 
-def blob_from_state_dict(sd):
+def layers(in_channel=32):
+    """LAYERS with `in_channel` encoder features (2 per level): 32 in the reference; BASELINE configs[0] uses 8 levels."""
+    return tuple((n, o, in_channel if n == "Spatial_MLP.mlp.0" else i) for n, o, i in LAYERS)
+
+
+def blob_from_state_dict(sd, in_channel=32):
     parts = []
-    for name, o, i in LAYERS:
+    for name, o, i in layers(in_channel):
         w, b = sd[name + ".weight"], sd[name + ".bias"]
         assert tuple(w.shape) == (o, i), (name, tuple(w.shape))
         parts += [b.reshape(-1), w.t().reshape(-1)]
     blob = torch.cat(parts).float().contiguous()
-    assert blob.numel() == PARAMSIZE
+    assert blob.numel() == PARAMSIZE - 64 * (32 - in_channel)
     return blob
 
 
@@ -36,14 +41,14 @@ def state_dict_from_blob(blob):
     return sd
 
 
-def xavier_blob(seed=0, device="cpu", bias_scale=0.0):
+def xavier_blob(seed=0, device="cpu", bias_scale=0.0, in_channel=32):
     """Random decoder: Xavier-normal weights, zero (or small) biases (network.py:202-205)."""
     g = torch.Generator().manual_seed(seed)
     sd = {}
-    for name, o, i in LAYERS:
+    for name, o, i in layers(in_channel):
         sd[name + ".weight"] = torch.randn(o, i, generator=g) * math.sqrt(2.0 / (i + o))
         sd[name + ".bias"] = torch.randn(o, generator=g) * bias_scale
-    return blob_from_state_dict(sd).to(device)
+    return blob_from_state_dict(sd, in_channel).to(device)
 
 
 def weight_feature(global_step, device="cpu"):

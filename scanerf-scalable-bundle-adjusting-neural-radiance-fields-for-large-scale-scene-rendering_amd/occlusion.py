@@ -58,11 +58,29 @@ def render_shared_depth(model, get_rays, H, W, visible_poses, overlap_idxs, shar
 
 
 @torch.no_grad()
-def exchange_shared_depth(shared_depth, group=None):
-    """All ranks end up with every published map: elementwise MIN over ranks of buffers that hold +inf where a rank has
-    nothing to say (one publisher per camera, so MIN is a gather)."""
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.all_reduce(shared_depth, op=dist.ReduceOp.MIN, group=group)
+def exchange_shared_depth(shared_depth, published=None, group=None):
+    """One round of the exchange: every rank ends up with every map published THIS round; entries nobody re-published keep
+    what an earlier round delivered (the reference replaces a camera's entry in the master's dictionary when a new map
+    arrives and leaves the others alone, tile.py:436-471 / admm_trainer.py shared dict).
+
+    published: global camera ids this rank wrote into `shared_depth` since the last exchange (None = every finite entry,
+    for a first or only round).  Only those rows enter the collective -- a fresh +inf buffer reduced with MIN (one
+    publisher per camera, so MIN is a gather).  Reducing the persistent buffer itself would mix rounds: ranks that hold a
+    camera's OLD map would contribute it again and the result would be min(old, new), so depths could only ever decrease.
+    Every rank must call this the same number of times (it is a collective): AdmmDriver does, once per stretch."""
+    multi = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    if published is None and not multi:
+        return shared_depth
+    fresh = torch.full_like(shared_depth, NO_DEPTH)
+    if published is None:
+        fresh.copy_(shared_depth)
+    elif len(published):
+        idx = torch.as_tensor(sorted(set(int(i) for i in published)), dtype=torch.long, device=shared_depth.device)
+        fresh[idx] = shared_depth[idx]
+    if multi:
+        dist.all_reduce(fresh, op=dist.ReduceOp.MIN, group=group)
+    arrived = torch.isfinite(fresh).reshape(fresh.shape[0], -1).any(1)
+    shared_depth[arrived] = fresh[arrived]
     return shared_depth
 
 

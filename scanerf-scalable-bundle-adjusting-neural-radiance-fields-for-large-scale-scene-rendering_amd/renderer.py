@@ -44,6 +44,10 @@ class TileSetRenderer:
         t = lambda a, dt: torch.as_tensor(np.ascontiguousarray(a), dtype=dt).to(device).contiguous()
         self.feature_tables = t(np.stack([x["features"] for x in tiles]), torch.float16)
         self.params = t(np.stack([x["blob"] for x in tiles]), torch.float32)
+        # the decoders' MFMA images are packed ONCE, here, and owned by this renderer (not looked up per call in a cache
+        # keyed on an address the allocator may hand to the next renderer's blobs)
+        from .hashgrid.lib.HASHGRID import PackedDecoders
+        self.packed = PackedDecoders(self.params)
         self.resolution = t(np.stack([x["resolution"] for x in tiles]), torch.int32)
         self.grid_log2dim = t(np.stack([x["grid_log2dim"] for x in tiles]), torch.int32)
         grids = [np.asarray(x["occupied_grid"]).reshape(-1) for x in tiles]
@@ -94,7 +98,7 @@ class TileSetRenderer:
                           self.grid_log2dim, tracing_blocks, inter, tracing_idx, z_start, z, dd)
             bi = torch.full((B, num_sample, 4), -1, dtype=torch.int16, device=dev)
             prepare_points(z, running, inter, bi)
-            pts_inference(rays_o, rays_d, z, dd, bi, self.feature_tables, self.params, self.resolution, self.occupied_grid,
+            pts_inference(rays_o, rays_d, z, dd, bi, self.feature_tables, self.packed, self.resolution, self.occupied_grid,
                           self.grid_starts, self.grid_log2dim, self.block_corner, self.block_size, pd, ps, pa)
             accumulate_color(pd, ps, pa, transp, z, dif, spec, depth)
         # blended backgrounds of the exit tile(s)
@@ -113,7 +117,7 @@ class TileSetRenderer:
             inverse_z_sampling(inter, bg_b[:, i].contiguous(), zb, sample_range)
             pd.zero_(), ps.zero_(), pa.zero_()
             bg_pts_inference_v2(rays_o, rays_d, zb, bg_b, i, self.block_corner, self.block_size, self.resolution,
-                                self.feature_tables, self.params, pd, ps, pa)
+                                self.feature_tables, self.packed, pd, ps, pa)
             t1 = torch.ones(B, 1, device=dev)
             td, ts, tz = torch.zeros(B, 3, device=dev), torch.zeros(B, 3, device=dev), torch.zeros(B, 1, device=dev)
             accumulate_color(pd, ps, pa, t1, zb, td, ts, tz)

@@ -45,15 +45,17 @@ class Decoder(nn.Module):
     kernels read it as it is, their gradient is its .grad, and the optimiser steps one tensor instead of sixteen
     (Adam is element-wise, so the update is the same).  Per-layer views carry the reference's parameter names."""
 
-    def __init__(self, seed=0):
+    def __init__(self, seed=0, in_channel=32):
         super().__init__()
-        self.params = nn.Parameter(network.xavier_blob(seed))
+        self.in_channel = in_channel  # 2 features per level: 32 in the reference, 16 for BASELINE configs[0] (ops path only)
+        self.layers = network.layers(in_channel)
+        self.params = nn.Parameter(network.xavier_blob(seed, in_channel=in_channel))
         self._views = {}
 
     def _view(self, name, kind):
         """weight [out,in] / bias [out] of a layer as a (differentiable) view of the blob"""
         k = 0
-        for n, o, i in network.LAYERS:
+        for n, o, i in self.layers:
             if n == name:
                 return self.params[k:k + o] if kind == "bias" else self.params[k + o:k + o + i * o].reshape(i, o).t()
             k += o + i * o
@@ -71,7 +73,7 @@ class Decoder(nn.Module):
 
     def load_ref_state_dict(self, sd):
         with torch.no_grad():
-            self.params.copy_(network.blob_from_state_dict(sd).to(self.params.device))
+            self.params.copy_(network.blob_from_state_dict(sd, self.in_channel).to(self.params.device))
 
     def blob(self):
         return self.params
@@ -97,8 +99,9 @@ class TileModel(nn.Module):
     `corner`/`size` describe the tile; the hash grid covers the 2x box around it."""
 
     def __init__(self, corner, size, device, log2_T=19, grid_resolution=(32, 2048), sampler_log2dim=4, seed=0,
-                 table_dtype=torch.float32):
+                 table_dtype=torch.float32, n_levels=16):
         super().__init__()
+        self.n_levels = n_levels  # the reference hard-codes 16; other counts run on the "ops" path only (configs[0]: 8)
         corner = torch.as_tensor(corner, dtype=torch.float32)
         size = torch.as_tensor(size, dtype=torch.float32)
         self.device = device
@@ -107,13 +110,13 @@ class TileModel(nn.Module):
         self.min_bbox = self.bbox_center - self.bbox_size / 2.0
         fin = (self.bbox_size / self.bbox_size.min() * grid_resolution[1]).int()
         base = (self.bbox_size / self.bbox_size.min() * grid_resolution[0]).int()
-        self.resolution = level_resolutions(base, fin, 16).to(device).contiguous()
+        self.resolution = level_resolutions(base, fin, n_levels).to(device).contiguous()
         g = torch.Generator().manual_seed(seed)
         T = 2 ** log2_T
-        std = math.sqrt(2.0 / (T * 2 + 16 * 2))  # xavier_normal_ on [16,T,2] (PyHashGridBG.py:72-73)
-        self.features = nn.Parameter((torch.randn(16, T, 2, generator=g) * std).to(device))
+        std = math.sqrt(2.0 / (T * 2 + n_levels * 2))  # xavier_normal_ on [L,T,2] (PyHashGridBG.py:72-73)
+        self.features = nn.Parameter((torch.randn(n_levels, T, 2, generator=g) * std).to(device))
         self.table_dtype = table_dtype
-        self.decoder = Decoder(seed).to(device)
+        self.decoder = Decoder(seed, 2 * n_levels).to(device)
         self.log2dim = (sampler_log2dim - torch.log2(self.bbox_size.max() / self.bbox_size).int()).int().to(device)
         self.occupied_grid = torch.ones(tuple(int(2 ** k) for k in self.log2dim), dtype=torch.bool, device=device)
         self._occ_full = True  # set_occupancy() keeps it in step with the grid
@@ -160,8 +163,8 @@ class TileModel(nn.Module):
         B = o.shape[0]
         pts = o[:, None, :] + z[..., None] * d[:, None, :]
         x = (pts.reshape(-1, 3) - self._min_dev) / self._size_dev * 4.0 - 2.0
-        feats = HashEmbeddingBG(x.contiguous(), self.features, self.resolution).reshape(B, S, 32)
-        wf = network.weight_feature(global_step, self.device)
+        feats = HashEmbeddingBG(x.contiguous(), self.features, self.resolution).reshape(B, S, 2 * self.n_levels)
+        wf = network.weight_feature(global_step, self.device)[:2 * self.n_levels]
         sigma, dif, spec, tint = self.decoder(feats, d[:, None, :].expand(B, S, 3), wf)
         delta = dist * d.norm(dim=-1, keepdim=True)
         alpha = 1.0 - torch.exp(-sigma[..., 0] * delta)

@@ -125,3 +125,55 @@ def test_world2_gloo_matches_single_process():
         np.testing.assert_allclose(shared, drv.shared_poses(N_CAM).numpy(), rtol=1e-4, atol=1e-8)
         for t, got in zip(mine, se3s):
             np.testing.assert_allclose(got, trainers[t].cameras.se3_refine.detach().numpy(), rtol=1e-4, atol=1e-8)
+
+
+def _depth_driver_worker(rank, world, port, q):
+    """3 tiles on 2 ranks (rank 0 owns tiles 0 and 2, rank 1 owns tile 1): with the shared-depth collective inside a
+    per-trainer hook the ranks would issue 2 vs 1 collectives per stretch and hang; the driver issues exactly one."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import scanerf_amd  # noqa
+    from scanerf_amd import admm
+    from scanerf_amd import occlusion as OC
+    mine = admm.tiles_of_rank(3, rank, world)
+    trainers = [_ToyTrainer(t) for t in mine]
+    for t, tr in zip(mine, trainers):
+        tr.tile = t
+    shared = torch.full((N_CAM, 2, 3), OC.NO_DEPTH)
+    rounds = {"n": 0}
+    seen = []
+
+    def publish(tr):  # tile t publishes camera t's map; its depth grows from one stretch to the next
+        shared[tr.tile] = 10.0 * tr.tile + tr.steps
+        return [tr.tile]
+
+    def consume(tr):
+        seen.append((tr.tile, shared[:3, 0, 0].tolist()))
+
+    drv = admm.AdmmDriver(trainers, total_step=20, syn_iters=10, depth_hooks=(publish, consume, shared))
+    drv.run()
+    q.put((rank, mine, seen, shared[:3, 0, 0].tolist()))
+    dist.destroy_process_group()
+
+
+def test_world2_shared_depth_exchange_once_per_stretch_with_unequal_tile_counts():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_depth_driver_worker, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in ps]
+    res = sorted([q.get(timeout=180) for _ in ps], key=lambda t: t[0])
+    [p.join(60) for p in ps]
+    assert [r[1] for r in res] == [[0, 2], [1]]
+    # after stretch 2 every rank holds every tile's LATEST map (steps = 20): replaced, not min'ed with the first round's
+    for _, _, seen, final in res:
+        assert final == [20.0, 30.0, 40.0]
+        # what the tiles consumed at the start of stretch 2 = the first round's maps (steps = 10), identical on both ranks
+        # (a rank's later tiles also see what its earlier tiles have just re-published locally)
+        assert seen[0][1] == [10.0, 20.0, 30.0]
+        assert all(vals[1:] == [20.0, 30.0] for _, vals in seen)

@@ -282,17 +282,17 @@ def test_admm_driver_with_real_tile_trainers(tmp_path):
 
     def publish(tr):
         get = lambda v: tr.cameras.get_rays(CM.pixel_locs(3, torch.arange(H * W), W, DEV)[v * H * W:(v + 1) * H * W])
-        OC.render_shared_depth(tr.model, lambda v: tuple(x.detach() for x in get(v)), H, W, tr.views,
-                               torch.nonzero(tr.consensus.overlap_flags)[:, 0], shared_depth, S_fg=S_, S_bg=16, global_step=tr.global_step)
+        return OC.render_shared_depth(tr.model, lambda v: tuple(x.detach() for x in get(v)), H, W, tr.views,
+                                      torch.nonzero(tr.consensus.overlap_flags)[:, 0], shared_depth, S_fg=S_, S_bg=16,
+                                      global_step=tr.global_step)
 
     masks = {}
 
     def consume(tr):
         get = lambda v: tuple(x.detach() for x in tr.cameras.get_rays(CM.pixel_locs(3, torch.arange(H * W), W, DEV)[v * H * W:(v + 1) * H * W]))
-        OC.exchange_shared_depth(shared_depth)
         masks[id(tr)] = OC.update_occlusion_mask(tr.model, get, H, W, tr.views, shared_depth, kernel_size=5)
 
-    drv = admm.AdmmDriver(trainers, total_step=8, syn_iters=4, log_dir=str(tmp_path), depth_hooks=(publish, consume))
+    drv = admm.AdmmDriver(trainers, total_step=8, syn_iters=4, log_dir=str(tmp_path), depth_hooks=(publish, consume, shared_depth))
     hist = drv.run()
     assert len(hist) == 3 and all(np.isfinite(h).all() for h in hist) and all(tr.global_step == 8 for tr in trainers)
     for tr in trainers:  # camera 2 is flagged as overlapping in both tiles, the others are not

@@ -138,7 +138,40 @@ def test_render_loop_stage_by_stage():
             assert (ob_ref[:, 0] != -1).sum() > B // 2 and ra_.max() > 0.05
 
 
-def test_process_occupied_grid_and_firsthit_and_sort():
+def test_ray_firsthit_block():
+    """rendering_kernel.cu:705-813 through the HASHGRID binding name, bit-exact against the oracle's restatement: the tile
+    with the nearest far bound among those whose occupancy the ray touches, else the last tile crossed, else -1."""
+    import scanerf_amd  # noqa
+    from scanerf_amd import hashgrid as H
+    rng = np.random.default_rng(23)
+    sc = _scene(rng)
+    # sparse grids so that many rays cross a tile without touching an occupied cell (the "last tile" rule), tile 2 empty
+    grids = [rng.random(tuple(2 ** k for k in l)) < p for l, p in zip(sc["l2d"], (0.02, 0.01, 0.0))]
+    sc["occ"] = np.concatenate([gr.reshape(-1) for gr in grids])
+    B, nb = 3000, 3
+    o, d = _rays(rng, B)
+    d[::5, 0] *= -1.0                     # rays that leave the scene backwards
+    d[1::7, 1:] = 0.0                     # axis-aligned rays (safe_divide branch of the DDA)
+    C, Z, OCC, ST, L2 = g(sc["corners"]), g(sc["sizes"]), g(sc["occ"]), g(sc["starts"]), g(sc["l2d"])
+    RO, RD = g(o), g(d)
+    inter = torch.full((B, nb, 2), 1e7, device=DEV)
+    H.ray_block_intersection(RO, RD, C, Z, inter)
+    TB = torch.argsort(inter[..., 0], dim=-1).int().contiguous()   # rendering.py:301 tracing order
+    hit = torch.full((B,), -1, dtype=torch.int16, device=DEV)
+    H.ray_firsthit_block(RO, RD, C, Z, OCC, ST, L2, TB, inter, hit)
+    inter_ref = O.ray_block_intersection(o, d, sc["corners"], sc["sizes"])
+    assert np.array_equal(inter.cpu().numpy(), inter_ref)
+    hit_ref = O.ray_firsthit_block(o, d, sc["corners"], sc["sizes"], sc["occ"], sc["starts"], sc["l2d"], TB.cpu().numpy(), inter_ref)
+    got = hit.cpu().numpy()
+    assert np.array_equal(got, hit_ref)
+    # the three outcomes all occur: a touched tile, the last tile crossed without touching anything, no tile at all
+    crossed = (inter_ref[..., 0] != 1e7).any(1)
+    assert (got == -1).sum() > 0 and ((got != -1) & crossed).sum() > B // 2
+    assert np.array_equal(got == -1, ~crossed)
+    assert (got == 2).sum() > 0   # tile 2 is empty: it can only be chosen by the last-tile rule
+
+
+def test_process_occupied_grid_and_sort_by_key():
     import scanerf_amd  # noqa
     from scanerf_amd import hashgrid as H
     rng = np.random.default_rng(22)
@@ -224,3 +257,48 @@ def test_renderer_end_to_end_and_tile_formats(tmp_path):
     img_a = np.clip((dif + spec).cpu().numpy(), 0, 1) * 255
     img_b = np.clip(ref["dif"] + ref["spec"], 0, 1).reshape(H, W, 3) * 255
     assert O.psnr(img_a, img_b) > 80.0  # tools/utils.py:53-55 PSNR of the HIP render vs the oracle render
+
+
+def test_packed_decoders_follow_their_owner_not_an_address():
+    """Two renderers built one after the other over the same tile geometry but different decoders: the second must render
+    with ITS decoders even when the caching allocator hands its blobs the address the first one's had (the packed MFMA
+    images are owned by the renderer; the raw-tensor convenience cache is keyed on the tensor object, not its address)."""
+    import gc
+    import scanerf_amd  # noqa
+    from scanerf_amd import hashgrid as H
+    from scanerf_amd.hashgrid.lib import HASHGRID as HG
+    rng = np.random.default_rng(24)
+    sc = _scene(rng)
+    B, S, nb = 64, 32, 3
+    o, d = _rays(rng, B)
+    RO, RD = g(o), g(d)
+    C, Z, OCC, ST, L2, TAB, RES = (g(sc[k]) for k in ("corners", "sizes", "occ", "starts", "l2d", "tables", "res"))
+    z = torch.linspace(4.0, 12.0, S, device=DEV).repeat(B, 1).contiguous()
+    dd = torch.full((B, S), 0.25, device=DEV)
+    bi = torch.full((B, S, 4), -1, dtype=torch.int16, device=DEV)
+    bi[..., 0] = 1
+
+    def infer(params):
+        pd, ps, pa = torch.zeros(B, S, 3, device=DEV), torch.zeros(B, S, 3, device=DEV), torch.zeros(B, S, 1, device=DEV)
+        H.pts_inference(RO, RD, z, dd, bi, TAB, params, RES, OCC, ST, L2, C, Z, pd, ps, pa)
+        torch.cuda.synchronize()
+        return torch.cat([pd, ps, pa], -1).clone()
+
+    p1 = g(sc["params"])
+    addr = p1.data_ptr()
+    out1 = infer(p1)
+    del p1
+    gc.collect()
+    assert not HG._images, "the cache entry must die with its tensor"
+    p2 = g(sc["params"][::-1].copy())       # same shape, different decoders; very likely the same address
+    out2 = infer(p2)
+    ref2 = infer(HG.PackedDecoders(p2))      # owner-held images
+    assert torch.equal(out2, ref2)
+    assert not torch.equal(out1, out2), f"second parameter set rendered with the first one's decoders (addr reuse: {p2.data_ptr() == addr})"
+    # an in-place update through the version counter is seen; alternating two live parameter sets does not thrash
+    p3 = g(sc["params"])
+    out3 = infer(p3)
+    assert torch.equal(out3, out1) and len(HG._images) == 2
+    assert torch.equal(infer(p2), out2) and torch.equal(infer(p3), out3) and len(HG._images) == 2
+    p3.mul_(0.5)
+    assert not torch.equal(infer(p3), out3)

@@ -177,11 +177,20 @@ def _depth_worker(rank, world, port, q):
     from scanerf_amd import occlusion as OC
     dist.init_process_group("gloo", rank=rank, world_size=world)
     buf = torch.full((6, 4, 5), OC.NO_DEPTH)
-    for cam in range(6):  # camera c is published by rank c % 3 if that rank exists; camera 5 by nobody
-        if cam < 5 and cam % 3 == rank:
-            buf[cam] = torch.arange(20.0).reshape(4, 5) + 100 * cam
-    OC.exchange_shared_depth(buf)
-    q.put((rank, buf.numpy()))
+    # round 1: camera c is published by rank c % 3 if that rank exists; camera 5 by nobody
+    mine = [cam for cam in range(5) if cam % 3 == rank]
+    for cam in mine:
+        buf[cam] = torch.arange(20.0).reshape(4, 5) + 100 * cam
+    OC.exchange_shared_depth(buf, mine)
+    first = buf.clone()
+    # round 2: the publishers re-render and every depth INCREASES (a surface receded), except camera 0 whose publisher
+    # (rank 0) publishes nothing this round: its entry must survive.  A MIN over the persistent buffers would keep the old,
+    # smaller values.
+    again = [cam for cam in mine if cam != 0]
+    for cam in again:
+        buf[cam] = torch.arange(20.0).reshape(4, 5) + 100 * cam + 7.0
+    OC.exchange_shared_depth(buf, again)
+    q.put((rank, first.numpy(), buf.numpy()))
     dist.destroy_process_group()
 
 
@@ -196,13 +205,17 @@ def test_shared_depth_exchange_world2_gloo():
     [p.start() for p in ps]
     res = sorted([q.get(timeout=120) for _ in ps], key=lambda t: t[0])
     [p.join(60) for p in ps]
-    for _, buf in res:
+    base = np.arange(20.0).reshape(4, 5)
+    for _, first, second in res:
         for cam in range(6):
             if cam < 5 and cam % 3 < 2:
-                np.testing.assert_array_equal(buf[cam], np.arange(20.0).reshape(4, 5) + 100 * cam)
+                np.testing.assert_array_equal(first[cam], base + 100 * cam)
+                # round 2 REPLACES what was republished (depths went up by 7) and keeps camera 0, which nobody republished
+                np.testing.assert_array_equal(second[cam], base + 100 * cam + (0.0 if cam == 0 else 7.0))
             else:
-                assert np.isinf(buf[cam]).all()
+                assert np.isinf(first[cam]).all() and np.isinf(second[cam]).all()
     np.testing.assert_array_equal(res[0][1], res[1][1])
+    np.testing.assert_array_equal(res[0][2], res[1][2])
 
 
 def test_camera_algebra_matches_reference_golden_g7(golden):

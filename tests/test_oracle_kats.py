@@ -190,3 +190,27 @@ def test_compute_ray_backward_is_adjoint():
     o0, d0 = O.compute_ray_forward(locs, Ks, M)
     lhs = np.sum(go * (o1 - o0)) + np.sum(gd * (d1 - d0))  # forward is linear in C2W
     np.testing.assert_allclose(lhs, np.sum(g * dM), rtol=1e-3)
+
+
+def test_ray_firsthit_block_known_answers():
+    """rendering_kernel.cu:705-813 from the source text: two 2 m tiles side by side on x, rays along +x through both.
+    (tile 0 occupancy, tile 1 occupancy) -> expected hit: the touched tile with the smallest far bound; if none is touched
+    the last tile crossed; -1 for a ray that meets no tile."""
+    corners = np.float32([[0, 0, 0], [2, 0, 0]])
+    sizes = np.float32([[2, 2, 2], [2, 2, 2]])
+    l2d = np.int32([[1, 1, 1], [1, 1, 1]])
+    starts = np.int64([0, 8])
+    o = np.float32([[-1, 0.5, 0.5], [-1, 0.5, 0.5], [-1, 5.0, 0.5]])
+    d = np.float32([[1, 0, 0], [-1, 0, 0], [1, 0, 0]])   # through both / away from both / beside both
+    inter = O.ray_block_intersection(o, d, corners, sizes)
+    assert inter[0].tolist() == [[1.0, 3.0], [3.0, 5.0]] and np.all(inter[1:] == 1e7)
+    tb = np.argsort(inter[..., 0], axis=-1, kind="stable").astype(np.int32)
+    full, empty = np.ones(8, np.uint8), np.zeros(8, np.uint8)
+    for occ0, occ1, want in ((full, full, 0), (empty, full, 1), (full, empty, 0), (empty, empty, 1)):
+        hit = O.ray_firsthit_block(o, d, corners, sizes, np.concatenate([occ0, occ1]), starts, l2d, tb, inter)
+        assert hit.tolist() == [want, -1, -1], (occ0[0], occ1[0], hit)
+    # only the cell the ray does NOT cross is occupied: the tile is crossed but not touched
+    one = np.zeros(8, np.uint8)
+    one[(1 << 2) | (1 << 1) | 1] = 1   # cell (1,1,1): y,z in [1,2), the ray runs at y = z = 0.5
+    hit = O.ray_firsthit_block(o, d, corners, sizes, np.concatenate([one, full]), starts, l2d, tb, inter)
+    assert hit.tolist() == [1, -1, -1]
