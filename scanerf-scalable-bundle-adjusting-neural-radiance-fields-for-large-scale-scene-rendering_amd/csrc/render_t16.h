@@ -1,0 +1,219 @@
+// render_t16.h -- decoder images and matrix-core primitives of the 16-sample-tile backward kernel
+// (render_bwd_t16.hip): v_mfma_f32_16x16x32_f16, two waves per SIMD.
+//
+// Why a second tiling.  The 32-sample-tile kernel (render_bwd_h3.hip) needs 512 registers and 150 KB of LDS per
+// 4-wave workgroup: one wave per SIMD, every LDS / memory / MFMA latency exposed, VALU issue at half rate
+// (one wave alone issues a vector instruction every 4 cycles; two waves share the SIMD at one per 2).  With
+// 16-sample tiles every per-sample array halves, so a wave fits 256 registers and 8 waves share one CU.
+//
+// Lane map of v_mfma_f32_16x16x32_f16 (D = A B + C, A 16x32, B 32x16, C/D 16x16):
+//     lane l: c = l & 15, q = l >> 4
+//     A: lane holds A[row c][k-slot 8q + j], j = 0..7        (one h8 = 4 registers)
+//     B: lane holds B[k-slot 8q + j][col c]
+//     D: lane holds D[row 4q + g][col c], g = 0..3           (one v4f)
+// The decoder is evaluated transposed, as in the other fused kernels: rows = units, columns = samples, weights are
+// the A operand (from LDS), activations the B operand.  A layer's output is 4 row blocks b of 16 units:
+// block b, lane (c, q), register g = unit 16b + 4q + g of sample c.  The B operand of k-step t of the NEXT layer
+// is blocks 2t and 2t+1 converted in place: slot (q, j) = unit ku(t, q, j) = 32t + 16(j >> 2) + 4q + (j & 3),
+// so activations never move between lanes; the weight images store W[n][ku(...)] at that slot.
+//
+// Arithmetic.  Forward recompute: split f16 ("h3", render_h3.h): every operand hi + lo, three MFMAs per term,
+// f32 accumulate -- f32-equivalent results.  Gradient products (dX = W^T dY, dW = dY X^T): ONE f16 MFMA on
+// the hi parts (W^T from its own transposed image, dY under the workgroup's power-of-two scale); nothing in the
+// path's contract holds gradients to 1e-4, the error against the oracle is reported by the tests
+// (tests/test_gpu_parity.py, test_gpu_fullsize.py).
+//
+// LDS images (bytes):
+//   forward image   32 pairs (hi, lo) of 1 KB sub-images: lane l's 16 B at 16 l (ds_read_b128, conflict-free)
+//   transposed image 30 sub-images, hi only: A operand of dX = W^T dY, rows = input units, k = output units
+//   bias tail       f32 accumulator start values (natural unit order: block b, lane q reads 16 B at 16b + 4q)
+#pragma once
+#include "render_device.h"
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef _Float16 t16_h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 t16_h4 __attribute__((ext_vector_type(4)));
+typedef _Float16 t16_h2 __attribute__((ext_vector_type(2)));
+typedef float t16_f2 __attribute__((ext_vector_type(2)));
+
+namespace scanerf {
+
+constexpr int T16_SUB = 1024;
+constexpr int T16_PAIR = 2 * T16_SUB;
+// forward image: pairs [block b][k-step t]
+constexpr int T16_L0 = 0;                               // 4 x 1   (weight_feature folded in; slot (q, j) = x-stash position 8q + j)
+constexpr int T16_L1 = T16_L0 + 4 * T16_PAIR;           // 4 x 2
+constexpr int T16_HEAD = T16_L1 + 8 * T16_PAIR;         // 2 x 1   rows 4q+g: block 0 = (sigma, dif xyz), block 1 = (tint xyz, 0), every q
+constexpr int T16_D0 = T16_HEAD + 2 * T16_PAIR;         // 4 x 2   k-step 0 = H[32:64], k-step 1 = SH (slot (q, j) = SH[8q + j], q < 2)
+constexpr int T16_D1 = T16_D0 + 8 * T16_PAIR;           // 4 x 2
+constexpr int T16_D2 = T16_D1 + 8 * T16_PAIR;           // 1 x 2   rows 4q+g = (rgb xyz, 0), every q
+constexpr int T16_FWD_BYTES = T16_D2 + 2 * T16_PAIR;    // 32 pairs
+// transposed image: sub-images [input block b_in][k-step t of the layer's OUTPUT units]
+constexpr int T16T_D2 = T16_FWD_BYTES;                  // 4 x 1   k = narrow rows (8..10 = rgb)
+constexpr int T16T_D1 = T16T_D2 + 4 * T16_SUB;          // 4 x 2
+constexpr int T16T_D0 = T16T_D1 + 8 * T16_SUB;          // 2 x 2   input = H[32:64] (dH blocks 2, 3)
+constexpr int T16T_HEAD = T16T_D0 + 4 * T16_SUB;        // 2 x 1   k = narrow rows (0..6 = sigma, dif, tint); dH blocks 0, 1
+constexpr int T16T_L1 = T16T_HEAD + 2 * T16_SUB;        // 4 x 2
+constexpr int T16T_L0 = T16T_L1 + 8 * T16_SUB;          // 2 x 2   rows = x-stash positions (see t16_pos)
+constexpr int T16_BIAS = T16T_L0 + 4 * T16_SUB;         // f32 [L0 64][L1 64][D0 64][D1 64][headA 4][headB 4][D2 4][pad 4]
+constexpr int T16_BYTES = T16_BIAS + (256 + 16) * 4;
+static_assert(T16_BYTES % 16 == 0, "t16 image is copied as float4");
+constexpr int T16_FLOATS = T16_BYTES / 4;
+
+__host__ __device__ constexpr int t16_ku(int t, int q, int j) { return 32 * t + 16 * (j >> 2) + 4 * q + (j & 3); }
+// x-stash position (render.hip: 16h + 2jj + f holds feature f of level 4(jj>>1) + 2h + (jj&1)) -> decoder input index 2 level + f
+__host__ __device__ constexpr int t16_pos_to_input(int pos)
+{
+    const int h = pos >> 4, jj = (pos & 15) >> 1, f = pos & 1;
+    return 2 * (4 * (jj >> 1) + 2 * h + (jj & 1)) + f;
+}
+// row m of dX block e of the first layer (input "unit" 16e + m) <-> x-stash position: lane (c, q) of block e holds
+// register g = position 8q + 4e + g, i.e. exactly the 8 positions 8q .. 8q+7 the lane loaded
+__host__ __device__ constexpr int t16_l0_row_to_pos(int e, int m) { return 8 * (m >> 2) + 4 * e + (m & 3); }
+
+// ---- operands
+struct T16HL {
+    t16_h8 hi, lo;
+};
+// k-step operand from two accumulator blocks (slots j < 4 from `a`, j >= 4 from `b`), split hi + lo
+__device__ __forceinline__ T16HL t16_split(const v4f &a, const v4f &b)
+{
+    T16HL o;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const t16_f2 x = p < 2 ? t16_f2{ a[2 * p], a[2 * p + 1] } : t16_f2{ b[2 * p - 4], b[2 * p - 3] };
+        const t16_h2 hi = __builtin_convertvector(x, t16_h2);
+        const t16_f2 back = __builtin_convertvector(hi, t16_f2);
+        const t16_f2 r = { x[0] - back[0], x[1] - back[1] };
+        const t16_h2 lo = __builtin_convertvector(r, t16_h2);
+        o.hi[2 * p] = hi[0];
+        o.hi[2 * p + 1] = hi[1];
+        o.lo[2 * p] = lo[0];
+        o.lo[2 * p + 1] = lo[1];
+    }
+    asm volatile("s_nop 1" : "+v"(o.hi), "+v"(o.lo));  // operand guard (render_h3.h, "operand hazard")
+    return o;
+}
+// hi part only (gradient operands)
+__device__ __forceinline__ t16_h8 t16_hi(const v4f &a, const v4f &b)
+{
+    t16_h8 o;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const t16_f2 x = p < 2 ? t16_f2{ a[2 * p], a[2 * p + 1] } : t16_f2{ b[2 * p - 4], b[2 * p - 3] };
+        const t16_h2 hi = __builtin_convertvector(x, t16_h2);
+        o[2 * p] = hi[0];
+        o[2 * p + 1] = hi[1];
+    }
+    asm volatile("s_nop 1" : "+v"(o));
+    return o;
+}
+__device__ __forceinline__ t16_h4 t16_hi4(const v4f &a)
+{
+    const t16_h2 p0 = __builtin_convertvector(t16_f2{ a[0], a[1] }, t16_h2), p1 = __builtin_convertvector(t16_f2{ a[2], a[3] }, t16_h2);
+    return t16_h4{ p0[0], p0[1], p1[0], p1[1] };
+}
+
+__device__ __forceinline__ v4f t16_mfma(const t16_h8 &a, const t16_h8 &b, const v4f &c)
+{
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
+
+// forward layer: u[b] += W[b] X over KS k-steps (three products per term, small ones first).  `img` + `base` =
+// the layer's first pair, `lo16` = 16 * lane.
+template <int NB, int KS>
+__device__ __forceinline__ void t16_layer(v4f u[NB], const char *img, int base, int lo16, const T16HL B[KS])
+{
+#pragma unroll
+    for (int t = 0; t < KS; ++t) {
+        t16_h8 ahi[NB], alo[NB];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const char *p = img + base + (b * KS + t) * T16_PAIR + lo16;
+            ahi[b] = *reinterpret_cast<const t16_h8 *>(p);
+            alo[b] = *reinterpret_cast<const t16_h8 *>(p + T16_SUB);
+        }
+#pragma unroll
+        for (int b = 0; b < NB; ++b) u[b] = t16_mfma(alo[b], B[t].hi, u[b]);
+#pragma unroll
+        for (int b = 0; b < NB; ++b) u[b] = t16_mfma(ahi[b], B[t].lo, u[b]);
+#pragma unroll
+        for (int b = 0; b < NB; ++b) u[b] = t16_mfma(ahi[b], B[t].hi, u[b]);
+    }
+}
+// transposed product: dx[b_in] += W^T[b_in] dY over KS k-steps of the output units (hi parts only)
+template <int NBI, int KS>
+__device__ __forceinline__ void t16_chain(v4f dx[NBI], const char *img, int base, int lo16, const t16_h8 dY[KS])
+{
+#pragma unroll
+    for (int t = 0; t < KS; ++t) {
+        t16_h8 a[NBI];
+#pragma unroll
+        for (int b = 0; b < NBI; ++b) a[b] = *reinterpret_cast<const t16_h8 *>(img + base + (b * KS + t) * T16_SUB + lo16);
+#pragma unroll
+        for (int b = 0; b < NBI; ++b) dx[b] = t16_mfma(a[b], dY[t], dx[b]);
+    }
+}
+__device__ __forceinline__ v4f t16_ld4(const char *img, int byte_off)
+{
+    const float4 v = *reinterpret_cast<const float4 *>(img + byte_off);
+    return v4f{ v.x, v.y, v.z, v.w };
+}
+__device__ __forceinline__ v4f t16_bias(const char *img, int layer, int b, int q) { return t16_ld4(img, T16_BIAS + (layer * 64 + 16 * b + 4 * q) * 4); }
+
+// ---- staging image of one wave's tile for the sample-reduction products (dW = dY X^T): a matrix of 64 units x 16
+// samples of f16 kept as [sample s][16 chunks of 4 units] with chunk position  chunk ^ g(s),
+//     g(s) = (s1 << 3) | (s3 << 2) | (s2 << 1) | s0        (s3..s0 = bits of s)
+// The writer (lane = sample c, its 4 registers of block b = chunk 4b + q: one ds_write_b64) hits 16 distinct
+// chunk positions per 16-lane group; the owner's transposed read (ds_read_b64_tr_b16: 4 samples x 16 units per
+// 16-lane group, lane 4a+p supplies sample a's chunk 4b'+p) hits 32 distinct bank pairs per half-wave.
+constexpr int T16_STAGE_MAT = 16 * 128;       // bytes per matrix (Y or X)
+constexpr int T16_STAGE_WAVE = 2 * T16_STAGE_MAT;
+__host__ __device__ constexpr int t16_g(int s) { return (((s >> 1) & 1) << 3) | (((s >> 3) & 1) << 2) | (((s >> 2) & 1) << 1) | (s & 1); }
+
+typedef short t16_s4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) t16_s4 t16_lds_s4;
+__device__ __forceinline__ t16_h4 t16_tr4(const char *p)
+{
+    const t16_s4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((t16_lds_s4 *)(p));
+    return __builtin_bit_cast(t16_h4, v);
+}
+struct T16Lane {
+    int lo16;   // 16 * lane: this lane's 16 B of an operand sub-image
+    int w1;     // staging write: block b of this lane's sample goes to  mat + (w1 ^ (32 b))
+    int r1, r2; // staging reads: operand of unit block b', tile pair P, matrix M:  tr(P*2*WAVE + M*MAT + (r1 ^ (32 b'))) ++ tr(... r2 ...)
+};
+__device__ __forceinline__ T16Lane t16_lane(int lane)
+{
+    T16Lane L;
+    const int c = lane & 15, q = lane >> 4, a = (lane >> 2) & 3, p = lane & 3;
+    L.lo16 = lane * 16;
+    L.w1 = c * 128 + ((q ^ t16_g(c)) << 3);
+    const int s1 = 8 * (q & 1) + a, s2 = s1 + 4;  // samples this lane addresses in the two transposed reads
+    L.r1 = (q >> 1) * T16_STAGE_WAVE + s1 * 128 + ((p ^ t16_g(s1)) << 3);
+    L.r2 = (q >> 1) * T16_STAGE_WAVE + s2 * 128 + ((p ^ t16_g(s2)) << 3);
+    return L;
+}
+__device__ __forceinline__ void t16_stage_put(char *mat, const T16Lane &L, int b, const t16_h4 &v)
+{
+    *reinterpret_cast<t16_h4 *>(mat + (L.w1 ^ (32 * b))) = v;
+}
+// operand (A or B alike) for units 16b' + (lane & 15), samples of tiles 2P (q < 2) and 2P+1 (q >= 2): slot (q, j) = sample 8(q&1) + j
+__device__ __forceinline__ t16_h8 t16_stage_get(const char *pair_mat, const T16Lane &L, int b)
+{
+    const t16_h4 x0 = t16_tr4(pair_mat + (L.r1 ^ (32 * b))), x1 = t16_tr4(pair_mat + (L.r2 ^ (32 * b)));
+    return __builtin_shufflevector(x0, x1, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+__device__ __forceinline__ float t16_sum8(const t16_h8 &v, float acc)
+{
+    const t16_h2 one = { (_Float16)1.0f, (_Float16)1.0f };
+#pragma unroll
+    for (int p = 0; p < 4; ++p) acc = __builtin_amdgcn_fdot2(t16_h2{ v[2 * p], v[2 * p + 1] }, one, acc, false);
+    return acc;
+}
+
+// launchers (render_bwd_t16.hip)
+struct BwdArgs;
+int launch_pack_decoder_t16(const float *blob, const float *wf, char *out, hipStream_t st);
+
+}  // namespace scanerf

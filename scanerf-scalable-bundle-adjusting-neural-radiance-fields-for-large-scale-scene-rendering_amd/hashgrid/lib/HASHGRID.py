@@ -87,6 +87,21 @@ _i16, _i64, _bool = torch.int16, torch.int64, (torch.bool, torch.uint8)
 _I = ctypes.c_int
 
 
+def _pack_images(params, images):
+    p = params.contiguous()
+    ones = torch.ones(32, dtype=_f32, device=p.device)
+    for b in range(p.shape[0]):
+        check(lib().scanerf_pack_decoder(ctypes.c_void_p(p[b].data_ptr()), dev_ptr(ones, _f32, "wf"),
+                                         ctypes.c_void_p(images[b].data_ptr()), stream()), "pack_decoder")
+    return images
+
+
+def _new_images(params):
+    if params.dim() != 2 or params.shape[1] != 13994:
+        raise RuntimeError(f"scanerf: decoder blobs must be [nb, 13994], got {tuple(params.shape)}")
+    return torch.empty((params.shape[0], lib().scanerf_render_workspace_floats()), dtype=_f32, device=params.device)
+
+
 class PackedDecoders:
     """[nb, 13994] render-time decoder blobs packed once into the LDS images of the MFMA decoder (weight_feature == 1:
     the render-time decoder has no coarse-to-fine mask, decoder.h:169-218).  Owned by whoever owns the blobs
@@ -94,27 +109,20 @@ class PackedDecoders:
     place of the raw `params` tensor; call repack() after changing the blobs."""
 
     def __init__(self, params):
-        if params.dim() != 2 or params.shape[1] != 13994:
-            raise RuntimeError(f"scanerf: decoder blobs must be [nb, 13994], got {tuple(params.shape)}")
         self.params = params
-        self.images = torch.empty((params.shape[0], lib().scanerf_render_workspace_floats()), dtype=_f32, device=params.device)
+        self.images = _new_images(params)
         self.repack()
 
     def repack(self):
-        p = self.params.contiguous()
-        ones = torch.ones(32, dtype=_f32, device=p.device)
-        for b in range(p.shape[0]):
-            check(lib().scanerf_pack_decoder(ctypes.c_void_p(p[b].data_ptr()), dev_ptr(ones, _f32, "wf"),
-                                             ctypes.c_void_p(self.images[b].data_ptr()), stream()), "pack_decoder")
-        self.version = self.params._version
+        _pack_images(self.params, self.images)
         return self
 
 
 # Raw `params` tensors (the reference's calling convention) are packed on first use and remembered PER TENSOR OBJECT: the
-# entry holds a weak reference, is dropped when the tensor dies, and is only trusted while the reference still points at
-# the very same object and its version counter is unchanged -- an address recycled by the caching allocator for a new
-# tensor can never hit an old entry.  Writes that bypass the version counter (params.data[...] = ...) are not seen: own
-# a PackedDecoders and repack() instead.
+# entry holds only a WEAK reference to the tensor, is dropped when the tensor dies, and is trusted only while that
+# reference still points at the very same object and its version counter is unchanged -- an address recycled by the
+# caching allocator for a new tensor can never hit an old entry.  Writes that bypass the version counter
+# (params.data[...] = ...) are not seen: own a PackedDecoders and repack() instead.
 _images = {}
 
 
@@ -124,11 +132,11 @@ def _packed_images(params):
     import weakref
     key = id(params)
     hit = _images.get(key)
-    if hit is not None and hit[0]() is params and hit[1].version == params._version:
-        return hit[1].images
-    packed = PackedDecoders(params)
-    _images[key] = (weakref.ref(params, lambda _r, key=key: _images.pop(key, None)), packed)
-    return packed.images
+    if hit is not None and hit[0]() is params and hit[1] == params._version:
+        return hit[2]
+    images = _pack_images(params, _new_images(params))
+    _images[key] = (weakref.ref(params, lambda _r, key=key: _images.pop(key, None)), params._version, images)
+    return images
 
 
 def ray_block_intersection(rays_o, rays_d, block_corners, block_sizes, intersections):
