@@ -368,7 +368,7 @@ def main():
 
     # the same step with the exact-f32 decoder arithmetic (f32-input MFMA), timed the same way, printed beside the headline
     from scanerf_amd import render as _render
-    h3_run = path == "fused" and _render.ARITH == 1
+    h3_run = path == "fused" and _render.ARITH != 0
     dtype_label = ("f32 tables/accumulate/compositing; decoder GEMMs split-f16 x3 MFMA, f32 accumulate (22-bit operands)"
                    if h3_run else "f32")
     if occ:
@@ -386,7 +386,7 @@ def main():
             sync()
             f32_ms = (time.perf_counter() - f0) / args.steps * 1e3
         finally:
-            _render.set_arith("h3")
+            _render.set_arith(_render.DEFAULT_ARITH)
 
     with torch.no_grad():  # rays that meet no occupied cell are skipped by every kernel: they are not counted as work
         valid_frac = float((model.sample(rays_o, rays_d, S)[0] != -1).all(1).float().mean())
@@ -414,11 +414,13 @@ def main():
         if timer and timer.count:
             name, avg_ms, alg_bytes, alg_flops = timer.dominant()
             from scanerf_amd import render as _render
-            h3 = _render.ARITH == 1 and path == "fused"
+            h3 = _render.ARITH != 0 and path == "fused"
             # matrix-pipe floor of the launch: f32-input MFMA, or 3 f16 MFMAs per term for the split arithmetic
             mfma_peak = MFMA_F16_PEAK_TFLOPS if h3 else MFMA_F32_PEAK_TFLOPS
             t_hbm, t_mfma = alg_bytes / (HBM_PEAK_GBS * 1e9), (3 if h3 else 1) * alg_flops / (mfma_peak * 1e12)
-            line["config"]["decoder_arith"] = "split f16 x3 MFMA, f32 accumulate (csrc/render_h3.h)" if h3 else "f32 MFMA"
+            line["config"]["decoder_arith"] = ("f32 MFMA" if not h3 else "split f16 x3 MFMA, f32 accumulate (csrc/render_h3.h)" if _render.ARITH == 1
+                                               else "forward + backward recompute: split f16 x3 MFMA, f32 accumulate; gradient products: f16 MFMA, f32 "
+                                                    "accumulate, power-of-two scaled (csrc/render_t16.h)")
             if t_mfma > t_hbm:  # the kernel's floor is set by the matrix pipe, not by HBM
                 ach = alg_flops / (avg_ms * 1e-3) / 1e12
                 roof = {"bound": "mfma", "achieved": ach, "peak": mfma_peak, "unit": "TFLOP/s",

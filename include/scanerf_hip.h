@@ -134,11 +134,16 @@ typedef struct {
     int infinity;      /* dists[:, -1] = 1e10 (hashgrid/__init__.py:349-350) */
     float min_bbox[3];
     float bbox_size[3];
-    int arith; /* decoder arithmetic: SCANERF_ARITH_F32 (f32-input MFMA, exact f32) or SCANERF_ARITH_H3 (f16 MFMA
-                  on hi/lo-split operands, three products per term: f32-equivalent results, csrc/render_h3.h) */
+    int arith; /* decoder arithmetic: SCANERF_ARITH_F32 (f32-input MFMA, exact f32), SCANERF_ARITH_H3 (f16 MFMA
+                  on hi/lo-split operands, three products per term: f32-equivalent results, csrc/render_h3.h) or
+                  SCANERF_ARITH_T16 (forward as H3; backward on 16-sample tiles at two waves per SIMD with the
+                  forward recompute in H3 and the gradient products on one f16 MFMA per term, csrc/render_t16.h;
+                  needs the x-stash, has no pose-gradient outputs).  plan / backward / accumulate of one step
+                  must be given the same value */
 } scanerf_render_cfg;
 #define SCANERF_ARITH_F32 0
 #define SCANERF_ARITH_H3 1
+#define SCANERF_ARITH_T16 2
 
 /* Packs the decoder blob (+ weight_feature folded into the first layer) into the LDS image
  * the fused kernels stage (csrc/render_common.h).  workspace: scanerf_render_workspace_floats()
@@ -148,8 +153,8 @@ int scanerf_pack_decoder(const float *mlp_blob, const float *weight_feature, flo
                          scanerf_stream_t stream);
 
 /* ray_valid [B] u8 (may be NULL): rays with 0 render as zeros with T_left = 1
- * (hashgrid/__init__.py:427-431) and are skipped.  tile_T [B, ceil(S/32)] (may be NULL): the
- * transmittance entering each 32-sample tile, saved for scanerf_render_backward.  xstash [B*S,32] f32
+ * (hashgrid/__init__.py:427-431) and are skipped.  tile_T [B, ceil(S/16)] (may be NULL): the
+ * transmittance entering each 16-sample tile, saved for scanerf_render_backward.  xstash [B*S,32] f32
  * (may be NULL): the encoder outputs in register order, so the backward can skip the re-gather. */
 int scanerf_render_forward_packed(const float *rays_o, const float *rays_d, const float *z_vals,
                                   const float *dists, const void *features, int feat_dtype,

@@ -39,7 +39,7 @@ class RenderCfg(ctypes.Structure):
                 ("min_bbox", ctypes.c_float * 3), ("bbox_size", ctypes.c_float * 3), ("arith", ctypes.c_int)]
 
 
-ARITH_F32, ARITH_H3 = 0, 1
+ARITH_F32, ARITH_H3, ARITH_T16 = 0, 1, 2
 
 
 def lib():

@@ -16,6 +16,7 @@
 #include <stdlib.h>
 
 #include "render_h3.h"
+#include "render_t16.h"
 
 using namespace scanerf;
 
@@ -111,7 +112,7 @@ __global__ void __launch_bounds__(kRenderThreads, 2) k_render_fwd(RenderArgs a)
     const int waves_per_block = kRenderThreads / 64;
     const int wave0 = blockIdx.x * waves_per_block + (threadIdx.x >> 6);
     const int nwaves = gridDim.x * waves_per_block;
-    const int S = a.S, ntiles = (S + 31) >> 5;
+    const int S = a.S, ntiles = (S + 31) >> 5, nt16 = (S + 15) >> 4;
 
     for (int ray = wave0; ray < a.B; ray += nwaves) {
         float *outp = a.out_ray + (size_t)ray * SCANERF_RAY_OUT;
@@ -184,8 +185,9 @@ __global__ void __launch_bounds__(kRenderThreads, 2) k_render_fwd(RenderArgs a)
             }
             float excl = __shfl_up(incl, 1, 32);
             if (sl == 0) excl = 1.0f;
-            if (a.tile_T && lane == 0) a.tile_T[(size_t)ray * ntiles + tile] = T_run;
             const float Ti = T_run * excl;
+            // transmittance entering each 16-sample tile (samples 32 tile and 32 tile + 16): what the backward kernels start from
+            if (a.tile_T && (lane == 0 || (lane == 16 && s < S))) a.tile_T[(size_t)ray * nt16 + 2 * tile + (lane >> 4)] = Ti;
             const float w = alpha * Ti;
             T_run *= __shfl(incl, 31, 32);
             if (tile == ntiles - 1) T_left = __shfl(Ti, (S - 1) & 31, 32);  // T before the last sample (:358-360)
@@ -302,7 +304,7 @@ __global__ void __launch_bounds__(kRenderThreads, 2) k_render_fwd_h3(RenderArgs 
     const int waves_per_block = kRenderThreads / 64;
     const int wave0 = blockIdx.x * waves_per_block + (threadIdx.x >> 6);
     const int nwaves = gridDim.x * waves_per_block;
-    const int S = a.S, ntiles = (S + 31) >> 5;
+    const int S = a.S, ntiles = (S + 31) >> 5, nt16 = (S + 15) >> 4;
 
     for (int ray = wave0; ray < a.B; ray += nwaves) {
         float *outp = a.out_ray + (size_t)ray * SCANERF_RAY_OUT;
@@ -370,8 +372,9 @@ __global__ void __launch_bounds__(kRenderThreads, 2) k_render_fwd_h3(RenderArgs 
             }
             float excl = __shfl_up(incl, 1, 32);
             if (sl == 0) excl = 1.0f;
-            if (a.tile_T && lane == 0) a.tile_T[(size_t)ray * ntiles + tile] = T_run;
             const float Ti = T_run * excl;
+            // transmittance entering each 16-sample tile (samples 32 tile and 32 tile + 16): what the backward kernels start from
+            if (a.tile_T && (lane == 0 || (lane == 16 && s < S))) a.tile_T[(size_t)ray * nt16 + 2 * tile + (lane >> 4)] = Ti;
             const float w = alpha * Ti;
             T_run *= __shfl(incl, 31, 32);
             if (tile == ntiles - 1) T_left = __shfl(Ti, (S - 1) & 31, 32);
@@ -416,6 +419,8 @@ SCANERF_API int scanerf_pack_decoder(const float *mlp_blob, const float *weight_
     // the same decoder as f16 hi/lo operand pairs for the split-precision kernels (render_h3.h)
     hipLaunchKernelGGL(k_pack_decoder_h3, dim3((32 * 512 + 64 + 288 + 255) / 256), dim3(256), 0, (hipStream_t)stream,
                        mlp_blob, weight_feature, reinterpret_cast<char *>(workspace + PK_TOTAL));
+    // and as the 16-sample-tile images of the two-waves-per-SIMD backward kernel (render_t16.h)
+    launch_pack_decoder_t16(mlp_blob, weight_feature, reinterpret_cast<char *>(workspace + WS_T16), (hipStream_t)stream);
     return check_launch("pack_decoder");
 }
 
@@ -452,8 +457,8 @@ SCANERF_API int scanerf_render_forward_packed(const float *rays_o, const float *
     if (blocks > kNumCU) blocks = kNumCU;  // one resident 512-thread workgroup per CU (VGPR-bound), persistent
     dim3 grid(blocks), block(kRenderThreads);
     hipStream_t st = (hipStream_t)stream;
-    SCANERF_REQUIRE(cfg->arith == SCANERF_ARITH_F32 || cfg->arith == SCANERF_ARITH_H3, "render_forward: arith=%d", cfg->arith);
-    if (cfg->arith == SCANERF_ARITH_H3) {
+    SCANERF_REQUIRE(cfg->arith >= SCANERF_ARITH_F32 && cfg->arith <= SCANERF_ARITH_T16, "render_forward: arith=%d", cfg->arith);
+    if (cfg->arith != SCANERF_ARITH_F32) {  // (H3 and T16 differ in the backward kernel only)
         if (feat_dtype == SCANERF_F32) hipLaunchKernelGGL((k_render_fwd_h3<SCANERF_F32>), grid, block, 0, st, a);
         else if (feat_dtype == SCANERF_F16) hipLaunchKernelGGL((k_render_fwd_h3<SCANERF_F16>), grid, block, 0, st, a);
         else hipLaunchKernelGGL((k_render_fwd_h3<SCANERF_BF16>), grid, block, 0, st, a);

@@ -271,7 +271,7 @@ __global__ void __launch_bounds__(kBwdThreads, 1) k_render_bwd(BwdArgs a)
             }
             float excl = __shfl_up(incl, 1, 32);
             if (sl == 0) excl = 1.0f;
-            const float Ti = (tile < ntiles ? a.tile_T[(size_t)ray * ntiles + tile] : 0.0f) * excl;
+            const float Ti = (tile < ntiles ? a.tile_T[(size_t)ray * ((a.f.S + 15) >> 4) + 2 * tile] : 0.0f) * excl;
             const float w = alpha * Ti;
             // upstream gradients (uniform per ray; read through the scalar cache)
             float gD[3], gS[3], gTi[3];
@@ -645,10 +645,13 @@ SCANERF_API int scanerf_render_backward(const float *rays_o, const float *rays_d
         a.f.bbox_size[k] = cfg->bbox_size[k];
         a.f.inv_size4[k] = 4.0f / cfg->bbox_size[k];
     }
+    { const char *e = getenv("SCANERF_DEBUG_BWD"); a.f.dbg = e ? atoi(e) : 0; }  // timing experiments only (-DSCANERF_BWD_EXPERIMENTS builds)
     a.grad_out = grad_out; a.tile_T = tile_T; a.dfeat = dfeat; a.dw_partial = dw_partial; a.xstash = xstash;
     a.g_dnorm = g_dnorm; a.g_rowsum = g_rowsum;
-    SCANERF_REQUIRE(cfg->arith == SCANERF_ARITH_F32 || cfg->arith == SCANERF_ARITH_H3, "render_backward: arith=%d", cfg->arith);
-    const bool h3 = cfg->arith == SCANERF_ARITH_H3;
+    SCANERF_REQUIRE(cfg->arith >= SCANERF_ARITH_F32 && cfg->arith <= SCANERF_ARITH_T16, "render_backward: arith=%d", cfg->arith);
+    const bool h3 = cfg->arith == SCANERF_ARITH_H3, t16 = cfg->arith == SCANERF_ARITH_T16;
+    SCANERF_REQUIRE(!t16 || (xstash && !g_dnorm && !g_rowsum),
+                    "render_backward: arith T16 needs the forward's x-stash and has no pose-gradient outputs (use SCANERF_ARITH_H3)");
     const int blocks = scanerf_render_backward_grid(B);
     size_t lds_extra = 0;
     a.recs = nullptr;
@@ -661,7 +664,7 @@ SCANERF_API int scanerf_render_backward(const float *rays_o, const float *rays_d
         a.bins.NB = T >> a.bins.bucket_log;
         a.bins.W = blocks;
         a.bins.per_wg = 0;
-        a.bins.rpg = h3 ? 4 : 1;
+        a.bins.rpg = t16 ? 8 : (h3 ? 4 : 1);
         BinWorkspace w;
         SCANERF_REQUIRE(bin_workspace_carve(scatter_ws, scatter_ws_bytes, 16 * a.bins.NB, blocks, w),
                         "render_backward: scatter workspace too small (%zu B)", scatter_ws_bytes);
@@ -671,13 +674,16 @@ SCANERF_API int scanerf_render_backward(const float *rays_o, const float *rays_d
         lds_extra = (size_t)16 * a.bins.NB * sizeof(uint32_t);
     }
     hipStream_t st = (hipStream_t)stream;
-    hipError_t me = hipMemsetAsync(dw_partial, 0, (size_t)blocks * 4 * SCANERF_PARAMSIZE * sizeof(float), st);
+    // partial rows: one per wave (f32 / h3 kernels), one per workgroup (t16: every entry has one owner in the workgroup)
+    const int prows = t16 ? blocks : blocks * 4;
+    hipError_t me = hipMemsetAsync(dw_partial, 0, (size_t)prows * SCANERF_PARAMSIZE * sizeof(float), st);
     SCANERF_REQUIRE(me == hipSuccess, "render_backward: memset failed: %s", hipGetErrorString(me));
-    if (int e = h3 ? launch_render_bwd_h3(a, feat_dtype, blocks, lds_extra, st)
+    if (int e = t16 ? launch_render_bwd_t16(a, feat_dtype, blocks, lds_extra, st)
+              : h3 ? launch_render_bwd_h3(a, feat_dtype, blocks, lds_extra, st)
                    : launch_render_bwd_f32(a, feat_dtype, blocks, lds_extra, st))
         return e;
     if (int e = check_launch("render_backward")) return e;
-    hipLaunchKernelGGL(k_reduce_dw, dim3(ceil_div(SCANERF_PARAMSIZE, 64)), dim3(1024), 0, st, dw_partial, blocks * 4,
+    hipLaunchKernelGGL(k_reduce_dw, dim3(ceil_div(SCANERF_PARAMSIZE, 64)), dim3(1024), 0, st, dw_partial, prows,
                        weight_feature, grad_blob);
     return check_launch("render_backward(reduce)");
 }

@@ -9,7 +9,7 @@ namespace scanerf {
 struct BwdArgs {
     RenderArgs f;              // forward inputs (out_ray = forward outputs, read-only here)
     const float *grad_out;     // [B,16] dL/d(out_ray)
-    const float *tile_T;       // [B, ntiles] from the forward
+    const float *tile_T;       // [B, ceil(S/16)] from the forward: transmittance entering each 16-sample tile
     float *dfeat;              // [16][B*S][2]; may be null when recs != nullptr
     float *dw_partial;         // [nwaves][SCANERF_PARAMSIZE], zero-filled by the host wrapper
     const float *xstash;       // optional [B*S][2][16]: the forward's encoder outputs (skips the re-gather)
@@ -45,5 +45,6 @@ __device__ __forceinline__ float opaque1(float v)
 // launchers of the two arithmetics (defined next to their kernels); lds_extra = bytes of record cursors
 int launch_render_bwd_f32(const BwdArgs &a, int feat_dtype, int blocks, size_t lds_extra, hipStream_t st);
 int launch_render_bwd_h3(const BwdArgs &a, int feat_dtype, int blocks, size_t lds_extra, hipStream_t st);
+int launch_render_bwd_t16(const BwdArgs &a, int feat_dtype, int blocks, size_t lds_extra, hipStream_t st);
 
 }  // namespace scanerf

@@ -332,7 +332,7 @@ __global__ void __launch_bounds__(kThreads, 1) k_render_bwd_h3(BwdArgs a)
             }
             float excl = __shfl_up(incl, 1, 32);
             if (sl == 0) excl = 1.0f;
-            const float Ti = a.tile_T[(size_t)rayc * ntiles + tile] * excl;
+            const float Ti = a.tile_T[(size_t)rayc * ((S + 15) >> 4) + 2 * tile] * excl;
             const float w = alpha * Ti;
             float gD[3], gS[3], gTi[3];
 #pragma unroll

@@ -1,0 +1,770 @@
+// render_bwd_t16.hip -- fused per-ray volume rendering, backward, 16-sample tiles on v_mfma_f32_16x16x32_f16:
+// 8 waves per workgroup, TWO WAVES PER SIMD (render_t16.h explains why and gives the lane maps and images).
+//
+// Same adjoint as render_bwd_h3.hip (hashgrid/__init__.py:512-596 under autograd in the reference).  Structure:
+//   * one wave per ray, its 16-sample tiles walked last -> first (compositing adjoint = register carry);
+//   * the 8 waves of a workgroup walk their rays in lock step; every weight-gradient block (16 x 16) is OWNED by one
+//     wave, which sums it over the 8 waves' tiles (two tiles = one K = 32 MFMA) from their staged operands
+//     (28 accumulator registers per wave); one partial row per workgroup, reduced by k_reduce_dw;
+//   * forward recompute in split-f16 (three products per term); what the backward steps need from it is kept as
+//     f16 (hi parts of the activations, G'(u) of the three Gaussian layers): 48 registers, nothing is recomputed twice;
+//   * gradient products on ONE f16 MFMA per term under the workgroup's power-of-two scale (render_bwd_h3.hip);
+//   * the table-gradient scatter records are emitted here (scatter.hip), 4 levels per lane.
+// Not supported here (the caller falls back to render_bwd_h3.hip): pose-gradient outputs (g_dnorm / g_rowsum),
+// the re-gather without an x-stash.
+#include <stdlib.h>
+
+#include "render_bwd_common.h"
+#include "render_t16.h"
+
+using namespace scanerf;
+
+namespace {
+
+constexpr int kThreads = 512;
+constexpr int kWaves = 8;
+constexpr int kLdsRes = T16_BYTES;                            // resolutions [16][4] i32
+constexpr int kLdsDinit = kLdsRes + 256;                      // 8 waves x 64 f32: Dir layer-0 accumulator start of the wave's ray (unit order)
+constexpr int kLdsSh = kLdsDinit + kWaves * 256;              // 8 waves x SH[16]
+constexpr int kLdsMx = kLdsSh + kWaves * 64;                  // 8 floats
+constexpr int kLdsStage = kLdsMx + 64;                        // 8 waves x {Y, X}
+constexpr int kLdsCursor = kLdsStage + kWaves * T16_STAGE_WAVE;  // record cursors (fused scatter producer only)
+static_assert(kLdsStage % 16 == 0 && kLdsCursor % 16 == 0, "LDS carve alignment");
+
+// ------------------------------------------------------------------ pack: blob -> t16 images
+__global__ void __launch_bounds__(256) k_pack_decoder_t16(const float *__restrict__ blob, const float *__restrict__ wf,
+                                                          char *__restrict__ out)
+{
+    auto W = [&](int base, int n_out, int n, int k) { return blob[base + n_out + k * n_out + n]; };
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < 32 * 512) {  // forward image: one thread per (pair, lane, j)
+        const int pair = e >> 9, lane = (e >> 3) & 63, j = e & 7;
+        const int m = lane & 15, q = lane >> 4;
+        int pp = pair, layer, ks;
+        if (pp < 4) { layer = 0; ks = 1; }
+        else if ((pp -= 4) < 8) { layer = 1; ks = 2; }
+        else if ((pp -= 8) < 2) { layer = 2; ks = 1; }
+        else if ((pp -= 2) < 8) { layer = 3; ks = 2; }
+        else if ((pp -= 8) < 8) { layer = 4; ks = 2; }
+        else { pp -= 8; layer = 5; ks = 2; }
+        const int b = pp / ks, t = pp % ks;
+        const int n = 16 * b + m, ku = t16_ku(t, q, j);
+        float w = 0.0f;
+        if (layer == 0) {
+            const int k = t16_pos_to_input(8 * q + j);
+            w = W(BLOB_S0, 64, n, k) * wf[k];
+        } else if (layer == 1) w = W(BLOB_S1, 64, n, ku);
+        else if (layer == 2) {  // heads on H[:32] (k-step 0 of H): rows replicated in every q
+            const int r = m & 3;
+            if (b == 0) w = r == 0 ? W(BLOB_SIG, 1, 0, ku) : W(BLOB_DIF, 3, r - 1, ku);
+            else if (r < 3) w = W(BLOB_TINT, 3, r, ku);
+        } else if (layer == 3) {
+            if (t == 0) w = W(BLOB_D0, 64, n, ku);                      // input k = H[32 + k], slot unit ku(0, q, j) - 0
+            else if (q < 2) w = W(BLOB_D0, 64, n, 32 + 8 * q + j);      // SH part
+        } else if (layer == 4) w = W(BLOB_D1, 64, n, ku);
+        else {
+            const int r = m & 3;
+            if (r < 3) w = W(BLOB_D2, 3, r, ku);
+        }
+        const _Float16 hi = (_Float16)w, lo = (_Float16)(w - (float)hi);
+        char *p = out + pair * T16_PAIR + lane * 16 + j * 2;
+        *reinterpret_cast<_Float16 *>(p) = hi;
+        *reinterpret_cast<_Float16 *>(p + T16_SUB) = lo;
+    } else if (e < 32 * 512 + 30 * 512) {  // transposed image (hi only): lane (m, q), j: W[n = ku(t, q, j)][i = 16 b_in + m]
+        const int f = e - 32 * 512;
+        const int sub = f >> 9, lane = (f >> 3) & 63, j = f & 7;
+        const int m = lane & 15, q = lane >> 4;
+        int ss = sub, layer, ks;
+        if (ss < 4) { layer = 5; ks = 1; }
+        else if ((ss -= 4) < 8) { layer = 4; ks = 2; }
+        else if ((ss -= 8) < 4) { layer = 3; ks = 2; }
+        else if ((ss -= 4) < 2) { layer = 2; ks = 1; }
+        else if ((ss -= 2) < 8) { layer = 1; ks = 2; }
+        else { ss -= 8; layer = 0; ks = 2; }
+        const int bi = ss / ks, t = ss % ks;
+        const int n = t16_ku(t, q, j), i = 16 * bi + m;
+        float w = 0.0f;
+        if (layer == 5) {           // narrow rows 8..10 = rgb
+            if (n >= 8 && n < 11) w = W(BLOB_D2, 3, n - 8, i);
+        } else if (layer == 4) w = W(BLOB_D1, 64, n, i);
+        else if (layer == 3) w = W(BLOB_D0, 64, n, i);      // i = 16 b_in + m in 0..31 <-> H[32 + i]
+        else if (layer == 2) {      // narrow rows 0..6 = sigma, dif, tint; i = H unit 0..31
+            if (n == 0) w = W(BLOB_SIG, 1, 0, i);
+            else if (n < 4) w = W(BLOB_DIF, 3, n - 1, i);
+            else if (n < 7) w = W(BLOB_TINT, 3, n - 4, i);
+        } else if (layer == 1) w = W(BLOB_S1, 64, n, i);
+        else {
+            const int k = t16_pos_to_input(t16_l0_row_to_pos(bi, m));
+            w = W(BLOB_S0, 64, n, k) * wf[k];
+        }
+        *reinterpret_cast<_Float16 *>(out + T16_FWD_BYTES + sub * T16_SUB + lane * 16 + j * 2) = (_Float16)w;
+    } else if (e < 62 * 512 + 272) {
+        const int t = e - 62 * 512;
+        float v = 0.0f;
+        if (t < 256) {
+            const int bases[4] = { BLOB_S0, BLOB_S1, BLOB_D0, BLOB_D1 };
+            v = blob[bases[t >> 6] + (t & 63)];
+        } else if (t < 260) v = t == 256 ? blob[BLOB_SIG] : blob[BLOB_DIF + t - 257];
+        else if (t < 264) v = t < 263 ? blob[BLOB_TINT + t - 260] : 0.0f;
+        else if (t < 268) v = t < 267 ? blob[BLOB_D2 + t - 264] : 0.0f;
+        reinterpret_cast<float *>(out + T16_BIAS)[t] = v;
+    }
+}
+
+// ------------------------------------------------------------------ device helpers
+// A lane index the optimiser cannot trace back.  LDS addresses derived from the plain lane index are loop invariants: the
+// ~60 distinct ones this kernel uses (operand slots in three 64 KB windows, bias rows, the XOR-swizzled staging slots of
+// every block) get hoisted out of the tile loop and held -- or spilled -- for its whole duration.  Derived from an opaque
+// copy they are recomputed where they are used (a handful of VALU per step).
+__device__ __forceinline__ int fresh(int v)
+{
+    asm volatile("" : "+v"(v));
+    return v;
+}
+__device__ __forceinline__ T16Lane fresh_lane(const T16Lane &L)
+{
+    T16Lane r;
+    r.lo16 = fresh(L.lo16);
+    r.w1 = fresh(L.w1);
+    r.r1 = fresh(L.r1);
+    r.r2 = fresh(L.r2);
+    return r;
+}
+template <int N>
+__device__ __forceinline__ void zero4(v4f (&v)[N])
+{
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] = v4f{ 0, 0, 0, 0 };
+}
+// Gaussian activation of a block and its derivative factor G'(u) = -100 u G(u) as f16
+__device__ __forceinline__ void act_deriv(v4f &u, t16_h4 &dg)
+{
+    v4f d;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const float a = gauss_fast(u[g]);
+        d[g] = -100.0f * u[g] * a;
+        u[g] = a;
+    }
+    dg = t16_hi4(d);
+}
+__device__ __forceinline__ v4f mul_dg(const v4f &a, const t16_h4 &dg)
+{
+    return v4f{ a[0] * (float)dg[0], a[1] * (float)dg[1], a[2] * (float)dg[2], a[3] * (float)dg[3] };
+}
+__device__ __forceinline__ t16_h4 lo4(const t16_h8 &v) { return __builtin_shufflevector(v, v, 0, 1, 2, 3); }
+__device__ __forceinline__ t16_h4 hi4(const t16_h8 &v) { return __builtin_shufflevector(v, v, 4, 5, 6, 7); }
+
+// Weight-gradient blocks owned by this wave: acc[i] += sum over the 4 tile pairs of dY[yb] X[xb0 + i]^T (operands read back
+// transposed from the pairs' staging images).  ROWSUM: also accumulate this lane's row sums of dY (bias gradients).
+template <int NX, bool ROWSUM, int XSTRIDE = 1>
+__device__ __forceinline__ void wgrad(v4f *acc, float &rowsum, const char *stage, const T16Lane &L, int yb, int x_mat_off, int xb0)
+{
+#pragma unroll
+    for (int P = 0; P < 4; ++P) {
+        const char *pm = stage + P * 2 * T16_STAGE_WAVE;
+        const t16_h8 a = t16_stage_get(pm, L, yb);
+        t16_h8 b[NX];
+#pragma unroll
+        for (int i = 0; i < NX; ++i) b[i] = t16_stage_get(pm + x_mat_off, L, xb0 + i * XSTRIDE);
+        if (ROWSUM) rowsum = t16_sum8(a, rowsum);
+#pragma unroll
+        for (int i = 0; i < NX; ++i) acc[i] = t16_mfma(a, b[i], acc[i]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+template <int DT>
+__global__ void __launch_bounds__(kThreads, 2) k_render_bwd_t16(BwdArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    int *lres = reinterpret_cast<int *>(lds + kLdsRes);
+    uint32_t *cursor = reinterpret_cast<uint32_t *>(lds + kLdsCursor);
+    float *shbuf = reinterpret_cast<float *>(lds + kLdsSh);
+    float *mxbuf = reinterpret_cast<float *>(lds + kLdsMx);
+    {
+        const float4 *src = reinterpret_cast<const float4 *>(a.f.packed + WS_T16);
+        float4 *dst = reinterpret_cast<float4 *>(lds);
+        for (int i = threadIdx.x; i < T16_BYTES / 16; i += kThreads) dst[i] = src[i];
+        if (threadIdx.x < 64) {
+            const int lv = threadIdx.x >> 2, c = threadIdx.x & 3;
+            lres[threadIdx.x] = c < 3 ? a.f.resolutions[3 * lv + c] : 0;
+        }
+        float4 *stz = reinterpret_cast<float4 *>(lds + kLdsStage);  // finite contents wherever a step leaves a block unwritten
+        for (int i = threadIdx.x; i < kWaves * T16_STAGE_WAVE / 16; i += kThreads) stz[i] = make_float4(0, 0, 0, 0);
+        if (a.recs) {
+            const int nbins = 16 * a.bins.NB;
+            for (int i = threadIdx.x; i < nbins; i += kThreads)
+                cursor[i] = a.bin_starts[i] + a.bin_rowprefix[(size_t)i * a.bins.W + blockIdx.x];
+        }
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: ray index, per-ray loads and branches go scalar
+    const char *stage = lds + kLdsStage;
+    char *stY = lds + kLdsStage + wv * T16_STAGE_WAVE, *stX = stY + T16_STAGE_MAT;
+    const int S = a.f.S, nt16 = (S + 15) >> 4;
+    __builtin_amdgcn_s_setreg(1 | (23 << 6), 1);  // hwreg(HW_REG_MODE, 23, 1) = FP16_OVFL: f16 conversions saturate
+
+    // ---- ownership of the weight-gradient blocks
+    const int rb = wv >> 1, cb = wv & 1;
+    v4f gW_D1[2], gW_L1[2], gW_D0[2], gW_L0[1], gW_nar[1];   // gW_D0: [0] = H part (block cb), [1] = SH part (cb == 0 only)
+    zero4(gW_D1); zero4(gW_L1); zero4(gW_D0); zero4(gW_L0); zero4(gW_nar);
+    float gB_D1 = 0.0f, gB_L1 = 0.0f, gB_D0 = 0.0f, gB_L0 = 0.0f, gB_nar = 0.0f;  // (cb == 0 / wave 0) lane = unit, this lane's 8 samples of every pair
+    float gmax = 0.0f;
+    int K = 0;                             // gradient scale 2^K of the workgroup (identical in its 8 waves)
+    float sc = 1.0f, isc = 1.0f;
+
+    const int ngroups_all = (a.f.B + kWaves - 1) / kWaves;
+    for (int grp = blockIdx.x; grp < ngroups_all; grp += gridDim.x) {
+        const int ray = kWaves * grp + wv;
+        const bool active = ray < a.f.B && !(a.f.ray_valid && !a.f.ray_valid[ray]);  // wave-uniform
+        const int rayc = active ? ray : 0;  // inactive waves run on ray 0's geometry with zero inputs and gradients
+        if (ray < a.f.B && !active && a.dfeat)  // invalid ray: zero feature gradients
+            for (int s = lane >> 2; s < S; s += 16)
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj)
+                    reinterpret_cast<float2 *>(a.dfeat)[(size_t)(4 * jj + (lane & 3)) * a.f.B * S + (size_t)ray * S + s] = make_float2(0, 0);
+        float o[3], d[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            o[k] = a.f.rays_o[3 * rayc + k];
+            d[k] = a.f.rays_d[3 * rayc + k];
+        }
+        const float dnorm = sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+        const float *go = a.grad_out + (size_t)rayc * SCANERF_RAY_OUT;
+        const float *fo = a.f.out_ray + (size_t)rayc * SCANERF_RAY_OUT;
+        {   // per ray: SH (published for the owners of the SH part) and the Dir layer-0 accumulator start, parked in LDS
+            const int ln = fresh(lane), c = ln & 15, q = ln >> 4;
+            const T16Lane L = t16_lane(ln);
+            float sh[16];
+            ray_sh(d, dnorm, sh);
+            v4f s0, s1;  // B operand of the SH k-step: slot (q, j) = SH[8q + j] for q < 2, zero above
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                s0[j] = q == 0 ? sh[j] : (q == 1 ? sh[8 + j] : 0.0f);
+                s1[j] = q == 0 ? sh[4 + j] : (q == 1 ? sh[12 + j] : 0.0f);
+            }
+            const T16HL shB = t16_split(s0, s1);
+            v4f dinit[4];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) dinit[b] = t16_bias(lds, 2, b, q);
+            // k-step 1 of the D0 pairs
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const char *p = lds + T16_D0 + (b * 2 + 1) * T16_PAIR + L.lo16;
+                const t16_h8 ahi = *reinterpret_cast<const t16_h8 *>(p), alo = *reinterpret_cast<const t16_h8 *>(p + T16_SUB);
+                dinit[b] = t16_mfma(alo, shB.hi, dinit[b]);
+                dinit[b] = t16_mfma(ahi, shB.lo, dinit[b]);
+                dinit[b] = t16_mfma(ahi, shB.hi, dinit[b]);
+            }
+            if (c == 0) {
+                float4 *dp = reinterpret_cast<float4 *>(lds + kLdsDinit + wv * 256);
+#pragma unroll
+                for (int b = 0; b < 4; ++b) dp[4 * b + q] = make_float4(dinit[b][0], dinit[b][1], dinit[b][2], dinit[b][3]);
+            }
+            if (lane < 16) {
+                float v = 0.0f;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) v = lane == j ? sh[j] : v;
+                shbuf[wv * 16 + lane] = v;
+            }
+        }
+        float Rcarry = 0.0f;              // sum of a_j w_j over all later tiles of the ray
+
+        // Feature gradients of one tile: dfeat rows and / or the scatter records (scatter.hip) into the ranges the plan
+        // reserved.  e0 / e1 = dX blocks 0 / 1: register g of block e = x-stash position 8q + 4e + g = feature g & 1 of this
+        // lane's level jj = 2e + (g >> 1); level(q, jj) = 4(j8 >> 1) + 2(q >> 1) + (j8 & 1) with j8 = 4(q & 1) + jj.
+        auto emit_tile = [&](int tile_e, const v4f &e0, const v4f &e1) {
+            const int ln = fresh(lane), c = ln & 15, q = ln >> 4;
+            const int s = tile_e * 16 + c;
+            if (!(s < S) || !active) return;
+            auto lvl = [&](int jj) { const int j8 = 4 * (q & 1) + jj; return 4 * (j8 >> 1) + 2 * (q >> 1) + (j8 & 1); };
+            if (a.dfeat) {
+                const size_t n = (size_t)ray * S + s, NS = (size_t)a.f.B * S;
+                reinterpret_cast<float2 *>(a.dfeat)[(size_t)lvl(0) * NS + n] = make_float2(e0[0], e0[1]);
+                reinterpret_cast<float2 *>(a.dfeat)[(size_t)lvl(1) * NS + n] = make_float2(e0[2], e0[3]);
+                reinterpret_cast<float2 *>(a.dfeat)[(size_t)lvl(2) * NS + n] = make_float2(e1[0], e1[1]);
+                reinterpret_cast<float2 *>(a.dfeat)[(size_t)lvl(3) * NS + n] = make_float2(e1[2], e1[3]);
+            }
+            if (a.recs) {
+                float pe[3];
+                contract_point(a.f, o, d, a.f.z_vals[(size_t)rayc * S + s], pe);
+                const uint32_t mask = (uint32_t)a.f.T - 1u;
+                // one level at a time (a second set of index registers in flight -- the 32-sample kernel's software pipeline --
+                // does not fit the 256-register budget)
+#pragma unroll 1
+                for (int jj = 0; jj < 4; ++jj) {
+                    const int level = lvl(jj);
+                    const int4 r = *reinterpret_cast<const int4 *>(lres + 4 * level);
+                    const int32_t rr[3] = { r.x, r.y, r.z };
+                    Pairs pr;
+                    make_pairs(pe, rr, mask, pr);
+                    const float gx = jj == 0 ? e0[0] : (jj == 1 ? e0[2] : (jj == 2 ? e1[0] : e1[2]));
+                    const float gy = jj == 0 ? e0[1] : (jj == 1 ? e0[3] : (jj == 2 ? e1[1] : e1[3]));
+                    gmax = fmaxf(gmax, fmaxf(fabsf(gx), fabsf(gy)));
+                    uint32_t *cl = cursor + level * a.bins.NB;
+                    float *gl = a.grad_features + (size_t)level * a.f.T * 2;
+                    if ((a.f.dbg & 15) == 0) emit_pairs(pr, gx, gy, cl, a.bins.bucket_log, a.bins.capacity, a.recs, gl);
+#ifdef SCANERF_BWD_EXPERIMENTS
+                    else if ((a.f.dbg & 15) == 1) emit_pairs<1>(pr, gx, gy, cl, a.bins.bucket_log, a.bins.capacity, a.recs, gl);
+                    else if ((a.f.dbg & 15) == 2) emit_pairs<2>(pr, gx, gy, cl, a.bins.bucket_log, a.bins.capacity, a.recs, gl);
+                    else if ((a.f.dbg & 15) == 3) emit_pairs<3>(pr, gx, gy, cl, a.bins.bucket_log, a.bins.capacity, a.recs, gl);
+                    else if ((a.f.dbg & 15) == 4) emit_pairs<4>(pr, gx, gy, cl, a.bins.bucket_log, a.bins.capacity, a.recs, gl);
+                    else emit_pairs<8>(pr, gx, gy, cl, a.bins.bucket_log, a.bins.capacity, a.recs, gl);
+#endif
+                }
+            }
+        };
+        // EMISSION IS STAGGERED between the two waves of a SIMD (waves w and w + 4).  All 8 waves reach the end of a tile
+        // together; emitting there they would all wait on cursor round trips and record stores at the same time and then all
+        // compute at the same time.  Waves 4-7 therefore carry their tile's gradients over the NEXT tile's forward recompute
+        // (which needs no barrier) and emit after it: while one wave of a SIMD waits on its records the other one computes.
+#ifdef SCANERF_BWD_EXPERIMENTS
+        const int dm = a.f.dbg >> 4;
+        const bool defer = dm == 0 ? wv >= 4 : (dm == 1 ? (wv & 1) : (dm == 2 ? false : ((wv >> 1) & 1)));
+#else
+        const bool defer = wv >= 4;
+#endif
+        v4f pdx0 = { 0, 0, 0, 0 }, pdx1 = { 0, 0, 0, 0 };
+        int ptile = -1;
+
+        // A tile's inputs are loaded ONE TILE AHEAD, before the previous tile's records are stored: vector-memory operations
+        // complete in issue order, so a load issued behind the 16 record stores of a tile would not return before they
+        // have drained -- at the write rate of the whole chip, the stores' latency would be exposed at the top of every
+        // tile (measured: 2.0 of 5.5 ms).  Issued first, the loads (and the HBM misses of the x-stash) have a whole tile to land.
+        struct TileIn {
+            float z, dist, tT;
+            v4f xa, xb;
+        };
+        auto load_tile = [&](int t) {
+            TileIn in;
+            const int ln = fresh(lane), c = ln & 15, q = ln >> 4;
+            const int s = t * 16 + c;
+            const bool live = s < S;
+            in.z = live ? a.f.z_vals[(size_t)rayc * S + s] : 0.0f;
+            in.dist = live ? a.f.dists[(size_t)rayc * S + s] : 0.0f;
+            in.tT = a.tile_T[(size_t)rayc * nt16 + t];
+            in.xa = v4f{ 0, 0, 0, 0 };
+            in.xb = v4f{ 0, 0, 0, 0 };
+            if (active) {
+                const float4 *xs = reinterpret_cast<const float4 *>(a.xstash + ((size_t)ray * S + (live ? s : 0)) * 32 + 8 * q);
+                const float4 q0 = xs[0], q1 = xs[1];
+                in.xa = v4f{ q0.x, q0.y, q0.z, q0.w };
+                in.xb = v4f{ q1.x, q1.y, q1.z, q1.w };
+            }
+            return in;
+        };
+        TileIn nxt = load_tile(nt16 - 1);
+        for (int tile = nt16 - 1; tile >= 0; --tile) {
+            const int ln = fresh(lane);               // this tile's lane terms (not loop invariants: see fresh())
+            const int c = ln & 15, q = ln >> 4;
+            T16Lane L = t16_lane(ln);
+            const int s = tile * 16 + c;
+            const bool live = s < S;
+            const float z = nxt.z, dist_i = nxt.dist, tile_T_in = nxt.tT;
+            float delta = dist_i * dnorm;
+            if (a.f.infinity && s == S - 1) delta = 1e10f;
+
+            // ================= forward recompute =================
+            const v4f xa = nxt.xa, xb = nxt.xb;
+            t16_h8 xh, a0h[2], c0h[2], c1h[2], Hh[2];   // hi parts kept for the weight gradients
+            t16_h4 dg0[4], dgv0[4], dgv1[4];           // G'(u0), G'(v0), G'(v1)
+            float sigma, dsig_dpre, dif[3], tint[3], spec[3];
+            {
+                T16HL HB[2];
+                {
+                    const T16HL xB = t16_split(xa, xb);
+                    xh = xB.hi;
+                    v4f u[4];
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) u[b] = t16_bias(lds, 0, b, q);
+                    t16_layer<4, 1>(u, lds, T16_L0, L.lo16, &xB);
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) act_deriv(u[b], dg0[b]);
+                    const T16HL aB[2] = { t16_split(u[0], u[1]), t16_split(u[2], u[3]) };
+                    a0h[0] = aB[0].hi;
+                    a0h[1] = aB[1].hi;
+                    v4f hh[4];
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) hh[b] = t16_bias(lds, 1, b, q);
+                    t16_layer<4, 2>(hh, lds, T16_L1, L.lo16, aB);
+                    HB[0] = t16_split(hh[0], hh[1]);
+                    HB[1] = t16_split(hh[2], hh[3]);
+                    Hh[0] = HB[0].hi;
+                    Hh[1] = HB[1].hi;
+                }
+                {   // heads on H[:32]
+                    v4f hd[2] = { t16_ld4(lds, T16_BIAS + 256 * 4), t16_ld4(lds, T16_BIAS + 260 * 4) };
+                    t16_layer<2, 1>(hd, lds, T16_HEAD, L.lo16, &HB[0]);
+                    sigma = softplus_(hd[0][0]);
+                    dsig_dpre = hd[0][0] > 20.0f ? 1.0f : sigmoid_fast(hd[0][0]);
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        dif[k] = sigmoid_fast(hd[0][1 + k]);
+                        tint[k] = sigmoid_fast(hd[1][k]);
+                    }
+                }
+                T16HL cB[2];
+                {   // Directional_MLP.mlp.0: H[32:64] part; SH part + bias in dinit
+                    v4f v[4];
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) v[b] = t16_ld4(lds, kLdsDinit + wv * 256 + (16 * b + 4 * q) * 4);
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) {  // k-step 0 of the D0 pairs
+                        const char *p = lds + T16_D0 + (b * 2) * T16_PAIR + L.lo16;
+                        const t16_h8 ahi = *reinterpret_cast<const t16_h8 *>(p), alo = *reinterpret_cast<const t16_h8 *>(p + T16_SUB);
+                        v[b] = t16_mfma(alo, HB[1].hi, v[b]);
+                        v[b] = t16_mfma(ahi, HB[1].lo, v[b]);
+                        v[b] = t16_mfma(ahi, HB[1].hi, v[b]);
+                    }
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) act_deriv(v[b], dgv0[b]);
+                    cB[0] = t16_split(v[0], v[1]);
+                    cB[1] = t16_split(v[2], v[3]);
+                    c0h[0] = cB[0].hi;
+                    c0h[1] = cB[1].hi;
+                }
+                {
+                    v4f v[4];
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) v[b] = t16_bias(lds, 3, b, q);
+                    t16_layer<4, 2>(v, lds, T16_D1, L.lo16, cB);
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) act_deriv(v[b], dgv1[b]);
+                    cB[0] = t16_split(v[0], v[1]);
+                    cB[1] = t16_split(v[2], v[3]);
+                    c1h[0] = cB[0].hi;
+                    c1h[1] = cB[1].hi;
+                }
+                {
+                    v4f r[1] = { t16_ld4(lds, T16_BIAS + 264 * 4) };
+                    t16_layer<1, 2>(r, lds, T16_D2, L.lo16, cB);
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) spec[k] = sigmoid_fast(r[0][k]);
+                }
+            }
+
+            if (defer && ptile >= 0) emit_tile(ptile, pdx0, pdx1);  // the previous tile's records (see emit_tile)
+
+            // ================= compositing: recompute and adjoint (16-lane scans, identical in the 4 lane groups) =================
+            const float ex = live ? expf(-sigma * delta) : 1.0f;  // 1 - alpha
+            const float alpha = 1.0f - ex;
+            const float fi = 1.0f - alpha + 1e-6f;
+            float incl = fi;
+#pragma unroll
+            for (int off = 1; off < 16; off <<= 1) {
+                const float t = __shfl_up(incl, off, 16);
+                if (c >= off) incl *= t;
+            }
+            float excl = __shfl_up(incl, 1, 16);
+            if (c == 0) excl = 1.0f;
+            const float Ti = tile_T_in * excl;
+            const float w = alpha * Ti;
+            float gD[3], gS[3], gTi[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const float pre = fo[5 + k] + fo[8 + k];  // diffuse + specular before the clamp
+                const float grgb = (pre >= 0.0f && pre <= 1.0f) ? go[k] : 0.0f;
+                gD[k] = go[5 + k] + grgb;
+                gS[k] = go[8 + k] + grgb;
+                gTi[k] = go[11 + k];
+            }
+            const float gDepth = go[3], gTl = go[4], gW2 = go[14], Tl = fo[4];
+            float ai = gDepth * z;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) ai += gD[k] * dif[k] + gS[k] * tint[k] * spec[k] + gTi[k] * tint[k];
+            const float aw = live ? ai * w : 0.0f;
+            float rs = aw;  // inclusive suffix sum inside the tile
+#pragma unroll
+            for (int off = 1; off < 16; off <<= 1) {
+                const float t = __shfl_down(rs, off, 16);
+                if (c + off < 16) rs += t;
+            }
+            const float suffix = Rcarry + rs - aw;
+            Rcarry += __shfl(rs, 0, 16);
+            float dalpha = Ti * ai - (suffix + ((s < S - 1) ? gTl * Tl : 0.0f)) / fi;
+            if (!live) dalpha = 0.0f;
+            const float dsigma = dalpha * delta * ex;
+            float gh[7], gs3[3];  // gradients w.r.t. the head / rgb pre-activations
+            gh[0] = dsigma * dsig_dpre;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                gh[1 + k] = w * gD[k] * dif[k] * (1.0f - dif[k]);
+                gh[4 + k] = w * (gS[k] * spec[k] + gTi[k]) * tint[k] * (1.0f - tint[k]);
+                gs3[k] = (w * gS[k] * tint[k] + gW2 * w * 2.0f * spec[k]) * spec[k] * (1.0f - spec[k]);
+            }
+            if (!active) {  // select, not multiply: the inputs of an inactive wave may be anything
+#pragma unroll
+                for (int k = 0; k < 7; ++k) gh[k] = 0.0f;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) gs3[k] = 0.0f;
+            }
+            {   // this tile's largest |gradient|, published for the workgroup's scale
+                float mx = 0.0f;
+#pragma unroll
+                for (int k = 0; k < 7; ++k) mx = fmaxf(mx, fabsf(gh[k]));
+#pragma unroll
+                for (int k = 0; k < 3; ++k) mx = fmaxf(mx, fabsf(gs3[k]));
+#pragma unroll
+                for (int off = 8; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 16));
+                if (lane == 0) mxbuf[wv] = mx;
+            }
+            __syncthreads();  // ---- S: tile maxima visible; every wave is done with the previous tile's staged operands
+            {   // gradient scale: keep the workgroup's largest |gradient| * 2^K in [2^2, 2^6): with single f16 operands the
+                // 8 tiles' smaller gradients need the room BELOW the maximum (full precision down to 2^-19 of it, subnormal to
+                // 2^-29), the chains' growth through G' <= 6 and the weights the 2^10 above it
+                const float4 m0 = reinterpret_cast<const float4 *>(mxbuf)[0], m1 = reinterpret_cast<const float4 *>(mxbuf)[1];
+                const float mx = fmaxf(fmaxf(fmaxf(m0.x, m0.y), fmaxf(m0.z, m0.w)), fmaxf(fmaxf(m1.x, m1.y), fmaxf(m1.z, m1.w)));
+                const float ms = mx * sc;
+                if (mx > 0.0f && mx < 3.0e38f && (ms >= 64.0f || ms < 4.0f)) {
+                    int e;
+                    frexpf(mx, &e);  // mx = f * 2^e, f in [0.5, 1)
+                    int Kn = 6 - e;  // mx * 2^K in [32, 64)
+                    Kn = Kn > K + 100 ? K + 100 : (Kn < K - 100 ? K - 100 : Kn);  // rescale factor stays an f32 power of two
+                    Kn = Kn > 100 ? 100 : (Kn < -100 ? -100 : Kn);
+                    const float r = ldexpf(1.0f, Kn - K);
+                    K = Kn;
+                    sc = ldexpf(1.0f, K);
+                    isc = ldexpf(1.0f, -K);
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) { gW_D1[i] *= r; gW_L1[i] *= r; }
+                    gW_D0[0] *= r; gW_D0[1] *= r; gW_L0[0] *= r; gW_nar[0] *= r;
+                    gB_D1 *= r; gB_L1 *= r; gB_D0 *= r; gB_L0 *= r; gB_nar *= r;
+                }
+#pragma unroll
+                for (int k = 0; k < 7; ++k) gh[k] *= sc;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) gs3[k] *= sc;
+            }
+            // ================= narrow layers: heads (32 -> 7) and rgb (64 -> 3) =================
+            L = fresh_lane(L);
+            // one 16-row block: rows 0-3 sigma, dif; 4-6 tint; 8-10 rgb  (lane group q holds rows 4q .. 4q+3)
+            t16_h8 narB;   // B operand of the transposed products (second block of the k-step = zeros)
+            {
+                v4f nar;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float r1 = g < 3 ? gh[4 + g] : 0.0f, r2 = g < 3 ? gs3[g] : 0.0f;
+                    nar[g] = q == 0 ? gh[g] : (q == 1 ? r1 : (q == 2 ? r2 : 0.0f));
+                }
+                const v4f zero = { 0, 0, 0, 0 };
+                narB = t16_hi(nar, zero);
+                t16_stage_put(stY, L, 0, lo4(narB));
+                t16_stage_put(stY, L, 2, lo4(Hh[0]));   // X operand of the heads' weight gradient: H[:32] in blocks 2, 3 of Y
+                t16_stage_put(stY, L, 3, hi4(Hh[0]));
+                t16_stage_put(stX, L, 0, lo4(c1h[0]));  // X operand of the rgb layer's weight gradient
+                t16_stage_put(stX, L, 1, hi4(c1h[0]));
+                t16_stage_put(stX, L, 2, lo4(c1h[1]));
+                t16_stage_put(stX, L, 3, hi4(c1h[1]));
+            }
+            __syncthreads();  // ---- A1
+            if (wv == 0) wgrad<1, true>(gW_nar, gB_nar, stage, L, 0, 0, 2);          // heads: x = H[0:16]
+            else if (wv == 1) { float dummy = 0.0f; wgrad<1, false>(gW_nar, dummy, stage, L, 0, 0, 3); }   // heads: x = H[16:32]
+            else if (wv < 6) { float dummy = 0.0f; wgrad<1, false>(gW_nar, dummy, stage, L, 0, T16_STAGE_MAT, wv - 2); }  // rgb: x = c1 block wv-2
+            // dv1 = (W_rgb^T gs3) * G'(v1)
+            t16_h8 dyB[2];
+            {
+                v4f dc[4];
+                zero4(dc);
+                t16_chain<4, 1>(dc, lds, T16T_D2, L.lo16, &narB);
+#pragma unroll
+                for (int b = 0; b < 4; ++b) dc[b] = mul_dg(dc[b], dgv1[b]);
+                dyB[0] = t16_hi(dc[0], dc[1]);
+                dyB[1] = t16_hi(dc[2], dc[3]);
+            }
+            __syncthreads();  // ---- B1
+            // ================= Directional_MLP.mlp.2 (64 -> 64) =================
+            L = fresh_lane(L);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                t16_stage_put(stY, L, 2 * t, lo4(dyB[t]));
+                t16_stage_put(stY, L, 2 * t + 1, hi4(dyB[t]));
+                t16_stage_put(stX, L, 2 * t, lo4(c0h[t]));
+                t16_stage_put(stX, L, 2 * t + 1, hi4(c0h[t]));
+            }
+            __syncthreads();  // ---- A2
+            if (cb == 0) wgrad<2, true>(gW_D1, gB_D1, stage, L, rb, T16_STAGE_MAT, 0);
+            else { float dummy = 0.0f; wgrad<2, false>(gW_D1, dummy, stage, L, rb, T16_STAGE_MAT, 2); }
+            {
+                v4f dc[4];
+                zero4(dc);
+                t16_chain<4, 2>(dc, lds, T16T_D1, L.lo16, dyB);
+#pragma unroll
+                for (int b = 0; b < 4; ++b) dc[b] = mul_dg(dc[b], dgv0[b]);   // dv0
+                dyB[0] = t16_hi(dc[0], dc[1]);
+                dyB[1] = t16_hi(dc[2], dc[3]);
+            }
+            __syncthreads();  // ---- B2
+            // ================= Directional_MLP.mlp.0 (32 of its 48 inputs; the SH part per ray) =================
+            L = fresh_lane(L);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                t16_stage_put(stY, L, 2 * t, lo4(dyB[t]));
+                t16_stage_put(stY, L, 2 * t + 1, hi4(dyB[t]));
+            }
+            t16_stage_put(stX, L, 0, lo4(Hh[1]));
+            t16_stage_put(stX, L, 1, hi4(Hh[1]));
+            {   // the SH part of the layer's input is constant along the ray: staged as 16 more "units" (block 2 of X)
+                const float4 shq = *reinterpret_cast<const float4 *>(shbuf + wv * 16 + 4 * q);
+                t16_stage_put(stX, L, 2, t16_hi4(v4f{ shq.x, shq.y, shq.z, shq.w }));
+            }
+            __syncthreads();  // ---- A3
+            if (cb == 0) wgrad<2, true, 2>(gW_D0, gB_D0, stage, L, rb, T16_STAGE_MAT, 0);   // x = H[32:48] and SH
+            else { float dummy = 0.0f; wgrad<1, false>(gW_D0, dummy, stage, L, rb, T16_STAGE_MAT, 1); }   // x = H[48:64]
+            {
+                v4f dH[4];
+                zero4(dH);
+                t16_chain<2, 2>(&dH[2], lds, T16T_D0, L.lo16, dyB);     // dH[32:64] = W_D0[:, :32]^T dv0
+                t16_chain<2, 1>(&dH[0], lds, T16T_HEAD, L.lo16, &narB);  // dH[0:32] = heads^T gh
+                dyB[0] = t16_hi(dH[0], dH[1]);
+                dyB[1] = t16_hi(dH[2], dH[3]);
+            }
+            __syncthreads();  // ---- B3
+            // ================= Spatial_MLP.mlp.2 (64 -> 64, linear) =================
+            L = fresh_lane(L);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                t16_stage_put(stY, L, 2 * t, lo4(dyB[t]));
+                t16_stage_put(stY, L, 2 * t + 1, hi4(dyB[t]));
+                t16_stage_put(stX, L, 2 * t, lo4(a0h[t]));
+                t16_stage_put(stX, L, 2 * t + 1, hi4(a0h[t]));
+            }
+            __syncthreads();  // ---- A4
+            if (cb == 0) wgrad<2, true>(gW_L1, gB_L1, stage, L, rb, T16_STAGE_MAT, 0);
+            else { float dummy = 0.0f; wgrad<2, false>(gW_L1, dummy, stage, L, rb, T16_STAGE_MAT, 2); }
+            {
+                v4f dc[4];
+                zero4(dc);
+                t16_chain<4, 2>(dc, lds, T16T_L1, L.lo16, dyB);
+#pragma unroll
+                for (int b = 0; b < 4; ++b) dc[b] = mul_dg(dc[b], dg0[b]);   // du0
+                dyB[0] = t16_hi(dc[0], dc[1]);
+                dyB[1] = t16_hi(dc[2], dc[3]);
+            }
+            __syncthreads();  // ---- B4
+            // ================= Spatial_MLP.mlp.0 (32 -> 64) =================
+            L = fresh_lane(L);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                t16_stage_put(stY, L, 2 * t, lo4(dyB[t]));
+                t16_stage_put(stY, L, 2 * t + 1, hi4(dyB[t]));
+            }
+            t16_stage_put(stX, L, 0, lo4(xh));
+            t16_stage_put(stX, L, 1, hi4(xh));
+            __syncthreads();  // ---- A5
+            if (cb == 0) wgrad<1, true>(gW_L0, gB_L0, stage, L, rb, T16_STAGE_MAT, 0);
+            else { float dummy = 0.0f; wgrad<1, false>(gW_L0, dummy, stage, L, rb, T16_STAGE_MAT, 1); }
+            v4f dx[2];
+            zero4(dx);
+            t16_chain<2, 2>(dx, lds, T16T_L0, L.lo16, dyB);
+            dx[0] *= isc;
+            dx[1] *= isc;
+            // (no barrier here: the next tile's staging writes come after its barrier S)
+
+            if (tile > 0) nxt = load_tile(tile - 1);   // before this tile's record stores (see load_tile)
+            // ================= feature gradients =================
+            if (!defer) emit_tile(tile, dx[0], dx[1]);
+            else {
+                pdx0 = dx[0];
+                pdx1 = dx[1];
+                ptile = tile;
+            }
+        }
+        if (defer && ptile >= 0) emit_tile(ptile, pdx0, pdx1);
+    }
+
+    if (a.recs) {  // launch-wide max |dL/dfeature| for the fixed-point scale of the accumulate pass
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) gmax = fmaxf(gmax, __shfl_xor(gmax, off, 64));
+        if (lane == 0 && gmax > 0.0f) atomicMax(a.maxbits, __float_as_uint(gmax));
+    }
+    // ---- flush: the workgroup's partial sums in blob order, ONE row per workgroup (every entry has exactly one owner)
+    const int c = lane & 15, q = lane >> 4;
+    float *out = a.dw_partial + (size_t)blockIdx.x * SCANERF_PARAMSIZE;
+    auto put64 = [&](const v4f &acc, int base, int cblk) {   // 64-output layer: acc = dW[n = 16rb + 4q + g][k = 16 cblk + c]
+#pragma unroll
+        for (int g = 0; g < 4; ++g) out[base + 64 + (16 * cblk + c) * 64 + 16 * rb + 4 * q + g] = acc[g] * isc;
+    };
+    put64(gW_D1[0], BLOB_D1, 2 * cb);
+    put64(gW_D1[1], BLOB_D1, 2 * cb + 1);
+    put64(gW_L1[0], BLOB_S1, 2 * cb);
+    put64(gW_L1[1], BLOB_S1, 2 * cb + 1);
+    put64(gW_D0[0], BLOB_D0, cb);
+    if (cb == 0) put64(gW_D0[1], BLOB_D0, 2);   // SH part: input index 32 + c
+    {
+        const int kin = t16_pos_to_input(t16_l0_row_to_pos(cb, c));
+#pragma unroll
+        for (int g = 0; g < 4; ++g) out[BLOB_S0 + 64 + kin * 64 + 16 * rb + 4 * q + g] = gW_L0[0][g] * isc;
+    }
+    auto rowtotal = [&](float v) {  // sum over the 4 lane groups: lane = unit
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+        return v;
+    };
+    if (cb == 0) {
+        float v;
+        v = rowtotal(gB_D1) * isc;
+        if (q == 0) out[BLOB_D1 + 16 * rb + c] = v;
+        v = rowtotal(gB_L1) * isc;
+        if (q == 0) out[BLOB_S1 + 16 * rb + c] = v;
+        v = rowtotal(gB_L0) * isc;
+        if (q == 0) out[BLOB_S0 + 16 * rb + c] = v;
+        v = rowtotal(gB_D0) * isc;
+        if (q == 0) out[BLOB_D0 + 16 * rb + c] = v;
+    }
+    if (wv < 2) {  // heads: acc = d[row 4q + g][H unit 16 wv + c]; rows 0 sigma, 1-3 dif, 4-6 tint
+        const int k = 16 * wv + c;
+        if (q == 0) {
+            out[BLOB_SIG + 1 + k] = gW_nar[0][0] * isc;
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) out[BLOB_DIF + 3 + k * 3 + ch] = gW_nar[0][1 + ch] * isc;
+        } else if (q == 1) {
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) out[BLOB_TINT + 3 + k * 3 + ch] = gW_nar[0][ch] * isc;
+        }
+    } else if (wv < 6 && q == 2) {  // rgb layer: rows 8-10, column = c1 unit 16(wv-2) + c
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) out[BLOB_D2 + 3 + (16 * (wv - 2) + c) * 3 + ch] = gW_nar[0][ch] * isc;
+    }
+    if (wv == 0) {  // narrow biases = row sums of the narrow block
+        const float v = rowtotal(gB_nar) * isc;
+        if (q == 0) {
+            if (c == 0) out[BLOB_SIG] = v;
+            else if (c < 4) out[BLOB_DIF + c - 1] = v;
+            else if (c < 7) out[BLOB_TINT + c - 4] = v;
+            else if (c >= 8 && c < 11) out[BLOB_D2 + c - 8] = v;
+        }
+    }
+}
+
+}  // namespace
+
+namespace scanerf {
+
+int launch_pack_decoder_t16(const float *blob, const float *wf, char *out, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_pack_decoder_t16, dim3((62 * 512 + 272 + 255) / 256), dim3(256), 0, st, blob, wf, out);
+    return 0;
+}
+
+int launch_render_bwd_t16(const BwdArgs &a, int feat_dtype, int blocks, size_t lds_extra, hipStream_t st)
+{
+    const size_t lds_bytes = (size_t)kLdsCursor + lds_extra;
+    SCANERF_REQUIRE(lds_bytes <= 160 * 1024, "render_backward(t16): %zu B of LDS needed (table too large for the fused scatter)", lds_bytes);
+    SCANERF_REQUIRE(a.xstash && !a.g_dnorm && !a.g_rowsum, "render_backward(t16): needs the x-stash and has no pose-gradient outputs");
+#define SCANERF_LAUNCH_BWD(DT)                                                                                     \
+    {                                                                                                              \
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_render_bwd_t16<DT>),                  \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);            \
+        SCANERF_REQUIRE(e == hipSuccess, "render_backward(t16): cannot reserve %zu B of LDS: %s", lds_bytes,        \
+                        hipGetErrorString(e));                                                                     \
+        hipLaunchKernelGGL((k_render_bwd_t16<DT>), dim3(blocks), dim3(kThreads), lds_bytes, st, a);                 \
+    }
+    (void)feat_dtype;  // the table is only read through the x-stash here
+    SCANERF_LAUNCH_BWD(SCANERF_F32)
+#undef SCANERF_LAUNCH_BWD
+    return 0;
+}
+
+}  // namespace scanerf

@@ -68,8 +68,33 @@ constexpr int H3_BYTES = H3_D2B + 16 * 4;
 static_assert(H3_BYTES % 16 == 0 && H3_IMG_BYTES % 256 == 0, "h3 image is copied as float4");
 constexpr int H3_FLOATS = H3_BYTES / 4;
 
-// packed workspace = [fp32 image PK_TOTAL floats][h3 image H3_FLOATS floats]
-constexpr int WS_FLOATS = PK_TOTAL + H3_FLOATS;
+// ---- 16-sample-tile images of the backward kernel render_bwd_t16.hip, see render_t16.h (bytes from the start of the t16 part)
+constexpr int T16_SUB = 1024;
+constexpr int T16_PAIR = 2 * T16_SUB;
+// forward image: pairs [block b][k-step t]
+constexpr int T16_L0 = 0;                               // 4 x 1   (weight_feature folded in; slot (q, j) = x-stash position 8q + j)
+constexpr int T16_L1 = T16_L0 + 4 * T16_PAIR;           // 4 x 2
+constexpr int T16_HEAD = T16_L1 + 8 * T16_PAIR;         // 2 x 1   rows 4q+g: block 0 = (sigma, dif xyz), block 1 = (tint xyz, 0), every q
+constexpr int T16_D0 = T16_HEAD + 2 * T16_PAIR;         // 4 x 2   k-step 0 = H[32:64], k-step 1 = SH (slot (q, j) = SH[8q + j], q < 2)
+constexpr int T16_D1 = T16_D0 + 8 * T16_PAIR;           // 4 x 2
+constexpr int T16_D2 = T16_D1 + 8 * T16_PAIR;           // 1 x 2   rows 4q+g = (rgb xyz, 0), every q
+constexpr int T16_FWD_BYTES = T16_D2 + 2 * T16_PAIR;    // 32 pairs
+// transposed image: sub-images [input block b_in][k-step t of the layer's OUTPUT units]
+constexpr int T16T_D2 = T16_FWD_BYTES;                  // 4 x 1   k = narrow rows (8..10 = rgb)
+constexpr int T16T_D1 = T16T_D2 + 4 * T16_SUB;          // 4 x 2
+constexpr int T16T_D0 = T16T_D1 + 8 * T16_SUB;          // 2 x 2   input = H[32:64] (dH blocks 2, 3)
+constexpr int T16T_HEAD = T16T_D0 + 4 * T16_SUB;        // 2 x 1   k = narrow rows (0..6 = sigma, dif, tint); dH blocks 0, 1
+constexpr int T16T_L1 = T16T_HEAD + 2 * T16_SUB;        // 4 x 2
+constexpr int T16T_L0 = T16T_L1 + 8 * T16_SUB;          // 2 x 2   rows = x-stash positions (see t16_pos)
+constexpr int T16_BIAS = T16T_L0 + 4 * T16_SUB;         // f32 [L0 64][L1 64][D0 64][D1 64][headA 4][headB 4][D2 4][pad 4]
+constexpr int T16_BYTES = T16_BIAS + (256 + 16) * 4;
+static_assert(T16_BYTES % 16 == 0, "t16 image is copied as float4");
+constexpr int T16_FLOATS = T16_BYTES / 4;
+
+
+// packed workspace = [fp32 image PK_TOTAL floats][h3 image H3_FLOATS floats][t16 images T16_FLOATS floats]
+constexpr int WS_T16 = PK_TOTAL + H3_FLOATS;
+constexpr int WS_FLOATS = WS_T16 + T16_FLOATS;
 
 __host__ __device__ constexpr int nmap(int g, int h) { return (g & 3) + 8 * (g >> 2) + 4 * h; }
 

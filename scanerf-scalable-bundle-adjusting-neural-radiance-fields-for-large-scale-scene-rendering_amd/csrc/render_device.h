@@ -116,7 +116,7 @@ struct RenderArgs {
     const float *packed;      // PK_TOTAL floats
     const uint8_t *ray_valid; // optional
     float *out_ray, *weights;
-    float *tile_T;            // optional [B, ceil(S/32)]: transmittance entering each tile (for backward)
+    float *tile_T;            // optional [B, ceil(S/16)]: transmittance entering each 16-sample tile (for backward)
     float *xstash;            // optional [B*S][2][16]: encoder outputs per (sample, half-wave) (for backward)
     int B, S, T;
     int contract_mode, infinity;

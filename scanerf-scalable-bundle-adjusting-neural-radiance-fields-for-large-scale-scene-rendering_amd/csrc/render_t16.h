@@ -38,28 +38,6 @@ typedef float t16_f2 __attribute__((ext_vector_type(2)));
 
 namespace scanerf {
 
-constexpr int T16_SUB = 1024;
-constexpr int T16_PAIR = 2 * T16_SUB;
-// forward image: pairs [block b][k-step t]
-constexpr int T16_L0 = 0;                               // 4 x 1   (weight_feature folded in; slot (q, j) = x-stash position 8q + j)
-constexpr int T16_L1 = T16_L0 + 4 * T16_PAIR;           // 4 x 2
-constexpr int T16_HEAD = T16_L1 + 8 * T16_PAIR;         // 2 x 1   rows 4q+g: block 0 = (sigma, dif xyz), block 1 = (tint xyz, 0), every q
-constexpr int T16_D0 = T16_HEAD + 2 * T16_PAIR;         // 4 x 2   k-step 0 = H[32:64], k-step 1 = SH (slot (q, j) = SH[8q + j], q < 2)
-constexpr int T16_D1 = T16_D0 + 8 * T16_PAIR;           // 4 x 2
-constexpr int T16_D2 = T16_D1 + 8 * T16_PAIR;           // 1 x 2   rows 4q+g = (rgb xyz, 0), every q
-constexpr int T16_FWD_BYTES = T16_D2 + 2 * T16_PAIR;    // 32 pairs
-// transposed image: sub-images [input block b_in][k-step t of the layer's OUTPUT units]
-constexpr int T16T_D2 = T16_FWD_BYTES;                  // 4 x 1   k = narrow rows (8..10 = rgb)
-constexpr int T16T_D1 = T16T_D2 + 4 * T16_SUB;          // 4 x 2
-constexpr int T16T_D0 = T16T_D1 + 8 * T16_SUB;          // 2 x 2   input = H[32:64] (dH blocks 2, 3)
-constexpr int T16T_HEAD = T16T_D0 + 4 * T16_SUB;        // 2 x 1   k = narrow rows (0..6 = sigma, dif, tint); dH blocks 0, 1
-constexpr int T16T_L1 = T16T_HEAD + 2 * T16_SUB;        // 4 x 2
-constexpr int T16T_L0 = T16T_L1 + 8 * T16_SUB;          // 2 x 2   rows = x-stash positions (see t16_pos)
-constexpr int T16_BIAS = T16T_L0 + 4 * T16_SUB;         // f32 [L0 64][L1 64][D0 64][D1 64][headA 4][headB 4][D2 4][pad 4]
-constexpr int T16_BYTES = T16_BIAS + (256 + 16) * 4;
-static_assert(T16_BYTES % 16 == 0, "t16 image is copied as float4");
-constexpr int T16_FLOATS = T16_BYTES / 4;
-
 __host__ __device__ constexpr int t16_ku(int t, int q, int j) { return 32 * t + 16 * (j >> 2) + 4 * q + (j & 3); }
 // x-stash position (render.hip: 16h + 2jj + f holds feature f of level 4(jj>>1) + 2h + (jj&1)) -> decoder input index 2 level + f
 __host__ __device__ constexpr int t16_pos_to_input(int pos)
@@ -124,22 +102,26 @@ __device__ __forceinline__ v4f t16_mfma(const t16_h8 &a, const t16_h8 &b, const 
 template <int NB, int KS>
 __device__ __forceinline__ void t16_layer(v4f u[NB], const char *img, int base, int lo16, const T16HL B[KS])
 {
+    constexpr int G = NB < 2 ? NB : 2;  // blocks per group: their A operands (hi, lo) are the registers in flight
 #pragma unroll
-    for (int t = 0; t < KS; ++t) {
-        t16_h8 ahi[NB], alo[NB];
+    for (int b0 = 0; b0 < NB; b0 += G)
 #pragma unroll
-        for (int b = 0; b < NB; ++b) {
-            const char *p = img + base + (b * KS + t) * T16_PAIR + lo16;
-            ahi[b] = *reinterpret_cast<const t16_h8 *>(p);
-            alo[b] = *reinterpret_cast<const t16_h8 *>(p + T16_SUB);
+        for (int t = 0; t < KS; ++t) {
+            t16_h8 ahi[G], alo[G];
+#pragma unroll
+            for (int b = 0; b < G; ++b) {
+                const char *p = img + base + ((b0 + b) * KS + t) * T16_PAIR + lo16;
+                ahi[b] = *reinterpret_cast<const t16_h8 *>(p);
+                alo[b] = *reinterpret_cast<const t16_h8 *>(p + T16_SUB);
+            }
+#pragma unroll
+            for (int b = 0; b < G; ++b) u[b0 + b] = t16_mfma(alo[b], B[t].hi, u[b0 + b]);
+#pragma unroll
+            for (int b = 0; b < G; ++b) u[b0 + b] = t16_mfma(ahi[b], B[t].lo, u[b0 + b]);
+#pragma unroll
+            for (int b = 0; b < G; ++b) u[b0 + b] = t16_mfma(ahi[b], B[t].hi, u[b0 + b]);
+            __builtin_amdgcn_sched_barrier(0);  // keep the scheduler from hoisting later operand reads (registers)
         }
-#pragma unroll
-        for (int b = 0; b < NB; ++b) u[b] = t16_mfma(alo[b], B[t].hi, u[b]);
-#pragma unroll
-        for (int b = 0; b < NB; ++b) u[b] = t16_mfma(ahi[b], B[t].lo, u[b]);
-#pragma unroll
-        for (int b = 0; b < NB; ++b) u[b] = t16_mfma(ahi[b], B[t].hi, u[b]);
-    }
 }
 // transposed product: dx[b_in] += W^T[b_in] dY over KS k-steps of the output units (hi parts only)
 template <int NBI, int KS>
@@ -152,6 +134,7 @@ __device__ __forceinline__ void t16_chain(v4f dx[NBI], const char *img, int base
         for (int b = 0; b < NBI; ++b) a[b] = *reinterpret_cast<const t16_h8 *>(img + base + (b * KS + t) * T16_SUB + lo16);
 #pragma unroll
         for (int b = 0; b < NBI; ++b) dx[b] = t16_mfma(a[b], dY[t], dx[b]);
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 __device__ __forceinline__ v4f t16_ld4(const char *img, int byte_off)
@@ -212,8 +195,7 @@ __device__ __forceinline__ float t16_sum8(const t16_h8 &v, float acc)
     return acc;
 }
 
-// launchers (render_bwd_t16.hip)
-struct BwdArgs;
+// launcher of the pack kernel (render_bwd_t16.hip)
 int launch_pack_decoder_t16(const float *blob, const float *wf, char *out, hipStream_t st);
 
 }  // namespace scanerf

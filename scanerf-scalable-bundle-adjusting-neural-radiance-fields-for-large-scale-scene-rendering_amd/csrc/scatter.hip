@@ -355,7 +355,7 @@ bool fused_geom(int B, int S, int T, BinGeom &g, int arith = SCANERF_ARITH_F32)
     g.NB = T >> g.bucket_log;
     g.W = scanerf_render_backward_grid(B);
     g.per_wg = 0;
-    g.rpg = arith == SCANERF_ARITH_H3 ? 4 : 1;
+    g.rpg = arith == SCANERF_ARITH_T16 ? 8 : (arith == SCANERF_ARITH_H3 ? 4 : 1);
     g.capacity = 0;
     return true;
 }

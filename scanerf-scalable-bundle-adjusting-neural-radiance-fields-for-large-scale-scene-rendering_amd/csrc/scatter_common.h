@@ -8,7 +8,12 @@
 namespace scanerf {
 
 constexpr int kBucketLog = 11;  // 2048 entries (16 KB of fp32 pairs) per bucket
-constexpr int kFusedBucketLog = 11;
+// Fused producer: 2^13 entries per bucket = the largest the accumulate's 64-bit LDS image holds (128 KB).  Every workgroup
+// appends to 16 * NB ranges at once; each XCD's L2 (4 MiB) has to hold one partially written 128-B line per range of its
+// 32 workgroups to merge the 16-byte records into full-line writes: 2^11-entry buckets = 16 MiB of such lines per XCD,
+// 2^13 = 4 MiB.  Measured (two-waves-per-SIMD backward kernel, T = 2^19): plan + backward 5.80 / 5.45 / 5.17 / 5.12 ms at
+// 2^11 / 2^12 / 2^13 / 2^14 entries, accumulate 1.75 / 1.78 / 1.83 / 3.9 ms (above 2^13 it works in windows).
+constexpr int kFusedBucketLog = 13;
 
 struct BinGeom {
     int N, L, T;
@@ -24,6 +29,15 @@ struct Rec {
     uint32_t hdr;
     float tx, gx, gy;
 };
+
+// One 16-byte record store.  Plain (write-back) stores: measured in the two-waves-per-SIMD backward kernel, non-temporal
+// stores of the same records take 2.7x the kernel's time (14.2 vs 5.2 ms) and sc1 (write-through) ones 1.5x: the records of
+// a (bin, workgroup) range are written 16 bytes at a time and only the L2 can merge them into full lines.  What helps is
+// FEWER ranges being filled at once (kFusedBucketLog).
+__device__ __forceinline__ void store_rec(Rec *recs, uint32_t pos, uint32_t hdr, float tx, float gx, float gy)
+{
+    reinterpret_cast<float4 *>(recs)[pos] = make_float4(__uint_as_float(hdr), tx, gx, gy);
+}
 
 // the 4 (y,z) corner pairs of one (point, level): bucket, locals, weights
 struct Pairs {
@@ -64,6 +78,7 @@ __device__ __forceinline__ void make_pairs(const float p[3], const int32_t *res,
 // idx0 ^ idx1 = (x ^ (x+1)) & mask for all four pairs, so "straddles a bucket boundary" is ONE test per (sample, level);
 // the common case is 4 cursor atomics issued back to back and 4 predicated 16-B stores, no branch; straddling lanes and
 // workspace overflow share one rarely taken, wave-uniform branch.
+template <int DBG = 0>  // timing experiments only: 1 = no record stores, 2 = no cursor atomics, 3 = neither
 __device__ __forceinline__ void emit_pairs(const Pairs &pr, float gix, float giy, uint32_t *cursor_level, int bucket_log,
                                            uint32_t capacity, Rec *recs, float *grad_level)
 {
@@ -80,7 +95,8 @@ __device__ __forceinline__ void emit_pairs(const Pairs &pr, float gix, float giy
     };
     uint32_t pos[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) pos[q] = atomicAdd(&cursor_level[pr.idx0[q] >> bucket_log], 1u);
+    for (int q = 0; q < 4; ++q)
+        pos[q] = (DBG == 2 || DBG == 3) ? cursor_level[pr.idx0[q] >> bucket_log] + (threadIdx.x & 15) : atomicAdd(&cursor_level[pr.idx0[q] >> bucket_log], 1u);
     const float txr = straddle ? 0.0f : pr.tx;
     bool rare = straddle;
 #pragma unroll
@@ -89,10 +105,16 @@ __device__ __forceinline__ void emit_pairs(const Pairs &pr, float gix, float giy
         const uint32_t hdr = straddle ? l0 * 0x10001u : (l0 | ((l0 ^ pr.xm) << 16));
         const float gx = pr.wyz[q] * gix, gy = pr.wyz[q] * giy;
         const float ax = straddle ? a0 * gx : gx, ay = straddle ? a0 * gy : gy;
-        if (pos[q] < capacity) reinterpret_cast<float4 *>(recs)[pos[q]] = make_float4(__uint_as_float(hdr), txr, ax, ay);
+        if (DBG & 1) {
+            if (pos[q] == 0xffffffffu && ax == 1.2345f) reinterpret_cast<float4 *>(recs)[0] = make_float4(__uint_as_float(hdr), txr, ax, ay);
+        } else if (DBG == 4) {  // 8-byte stores at 8-byte stride (is the cost per request or per byte?)
+            if (pos[q] < capacity) reinterpret_cast<float2 *>(recs)[pos[q]] = make_float2(__uint_as_float(hdr) + txr, ax + ay);
+        } else if (DBG == 8) {  // 16-byte stores, every lane group's 16 records contiguous whatever the bins (is it the scatter?)
+            reinterpret_cast<float4 *>(recs)[(size_t)blockIdx.x * 65536 + (threadIdx.x & 1023) * 4 + q] = make_float4(__uint_as_float(hdr), txr, ax, ay);
+        } else if (pos[q] < capacity) store_rec(recs, pos[q], hdr, txr, ax, ay);
         rare |= pos[q] >= capacity;
     }
-    if (__builtin_expect(__any(rare), 0)) {
+    if (DBG == 0 && __builtin_expect(__any(rare), 0)) {
 #pragma unroll  // (rolled, pr would be indexed dynamically and live in scratch -- whose stores cost a vmcnt(0) per level)
         for (int q = 0; q < 4; ++q) {
             const uint32_t l0 = pr.idx0[q] & lmask, b0 = pr.idx0[q] >> bucket_log;
@@ -104,7 +126,7 @@ __device__ __forceinline__ void emit_pairs(const Pairs &pr, float gix, float giy
             if (straddle) {  // second record: the x+1 neighbour in its own bucket
                 const uint32_t i1 = pr.idx0[q] ^ pr.xm, b1 = i1 >> bucket_log, hdr1 = (i1 & lmask) * 0x10001u;
                 const uint32_t p1 = atomicAdd(&cursor_level[b1], 1u);
-                if (p1 < capacity) reinterpret_cast<float4 *>(recs)[p1] = make_float4(__uint_as_float(hdr1), 0.0f, pr.tx * gx, pr.tx * gy);
+                if (p1 < capacity) store_rec(recs, p1, hdr1, 0.0f, pr.tx * gx, pr.tx * gy);
                 else fallback(b1, hdr1, 0.0f, pr.tx * gx, pr.tx * gy);
             }
         }
@@ -142,7 +164,7 @@ __device__ __forceinline__ void commit_pairs(const Pairs &pr, const PairSlots &s
         const uint32_t hdr = straddle ? l0 * 0x10001u : (l0 | ((l0 ^ pr.xm) << 16));
         const float gx = pr.wyz[q] * gix, gy = pr.wyz[q] * giy;
         const float ax = straddle ? a0 * gx : gx, ay = straddle ? a0 * gy : gy;
-        if (sl.pos[q] < capacity) reinterpret_cast<float4 *>(recs)[sl.pos[q]] = make_float4(__uint_as_float(hdr), txr, ax, ay);
+        if (sl.pos[q] < capacity) store_rec(recs, sl.pos[q], hdr, txr, ax, ay);
         rare |= sl.pos[q] >= capacity;
     }
     if (__builtin_expect(__any(rare), 0)) {
@@ -157,7 +179,7 @@ __device__ __forceinline__ void commit_pairs(const Pairs &pr, const PairSlots &s
             if (straddle) {
                 const uint32_t i1 = pr.idx0[q] ^ pr.xm, b1 = i1 >> bucket_log, hdr1 = (i1 & lmask) * 0x10001u;
                 const uint32_t p1 = atomicAdd(&cursor_level[b1], 1u);
-                if (p1 < capacity) reinterpret_cast<float4 *>(recs)[p1] = make_float4(__uint_as_float(hdr1), 0.0f, pr.tx * gx, pr.tx * gy);
+                if (p1 < capacity) store_rec(recs, p1, hdr1, 0.0f, pr.tx * gx, pr.tx * gy);
                 else fallback(b1, hdr1, 0.0f, pr.tx * gx, pr.tx * gy);
             }
         }

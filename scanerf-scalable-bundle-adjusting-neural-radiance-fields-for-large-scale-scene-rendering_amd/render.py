@@ -9,16 +9,35 @@ from ._capi import RAY_OUT, RenderCfg, check, dev_ptr, feat_dtype_code, lib, str
 _f32 = torch.float32
 FORE, BG = 0, 1
 
-# Decoder arithmetic of the fused kernels: "h3" = f16 matrix cores on hi/lo-split operands (three products
-# per term, f32 accumulate: results as close to fp64 as the f32 evaluation, csrc/render_h3.h), "f32" = the
-# f32-input MFMA.  Module-level switch (also SCANERF_ARITH=f32|h3 in the environment).
+# Decoder arithmetic of the fused kernels (module-level switch, also SCANERF_ARITH=f32|h3|t16 in the environment):
+#   "f32" = the f32-input MFMA (exact f32);
+#   "h3"  = f16 matrix cores on hi/lo-split operands, three products per term, f32 accumulate: results as close to fp64 as
+#           the f32 evaluation (csrc/render_h3.h), forward and backward;
+#   "t16" = (default) forward as "h3"; backward on 16-sample tiles at two waves per SIMD, forward recompute in h3, gradient
+#           products on one f16 MFMA per term (csrc/render_t16.h).  Calls it cannot serve (no x-stash, pose-gradient
+#           outputs) run the "h3" backward: see backward_arith().
 import os as _os
-ARITH = {"f32": _capi.ARITH_F32, "h3": _capi.ARITH_H3}[_os.environ.get("SCANERF_ARITH", "h3")]
+_ARITH_CODES = {"f32": _capi.ARITH_F32, "h3": _capi.ARITH_H3, "t16": _capi.ARITH_T16}
+DEFAULT_ARITH = _os.environ.get("SCANERF_ARITH", "t16")
+ARITH = _ARITH_CODES[DEFAULT_ARITH]
 
 
 def set_arith(name):
     global ARITH
-    ARITH = {"f32": _capi.ARITH_F32, "h3": _capi.ARITH_H3}[name]
+    ARITH = _ARITH_CODES[name]
+
+
+def backward_arith(have_xstash=True, pose_grads=False):
+    """The arithmetic code one training step's scatter_plan / render_backward / scatter_accumulate must agree on."""
+    if ARITH == _capi.ARITH_T16 and (not have_xstash or pose_grads):
+        return _capi.ARITH_H3
+    return ARITH
+
+
+def tile_T_columns(S):
+    """Columns of the forward's tile_T output: transmittance entering each 16-sample tile."""
+    return (S + 15) // 16
+
 
 # columns of out_ray [B,16]
 RGB, DEPTH, T_LEFT, DIFFUSE, SPECULAR, TINT, W_SPEC2 = slice(0, 3), 3, 4, slice(5, 8), slice(8, 11), slice(11, 14), 14
@@ -39,10 +58,10 @@ class PackedDecoder:
         return self
 
 
-def _cfg(min_bbox, bbox_size, contract_mode, infinity):
+def _cfg(min_bbox, bbox_size, contract_mode, infinity, arith=None):
     c = RenderCfg()
     c.contract_mode, c.infinity = int(contract_mode), int(bool(infinity))
-    c.arith = ARITH
+    c.arith = ARITH if arith is None else arith
     for k in range(3):
         c.min_bbox[k] = float(min_bbox[k])
         c.bbox_size[k] = float(bbox_size[k])
@@ -75,12 +94,15 @@ def render_forward(rays_o, rays_d, z_vals, dists, features, resolutions, packed,
 
 def render_backward(rays_o, rays_d, z_vals, dists, features, resolutions, packed, weight_feature, min_bbox, bbox_size,
                     contract_mode, infinity, out_ray, tile_T, grad_out, ray_valid=None, grad_blob=None, xstash=None,
-                    ray_grad_buffers=None, scatter=None, want_dfeat=True):
+                    ray_grad_buffers=None, scatter=None, want_dfeat=True, arith=None):
     """Adjoint of render_forward -> (dfeat [16, B*S, 2] level-major, grad_blob [13994]).
     scatter = (workspace, grad_features) from scatter_plan(): the kernel emits the table-gradient records
-    itself; finish with scatter_accumulate().  dfeat is then only produced if want_dfeat."""
+    itself; finish with scatter_accumulate().  dfeat is then only produced if want_dfeat.
+    arith: as given to scatter_plan (default: backward_arith() of this call's inputs)."""
     B, S = z_vals.shape
     dev = z_vals.device
+    if arith is None:
+        arith = backward_arith(xstash is not None, ray_grad_buffers is not None)
     if scatter is None and not want_dfeat:
         raise ValueError("render_backward: nothing would receive the feature gradients")
     dfeat = torch.empty((16, B * S, 2), dtype=_f32, device=dev) if want_dfeat else None
@@ -88,7 +110,7 @@ def render_backward(rays_o, rays_d, z_vals, dists, features, resolutions, packed
     dw_partial = torch.empty((4 * nblk, _capi.PARAMSIZE), dtype=_f32, device=dev)
     if grad_blob is None:
         grad_blob = torch.zeros(_capi.PARAMSIZE, dtype=_f32, device=dev)
-    cfg = _cfg(min_bbox, bbox_size, contract_mode, infinity)
+    cfg = _cfg(min_bbox, bbox_size, contract_mode, infinity, arith)
     check(lib().scanerf_render_backward(
         dev_ptr(rays_o, _f32, "rays_o"), dev_ptr(rays_d, _f32, "rays_d"), dev_ptr(z_vals, _f32, "z_vals"),
         dev_ptr(dists, _f32, "dists"), dev_ptr(features, (torch.float32, torch.float16, torch.bfloat16), "features"),
@@ -126,16 +148,19 @@ def scatter_supported(B, S, T):
     return lib().scanerf_render_scatter_workspace_bytes(ctypes.c_int(B), ctypes.c_int(S), ctypes.c_int(T)) != 0
 
 
-def scatter_plan(rays_o, rays_d, z_vals, resolutions, T, min_bbox, bbox_size, contract_mode, infinity, ray_valid=None):
+def scatter_plan(rays_o, rays_d, z_vals, resolutions, T, min_bbox, bbox_size, contract_mode, infinity, ray_valid=None,
+                 arith=None):
     """Reserve the record ranges of the fused table-gradient path for this batch (count + scan).
     Returns the workspace tensor to hand to render_backward(scatter=(ws, grad_features)) and scatter_accumulate.
-    The workspace is a per-device cache: one plan/backward/accumulate sequence at a time."""
+    The workspace is a per-(device, stream) cache: one plan/backward/accumulate sequence at a time.
+    arith: the backward kernel that will emit the records (its ray -> workgroup map is reserved here); default
+    backward_arith() = what render_backward picks when it is given an x-stash and no pose-gradient buffers."""
     B, S = z_vals.shape
     need = lib().scanerf_render_scatter_workspace_bytes(ctypes.c_int(B), ctypes.c_int(S), ctypes.c_int(T))
     if not need:
         raise RuntimeError(f"scanerf: fused scatter does not support B={B} S={S} T={T}")
     ws = _capi.workspace(z_vals.device, need)
-    cfg = _cfg(min_bbox, bbox_size, contract_mode, infinity)
+    cfg = _cfg(min_bbox, bbox_size, contract_mode, infinity, backward_arith() if arith is None else arith)
     check(lib().scanerf_render_scatter_plan(
         dev_ptr(rays_o, _f32, "rays_o"), dev_ptr(rays_d, _f32, "rays_d"), dev_ptr(z_vals, _f32, "z_vals"),
         dev_ptr(resolutions, torch.int32, "resolutions"), ctypes.byref(cfg),

@@ -360,7 +360,8 @@ def train_step_fused(model, dec_opt, rays_o, rays_d, target, S, global_step, tab
         blob = model.decoder.blob()
         model.packed.pack(blob, wf)
         ntile = (S + 31) // 32
-        tile_T = torch.empty((B, ntile), device=dev)
+        tile_T = torch.empty((B, render.tile_T_columns(S)), device=dev)
+        bwd_arith = render.backward_arith(True, pose_grads)
         xstash = torch.empty((B * S, 32), device=dev)  # encoder outputs: 1 GB at 65 536 x 128, saves the re-gather
         box = (model.min_bbox.tolist(), model.bbox_size.tolist(), render.FORE, False)
         T = model.features.shape[1]
@@ -378,7 +379,7 @@ def train_step_fused(model, dec_opt, rays_o, rays_d, target, S, global_step, tab
             # so it is off by default
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
-                ws = render.scatter_plan(rays_o, rays_d, z, model.resolution, T, *box, ray_valid=valid)
+                ws = render.scatter_plan(rays_o, rays_d, z, model.resolution, T, *box, ray_valid=valid, arith=bwd_arith)
                 plan_done = torch.cuda.Event()
                 plan_done.record(side)
         # gather table: the fp32 master itself, or its bf16/f16 image (configs[2]: half the gather bytes, fp32 accumulate)
@@ -397,7 +398,7 @@ def train_step_fused(model, dec_opt, rays_o, rays_d, target, S, global_step, tab
         if fused and ws is None:
             # count + scan of the scatter records (depends on the sample positions only)
             with _sec(timer, "scatter_plan", B * S * 4):
-                ws = render.scatter_plan(rays_o, rays_d, z, model.resolution, T, *box, ray_valid=valid)
+                ws = render.scatter_plan(rays_o, rays_d, z, model.resolution, T, *box, ray_valid=valid, arith=bwd_arith)
         elif plan_done is not None:
             torch.cuda.current_stream().wait_event(plan_done)
         # forward recompute + activation gradients + weight gradients = 3x the forward MLP FLOPs
@@ -405,7 +406,7 @@ def train_step_fused(model, dec_opt, rays_o, rays_d, target, S, global_step, tab
             dfeat, _ = render.render_backward(rays_o, rays_d, z, dist, table, model.resolution, model.packed, wf,
                                               *box, out, tile_T, grad_out, ray_valid=valid, grad_blob=gblob, xstash=xstash,
                                               ray_grad_buffers=ray_bufs, scatter=(ws, gtab) if fused else None,
-                                              want_dfeat=pose_grads or not fused)
+                                              want_dfeat=pose_grads or not fused, arith=bwd_arith)
         if pose_grads:
             g_o, g_d = render.ray_gradients(rays_o, rays_d, z, model.features, model.resolution, blob, box[0], box[1],
                                             box[2], dfeat, ray_bufs[0], ray_bufs[1], ray_valid=valid)
@@ -446,7 +447,7 @@ def fgbg_gradients(model, rays_o, rays_d, target, S_fg, S_bg, global_step, inval
         outs, state = [], []
         for z_, d_, v_, mode, inf in branches:
             S = z_.shape[1]
-            tile_T = torch.empty((B, (S + 31) // 32), device=dev)
+            tile_T = torch.empty((B, render.tile_T_columns(S)), device=dev)
             xs = torch.empty((B * S, 32), device=dev)
             out, _ = render.render_forward(rays_o, rays_d, z_, d_, model.features, model.resolution, model.packed, *box, mode, inf,
                                            ray_valid=v_, want_weights=False, tile_T=tile_T, xstash=xs)

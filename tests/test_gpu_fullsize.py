@@ -47,15 +47,15 @@ def full():
     return dict(m=m, o=o, d=d, z=z, dist=dist, wf=wf, box=box, gout=gout, step=step)
 
 
-def _fused(full, valid, arith="h3", want_dfeat=False):
+def _fused(full, valid, arith=None, want_dfeat=False):
     """plan -> forward (tile_T, xstash) -> backward (emits records) -> accumulate, as tile_model.train_step_fused does."""
     from scanerf_amd import render
     m, o, d, z, dist = (full[k] for k in ("m", "o", "d", "z", "dist"))
-    render.set_arith(arith)
+    render.set_arith(arith or render.DEFAULT_ARITH)
     try:
         m.packed.pack(m.decoder.blob(), full["wf"])
         T = m.features.shape[1]
-        tile_T = torch.empty(B, (S_ + 31) // 32, device=DEV)
+        tile_T = torch.empty(B, (S_ + 15) // 16, device=DEV)
         xs = torch.empty(B * S_, 32, device=DEV)
         out, w = render.render_forward(o, d, z, dist, m.features, m.resolution, m.packed, *full["box"], ray_valid=valid,
                                        want_weights=True, tile_T=tile_T, xstash=xs)
@@ -69,7 +69,7 @@ def _fused(full, valid, arith="h3", want_dfeat=False):
         torch.cuda.synchronize()
         return out, w, dfeat, gtab, gblob
     finally:
-        render.set_arith("h3")
+        render.set_arith(render.DEFAULT_ARITH)
 
 
 def test_full_size_fused_scatter_vs_atomics_and_conservation(full):
@@ -104,17 +104,21 @@ def test_full_size_fused_scatter_vs_atomics_and_conservation(full):
     assert abs(nz1 - nz2) <= 1e-4 * nz1, (nz1, nz2)
 
 
-def test_full_size_h3_vs_f32_arith(full):
+def test_full_size_h3_and_t16_vs_f32_arith(full):
     """(iii) the split-f16 decoder arithmetic against the exact-f32 MFMA kernels at full size: per-ray outputs to 1e-4
-    (north_star), decoder and table gradients to 1e-4 of their maxima."""
-    out_h, w_h, _, gtab_h, gblob_h = _fused(full, None, "h3")
+    (north_star); decoder and table gradients to 1e-4 of their maxima for h3 (every product split), to 1e-3 for t16
+    (gradient products on one f16 MFMA per term; the measured figure is printed)."""
     out_f, w_f, _, gtab_f, gblob_f = _fused(full, None, "f32")
-    np.testing.assert_allclose(out_h[:, :5].cpu().numpy(), out_f[:, :5].cpu().numpy(), rtol=1e-4, atol=1e-6)
-    np.testing.assert_allclose(w_h.cpu().numpy(), w_f.cpu().numpy(), rtol=1e-4, atol=1e-7)
-    for a, b, name in ((gblob_h, gblob_f, "decoder"), (gtab_h, gtab_f, "table")):
-        sc = float(b.abs().max())
-        err = float((a - b).abs().max()) / sc
-        assert err < 1e-4, f"{name} gradient h3 vs f32: {err:.3e} of max"
+    for arith, tol in (("h3", 1e-4), ("t16", 1e-3)):
+        out_h, w_h, _, gtab_h, gblob_h = _fused(full, None, arith)
+        np.testing.assert_allclose(out_h[:, :5].cpu().numpy(), out_f[:, :5].cpu().numpy(), rtol=1e-4, atol=1e-6)
+        np.testing.assert_allclose(w_h.cpu().numpy(), w_f.cpu().numpy(), rtol=1e-4, atol=1e-7)
+        for a, b, name in ((gblob_h, gblob_f, "decoder"), (gtab_h, gtab_f, "table")):
+            sc = float(b.abs().max())
+            err = float((a - b).abs().max()) / sc
+            rel = float((a - b).norm() / b.norm())
+            print(f"full size, {arith} vs f32, {name} gradient: max err {err:.3e} of max, relative L2 {rel:.3e}")
+            assert err < tol, f"{name} gradient {arith} vs f32: {err:.3e} of max"
 
 
 @pytest.mark.parametrize("first", [0, 21845, 43690, 63488])

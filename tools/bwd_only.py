@@ -13,7 +13,7 @@ d = torch.nn.functional.normalize(torch.randn(B, 3, device=dev), dim=-1)
 z, dist = m.sample(o, d, S)
 wf = network.weight_feature(5000, dev)
 m.packed.pack(m.decoder.blob(), wf)
-tile_T = torch.empty(B, 4, device=dev)
+tile_T = torch.empty(B, (S + 15) // 16, device=dev)
 box = (m.min_bbox.tolist(), m.bbox_size.tolist(), render.FORE, False)
 XS = torch.empty(B * S, 32, device=dev) if os.environ.get("XS", "1") == "1" else None
 out, _ = render.render_forward(o, d, z, dist, m.features, m.resolution, m.packed, *box, want_weights=False, tile_T=tile_T, xstash=XS)

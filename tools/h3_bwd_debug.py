@@ -22,7 +22,7 @@ ntile = (S_ + 31) // 32
 res = {}
 for ar in ("f32", "h3", "h3"):
     render.set_arith(ar)
-    tile_T = torch.empty(B, ntile, device=DEV)
+    tile_T = torch.empty(B, (S_ + 15) // 16, device=DEV)
     xs = torch.empty(B * S_, 32, device=DEV)
     out, _ = render.render_forward(o, d, z, dist, m.features, m.resolution, m.packed, *box, ray_valid=valid,
                                    want_weights=False, tile_T=tile_T, xstash=xs)
