@@ -19,6 +19,14 @@
 
 using namespace scanerf;
 
+// timing experiments only (results are wrong): -DT16_NO_BARRIER drops the per-step workgroup barriers, -DT16_NO_WGRAD the
+// weight-gradient products
+#ifdef T16_NO_BARRIER
+#define STEP_BARRIER() __builtin_amdgcn_sched_barrier(0)
+#else
+#define STEP_BARRIER() __syncthreads()
+#endif
+
 namespace {
 
 constexpr int kThreads = 512;
@@ -160,6 +168,9 @@ __device__ __forceinline__ t16_h4 hi4(const t16_h8 &v) { return __builtin_shuffl
 template <int NX, bool ROWSUM, int XSTRIDE = 1>
 __device__ __forceinline__ void wgrad(v4f *acc, float &rowsum, const char *stage, const T16Lane &L, int yb, int x_mat_off, int xb0)
 {
+#ifdef T16_NO_WGRAD
+    return;
+#endif
 #pragma unroll
     for (int P = 0; P < 4; ++P) {
         const char *pm = stage + P * 2 * T16_STAGE_WAVE;
@@ -168,9 +179,10 @@ __device__ __forceinline__ void wgrad(v4f *acc, float &rowsum, const char *stage
 #pragma unroll
         for (int i = 0; i < NX; ++i) b[i] = t16_stage_get(pm + x_mat_off, L, xb0 + i * XSTRIDE);
         if (ROWSUM) rowsum = t16_sum8(a, rowsum);
+        T16_REGION_BEGIN();
 #pragma unroll
         for (int i = 0; i < NX; ++i) acc[i] = t16_mfma(a, b[i], acc[i]);
-        __builtin_amdgcn_sched_barrier(0);
+        T16_REGION_END();
     }
 }
 
@@ -254,9 +266,11 @@ __global__ void __launch_bounds__(kThreads, 2) k_render_bwd_t16(BwdArgs a)
             for (int b = 0; b < 4; ++b) {
                 const char *p = lds + T16_D0 + (b * 2 + 1) * T16_PAIR + L.lo16;
                 const t16_h8 ahi = *reinterpret_cast<const t16_h8 *>(p), alo = *reinterpret_cast<const t16_h8 *>(p + T16_SUB);
+                T16_REGION_BEGIN();
                 dinit[b] = t16_mfma(alo, shB.hi, dinit[b]);
                 dinit[b] = t16_mfma(ahi, shB.lo, dinit[b]);
                 dinit[b] = t16_mfma(ahi, shB.hi, dinit[b]);
+                T16_REGION_END();
             }
             if (c == 0) {
                 float4 *dp = reinterpret_cast<float4 *>(lds + kLdsDinit + wv * 256);
@@ -273,60 +287,44 @@ __global__ void __launch_bounds__(kThreads, 2) k_render_bwd_t16(BwdArgs a)
         float Rcarry = 0.0f;              // sum of a_j w_j over all later tiles of the ray
 
         // Feature gradients of one tile: dfeat rows and / or the scatter records (scatter.hip) into the ranges the plan
-        // reserved.  e0 / e1 = dX blocks 0 / 1: register g of block e = x-stash position 8q + 4e + g = feature g & 1 of this
-        // lane's level jj = 2e + (g >> 1); level(q, jj) = 4(j8 >> 1) + 2(q >> 1) + (j8 & 1) with j8 = 4(q & 1) + jj.
-        auto emit_tile = [&](int tile_e, const v4f &e0, const v4f &e1) {
+        // reserved, ONE LEVEL PER CALL.  e0 / e1 = dX blocks 0 / 1: register g of block e = x-stash position 8q + 4e + g =
+        // feature g & 1 of this lane's level jj = 2e + (g >> 1); level(q, jj) = 4(j8 >> 1) + 2(q >> 1) + (j8 & 1), j8 = 4(q & 1) + jj.
+        //
+        // THE FOUR LEVELS OF A TILE ARE EMITTED AT FOUR POINTS OF THE NEXT TILE.  The 8.6 GB of records are the kernel's
+        // memory traffic; stored in one piece at the end of a tile they arrive at the L2s in bursts (the 8 waves of every
+        // workgroup run in lock step), every new line evicts a dirty one, and the waves wait for the chip's write bandwidth
+        // while nothing computes: removing the barriers or the weight-gradient products did not change the kernel's time.
+        // Spread over the next tile's layers the same stores overlap its matrix work.
+        auto emit_level = [&](int tile_e, int jj, const v4f &e0, const v4f &e1) {
             const int ln = fresh(lane), c = ln & 15, q = ln >> 4;
             const int s = tile_e * 16 + c;
-            if (!(s < S) || !active) return;
-            auto lvl = [&](int jj) { const int j8 = 4 * (q & 1) + jj; return 4 * (j8 >> 1) + 2 * (q >> 1) + (j8 & 1); };
-            if (a.dfeat) {
-                const size_t n = (size_t)ray * S + s, NS = (size_t)a.f.B * S;
-                reinterpret_cast<float2 *>(a.dfeat)[(size_t)lvl(0) * NS + n] = make_float2(e0[0], e0[1]);
-                reinterpret_cast<float2 *>(a.dfeat)[(size_t)lvl(1) * NS + n] = make_float2(e0[2], e0[3]);
-                reinterpret_cast<float2 *>(a.dfeat)[(size_t)lvl(2) * NS + n] = make_float2(e1[0], e1[1]);
-                reinterpret_cast<float2 *>(a.dfeat)[(size_t)lvl(3) * NS + n] = make_float2(e1[2], e1[3]);
-            }
+            if (tile_e < 0 || !(s < S) || !active) return;
+            const int j8 = 4 * (q & 1) + jj, level = 4 * (j8 >> 1) + 2 * (q >> 1) + (j8 & 1);
+            const float gx = jj == 0 ? e0[0] : (jj == 1 ? e0[2] : (jj == 2 ? e1[0] : e1[2]));
+            const float gy = jj == 0 ? e0[1] : (jj == 1 ? e0[3] : (jj == 2 ? e1[1] : e1[3]));
+            if (a.dfeat) reinterpret_cast<float2 *>(a.dfeat)[(size_t)level * a.f.B * S + (size_t)ray * S + s] = make_float2(gx, gy);
             if (a.recs) {
                 float pe[3];
                 contract_point(a.f, o, d, a.f.z_vals[(size_t)rayc * S + s], pe);
                 const uint32_t mask = (uint32_t)a.f.T - 1u;
-                // one level at a time (a second set of index registers in flight -- the 32-sample kernel's software pipeline --
-                // does not fit the 256-register budget)
-#pragma unroll 1
-                for (int jj = 0; jj < 4; ++jj) {
-                    const int level = lvl(jj);
-                    const int4 r = *reinterpret_cast<const int4 *>(lres + 4 * level);
-                    const int32_t rr[3] = { r.x, r.y, r.z };
-                    Pairs pr;
-                    make_pairs(pe, rr, mask, pr);
-                    const float gx = jj == 0 ? e0[0] : (jj == 1 ? e0[2] : (jj == 2 ? e1[0] : e1[2]));
-                    const float gy = jj == 0 ? e0[1] : (jj == 1 ? e0[3] : (jj == 2 ? e1[1] : e1[3]));
-                    gmax = fmaxf(gmax, fmaxf(fabsf(gx), fabsf(gy)));
-                    uint32_t *cl = cursor + level * a.bins.NB;
-                    float *gl = a.grad_features + (size_t)level * a.f.T * 2;
-                    if ((a.f.dbg & 15) == 0) emit_pairs(pr, gx, gy, cl, a.bins.bucket_log, a.bins.capacity, a.recs, gl);
+                const int4 r = *reinterpret_cast<const int4 *>(lres + 4 * level);
+                const int32_t rr[3] = { r.x, r.y, r.z };
+                Pairs pr;
+                make_pairs(pe, rr, mask, pr);
+                gmax = fmaxf(gmax, fmaxf(fabsf(gx), fabsf(gy)));
+                uint32_t *cl = cursor + level * a.bins.NB;
+                float *gl = a.grad_features + (size_t)level * a.f.T * 2;
+                if ((a.f.dbg & 15) == 0) emit_pairs(pr, gx, gy, cl, a.bins.bucket_log, a.bins.capacity, a.recs, gl);
 #ifdef SCANERF_BWD_EXPERIMENTS
-                    else if ((a.f.dbg & 15) == 1) emit_pairs<1>(pr, gx, gy, cl, a.bins.bucket_log, a.bins.capacity, a.recs, gl);
-                    else if ((a.f.dbg & 15) == 2) emit_pairs<2>(pr, gx, gy, cl, a.bins.bucket_log, a.bins.capacity, a.recs, gl);
-                    else if ((a.f.dbg & 15) == 3) emit_pairs<3>(pr, gx, gy, cl, a.bins.bucket_log, a.bins.capacity, a.recs, gl);
-                    else if ((a.f.dbg & 15) == 4) emit_pairs<4>(pr, gx, gy, cl, a.bins.bucket_log, a.bins.capacity, a.recs, gl);
-                    else emit_pairs<8>(pr, gx, gy, cl, a.bins.bucket_log, a.bins.capacity, a.recs, gl);
+                else if ((a.f.dbg & 15) == 1) emit_pairs<1>(pr, gx, gy, cl, a.bins.bucket_log, a.bins.capacity, a.recs, gl);
+                else if ((a.f.dbg & 15) == 2) emit_pairs<2>(pr, gx, gy, cl, a.bins.bucket_log, a.bins.capacity, a.recs, gl);
+                else if ((a.f.dbg & 15) == 3) emit_pairs<3>(pr, gx, gy, cl, a.bins.bucket_log, a.bins.capacity, a.recs, gl);
+                else if ((a.f.dbg & 15) == 4) emit_pairs<4>(pr, gx, gy, cl, a.bins.bucket_log, a.bins.capacity, a.recs, gl);
+                else emit_pairs<8>(pr, gx, gy, cl, a.bins.bucket_log, a.bins.capacity, a.recs, gl);
 #endif
-                }
             }
         };
-        // EMISSION IS STAGGERED between the two waves of a SIMD (waves w and w + 4).  All 8 waves reach the end of a tile
-        // together; emitting there they would all wait on cursor round trips and record stores at the same time and then all
-        // compute at the same time.  Waves 4-7 therefore carry their tile's gradients over the NEXT tile's forward recompute
-        // (which needs no barrier) and emit after it: while one wave of a SIMD waits on its records the other one computes.
-#ifdef SCANERF_BWD_EXPERIMENTS
-        const int dm = a.f.dbg >> 4;
-        const bool defer = dm == 0 ? wv >= 4 : (dm == 1 ? (wv & 1) : (dm == 2 ? false : ((wv >> 1) & 1)));
-#else
-        const bool defer = wv >= 4;
-#endif
-        v4f pdx0 = { 0, 0, 0, 0 }, pdx1 = { 0, 0, 0, 0 };
+        v4f pdx0 = { 0, 0, 0, 0 }, pdx1 = { 0, 0, 0, 0 };   // the previous tile's dX, emitted during this one
         int ptile = -1;
 
         // A tile's inputs are loaded ONE TILE AHEAD, before the previous tile's records are stored: vector-memory operations
@@ -394,6 +392,7 @@ __global__ void __launch_bounds__(kThreads, 2) k_render_bwd_t16(BwdArgs a)
                     Hh[0] = HB[0].hi;
                     Hh[1] = HB[1].hi;
                 }
+                emit_level(ptile, 0, pdx0, pdx1);
                 {   // heads on H[:32]
                     v4f hd[2] = { t16_ld4(lds, T16_BIAS + 256 * 4), t16_ld4(lds, T16_BIAS + 260 * 4) };
                     t16_layer<2, 1>(hd, lds, T16_HEAD, L.lo16, &HB[0]);
@@ -414,9 +413,11 @@ __global__ void __launch_bounds__(kThreads, 2) k_render_bwd_t16(BwdArgs a)
                     for (int b = 0; b < 4; ++b) {  // k-step 0 of the D0 pairs
                         const char *p = lds + T16_D0 + (b * 2) * T16_PAIR + L.lo16;
                         const t16_h8 ahi = *reinterpret_cast<const t16_h8 *>(p), alo = *reinterpret_cast<const t16_h8 *>(p + T16_SUB);
+                        T16_REGION_BEGIN();
                         v[b] = t16_mfma(alo, HB[1].hi, v[b]);
                         v[b] = t16_mfma(ahi, HB[1].lo, v[b]);
                         v[b] = t16_mfma(ahi, HB[1].hi, v[b]);
+                        T16_REGION_END();
                     }
 #pragma unroll
                     for (int b = 0; b < 4; ++b) act_deriv(v[b], dgv0[b]);
@@ -425,6 +426,7 @@ __global__ void __launch_bounds__(kThreads, 2) k_render_bwd_t16(BwdArgs a)
                     c0h[0] = cB[0].hi;
                     c0h[1] = cB[1].hi;
                 }
+                emit_level(ptile, 1, pdx0, pdx1);
                 {
                     v4f v[4];
 #pragma unroll
@@ -437,6 +439,7 @@ __global__ void __launch_bounds__(kThreads, 2) k_render_bwd_t16(BwdArgs a)
                     c1h[0] = cB[0].hi;
                     c1h[1] = cB[1].hi;
                 }
+                emit_level(ptile, 2, pdx0, pdx1);
                 {
                     v4f r[1] = { t16_ld4(lds, T16_BIAS + 264 * 4) };
                     t16_layer<1, 2>(r, lds, T16_D2, L.lo16, cB);
@@ -445,7 +448,7 @@ __global__ void __launch_bounds__(kThreads, 2) k_render_bwd_t16(BwdArgs a)
                 }
             }
 
-            if (defer && ptile >= 0) emit_tile(ptile, pdx0, pdx1);  // the previous tile's records (see emit_tile)
+            emit_level(ptile, 3, pdx0, pdx1);
 
             // ================= compositing: recompute and adjoint (16-lane scans, identical in the 4 lane groups) =================
             const float ex = live ? expf(-sigma * delta) : 1.0f;  // 1 - alpha
@@ -510,7 +513,7 @@ __global__ void __launch_bounds__(kThreads, 2) k_render_bwd_t16(BwdArgs a)
                 for (int off = 8; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 16));
                 if (lane == 0) mxbuf[wv] = mx;
             }
-            __syncthreads();  // ---- S: tile maxima visible; every wave is done with the previous tile's staged operands
+            STEP_BARRIER();  // ---- S: tile maxima visible; every wave is done with the previous tile's staged operands
             {   // gradient scale: keep the workgroup's largest |gradient| * 2^K in [2^2, 2^6): with single f16 operands the
                 // 8 tiles' smaller gradients need the room BELOW the maximum (full precision down to 2^-19 of it, subnormal to
                 // 2^-29), the chains' growth through G' <= 6 and the weights the 2^10 above it
@@ -558,7 +561,7 @@ __global__ void __launch_bounds__(kThreads, 2) k_render_bwd_t16(BwdArgs a)
                 t16_stage_put(stX, L, 2, lo4(c1h[1]));
                 t16_stage_put(stX, L, 3, hi4(c1h[1]));
             }
-            __syncthreads();  // ---- A1
+            STEP_BARRIER();  // ---- A1
             if (wv == 0) wgrad<1, true>(gW_nar, gB_nar, stage, L, 0, 0, 2);          // heads: x = H[0:16]
             else if (wv == 1) { float dummy = 0.0f; wgrad<1, false>(gW_nar, dummy, stage, L, 0, 0, 3); }   // heads: x = H[16:32]
             else if (wv < 6) { float dummy = 0.0f; wgrad<1, false>(gW_nar, dummy, stage, L, 0, T16_STAGE_MAT, wv - 2); }  // rgb: x = c1 block wv-2
@@ -573,7 +576,7 @@ __global__ void __launch_bounds__(kThreads, 2) k_render_bwd_t16(BwdArgs a)
                 dyB[0] = t16_hi(dc[0], dc[1]);
                 dyB[1] = t16_hi(dc[2], dc[3]);
             }
-            __syncthreads();  // ---- B1
+            STEP_BARRIER();  // ---- B1
             // ================= Directional_MLP.mlp.2 (64 -> 64) =================
             L = fresh_lane(L);
 #pragma unroll
@@ -583,7 +586,7 @@ __global__ void __launch_bounds__(kThreads, 2) k_render_bwd_t16(BwdArgs a)
                 t16_stage_put(stX, L, 2 * t, lo4(c0h[t]));
                 t16_stage_put(stX, L, 2 * t + 1, hi4(c0h[t]));
             }
-            __syncthreads();  // ---- A2
+            STEP_BARRIER();  // ---- A2
             if (cb == 0) wgrad<2, true>(gW_D1, gB_D1, stage, L, rb, T16_STAGE_MAT, 0);
             else { float dummy = 0.0f; wgrad<2, false>(gW_D1, dummy, stage, L, rb, T16_STAGE_MAT, 2); }
             {
@@ -595,7 +598,7 @@ __global__ void __launch_bounds__(kThreads, 2) k_render_bwd_t16(BwdArgs a)
                 dyB[0] = t16_hi(dc[0], dc[1]);
                 dyB[1] = t16_hi(dc[2], dc[3]);
             }
-            __syncthreads();  // ---- B2
+            STEP_BARRIER();  // ---- B2
             // ================= Directional_MLP.mlp.0 (32 of its 48 inputs; the SH part per ray) =================
             L = fresh_lane(L);
 #pragma unroll
@@ -609,7 +612,7 @@ __global__ void __launch_bounds__(kThreads, 2) k_render_bwd_t16(BwdArgs a)
                 const float4 shq = *reinterpret_cast<const float4 *>(shbuf + wv * 16 + 4 * q);
                 t16_stage_put(stX, L, 2, t16_hi4(v4f{ shq.x, shq.y, shq.z, shq.w }));
             }
-            __syncthreads();  // ---- A3
+            STEP_BARRIER();  // ---- A3
             if (cb == 0) wgrad<2, true, 2>(gW_D0, gB_D0, stage, L, rb, T16_STAGE_MAT, 0);   // x = H[32:48] and SH
             else { float dummy = 0.0f; wgrad<1, false>(gW_D0, dummy, stage, L, rb, T16_STAGE_MAT, 1); }   // x = H[48:64]
             {
@@ -620,7 +623,7 @@ __global__ void __launch_bounds__(kThreads, 2) k_render_bwd_t16(BwdArgs a)
                 dyB[0] = t16_hi(dH[0], dH[1]);
                 dyB[1] = t16_hi(dH[2], dH[3]);
             }
-            __syncthreads();  // ---- B3
+            STEP_BARRIER();  // ---- B3
             // ================= Spatial_MLP.mlp.2 (64 -> 64, linear) =================
             L = fresh_lane(L);
 #pragma unroll
@@ -630,7 +633,7 @@ __global__ void __launch_bounds__(kThreads, 2) k_render_bwd_t16(BwdArgs a)
                 t16_stage_put(stX, L, 2 * t, lo4(a0h[t]));
                 t16_stage_put(stX, L, 2 * t + 1, hi4(a0h[t]));
             }
-            __syncthreads();  // ---- A4
+            STEP_BARRIER();  // ---- A4
             if (cb == 0) wgrad<2, true>(gW_L1, gB_L1, stage, L, rb, T16_STAGE_MAT, 0);
             else { float dummy = 0.0f; wgrad<2, false>(gW_L1, dummy, stage, L, rb, T16_STAGE_MAT, 2); }
             {
@@ -642,7 +645,7 @@ __global__ void __launch_bounds__(kThreads, 2) k_render_bwd_t16(BwdArgs a)
                 dyB[0] = t16_hi(dc[0], dc[1]);
                 dyB[1] = t16_hi(dc[2], dc[3]);
             }
-            __syncthreads();  // ---- B4
+            STEP_BARRIER();  // ---- B4
             // ================= Spatial_MLP.mlp.0 (32 -> 64) =================
             L = fresh_lane(L);
 #pragma unroll
@@ -652,7 +655,7 @@ __global__ void __launch_bounds__(kThreads, 2) k_render_bwd_t16(BwdArgs a)
             }
             t16_stage_put(stX, L, 0, lo4(xh));
             t16_stage_put(stX, L, 1, hi4(xh));
-            __syncthreads();  // ---- A5
+            STEP_BARRIER();  // ---- A5
             if (cb == 0) wgrad<1, true>(gW_L0, gB_L0, stage, L, rb, T16_STAGE_MAT, 0);
             else { float dummy = 0.0f; wgrad<1, false>(gW_L0, dummy, stage, L, rb, T16_STAGE_MAT, 1); }
             v4f dx[2];
@@ -663,15 +666,13 @@ __global__ void __launch_bounds__(kThreads, 2) k_render_bwd_t16(BwdArgs a)
             // (no barrier here: the next tile's staging writes come after its barrier S)
 
             if (tile > 0) nxt = load_tile(tile - 1);   // before this tile's record stores (see load_tile)
-            // ================= feature gradients =================
-            if (!defer) emit_tile(tile, dx[0], dx[1]);
-            else {
-                pdx0 = dx[0];
-                pdx1 = dx[1];
-                ptile = tile;
-            }
+            // ================= feature gradients: emitted during the next tile (emit_level) =================
+            pdx0 = dx[0];
+            pdx1 = dx[1];
+            ptile = tile;
         }
-        if (defer && ptile >= 0) emit_tile(ptile, pdx0, pdx1);
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) emit_level(ptile, jj, pdx0, pdx1);   // the ray's first tile
     }
 
     if (a.recs) {  // launch-wide max |dL/dfeature| for the fixed-point scale of the accumulate pass

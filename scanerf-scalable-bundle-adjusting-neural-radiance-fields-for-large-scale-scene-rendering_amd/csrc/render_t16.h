@@ -96,6 +96,15 @@ __device__ __forceinline__ v4f t16_mfma(const t16_h8 &a, const t16_h8 &b, const 
 {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
 }
+// Every group of MFMAs is a CLOSED scheduling region followed by wait states.  Measured on MI355X (ROCm 7.2 hipcc,
+// tools/fwd_determinism.py): with f16 MFMAs scheduled freely among the vector code around them, about 1e-5 .. 3e-3 of the
+// 32-sample tiles of the forward kernel (by table type, i.e. by the code around the MFMAs) come out wrong in sample columns
+// 16-31, differently on every launch and only in the second wave of a SIMD; the listing shows vector instructions that
+// REWRITE an MFMA's A / B source registers (or loads into them) right behind it.  Fenced like this: 0 in 10^6 tiles.
+#define T16_REGION_BEGIN() __builtin_amdgcn_sched_barrier(0)
+#define T16_REGION_END()       \
+    asm volatile("s_nop 3");   \
+    __builtin_amdgcn_sched_barrier(0)
 
 // forward layer: u[b] += W[b] X over KS k-steps (three products per term, small ones first).  `img` + `base` =
 // the layer's first pair, `lo16` = 16 * lane.
@@ -114,13 +123,14 @@ __device__ __forceinline__ void t16_layer(v4f u[NB], const char *img, int base, 
                 ahi[b] = *reinterpret_cast<const t16_h8 *>(p);
                 alo[b] = *reinterpret_cast<const t16_h8 *>(p + T16_SUB);
             }
+            T16_REGION_BEGIN();
 #pragma unroll
             for (int b = 0; b < G; ++b) u[b0 + b] = t16_mfma(alo[b], B[t].hi, u[b0 + b]);
 #pragma unroll
             for (int b = 0; b < G; ++b) u[b0 + b] = t16_mfma(ahi[b], B[t].lo, u[b0 + b]);
 #pragma unroll
             for (int b = 0; b < G; ++b) u[b0 + b] = t16_mfma(ahi[b], B[t].hi, u[b0 + b]);
-            __builtin_amdgcn_sched_barrier(0);  // keep the scheduler from hoisting later operand reads (registers)
+            T16_REGION_END();
         }
 }
 // transposed product: dx[b_in] += W^T[b_in] dY over KS k-steps of the output units (hi parts only)
@@ -132,9 +142,10 @@ __device__ __forceinline__ void t16_chain(v4f dx[NBI], const char *img, int base
         t16_h8 a[NBI];
 #pragma unroll
         for (int b = 0; b < NBI; ++b) a[b] = *reinterpret_cast<const t16_h8 *>(img + base + (b * KS + t) * T16_SUB + lo16);
+        T16_REGION_BEGIN();
 #pragma unroll
         for (int b = 0; b < NBI; ++b) dx[b] = t16_mfma(a[b], dY[t], dx[b]);
-        __builtin_amdgcn_sched_barrier(0);
+        T16_REGION_END();
     }
 }
 __device__ __forceinline__ v4f t16_ld4(const char *img, int byte_off)

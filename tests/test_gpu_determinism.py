@@ -1,0 +1,74 @@
+"""Launch-to-launch bit-reproducibility of the fused kernels.  No atomics on float data and fixed reduction orders: two
+launches on the same inputs must agree bit for bit.  This is also the detector for the f16-MFMA scheduling hazard described in
+csrc/render_h3.h / render_t16.h (intermittently wrong sample columns 16-31 of a tile in the second wave of a SIMD), which
+tolerance-based parity tests on a few hundred rays miss."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _setup(B, S, mode_bg=False):
+    import scanerf_amd  # noqa: F401
+    from scanerf_amd import network, render
+    from scanerf_amd.tile_model import TileModel
+    torch.manual_seed(0)
+    m = TileModel([-4, -4, -4], [8, 8, 8], DEV, log2_T=14)
+    with torch.no_grad():
+        m.features.mul_(200.0)
+    o = torch.rand(B, 3, device=DEV) * 8 - 4
+    d = torch.nn.functional.normalize(torch.randn(B, 3, device=DEV), dim=-1)
+    if mode_bg:
+        z, dist, _ = m.inverse_z_sampling(o, d, S)
+    else:
+        z, dist = m.sample(o, d, S)
+    wf = network.weight_feature(40000, DEV)
+    m.packed.pack(m.decoder.blob(), wf)
+    box = (m.min_bbox.tolist(), m.bbox_size.tolist(), render.BG if mode_bg else render.FORE, mode_bg)
+    return m, o, d, z, dist, wf, box
+
+
+@pytest.mark.parametrize("dt,S,bg", [(torch.float32, 64, False), (torch.bfloat16, 64, False), (torch.float16, 64, False),
+                                     (torch.float32, 32, True), (torch.float32, 128, False)])
+def test_forward_is_bit_reproducible(dt, S, bg):
+    from scanerf_amd import render
+    B = 32768
+    m, o, d, z, dist, wf, box = _setup(B, S, bg)
+    table = m.features.detach().to(dt).contiguous()
+    ref = None
+    for it in range(8):
+        out, w = render.render_forward(o, d, z, dist, table, m.resolution, m.packed, *box)
+        torch.cuda.synchronize()
+        if ref is None:
+            ref = (out.clone(), w.clone())
+        else:
+            nbad = int(((out != ref[0]).any(1) | (w != ref[1]).any(1)).sum())
+            assert nbad == 0, f"launch {it}: {nbad} of {B} rays differ from launch 0 (table {dt}, S={S}, bg={bg})"
+
+
+@pytest.mark.parametrize("arith", ["t16", "h3"])
+def test_backward_is_bit_reproducible(arith):
+    from scanerf_amd import render
+    render.set_arith(arith)
+    try:
+        B, S = 32768, 64
+        m, o, d, z, dist, wf, box = _setup(B, S)
+        tile_T = torch.empty(B, render.tile_T_columns(S), device=DEV)
+        xs = torch.empty(B * S, 32, device=DEV)
+        out, _ = render.render_forward(o, d, z, dist, m.features, m.resolution, m.packed, *box, want_weights=False, tile_T=tile_T,
+                                       xstash=xs)
+        g = torch.randn(B, 16, device=DEV) / B
+        ref = None
+        for it in range(6):
+            dfeat, gblob = render.render_backward(o, d, z, dist, m.features, m.resolution, m.packed, wf, *box, out, tile_T, g,
+                                                  xstash=xs)
+            torch.cuda.synchronize()
+            if ref is None:
+                ref = (dfeat.clone(), gblob.clone())
+            else:
+                assert torch.equal(dfeat, ref[0]), f"{arith}: dfeat of launch {it} differs from launch 0"
+                assert torch.equal(gblob, ref[1]), f"{arith}: decoder gradient of launch {it} differs from launch 0"
+    finally:
+        render.set_arith(render.DEFAULT_ARITH)

@@ -152,12 +152,21 @@ def test_full_size_slice_vs_oracle_autograd(full, first):
     rest = torch.ones(B, dtype=torch.bool)
     rest[sl] = False
     assert torch.all(out[rest.to(DEV)][:, :4] == 0)
-    gF = F.grad.numpy()
+    # gradients: the default backward (arith t16) does its gradient products on one f16 MFMA per term: rounding noise of
+    # ~5e-4 of the largest element on every element, bounded here as 2e-3 of the maximum and 2e-3 in relative L2
+    # (arith h3: 2e-3 relative with a floor of 2e-5 of the maximum, tests/test_gpu_parity.py)
+    from scanerf_amd import render
+    tol = dict(rtol=2e-3, atol=2e-5) if render.DEFAULT_ARITH == "h3" else dict(rtol=2e-3, atol=2e-3)
+    gF, gT = F.grad.numpy(), gtab.cpu().numpy()
     fs = np.abs(gF).max()
-    np.testing.assert_allclose(gtab.cpu().numpy() / fs, gF / fs, rtol=2e-3, atol=2e-5)
-    gb_ref = O.pack_blob({k: v.grad for k, v in sd.items()}).numpy()
+    gb_ref, gB = O.pack_blob({k: v.grad for k, v in sd.items()}).numpy(), gblob.cpu().numpy()
     bs = np.abs(gb_ref).max()
-    np.testing.assert_allclose(gblob.cpu().numpy() / bs, gb_ref / bs, rtol=2e-3, atol=2e-5)
+    l2t, l2b = np.linalg.norm(gT - gF) / np.linalg.norm(gF), np.linalg.norm(gB - gb_ref) / np.linalg.norm(gb_ref)
+    print(f"slice {first}: table gradient max err {np.abs(gT - gF).max() / fs:.2e} of max, rel L2 {l2t:.2e}; "
+          f"decoder gradient max err {np.abs(gB - gb_ref).max() / bs:.2e} of max, rel L2 {l2b:.2e}")
+    np.testing.assert_allclose(gT / fs, gF / fs, **tol)
+    np.testing.assert_allclose(gB / bs, gb_ref / bs, **tol)
+    assert l2t < 2e-3 and l2b < 2e-3
 
 
 def test_configs0_L8_render_on_the_hip_ops_path():
