@@ -198,6 +198,16 @@ int scanerf_render_scatter_plan(const float *rays_o, const float *rays_d, const 
                                 size_t workspace_bytes, scanerf_stream_t stream);
 int scanerf_render_scatter_accumulate(float *grad_features, int B, int S, int T, void *workspace,
                                       size_t workspace_bytes, scanerf_stream_t stream);
+/* accumulate + fused sparse Adam in one pass (replaces scanerf_render_scatter_accumulate + scanerf_adam_step on the table:
+ * the bucket images ARE the touched-entry list, so no gradient table, no zero-fill, no scan; same per-element IEEE sequence as
+ * scanerf_adam_step / cuda/adam_kernel.cu:24-69, `step` = the previous step count).  params / exp_avg / exp_avg_sq [16][T][2]
+ * f32; half_table (may be NULL): f16 / bf16 (half_dtype = SCANERF_F16 / SCANERF_BF16) gather copy of params, refreshed where
+ * params change; overflow_grad (may be NULL): the table given to scanerf_render_backward as grad_features -- consulted and
+ * re-zeroed only if the record workspace overflowed, so it is allocated zero once and never filled per step. */
+int scanerf_render_scatter_accumulate_adam(float *params, float *exp_avg, float *exp_avg_sq, void *half_table,
+                                           int half_dtype, float *overflow_grad, float lr, float beta1, float beta2,
+                                           float eps, int step, int B, int S, int T, void *workspace,
+                                           size_t workspace_bytes, scanerf_stream_t stream);
 /* Photometric loss of the training step and dL/d(out_ray) in two launches (criterions.py:90,142-144 MSE over the valid
  * rays' rgb + tile.py:999 reg_weight * l2_reg_specular = mean over valid rays x 3 of out_ray[:,14]):
  *   loss [1] = (sum_valid |rgb - target|^2 + reg_weight * sum_valid out_ray[:,14]) / (3 * n_valid)

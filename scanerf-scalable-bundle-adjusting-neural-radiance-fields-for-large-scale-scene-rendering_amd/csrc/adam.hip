@@ -11,15 +11,11 @@
 #include <hip/hip_fp16.h>
 #include <math.h>
 
-#include "common.h"
+#include "adam_common.h"
 
 using namespace scanerf;
 
 namespace {
-
-struct AdamArgs {
-    float lr, beta1, beta2, eps, bc1, bc2;
-};
 
 template <bool HALF_STATE>
 struct Moments;
@@ -36,26 +32,10 @@ struct Moments<true> {
     static __device__ __forceinline__ void put(T *p, int64_t i, float v) { p[i] = __float2half(v); }
 };
 
-// one element; returns false when it is untouched (g == 0)
 template <bool HALF_STATE>
 __device__ __forceinline__ bool update_one(float &p, float &mi, float &vi, float g_raw, const AdamArgs &a)
 {
-    constexpr float LS = 128.0f;
-    const float g = HALF_STATE ? g_raw * LS : g_raw;
-    if (g == 0.0f) return false;
-    mi = a.beta1 * mi + (1.0f - a.beta1) * g;
-    vi = a.beta2 * vi + (1.0f - a.beta2) * g * g;
-    const float step_size = a.lr / a.bc1;
-    float denom, upd;
-    if (HALF_STATE) {
-        denom = sqrtf(vi / (a.bc2 * LS * LS)) + a.eps;
-        upd = step_size * mi / (denom * LS);
-    } else {
-        denom = sqrtf(vi / a.bc2) + a.eps;
-        upd = step_size * mi / denom;
-    }
-    p = p - upd;
-    return true;
+    return adam_update_one<HALF_STATE>(p, mi, vi, g_raw, a);
 }
 
 // One thread owns HALF a row: 4 consecutive parameters = one 16-B vector of grad / params (and of the fp32 moments; 8 B of
@@ -121,8 +101,7 @@ int launch(float *params, const float *grad, void *m, void *v, float lr, float b
     SCANERF_REQUIRE(params && grad && m && v, "%s: null pointer", what);
     SCANERF_REQUIRE((((uintptr_t)grad | (uintptr_t)params) & 15) == 0 && (((uintptr_t)m | (uintptr_t)v) & (HALF_STATE ? 7 : 15)) == 0,
                     "%s: params, grad and moments must be 16-byte aligned (8 for fp16 moments)", what);
-    float t = (float)(step + 1);
-    AdamArgs a{ lr, beta1, beta2, eps, 1.0f - powf(beta1, t), 1.0f - powf(beta2, t) };
+    const AdamArgs a = make_adam_args(lr, beta1, beta2, eps, step);
     using MT = typename Moments<HALF_STATE>::T;
     hipLaunchKernelGGL((k_adam<HALF_STATE>), dim3(stream_grid(2 * K, 256)), dim3(256), 0, st, params, grad, (MT *)m,
                        (MT *)v, a, K, param_dim);

@@ -35,6 +35,18 @@ inline int check_launch(const char *what)
         }                                          \
     } while (0)
 
+// After global stores in kernels that also run matrix instructions.  A vector-memory store reads its data registers for a few
+// cycles after it issues.  Measured on MI355X / ROCm 7.2 (tools/step_determinism.py): in 1 of ~4e5 tiles the x-stash store of
+// the forward kernel picked up, in its last quarter-wave, a register that later code (the next layer's MFMA results are
+// allocated over the stored values) had already rewritten -- nothing in the generated code holds such writers back.  Sixteen
+// wait states behind the stores, fenced for the scheduler, and no launch in 600 differed.
+#define SCANERF_STORE_GUARD()                    \
+    do {                                         \
+        __builtin_amdgcn_sched_barrier(0);       \
+        asm volatile("s_nop 7\n\ts_nop 7");      \
+        __builtin_amdgcn_sched_barrier(0);       \
+    } while (0)
+
 inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
 // Grid for memory-bound 1-thread-per-item kernels: enough blocks to fill 256 CUs several

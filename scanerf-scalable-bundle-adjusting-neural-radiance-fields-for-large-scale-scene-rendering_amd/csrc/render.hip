@@ -172,6 +172,7 @@ __global__ void __launch_bounds__(kRenderThreads, 2) k_render_fwd(RenderArgs a)
                 xs[1] = make_float4(x[4], x[5], x[6], x[7]);
                 xs[2] = make_float4(x[8], x[9], x[10], x[11]);
                 xs[3] = make_float4(x[12], x[13], x[14], x[15]);
+                SCANERF_STORE_GUARD();
             }
             SampleOut so = decode_tile(lds, lane, x, dinit);
 
@@ -192,6 +193,7 @@ __global__ void __launch_bounds__(kRenderThreads, 2) k_render_fwd(RenderArgs a)
             T_run *= __shfl(incl, 31, 32);
             if (tile == ntiles - 1) T_left = __shfl(Ti, (S - 1) & 31, 32);  // T before the last sample (:358-360)
             if (a.weights && live && h == 0) a.weights[(size_t)ray * S + s] = w;
+            if (a.weights || a.tile_T) SCANERF_STORE_GUARD();
 
             acc[0] = fmaf(w, z, acc[0]);
             float s2 = 0.0f;
@@ -353,6 +355,7 @@ __global__ void __launch_bounds__(kRenderThreads, 2) k_render_fwd_h3(RenderArgs 
                 xs[1] = make_float4(x[4], x[5], x[6], x[7]);
                 xs[2] = make_float4(x[8], x[9], x[10], x[11]);
                 xs[3] = make_float4(x[12], x[13], x[14], x[15]);
+                SCANERF_STORE_GUARD();
             }
             SampleOut so;
             if (a.dbg == 1) {
@@ -379,6 +382,7 @@ __global__ void __launch_bounds__(kRenderThreads, 2) k_render_fwd_h3(RenderArgs 
             T_run *= __shfl(incl, 31, 32);
             if (tile == ntiles - 1) T_left = __shfl(Ti, (S - 1) & 31, 32);
             if (a.weights && live && h == 0) a.weights[(size_t)ray * S + s] = w;
+            if (a.weights || a.tile_T) SCANERF_STORE_GUARD();
 
             acc[0] = fmaf(w, z, acc[0]);
             float s2 = 0.0f;

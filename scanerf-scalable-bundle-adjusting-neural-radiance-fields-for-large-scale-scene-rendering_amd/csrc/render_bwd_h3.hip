@@ -615,6 +615,7 @@ __global__ void __launch_bounds__(kThreads, 1) k_render_bwd_h3(BwdArgs a)
                     }
                 }
             }
+            SCANERF_STORE_GUARD();  // dfeat / record stores: their data registers are about to be reused by matrix results
         }
         // ---- per ray group: pose-gradient row sums of the own slots' rays
         if (a.g_rowsum && h == 0) {

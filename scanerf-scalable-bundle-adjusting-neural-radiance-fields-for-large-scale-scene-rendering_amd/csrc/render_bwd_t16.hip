@@ -323,6 +323,7 @@ __global__ void __launch_bounds__(kThreads, 2) k_render_bwd_t16(BwdArgs a)
                 else emit_pairs<8>(pr, gx, gy, cl, a.bins.bucket_log, a.bins.capacity, a.recs, gl);
 #endif
             }
+            SCANERF_STORE_GUARD();  // the records' / dfeat's data registers are about to be reused by matrix results
         };
         v4f pdx0 = { 0, 0, 0, 0 }, pdx1 = { 0, 0, 0, 0 };   // the previous tile's dX, emitted during this one
         int ptile = -1;

@@ -487,6 +487,7 @@ __global__ void __launch_bounds__(256, 2) k_pts_inference_chunks(InferArgs a)
                 }
             }
         }
+        SCANERF_STORE_GUARD();
       }
       }
     }

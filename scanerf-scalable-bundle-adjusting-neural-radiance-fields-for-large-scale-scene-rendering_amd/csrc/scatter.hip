@@ -21,6 +21,7 @@
 // HBM traffic: 64 B written + 64 B read per (point, level) instead of 16 memory-side atomics.
 #include <stdlib.h>
 
+#include "adam_common.h"
 #include "render_device.h"
 #include "scatter_common.h"
 
@@ -210,11 +211,23 @@ __global__ void __launch_bounds__(1024) k_bin_scatter(const float *__restrict__ 
 // 2^k, k = 50 - ceil(log2 M) - ceil(log2(n+1)): no overflow, resolution n*M*2^-50.  Integer
 // addition is associative, so the table gradient is bit-reproducible run to run (the
 // reference's atomics are not) and closer to the exact sum than an fp32 running sum.
-template <int kThreads, int U, bool LANE_OWNS_RUN = false>
+// ADAM: the epilogue applies the fused sparse Adam (adam_common.h: the IEEE sequence of adam.hip / the oracle) to the bucket's
+// entries instead of adding the image to grad_features.  The image IS the list of touched entries, so the gradient table, its
+// zero-fill and the optimiser's scan of it disappear (T = 2^24: 0.4 + 1.4 ms of a 7.7 ms step).  Optionally the half-precision
+// gather table is refreshed in the same pass.  ad.overflow_grad (may be null): the table the backward's workspace-overflow
+// path adds to -- read (and re-zeroed) only if the overflow flag is set.
+struct AdamEpilogue {
+    float *params, *exp_avg, *exp_avg_sq;
+    void *half_table;        // optional f16 / bf16 copy of params (same [L][T][2] layout)
+    int half_dtype;          // SCANERF_F16 / SCANERF_BF16
+    float *overflow_grad;    // optional
+    AdamArgs a;
+};
+template <int kThreads, int U, bool LANE_OWNS_RUN = false, bool ADAM = false>
 __global__ void __launch_bounds__(kThreads) k_bin_accumulate(const Rec *__restrict__ recs,
                                                              const uint32_t *__restrict__ starts,
                                                              const uint32_t *__restrict__ maxbits, BinGeom g,
-                                                             float *__restrict__ grad_features)
+                                                             float *__restrict__ grad_features, AdamEpilogue ad)
 {
     extern __shared__ long long acc64[];  // [2 << window_log]
     // Buckets larger than the LDS image (tables above 2^21 entries: bucket = T/256 so that the producer's cursors fit its
@@ -223,7 +236,8 @@ __global__ void __launch_bounds__(kThreads) k_bin_accumulate(const Rec *__restri
     const int wl = g.bucket_log < 13 ? g.bucket_log : 13, ws = 1 << wl;
     const uint32_t lo = min(starts[blockIdx.x], g.capacity), hi = min(starts[blockIdx.x + 1], g.capacity);
     const float M = __uint_as_float(*maxbits);
-    if (hi == lo || !(M > 0.0f)) return;  // nothing to add (uniform per workgroup)
+    const bool overflowed = ADAM && ad.overflow_grad && *overflow_flag(const_cast<Rec *>(recs)) != 0u;  // uniform
+    if ((hi == lo || !(M > 0.0f)) && !overflowed) return;  // nothing to add (uniform per workgroup)
     int eM;
     frexpf(M, &eM);  // M < 2^eM
     // float -> fixed point through the double "magic number": d = v*2^k + 1.5*2^52 holds round(v*2^k) in
@@ -287,14 +301,48 @@ __global__ void __launch_bounds__(kThreads) k_bin_accumulate(const Rec *__restri
         }
         for (; i < hi; i += kThreads) apply(r4[i]);
         __syncthreads();
-        float2 *dst = reinterpret_cast<float2 *>(grad_features) + (size_t)level * g.T + ((size_t)bucket << g.bucket_log) + wbase;
-        for (int j = threadIdx.x; j < ws; j += kThreads) {
-            const long long qx = acc64[2 * j], qy = acc64[2 * j + 1];
-            if (qx | qy) {
-                float2 v = dst[j];
-                v.x += (float)ldexp((double)qx, -k);
-                v.y += (float)ldexp((double)qy, -k);
-                dst[j] = v;
+        const size_t ebase = (size_t)level * g.T + ((size_t)bucket << g.bucket_log) + wbase;  // first entry of the window
+        if (ADAM) {
+            float2 *P = reinterpret_cast<float2 *>(ad.params) + ebase, *Mo = reinterpret_cast<float2 *>(ad.exp_avg) + ebase,
+                   *Vo = reinterpret_cast<float2 *>(ad.exp_avg_sq) + ebase;
+            float2 *og = overflowed ? reinterpret_cast<float2 *>(ad.overflow_grad) + ebase : nullptr;
+            for (int j = threadIdx.x; j < ws; j += kThreads) {
+                const long long qx = acc64[2 * j], qy = acc64[2 * j + 1];
+                float gx = 0.0f + (float)ldexp((double)qx, -k), gy = 0.0f + (float)ldexp((double)qy, -k);  // as grad_features would hold them
+                if (og) {
+                    const float2 e = og[j];
+                    if (e.x != 0.0f || e.y != 0.0f) {
+                        gx += e.x;
+                        gy += e.y;
+                        og[j] = make_float2(0.0f, 0.0f);
+                    }
+                }
+                if (gx != 0.0f || gy != 0.0f) {
+                    float2 p = P[j], m = Mo[j], v = Vo[j];
+                    adam_update_one<false>(p.x, m.x, v.x, gx, ad.a);
+                    adam_update_one<false>(p.y, m.y, v.y, gy, ad.a);
+                    P[j] = p;
+                    Mo[j] = m;
+                    Vo[j] = v;
+                    if (ad.half_table) {
+                        if (ad.half_dtype == SCANERF_F16)
+                            reinterpret_cast<__half2 *>(ad.half_table)[ebase + j] = __floats2half2_rn(p.x, p.y);
+                        else
+                            reinterpret_cast<__hip_bfloat162 *>(ad.half_table)[ebase + j] =
+                                __hip_bfloat162{ __float2bfloat16(p.x), __float2bfloat16(p.y) };  // round to nearest even, as torch
+                    }
+                }
+            }
+        } else {
+            float2 *dst = reinterpret_cast<float2 *>(grad_features) + ebase;
+            for (int j = threadIdx.x; j < ws; j += kThreads) {
+                const long long qx = acc64[2 * j], qy = acc64[2 * j + 1];
+                if (qx | qy) {
+                    float2 v = dst[j];
+                    v.x += (float)ldexp((double)qx, -k);
+                    v.y += (float)ldexp((double)qy, -k);
+                    dst[j] = v;
+                }
             }
         }
         __syncthreads();
@@ -306,10 +354,13 @@ __global__ void __launch_bounds__(kThreads) k_bin_accumulate(const Rec *__restri
 // (contract_point) and the same make_pairs/count_pairs as its emit_pairs, so the ranges it reserves
 // are exactly the ones the backward kernel fills.
 __global__ void __launch_bounds__(1024) k_bin_count_rays(RenderArgs f, BinGeom g, uint32_t *__restrict__ counts,
-                                                         uint32_t *__restrict__ maxbits)
+                                                         uint32_t *__restrict__ maxbits, uint32_t *__restrict__ overflow)
 {
     extern __shared__ uint32_t hist[];  // [16*NB]
-    if (blockIdx.x == 0 && threadIdx.x == 0) *maxbits = 0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        *maxbits = 0;
+        *overflow = 0;
+    }
     const int nbins = 16 * g.NB;
     for (int i = threadIdx.x; i < nbins; i += 1024) hist[i] = 0;
     __syncthreads();
@@ -446,10 +497,10 @@ SCANERF_API int scanerf_embedding_bg_backward_binned(const float *points, const 
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_acc);
         SCANERF_REQUIRE(e == hipSuccess, "embedding_bg_backward_binned: cannot reserve %zu B of LDS: %s", lds_acc, hipGetErrorString(e));
         hipLaunchKernelGGL((k_bin_accumulate<1024, 16, true>), dim3(nbins), dim3(1024), lds_acc, st, recs, starts, maxbits, g,
-                           grad_features);
+                           grad_features, AdamEpilogue{});
     } else {
         hipLaunchKernelGGL((k_bin_accumulate<256, 32, true>), dim3(nbins), dim3(256), lds_acc, st, recs, starts, maxbits, g,
-                           grad_features);
+                           grad_features, AdamEpilogue{});
     }
     return check_launch("embedding_bg_backward_binned");
 }
@@ -491,7 +542,7 @@ SCANERF_API int scanerf_render_scatter_plan(const float *rays_o, const float *ra
         f.inv_size4[k] = 4.0f / cfg->bbox_size[k];
     }
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_bin_count_rays, dim3(g.W), dim3(1024), (size_t)nbins * 4, st, f, g, w.counts, w.maxbits);
+    hipLaunchKernelGGL(k_bin_count_rays, dim3(g.W), dim3(1024), (size_t)nbins * 4, st, f, g, w.counts, w.maxbits, overflow_flag(w.recs));
     hipLaunchKernelGGL(k_bin_rowscan, dim3(nbins), dim3(kThreads), 0, st, w.counts, w.totals, g.W);
     hipLaunchKernelGGL(k_bin_starts, dim3(1), dim3(1024), 0, st, w.totals, w.starts, nbins);
     return check_launch("render_scatter_plan");
@@ -520,7 +571,7 @@ SCANERF_API int scanerf_render_scatter_accumulate(float *grad_features, int B, i
         SCANERF_REQUIRE(e == hipSuccess, "render_scatter_accumulate: cannot reserve %zu B of LDS: %s", lds_bytes,    \
                         hipGetErrorString(e));                                                                      \
         hipLaunchKernelGGL((k_bin_accumulate<TH, UU>), dim3(nbins), dim3(TH), lds_bytes, (hipStream_t)stream, w.recs, \
-                           w.starts, w.maxbits, g, grad_features);                                                  \
+                           w.starts, w.maxbits, g, grad_features, AdamEpilogue{});                                  \
     }
 #define SCANERF_LAUNCH_ACC_RUN(TH, UU)                                                                              \
     {                                                                                                               \
@@ -529,7 +580,7 @@ SCANERF_API int scanerf_render_scatter_accumulate(float *grad_features, int B, i
         SCANERF_REQUIRE(e == hipSuccess, "render_scatter_accumulate: cannot reserve %zu B of LDS: %s", lds_bytes,    \
                         hipGetErrorString(e));                                                                      \
         hipLaunchKernelGGL((k_bin_accumulate<TH, UU, true>), dim3(nbins), dim3(TH), lds_bytes, (hipStream_t)stream, \
-                           w.recs, w.starts, w.maxbits, g, grad_features);                                          \
+                           w.recs, w.starts, w.maxbits, g, grad_features, AdamEpilogue{});                          \
     }
     // measured on MI355X (tools/bench_accum.py, 5.4e8 records = 8.6 GB): record i -> lane i (lane-interleaved) 256x8 3.61 ms,
     // 512x8 3.38, 1024x4 3.31; U consecutive records per lane 1024x4 2.21, 512x8 2.34, 1024x8 2.35, 1024x16 2.01-2.06,
@@ -554,4 +605,36 @@ SCANERF_API int scanerf_render_scatter_accumulate(float *grad_features, int B, i
 #undef SCANERF_LAUNCH_ACC
 #undef SCANERF_LAUNCH_ACC_RUN
     return check_launch("render_scatter_accumulate");
+}
+
+// The records of one fused training step applied straight to the table: accumulate + fused sparse Adam in one pass
+// (cuda/adam_kernel.cu:24-69 semantics per element: untouched if its gradient is exactly zero; pass the PREVIOUS step count).
+// params / exp_avg / exp_avg_sq: [16][T][2] f32.  half_table (may be NULL): f16 / bf16 gather copy of params, refreshed for
+// the touched entries.  overflow_grad (may be NULL): the [16][T][2] f32 table given to scanerf_render_backward as
+// grad_features (only written if the record workspace overflowed); when the plan's overflow flag is set its entries are added
+// to the gradient and re-zeroed, otherwise it is not touched -- it never needs a per-step zero-fill.
+SCANERF_API int scanerf_render_scatter_accumulate_adam(float *params, float *exp_avg, float *exp_avg_sq, void *half_table,
+                                                       int half_dtype, float *overflow_grad, float lr, float beta1,
+                                                       float beta2, float eps, int step, int B, int S, int T,
+                                                       void *workspace, size_t workspace_bytes, scanerf_stream_t stream)
+{
+    if (B == 0) return 0;
+    BinGeom g;
+    SCANERF_REQUIRE(fused_geom(B, S, T, g), "render_scatter_accumulate_adam: shape B=%d S=%d T=%d not supported", B, S, T);
+    SCANERF_REQUIRE(params && exp_avg && exp_avg_sq && workspace, "render_scatter_accumulate_adam: null pointer");
+    SCANERF_REQUIRE(!half_table || half_dtype == SCANERF_F16 || half_dtype == SCANERF_BF16,
+                    "render_scatter_accumulate_adam: half_dtype=%d", half_dtype);
+    const int nbins = 16 * g.NB;
+    BinWorkspace w;
+    SCANERF_REQUIRE(bin_workspace_carve(workspace, workspace_bytes, nbins, g.W, w),
+                    "render_scatter_accumulate_adam: workspace too small (%zu B)", workspace_bytes);
+    g.capacity = w.capacity;
+    const size_t lds_bytes = (size_t)(2 << (g.bucket_log < 13 ? g.bucket_log : 13)) * 8;
+    AdamEpilogue ad{ params, exp_avg, exp_avg_sq, half_table, half_dtype, overflow_grad, make_adam_args(lr, beta1, beta2, eps, step) };
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bin_accumulate<256, 32, true, true>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    SCANERF_REQUIRE(e == hipSuccess, "render_scatter_accumulate_adam: cannot reserve %zu B of LDS: %s", lds_bytes, hipGetErrorString(e));
+    hipLaunchKernelGGL((k_bin_accumulate<256, 32, true, true>), dim3(nbins), dim3(256), lds_bytes, (hipStream_t)stream, w.recs,
+                       w.starts, w.maxbits, g, (float *)nullptr, ad);
+    return check_launch("render_scatter_accumulate_adam");
 }

@@ -29,6 +29,10 @@ struct Rec {
     uint32_t hdr;
     float tx, gx, gy;
 };
+// The word right before the records (bin_workspace_head reserves it).  Set (non-zero) when a record did not fit the workspace
+// and went to grad_features through atomics instead (emit_pairs / commit_pairs fallback); zeroed by the plan.  Lets the
+// Adam-fused accumulate skip the overflow table in the common case.
+__host__ __device__ inline uint32_t *overflow_flag(Rec *recs) { return reinterpret_cast<uint32_t *>(recs) - 1; }
 
 // One 16-byte record store.  Plain (write-back) stores: measured in the two-waves-per-SIMD backward kernel, non-temporal
 // stores of the same records take 2.7x the kernel's time (14.2 vs 5.2 ms) and sc1 (write-through) ones 1.5x: the records of
@@ -86,6 +90,7 @@ __device__ __forceinline__ void emit_pairs(const Pairs &pr, float gix, float giy
     const bool straddle = (pr.xm >> bucket_log) != 0u;
     const float a0 = 1.0f - pr.tx;
     auto fallback = [&](uint32_t bkt, uint32_t hdr, float tx, float ax, float ay) {
+        *overflow_flag(recs) = 1u;
         float *gs = grad_level + ((size_t)bkt << bucket_log) * 2;
         const uint32_t e0 = hdr & 0xffffu, e1 = hdr >> 16;
         unsafeAtomicAdd(gs + 2 * e0, (1.0f - tx) * ax);
@@ -149,6 +154,7 @@ __device__ __forceinline__ void commit_pairs(const Pairs &pr, const PairSlots &s
     const bool straddle = (pr.xm >> bucket_log) != 0u;
     const float a0 = 1.0f - pr.tx;
     auto fallback = [&](uint32_t bkt, uint32_t hdr, float tx, float ax, float ay) {
+        *overflow_flag(recs) = 1u;
         float *gs = grad_level + ((size_t)bkt << bucket_log) * 2;
         const uint32_t e0 = hdr & 0xffffu, e1 = hdr >> 16;
         unsafeAtomicAdd(gs + 2 * e0, (1.0f - tx) * ax);
@@ -203,9 +209,10 @@ struct BinWorkspace {
     Rec *recs;
     uint32_t capacity;
 };
+// [counts nbins*W][totals nbins][starts nbins+1][maxbits][... pad ...][overflow flag = the word right before the records]
 inline size_t bin_workspace_head(int nbins, int W)
 {
-    size_t head = ((size_t)nbins * W + 2 * (size_t)nbins + 2) * 4;
+    size_t head = ((size_t)nbins * W + 2 * (size_t)nbins + 3) * 4;
     return (head + 255) & ~(size_t)255;
 }
 inline bool bin_workspace_carve(void *workspace, size_t bytes, int nbins, int W, BinWorkspace &w)

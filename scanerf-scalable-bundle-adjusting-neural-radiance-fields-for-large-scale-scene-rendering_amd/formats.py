@@ -140,6 +140,8 @@ def load_check_point(path, model, consensus=None, dec_opt=None):
     hg = ckp["hashgrid"]
     with torch.no_grad():
         model.features.copy_(torch.as_tensor(hg["features"]).to(dev))
+        if hasattr(model, "invalidate_gather_table"):
+            model.invalidate_gather_table()
     model.log2dim = torch.as_tensor(hg["sampler_log2dim"]).int().to(dev)
     model.occupied_grid = torch.as_tensor(hg["occupied_grid"]).to(dev, torch.bool).contiguous()
     model._occ_full = bool(model.occupied_grid.all())

@@ -149,7 +149,7 @@ def scatter_supported(B, S, T):
 
 
 def scatter_plan(rays_o, rays_d, z_vals, resolutions, T, min_bbox, bbox_size, contract_mode, infinity, ray_valid=None,
-                 arith=None):
+                 arith=None, workspace=None):
     """Reserve the record ranges of the fused table-gradient path for this batch (count + scan).
     Returns the workspace tensor to hand to render_backward(scatter=(ws, grad_features)) and scatter_accumulate.
     The workspace is a per-(device, stream) cache: one plan/backward/accumulate sequence at a time.
@@ -159,7 +159,9 @@ def scatter_plan(rays_o, rays_d, z_vals, resolutions, T, min_bbox, bbox_size, co
     need = lib().scanerf_render_scatter_workspace_bytes(ctypes.c_int(B), ctypes.c_int(S), ctypes.c_int(T))
     if not need:
         raise RuntimeError(f"scanerf: fused scatter does not support B={B} S={S} T={T}")
-    ws = _capi.workspace(z_vals.device, need)
+    # (workspace: a caller-owned uint8 tensor instead of the cached one; smaller than `need` = overflow records take the
+    # atomic path -- tests)
+    ws = _capi.workspace(z_vals.device, need) if workspace is None else workspace
     cfg = _cfg(min_bbox, bbox_size, contract_mode, infinity, backward_arith() if arith is None else arith)
     check(lib().scanerf_render_scatter_plan(
         dev_ptr(rays_o, _f32, "rays_o"), dev_ptr(rays_d, _f32, "rays_d"), dev_ptr(z_vals, _f32, "z_vals"),
@@ -176,6 +178,22 @@ def scatter_accumulate(ws, grad_features, B, S):
         ctypes.c_int(grad_features.shape[1]), ctypes.c_void_p(ws.data_ptr()), ctypes.c_size_t(ws.numel()), stream()),
         "scatter_accumulate")
     return grad_features
+
+
+def scatter_accumulate_adam(ws, params, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, step, B, S, half_table=None,
+                            overflow_grad=None):
+    """The records the fused backward emitted into ws applied straight to the table: accumulate + fused sparse Adam in one
+    pass (no gradient table, no zero-fill, no scan of it).  `step` = the previous step count (cuda/adam_kernel.cu:83).
+    half_table: optional f16 / bf16 gather copy of params, refreshed where params change; overflow_grad: the zero table
+    handed to render_backward as grad_features (touched only if the record workspace overflows)."""
+    check(lib().scanerf_render_scatter_accumulate_adam(
+        dev_ptr(params, _f32, "params"), dev_ptr(exp_avg, _f32, "exp_avg"), dev_ptr(exp_avg_sq, _f32, "exp_avg_sq"),
+        dev_ptr(half_table, (torch.float16, torch.bfloat16), "half_table", allow_none=True),
+        ctypes.c_int(feat_dtype_code(half_table) if half_table is not None else 0),
+        dev_ptr(overflow_grad, _f32, "overflow_grad", allow_none=True), ctypes.c_float(lr), ctypes.c_float(beta1),
+        ctypes.c_float(beta2), ctypes.c_float(eps), ctypes.c_int(step), ctypes.c_int(B), ctypes.c_int(S),
+        ctypes.c_int(params.shape[1]), ctypes.c_void_p(ws.data_ptr()), ctypes.c_size_t(ws.numel()), stream()),
+        "scatter_accumulate_adam")
 
 
 def scatter_table_grad(points, dfeat, grad_features, resolutions):

@@ -132,6 +132,27 @@ class TileModel(nn.Module):
         self.exp_avg = torch.zeros_like(self.features)
         self.exp_avg_sq = torch.zeros_like(self.features)
         self.adam_step = 0
+        self._half_table = None       # f16 / bf16 gather copy of the table (configs[2]); kept in step by the Adam epilogue
+        self._overflow_grad = None    # zero table for the fused scatter's workspace-overflow path (never filled per step)
+
+    def gather_table(self):
+        """The table the fused kernels gather from: the fp32 master, or its resident half-precision copy (half the gather
+        bytes, fp32 accumulate).  The copy is converted ONCE; after that the accumulate's Adam epilogue rewrites exactly the
+        entries it moves (train_step_fused), so there is no per-step full-table conversion."""
+        if self.table_dtype == torch.float32:
+            return self.features
+        if self._half_table is None or self._half_table.dtype != self.table_dtype:
+            self._half_table = self.features.detach().to(self.table_dtype).contiguous()
+        return self._half_table
+
+    def invalidate_gather_table(self):
+        """Call after writing the fp32 master any other way than through train_step_fused (loading a checkpoint, ...)."""
+        self._half_table = None
+
+    def overflow_grad(self):
+        if self._overflow_grad is None:
+            self._overflow_grad = torch.zeros_like(self.features)
+        return self._overflow_grad
 
     def set_occupancy(self, grid):
         """Replace the sampler's occupancy grid (pruning: hashgrid/__init__.py:138-225)."""
@@ -183,7 +204,7 @@ class TileModel(nn.Module):
         z, dist = self.sample(rays_o, rays_d, S)
         valid = torch.all(z != -1, dim=-1)
         self.packed.pack(self.decoder.blob(), network.weight_feature(global_step, self.device))
-        table = self.features if self.table_dtype == torch.float32 else self.features.to(self.table_dtype)
+        table = self.gather_table()
         out, w = render.render_forward(rays_o, rays_d, z, dist, table, self.resolution, self.packed,
                                        self.min_bbox.tolist(), self.bbox_size.tolist(), render.FORE, False,
                                        ray_valid=valid)
@@ -214,7 +235,7 @@ class TileModel(nn.Module):
         """tile.py:639-692 on the fused kernels: foreground (occupancy-sampled, contract_fore) and
         background (inverse-z, contract_bg, infinity) renders, merged with the foreground's T_left."""
         self.packed.pack(self.decoder.blob(), network.weight_feature(global_step, self.device))
-        table = self.features if self.table_dtype == torch.float32 else self.features.to(self.table_dtype)
+        table = self.gather_table()
         box = (self.min_bbox.tolist(), self.bbox_size.tolist())
         z, dist = self.sample(rays_o, rays_d, S_fg)
         vf = torch.all(z != -1, dim=-1)
@@ -239,6 +260,7 @@ class TileModel(nn.Module):
         adam_step_cuda(self.features.data.view(K, 8), g.view(K, 8), self.exp_avg.view(K, 8),
                        self.exp_avg_sq.view(K, 8), lr, betas[0], betas[1], eps, self.adam_step)
         self.adam_step += 1
+        self._half_table = None  # (the fused path's epilogue keeps it in step instead: train_step_fused)
 
 
 def sphere_shell_occupancy(model, radius, thickness):
@@ -332,9 +354,12 @@ def train_step_ops(model, dec_opt, rays_o, rays_d, target, S, global_step, table
 
 
 def train_step_fused(model, dec_opt, rays_o, rays_d, target, S, global_step, table_lr=1e-2, timer=None,
-                     pose_grads=False, fused_scatter=None, compact_rays=None, overlap_plan=False, dec_step=True):
+                     pose_grads=False, fused_scatter=None, compact_rays=None, overlap_plan=False, dec_step=True,
+                     fused_adam=True):
     """The same iteration as train_step_ops on the fused kernels: one launch for the render forward,
     one for its adjoint, the atomic-free binned scatter for the table gradient, fused sparse Adam.
+    fused_adam (default): the sparse Adam on the table runs in the accumulate's epilogue (no gradient table, model.features.grad
+    is NOT set); False keeps accumulate -> model.features.grad -> adam_step_cuda (the binding-surface op).
     pose_grads=True also returns dL/d(rays_o), dL/d(rays_d) (feed them to the pose graph:
     torch.autograd.backward([rays_o, rays_d], [g_o, g_d]) -- camera_utils.py:65-84 in the reference)."""
     B = rays_o.shape[0]
@@ -382,8 +407,8 @@ def train_step_fused(model, dec_opt, rays_o, rays_d, target, S, global_step, tab
                 ws = render.scatter_plan(rays_o, rays_d, z, model.resolution, T, *box, ray_valid=valid, arith=bwd_arith)
                 plan_done = torch.cuda.Event()
                 plan_done.record(side)
-        # gather table: the fp32 master itself, or its bf16/f16 image (configs[2]: half the gather bytes, fp32 accumulate)
-        table = model.features if model.table_dtype == torch.float32 else model.features.detach().to(model.table_dtype)
+        # gather table: the fp32 master itself, or its resident bf16/f16 copy (configs[2]: half the gather bytes, fp32 accumulate)
+        table = model.gather_table()
         with _sec(timer, "render_forward", B * (24 + 20 + S * 16 * 8 * 2 * table.element_size()),
                   B * S * MLP_FLOPS_PER_SAMPLE):
             out, _ = render.render_forward(rays_o, rays_d, z, dist, table, model.resolution, model.packed, *box,
@@ -391,7 +416,9 @@ def train_step_fused(model, dec_opt, rays_o, rays_d, target, S, global_step, tab
     # loss and dL/d(out_ray) in two launches (the torch graph for it was ~60 tiny kernels with host-bound gaps)
     loss, grad_out = render.photometric_loss_grad(out, target, valid, 0.01)
     with torch.no_grad():
-        gtab = torch.zeros_like(model.features)
+        # the fused scatter ends in the Adam epilogue: no gradient table (only the overflow table, never filled per step)
+        adam_epilogue = fused and fused_adam
+        gtab = model.overflow_grad() if adam_epilogue else torch.zeros_like(model.features)
         gblob = torch.zeros(network.PARAMSIZE, device=dev)
         ray_bufs = (torch.zeros(B, ntile, device=dev), torch.zeros(B, 2, 64, device=dev)) if pose_grads else None
         g_o = g_d = None
@@ -410,7 +437,12 @@ def train_step_fused(model, dec_opt, rays_o, rays_d, target, S, global_step, tab
         if pose_grads:
             g_o, g_d = render.ray_gradients(rays_o, rays_d, z, model.features, model.resolution, blob, box[0], box[1],
                                             box[2], dfeat, ray_bufs[0], ray_bufs[1], ray_valid=valid)
-        if fused:
+        if adam_epilogue:
+            with _sec(timer, "table_grad_accumulate_adam", B * S * 16 * 64 + model.features.numel() * 28):
+                render.scatter_accumulate_adam(ws, model.features.data, model.exp_avg, model.exp_avg_sq, table_lr, 0.9, 0.99, 1e-15,
+                                               model.adam_step, B, S, half_table=model._half_table, overflow_grad=gtab)
+            model.adam_step += 1
+        elif fused:
             with _sec(timer, "table_grad_accumulate", B * S * 16 * 64):
                 render.scatter_accumulate(ws, gtab, B, S)
         else:
@@ -418,9 +450,10 @@ def train_step_fused(model, dec_opt, rays_o, rays_d, target, S, global_step, tab
                 / model._size_dev * 4.0 - 2.0
             with _sec(timer, "table_grad_scatter", B * S * 16 * (8 + 16 * 8)):
                 render.scatter_table_grad(pts.contiguous(), dfeat, gtab, model.resolution)
-        model.features.grad = gtab
-        with _sec(timer, "sparse_adam", model.features.numel() * 28):
-            model.table_adam(table_lr)
+        if not adam_epilogue:
+            model.features.grad = gtab
+            with _sec(timer, "sparse_adam", model.features.numel() * 28):
+                model.table_adam(table_lr)
         model.decoder.params.grad = gblob
         if dec_step:  # False: the caller steps the optimiser itself (it holds more parameter groups: camera poses)
             dec_opt.step()

@@ -72,3 +72,36 @@ def test_backward_is_bit_reproducible(arith):
                 assert torch.equal(gblob, ref[1]), f"{arith}: decoder gradient of launch {it} differs from launch 0"
     finally:
         render.set_arith(render.DEFAULT_ARITH)
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float32])
+def test_forward_as_the_training_step_calls_it_is_bit_reproducible(dt):
+    """Forward with the x-stash and tile_T outputs (what train_step_fused launches) after two training steps: this is the
+    configuration in which a vector-memory store picked up a rewritten data register in 1 of ~4e5 tiles before
+    SCANERF_STORE_GUARD (csrc/common.h)."""
+    from scanerf_amd import render
+    from scanerf_amd.tile_model import TileModel, train_step_fused
+    torch.manual_seed(9)
+    B, S = 16384, 64
+    o = torch.rand(B, 3, device=DEV) * 8 - 4
+    d = torch.nn.functional.normalize(torch.randn(B, 3, device=DEV), dim=-1) * (0.5 + torch.rand(B, 1, device=DEV))
+    tgt = torch.rand(B, 3, device=DEV)
+    m = TileModel([-4, -4, -4], [8, 8, 8], DEV, log2_T=14, seed=1, table_dtype=dt)
+    with torch.no_grad():
+        m.features.mul_(30.0)
+    opt = torch.optim.Adam(m.decoder.parameters(), lr=1e-3, betas=(0.9, 0.99), eps=1e-15)
+    for i in range(2):
+        train_step_fused(m, opt, o, d, tgt, S, 20000 + i)
+    z, dist = m.sample(o, d, S)
+    m.packed.pack(m.decoder.blob(), m.weight_feature(20000))
+    box = (m.min_bbox.tolist(), m.bbox_size.tolist(), render.FORE, False)
+    table = m.gather_table()
+    ref = None
+    for it in range(120):
+        tile_T = torch.empty(B, render.tile_T_columns(S), device=DEV)
+        xs = torch.empty(B * S, 32, device=DEV)
+        out, _ = render.render_forward(o, d, z, dist, table, m.resolution, m.packed, *box, want_weights=False, tile_T=tile_T, xstash=xs)
+        if ref is None:
+            ref = (out.clone(), xs.clone(), tile_T.clone())
+        else:
+            assert torch.equal(out, ref[0]) and torch.equal(xs, ref[1]) and torch.equal(tile_T, ref[2]), f"launch {it} differs (table {dt})"

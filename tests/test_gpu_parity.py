@@ -761,3 +761,117 @@ def _compaction_equivalence(table_dtype, TileModel, sphere_shell_occupancy, trai
         n_off = int((dfe > tol).sum())
         db = (res["compact"][2] - res[other][2]).abs().max() / res[other][2].abs().max()
         assert n_off <= 16 and float(dfe.max()) < 0.05 and float(db) < tol, (other, n_off, float(dfe.max()), float(db))
+
+
+# ------------------------------------------------------------------ accumulate + fused sparse Adam (a7 + a14 in one pass)
+def _emit_records(m, B, S_, seed, workspace=None):
+    """plan -> forward -> backward (emits the records) on a fresh batch; returns what the two accumulate flavours need."""
+    from scanerf_amd import network, render
+    torch.manual_seed(seed)
+    o = torch.rand(B, 3, device=DEV) * 8 - 4
+    d = torch.nn.functional.normalize(torch.randn(B, 3, device=DEV), dim=-1) * (0.5 + torch.rand(B, 1, device=DEV))
+    z, dist = m.sample(o, d, S_)
+    wf = network.weight_feature(20000, DEV)
+    m.packed.pack(m.decoder.blob(), wf)
+    box = (m.min_bbox.tolist(), m.bbox_size.tolist(), render.FORE, False)
+    tile_T = torch.empty(B, render.tile_T_columns(S_), device=DEV)
+    xs = torch.empty(B * S_, 32, device=DEV)
+    out, _ = render.render_forward(o, d, z, dist, m.features, m.resolution, m.packed, *box, want_weights=False, tile_T=tile_T, xstash=xs)
+    gout = torch.randn(B, 16, device=DEV) / B
+    T = m.features.shape[1]
+    ws = render.scatter_plan(o, d, z, m.resolution, T, *box, workspace=workspace)
+    overflow = torch.zeros_like(m.features)
+    render.render_backward(o, d, z, dist, m.features, m.resolution, m.packed, wf, *box, out, tile_T, gout, xstash=xs,
+                           scatter=(ws, overflow), want_dfeat=False)
+    return ws, overflow
+
+
+@pytest.mark.parametrize("log2_T,half", [(14, None), (14, torch.bfloat16), (14, torch.float16), (22, None)])
+def test_accumulate_adam_epilogue_is_bit_exact(S, log2_T, half):
+    """The sparse Adam applied in the accumulate's epilogue == accumulate into a gradient table, then the oracle's adam_step
+    (cuda/adam_kernel.cu:24-69 restated) on it: bit for bit, for parameters and both moments, over 3 steps; untouched entries
+    keep their bits; the optional half-precision gather copy equals the converted master.  T = 2^22: windowed buckets."""
+    from scanerf_amd import render
+    from scanerf_amd.tile_model import TileModel
+    B, S_ = (3000, 64) if log2_T == 14 else (2000, 64)
+    m = TileModel([-4, -4, -4], [8, 8, 8], DEV, log2_T=log2_T, seed=3)
+    with torch.no_grad():
+        m.features.mul_(30.0 * 2 ** ((log2_T - 14) / 2))
+    P = m.features.data
+    M, V = torch.zeros_like(P), torch.zeros_like(P)
+    p_ref = P.cpu().numpy().reshape(-1, 8).copy()
+    m_ref, v_ref = np.zeros_like(p_ref), np.zeros_like(p_ref)
+    H = P.to(half).contiguous() if half is not None else None
+    for step in range(3):
+        ws, overflow = _emit_records(m, B, S_, 40 + step)
+        gtab = torch.zeros_like(P)
+        render.scatter_accumulate(ws, gtab, B, S_)          # the same records, into a gradient table
+        assert float(overflow.abs().max()) == 0.0
+        g_np = gtab.cpu().numpy().reshape(-1, 8)
+        touched = g_np != 0
+        assert 0.001 < touched.mean() < 1.0
+        O.adam_step(p_ref, g_np, m_ref, v_ref, 1e-2, 0.9, 0.99, 1e-15, step)   # in place on the references
+        before = P.clone()
+        render.scatter_accumulate_adam(ws, P, M, V, 1e-2, 0.9, 0.99, 1e-15, step, B, S_, half_table=H, overflow_grad=overflow)
+        torch.cuda.synchronize()
+        assert np.array_equal(P.cpu().numpy().reshape(-1, 8), p_ref), f"step {step}: parameters"
+        assert np.array_equal(M.cpu().numpy().reshape(-1, 8), m_ref) and np.array_equal(V.cpu().numpy().reshape(-1, 8), v_ref)
+        assert torch.equal(P.reshape(-1, 8)[~torch.from_numpy(touched).to(DEV)], before.reshape(-1, 8)[~torch.from_numpy(touched).to(DEV)])
+        if H is not None:
+            assert torch.equal(H, P.to(half)), "half-precision gather copy out of step with the master"
+
+
+def test_accumulate_adam_uses_the_overflow_table_only_when_flagged(S):
+    """Record workspace too small: the overflowing records go to the overflow table through atomics, the plan's flag is set,
+    and the epilogue folds that table in (and re-zeroes it).  The update then equals the full-workspace one up to the f32
+    atomics' summation order."""
+    from scanerf_amd import render
+    from scanerf_amd._capi import lib
+    from scanerf_amd.tile_model import TileModel
+    import ctypes
+    B, S_ = 2000, 64
+    res = {}
+    for tag in ("full", "small"):
+        m = TileModel([-4, -4, -4], [8, 8, 8], DEV, log2_T=14, seed=3)
+        with torch.no_grad():
+            m.features.mul_(30.0)
+        P = m.features.data
+        M, V = torch.zeros_like(P), torch.zeros_like(P)
+        need = lib().scanerf_render_scatter_workspace_bytes(ctypes.c_int(B), ctypes.c_int(S_), ctypes.c_int(P.shape[1]))
+        wsbuf = torch.empty(need if tag == "full" else need // 3, dtype=torch.uint8, device=DEV)
+        ws, overflow = _emit_records(m, B, S_, 77, workspace=wsbuf)
+        if tag == "small":
+            assert float(overflow.abs().max()) > 0.0
+        render.scatter_accumulate_adam(ws, P, M, V, 1e-2, 0.9, 0.99, 1e-15, 0, B, S_, overflow_grad=overflow)
+        torch.cuda.synchronize()
+        assert float(overflow.abs().max()) == 0.0   # consumed and re-zeroed (or never touched)
+        res[tag] = (M.clone(), V.clone())
+    # first moments = (1 - beta1) * gradient: compare the gradients the two runs saw
+    a, b = res["full"][0], res["small"][0]
+    assert float((a - b).abs().max()) <= 2e-5 * float(a.abs().max())
+    assert int(((a != 0) != (b != 0)).sum()) <= 8
+
+
+def test_train_step_fused_adam_epilogue_equals_separate_adam(S):
+    """train_step_fused(fused_adam=True) (default: Adam in the accumulate's epilogue) and fused_adam=False (accumulate ->
+    features.grad -> adam_step_cuda) move the table identically, bit for bit, and keep a bf16 gather table in step."""
+    from scanerf_amd.tile_model import TileModel, train_step_fused
+    torch.manual_seed(9)
+    B, S_ = 4096, 64
+    o = torch.rand(B, 3, device=DEV) * 8 - 4
+    d = torch.nn.functional.normalize(torch.randn(B, 3, device=DEV), dim=-1) * (0.5 + torch.rand(B, 1, device=DEV))
+    tgt = torch.rand(B, 3, device=DEV)
+    for dt in (torch.float32, torch.bfloat16):
+        out = {}
+        for fused_adam in (True, False):
+            m = TileModel([-4, -4, -4], [8, 8, 8], DEV, log2_T=14, seed=1, table_dtype=dt)
+            with torch.no_grad():
+                m.features.mul_(30.0)
+            opt = torch.optim.Adam(m.decoder.parameters(), lr=1e-3, betas=(0.9, 0.99), eps=1e-15)
+            losses = [float(train_step_fused(m, opt, o, d, tgt, S_, 20000 + i, fused_adam=fused_adam)) for i in range(3)]
+            out[fused_adam] = (losses, m.features.detach().clone(), m.exp_avg.clone(), m.exp_avg_sq.clone(), m.adam_step)
+            if dt != torch.float32 and fused_adam:
+                assert m._half_table is not None and torch.equal(m._half_table, m.features.detach().to(dt))
+        assert out[True][0] == out[False][0] and out[True][4] == out[False][4] == 3
+        for k in (1, 2, 3):
+            assert torch.equal(out[True][k], out[False][k]), (dt, k)

@@ -1,0 +1,45 @@
+"""Distinct results of N launches of the forward (with x-stash and tile_T outputs, as the training step calls it) on the same
+inputs after PRE training steps; must be 1."""
+import hashlib, os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import scanerf_amd
+from scanerf_amd import network, render
+from scanerf_amd.tile_model import TileModel, train_step_fused
+DEV = "cuda:0"
+torch.manual_seed(9)
+B, S = int(os.environ.get("B", 4096)), 64
+o = torch.rand(B, 3, device=DEV) * 8 - 4
+d = torch.nn.functional.normalize(torch.randn(B, 3, device=DEV), dim=-1) * (0.5 + torch.rand(B, 1, device=DEV))
+tgt = torch.rand(B, 3, device=DEV)
+dt = {"bf16": torch.bfloat16, "f32": torch.float32, "f16": torch.float16}[os.environ.get("DT", "bf16")]
+m = TileModel([-4, -4, -4], [8, 8, 8], DEV, log2_T=14, seed=1, table_dtype=dt)
+with torch.no_grad():
+    m.features.mul_(30.0)
+opt = torch.optim.Adam(m.decoder.parameters(), lr=1e-3, betas=(0.9, 0.99), eps=1e-15)
+for i in range(int(os.environ.get("PRE", 2))):
+    train_step_fused(m, opt, o, d, tgt, S, 20000 + i)
+z, dist = m.sample(o, d, S)
+m.packed.pack(m.decoder.blob(), m.weight_feature(20000))
+box = (m.min_bbox.tolist(), m.bbox_size.tolist(), render.FORE, False)
+table = m.gather_table()
+ref_out = ref_xs = None
+n_out = n_xs = 0
+detail = 0
+for it in range(int(os.environ.get("N", 60))):
+    tile_T = torch.empty(B, render.tile_T_columns(S), device=DEV)
+    xs = torch.empty(B * S, 32, device=DEV)
+    out, _ = render.render_forward(o, d, z, dist, table, m.resolution, m.packed, *box, want_weights=False, tile_T=tile_T, xstash=xs)
+    if ref_out is None:
+        ref_out, ref_xs = out.clone(), xs.clone()
+        continue
+    if not torch.equal(out, ref_out):
+        n_out += 1
+    if not torch.equal(xs, ref_xs):
+        n_xs += 1
+        if detail < 3:
+            detail += 1
+            dif = torch.nonzero(xs != ref_xs)
+            rows = dif[:, 0].unique()
+            print(f"  launch {it}: {dif.shape[0]} x-stash elements differ in {rows.numel()} samples; first (ray, sample): "
+                  f"{[(int(r) // S, int(r) % S) for r in rows[:4]]}; positions {dif[dif[:, 0] == rows[0]][:, 1].tolist()}")
+print(f"{os.environ.get('TAG', '')} table {dt}: launches whose out / x-stash differ from launch 0: {n_out} / {n_xs} of {int(os.environ.get('N', 60)) - 1}")
