@@ -208,6 +208,16 @@ int scanerf_render_scatter_accumulate_adam(float *params, float *exp_avg, float 
                                            int half_dtype, float *overflow_grad, float lr, float beta1, float beta2,
                                            float eps, int step, int B, int S, int T, void *workspace,
                                            size_t workspace_bytes, scanerf_stream_t stream);
+/* Valid-ray compaction of a training batch (hashgrid/__init__.py:419-434: valid = all(z_vals != -1), then rays_o[valid],
+ * rays_d[valid], z_vals[valid], dists[valid]; tile.py gathers the targets the same way), without torch's nonzero + gathers:
+ * scanerf_ray_valid writes the flags, scanerf_compact_rays moves the valid rays' entries, in their original order, to rows
+ * [0, *count) of the out_* buffers (each sized for B rays; count: device int32).  target / out_t and out_index [B] i32 (source
+ * ray of each output row) may be NULL.  valid: 16-byte aligned.  Wave ballot + popcount prefix sums, no atomics. */
+int scanerf_ray_valid(const float *z_vals, uint8_t *valid, int B, int S, scanerf_stream_t stream);
+int scanerf_compact_rays(const uint8_t *valid, int B, int S, const float *rays_o, const float *rays_d, const float *target,
+                         const float *z_vals, const float *dists, float *out_o, float *out_d, float *out_t, float *out_z,
+                         float *out_dist, int32_t *out_index, int32_t *count, scanerf_stream_t stream);
+
 /* Photometric loss of the training step and dL/d(out_ray) in two launches (criterions.py:90,142-144 MSE over the valid
  * rays' rgb + tile.py:999 reg_weight * l2_reg_specular = mean over valid rays x 3 of out_ray[:,14]):
  *   loss [1] = (sum_valid |rgb - target|^2 + reg_weight * sum_valid out_ray[:,14]) / (3 * n_valid)

@@ -30,7 +30,7 @@ SYMBOLS = [
     "scanerf_ray_block_intersection", "scanerf_render_sample_points", "scanerf_prepare_points", "scanerf_pts_inference",
     "scanerf_accumulate_color", "scanerf_render_inverse_z_sampling", "scanerf_bg_pts_inference_v2",
     "scanerf_update_outgoing_bidx", "scanerf_update_outgoing_bidx_v2", "scanerf_get_last_block",
-    "scanerf_ray_firsthit_block", "scanerf_process_occupied_grid", "scanerf_embedding_bg_point_grad", "scanerf_voxelize_mesh",
+    "scanerf_ray_firsthit_block", "scanerf_process_occupied_grid", "scanerf_embedding_bg_point_grad", "scanerf_voxelize_mesh", "scanerf_ray_valid", "scanerf_compact_rays",
 ]
 
 

@@ -144,6 +144,41 @@ def photometric_loss_grad(out_ray, target, ray_valid=None, reg_weight=0.01, grad
     return loss, grad_out
 
 
+def ray_valid(z_vals):
+    """[B] uint8: every sample of the ray's row != -1 (hashgrid/__init__.py:419 torch.all(z_vals != -1, dim=-1))."""
+    B, S = z_vals.shape
+    n = (B + 15) // 16 * 16  # scanerf_compact_rays reads the flags 16 bytes at a time
+    buf = torch.zeros(n, dtype=torch.uint8, device=z_vals.device)
+    check(lib().scanerf_ray_valid(dev_ptr(z_vals, _f32, "z_vals"), dev_ptr(buf, torch.uint8, "valid"), ctypes.c_int(B),
+                                  ctypes.c_int(S), stream()), "ray_valid")
+    return buf[:B]
+
+
+def compact_rays(valid, rays_o, rays_d, target, z_vals, dists, want_index=False):
+    """Order-preserving compaction of the valid rays (hashgrid/__init__.py:419-434) in one launch (wave ballot / popcount
+    prefix sums): -> (count, rays_o, rays_d, target, z_vals, dists[, index]) with the valid rays' rows first; the returned
+    tensors are views of length `count` (one host read of the count, as torch's boolean-mask indexing needs too).
+    valid: from ray_valid()."""
+    B, S = z_vals.shape
+    dev = z_vals.device
+    if valid.dtype not in (torch.uint8, torch.bool) or valid.data_ptr() % 16:
+        raise RuntimeError("scanerf: compact_rays needs the 16-byte aligned uint8 flags ray_valid() returns")
+    o, d = torch.empty_like(rays_o), torch.empty_like(rays_d)
+    t = torch.empty_like(target) if target is not None else None
+    z, di = torch.empty_like(z_vals), torch.empty_like(dists)
+    idx = torch.empty(B, dtype=torch.int32, device=dev) if want_index else None
+    count = torch.zeros(1, dtype=torch.int32, device=dev)
+    check(lib().scanerf_compact_rays(
+        dev_ptr(valid, (torch.uint8, torch.bool), "valid"), ctypes.c_int(B), ctypes.c_int(S), dev_ptr(rays_o, _f32, "rays_o"),
+        dev_ptr(rays_d, _f32, "rays_d"), dev_ptr(target, _f32, "target", allow_none=True), dev_ptr(z_vals, _f32, "z_vals"),
+        dev_ptr(dists, _f32, "dists"), dev_ptr(o, _f32, "out_o"), dev_ptr(d, _f32, "out_d"), dev_ptr(t, _f32, "out_t", allow_none=True),
+        dev_ptr(z, _f32, "out_z"), dev_ptr(di, _f32, "out_dist"), dev_ptr(idx, torch.int32, "out_index", allow_none=True),
+        dev_ptr(count, torch.int32, "count"), stream()), "compact_rays")
+    n = int(count.item())
+    res = (n, o[:n], d[:n], t[:n] if t is not None else None, z[:n], di[:n])
+    return res + (idx[:n],) if want_index else res
+
+
 def scatter_supported(B, S, T):
     return lib().scanerf_render_scatter_workspace_bytes(ctypes.c_int(B), ctypes.c_int(S), ctypes.c_int(T)) != 0
 

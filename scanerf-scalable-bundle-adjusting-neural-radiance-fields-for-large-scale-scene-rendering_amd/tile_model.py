@@ -367,17 +367,18 @@ def train_step_fused(model, dec_opt, rays_o, rays_d, target, S, global_step, tab
     with torch.no_grad():
         with _sec(timer, "sample_points_grid", B * (24 + 2 * 4 * S)):
             z, dist = model.sample(rays_o, rays_d, S)
-        valid = torch.all(z != -1, dim=-1)
+        valid = render.ray_valid(z)  # all(z != -1) per ray (hashgrid/__init__.py:419)
         if compact_rays is None:  # a fully occupied sampler grid cannot produce invalid rays from inside the tile
             compact_rays = not getattr(model, "_occ_full", False) and not pose_grads
         if compact_rays:
-            # valid-mask compaction (hashgrid/__init__.py:419-421: the reference renders rays_o[valid] only): the fused
-            # backward runs its 4 waves per workgroup in lock step, so an invalid ray costs as much as a valid one there
-            keep = torch.nonzero(valid)[:, 0]
-            if keep.numel() < B:
-                rays_o, rays_d, target = rays_o[keep].contiguous(), rays_d[keep].contiguous(), target[keep].contiguous()
-                z, dist = z[keep].contiguous(), dist[keep].contiguous()
-                B = keep.numel()
+            # valid-ray compaction (hashgrid/__init__.py:419-421: the reference renders rays_o[valid] only) in one HIP launch
+            # (csrc/compact.hip: wave ballot + popcount prefix sums): the fused backward runs its waves in lock step, so an
+            # invalid ray costs as much as a valid one there
+            with _sec(timer, "compact_rays", B * (36 + 8 * S)):
+                n, co, cd, ct, cz, cdist = render.compact_rays(valid, rays_o, rays_d, target, z, dist)
+            if n < B:
+                rays_o, rays_d, target, z, dist = co, cd, ct, cz, cdist
+                B = n
                 valid = None
             if B == 0:
                 return torch.zeros((), device=dev)

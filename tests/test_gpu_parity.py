@@ -875,3 +875,27 @@ def test_train_step_fused_adam_epilogue_equals_separate_adam(S):
         assert out[True][0] == out[False][0] and out[True][4] == out[False][4] == 3
         for k in (1, 2, 3):
             assert torch.equal(out[True][k], out[False][k]), (dt, k)
+
+
+@pytest.mark.parametrize("B,S_,p_valid", [(70000, 128, 0.4), (1000, 33, 0.9), (257, 64, 0.0), (300, 16, 1.0), (5, 7, 0.5)])
+def test_compact_rays_equals_boolean_mask_indexing(S, B, S_, p_valid):
+    """csrc/compact.hip against what the reference does (hashgrid/__init__.py:419-434): valid = all(z != -1, -1), then
+    x[valid] for every per-ray array -- bit-identical, order-preserving, including empty and full batches."""
+    from scanerf_amd import render
+    gen = torch.Generator(device=DEV).manual_seed(B)
+    o, d, t = (torch.randn(B, 3, device=DEV, generator=gen) for _ in range(3))
+    z = torch.rand(B, S_, device=DEV, generator=gen) + 0.5
+    dist = torch.rand(B, S_, device=DEV, generator=gen)
+    bad = torch.rand(B, device=DEV, generator=gen) >= p_valid
+    z[bad] = -1.0                                             # the sampler's sentinel rows
+    if B > 20:
+        z[3, S_ - 1] = -1.0                                   # a single sentinel anywhere invalidates the ray
+        z[7, 0] = -1.0
+    valid = render.ray_valid(z)
+    want = torch.all(z != -1, dim=-1)
+    assert torch.equal(valid.bool(), want)
+    n, co, cd, ct, cz, cdist, idx = render.compact_rays(valid, o, d, t, z, dist, want_index=True)
+    assert n == int(want.sum())
+    for got, src in ((co, o), (cd, d), (ct, t), (cz, z), (cdist, dist)):
+        assert got.shape[0] == n and torch.equal(got, src[want])
+    assert torch.equal(idx.long(), torch.nonzero(want)[:, 0])
