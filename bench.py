@@ -59,8 +59,10 @@ def parse():
     ap.add_argument("--scatter", default="auto", choices=["auto", "fused", "dfeat"],
                     help="table-gradient records emitted by the backward kernel (fused, default) or by the stand-alone "
                          "binned scatter from a level-major dfeat (tuning comparison)")
-    ap.add_argument("--workload", default="configs1", choices=["configs1", "configs2", "configs4-render"],
+    ap.add_argument("--workload", default="configs1", choices=["configs1", "configs1-fgbg", "configs2", "configs4-render"],
                     help="configs1 (default, the metric's configuration): fp32 table, fully occupied sampler grid; "
+                         "configs1-fgbg: the reference's complete iteration (tile.py:639-692, config/default.yaml:15-18): foreground + "
+                         "T_left * background branch, --samples fg + --samples bg samples per ray, one merged loss, one Adam step; "
                          "configs2: + sphere-shell occupancy at log2dim 7 and a bf16 table (fp32 master + fused sparse Adam); "
                          "configs4-render: 4 tiles per GPU + background, one 1920x1080 novel view per step (render rays/s)")
     return ap.parse_args()
@@ -317,6 +319,10 @@ def main():
     if path == "auto":
         path = "fused" if hasattr(tm, "train_step_fused") else "ops"
     step_fn = tm.train_step_fused if path == "fused" else tm.train_step_ops
+    fgbg = args.workload == "configs1-fgbg"
+    if fgbg:
+        path = "fused"
+        step_fn = lambda m_, o_, ro, rd, tg, S_, st, timer=None: tm.train_step_fgbg(m_, o_, ro, rd, tg, S_, S_, st, timer=timer)
     if path == "fused" and args.scatter != "auto":
         import functools
         step_fn = functools.partial(tm.train_step_fused, fused_scatter=args.scatter == "fused")
@@ -374,7 +380,7 @@ def main():
     if occ:
         dtype_label = "bf16 gather table, fp32 master + accumulate; " + dtype_label
     f32_ms = None
-    if h3_run and not occ:
+    if h3_run and not occ and not fgbg:
         _render.set_arith("f32")
         try:
             for i in range(2):
@@ -402,6 +408,9 @@ def main():
             "config": {"workload": (f"configs[2]: as configs[1] + sphere-shell occupancy (r=3 m, 0.5 m thick, log2dim 7, "
                                     f"{float(model.occupied_grid.float().mean()):.3f} of cells), bf16 gather table (fp32 master, fp32 accumulate), "
                                     f"fused sparse Adam; {B} rays x {S} samples" if occ else
+                                    f"configs[1] rays through the reference's COMPLETE iteration (tile.py:639-692): foreground (occupancy-"
+                                    f"sampled, contract_fore) + T_left * background (inverse-z, contract_bg, infinity), L=16 T=2^{args.log2_T} fp32 "
+                                    f"hash grid, {B} rays x ({S} + {S}) samples, one merged loss, one sparse Adam step" if fgbg else
                                     f"configs[1]: single 8m^3 tile per GPU, L=16 T=2^{args.log2_T} fp32 hash grid, 2-hidden x 64 "
                                     f"decoder, {B} rays x {S} samples, full training iteration "
                                     f"(sample+encode+decode+composite fwd, bwd, sparse Adam); foreground branch"),
@@ -438,7 +447,7 @@ def main():
             except (OSError, ValueError, KeyError):
                 pass
             # SURVEY.md 8(d) bytes of the WHOLE step (forward + backward per ray) against the step time
-            whole = B * valid_frac * (BYTES_FWD_PER_RAY + BYTES_BWD_PER_RAY) if S == 128 else None
+            whole = B * valid_frac * (BYTES_FWD_PER_RAY + BYTES_BWD_PER_RAY) * (2 if fgbg else 1) if S == 128 else None
             if whole:
                 roof["whole_step"] = {"bytes": whole, "ms": ms_per_step, "frac": whole / (ms_per_step * 1e-3) / (HBM_PEAK_GBS * 1e9)}
             roof.update({"kernel": name, "traffic": traffic, "avg_launch_ms": avg_ms,

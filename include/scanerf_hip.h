@@ -208,6 +208,13 @@ int scanerf_render_scatter_accumulate_adam(float *params, float *exp_avg, float 
                                            int half_dtype, float *overflow_grad, float lr, float beta1, float beta2,
                                            float eps, int step, int B, int S, int T, void *workspace,
                                            size_t workspace_bytes, scanerf_stream_t stream);
+/* ... over TWO record sets (a tile's foreground and background branch, each planned / emitted on its own workspace over the
+ * same B rays and table, S1 / S2 samples): both gradients meet in one bucket image and ONE Adam step (tile.py:880-1015). */
+int scanerf_render_scatter_accumulate_adam2(float *params, float *exp_avg, float *exp_avg_sq, void *half_table,
+                                            int half_dtype, float *overflow_grad, float lr, float beta1, float beta2,
+                                            float eps, int step, int B, int T, int S1, void *workspace1,
+                                            size_t workspace1_bytes, int S2, void *workspace2, size_t workspace2_bytes,
+                                            scanerf_stream_t stream);
 /* Valid-ray compaction of a training batch (hashgrid/__init__.py:419-434: valid = all(z_vals != -1), then rays_o[valid],
  * rays_d[valid], z_vals[valid], dists[valid]; tile.py gathers the targets the same way), without torch's nonzero + gathers:
  * scanerf_ray_valid writes the flags, scanerf_compact_rays moves the valid rays' entries, in their original order, to rows
@@ -227,6 +234,13 @@ int scanerf_photometric_loss_scratch_floats(void);
 int scanerf_photometric_loss_grad(const float *out_ray, const float *target /*[B,3]*/, const uint8_t *ray_valid,
                                   float reg_weight, float *grad_out, float *loss, float *scratch, int B,
                                   scanerf_stream_t stream);
+/* The same for the complete per-tile render (tile.py:666-690 merge, tile.py:880-1015 loss): pred = fg.rgb + fg.T_left * bg.rgb,
+ * loss [1] = mean over all rays x 3 of (pred - target)^2 + reg_weight * (l2_reg_specular of the fg-valid rays + of the
+ * bg-valid rays); grad_fg / grad_bg [B,16] = its gradients w.r.t. the two branches' out_ray (fg: rgb, T_left and column 14;
+ * bg: rgb and column 14).  scratch as above. */
+int scanerf_photometric_loss_grad_fgbg(const float *out_fg, const float *out_bg, const float *target,
+                                       const uint8_t *valid_fg, const uint8_t *valid_bg, float reg_weight, float *grad_fg,
+                                       float *grad_bg, float *loss, float *scratch, int B, scanerf_stream_t stream);
 /* Device self-test of the split-f16 backward primitives (csrc/render_h3.h; test infrastructure, one wave):
  * workspace from scanerf_pack_decoder; dy, x [64][32] f32 -> out_dx [2][64][32] (W^T dy of Spatial_MLP.mlp.2, and
  * of the H part of Directional_MLP.mlp.0 in rows 0..31 of the second slab), out_dw [64][64] = dy x^T, out_rs [64]

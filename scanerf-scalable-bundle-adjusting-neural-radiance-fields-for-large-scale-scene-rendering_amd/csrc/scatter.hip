@@ -208,7 +208,7 @@ __global__ void __launch_bounds__(1024) k_bin_scatter(const float *__restrict__ 
 // LDS atomics: on gfx950 ds_add_f32 is ~12x slower than ds_add_u32/u64 (measured: 2.1e9 float
 // adds 9.5 ms, the same adds as u64 1.7 ms).  With M = max|dL/dout| of the launch (found by the
 // scatter pass) and n records in the bin, every partial sum is < n*M, so values are scaled by
-// 2^k, k = 50 - ceil(log2 M) - ceil(log2(n+1)): no overflow, resolution n*M*2^-50.  Integer
+// 2^k, k = min(51, 62 - ceil(log2(n+1))) - ceil(log2 M): no overflow, resolution M*2^-51 .. M*n*2^-62.  Integer
 // addition is associative, so the table gradient is bit-reproducible run to run (the
 // reference's atomics are not) and closer to the exact sum than an fp32 running sum.
 // ADAM: the epilogue applies the fused sparse Adam (adam_common.h: the IEEE sequence of adam.hip / the oracle) to the bucket's
@@ -217,6 +217,11 @@ __global__ void __launch_bounds__(1024) k_bin_scatter(const float *__restrict__ 
 // gather table is refreshed in the same pass.  ad.overflow_grad (may be null): the table the backward's workspace-overflow
 // path adds to -- read (and re-zeroed) only if the overflow flag is set.
 struct AdamEpilogue {
+    // a SECOND record set accumulated into the same image before the epilogue (the background branch of a tile's iteration:
+    // both branches' gradients must meet in ONE Adam step); null = none.  Same bin geometry as the first.
+    const Rec *recs2;
+    const uint32_t *starts2, *maxbits2;
+    uint32_t capacity2;
     float *params, *exp_avg, *exp_avg_sq;
     void *half_table;        // optional f16 / bf16 copy of params (same [L][T][2] layout)
     int half_dtype;          // SCANERF_F16 / SCANERF_BF16
@@ -234,18 +239,26 @@ __global__ void __launch_bounds__(kThreads) k_bin_accumulate(const Rec *__restri
     // LDS) are accumulated in windows of 2^13 entries: every window pass re-reads the bucket's records -- about 2 MB,
     // they stay in L2 -- and applies the entries that fall inside it.
     const int wl = g.bucket_log < 13 ? g.bucket_log : 13, ws = 1 << wl;
-    const uint32_t lo = min(starts[blockIdx.x], g.capacity), hi = min(starts[blockIdx.x + 1], g.capacity);
-    const float M = __uint_as_float(*maxbits);
-    const bool overflowed = ADAM && ad.overflow_grad && *overflow_flag(const_cast<Rec *>(recs)) != 0u;  // uniform
-    if ((hi == lo || !(M > 0.0f)) && !overflowed) return;  // nothing to add (uniform per workgroup)
+    const uint32_t lo1 = min(starts[blockIdx.x], g.capacity), hi1 = min(starts[blockIdx.x + 1], g.capacity);
+    const bool two = ADAM && ad.recs2 != nullptr;
+    const uint32_t lo2 = two ? min(ad.starts2[blockIdx.x], ad.capacity2) : 0u, hi2 = two ? min(ad.starts2[blockIdx.x + 1], ad.capacity2) : 0u;
+    const float M = two ? fmaxf(__uint_as_float(*maxbits), __uint_as_float(*ad.maxbits2)) : __uint_as_float(*maxbits);
+    const bool overflowed = ADAM && ad.overflow_grad &&
+                            (*overflow_flag(const_cast<Rec *>(recs)) != 0u || (two && *overflow_flag(const_cast<Rec *>(ad.recs2)) != 0u));  // uniform
+    const uint32_t nrec = (hi1 - lo1) + (hi2 - lo2);
+    if ((nrec == 0 || !(M > 0.0f)) && !overflowed) return;  // nothing to add (uniform per workgroup)
     int eM;
     frexpf(M, &eM);  // M < 2^eM
     // float -> fixed point through the double "magic number": d = v*2^k + 1.5*2^52 holds round(v*2^k) in
     // its low mantissa bits for |v*2^k| < 2^51, so bits(d) - bits(magic) is the integer (one cvt, one
     // fma, one 64-bit subtract instead of the ~20-instruction f32 -> i64 software conversion).
-    const int k = 50 - eM - (32 - __clz(hi - lo));
+    // |v| <= M < 2^eM: one value must stay below 2^51 after scaling (the magic-number conversion), the sum of the bin's n
+    // values below 2^62: k = min(51 - eM, 62 - eM - ceil(log2(n+1))).  At configs[1] (5e5 records per bin) the image resolves
+    // 2^-42 of the launch's largest gradient; contributions smaller than that vanish (the reference's f32 atomics keep them,
+    // and its sparse Adam then moves such an entry by ~lr: a few 1e-4 of the entries of a foreground + background step).
+    const int kb = 62 - eM - (32 - __clz(nrec));
+    const int k = kb < 51 - eM ? kb : 51 - eM;
     const double scale = ldexp(1.0, k), magic = 6755399441055744.0;  // 1.5 * 2^52
-    const float4 *r4 = reinterpret_cast<const float4 *>(recs);
     auto fx = [&](float v) {
         return (unsigned long long)(__double_as_longlong(fma((double)v, scale, magic)) - __double_as_longlong(magic));
     };
@@ -268,6 +281,9 @@ __global__ void __launch_bounds__(kThreads) k_bin_accumulate(const Rec *__restri
                 atomicAdd(&a[2 * e1 + 1], fx(w1 * r.w));
             }
         };
+        for (int set = 0; set < (two ? 2 : 1); ++set) {   // (one copy of the streaming code for both record sets)
+        const float4 *r4 = reinterpret_cast<const float4 *>(set ? ad.recs2 : recs);
+        const uint32_t lo = set ? lo2 : lo1, hi = set ? hi2 : hi1;
         // U independent 16-B loads in flight per lane (the records are read once from HBM; window passes re-read them from L2)
         uint32_t i = lo + threadIdx.x;
         if (LANE_OWNS_RUN) {
@@ -300,6 +316,7 @@ __global__ void __launch_bounds__(kThreads) k_bin_accumulate(const Rec *__restri
             for (int u = 0; u < U; ++u) apply(r[u]);
         }
         for (; i < hi; i += kThreads) apply(r4[i]);
+        }
         __syncthreads();
         const size_t ebase = (size_t)level * g.T + ((size_t)bucket << g.bucket_log) + wbase;  // first entry of the window
         if (ADAM) {
@@ -613,10 +630,10 @@ SCANERF_API int scanerf_render_scatter_accumulate(float *grad_features, int B, i
 // the touched entries.  overflow_grad (may be NULL): the [16][T][2] f32 table given to scanerf_render_backward as
 // grad_features (only written if the record workspace overflowed); when the plan's overflow flag is set its entries are added
 // to the gradient and re-zeroed, otherwise it is not touched -- it never needs a per-step zero-fill.
-SCANERF_API int scanerf_render_scatter_accumulate_adam(float *params, float *exp_avg, float *exp_avg_sq, void *half_table,
-                                                       int half_dtype, float *overflow_grad, float lr, float beta1,
-                                                       float beta2, float eps, int step, int B, int S, int T,
-                                                       void *workspace, size_t workspace_bytes, scanerf_stream_t stream)
+static int accumulate_adam(float *params, float *exp_avg, float *exp_avg_sq, void *half_table, int half_dtype,
+                           float *overflow_grad, float lr, float beta1, float beta2, float eps, int step, int B, int S, int T,
+                           void *workspace, size_t workspace_bytes, int S2, void *workspace2, size_t workspace2_bytes,
+                           scanerf_stream_t stream)
 {
     if (B == 0) return 0;
     BinGeom g;
@@ -630,11 +647,43 @@ SCANERF_API int scanerf_render_scatter_accumulate_adam(float *params, float *exp
                     "render_scatter_accumulate_adam: workspace too small (%zu B)", workspace_bytes);
     g.capacity = w.capacity;
     const size_t lds_bytes = (size_t)(2 << (g.bucket_log < 13 ? g.bucket_log : 13)) * 8;
-    AdamEpilogue ad{ params, exp_avg, exp_avg_sq, half_table, half_dtype, overflow_grad, make_adam_args(lr, beta1, beta2, eps, step) };
+    AdamEpilogue ad{ nullptr, nullptr, nullptr, 0u, params, exp_avg, exp_avg_sq, half_table, half_dtype, overflow_grad,
+                     make_adam_args(lr, beta1, beta2, eps, step) };
+    if (workspace2) {  // the second branch's records: planned on the same B and T (same bins and producer grid), its own S
+        BinGeom g2;
+        SCANERF_REQUIRE(fused_geom(B, S2, T, g2) && g2.NB == g.NB && g2.W == g.W,
+                        "render_scatter_accumulate_adam2: second record set B=%d S=%d T=%d does not match the first", B, S2, T);
+        BinWorkspace w2;
+        SCANERF_REQUIRE(bin_workspace_carve(workspace2, workspace2_bytes, nbins, g2.W, w2),
+                        "render_scatter_accumulate_adam2: second workspace too small (%zu B)", workspace2_bytes);
+        ad.recs2 = w2.recs; ad.starts2 = w2.starts; ad.maxbits2 = w2.maxbits; ad.capacity2 = w2.capacity;
+    }
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bin_accumulate<256, 32, true, true>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     SCANERF_REQUIRE(e == hipSuccess, "render_scatter_accumulate_adam: cannot reserve %zu B of LDS: %s", lds_bytes, hipGetErrorString(e));
     hipLaunchKernelGGL((k_bin_accumulate<256, 32, true, true>), dim3(nbins), dim3(256), lds_bytes, (hipStream_t)stream, w.recs,
                        w.starts, w.maxbits, g, (float *)nullptr, ad);
     return check_launch("render_scatter_accumulate_adam");
+}
+
+SCANERF_API int scanerf_render_scatter_accumulate_adam(float *params, float *exp_avg, float *exp_avg_sq, void *half_table,
+                                                       int half_dtype, float *overflow_grad, float lr, float beta1,
+                                                       float beta2, float eps, int step, int B, int S, int T,
+                                                       void *workspace, size_t workspace_bytes, scanerf_stream_t stream)
+{
+    return accumulate_adam(params, exp_avg, exp_avg_sq, half_table, half_dtype, overflow_grad, lr, beta1, beta2, eps, step, B, S, T,
+                           workspace, workspace_bytes, 0, nullptr, 0, stream);
+}
+
+// The same over TWO record sets (a tile's foreground and background branches, tile.py:639-692: each planned and emitted on
+// its own workspace over the same B rays and table): both gradients meet in one image and ONE Adam step.
+SCANERF_API int scanerf_render_scatter_accumulate_adam2(float *params, float *exp_avg, float *exp_avg_sq, void *half_table,
+                                                        int half_dtype, float *overflow_grad, float lr, float beta1,
+                                                        float beta2, float eps, int step, int B, int T, int S1,
+                                                        void *workspace1, size_t workspace1_bytes, int S2, void *workspace2,
+                                                        size_t workspace2_bytes, scanerf_stream_t stream)
+{
+    SCANERF_REQUIRE(workspace2, "render_scatter_accumulate_adam2: second workspace is null");
+    return accumulate_adam(params, exp_avg, exp_avg_sq, half_table, half_dtype, overflow_grad, lr, beta1, beta2, eps, step, B, S1, T,
+                           workspace1, workspace1_bytes, S2, workspace2, workspace2_bytes, stream);
 }

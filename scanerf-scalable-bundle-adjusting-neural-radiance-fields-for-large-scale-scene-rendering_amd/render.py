@@ -144,6 +144,38 @@ def photometric_loss_grad(out_ray, target, ray_valid=None, reg_weight=0.01, grad
     return loss, grad_out
 
 
+def photometric_loss_grad_fgbg(out_fg, out_bg, target, valid_fg=None, valid_bg=None, reg_weight=0.01):
+    """Loss of the complete per-tile render (tile.py:666-690: pred = fg.rgb + fg.T_left * bg.rgb; MSE over all rays +
+    reg_weight * both branches' l2_reg_specular, tile.py:999) and its gradients w.r.t. the two branches' out_ray, without a
+    torch graph -> (loss [1], grad_fg [B,16], grad_bg [B,16])."""
+    B = out_fg.shape[0]
+    dev = out_fg.device
+    gfg, gbg = torch.empty((B, RAY_OUT), dtype=_f32, device=dev), torch.empty((B, RAY_OUT), dtype=_f32, device=dev)
+    loss = torch.empty(1, dtype=_f32, device=dev)
+    scratch = torch.empty(lib().scanerf_photometric_loss_scratch_floats(), dtype=_f32, device=dev)
+    vt = (torch.bool, torch.uint8)
+    check(lib().scanerf_photometric_loss_grad_fgbg(
+        dev_ptr(out_fg, _f32, "out_fg"), dev_ptr(out_bg, _f32, "out_bg"), dev_ptr(target, _f32, "target"),
+        dev_ptr(valid_fg, vt, "valid_fg", allow_none=True), dev_ptr(valid_bg, vt, "valid_bg", allow_none=True),
+        ctypes.c_float(reg_weight), dev_ptr(gfg, _f32, "grad_fg"), dev_ptr(gbg, _f32, "grad_bg"), dev_ptr(loss, _f32, "loss"),
+        dev_ptr(scratch, _f32, "scratch"), ctypes.c_int(B), stream()), "photometric_loss_grad_fgbg")
+    return loss, gfg, gbg
+
+
+def scatter_accumulate_adam2(ws1, S1, ws2, S2, params, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, step, B, half_table=None,
+                             overflow_grad=None):
+    """scatter_accumulate_adam over the record sets of TWO fused backward launches on the same rays and table (a tile's
+    foreground and background branches): both gradients meet in one Adam step."""
+    check(lib().scanerf_render_scatter_accumulate_adam2(
+        dev_ptr(params, _f32, "params"), dev_ptr(exp_avg, _f32, "exp_avg"), dev_ptr(exp_avg_sq, _f32, "exp_avg_sq"),
+        dev_ptr(half_table, (torch.float16, torch.bfloat16), "half_table", allow_none=True),
+        ctypes.c_int(feat_dtype_code(half_table) if half_table is not None else 0),
+        dev_ptr(overflow_grad, _f32, "overflow_grad", allow_none=True), ctypes.c_float(lr), ctypes.c_float(beta1),
+        ctypes.c_float(beta2), ctypes.c_float(eps), ctypes.c_int(step), ctypes.c_int(B), ctypes.c_int(params.shape[1]),
+        ctypes.c_int(S1), ctypes.c_void_p(ws1.data_ptr()), ctypes.c_size_t(ws1.numel()), ctypes.c_int(S2),
+        ctypes.c_void_p(ws2.data_ptr()), ctypes.c_size_t(ws2.numel()), stream()), "scatter_accumulate_adam2")
+
+
 def ray_valid(z_vals):
     """[B] uint8: every sample of the ray's row != -1 (hashgrid/__init__.py:419 torch.all(z_vals != -1, dim=-1))."""
     B, S = z_vals.shape

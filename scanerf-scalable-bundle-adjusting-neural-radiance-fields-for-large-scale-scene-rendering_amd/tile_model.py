@@ -487,13 +487,14 @@ def fgbg_gradients(model, rays_o, rays_d, target, S_fg, S_bg, global_step, inval
                                            ray_valid=v_, want_weights=False, tile_T=tile_T, xstash=xs)
             outs.append(out)
             state.append((tile_T, xs))
-    # merge and loss on the per-ray outputs (tile.py:666-690; criterions.py:142-144; tile.py:999)
-    fg, bg = (o.detach().requires_grad_(True) for o in outs)
+    # merge and loss on the per-ray outputs (tile.py:666-690; criterions.py:142-144; tile.py:999), two HIP launches
     vf, vbg = branches[0][2], branches[1][2]
-    pred = fg[:, 0:3] + fg[:, 4:5] * bg[:, 0:3]
-    l2 = sum(leaf[:, 14][v].sum() / (3 * v.sum().clamp(min=1)) for leaf, v in ((fg, vf), (bg, vbg)))
-    loss = F.mse_loss(pred, target) + 0.01 * l2
-    loss.backward()
+    loss, gfg, gbg = render.photometric_loss_grad_fgbg(outs[0], outs[1], target, vf, vbg, 0.01)
+
+    class _Leaf:  # (what the loop below reads from the former autograd leaves)
+        def __init__(self, g):
+            self.grad = g
+    fg, bg = _Leaf(gfg), _Leaf(gbg)
     with torch.no_grad():
         gtab = torch.zeros_like(model.features)
         gblob = torch.zeros(network.PARAMSIZE, device=dev)
@@ -514,16 +515,66 @@ def fgbg_gradients(model, rays_o, rays_d, target, S_fg, S_bg, global_step, inval
                     linf = pts.abs().amax(-1, keepdim=True)
                     pts = pts * ((2.0 - 1.0 / linf) / linf)
                 render.scatter_table_grad(pts.contiguous(), dfeat, gtab, model.resolution)
-    return loss.detach(), gtab, gblob
+    return loss[0].detach(), gtab, gblob
 
 
 def train_step_fgbg(model, dec_opt, rays_o, rays_d, target, S_fg, S_bg, global_step, table_lr=1e-2,
                     invalid_underground=False, timer=None):
-    """One complete training iteration of a tile (foreground + background branch, tile.py:880-1015) on the fused kernels."""
-    loss, gtab, gblob = fgbg_gradients(model, rays_o, rays_d, target, S_fg, S_bg, global_step, invalid_underground, timer)
+    """One complete training iteration of a tile (tile.py:880-1015: foreground + T_left * background, tile.py:639-692) on the
+    fused kernels: both branches' forward, ONE loss launch pair for the merged prediction, both branches' backward emitting
+    their scatter records, and ONE accumulate + sparse Adam over both record sets (the two gradients meet in one Adam step).
+    Falls back to gradient tables + adam_step_cuda where the fused scatter does not apply (tables above 2^21 entries)."""
+    B = rays_o.shape[0]
+    dev = model.device
+    T = model.features.shape[1]
+    fused = T <= (1 << 21) and render.scatter_supported(B, S_fg, T) and render.scatter_supported(B, S_bg, T) \
+        and render.backward_arith() != render._capi.ARITH_F32
+    if not fused:
+        loss, gtab, gblob = fgbg_gradients(model, rays_o, rays_d, target, S_fg, S_bg, global_step, invalid_underground, timer)
+        with torch.no_grad():
+            model.features.grad = gtab
+            model.table_adam(table_lr)
+            model.decoder.params.grad = gblob
+            dec_opt.step()
+        return loss
     with torch.no_grad():
-        model.features.grad = gtab
-        model.table_adam(table_lr)
+        wf = model.weight_feature(global_step)
+        model.packed.pack(model.decoder.blob(), wf)
+        box = (model.min_bbox.tolist(), model.bbox_size.tolist())
+        table = model.gather_table()
+        with _sec(timer, "sample_points_grid", B * (24 + 2 * 4 * S_fg)):
+            z, dist = model.sample(rays_o, rays_d, S_fg)
+        vf = render.ray_valid(z)
+        zb, db, vb = model.inverse_z_sampling(rays_o, rays_d, S_bg, invalid_underground)
+        branches = ((z, dist, vf, render.FORE, False, S_fg), (zb, db, vb, render.BG, True, S_bg))
+        outs, state = [], []
+        for z_, d_, v_, mode, inf, S in branches:
+            tile_T = torch.empty((B, render.tile_T_columns(S)), device=dev)
+            xs = torch.empty((B * S, 32), device=dev)
+            with _sec(timer, "render_forward", B * (24 + 20 + S * 16 * 8 * 2 * table.element_size()), B * S * MLP_FLOPS_PER_SAMPLE):
+                out, _ = render.render_forward(rays_o, rays_d, z_, d_, table, model.resolution, model.packed, *box, mode, inf,
+                                               ray_valid=v_, want_weights=False, tile_T=tile_T, xstash=xs)
+            outs.append(out)
+            state.append((tile_T, xs))
+        loss, gfg, gbg = render.photometric_loss_grad_fgbg(outs[0], outs[1], target, vf, vb, 0.01)
+        gblob = torch.zeros(network.PARAMSIZE, device=dev)
+        overflow = model.overflow_grad()
+        need_bg = render.lib().scanerf_render_scatter_workspace_bytes(B, S_bg, T)
+        if getattr(model, "_ws_bg", None) is None or model._ws_bg.numel() < need_bg:
+            model._ws_bg = torch.empty(need_bg, dtype=torch.uint8, device=dev)  # the background branch's own record workspace
+        wss = []
+        for (z_, d_, v_, mode, inf, S), out, g, (tile_T, xs), wsbuf in zip(branches, outs, (gfg, gbg), state, (None, model._ws_bg)):
+            with _sec(timer, "scatter_plan", B * S * 4):
+                ws = render.scatter_plan(rays_o, rays_d, z_, model.resolution, T, *box, mode, inf, ray_valid=v_, workspace=wsbuf)
+            with _sec(timer, "render_backward", B * (24 + 20 + S * 16 * 8 * 2 * 4 + S * 16 * 8), 3 * B * S * MLP_FLOPS_PER_SAMPLE):
+                render.render_backward(rays_o, rays_d, z_, d_, table, model.resolution, model.packed, wf, *box, mode, inf, out,
+                                       tile_T, g, ray_valid=v_, grad_blob=gblob, xstash=xs, scatter=(ws, overflow), want_dfeat=False)
+            wss.append(ws)
+        with _sec(timer, "table_grad_accumulate_adam", B * (S_fg + S_bg) * 16 * 64 + model.features.numel() * 28):
+            render.scatter_accumulate_adam2(wss[0], S_fg, wss[1], S_bg, model.features.data, model.exp_avg, model.exp_avg_sq,
+                                            table_lr, 0.9, 0.99, 1e-15, model.adam_step, B, half_table=model._half_table,
+                                            overflow_grad=overflow)
+        model.adam_step += 1
         model.decoder.params.grad = gblob
         dec_opt.step()
-    return loss
+    return loss[0]

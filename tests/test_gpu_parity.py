@@ -899,3 +899,41 @@ def test_compact_rays_equals_boolean_mask_indexing(S, B, S_, p_valid):
     for got, src in ((co, o), (cd, d), (ct, t), (cz, z), (cdist, dist)):
         assert got.shape[0] == n and torch.equal(got, src[want])
     assert torch.equal(idx.long(), torch.nonzero(want)[:, 0])
+
+
+def test_train_step_fgbg_one_adam_step_over_both_branches(S):
+    """train_step_fgbg (both branches' records into ONE accumulate + sparse Adam) against the unfused route (fgbg_gradients ->
+    gradient table -> adam_step_cuda): same loss, and the same table / moments up to the rounding of where the two branches'
+    gradients are added (one fixed-point image vs two f32 additions)."""
+    from scanerf_amd.tile_model import TileModel, fgbg_gradients, train_step_fgbg
+    torch.manual_seed(13)
+    B, Sf, Sb = 2048, 64, 48
+    o = torch.rand(B, 3, device=DEV) * 7.8 - 3.9
+    d = torch.nn.functional.normalize(torch.randn(B, 3, device=DEV), dim=-1)
+    tgt = torch.rand(B, 3, device=DEV)
+    occ = torch.rand(16, 16, 16, device=DEV) < 0.7
+    res = {}
+    for fused in (True, False):
+        m = TileModel([-4, -4, -4], [8, 8, 8], DEV, log2_T=14, seed=4)
+        with torch.no_grad():
+            m.features.mul_(100.0)
+        m.set_occupancy(occ)
+        opt = torch.optim.Adam(m.decoder.parameters(), lr=1e-3, betas=(0.9, 0.99), eps=1e-15)
+        if fused:
+            loss = train_step_fgbg(m, opt, o, d, tgt, Sf, Sb, 6000, invalid_underground=True)
+        else:
+            loss, gtab, gblob = fgbg_gradients(m, o, d, tgt, Sf, Sb, 6000, invalid_underground=True)
+            with torch.no_grad():
+                m.features.grad = gtab
+                m.table_adam(1e-2)
+                m.decoder.params.grad = gblob
+                opt.step()
+        res[fused] = (float(loss), m.exp_avg.clone(), m.exp_avg_sq.clone(), m.features.detach().clone(), m.decoder.params.detach().clone())
+    assert res[True][0] == res[False][0]
+    m1, m0 = res[True][1], res[False][1]            # first moments = 0.1 * gradient
+    assert float((m1 - m0).abs().max()) <= 2e-6 * float(m0.abs().max())
+    n_zero_mismatch = int(((m1 != 0) != (m0 != 0)).sum())
+    assert n_zero_mismatch <= 2e-4 * m0.numel(), n_zero_mismatch   # gradients that cancel, or lie below the image resolution in one route only
+    assert torch.equal(res[True][4], res[False][4])  # decoder: same gradient blob, same torch Adam
+    dfe = (res[True][3] - res[False][3]).abs() / res[False][3].abs().max()
+    assert int((dfe > 1e-4).sum()) <= 1e-4 * dfe.numel()   # (those entries move by +-lr: see the compaction test)
