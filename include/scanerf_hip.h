@@ -105,6 +105,15 @@ size_t scanerf_embedding_bwd_workspace_bytes(int N, int L, int T);
 int scanerf_embedding_bg_backward_binned(const float *points, const float *grad_in, float *grad_features,
                                          const int32_t *resolutions, int N, int L, int T, int grad_layout,
                                          void *workspace, size_t workspace_bytes, scanerf_stream_t stream);
+/* The same ending in the fused sparse Adam (the bucket images are the touched-entry list: no gradient table, no zero-fill, no
+ * scan; per element the IEEE sequence of scanerf_adam_step, `step` = previous count).  half_table (may be NULL): f16 / bf16
+ * gather copy refreshed where params change.  overflow_grad: zero [L][T][2] f32 table, written (and consumed) only if the
+ * workspace overflows. */
+int scanerf_embedding_bg_backward_binned_adam(const float *points, const float *grad_in, const int32_t *resolutions, int N,
+                                              int L, int T, int grad_layout, void *workspace, size_t workspace_bytes,
+                                              float *params, float *exp_avg, float *exp_avg_sq, void *half_table,
+                                              int half_dtype, float *overflow_grad, float lr, float beta1, float beta2,
+                                              float eps, int step, scanerf_stream_t stream);
 /* hashgrid/src/hashgrid_kernel.cu:246-270 / :272-300 (world-space box variant) */
 int scanerf_embedding_forward(const float *points, float *outputs, const float *features,
                               const float *block_corner, const float *block_size,

@@ -42,10 +42,14 @@ constexpr int kRun = 8;  // consecutive points per lane in the stand-alone count
 template <bool PER_LEVEL>
 __global__ void __launch_bounds__(1024) k_bin_count(const float *__restrict__ points,
                                                         const int32_t *__restrict__ resolutions, BinGeom g,
-                                                        uint32_t *__restrict__ counts, uint32_t *__restrict__ maxbits)
+                                                        uint32_t *__restrict__ counts, uint32_t *__restrict__ maxbits,
+                                                        uint32_t *__restrict__ overflow)
 {
     extern __shared__ uint32_t hist[];  // [L*NB], or [NB] if PER_LEVEL
-    if (blockIdx.x == 0 && threadIdx.x == 0) *maxbits = 0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        *maxbits = 0;
+        *overflow = 0;
+    }
     if (PER_LEVEL) {
         const uint32_t mask = (uint32_t)g.T - 1u;
         const int lo = blockIdx.x * g.per_wg, hi = min(g.N, lo + g.per_wg);
@@ -456,9 +460,10 @@ SCANERF_API size_t scanerf_embedding_bwd_workspace_bytes(int N, int L, int T)
 }
 
 // grad_features += scatter(grad_in) through the binned path.  grad_layout: 0 = [N][L][2], 1 = [L][N][2].
-SCANERF_API int scanerf_embedding_bg_backward_binned(const float *points, const float *grad_in, float *grad_features,
-                                                     const int32_t *resolutions, int N, int L, int T, int grad_layout,
-                                                     void *workspace, size_t workspace_bytes, scanerf_stream_t stream)
+// grad_features: the table the image is added to -- or, with an Adam epilogue, the overflow table (ad->overflow_grad)
+static int binned_backward(const float *points, const float *grad_in, float *grad_features, const int32_t *resolutions, int N,
+                           int L, int T, int grad_layout, void *workspace, size_t workspace_bytes, const AdamEpilogue *ad,
+                           scanerf_stream_t stream)
 {
     SCANERF_REQUIRE(N >= 0 && L >= 1, "embedding_bg_backward_binned: N=%d L=%d", N, L);
     if (N == 0) return 0;
@@ -491,9 +496,9 @@ SCANERF_API int scanerf_embedding_bg_backward_binned(const float *points, const 
     const size_t lds_bins = per_level ? (size_t)g.NB * 4 : (size_t)nbins * 4;
     const float2 *gi = reinterpret_cast<const float2 *>(grad_in);
     if (per_level)
-        hipLaunchKernelGGL((k_bin_count<true>), dim3(g.W), dim3(1024), lds_bins, st, points, resolutions, g, counts, maxbits);
+        hipLaunchKernelGGL((k_bin_count<true>), dim3(g.W), dim3(1024), lds_bins, st, points, resolutions, g, counts, maxbits, overflow_flag(recs));
     else
-        hipLaunchKernelGGL((k_bin_count<false>), dim3(g.W), dim3(kThreads), lds_bins, st, points, resolutions, g, counts, maxbits);
+        hipLaunchKernelGGL((k_bin_count<false>), dim3(g.W), dim3(kThreads), lds_bins, st, points, resolutions, g, counts, maxbits, overflow_flag(recs));
     hipLaunchKernelGGL(k_bin_rowscan, dim3(nbins), dim3(kThreads), 0, st, counts, totals, g.W);
     hipLaunchKernelGGL(k_bin_starts, dim3(1), dim3(1024), 0, st, totals, starts, nbins);
     if (per_level && grad_layout == 0)
@@ -513,13 +518,48 @@ SCANERF_API int scanerf_embedding_bg_backward_binned(const float *points, const 
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bin_accumulate<1024, 16, true>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_acc);
         SCANERF_REQUIRE(e == hipSuccess, "embedding_bg_backward_binned: cannot reserve %zu B of LDS: %s", lds_acc, hipGetErrorString(e));
-        hipLaunchKernelGGL((k_bin_accumulate<1024, 16, true>), dim3(nbins), dim3(1024), lds_acc, st, recs, starts, maxbits, g,
-                           grad_features, AdamEpilogue{});
+        if (ad) {
+            e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bin_accumulate<1024, 16, true, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_acc);
+            SCANERF_REQUIRE(e == hipSuccess, "embedding_bg_backward_binned: cannot reserve %zu B of LDS: %s", lds_acc, hipGetErrorString(e));
+            hipLaunchKernelGGL((k_bin_accumulate<1024, 16, true, true>), dim3(nbins), dim3(1024), lds_acc, st, recs, starts, maxbits,
+                               g, (float *)nullptr, *ad);
+        } else
+            hipLaunchKernelGGL((k_bin_accumulate<1024, 16, true>), dim3(nbins), dim3(1024), lds_acc, st, recs, starts, maxbits, g,
+                               grad_features, AdamEpilogue{});
+    } else if (ad) {
+        hipLaunchKernelGGL((k_bin_accumulate<256, 32, true, true>), dim3(nbins), dim3(256), lds_acc, st, recs, starts, maxbits, g,
+                           (float *)nullptr, *ad);
     } else {
         hipLaunchKernelGGL((k_bin_accumulate<256, 32, true>), dim3(nbins), dim3(256), lds_acc, st, recs, starts, maxbits, g,
                            grad_features, AdamEpilogue{});
     }
     return check_launch("embedding_bg_backward_binned");
+}
+
+SCANERF_API int scanerf_embedding_bg_backward_binned(const float *points, const float *grad_in, float *grad_features,
+                                                     const int32_t *resolutions, int N, int L, int T, int grad_layout,
+                                                     void *workspace, size_t workspace_bytes, scanerf_stream_t stream)
+{
+    return binned_backward(points, grad_in, grad_features, resolutions, N, L, T, grad_layout, workspace, workspace_bytes, nullptr, stream);
+}
+
+// The binned scatter ending in the fused sparse Adam (see scanerf_render_scatter_accumulate_adam): the table-gradient path of
+// tables too large for the backward kernel's own record emission (the reference's default T = 2^24), without a gradient table,
+// its zero-fill or the optimiser's scan of 2 GB.  overflow_grad: zero [L][T][2] f32 table, written only if the workspace overflows.
+SCANERF_API int scanerf_embedding_bg_backward_binned_adam(const float *points, const float *grad_in, const int32_t *resolutions,
+                                                          int N, int L, int T, int grad_layout, void *workspace,
+                                                          size_t workspace_bytes, float *params, float *exp_avg,
+                                                          float *exp_avg_sq, void *half_table, int half_dtype,
+                                                          float *overflow_grad, float lr, float beta1, float beta2, float eps,
+                                                          int step, scanerf_stream_t stream)
+{
+    SCANERF_REQUIRE(params && exp_avg && exp_avg_sq && overflow_grad, "embedding_bg_backward_binned_adam: null pointer");
+    SCANERF_REQUIRE(!half_table || half_dtype == SCANERF_F16 || half_dtype == SCANERF_BF16,
+                    "embedding_bg_backward_binned_adam: half_dtype=%d", half_dtype);
+    const AdamEpilogue ad{ nullptr, nullptr, nullptr, 0u, params, exp_avg, exp_avg_sq, half_table, half_dtype, overflow_grad,
+                           make_adam_args(lr, beta1, beta2, eps, step) };
+    return binned_backward(points, grad_in, overflow_grad, resolutions, N, L, T, grad_layout, workspace, workspace_bytes, &ad, stream);
 }
 
 // ---- fused producer: plan (count + scan) before k_render_bwd, accumulate after it ---------------

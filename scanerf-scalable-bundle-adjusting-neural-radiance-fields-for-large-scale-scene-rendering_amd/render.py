@@ -277,6 +277,25 @@ def scatter_table_grad(points, dfeat, grad_features, resolutions):
     return grad_features
 
 
+def scatter_table_grad_adam(points, dfeat, resolutions, params, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, step,
+                            half_table=None, overflow_grad=None):
+    """scatter_table_grad ending in the fused sparse Adam (no gradient table): the table path of tables too large for the
+    backward kernel's own record emission.  overflow_grad: zero table like params (required by the C ABI)."""
+    N, (L, T) = points.shape[0], params.shape[:2]
+    need = lib().scanerf_embedding_bwd_workspace_bytes(ctypes.c_int(N), ctypes.c_int(L), ctypes.c_int(T))
+    if not need:
+        raise RuntimeError("scanerf: shape not supported by the binned scatter")
+    ws = _capi.workspace(points.device, need)
+    check(lib().scanerf_embedding_bg_backward_binned_adam(
+        dev_ptr(points, _f32, "points"), dev_ptr(dfeat, _f32, "dfeat"), dev_ptr(resolutions, torch.int32, "resolutions"),
+        ctypes.c_int(N), ctypes.c_int(L), ctypes.c_int(T), ctypes.c_int(1), ctypes.c_void_p(ws.data_ptr()), ctypes.c_size_t(ws.numel()),
+        dev_ptr(params, _f32, "params"), dev_ptr(exp_avg, _f32, "exp_avg"), dev_ptr(exp_avg_sq, _f32, "exp_avg_sq"),
+        dev_ptr(half_table, (torch.float16, torch.bfloat16), "half_table", allow_none=True),
+        ctypes.c_int(feat_dtype_code(half_table) if half_table is not None else 0), dev_ptr(overflow_grad, _f32, "overflow_grad"),
+        ctypes.c_float(lr), ctypes.c_float(beta1), ctypes.c_float(beta2), ctypes.c_float(eps), ctypes.c_int(step), stream()),
+        "scatter_table_grad_adam")
+
+
 def ray_gradients(rays_o, rays_d, z_vals, features, resolutions, blob, min_bbox, bbox_size, contract_mode, dfeat,
                   g_dnorm, g_rowsum, ray_valid=None):
     """dL/d(rays_o), dL/d(rays_d) of a fused render (for pose refinement: tile.py trains se3_refine through

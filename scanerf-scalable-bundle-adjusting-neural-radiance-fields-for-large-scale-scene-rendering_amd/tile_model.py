@@ -417,8 +417,8 @@ def train_step_fused(model, dec_opt, rays_o, rays_d, target, S, global_step, tab
     # loss and dL/d(out_ray) in two launches (the torch graph for it was ~60 tiny kernels with host-bound gaps)
     loss, grad_out = render.photometric_loss_grad(out, target, valid, 0.01)
     with torch.no_grad():
-        # the fused scatter ends in the Adam epilogue: no gradient table (only the overflow table, never filled per step)
-        adam_epilogue = fused and fused_adam
+        # the scatter ends in the Adam epilogue: no gradient table (only the overflow table, never filled per step)
+        adam_epilogue = fused_adam
         gtab = model.overflow_grad() if adam_epilogue else torch.zeros_like(model.features)
         gblob = torch.zeros(network.PARAMSIZE, device=dev)
         ray_bufs = (torch.zeros(B, ntile, device=dev), torch.zeros(B, 2, 64, device=dev)) if pose_grads else None
@@ -438,10 +438,18 @@ def train_step_fused(model, dec_opt, rays_o, rays_d, target, S, global_step, tab
         if pose_grads:
             g_o, g_d = render.ray_gradients(rays_o, rays_d, z, model.features, model.resolution, blob, box[0], box[1],
                                             box[2], dfeat, ray_bufs[0], ray_bufs[1], ray_valid=valid)
-        if adam_epilogue:
+        if adam_epilogue and fused:
             with _sec(timer, "table_grad_accumulate_adam", B * S * 16 * 64 + model.features.numel() * 28):
                 render.scatter_accumulate_adam(ws, model.features.data, model.exp_avg, model.exp_avg_sq, table_lr, 0.9, 0.99, 1e-15,
                                                model.adam_step, B, S, half_table=model._half_table, overflow_grad=gtab)
+            model.adam_step += 1
+        elif adam_epilogue:   # large tables: stand-alone binned scatter from dfeat, same epilogue
+            pts = ((rays_o[:, None, :] + z[:, :, None] * rays_d[:, None, :]).reshape(-1, 3) - model._min_dev) \
+                / model._size_dev * 4.0 - 2.0
+            with _sec(timer, "table_grad_scatter_adam", B * S * 16 * (8 + 16 * 8)):
+                render.scatter_table_grad_adam(pts.contiguous(), dfeat, model.resolution, model.features.data, model.exp_avg,
+                                               model.exp_avg_sq, table_lr, 0.9, 0.99, 1e-15, model.adam_step,
+                                               half_table=model._half_table, overflow_grad=gtab)
             model.adam_step += 1
         elif fused:
             with _sec(timer, "table_grad_accumulate", B * S * 16 * 64):

@@ -937,3 +937,26 @@ def test_train_step_fgbg_one_adam_step_over_both_branches(S):
     assert torch.equal(res[True][4], res[False][4])  # decoder: same gradient blob, same torch Adam
     dfe = (res[True][3] - res[False][3]).abs() / res[False][3].abs().max()
     assert int((dfe > 1e-4).sum()) <= 1e-4 * dfe.numel()   # (those entries move by +-lr: see the compaction test)
+
+
+def test_train_step_large_table_adam_epilogue(S):
+    """Tables above 2^21 entries (the reference's default is 2^24) take the stand-alone binned scatter from dfeat; with
+    fused_adam it ends in the same Adam epilogue (no gradient table): bit-identical to accumulate -> adam_step_cuda."""
+    from scanerf_amd.tile_model import TileModel, train_step_fused
+    torch.manual_seed(21)
+    B, S_ = 2048, 64
+    o = torch.rand(B, 3, device=DEV) * 8 - 4
+    d = torch.nn.functional.normalize(torch.randn(B, 3, device=DEV), dim=-1)
+    tgt = torch.rand(B, 3, device=DEV)
+    out = {}
+    for fused_adam in (True, False):
+        m = TileModel([-4, -4, -4], [8, 8, 8], DEV, log2_T=22, seed=1)
+        with torch.no_grad():
+            m.features.mul_(500.0)
+        opt = torch.optim.Adam(m.decoder.parameters(), lr=1e-3, betas=(0.9, 0.99), eps=1e-15)
+        losses = [float(train_step_fused(m, opt, o, d, tgt, S_, 20000 + i, fused_adam=fused_adam)) for i in range(2)]
+        out[fused_adam] = (losses, m.features.detach().clone(), m.exp_avg.clone(), m.exp_avg_sq.clone())
+    assert out[True][0] == out[False][0]
+    for k in (1, 2, 3):
+        assert torch.equal(out[True][k], out[False][k]), k
+    assert int((out[True][2] != 0).sum()) > 1000
