@@ -440,10 +440,10 @@ def main():
             # HBM-side bytes of that kernel per launch: rocprofv3 PMC passes of this same command, committed under profiles/
             traffic = None
             try:
-                pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+                pm = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))
                 if h3 and name in pm and args.workload == "configs1" and B == 65536 and S == 128 and args.log2_T == 19:
                     traffic = pm[name]["fetch_bytes"] + pm[name]["write_bytes"]
-                    roof["traffic_source"] = "profiles/r01_pmc_traffic.json (FETCH_SIZE + WRITE_SIZE of " + pm[name]["kernel"] + ")"
+                    roof["traffic_source"] = "profiles/r02_pmc_traffic.json (FETCH_SIZE + WRITE_SIZE of " + pm[name]["kernel"] + ")"
             except (OSError, ValueError, KeyError):
                 pass
             # SURVEY.md 8(d) bytes of the WHOLE step (forward + backward per ray) against the step time

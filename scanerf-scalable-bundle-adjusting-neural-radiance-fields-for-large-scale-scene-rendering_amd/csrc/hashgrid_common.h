@@ -113,7 +113,23 @@ struct TableElem<SCANERF_BF16> {
 template <int DT>
 __device__ __forceinline__ void gather_cell(const void *slice, const uint32_t idx[8], bool x_odd, float2 f[8])
 {
-    static_assert(DT == SCANERF_F16 || DT == SCANERF_BF16, "paired gathers are for the half-precision tables");
+    if constexpr (DT == SCANERF_F32) {
+        // fp32 entries: the aligned pair (i & ~1, i | 1) is one 16-byte load.  Branch-free form: every lane loads the pair of
+        // its x0 corner; lanes with odd x0 (the x1 corner lives elsewhere) add one 8-byte load, issued under EXEC so that only
+        // those lanes cost a cache-line lookup: 6 lookups per cell on average instead of 8.
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float4 t = reinterpret_cast<const float4 *>(slice)[idx[q] >> 1];
+            const bool hi = idx[q] & 1u;
+            f[q] = hi ? make_float2(t.z, t.w) : make_float2(t.x, t.y);
+            f[4 + q] = hi ? make_float2(t.x, t.y) : make_float2(t.z, t.w);
+        }
+        if (x_odd) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) f[4 + q] = reinterpret_cast<const float2 *>(slice)[idx[4 + q]];
+        }
+        return;
+    }
     auto unpack = [](uint32_t u) {
         if (DT == SCANERF_F16) return __half22float2(*reinterpret_cast<const __half2 *>(&u));
         return make_float2(__uint_as_float(u << 16), __uint_as_float(u & 0xffff0000u));

@@ -295,7 +295,7 @@ __global__ void __launch_bounds__(kThreads, 2) k_render_bwd_t16(BwdArgs a)
         // workgroup run in lock step), every new line evicts a dirty one, and the waves wait for the chip's write bandwidth
         // while nothing computes: removing the barriers or the weight-gradient products did not change the kernel's time.
         // Spread over the next tile's layers the same stores overlap its matrix work.
-        auto emit_level = [&](int tile_e, int jj, const v4f &e0, const v4f &e1) {
+        auto emit_level = [&](int tile_e, int jj, const v4f &e0, const v4f &e1, const float pe[3]) {
             const int ln = fresh(lane), c = ln & 15, q = ln >> 4;
             const int s = tile_e * 16 + c;
             if (tile_e < 0 || !(s < S) || !active) return;
@@ -304,8 +304,6 @@ __global__ void __launch_bounds__(kThreads, 2) k_render_bwd_t16(BwdArgs a)
             const float gy = jj == 0 ? e0[1] : (jj == 1 ? e0[3] : (jj == 2 ? e1[1] : e1[3]));
             if (a.dfeat) reinterpret_cast<float2 *>(a.dfeat)[(size_t)level * a.f.B * S + (size_t)ray * S + s] = make_float2(gx, gy);
             if (a.recs) {
-                float pe[3];
-                contract_point(a.f, o, d, a.f.z_vals[(size_t)rayc * S + s], pe);
                 const uint32_t mask = (uint32_t)a.f.T - 1u;
                 const int4 r = *reinterpret_cast<const int4 *>(lres + 4 * level);
                 const int32_t rr[3] = { r.x, r.y, r.z };
@@ -326,6 +324,7 @@ __global__ void __launch_bounds__(kThreads, 2) k_render_bwd_t16(BwdArgs a)
             SCANERF_STORE_GUARD();  // the records' / dfeat's data registers are about to be reused by matrix results
         };
         v4f pdx0 = { 0, 0, 0, 0 }, pdx1 = { 0, 0, 0, 0 };   // the previous tile's dX, emitted during this one
+        float ppe[3] = { 0, 0, 0 };                         // ... and its samples' contracted positions (computed once per tile)
         int ptile = -1;
 
         // A tile's inputs are loaded ONE TILE AHEAD, before the previous tile's records are stored: vector-memory operations
@@ -393,7 +392,7 @@ __global__ void __launch_bounds__(kThreads, 2) k_render_bwd_t16(BwdArgs a)
                     Hh[0] = HB[0].hi;
                     Hh[1] = HB[1].hi;
                 }
-                emit_level(ptile, 0, pdx0, pdx1);
+                emit_level(ptile, 0, pdx0, pdx1, ppe);
                 {   // heads on H[:32]
                     v4f hd[2] = { t16_ld4(lds, T16_BIAS + 256 * 4), t16_ld4(lds, T16_BIAS + 260 * 4) };
                     t16_layer<2, 1>(hd, lds, T16_HEAD, L.lo16, &HB[0]);
@@ -427,7 +426,7 @@ __global__ void __launch_bounds__(kThreads, 2) k_render_bwd_t16(BwdArgs a)
                     c0h[0] = cB[0].hi;
                     c0h[1] = cB[1].hi;
                 }
-                emit_level(ptile, 1, pdx0, pdx1);
+                emit_level(ptile, 1, pdx0, pdx1, ppe);
                 {
                     v4f v[4];
 #pragma unroll
@@ -440,7 +439,7 @@ __global__ void __launch_bounds__(kThreads, 2) k_render_bwd_t16(BwdArgs a)
                     c1h[0] = cB[0].hi;
                     c1h[1] = cB[1].hi;
                 }
-                emit_level(ptile, 2, pdx0, pdx1);
+                emit_level(ptile, 2, pdx0, pdx1, ppe);
                 {
                     v4f r[1] = { t16_ld4(lds, T16_BIAS + 264 * 4) };
                     t16_layer<1, 2>(r, lds, T16_D2, L.lo16, cB);
@@ -449,7 +448,7 @@ __global__ void __launch_bounds__(kThreads, 2) k_render_bwd_t16(BwdArgs a)
                 }
             }
 
-            emit_level(ptile, 3, pdx0, pdx1);
+            emit_level(ptile, 3, pdx0, pdx1, ppe);
 
             // ================= compositing: recompute and adjoint (16-lane scans, identical in the 4 lane groups) =================
             const float ex = live ? expf(-sigma * delta) : 1.0f;  // 1 - alpha
@@ -671,9 +670,10 @@ __global__ void __launch_bounds__(kThreads, 2) k_render_bwd_t16(BwdArgs a)
             pdx0 = dx[0];
             pdx1 = dx[1];
             ptile = tile;
+            if (a.recs) contract_point(a.f, o, d, z, ppe);
         }
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj) emit_level(ptile, jj, pdx0, pdx1);   // the ray's first tile
+        for (int jj = 0; jj < 4; ++jj) emit_level(ptile, jj, pdx0, pdx1, ppe);   // the ray's first tile
     }
 
     if (a.recs) {  // launch-wide max |dL/dfeature| for the fixed-point scale of the accumulate pass

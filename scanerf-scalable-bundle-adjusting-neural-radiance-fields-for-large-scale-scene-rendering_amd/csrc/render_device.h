@@ -7,6 +7,10 @@
 
 typedef float v16f __attribute__((ext_vector_type(16)));
 
+#ifndef SCANERF_PAIRED_F32
+#define SCANERF_PAIRED_F32 0   // 1: paired (16-byte) gathers for fp32 tables too (experiment; see gather_cell)
+#endif
+
 namespace scanerf {
 
 // ------------------------------------------------------------------ device helpers
@@ -151,7 +155,7 @@ __device__ __forceinline__ void encode8(const RenderArgs &a, const int *lds_res,
         trilinear_weights(w, t[0], t[1], t[2]);
         const char *slice = (const char *)a.features + (size_t)level * a.T * TableElem<DT>::bytes;
         float2 f[8];
-        if constexpr (PAIRED && DT != SCANERF_F32) {
+        if constexpr (PAIRED && (DT != SCANERF_F32 || SCANERF_PAIRED_F32)) {
             gather_cell<DT>(slice, idx, b[0] & 1, f);
         } else {
 #pragma unroll
