@@ -11,6 +11,16 @@ torch.manual_seed(0)
 m = TileModel([-4, -4, -4], [8, 8, 8], dev, log2_T=int(os.environ.get("LOG2T", 19)))
 o = torch.rand(B, 3, device=dev) * 8 - 4
 d = torch.nn.functional.normalize(torch.randn(B, 3, device=dev), dim=-1)
+sort = os.environ.get("SORT", "0")
+if sort != "0":  # ray-ordering experiment: rays sorted by the Morton code of their origin's cell (2^k cells per axis)
+    k = int(sort)
+    c = ((o + 4) / 8 * (1 << k)).long().clamp(0, (1 << k) - 1)
+    code = torch.zeros(B, dtype=torch.long, device=dev)
+    for b in range(k):
+        for a in range(3):
+            code |= ((c[:, a] >> b) & 1) << (3 * b + a)
+    order = torch.argsort(code)
+    o, d = o[order].contiguous(), d[order].contiguous()
 z, dist = m.sample(o, d, S)
 m.packed.pack(m.decoder.blob(), network.weight_feature(40000, dev))
 box = (m.min_bbox.tolist(), m.bbox_size.tolist(), render.FORE, False)
