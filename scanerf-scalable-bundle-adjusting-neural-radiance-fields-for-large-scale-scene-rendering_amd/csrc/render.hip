@@ -284,6 +284,9 @@ __global__ void __launch_bounds__(256) k_pack_decoder_h3(const float *__restrict
     }
 }
 
+#ifndef FWD_GATHER_BATCH
+#define FWD_GATHER_BATCH 2
+#endif
 constexpr int kH3LdsBytes = H3_BYTES + 64 * 4;  // + resolutions [16][4] i32
 
 template <int DT>
@@ -347,7 +350,7 @@ __global__ void __launch_bounds__(kRenderThreads, 2) k_render_fwd_h3(RenderArgs 
 #pragma unroll
                 for (int g = 0; g < 16; ++g) x[g] = p[g % 3] * (0.01f * g);
             } else {
-                encode8<DT, 2, true>(a, lds_res, h, p, x);
+                encode8<DT, FWD_GATHER_BATCH, true>(a, lds_res, h, p, x);
             }
             if (a.xstash && live) {  // (plain stores: streaming / nontemporal ones measured 3.16 -> 3.41 ms)
                 float4 *xs = reinterpret_cast<float4 *>(a.xstash + ((size_t)ray * S + s) * 32 + 16 * h);

@@ -186,7 +186,7 @@ __device__ __forceinline__ void wgrad(v4f *acc, float &rowsum, const char *stage
     }
 }
 
-template <int DT>
+template <int DT, bool REC8>  // REC8: the scatter records are 8 bytes (scatter_common.h: Rec8), else 16 (Rec)
 __global__ void __launch_bounds__(kThreads, 2) k_render_bwd_t16(BwdArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -312,7 +312,8 @@ __global__ void __launch_bounds__(kThreads, 2) k_render_bwd_t16(BwdArgs a)
                 gmax = fmaxf(gmax, fmaxf(fabsf(gx), fabsf(gy)));
                 uint32_t *cl = cursor + level * a.bins.NB;
                 float *gl = a.grad_features + (size_t)level * a.f.T * 2;
-                if ((a.f.dbg & 15) == 0) emit_pairs(pr, gx, gy, cl, a.bins.bucket_log, a.bins.capacity, a.recs, gl);
+                if (REC8) emit_pairs8(pr, gx, gy, cl, a.bins.bucket_log, rec_capacity(a.bins.capacity, true), a.recs, gl);
+                else if ((a.f.dbg & 15) == 0) emit_pairs(pr, gx, gy, cl, a.bins.bucket_log, a.bins.capacity, a.recs, gl);
 #ifdef SCANERF_BWD_EXPERIMENTS
                 else if ((a.f.dbg & 15) == 1) emit_pairs<1>(pr, gx, gy, cl, a.bins.bucket_log, a.bins.capacity, a.recs, gl);
                 else if ((a.f.dbg & 15) == 2) emit_pairs<2>(pr, gx, gy, cl, a.bins.bucket_log, a.bins.capacity, a.recs, gl);
@@ -755,16 +756,17 @@ int launch_render_bwd_t16(const BwdArgs &a, int feat_dtype, int blocks, size_t l
     const size_t lds_bytes = (size_t)kLdsCursor + lds_extra;
     SCANERF_REQUIRE(lds_bytes <= 160 * 1024, "render_backward(t16): %zu B of LDS needed (table too large for the fused scatter)", lds_bytes);
     SCANERF_REQUIRE(a.xstash && !a.g_dnorm && !a.g_rowsum, "render_backward(t16): needs the x-stash and has no pose-gradient outputs");
-#define SCANERF_LAUNCH_BWD(DT)                                                                                     \
+#define SCANERF_LAUNCH_BWD(DT, R8)                                                                                 \
     {                                                                                                              \
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_render_bwd_t16<DT>),                  \
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_render_bwd_t16<DT, R8>),              \
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);            \
         SCANERF_REQUIRE(e == hipSuccess, "render_backward(t16): cannot reserve %zu B of LDS: %s", lds_bytes,        \
                         hipGetErrorString(e));                                                                     \
-        hipLaunchKernelGGL((k_render_bwd_t16<DT>), dim3(blocks), dim3(kThreads), lds_bytes, st, a);                 \
+        hipLaunchKernelGGL((k_render_bwd_t16<DT, R8>), dim3(blocks), dim3(kThreads), lds_bytes, st, a);             \
     }
     (void)feat_dtype;  // the table is only read through the x-stash here
-    SCANERF_LAUNCH_BWD(SCANERF_F32)
+    if (a.recs && a.bins.rec8) SCANERF_LAUNCH_BWD(SCANERF_F32, true)
+    else SCANERF_LAUNCH_BWD(SCANERF_F32, false)
 #undef SCANERF_LAUNCH_BWD
     return 0;
 }

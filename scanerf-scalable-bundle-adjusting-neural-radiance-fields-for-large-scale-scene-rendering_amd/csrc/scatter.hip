@@ -243,9 +243,12 @@ __global__ void __launch_bounds__(kThreads) k_bin_accumulate(const Rec *__restri
     // LDS) are accumulated in windows of 2^13 entries: every window pass re-reads the bucket's records -- about 2 MB,
     // they stay in L2 -- and applies the entries that fall inside it.
     const int wl = g.bucket_log < 13 ? g.bucket_log : 13, ws = 1 << wl;
-    const uint32_t lo1 = min(starts[blockIdx.x], g.capacity), hi1 = min(starts[blockIdx.x + 1], g.capacity);
+    // record format (uniform): the fused plan wrote it next to the records; both sets of a two-branch step share it
+    const bool rec8 = g.rec8 < 0 ? *format_word(const_cast<Rec *>(recs)) != 0u : g.rec8 != 0;
+    const uint32_t cap1 = rec_capacity(g.capacity, rec8), cap2 = rec_capacity(ad.capacity2, rec8);
+    const uint32_t lo1 = min(starts[blockIdx.x], cap1), hi1 = min(starts[blockIdx.x + 1], cap1);
     const bool two = ADAM && ad.recs2 != nullptr;
-    const uint32_t lo2 = two ? min(ad.starts2[blockIdx.x], ad.capacity2) : 0u, hi2 = two ? min(ad.starts2[blockIdx.x + 1], ad.capacity2) : 0u;
+    const uint32_t lo2 = two ? min(ad.starts2[blockIdx.x], cap2) : 0u, hi2 = two ? min(ad.starts2[blockIdx.x + 1], cap2) : 0u;
     const float M = two ? fmaxf(__uint_as_float(*maxbits), __uint_as_float(*ad.maxbits2)) : __uint_as_float(*maxbits);
     const bool overflowed = ADAM && ad.overflow_grad &&
                             (*overflow_flag(const_cast<Rec *>(recs)) != 0u || (two && *overflow_flag(const_cast<Rec *>(ad.recs2)) != 0u));  // uniform
@@ -285,9 +288,60 @@ __global__ void __launch_bounds__(kThreads) k_bin_accumulate(const Rec *__restri
                 atomicAdd(&a[2 * e1 + 1], fx(w1 * r.w));
             }
         };
+        // Rec8 (scatter_common.h): integers end to end.  p = m * weight < 2^25 in magnitude, value = p * 2^(E - 25); the
+        // double product p * 2^(E - 25 + k) is exact and below 2^51 (E <= eM, k <= 51 - eM), the magic number rounds it
+        // to the image's grid.  k = 15 records have l1 outside the bucket: one entry only.
+        auto apply8 = [&](uint32_t w0, uint32_t w1) {
+            const uint32_t l0 = w0 & 0x1fffu, l1 = l0 ^ ((2u << ((w0 >> 13) & 15u)) - 1u);
+            const int t = (int)((w0 >> 17) & 0x1fffu);
+            const int sh = (int)((w0 >> 30) | ((w1 >> 26) << 2)) - 128 - 25 + k;
+            const double sc = __hiloint2double((1023 + sh) << 20, 0);
+            const int mx = (int)(w1 << 19) >> 19, my = (int)(w1 << 6) >> 19;
+            auto fi = [&](int p) {
+                return (unsigned long long)(__double_as_longlong(fma((double)p, sc, magic)) - __double_as_longlong(magic));
+            };
+            unsigned long long *a = reinterpret_cast<unsigned long long *>(acc64);
+            atomicAdd(&a[2 * l0], fi(mx * (8192 - t)));
+            atomicAdd(&a[2 * l0 + 1], fi(my * (8192 - t)));
+            if (l1 < (uint32_t)ws) {
+                atomicAdd(&a[2 * l1], fi(mx * t));
+                atomicAdd(&a[2 * l1 + 1], fi(my * t));
+            }
+        };
         for (int set = 0; set < (two ? 2 : 1); ++set) {   // (one copy of the streaming code for both record sets)
         const float4 *r4 = reinterpret_cast<const float4 *>(set ? ad.recs2 : recs);
         const uint32_t lo = set ? lo2 : lo1, hi = set ? hi2 : hi1;
+        if (rec8) {
+            const uint2 *r2 = reinterpret_cast<const uint2 *>(r4);
+            if (LANE_OWNS_RUN) {
+                // as below: each lane takes a run of consecutive records, 2 * U of them through U 16-byte loads; runs start
+                // at even record indices (the bin's range may not), partial runs go one record at a time
+                const uint4 *u4 = reinterpret_cast<const uint4 *>(r4);
+                for (uint32_t c = (lo & ~1u) + threadIdx.x * 2 * U; c < hi; c += 2 * U * kThreads) {
+                    if (c >= lo && c + 2 * U <= hi) {
+                        uint4 r[U];
+#pragma unroll
+                        for (int u = 0; u < U; ++u) r[u] = u4[(c >> 1) + u];
+#pragma unroll
+                        for (int u = 0; u < U; ++u) {
+                            apply8(r[u].x, r[u].y);
+                            apply8(r[u].z, r[u].w);
+                        }
+                    } else {
+                        for (uint32_t j = c < lo ? lo : c; j < hi && j < c + 2 * U; ++j) {
+                            const uint2 r = r2[j];
+                            apply8(r.x, r.y);
+                        }
+                    }
+                }
+            } else {
+                for (uint32_t j = lo + threadIdx.x; j < hi; j += kThreads) {
+                    const uint2 r = r2[j];
+                    apply8(r.x, r.y);
+                }
+            }
+            continue;
+        }
         // U independent 16-B loads in flight per lane (the records are read once from HBM; window passes re-read them from L2)
         uint32_t i = lo + threadIdx.x;
         if (LANE_OWNS_RUN) {
@@ -381,6 +435,7 @@ __global__ void __launch_bounds__(1024) k_bin_count_rays(RenderArgs f, BinGeom g
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         *maxbits = 0;
         *overflow = 0;
+        overflow[-1] = (uint32_t)g.rec8;  // format_word(): what the backward will emit and the accumulate must decode
     }
     const int nbins = 16 * g.NB;
     for (int i = threadIdx.x; i < nbins; i += 1024) hist[i] = 0;
@@ -429,6 +484,7 @@ bool fused_geom(int B, int S, int T, BinGeom &g, int arith = SCANERF_ARITH_F32)
     g.per_wg = 0;
     g.rpg = arith == SCANERF_ARITH_T16 ? 8 : (arith == SCANERF_ARITH_H3 ? 4 : 1);
     g.capacity = 0;
+    g.rec8 = fused_rec8(arith, g.bucket_log) ? 1 : 0;
     return true;
 }
 
@@ -456,7 +512,7 @@ SCANERF_API size_t scanerf_embedding_bwd_workspace_bytes(int N, int L, int T)
     if ((int64_t)N * L * 4 + (1 << 20) >= (int64_t)1 << 31) return 0;  // 32-bit record offsets
     const int W = 1024;
     const size_t recs = ((size_t)N * L * 4 + (size_t)N * L / 8 + 4096) * sizeof(Rec);
-    return recs + (size_t)nbins * W * 4 + (size_t)(2 * nbins + 2) * 4 + 256;
+    return recs + (size_t)nbins * W * 4 + (size_t)(2 * nbins + 4) * 4 + 256;
 }
 
 // grad_features += scatter(grad_in) through the binned path.  grad_layout: 0 = [N][L][2], 1 = [L][N][2].
@@ -476,6 +532,7 @@ static int binned_backward(const float *points, const float *grad_in, float *gra
     hipStream_t st = (hipStream_t)stream;
     BinGeom g;
     g.N = N; g.L = L; g.T = T;
+    g.rpg = 1; g.rec8 = 0;  // the stand-alone producer always writes 16-byte records
     g.bucket_log = standalone_bucket_log(T);
     g.NB = T >> g.bucket_log;
     // producer workgroups: every one of them writes and reads a counter per bin, so with the tens of thousands of bins of a
@@ -618,6 +675,7 @@ SCANERF_API int scanerf_render_scatter_accumulate(float *grad_features, int B, i
     SCANERF_REQUIRE(bin_workspace_carve(workspace, workspace_bytes, nbins, g.W, w),
                     "render_scatter_accumulate: workspace too small (%zu B)", workspace_bytes);
     g.capacity = w.capacity;
+    g.rec8 = -1;  // as the plan recorded it in the workspace
     const size_t lds_bytes = (size_t)(2 << (g.bucket_log < 13 ? g.bucket_log : 13)) * 8;
     const char *ve = getenv("SCANERF_ACC_VARIANT");  // tuning experiments only
     const int variant = ve ? atoi(ve) : 0;
@@ -686,6 +744,7 @@ static int accumulate_adam(float *params, float *exp_avg, float *exp_avg_sq, voi
     SCANERF_REQUIRE(bin_workspace_carve(workspace, workspace_bytes, nbins, g.W, w),
                     "render_scatter_accumulate_adam: workspace too small (%zu B)", workspace_bytes);
     g.capacity = w.capacity;
+    g.rec8 = -1;  // as the plan recorded it in the workspace
     const size_t lds_bytes = (size_t)(2 << (g.bucket_log < 13 ? g.bucket_log : 13)) * 8;
     AdamEpilogue ad{ nullptr, nullptr, nullptr, 0u, params, exp_avg, exp_avg_sq, half_table, half_dtype, overflow_grad,
                      make_adam_args(lr, beta1, beta2, eps, step) };
@@ -698,11 +757,30 @@ static int accumulate_adam(float *params, float *exp_avg, float *exp_avg_sq, voi
                         "render_scatter_accumulate_adam2: second workspace too small (%zu B)", workspace2_bytes);
         ad.recs2 = w2.recs; ad.starts2 = w2.starts; ad.maxbits2 = w2.maxbits; ad.capacity2 = w2.capacity;
     }
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bin_accumulate<256, 32, true, true>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    SCANERF_REQUIRE(e == hipSuccess, "render_scatter_accumulate_adam: cannot reserve %zu B of LDS: %s", lds_bytes, hipGetErrorString(e));
-    hipLaunchKernelGGL((k_bin_accumulate<256, 32, true, true>), dim3(nbins), dim3(256), lds_bytes, (hipStream_t)stream, w.recs,
-                       w.starts, w.maxbits, g, (float *)nullptr, ad);
+#define SCANERF_LAUNCH_ACC_ADAM(TH, UU)                                                                                \
+    {                                                                                                                 \
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bin_accumulate<TH, UU, true, true>),     \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);               \
+        SCANERF_REQUIRE(e == hipSuccess, "render_scatter_accumulate_adam: cannot reserve %zu B of LDS: %s", lds_bytes, \
+                        hipGetErrorString(e));                                                                        \
+        hipLaunchKernelGGL((k_bin_accumulate<TH, UU, true, true>), dim3(nbins), dim3(TH), lds_bytes, (hipStream_t)stream, \
+                           w.recs, w.starts, w.maxbits, g, (float *)nullptr, ad);                                     \
+    }
+    const char *ve = getenv("SCANERF_ACC_VARIANT");  // tuning experiments only
+    const int variant = ve ? atoi(ve) : 0;
+    if (variant == 1) SCANERF_LAUNCH_ACC_ADAM(512, 16)
+    else if (variant == 2) SCANERF_LAUNCH_ACC_ADAM(1024, 8)
+    else if (variant == 3) SCANERF_LAUNCH_ACC_ADAM(256, 16)
+    else if (variant == 4) SCANERF_LAUNCH_ACC_ADAM(512, 32)
+    else if (variant == 5) SCANERF_LAUNCH_ACC_ADAM(1024, 16)
+    else if (variant == 6) SCANERF_LAUNCH_ACC_ADAM(512, 8)
+    else if (variant == 7) SCANERF_LAUNCH_ACC_ADAM(1024, 4)
+    else if (variant == 8) SCANERF_LAUNCH_ACC_ADAM(768, 32)
+    else if (variant == 9) SCANERF_LAUNCH_ACC_ADAM(512, 48)
+    else if (variant == 10) SCANERF_LAUNCH_ACC_ADAM(640, 32)
+    else if (variant == 11) SCANERF_LAUNCH_ACC_ADAM(768, 16)
+    else SCANERF_LAUNCH_ACC_ADAM(256, 32)
+#undef SCANERF_LAUNCH_ACC_ADAM
     return check_launch("render_scatter_accumulate_adam");
 }
 

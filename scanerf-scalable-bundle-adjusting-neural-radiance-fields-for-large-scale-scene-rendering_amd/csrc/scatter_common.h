@@ -23,6 +23,7 @@ struct BinGeom {
     int per_wg;       // samples per producer workgroup
     int rpg;          // fused producer: rays per workgroup visit (ray = (wg + i*W)*rpg + r): 1 f32 kernel, 4 h3 kernel
     uint32_t capacity;  // records that fit the workspace
+    int rec8;         // record format: 0 = Rec (16 bytes), 1 = Rec8 (8 bytes), -1 = read format_word() (accumulate of a fused plan)
 };
 
 struct Rec {
@@ -33,6 +34,10 @@ struct Rec {
 // and went to grad_features through atomics instead (emit_pairs / commit_pairs fallback); zeroed by the plan.  Lets the
 // Adam-fused accumulate skip the overflow table in the common case.
 __host__ __device__ inline uint32_t *overflow_flag(Rec *recs) { return reinterpret_cast<uint32_t *>(recs) - 1; }
+
+// The word before that: the record format the plan chose (0 = Rec, 1 = Rec8); the accumulate of a fused plan reads it, so
+// plan, producer and consumer cannot disagree about the stream they share.
+__host__ __device__ inline uint32_t *format_word(Rec *recs) { return reinterpret_cast<uint32_t *>(recs) - 2; }
 
 // One 16-byte record store.  Plain (write-back) stores: measured in the two-waves-per-SIMD backward kernel, non-temporal
 // stores of the same records take 2.7x the kernel's time (14.2 vs 5.2 ms) and sc1 (write-through) ones 1.5x: the records of
@@ -192,6 +197,84 @@ __device__ __forceinline__ void commit_pairs(const Pairs &pr, const PairSlots &s
     }
 }
 
+// ---- 8-byte records: the stream of the t16 backward (render_bwd_t16.hip) -----------------------------------------------
+// That kernel's gradient products run on f16 matrix operands (11-bit significands, ~5e-4 of the largest gradient); carrying
+// its records as three f32 spends 8.6 GB per configs[1] step (written, then read) on digits the values do not have.  Rec8
+// keeps 12 significant bits + sign per component under the pair's own 8-bit exponent (no launch-wide scale to guess) and
+// the x-weight in 13 bits:
+//   word0: l0 [12:0] | k [16:13] | t [29:17] | exponent bits 1:0 [31:30]
+//   word1: mx [12:0] | my [25:13] (two's complement) | exponent bits 7:2 [31:26]
+//   (gx, gy) = (mx, my) * 2^(E - 12), E = exponent - 128 = frexp exponent of max(|gx|, |gy|) (clamped to >= -127: smaller
+//   values lose bits gradually); entry l0 gets weight (8192 - t) / 8192, entry l1 = l0 ^ ((2 << k) - 1) -- the hash of x + 1
+//   differs from that of x in the k + 1 low bits, k = trailing ones of x -- gets t / 8192; k = 15: no second entry (t = 0).
+// Worst-case rounding 2^-13 of the larger component and 2^-14 in the weight, a quarter of the products' own noise; the
+// accumulate (k_bin_accumulate) works on the integers, so the sum stays bit-reproducible.  Buckets of at most 2^13 entries.
+constexpr int kRec8MaxBucketLog = 13;
+inline bool fused_rec8(int arith, int bucket_log)
+{
+    if (getenv("SCANERF_REC16")) return false;  // experiments: the t16 kernel on 16-byte records
+    return arith == 2 /* SCANERF_ARITH_T16 */ && bucket_log <= kRec8MaxBucketLog;
+}
+__device__ __forceinline__ uint2 pack_rec8(uint32_t l0, uint32_t k, uint32_t t, float gx, float gy)
+{
+    int E = __builtin_amdgcn_frexp_expf(fmaxf(fabsf(gx), fabsf(gy)));  // max < 2^E
+    E = E < -127 ? -127 : (E > 127 ? 127 : E);
+    const int mx = min(__float2int_rn(__builtin_amdgcn_ldexpf(gx, 12 - E)), 4095);
+    const int my = min(__float2int_rn(__builtin_amdgcn_ldexpf(gy, 12 - E)), 4095);
+    const uint32_t e = (uint32_t)(E + 128);
+    return make_uint2(l0 | (k << 13) | (t << 17) | (e << 30), ((uint32_t)mx & 0x1fffu) | (((uint32_t)my & 0x1fffu) << 13) | ((e >> 2) << 26));
+}
+__device__ __forceinline__ void store_rec8(Rec *recs, uint32_t pos, uint2 r) { reinterpret_cast<uint2 *>(recs)[pos] = r; }
+
+// emit_pairs for the Rec8 stream: same ranges, same cursors, same rare paths (count_pairs is its histogram as well);
+// capacity counts 8-byte records here.
+__device__ __forceinline__ void emit_pairs8(const Pairs &pr, float gix, float giy, uint32_t *cursor_level, int bucket_log,
+                                            uint32_t capacity, Rec *recs, float *grad_level)
+{
+    const uint32_t lmask = (1u << bucket_log) - 1u;
+    const bool straddle = (pr.xm >> bucket_log) != 0u;
+    const float a0 = 1.0f - pr.tx;
+    auto fallback = [&](uint32_t bkt, uint32_t e0, uint32_t e1, float tx, float ax, float ay) {
+        *overflow_flag(recs) = 1u;
+        float *gs = grad_level + ((size_t)bkt << bucket_log) * 2;
+        unsafeAtomicAdd(gs + 2 * e0, (1.0f - tx) * ax);
+        unsafeAtomicAdd(gs + 2 * e0 + 1, (1.0f - tx) * ay);
+        unsafeAtomicAdd(gs + 2 * e1, tx * ax);
+        unsafeAtomicAdd(gs + 2 * e1 + 1, tx * ay);
+    };
+    uint32_t pos[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) pos[q] = atomicAdd(&cursor_level[pr.idx0[q] >> bucket_log], 1u);
+    // k = trailing ones of x: xm = 2^(k+1) - 1 (below the bucket size unless the pair straddles)
+    const uint32_t k = straddle ? 15u : (uint32_t)(31 - __clz((int)pr.xm));
+    const uint32_t t = straddle ? 0u : (uint32_t)min(__float2int_rn(pr.tx * 8192.0f), 8191);
+    bool rare = straddle;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float gx = pr.wyz[q] * gix, gy = pr.wyz[q] * giy;
+        const float ax = straddle ? a0 * gx : gx, ay = straddle ? a0 * gy : gy;
+        if (pos[q] < capacity) store_rec8(recs, pos[q], pack_rec8(pr.idx0[q] & lmask, k, t, ax, ay));
+        rare |= pos[q] >= capacity;
+    }
+    if (__builtin_expect(__any(rare), 0)) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint32_t l0 = pr.idx0[q] & lmask, b0 = pr.idx0[q] >> bucket_log;
+            const float gx = pr.wyz[q] * gix, gy = pr.wyz[q] * giy;
+            if (pos[q] >= capacity) {
+                if (straddle) fallback(b0, l0, l0, 0.0f, a0 * gx, a0 * gy);
+                else fallback(b0, l0, l0 ^ pr.xm, pr.tx, gx, gy);
+            }
+            if (straddle) {  // second record: the x+1 neighbour in its own bucket
+                const uint32_t i1 = pr.idx0[q] ^ pr.xm, b1 = i1 >> bucket_log, l1 = i1 & lmask;
+                const uint32_t p1 = atomicAdd(&cursor_level[b1], 1u);
+                if (p1 < capacity) store_rec8(recs, p1, pack_rec8(l1, 15u, 0u, pr.tx * gx, pr.tx * gy));
+                else fallback(b1, l1, l1, 0.0f, pr.tx * gx, pr.tx * gy);
+            }
+        }
+    }
+}
+
 // histogram counterpart of emit_pairs (must stay in lock-step with it)
 __device__ __forceinline__ void count_pairs(const Pairs &pr, uint32_t *hist_level, int bucket_log)
 {
@@ -209,12 +292,13 @@ struct BinWorkspace {
     Rec *recs;
     uint32_t capacity;
 };
-// [counts nbins*W][totals nbins][starts nbins+1][maxbits][... pad ...][overflow flag = the word right before the records]
+// [counts nbins*W][totals nbins][starts nbins+1][maxbits][... pad ...][format word][overflow flag = the word right before the records]
 inline size_t bin_workspace_head(int nbins, int W)
 {
-    size_t head = ((size_t)nbins * W + 2 * (size_t)nbins + 3) * 4;
+    size_t head = ((size_t)nbins * W + 2 * (size_t)nbins + 4) * 4;
     return (head + 255) & ~(size_t)255;
 }
+// (capacity counts 16-byte records; a Rec8 stream holds twice as many: rec_capacity())
 inline bool bin_workspace_carve(void *workspace, size_t bytes, int nbins, int W, BinWorkspace &w)
 {
     const size_t head = bin_workspace_head(nbins, W);
@@ -225,9 +309,10 @@ inline bool bin_workspace_carve(void *workspace, size_t bytes, int nbins, int W,
     w.maxbits = w.starts + nbins + 1;
     w.recs = reinterpret_cast<Rec *>(reinterpret_cast<char *>(workspace) + head);
     const size_t cap = (bytes - head) / sizeof(Rec);
-    w.capacity = cap > 0xfffffff0u ? 0xfffffff0u : (uint32_t)cap;
+    w.capacity = cap > 0x7ffffff0u ? 0x7ffffff0u : (uint32_t)cap;
     return true;
 }
+__host__ __device__ inline uint32_t rec_capacity(uint32_t capacity16, bool rec8) { return rec8 ? capacity16 * 2u : capacity16; }
 // bucket size of the FUSED producer (k_render_bwd* emits, scanerf_render_scatter_accumulate consumes): log2 entries
 inline int fused_bucket_log(int T);
 inline int bin_ilog2(int v)

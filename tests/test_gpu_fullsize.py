@@ -72,13 +72,15 @@ def _fused(full, valid, arith=None, want_dfeat=False):
         render.set_arith(render.DEFAULT_ARITH)
 
 
-def test_full_size_fused_scatter_vs_atomics_and_conservation(full):
-    """All 65 536 rays valid: 5.4e8 records (8.6 GB, byte offsets past 2^32).  The table gradient of the fused path equals
-    the reference-style atomic scatter (hashgrid_bg_kernel.cu:196-201) of the SAME dfeat, and per (level, feature) the
-    sum over table entries equals the sum over samples of dfeat (the 8 trilinear weights sum to one)."""
+@pytest.mark.parametrize("arith,tol", [("h3", 1e-4), ("t16", 5e-4)])
+def test_full_size_fused_scatter_vs_atomics_and_conservation(full, arith, tol):
+    """All 65 536 rays valid: 5.4e8 records (h3: 16-byte records, 8.6 GB, byte offsets past 2^32; t16: 8-byte records with
+    13-bit significands, scatter_common.h).  The table gradient of the fused path equals the reference-style atomic scatter
+    (hashgrid_bg_kernel.cu:196-201) of the SAME dfeat, and per (level, feature) the sum over table entries equals the sum
+    over samples of dfeat (the 8 trilinear weights sum to one)."""
     from scanerf_amd.hashgrid.lib.HASHGRID import embedding_bg_backward_cuda
     m, o, d, z = (full[k] for k in ("m", "o", "d", "z"))
-    out, w, dfeat, gtab, gblob = _fused(full, None, want_dfeat=True)
+    out, w, dfeat, gtab, gblob = _fused(full, None, arith, want_dfeat=True)
     assert torch.isfinite(out).all() and torch.isfinite(gtab).all() and torch.isfinite(gblob).all()
     # (ii) conservation, in float64
     lhs = gtab.double().sum(1).cpu().numpy()            # [16, 2]
@@ -98,7 +100,8 @@ def test_full_size_fused_scatter_vs_atomics_and_conservation(full):
     sc = float(g1.abs().max())
     assert sc > 0
     err = float((gtab - g1).abs().max()) / sc
-    assert err < 1e-4, f"fused scatter vs atomics: {err:.3e} of max"
+    print(f"full size, {arith}: fused scatter vs atomics max err {err:.3e} of max, relative L2 {float((gtab - g1).norm() / g1.norm()):.3e}")
+    assert err < tol, f"fused scatter vs atomics: {err:.3e} of max"
     # every table entry the atomics touched is touched by the fused path and vice versa (up to exact cancellations)
     nz1, nz2 = int((g1 != 0).sum()), int((gtab != 0).sum())
     assert abs(nz1 - nz2) <= 1e-4 * nz1, (nz1, nz2)

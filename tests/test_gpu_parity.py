@@ -511,7 +511,15 @@ def test_fused_scatter_equals_dfeat_scatter(S, arith, B, S_):
         assert torch.equal(gb1, gb2)
         sc = float(g1.abs().max())
         assert sc > 0
-        np.testing.assert_allclose(g2.cpu().numpy() / sc, g1.cpu().numpy() / sc, rtol=1e-4, atol=1e-6)
+        l2 = float((g2 - g1).norm() / g1.norm())
+        print(f"fused records vs dfeat scatter ({arith}, B={B}, S={S_}): max err {float((g2 - g1).abs().max()) / sc:.2e} of max, relative L2 {l2:.2e}")
+        if arith == "t16":
+            # 8-byte records (scatter_common.h Rec8): 13-bit significands under the pair's exponent, 13-bit x-weight --
+            # per record <= 2^-13 of its larger component; an entry's sum of n records is off by ~2^-13 / sqrt(3) * |g| sqrt(n)
+            np.testing.assert_allclose(g2.cpu().numpy() / sc, g1.cpu().numpy() / sc, rtol=5e-4, atol=5e-4)
+            assert l2 < 3e-4
+        else:
+            np.testing.assert_allclose(g2.cpu().numpy() / sc, g1.cpu().numpy() / sc, rtol=1e-4, atol=1e-6)
     finally:
         render.set_arith(render.DEFAULT_ARITH)
 
@@ -821,10 +829,20 @@ def test_accumulate_adam_epilogue_is_bit_exact(S, log2_T, half):
             assert torch.equal(H, P.to(half)), "half-precision gather copy out of step with the master"
 
 
-def test_accumulate_adam_uses_the_overflow_table_only_when_flagged(S):
+@pytest.mark.parametrize("arith,tol", [("h3", 2e-5), ("t16", 5e-4)])
+def test_accumulate_adam_uses_the_overflow_table_only_when_flagged(S, arith, tol):
     """Record workspace too small: the overflowing records go to the overflow table through atomics, the plan's flag is set,
     and the epilogue folds that table in (and re-zeroes it).  The update then equals the full-workspace one up to the f32
-    atomics' summation order."""
+    atomics' summation order (t16: and the 8-byte records' 13-bit significands, which the atomic path does not round to)."""
+    from scanerf_amd import render
+    render.set_arith(arith)
+    try:
+        _overflow_table_case(tol)
+    finally:
+        render.set_arith(render.DEFAULT_ARITH)
+
+
+def _overflow_table_case(tol):
     from scanerf_amd import render
     from scanerf_amd._capi import lib
     from scanerf_amd.tile_model import TileModel
@@ -848,7 +866,7 @@ def test_accumulate_adam_uses_the_overflow_table_only_when_flagged(S):
         res[tag] = (M.clone(), V.clone())
     # first moments = (1 - beta1) * gradient: compare the gradients the two runs saw
     a, b = res["full"][0], res["small"][0]
-    assert float((a - b).abs().max()) <= 2e-5 * float(a.abs().max())
+    assert float((a - b).abs().max()) <= tol * float(a.abs().max())
     assert int(((a != 0) != (b != 0)).sum()) <= 8
 
 
