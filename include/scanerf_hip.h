@@ -256,6 +256,10 @@ int scanerf_photometric_loss_grad_fgbg(const float *out_fg, const float *out_bg,
  * = row sums of dy. */
 int scanerf_h3_selftest(const float *workspace, const float *dy, const float *x, float *out_dx, float *out_dw,
                         float *out_rs, scanerf_stream_t stream);
+/* Test infrastructure: the 8-byte scatter-record codec (csrc/scatter_common.h Rec8) on n values.  words [n][2] = the packed
+ * records; out [n][8] = l0, l1, the four contributions the accumulate adds (x, y to l0; x, y to l1), E - 25, t. */
+int scanerf_rec8_selftest(const float *gx, const float *gy, const float *tx, const uint32_t *l0, const uint32_t *k, int n,
+                          uint32_t *words, float *out, scanerf_stream_t stream);
 /* For pose refinement (gradients w.r.t. the rays): g_dnorm = per-tile partials of dL/d|rays_d| through
  * delta = dist*|d| (hashgrid/__init__.py:347); g_rowsum = per-ray sums of dL/d(Directional_MLP.mlp.0
  * pre-activation) in two partial rows (their sum times W[:,32:48] is dL/dSH(viewdir)).  The gradient

@@ -23,6 +23,8 @@
 
 #include "adam_common.h"
 #include "render_device.h"
+#include <mutex>
+#include <unordered_map>
 #include "scatter_common.h"
 
 using namespace scanerf;
@@ -288,18 +290,17 @@ __global__ void __launch_bounds__(kThreads) k_bin_accumulate(const Rec *__restri
                 atomicAdd(&a[2 * e1 + 1], fx(w1 * r.w));
             }
         };
-        // Rec8 (scatter_common.h): integers end to end.  p = m * weight < 2^25 in magnitude, value = p * 2^(E - 25); the
-        // double product p * 2^(E - 25 + k) is exact and below 2^51 (E <= eM, k <= 51 - eM), the magic number rounds it
-        // to the image's grid.  k = 15 records have l1 outside the bucket: one entry only.
+        // Rec8 (scatter_common.h): integers end to end.  p = m * weight < 2^25 in magnitude, value = p * 2^(E - 25), on the
+        // image's grid p * 2^(E - 25 + k) < 2^51.  k = 15 records have l1 outside the bucket: one entry only.
         auto apply8 = [&](uint32_t w0, uint32_t w1) {
-            const uint32_t l0 = w0 & 0x1fffu, l1 = l0 ^ ((2u << ((w0 >> 13) & 15u)) - 1u);
-            const int t = (int)((w0 >> 17) & 0x1fffu);
-            const int sh = (int)((w0 >> 30) | ((w1 >> 26) << 2)) - 128 - 25 + k;
-            const double sc = __hiloint2double((1023 + sh) << 20, 0);
-            const int mx = (int)(w1 << 19) >> 19, my = (int)(w1 << 6) >> 19;
-            auto fi = [&](int p) {
-                return (unsigned long long)(__double_as_longlong(fma((double)p, sc, magic)) - __double_as_longlong(magic));
-            };
+            const Rec8Fields f = unpack_rec8(w0, w1);
+            const uint32_t l0 = f.l0, l1 = f.l1;
+            const int t = f.t, mx = f.mx, my = f.my;
+            const int sh = f.e25 + k;   // <= 26 (E <= eM, k <= 51 - eM)
+            const int rs = 32 - sh > 63 ? 63 : 32 - sh;
+            // p * 2^sh on the image's grid: one 64-bit shift of p * 2^32 (values below the grid are floored: records
+            // 2^-18 of the launch's largest gradient and smaller, by less than 2^-43 of it each)
+            auto fi = [&](int p) { return (unsigned long long)(((long long)p << 32) >> rs); };
             unsigned long long *a = reinterpret_cast<unsigned long long *>(acc64);
             atomicAdd(&a[2 * l0], fi(mx * (8192 - t)));
             atomicAdd(&a[2 * l0 + 1], fi(my * (8192 - t)));
@@ -619,6 +620,23 @@ SCANERF_API int scanerf_embedding_bg_backward_binned_adam(const float *points, c
     return binned_backward(points, grad_in, overflow_grad, resolutions, N, L, T, grad_layout, workspace, workspace_bytes, &ad, stream);
 }
 
+// Launch-shape hint for the accumulate: which record format the last plan on a workspace chose.  The kernel decodes by the
+// format word IN the workspace; this host-side note only picks the faster of two equally correct launch shapes.
+static std::mutex g_hint_mutex;
+static std::unordered_map<const void *, int> g_plan_rec8;
+static void note_plan_format(const void *workspace, int rec8)
+{
+    std::lock_guard<std::mutex> lock(g_hint_mutex);
+    if (g_plan_rec8.size() > 64) g_plan_rec8.clear();
+    g_plan_rec8[workspace] = rec8;
+}
+static bool plan_was_rec8(const void *workspace)
+{
+    std::lock_guard<std::mutex> lock(g_hint_mutex);
+    auto it = g_plan_rec8.find(workspace);
+    return it != g_plan_rec8.end() && it->second != 0;
+}
+
 // ---- fused producer: plan (count + scan) before k_render_bwd, accumulate after it ---------------
 // Workspace bytes of the fused table-gradient path of scanerf_render_backward; 0 => shape unsupported
 // (use dfeat + scanerf_embedding_bg_backward_binned instead).
@@ -656,6 +674,7 @@ SCANERF_API int scanerf_render_scatter_plan(const float *rays_o, const float *ra
         f.inv_size4[k] = 4.0f / cfg->bbox_size[k];
     }
     hipStream_t st = (hipStream_t)stream;
+    note_plan_format(workspace, g.rec8);
     hipLaunchKernelGGL(k_bin_count_rays, dim3(g.W), dim3(1024), (size_t)nbins * 4, st, f, g, w.counts, w.maxbits, overflow_flag(w.recs));
     hipLaunchKernelGGL(k_bin_rowscan, dim3(nbins), dim3(kThreads), 0, st, w.counts, w.totals, g.W);
     hipLaunchKernelGGL(k_bin_starts, dim3(1), dim3(1024), 0, st, w.totals, w.starts, nbins);
@@ -766,8 +785,10 @@ static int accumulate_adam(float *params, float *exp_avg, float *exp_avg_sq, voi
         hipLaunchKernelGGL((k_bin_accumulate<TH, UU, true, true>), dim3(nbins), dim3(TH), lds_bytes, (hipStream_t)stream, \
                            w.recs, w.starts, w.maxbits, g, (float *)nullptr, ad);                                     \
     }
+    // measured (configs[1], MI355X), threads x 16-byte loads per lane: 16-byte records 256x32 2.28 ms, 512x32 2.55, 768x32 2.59;
+    // 8-byte records 256x32 1.77, 512x16 1.58, 1024x8 1.70, 1024x16 1.55, 768x32 1.51, 512x48 1.53, 512x32 1.47
     const char *ve = getenv("SCANERF_ACC_VARIANT");  // tuning experiments only
-    const int variant = ve ? atoi(ve) : 0;
+    const int variant = ve ? atoi(ve) : (plan_was_rec8(workspace) ? 4 : 0);
     if (variant == 1) SCANERF_LAUNCH_ACC_ADAM(512, 16)
     else if (variant == 2) SCANERF_LAUNCH_ACC_ADAM(1024, 8)
     else if (variant == 3) SCANERF_LAUNCH_ACC_ADAM(256, 16)
@@ -804,4 +825,37 @@ SCANERF_API int scanerf_render_scatter_accumulate_adam2(float *params, float *ex
     SCANERF_REQUIRE(workspace2, "render_scatter_accumulate_adam2: second workspace is null");
     return accumulate_adam(params, exp_avg, exp_avg_sq, half_table, half_dtype, overflow_grad, lr, beta1, beta2, eps, step, B, S1, T,
                            workspace1, workspace1_bytes, S2, workspace2, workspace2_bytes, stream);
+}
+
+// ---- test infrastructure (tests/test_gpu_parity.py), not on the product path: the Rec8 codec on its own -------------------
+namespace {
+__global__ void k_rec8_selftest(const float *gx, const float *gy, const float *tx, const uint32_t *l0, const uint32_t *kk, int n,
+                                uint32_t *words, float *out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t t = kk[i] == 15u ? 0u : (uint32_t)min(__float2int_rn(tx[i] * 8192.0f), 8191);
+    const uint2 r = pack_rec8(l0[i], kk[i], t, gx[i], gy[i]);
+    words[2 * i] = r.x;
+    words[2 * i + 1] = r.y;
+    const Rec8Fields f = unpack_rec8(r.x, r.y);
+    float *o = out + 8 * (size_t)i;  // l0, l1, then the four contributions (x, y to l0; x, y to l1), E - 25, t
+    o[0] = (float)f.l0;
+    o[1] = (float)f.l1;
+    o[2] = ldexpf((float)(f.mx * (8192 - f.t)), f.e25);
+    o[3] = ldexpf((float)(f.my * (8192 - f.t)), f.e25);
+    o[4] = ldexpf((float)(f.mx * f.t), f.e25);
+    o[5] = ldexpf((float)(f.my * f.t), f.e25);
+    o[6] = (float)f.e25;
+    o[7] = (float)f.t;
+}
+}  // namespace
+
+SCANERF_API int scanerf_rec8_selftest(const float *gx, const float *gy, const float *tx, const uint32_t *l0, const uint32_t *k,
+                                      int n, uint32_t *words, float *out, scanerf_stream_t stream)
+{
+    SCANERF_REQUIRE(gx && gy && tx && l0 && k && words && out && n >= 0, "rec8_selftest: bad arguments");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(k_rec8_selftest, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, gx, gy, tx, l0, k, n, words, out);
+    return check_launch("rec8_selftest");
 }

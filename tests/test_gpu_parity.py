@@ -978,3 +978,65 @@ def test_train_step_large_table_adam_epilogue(S):
     for k in (1, 2, 3):
         assert torch.equal(out[True][k], out[False][k]), k
     assert int((out[True][2] != 0).sum()) > 1000
+
+
+def test_rec8_codec_against_its_restatement(S):
+    """The 8-byte scatter records (csrc/scatter_common.h Rec8: the t16 backward's stream): pack on the device, unpack as the
+    accumulate does, against a numpy restatement of the format -- bit-exact fields; and the decoded contributions against the
+    f32 values they stand for (half a unit of the 13-bit significand = 2^-13 of the pair's power-of-two ceiling, i.e. 2^-13 to
+    2^-12 of its larger component, + 2^-14 in the weight).  Zeros, denormals, 1e38, values
+    that round up to the next power of two, one-entry records (k = 15)."""
+    import ctypes
+    from scanerf_amd._capi import check, lib, stream
+    rng = np.random.default_rng(21)
+    n = 20000
+    gx = (rng.normal(size=n) * 10.0 ** rng.uniform(-30, 30, size=n)).astype(np.float32)
+    gy = (rng.normal(size=n) * 10.0 ** rng.uniform(-3, 3, size=n) * np.abs(gx)).astype(np.float32)
+    gy[::3] = (rng.normal(size=len(gy[::3])) * 10.0 ** rng.uniform(-30, 30, size=len(gy[::3]))).astype(np.float32)
+    special = np.array([0.0, -0.0, 1e-40, -3e-39, 3e38, -1e38, 1.0, np.nextafter(np.float32(1.0), np.float32(0.0)),
+                        -np.nextafter(np.float32(2.0), np.float32(0.0)), 4095.5 / 4096, 4095.49 / 4096, 2.0 ** -126, 2.0 ** -127, 2.0 ** -130],
+                       dtype=np.float32)
+    gx[:len(special)] = special
+    gy[:len(special)] = special[::-1]
+    gy[len(special):2 * len(special)] = 0.0
+    gx[len(special):2 * len(special)] = special
+    tx = rng.uniform(0, 1, size=n).astype(np.float32)
+    tx[:4] = [0.0, np.nextafter(np.float32(1.0), np.float32(0.0)), 0.5, 1.0 / 16384]
+    l0 = rng.integers(0, 8192, size=n).astype(np.uint32)
+    k = rng.integers(0, 13, size=n).astype(np.uint32)
+    k[::7] = 15
+    words = torch.zeros(n, 2, dtype=torch.int32, device=DEV)
+    out = torch.zeros(n, 8, device=DEV)
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    dev = [g(v) if v.dtype == np.float32 else torch.from_numpy(v.astype(np.int32)).to(DEV) for v in (gx, gy, tx, l0, k)]
+    check(lib().scanerf_rec8_selftest(*(p(t) for t in dev), ctypes.c_int(n), p(words), p(out), stream()), "rec8_selftest")
+    torch.cuda.synchronize()
+    o = out.cpu().numpy().astype(np.float64)
+    # restatement
+    with np.errstate(all="ignore"):
+        m = np.maximum(np.abs(gx), np.abs(gy))
+        m1 = (m.astype(np.float64) * (1.0 + 2.0 ** -13)).astype(np.float32)   # fmaf(m, 2^-13, m): one rounding
+        E = np.clip(np.frexp(m1)[1], -127, 128).astype(np.int64)      # m < 2^E (0 for m = 0)
+        q = lambda v: np.minimum(np.rint(np.ldexp(v.astype(np.float32), (12 - E).astype(np.int32)).astype(np.float32)), 4095).astype(np.int64)
+        mx, my = q(gx), q(gy)
+        t = np.where(k == 15, 0, np.minimum(np.rint((tx * np.float32(8192.0)).astype(np.float32)), 8191)).astype(np.int64)
+    l1 = l0.astype(np.int64) ^ ((2 << k.astype(np.int64)) - 1)
+    assert np.array_equal(o[:, 0], l0) and np.array_equal(o[:, 1], l1)
+    assert np.all(l1[k == 15] >= 8192) and np.all(l1[k != 15] < 8192)
+    assert np.array_equal(o[:, 6], E - 25) and np.array_equal(o[:, 7], t)
+    for col, mm, w in ((2, mx, 8192 - t), (3, my, 8192 - t), (4, mx, t), (5, my, t)):
+        assert np.array_equal(o[:, col], np.ldexp((mm * w).astype(np.float64), (E - 25).astype(np.int32)).astype(np.float32).astype(np.float64)), col
+    # the packed words are what the restatement packs
+    e = (E + 127).astype(np.int64)
+    w0 = l0.astype(np.int64) | (k.astype(np.int64) << 13) | (t << 17) | ((e & 3) << 30)
+    w1 = (mx & 0x1fff) | ((my & 0x1fff) << 13) | ((e >> 2) << 26)
+    got = words.cpu().numpy().astype(np.int64) & 0xffffffff
+    assert np.array_equal(got[:, 0], w0 & 0xffffffff) and np.array_equal(got[:, 1], w1 & 0xffffffff)
+    # what the records stand for: (1 - tx) g and tx g; values below 2^-127 of ... the exponent floor lose bits gradually
+    big = m.astype(np.float64)
+    for col0, col1, v in ((2, 4, gx), (3, 5, gy)):
+        tot = o[:, col0] + o[:, col1]
+        bad = np.nonzero(~(np.abs(tot - v.astype(np.float64)) <= big * 2.0 ** -12 + 2.0 ** -139))[0]
+        assert bad.size == 0, (col0, bad[:5], gx[bad[:5]], gy[bad[:5]], tot[bad[:5]])
+        w1_true = np.where(k == 15, 0.0, tx.astype(np.float64))
+        assert np.all(np.abs(o[:, col1] - w1_true * v) <= big * (2.0 ** -12 + 2.0 ** -14) + 2.0 ** -139)
