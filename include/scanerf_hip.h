@@ -171,6 +171,16 @@ int scanerf_render_forward_packed(const float *rays_o, const float *rays_d, cons
                                   const scanerf_render_cfg *cfg /*[host]*/, const uint8_t *ray_valid,
                                   float *out_ray, float *weights, float *tile_T, float *xstash, int B, int S,
                                   int T, scanerf_stream_t stream);
+/* scanerf_render_forward_packed that ALSO does scanerf_render_scatter_plan's work for the t16 backward of the same rays: the
+ * record counts come out of the forward kernel (its hash indices are the plan's), then the scans run.  Call it INSTEAD of
+ * scanerf_render_scatter_plan, with that function's workspace and cfg->arith = SCANERF_ARITH_T16; only for shapes where
+ * scanerf_render_forward_plan_supported() is non-zero (forward and backward kernels visit the same rays per workgroup). */
+int scanerf_render_forward_packed_plan(const float *rays_o, const float *rays_d, const float *z_vals, const float *dists,
+                                       const void *features, int feat_dtype, const int32_t *resolutions, const float *workspace,
+                                       const scanerf_render_cfg *cfg, const uint8_t *ray_valid, float *out_ray, float *weights,
+                                       float *tile_T, float *xstash, int B, int S, int T, void *scatter_ws,
+                                       size_t scatter_ws_bytes, scanerf_stream_t stream);
+int scanerf_render_forward_plan_supported(int B, int S, int T);
 
 /* Adjoint of scanerf_render_forward_packed (hashgrid/__init__.py:512-596 under autograd).
  *   out_ray, tile_T: the forward's outputs;  grad_out [B,16]: dL/d(out_ray) (columns as out_ray;

@@ -17,6 +17,7 @@
 
 #include "render_h3.h"
 #include "render_t16.h"
+#include "scatter_common.h"
 
 using namespace scanerf;
 
@@ -289,10 +290,22 @@ __global__ void __launch_bounds__(256) k_pack_decoder_h3(const float *__restrict
 #endif
 constexpr int kH3LdsBytes = H3_BYTES + 64 * 4;  // + resolutions [16][4] i32
 
-template <int DT>
+constexpr int kPlanHistWords = 16 * 256;  // scatter bins of the fused count: NB <= 256 buckets per level
+
+template <int DT, bool COUNT>  // COUNT: also count the backward's scatter records (RenderArgs::plan_counts)
 __global__ void __launch_bounds__(kRenderThreads, 2) k_render_fwd_h3(RenderArgs a)
 {
     __shared__ __attribute__((aligned(16))) char lds[kH3LdsBytes];
+    __shared__ uint32_t hist_store[COUNT ? kPlanHistWords : 1];
+    uint32_t *hist = COUNT ? hist_store : nullptr;
+    if (COUNT) {
+        for (int i = threadIdx.x; i < 16 * a.plan_NB; i += kRenderThreads) hist[i] = 0;
+        if (blockIdx.x == 0 && threadIdx.x == 0) {  // as k_bin_count_rays: launch maximum, format word, overflow flag
+            *a.plan_maxbits = 0;
+            *a.plan_overflow = 0;
+            a.plan_overflow[-1] = (uint32_t)a.plan_rec8;  // scatter_common.h format_word()
+        }
+    }
     {
         const float4 *src = reinterpret_cast<const float4 *>(a.packed + PK_TOTAL);
         float4 *dst = reinterpret_cast<float4 *>(lds);
@@ -350,7 +363,7 @@ __global__ void __launch_bounds__(kRenderThreads, 2) k_render_fwd_h3(RenderArgs 
 #pragma unroll
                 for (int g = 0; g < 16; ++g) x[g] = p[g % 3] * (0.01f * g);
             } else {
-                encode8<DT, FWD_GATHER_BATCH, true>(a, lds_res, h, p, x);
+                encode8<DT, FWD_GATHER_BATCH, true, COUNT>(a, lds_res, h, p, x, hist, live);
             }
             if (a.xstash && live) {  // (plain stores: streaming / nontemporal ones measured 3.16 -> 3.41 ms)
                 float4 *xs = reinterpret_cast<float4 *>(a.xstash + ((size_t)ray * S + s) * 32 + 16 * h);
@@ -409,6 +422,10 @@ __global__ void __launch_bounds__(kRenderThreads, 2) k_render_fwd_h3(RenderArgs 
             o4[3] = make_float4(acc[8], acc[9], acc[10], 0.0f);
         }
     }
+    if (COUNT) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < 16 * a.plan_NB; i += kRenderThreads) a.plan_counts[(size_t)i * a.plan_W + blockIdx.x] = hist[i];
+    }
 }
 
 }  // namespace
@@ -431,12 +448,11 @@ SCANERF_API int scanerf_pack_decoder(const float *mlp_blob, const float *weight_
     return check_launch("pack_decoder");
 }
 
-SCANERF_API int scanerf_render_forward_packed(const float *rays_o, const float *rays_d, const float *z_vals,
-                                              const float *dists, const void *features, int feat_dtype,
-                                              const int32_t *resolutions, const float *packed,
-                                              const scanerf_render_cfg *cfg, const uint8_t *ray_valid,
-                                              float *out_ray, float *weights, float *tile_T, float *xstash, int B, int S,
-                                              int T, scanerf_stream_t stream)
+static int render_forward(const float *rays_o, const float *rays_d, const float *z_vals, const float *dists,
+                          const void *features, int feat_dtype, const int32_t *resolutions, const float *packed,
+                          const scanerf_render_cfg *cfg, const uint8_t *ray_valid, float *out_ray, float *weights,
+                          float *tile_T, float *xstash, int B, int S, int T, void *scatter_ws, size_t scatter_ws_bytes,
+                          scanerf_stream_t stream)
 {
     SCANERF_REQUIRE(B >= 0 && S >= 1, "render_forward: B=%d S=%d", B, S);
     SCANERF_REQUIRE(T >= 2 && (T & (T - 1)) == 0, "render_forward: T=%d must be a power of two", T);
@@ -465,12 +481,60 @@ SCANERF_API int scanerf_render_forward_packed(const float *rays_o, const float *
     dim3 grid(blocks), block(kRenderThreads);
     hipStream_t st = (hipStream_t)stream;
     SCANERF_REQUIRE(cfg->arith >= SCANERF_ARITH_F32 && cfg->arith <= SCANERF_ARITH_T16, "render_forward: arith=%d", cfg->arith);
+    a.plan_counts = nullptr;
+    if (scatter_ws) {
+        // The t16 backward visits ray (wg + i W) 8 + r; this kernel's wave w of workgroup b visits (b + i grid) 8 + w: the same
+        // rays per workgroup when the grids are equal, so this launch can fill the plan's count matrix itself.
+        SCANERF_REQUIRE(cfg->arith == SCANERF_ARITH_T16, "render_forward_plan: the fused count is the t16 backward's plan (arith=%d)", cfg->arith);
+        SCANERF_REQUIRE(scanerf_render_forward_plan_supported(B, S, T), "render_forward_plan: B=%d S=%d T=%d not supported", B, S, T);
+        if (int e = scatter_plan_attach(scatter_ws, scatter_ws_bytes, B, S, T, cfg->arith, blocks, a)) return e;
+    }
     if (cfg->arith != SCANERF_ARITH_F32) {  // (H3 and T16 differ in the backward kernel only)
-        if (feat_dtype == SCANERF_F32) hipLaunchKernelGGL((k_render_fwd_h3<SCANERF_F32>), grid, block, 0, st, a);
-        else if (feat_dtype == SCANERF_F16) hipLaunchKernelGGL((k_render_fwd_h3<SCANERF_F16>), grid, block, 0, st, a);
-        else hipLaunchKernelGGL((k_render_fwd_h3<SCANERF_BF16>), grid, block, 0, st, a);
+        if (a.plan_counts) {
+            if (feat_dtype == SCANERF_F32) hipLaunchKernelGGL((k_render_fwd_h3<SCANERF_F32, true>), grid, block, 0, st, a);
+            else if (feat_dtype == SCANERF_F16) hipLaunchKernelGGL((k_render_fwd_h3<SCANERF_F16, true>), grid, block, 0, st, a);
+            else hipLaunchKernelGGL((k_render_fwd_h3<SCANERF_BF16, true>), grid, block, 0, st, a);
+        } else if (feat_dtype == SCANERF_F32) hipLaunchKernelGGL((k_render_fwd_h3<SCANERF_F32, false>), grid, block, 0, st, a);
+        else if (feat_dtype == SCANERF_F16) hipLaunchKernelGGL((k_render_fwd_h3<SCANERF_F16, false>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((k_render_fwd_h3<SCANERF_BF16, false>), grid, block, 0, st, a);
     } else if (feat_dtype == SCANERF_F32) hipLaunchKernelGGL((k_render_fwd<SCANERF_F32>), grid, block, 0, st, a);
     else if (feat_dtype == SCANERF_F16) hipLaunchKernelGGL((k_render_fwd<SCANERF_F16>), grid, block, 0, st, a);
     else hipLaunchKernelGGL((k_render_fwd<SCANERF_BF16>), grid, block, 0, st, a);
-    return check_launch("render_forward");
+    if (int e = check_launch("render_forward")) return e;
+    return a.plan_counts ? scatter_plan_finish(scatter_ws, scatter_ws_bytes, B, S, T, cfg->arith, stream) : 0;
+}
+
+SCANERF_API int scanerf_render_forward_packed(const float *rays_o, const float *rays_d, const float *z_vals,
+                                              const float *dists, const void *features, int feat_dtype,
+                                              const int32_t *resolutions, const float *packed,
+                                              const scanerf_render_cfg *cfg, const uint8_t *ray_valid,
+                                              float *out_ray, float *weights, float *tile_T, float *xstash, int B, int S,
+                                              int T, scanerf_stream_t stream)
+{
+    return render_forward(rays_o, rays_d, z_vals, dists, features, feat_dtype, resolutions, packed, cfg, ray_valid, out_ray,
+                          weights, tile_T, xstash, B, S, T, nullptr, 0, stream);
+}
+
+// The same launch, also doing scanerf_render_scatter_plan's work for the t16 backward of these rays (counts in the forward
+// kernel, where the hash indices already are; then the scan): call INSTEAD of scanerf_render_scatter_plan, with that
+// function's workspace.  Only where scanerf_render_forward_plan_supported(B, S, T) (equal forward and backward grids).
+SCANERF_API int scanerf_render_forward_packed_plan(const float *rays_o, const float *rays_d, const float *z_vals,
+                                                   const float *dists, const void *features, int feat_dtype,
+                                                   const int32_t *resolutions, const float *packed,
+                                                   const scanerf_render_cfg *cfg, const uint8_t *ray_valid,
+                                                   float *out_ray, float *weights, float *tile_T, float *xstash, int B,
+                                                   int S, int T, void *scatter_ws, size_t scatter_ws_bytes,
+                                                   scanerf_stream_t stream)
+{
+    SCANERF_REQUIRE(scatter_ws, "render_forward_plan: scatter workspace is null");
+    return render_forward(rays_o, rays_d, z_vals, dists, features, feat_dtype, resolutions, packed, cfg, ray_valid, out_ray,
+                          weights, tile_T, xstash, B, S, T, scatter_ws, scatter_ws_bytes, stream);
+}
+
+SCANERF_API int scanerf_render_forward_plan_supported(int B, int S, int T)
+{
+    if (scanerf_render_scatter_workspace_bytes(B, S, T) == 0) return 0;
+    const int fwd_grid = ceil_div(B, kRenderThreads / 64) > kNumCU ? kNumCU : ceil_div(B, kRenderThreads / 64);
+    if (fwd_grid != scanerf_render_backward_grid(B)) return 0;
+    return 1;  // (NB <= 256 buckets per level whatever T: scatter_common.h fused_bucket_log)
 }

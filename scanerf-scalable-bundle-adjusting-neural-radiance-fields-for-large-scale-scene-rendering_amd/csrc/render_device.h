@@ -127,6 +127,10 @@ struct RenderArgs {
     float min_bbox[3], inv_size4[3];  // 4/bbox_size
     float bbox_size[3];
     int dbg;                  // timing experiments only (SCANERF_DEBUG_FWD): 1 = encode only, 2 = decode only
+    // optional: the forward kernel also counts the scatter records the t16 backward will emit for these rays (scatter.hip
+    // k_bin_count_rays' job: the hash indices are already in registers here).  counts [16 * NB][W], this workgroup's column
+    uint32_t *plan_counts, *plan_maxbits, *plan_overflow;   // (launch maximum and overflow flag are zeroed here; plan_overflow[-1] = format)
+    int plan_NB, plan_bucket_log, plan_W, plan_rec8;
 };
 
 // hash-encode 8 levels of one sample: register 2j+f of half h holds feature f of level
@@ -136,8 +140,11 @@ struct RenderArgs {
 // two waves per SIMD (128-register budget); 8 issues all 64 gathers of the lane at once -- one
 // memory latency instead of four -- for the one-wave-per-SIMD backward kernel.
 // PAIRED: fetch x-neighbour pairs with one load where the hash puts them side by side (gather_cell; half-precision tables)
-template <int DT, int GATHER_BATCH = 2, bool PAIRED = false>
-__device__ __forceinline__ void encode8(const RenderArgs &a, const int *lds_res, int h, const float p[3], v16f &x)
+// hist (may be null): this workgroup's [16][NB] record counters in LDS -- one per (y,z) corner pair, two when the
+// x-neighbours fall into different buckets, exactly scatter_common.h count_pairs; count = this lane's sample is a real one
+template <int DT, int GATHER_BATCH = 2, bool PAIRED = false, bool COUNT = false>
+__device__ __forceinline__ void encode8(const RenderArgs &a, const int *lds_res, int h, const float p[3], v16f &x,
+                                        uint32_t *hist = nullptr, bool count = false)
 {
     const uint32_t mask = (uint32_t)a.T - 1u;
 #pragma unroll
@@ -153,6 +160,16 @@ __device__ __forceinline__ void encode8(const RenderArgs &a, const int *lds_res,
         float w[8];
         corner_indices(idx, b[0], b[1], b[2], mask);
         trilinear_weights(w, t[0], t[1], t[2]);
+        if constexpr (COUNT) {  // (no per-lane branch: dead lanes add zero)
+            uint32_t *hl = hist + level * a.plan_NB;
+            const uint32_t one = count ? 1u : 0u;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) atomicAdd(&hl[idx[q] >> a.plan_bucket_log], one);
+            // (x-neighbours in different buckets -- practically never -- cost a second count; added as 0 otherwise, no branch)
+            const uint32_t two = ((idx[0] ^ idx[4]) >> a.plan_bucket_log) != 0u ? one : 0u;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) atomicAdd(&hl[idx[4 + q] >> a.plan_bucket_log], two);
+        }
         const char *slice = (const char *)a.features + (size_t)level * a.T * TableElem<DT>::bytes;
         float2 f[8];
         if constexpr (PAIRED && (DT != SCANERF_F32 || SCANERF_PAIRED_F32)) {

@@ -681,6 +681,36 @@ SCANERF_API int scanerf_render_scatter_plan(const float *rays_o, const float *ra
     return check_launch("render_scatter_plan");
 }
 
+// The plan in two halves around a forward launch that counts (render.hip k_render_fwd_h3<.., true>): attach = carve the
+// workspace and point the kernel at its count matrix; finish = the scans.
+namespace scanerf {
+int scatter_plan_attach(void *workspace, size_t workspace_bytes, int B, int S, int T, int arith, int forward_grid, RenderArgs &a)
+{
+    BinGeom g;
+    SCANERF_REQUIRE(fused_geom(B, S, T, g, arith), "render_forward_plan: shape B=%d S=%d T=%d not supported", B, S, T);
+    SCANERF_REQUIRE(g.W == forward_grid && g.rpg == 8, "render_forward_plan: forward grid %d != backward grid %d", forward_grid, g.W);
+    SCANERF_REQUIRE(((uintptr_t)workspace & 15) == 0, "render_forward_plan: workspace must be 16-byte aligned");
+    BinWorkspace w;
+    SCANERF_REQUIRE(bin_workspace_carve(workspace, workspace_bytes, 16 * g.NB, g.W, w),
+                    "render_forward_plan: workspace too small (%zu B)", workspace_bytes);
+    a.plan_counts = w.counts; a.plan_maxbits = w.maxbits; a.plan_overflow = overflow_flag(w.recs);
+    a.plan_NB = g.NB; a.plan_bucket_log = g.bucket_log; a.plan_W = g.W; a.plan_rec8 = g.rec8;
+    return 0;
+}
+int scatter_plan_finish(void *workspace, size_t workspace_bytes, int B, int S, int T, int arith, scanerf_stream_t stream)
+{
+    BinGeom g;
+    BinWorkspace w;
+    if (!fused_geom(B, S, T, g, arith) || !bin_workspace_carve(workspace, workspace_bytes, 16 * g.NB, g.W, w)) return 1;
+    const int nbins = 16 * g.NB;
+    hipStream_t st = (hipStream_t)stream;
+    note_plan_format(workspace, g.rec8);
+    hipLaunchKernelGGL(k_bin_rowscan, dim3(nbins), dim3(kThreads), 0, st, w.counts, w.totals, g.W);
+    hipLaunchKernelGGL(k_bin_starts, dim3(1), dim3(1024), 0, st, w.totals, w.starts, nbins);
+    return check_launch("render_forward_plan(scan)");
+}
+}  // namespace scanerf
+
 // grad_features [16][T][2] += the records scanerf_render_backward emitted into `workspace`.
 SCANERF_API int scanerf_render_scatter_accumulate(float *grad_features, int B, int S, int T, void *workspace,
                                                   size_t workspace_bytes, scanerf_stream_t stream)

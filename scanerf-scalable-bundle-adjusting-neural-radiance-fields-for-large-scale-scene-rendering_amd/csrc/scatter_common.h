@@ -353,4 +353,9 @@ inline int fused_bucket_log(int T)
     return lt < bl ? lt : bl;
 }
 
+// scatter.hip: the fused plan split around a counting forward launch (render.hip)
+struct RenderArgs;
+int scatter_plan_attach(void *workspace, size_t workspace_bytes, int B, int S, int T, int arith, int forward_grid, RenderArgs &a);
+int scatter_plan_finish(void *workspace, size_t workspace_bytes, int B, int S, int T, int arith, void *stream);
+
 }  // namespace scanerf

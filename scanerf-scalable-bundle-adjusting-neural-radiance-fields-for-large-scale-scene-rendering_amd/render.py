@@ -68,10 +68,18 @@ def _cfg(min_bbox, bbox_size, contract_mode, infinity, arith=None):
     return c
 
 
+def forward_plan_supported(B, S, T):
+    """render_forward(plan=True) can do scatter_plan's work for the t16 backward of the same rays (equal kernel grids)."""
+    return bool(lib().scanerf_render_forward_plan_supported(ctypes.c_int(B), ctypes.c_int(S), ctypes.c_int(T)))
+
+
 def render_forward(rays_o, rays_d, z_vals, dists, features, resolutions, packed, min_bbox, bbox_size, contract_mode,
-                   infinity, ray_valid=None, want_weights=True, out_ray=None, weights=None, tile_T=None, xstash=None):
+                   infinity, ray_valid=None, want_weights=True, out_ray=None, weights=None, tile_T=None, xstash=None,
+                   plan=False, plan_workspace=None):
     """-> out_ray [B,16] (see column constants), weights [B,S] or None.
-    min_bbox / bbox_size: host sequences of 3 floats (the HashGrid 2x box)."""
+    min_bbox / bbox_size: host sequences of 3 floats (the HashGrid 2x box).
+    plan=True (only where forward_plan_supported): the launch also reserves the t16 backward's scatter-record ranges for these
+    rays -- call it INSTEAD of scatter_plan; returns (out_ray, weights, workspace)."""
     B, S = z_vals.shape
     if features.shape[0] != 16 or features.shape[2] != 2:
         raise RuntimeError("scanerf: fused path needs a [16,T,2] table (the reference hard-codes 16 levels)")
@@ -79,16 +87,25 @@ def render_forward(rays_o, rays_d, z_vals, dists, features, resolutions, packed,
         out_ray = torch.empty((B, RAY_OUT), dtype=_f32, device=z_vals.device)
     if weights is None and want_weights:
         weights = torch.empty((B, S), dtype=_f32, device=z_vals.device)
+    T = features.shape[1]
+    args = (dev_ptr(rays_o, _f32, "rays_o"), dev_ptr(rays_d, _f32, "rays_d"), dev_ptr(z_vals, _f32, "z_vals"),
+            dev_ptr(dists, _f32, "dists"), dev_ptr(features, (torch.float32, torch.float16, torch.bfloat16), "features"),
+            ctypes.c_int(feat_dtype_code(features)), dev_ptr(resolutions, torch.int32, "resolutions"),
+            dev_ptr(packed.workspace, _f32, "workspace"))
+    tail = (dev_ptr(ray_valid, (torch.bool, torch.uint8), "ray_valid", allow_none=True), dev_ptr(out_ray, _f32, "out_ray"),
+            dev_ptr(weights, _f32, "weights", allow_none=True), dev_ptr(tile_T, _f32, "tile_T", allow_none=True),
+            dev_ptr(xstash, _f32, "xstash", allow_none=True), ctypes.c_int(B), ctypes.c_int(S), ctypes.c_int(T))
+    if plan:
+        need = lib().scanerf_render_scatter_workspace_bytes(ctypes.c_int(B), ctypes.c_int(S), ctypes.c_int(T))
+        if not need or not forward_plan_supported(B, S, T):
+            raise RuntimeError(f"scanerf: render_forward(plan=True) does not support B={B} S={S} T={T}")
+        ws = _capi.workspace(z_vals.device, need) if plan_workspace is None else plan_workspace
+        cfg = _cfg(min_bbox, bbox_size, contract_mode, infinity, _capi.ARITH_T16)
+        check(lib().scanerf_render_forward_packed_plan(*args, ctypes.byref(cfg), *tail, ctypes.c_void_p(ws.data_ptr()),
+                                                       ctypes.c_size_t(ws.numel()), stream()), "render_forward(plan)")
+        return out_ray, weights, ws
     cfg = _cfg(min_bbox, bbox_size, contract_mode, infinity)
-    check(lib().scanerf_render_forward_packed(
-        dev_ptr(rays_o, _f32, "rays_o"), dev_ptr(rays_d, _f32, "rays_d"), dev_ptr(z_vals, _f32, "z_vals"),
-        dev_ptr(dists, _f32, "dists"), dev_ptr(features, (torch.float32, torch.float16, torch.bfloat16), "features"),
-        ctypes.c_int(feat_dtype_code(features)), dev_ptr(resolutions, torch.int32, "resolutions"),
-        dev_ptr(packed.workspace, _f32, "workspace"), ctypes.byref(cfg),
-        dev_ptr(ray_valid, (torch.bool, torch.uint8), "ray_valid", allow_none=True), dev_ptr(out_ray, _f32, "out_ray"),
-        dev_ptr(weights, _f32, "weights", allow_none=True), dev_ptr(tile_T, _f32, "tile_T", allow_none=True),
-        dev_ptr(xstash, _f32, "xstash", allow_none=True), ctypes.c_int(B), ctypes.c_int(S),
-        ctypes.c_int(features.shape[1]), stream()), "render_forward")
+    check(lib().scanerf_render_forward_packed(*args, ctypes.byref(cfg), *tail, stream()), "render_forward")
     return out_ray, weights
 
 

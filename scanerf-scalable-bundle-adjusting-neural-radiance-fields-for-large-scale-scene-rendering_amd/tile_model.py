@@ -412,8 +412,15 @@ def train_step_fused(model, dec_opt, rays_o, rays_d, target, S, global_step, tab
         table = model.gather_table()
         with _sec(timer, "render_forward", B * (24 + 20 + S * 16 * 8 * 2 * table.element_size()),
                   B * S * MLP_FLOPS_PER_SAMPLE):
-            out, _ = render.render_forward(rays_o, rays_d, z, dist, table, model.resolution, model.packed, *box,
-                                           ray_valid=valid, want_weights=False, tile_T=tile_T, xstash=xstash)
+            # t16 backward on the same grid as the forward: the forward kernel counts the scatter records itself (its hash
+            # indices are the plan's) -- no separate plan launch (0.25 ms at configs[1])
+            if (fused and ws is None and bwd_arith == render._capi.ARITH_T16 and render.forward_plan_supported(B, S, T)
+                    and not os.environ.get("SCANERF_NO_FORWARD_PLAN")):
+                out, _, ws = render.render_forward(rays_o, rays_d, z, dist, table, model.resolution, model.packed, *box,
+                                                   ray_valid=valid, want_weights=False, tile_T=tile_T, xstash=xstash, plan=True)
+            else:
+                out, _ = render.render_forward(rays_o, rays_d, z, dist, table, model.resolution, model.packed, *box,
+                                               ray_valid=valid, want_weights=False, tile_T=tile_T, xstash=xstash)
     # loss and dL/d(out_ray) in two launches (the torch graph for it was ~60 tiny kernels with host-bound gaps)
     loss, grad_out = render.photometric_loss_grad(out, target, valid, 0.01)
     with torch.no_grad():
@@ -555,25 +562,29 @@ def train_step_fgbg(model, dec_opt, rays_o, rays_d, target, S_fg, S_bg, global_s
         vf = render.ray_valid(z)
         zb, db, vb = model.inverse_z_sampling(rays_o, rays_d, S_bg, invalid_underground)
         branches = ((z, dist, vf, render.FORE, False, S_fg), (zb, db, vb, render.BG, True, S_bg))
-        outs, state = [], []
-        for z_, d_, v_, mode, inf, S in branches:
-            tile_T = torch.empty((B, render.tile_T_columns(S)), device=dev)
-            xs = torch.empty((B * S, 32), device=dev)
-            with _sec(timer, "render_forward", B * (24 + 20 + S * 16 * 8 * 2 * table.element_size()), B * S * MLP_FLOPS_PER_SAMPLE):
-                out, _ = render.render_forward(rays_o, rays_d, z_, d_, table, model.resolution, model.packed, *box, mode, inf,
-                                               ray_valid=v_, want_weights=False, tile_T=tile_T, xstash=xs)
-            outs.append(out)
-            state.append((tile_T, xs))
-        loss, gfg, gbg = render.photometric_loss_grad_fgbg(outs[0], outs[1], target, vf, vb, 0.01)
-        gblob = torch.zeros(network.PARAMSIZE, device=dev)
-        overflow = model.overflow_grad()
         need_bg = render.lib().scanerf_render_scatter_workspace_bytes(B, S_bg, T)
         if getattr(model, "_ws_bg", None) is None or model._ws_bg.numel() < need_bg:
             model._ws_bg = torch.empty(need_bg, dtype=torch.uint8, device=dev)  # the background branch's own record workspace
+        outs, state = [], []
+        for (z_, d_, v_, mode, inf, S), wsbuf in zip(branches, (None, model._ws_bg)):
+            tile_T = torch.empty((B, render.tile_T_columns(S)), device=dev)
+            xs = torch.empty((B * S, 32), device=dev)
+            # (the forward launch reserves the backward's record ranges as well where the two kernels share a grid)
+            in_fwd = (render.backward_arith(True, False) == render._capi.ARITH_T16 and render.forward_plan_supported(B, S, T)
+                      and not os.environ.get("SCANERF_NO_FORWARD_PLAN"))
+            with _sec(timer, "render_forward", B * (24 + 20 + S * 16 * 8 * 2 * table.element_size()), B * S * MLP_FLOPS_PER_SAMPLE):
+                r = render.render_forward(rays_o, rays_d, z_, d_, table, model.resolution, model.packed, *box, mode, inf,
+                                          ray_valid=v_, want_weights=False, tile_T=tile_T, xstash=xs, plan=in_fwd, plan_workspace=wsbuf)
+            outs.append(r[0])
+            state.append((tile_T, xs, r[2] if in_fwd else None))
+        loss, gfg, gbg = render.photometric_loss_grad_fgbg(outs[0], outs[1], target, vf, vb, 0.01)
+        gblob = torch.zeros(network.PARAMSIZE, device=dev)
+        overflow = model.overflow_grad()
         wss = []
-        for (z_, d_, v_, mode, inf, S), out, g, (tile_T, xs), wsbuf in zip(branches, outs, (gfg, gbg), state, (None, model._ws_bg)):
-            with _sec(timer, "scatter_plan", B * S * 4):
-                ws = render.scatter_plan(rays_o, rays_d, z_, model.resolution, T, *box, mode, inf, ray_valid=v_, workspace=wsbuf)
+        for (z_, d_, v_, mode, inf, S), out, g, (tile_T, xs, ws), wsbuf in zip(branches, outs, (gfg, gbg), state, (None, model._ws_bg)):
+            if ws is None:
+                with _sec(timer, "scatter_plan", B * S * 4):
+                    ws = render.scatter_plan(rays_o, rays_d, z_, model.resolution, T, *box, mode, inf, ray_valid=v_, workspace=wsbuf)
             with _sec(timer, "render_backward", B * (24 + 20 + S * 16 * 8 * 2 * 4 + S * 16 * 8), 3 * B * S * MLP_FLOPS_PER_SAMPLE):
                 render.render_backward(rays_o, rays_d, z_, d_, table, model.resolution, model.packed, wf, *box, mode, inf, out,
                                        tile_T, g, ray_valid=v_, grad_blob=gblob, xstash=xs, scatter=(ws, overflow), want_dfeat=False)

@@ -1040,3 +1040,58 @@ def test_rec8_codec_against_its_restatement(S):
         assert bad.size == 0, (col0, bad[:5], gx[bad[:5]], gy[bad[:5]], tot[bad[:5]])
         w1_true = np.where(k == 15, 0.0, tx.astype(np.float64))
         assert np.all(np.abs(o[:, col1] - w1_true * v) <= big * (2.0 ** -12 + 2.0 ** -14) + 2.0 ** -139)
+
+
+def test_forward_counts_the_scatter_plan(S, monkeypatch):
+    """render_forward(plan=True): the forward kernel fills the t16 backward's record plan itself (csrc/render.hip COUNT).
+    Same workspace head (counts, totals, starts, format word, flags) as scatter_plan, same outputs; and the training step
+    that uses it moves the table bit-identically to the one with the separate plan launch.  Rays that miss (ray_valid = 0),
+    a sample count that is not a multiple of 32, the contracted background branch."""
+    import ctypes
+    from scanerf_amd import network, render
+    from scanerf_amd._capi import lib
+    from scanerf_amd.tile_model import TileModel, train_step_fused
+    torch.manual_seed(4)
+    for B, S_, mode, inf in ((4096, 64, render.FORE, False), (3000, 40, render.BG, True)):
+        m = TileModel([-4, -4, -4], [8, 8, 8], DEV, log2_T=14, seed=2)
+        o = torch.rand(B, 3, device=DEV) * 8 - 4
+        d = torch.nn.functional.normalize(torch.randn(B, 3, device=DEV), dim=-1)
+        if mode == render.FORE:
+            z, dist = m.sample(o, d, S_)
+        else:
+            z = torch.sort(torch.rand(B, S_, device=DEV) * 30 + 0.5, dim=-1).values
+            dist = torch.cat([z[:, 1:] - z[:, :-1], torch.full((B, 1), 1e10, device=DEV)], -1)
+        valid = torch.rand(B, device=DEV) < 0.8
+        T = m.features.shape[1]
+        assert render.forward_plan_supported(B, S_, T)
+        m.packed.pack(m.decoder.blob(), network.weight_feature(3000, DEV))
+        box = (m.min_bbox.tolist(), m.bbox_size.tolist(), mode, inf)
+        need = lib().scanerf_render_scatter_workspace_bytes(ctypes.c_int(B), ctypes.c_int(S_), ctypes.c_int(T))
+        wa, wb = (torch.zeros(need, dtype=torch.uint8, device=DEV) for _ in range(2))
+        render.scatter_plan(o, d, z, m.resolution, T, *box, ray_valid=valid, arith=render._capi.ARITH_T16, workspace=wa)
+        out_a, w_a = render.render_forward(o, d, z, dist, m.features, m.resolution, m.packed, *box, ray_valid=valid)
+        out_b, w_b, ws = render.render_forward(o, d, z, dist, m.features, m.resolution, m.packed, *box, ray_valid=valid,
+                                               plan=True, plan_workspace=wb)
+        torch.cuda.synchronize()
+        assert ws is wb and torch.equal(out_a, out_b) and torch.equal(w_a, w_b)
+        nbins, W = 16 * max(1, T >> 13), lib().scanerf_render_backward_grid(ctypes.c_int(B))
+        head = ((nbins * W + 2 * nbins + 4) * 4 + 255) & ~255
+        assert int(wa[:head].view(torch.int32)[nbins * W:nbins * W + nbins].sum()) > 0      # totals
+        assert torch.equal(wa[:head], wb[:head])
+    # the step
+    B, S_ = 4096, 64
+    o = torch.rand(B, 3, device=DEV) * 8 - 4
+    d = torch.nn.functional.normalize(torch.randn(B, 3, device=DEV), dim=-1) * (0.5 + torch.rand(B, 1, device=DEV))
+    tgt = torch.rand(B, 3, device=DEV)
+    res = {}
+    for tag in ("forward", "separate"):
+        if tag == "separate":
+            monkeypatch.setenv("SCANERF_NO_FORWARD_PLAN", "1")
+        m = TileModel([-4, -4, -4], [8, 8, 8], DEV, log2_T=14, seed=1)
+        with torch.no_grad():
+            m.features.mul_(30.0)
+        opt = torch.optim.Adam(m.decoder.parameters(), lr=1e-3, betas=(0.9, 0.99), eps=1e-15)
+        losses = [float(train_step_fused(m, opt, o, d, tgt, S_, 20000 + i)) for i in range(3)]
+        res[tag] = (losses, m.features.detach().clone(), m.exp_avg.clone())
+    assert res["forward"][0] == res["separate"][0]
+    assert torch.equal(res["forward"][1], res["separate"][1]) and torch.equal(res["forward"][2], res["separate"][2])
