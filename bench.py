@@ -375,24 +375,33 @@ def main():
     # the same step with the exact-f32 decoder arithmetic (f32-input MFMA), timed the same way, printed beside the headline
     from scanerf_amd import render as _render
     h3_run = path == "fused" and _render.ARITH != 0
-    dtype_label = ("f32 tables/accumulate/compositing; decoder GEMMs split-f16 x3 MFMA, f32 accumulate (22-bit operands)"
+    dtype_label = ("f32 tables/compositing; decoder GEMMs split-f16 x3 MFMA, f32 accumulate (22-bit operands); backward gradient "
+                   "products f16 MFMA + 13-bit table-gradient records, summed in 64-bit fixed point (gradient error vs oracle 7e-4 "
+                   "rel. L2; h3_grad_ms_per_step = the same step with 22-bit gradient products and f32 records, 1e-5)"
+                   if h3_run and _render.ARITH == 2 else
+                   "f32 tables/accumulate/compositing; decoder GEMMs split-f16 x3 MFMA, f32 accumulate (22-bit operands)"
                    if h3_run else "f32")
     if occ:
         dtype_label = "bf16 gather table, fp32 master + accumulate; " + dtype_label
-    f32_ms = None
+    f32_ms = h3_ms = None
     if h3_run and not occ and not fgbg:
-        _render.set_arith("f32")
-        try:
-            for i in range(2):
-                step_fn(models[i % ntile], dec_opts[i % ntile], rays_o, rays_d, target, S, step0 + i)
-            sync()
-            f0 = time.perf_counter()
-            for i in range(args.steps):
-                step_fn(models[i % ntile], dec_opts[i % ntile], rays_o, rays_d, target, S, step0 + i)
-            sync()
-            f32_ms = (time.perf_counter() - f0) / args.steps * 1e3
-        finally:
-            _render.set_arith(_render.DEFAULT_ARITH)
+        for other in ("f32", "h3"):
+            _render.set_arith(other)
+            try:
+                for i in range(2):
+                    step_fn(models[i % ntile], dec_opts[i % ntile], rays_o, rays_d, target, S, step0 + i)
+                sync()
+                f0 = time.perf_counter()
+                for i in range(args.steps):
+                    step_fn(models[i % ntile], dec_opts[i % ntile], rays_o, rays_d, target, S, step0 + i)
+                sync()
+                ms = (time.perf_counter() - f0) / args.steps * 1e3
+                if other == "f32":
+                    f32_ms = ms
+                else:
+                    h3_ms = ms
+            finally:
+                _render.set_arith(_render.DEFAULT_ARITH)
 
     with torch.no_grad():  # rays that meet no occupied cell are skipped by every kernel: they are not counted as work
         valid_frac = float((model.sample(rays_o, rays_d, S)[0] != -1).all(1).float().mean())
@@ -416,7 +425,7 @@ def main():
                                     f"(sample+encode+decode+composite fwd, bwd, sparse Adam); foreground branch"),
                        "path": path, "rays_per_step": B, "valid_ray_fraction": valid_frac, "samples": S, "tiles_per_gpu": ntile,
                        "parallelism": f"tile-per-gpu x{world}", "syn_iters": SYN_ITERS},
-            "f32_arith_ms_per_step": f32_ms,
+            "f32_arith_ms_per_step": f32_ms, "h3_grad_ms_per_step": h3_ms,
             "consensus_ms": consensus_ms,
             "consensus_frac_of_iteration": consensus_ms / (SYN_ITERS * ms_per_step),
         }
@@ -429,7 +438,8 @@ def main():
             t_hbm, t_mfma = alg_bytes / (HBM_PEAK_GBS * 1e9), (3 if h3 else 1) * alg_flops / (mfma_peak * 1e12)
             line["config"]["decoder_arith"] = ("f32 MFMA" if not h3 else "split f16 x3 MFMA, f32 accumulate (csrc/render_h3.h)" if _render.ARITH == 1
                                                else "forward + backward recompute: split f16 x3 MFMA, f32 accumulate; gradient products: f16 MFMA, f32 "
-                                                    "accumulate, power-of-two scaled (csrc/render_t16.h)")
+                                                    "accumulate, power-of-two scaled (csrc/render_t16.h); table-gradient records 8 bytes: 13-bit "
+                                                    "significands under a per-record exponent (csrc/scatter_common.h)")
             if t_mfma > t_hbm:  # the kernel's floor is set by the matrix pipe, not by HBM
                 ach = alg_flops / (avg_ms * 1e-3) / 1e12
                 roof = {"bound": "mfma", "achieved": ach, "peak": mfma_peak, "unit": "TFLOP/s",
