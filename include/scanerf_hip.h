@@ -293,14 +293,18 @@ int scanerf_embedding_bg_forward_ex(const float *points, float *outputs, const v
 int scanerf_ray_block_intersection(const float *rays_o, const float *rays_d, const float *corners,
                                    const float *sizes, float *intersections, int B, int nb,
                                    scanerf_stream_t stream);                                   /* :126-174 */
+/* sample_major (the per-sample arrays of the render-time ops below): 0 = the reference's [B][S] arrays; 1 = [S][B] (z_vals,
+ * dists, block_idxs [S][B][4], the per-sample outputs [S][B][3] / [S][B]): the renderer's own layout -- a wave's 32 samples are
+ * then one depth index of 32 neighbouring rays (pixels), whose cells coincide down to the fine levels, instead of 32 depths of
+ * one ray.  Same arithmetic per sample. */
 int scanerf_render_sample_points(const float *rays_o, const float *rays_d, const float *corners,
                                  const float *sizes, const uint8_t *occ, const int64_t *grid_starts,
                                  const int32_t *log2dim, const int32_t *tracing_blocks,
                                  const float *intersections, int32_t *tracing_idx, float *z_start,
                                  float *z_vals, float *dists, int B, int S, int nb,
-                                 scanerf_stream_t stream);                                     /* :179-382 */
+                                 int sample_major, scanerf_stream_t stream);                                     /* :179-382 */
 int scanerf_prepare_points(const float *z_vals, const uint8_t *running_mask, const float *intersections,
-                           int16_t *block_idxs, int B, int S, int nb, scanerf_stream_t stream); /* :391-449 */
+                           int16_t *block_idxs, int B, int S, int nb, int sample_major, scanerf_stream_t stream); /* :391-449 */
 /* images [nb][scanerf_render_workspace_floats()]: each tile's decoder blob packed by
  * scanerf_pack_decoder with weight_feature == 1; tables [nb,16,T,2] f16; resolution [nb,16,3] i32 */
 int scanerf_pts_inference(const float *rays_o, const float *rays_d, const float *z_vals, const float *dists,
@@ -308,18 +312,18 @@ int scanerf_pts_inference(const float *rays_o, const float *rays_d, const float 
                           const int32_t *resolution, const uint8_t *occ, const int64_t *grid_starts,
                           const int32_t *log2dim, const float *corners, const float *sizes, float *diffuse,
                           float *specular, float *alpha, int B, int S, int T, int nb,
-                          scanerf_stream_t stream);                                            /* :467-621 */
+                          int sample_major, scanerf_stream_t stream);                                            /* :467-621 */
 int scanerf_accumulate_color(const float *pts_diffuse, const float *pts_specular, const float *pts_alpha,
                              float *transparency, const float *z_vals, float *diffuse, float *specular,
-                             float *depth, int B, int S, scanerf_stream_t stream);             /* :624-702 */
+                             float *depth, int B, int S, int sample_major, scanerf_stream_t stream);             /* :624-702 */
 int scanerf_render_inverse_z_sampling(const float *intersections, const int16_t *related_bidx, float *z_vals,
                                       float sample_range, int B, int S, int nb,
-                                      scanerf_stream_t stream);                                /* :816-868 */
+                                      int sample_major, scanerf_stream_t stream);                                /* :816-868 */
 int scanerf_bg_pts_inference_v2(const float *rays_o, const float *rays_d, const float *z_vals,
                                 const int16_t *bg_idxs, int step, const float *corners, const float *sizes,
                                 const int32_t *resolution, const void *tables_f16, const float *images,
                                 float *diffuse, float *specular, float *alpha, int B, int S, int T, int nb,
-                                scanerf_stream_t stream);                                      /* :1012-1171 */
+                                int sample_major, scanerf_stream_t stream);                                      /* :1012-1171 */
 int scanerf_update_outgoing_bidx(const float *rays_o, const float *rays_d, const float *corners,
                                  const float *sizes, const int32_t *tracing_blocks, const float *intersections,
                                  int16_t *outgoing_bidxs, float *blend_weights, float ratio, int skip, int B,

@@ -300,7 +300,7 @@ __device__ __forceinline__ SampleOut decode_tile(const float *lds, int lane, con
 
 // hash-encode 8 levels at p01 in [0,1]^3 (rendering_kernel.cu:79-114: v = p01*(res-1), no (p+2)/4 step);
 // same register<->level map as encode8.  Lanes with active == false issue no loads.
-template <int DT>
+template <int DT, int GATHER_BATCH = 2>
 __device__ __forceinline__ void encode8_01(const void *table, const int32_t *res, int T, int h, const float p01[3],
                                            bool active, v16f &x)
 {
@@ -339,7 +339,7 @@ __device__ __forceinline__ void encode8_01(const void *table, const int32_t *res
         }
         x[2 * j] = ax;
         x[2 * j + 1] = ay;
-        if (j & 1) __builtin_amdgcn_sched_barrier(0);
+        if ((j + 1) % GATHER_BATCH == 0) __builtin_amdgcn_sched_barrier(0);
     }
 }
 

@@ -44,6 +44,26 @@ __device__ __forceinline__ uint32_t cell_offset(const int c[3], int ly, int lz)
     return ((uint32_t)c[0] << (ly + lz)) | ((uint32_t)c[1] << lz) | (uint32_t)c[2];
 }
 
+// Layout of the per-sample arrays of the render-time ops (scanerf_hip.h `sample_major`): element (ray i, sample s) of B x S
+//   0  [B][S]          the reference's
+//   1  [S][B]          sample-major
+//   2  [B/32][S][32]   ray blocks: 32 neighbouring rays side by side, their samples in order (B a multiple of 32)
+// In 1 and 2 a wave's 32 samples are one depth index of 32 neighbouring rays (neighbouring pixels share their cells down to
+// the fine levels: the gathers of a wave fall on a few lines); in 2 consecutive groups of a wave also walk ALONG those rays, and
+// the chip is spread over all depths at any time (in 1 every CU works on the same depth slab and the same few lines of the
+// coarse levels -- measured 1.5-2x slower than 0).
+__device__ __forceinline__ size_t pt_index(int i, int s, int B, int S, int lay)
+{
+    return lay == 0 ? (size_t)i * S + s : lay == 1 ? (size_t)s * B + i : ((size_t)(i >> 5) * S + s) * 32 + (i & 31);
+}
+__device__ __forceinline__ void pt_decompose(uint32_t e, uint32_t B, uint32_t S, int lay, int &i, int &s)
+{
+    if (lay == 0) { i = (int)(e / S); s = (int)(e - (uint32_t)i * S); }
+    else if (lay == 1) { s = (int)(e / B); i = (int)(e - (uint32_t)s * B); }
+    else { const uint32_t g = e >> 5, rb = g / S; s = (int)(g - rb * S); i = (int)(rb * 32 + (e & 31u)); }
+}
+__device__ __forceinline__ size_t pt_sample_stride(int B, int lay) { return lay == 0 ? 1 : lay == 1 ? (size_t)B : 32; }
+
 // ---- rendering_kernel.cu:126-174 ---------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_ray_block_intersection(const float *__restrict__ rays_o,
                                                                 const float *__restrict__ rays_d, Tiles t,
@@ -72,14 +92,15 @@ __global__ void __launch_bounds__(64) k_render_sample_points(const float *__rest
                                                              const int32_t *__restrict__ tracing_blocks,
                                                              const float *__restrict__ inter,
                                                              int32_t *__restrict__ tracing_idx, float *__restrict__ z_start,
-                                                             float *__restrict__ z_vals, float *__restrict__ dists, int B)
+                                                             float *__restrict__ z_vals, float *__restrict__ dists, int B, int sm)
 {
+    const size_t ks = pt_sample_stride(B, sm);
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < B; i += gridDim.x * blockDim.x) {
         const float o[3] = { rays_o[3 * i], rays_o[3 * i + 1], rays_o[3 * i + 2] };
         const float d[3] = { rays_d[3 * i], rays_d[3 * i + 1], rays_d[3 * i + 2] };
         const int32_t *tb = tracing_blocks + (size_t)i * t.nb;
         const float2 *ci = reinterpret_cast<const float2 *>(inter) + (size_t)i * t.nb;
-        float *cz = z_vals + (size_t)i * S, *cd = dists + (size_t)i * S;
+        float *cz = z_vals + pt_index(i, 0, B, S, sm), *cd = dists + pt_index(i, 0, B, S, sm);
         int step = tracing_idx[i];
         float tsx = z_start[i];
         while (step < t.nb) {
@@ -128,8 +149,8 @@ __global__ void __launch_bounds__(64) k_render_sample_points(const float *__rest
                         if (n > 0) {
                             const float interval = (w.t1 - w.t0) / (float)n;
                             for (int k = 0; k < n; ++k) {
-                                cz[num + k] = w.t0 + (float)k * interval;
-                                cd[num + k] = interval;
+                                cz[(num + k) * ks] = w.t0 + (float)k * interval;
+                                cd[(num + k) * ks] = interval;
                             }
                         }
                         num += n;
@@ -151,11 +172,12 @@ __global__ void __launch_bounds__(64) k_render_sample_points(const float *__rest
 __global__ void __launch_bounds__(256) k_prepare_points(const float *__restrict__ z_vals,
                                                         const uint8_t *__restrict__ running,
                                                         int16_t *__restrict__ block_idxs,
-                                                        const float *__restrict__ inter, int S, int nb, int B)
+                                                        const float *__restrict__ inter, int S, int nb, int B, int sm)
 {
     const int64_t total = (int64_t)B * S;
     for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
-        const int i = (int)(e / S);
+        int i, s_;
+        pt_decompose((uint32_t)e, (uint32_t)B, (uint32_t)S, sm, i, s_);
         if (!running[i]) continue;
         const float z = z_vals[e];
         if (z == -1.0f) continue;
@@ -192,6 +214,8 @@ struct InferArgs {
     Tiles t;
     float *out_dif, *out_spec, *out_alpha;
     int T, B, S, step;
+    int sm;   // layout of the per-sample arrays (pt_index)
+    int dbg;  // timing experiments only (-DSCANERF_RT_EXPERIMENTS, SCANERF_DEBUG_RT): 1 = no decoder, 2 = no table gathers
 };
 
 // ---- rendering_kernel.cu:467-621 (BG == false) and :1012-1171 (BG == true) -------------------------
@@ -316,14 +340,20 @@ __global__ void __launch_bounds__(256, 2) k_pts_inference(InferArgs a)
 // the overlap of several tiles are blended across the chunk's tile steps: each adds w_b * pa * colour / sum_k w_k into the
 // (zero-filled) outputs; a sample belongs to one workgroup and the steps are sequential, so the read-modify-write is
 // race-free and its order (ascending tile index) is fixed.
+// 8 waves share one staged image (two per SIMD; with 4, the 104 KB image left one wave per SIMD and the decoder's dependent
+// MFMA chains exposed: 3.3e9 samples/s whatever the gathers did)
+#ifndef RT_GATHER_BATCH
+#define RT_GATHER_BATCH 2
+#endif
+constexpr int kChunkThreads = 512, kChunkWaves = kChunkThreads / 64, kChunkWaveGroups = 16;
 template <bool BG>
-__global__ void __launch_bounds__(256, 2) k_pts_inference_chunks(InferArgs a)
+__global__ void __launch_bounds__(kChunkThreads, 1) k_pts_inference_chunks(InferArgs a)
 {
     __shared__ __attribute__((aligned(16))) char lds[H3_BYTES];
     __shared__ uint32_t tileset[2];
     const int lane = threadIdx.x & 63, sl = lane & 31, h = lane >> 5, wave = threadIdx.x >> 6;
     const int64_t total = (int64_t)a.B * a.S;
-    constexpr int kWaveGroups = 16, kChunkGroups = 4 * kWaveGroups;
+    constexpr int kWaveGroups = kChunkWaveGroups, kChunkGroups = kChunkWaves * kWaveGroups;
     const int64_t ngroups = (total + 31) / 32, nchunks = (ngroups + kChunkGroups - 1) / kChunkGroups;
     for (int64_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
         if (threadIdx.x < 2) tileset[threadIdx.x] = 0;
@@ -343,7 +373,9 @@ __global__ void __launch_bounds__(256, 2) k_pts_inference_chunks(InferArgs a)
                 if (e >= total || h != 0) continue;
                 const uint32_t e32 = (uint32_t)e;
                 if (BG) {
-                    mark(a.block_idxs[(e32 / (uint32_t)a.S) * kMaxPtsBlocks + a.step]);
+                    int ri, rs;
+                    pt_decompose(e32, (uint32_t)a.B, (uint32_t)a.S, a.sm, ri, rs);
+                    mark(a.block_idxs[ri * kMaxPtsBlocks + a.step]);
                 } else {
                     const uint2 raw = *reinterpret_cast<const uint2 *>(a.block_idxs + (size_t)e32 * kMaxPtsBlocks);
                     const int s0 = (int16_t)(raw.x & 0xffffu), s1 = (int16_t)(raw.x >> 16), s2 = (int16_t)(raw.y & 0xffffu),
@@ -371,7 +403,7 @@ __global__ void __launch_bounds__(256, 2) k_pts_inference_chunks(InferArgs a)
         {
             const float4 *src = reinterpret_cast<const float4 *>(a.images + (size_t)b * WS_FLOATS + PK_TOTAL);
             float4 *dst = reinterpret_cast<float4 *>(lds);
-            for (int i = threadIdx.x; i < H3_BYTES / 16; i += 256) dst[i] = src[i];
+            for (int i = threadIdx.x; i < H3_BYTES / 16; i += kChunkThreads) dst[i] = src[i];
         }
         __syncthreads();
         float cb[3], sb[3];
@@ -388,8 +420,8 @@ __global__ void __launch_bounds__(256, 2) k_pts_inference_chunks(InferArgs a)
         const bool in_range = e < total;
         const int64_t ec = in_range ? e : total - 1;
         // (32-bit division: the host keeps B*S below 2^31 for this kernel; a 64-bit one costs ~100 instructions per group)
-        const uint32_t ec32 = (uint32_t)ec, S32 = (uint32_t)a.S;
-        const int i = (int)(ec32 / S32), s = (int)(ec32 - (uint32_t)i * S32);
+        int i, s;
+        pt_decompose((uint32_t)ec, (uint32_t)a.B, (uint32_t)a.S, a.sm, i, s);
         // does this sample list tile b?  (fg: the slot list stops at the first -1, rendering_kernel.cu:499)
         int16_t slot[kMaxPtsBlocks] = { -1, -1, -1, -1 };
         bool mine = false;
@@ -417,7 +449,7 @@ __global__ void __launch_bounds__(256, 2) k_pts_inference_chunks(InferArgs a)
         const float dnorm = sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
         const float z = a.z_vals[ec];
         float delta;
-        if (BG) delta = (s == a.S - 1) ? 10000000.0f : a.z_vals[ec + 1] - z;   // :1045-1047: raw depth step
+        if (BG) delta = (s == a.S - 1) ? 10000000.0f : a.z_vals[ec + pt_sample_stride(a.B, a.sm)] - z;   // :1045-1047: raw depth step
         else delta = a.dists[ec] * dnorm;                                       // :557
         float p01[3], w_b = 0.0f, weight = 0.0f;
         bool run = mine;
@@ -460,14 +492,28 @@ __global__ void __launch_bounds__(256, 2) k_pts_inference_chunks(InferArgs a)
         }
         if (!__any(run)) continue;  // wave-uniform: nothing of this group is occupied (the outputs stay as they are)
         v16f x;
-        encode8_01<SCANERF_F16>((const char *)a.tables + (size_t)b * 16 * a.T * 4, a.res + (size_t)b * 48, a.T, h, p01, run, x);
+#ifdef SCANERF_RT_EXPERIMENTS
+        if (a.dbg == 2) {
+#pragma unroll
+            for (int g2 = 0; g2 < 16; ++g2) x[g2] = p01[g2 % 3] * (0.01f * g2);
+        } else
+#endif
+        encode8_01<SCANERF_F16, RT_GATHER_BATCH>((const char *)a.tables + (size_t)b * 16 * a.T * 4, a.res + (size_t)b * 48, a.T, h, p01, run, x);
         v16f dinit[2];
         {
             float sh[16];
             ray_sh(d, dnorm, sh, 0.0f);
             h3_dinit(lds, lane, sh, dinit);
         }
-        const SampleOut so = decode_tile_h3(lds, lane, x, dinit);
+        SampleOut so;
+#ifdef SCANERF_RT_EXPERIMENTS
+        if (a.dbg == 1) {
+            so.sigma = x[0] + x[5] + x[10] + x[15] + dinit[0][0];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { so.dif[c] = x[1 + c] + x[12 + c]; so.tint[c] = x[4 + c] + x[9 + c]; so.spec[c] = x[7 + c] + x[6 + c]; }
+        } else
+#endif
+            so = decode_tile_h3(lds, lane, x, dinit);
         if (run && h == 0) {
             const float pa = 1.0f - expf(-1.0f * so.sigma * delta);
             if (BG) {
@@ -554,13 +600,45 @@ __global__ void __launch_bounds__(256) k_accumulate_color(const float *__restric
     }
 }
 
+// the same over layouts 1 and 2: one LANE per ray, its samples in order (neighbouring lanes = neighbouring rays read neighbouring words)
+__global__ void __launch_bounds__(256) k_accumulate_color_sm(const float *__restrict__ pts_dif, const float *__restrict__ pts_spec,
+                                                             const float *__restrict__ pts_alpha, float *__restrict__ transp,
+                                                             const float *__restrict__ z_vals, float *__restrict__ dif,
+                                                             float *__restrict__ spec, float *__restrict__ depth, int B, int S, int lay)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < B; i += gridDim.x * blockDim.x) {
+        float T = transp[i];
+        if (T < 0.00001f) continue;
+        float acc[7] = { 0, 0, 0, 0, 0, 0, 0 };
+        for (int s = 0; s < S; ++s) {
+            const size_t e = pt_index(i, s, B, S, lay);
+            const float al = pts_alpha[e];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                acc[c] += T * pts_dif[3 * e + c];
+                acc[3 + c] += T * pts_spec[3 * e + c];
+            }
+            acc[6] += T * al * z_vals[e];
+            T *= 1.0f - al;
+        }
+        transp[i] = T;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            dif[3 * i + c] += acc[c];
+            spec[3 * i + c] += acc[3 + c];
+        }
+        depth[i] += acc[6];
+    }
+}
+
 // ---- rendering_kernel.cu:816-868 -------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_render_inverse_z(const float *__restrict__ inter, const int16_t *__restrict__ related,
-                                                          int S, int nb, float range, float *__restrict__ z_vals, int B)
+                                                          int S, int nb, float range, float *__restrict__ z_vals, int B, int sm)
 {
     const int64_t total = (int64_t)B * S;
     for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
-        const int i = (int)(e / S), k = (int)(e % S);
+        int i, k;
+        pt_decompose((uint32_t)e, (uint32_t)B, (uint32_t)S, sm, i, k);
         const int b = related[i];
         if (b == -1) continue;
         const float2 bd = reinterpret_cast<const float2 *>(inter)[(size_t)i * nb + b];
@@ -780,26 +858,30 @@ SCANERF_API int scanerf_render_sample_points(const float *rays_o, const float *r
                                              const float *sizes, const uint8_t *occ, const int64_t *grid_starts,
                                              const int32_t *log2dim, const int32_t *tracing_blocks, const float *inter,
                                              int32_t *tracing_idx, float *z_start, float *z_vals, float *dists, int B, int S,
-                                             int nb, scanerf_stream_t stream)
+                                             int nb, int sample_major, scanerf_stream_t stream)
 {
     RT_REQ(B >= 0 && S >= 1 && nb >= 1, "sample_points");
+    SCANERF_REQUIRE(sample_major >= 0 && sample_major <= 2 && (sample_major != 2 || B % 32 == 0),
+                    "sample_points" ": sample_major=%d (0, 1, or 2 with B a multiple of 32; B=%d)", sample_major, B);
     if (B == 0) return 0;
     RT_REQ(rays_o && rays_d && corners && sizes && occ && grid_starts && log2dim && tracing_blocks && inter && tracing_idx &&
                z_start && z_vals && dists, "sample_points");
     hipLaunchKernelGGL(k_render_sample_points, dim3(stream_grid(B, 64, kNumCU * 64)), dim3(64), 0, (hipStream_t)stream, rays_o,
                        rays_d, make_tiles(corners, sizes, occ, grid_starts, log2dim, nb), S, tracing_blocks, inter, tracing_idx,
-                       z_start, z_vals, dists, B);
+                       z_start, z_vals, dists, B, sample_major);
     return check_launch("sample_points");
 }
 
 SCANERF_API int scanerf_prepare_points(const float *z_vals, const uint8_t *running_mask, const float *inter,
-                                       int16_t *block_idxs, int B, int S, int nb, scanerf_stream_t stream)
+                                       int16_t *block_idxs, int B, int S, int nb, int sample_major, scanerf_stream_t stream)
 {
     RT_REQ(B >= 0 && S >= 1 && nb >= 1, "prepare_points");
+    SCANERF_REQUIRE(sample_major >= 0 && sample_major <= 2 && (sample_major != 2 || B % 32 == 0),
+                    "prepare_points" ": sample_major=%d (0, 1, or 2 with B a multiple of 32; B=%d)", sample_major, B);
     if (B == 0) return 0;
     RT_REQ(z_vals && running_mask && inter && block_idxs, "prepare_points");
     hipLaunchKernelGGL(k_prepare_points, dim3(stream_grid((int64_t)B * S, 256)), dim3(256), 0, (hipStream_t)stream, z_vals,
-                       running_mask, block_idxs, inter, S, nb, B);
+                       running_mask, block_idxs, inter, S, nb, B, sample_major);
     return check_launch("prepare_points");
 }
 
@@ -808,9 +890,12 @@ SCANERF_API int scanerf_pts_inference(const float *rays_o, const float *rays_d, 
                                       const int16_t *block_idxs, const void *tables_f16, const float *images,
                                       const int32_t *res, const uint8_t *occ, const int64_t *grid_starts,
                                       const int32_t *log2dim, const float *corners, const float *sizes, float *out_dif,
-                                      float *out_spec, float *out_alpha, int B, int S, int T, int nb, scanerf_stream_t stream)
+                                      float *out_spec, float *out_alpha, int B, int S, int T, int nb, int sample_major,
+                                      scanerf_stream_t stream)
 {
     RT_REQ(B >= 0 && S >= 1 && nb >= 1, "pts_inference");
+    SCANERF_REQUIRE(sample_major >= 0 && sample_major <= 2 && (sample_major != 2 || B % 32 == 0),
+                    "pts_inference" ": sample_major=%d (0, 1, or 2 with B a multiple of 32; B=%d)", sample_major, B);
     SCANERF_REQUIRE(T >= 2 && (T & (T - 1)) == 0, "pts_inference: T=%d must be a power of two", T);
     if (B == 0) return 0;
     RT_REQ(rays_o && rays_d && z_vals && dists && block_idxs && tables_f16 && images && res && occ && grid_starts && log2dim &&
@@ -819,8 +904,11 @@ SCANERF_API int scanerf_pts_inference(const float *rays_o, const float *rays_d, 
     a.rays_o = rays_o; a.rays_d = rays_d; a.z_vals = z_vals; a.dists = dists; a.block_idxs = block_idxs;
     a.tables = tables_f16; a.images = images; a.res = res; a.t = make_tiles(corners, sizes, occ, grid_starts, log2dim, nb);
     a.out_dif = out_dif; a.out_spec = out_spec; a.out_alpha = out_alpha; a.T = T; a.B = B; a.S = S; a.step = 0;
+    a.sm = sample_major;
+    { const char *de = getenv("SCANERF_DEBUG_RT"); a.dbg = de ? atoi(de) : 0; }
     const int64_t tiles32 = ((int64_t)B * S + 31) / 32;
     int blocks = (int)((tiles32 + 3) / 4 < kNumCU * 4 ? (tiles32 + 3) / 4 : kNumCU * 4);
+    SCANERF_REQUIRE(!sample_major || !render_single_pass((int64_t)B * S, nb), "pts_inference: sample-major arrays need the chunk kernel");
     if (render_single_pass((int64_t)B * S, nb)) {
         hipLaunchKernelGGL((k_pts_inference<false>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
         return check_launch("pts_inference");
@@ -830,19 +918,21 @@ SCANERF_API int scanerf_pts_inference(const float *rays_o, const float *rays_d, 
     const hipError_t ce[3] = { hipMemsetAsync(out_dif, 0, n * 12, (hipStream_t)stream), hipMemsetAsync(out_spec, 0, n * 12, (hipStream_t)stream),
                                hipMemsetAsync(out_alpha, 0, n * 4, (hipStream_t)stream) };
     for (hipError_t e : ce) SCANERF_REQUIRE(e == hipSuccess, "pts_inference: clearing the outputs failed: %s", hipGetErrorString(e));
-    const int64_t nchunks = (tiles32 + 63) / 64;
+    const int64_t per_chunk = kChunkWaves * kChunkWaveGroups, nchunks = (tiles32 + per_chunk - 1) / per_chunk;
     blocks = (int)(nchunks < kNumCU * 8 ? nchunks : kNumCU * 8);
-    hipLaunchKernelGGL((k_pts_inference_chunks<false>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL((k_pts_inference_chunks<false>), dim3(blocks), dim3(kChunkThreads), 0, (hipStream_t)stream, a);
     return check_launch("pts_inference");
 }
 
 SCANERF_API int scanerf_bg_pts_inference_v2(const float *rays_o, const float *rays_d, const float *z_vals,
                                             const int16_t *bg_idxs, int step, const float *corners, const float *sizes,
                                             const int32_t *res, const void *tables_f16, const float *images, float *out_dif,
-                                            float *out_spec, float *out_alpha, int B, int S, int T, int nb,
+                                            float *out_spec, float *out_alpha, int B, int S, int T, int nb, int sample_major,
                                             scanerf_stream_t stream)
 {
     RT_REQ(B >= 0 && S >= 1 && nb >= 1 && step >= 0 && step < kMaxPtsBlocks, "bg_pts_inference_v2");
+    SCANERF_REQUIRE(sample_major >= 0 && sample_major <= 2 && (sample_major != 2 || B % 32 == 0),
+                    "bg_pts_inference_v2" ": sample_major=%d (0, 1, or 2 with B a multiple of 32; B=%d)", sample_major, B);
     SCANERF_REQUIRE(T >= 2 && (T & (T - 1)) == 0, "bg_pts_inference_v2: T=%d must be a power of two", T);
     if (B == 0) return 0;
     RT_REQ(rays_o && rays_d && z_vals && bg_idxs && tables_f16 && images && res && corners && sizes && out_dif && out_spec &&
@@ -851,38 +941,50 @@ SCANERF_API int scanerf_bg_pts_inference_v2(const float *rays_o, const float *ra
     a.rays_o = rays_o; a.rays_d = rays_d; a.z_vals = z_vals; a.dists = nullptr; a.block_idxs = bg_idxs;
     a.tables = tables_f16; a.images = images; a.res = res; a.t = make_tiles(corners, sizes, nullptr, nullptr, nullptr, nb);
     a.out_dif = out_dif; a.out_spec = out_spec; a.out_alpha = out_alpha; a.T = T; a.B = B; a.S = S; a.step = step;
+    a.sm = sample_major;
+    { const char *de = getenv("SCANERF_DEBUG_RT"); a.dbg = de ? atoi(de) : 0; }
     const int64_t tiles32 = ((int64_t)B * S + 31) / 32;
     int blocks = (int)((tiles32 + 3) / 4 < kNumCU * 4 ? (tiles32 + 3) / 4 : kNumCU * 4);
+    SCANERF_REQUIRE(!sample_major || !render_single_pass((int64_t)B * S, nb), "bg_pts_inference_v2: sample-major arrays need the chunk kernel");
     if (render_single_pass((int64_t)B * S, nb)) {
         hipLaunchKernelGGL((k_pts_inference<true>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
         return check_launch("bg_pts_inference_v2");
     }
-    const int64_t nchunks = (tiles32 + 63) / 64;
+    const int64_t per_chunk = kChunkWaves * kChunkWaveGroups, nchunks = (tiles32 + per_chunk - 1) / per_chunk;
     blocks = (int)(nchunks < kNumCU * 8 ? nchunks : kNumCU * 8);
-    hipLaunchKernelGGL((k_pts_inference_chunks<true>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL((k_pts_inference_chunks<true>), dim3(blocks), dim3(kChunkThreads), 0, (hipStream_t)stream, a);
     return check_launch("bg_pts_inference_v2");
 }
 
 SCANERF_API int scanerf_accumulate_color(const float *pts_dif, const float *pts_spec, const float *pts_alpha, float *transp,
                                          const float *z_vals, float *dif, float *spec, float *depth, int B, int S,
-                                         scanerf_stream_t stream)
+                                         int sample_major, scanerf_stream_t stream)
 {
     RT_REQ(B >= 0 && S >= 1, "accumulate_color");
+    SCANERF_REQUIRE(sample_major >= 0 && sample_major <= 2 && (sample_major != 2 || B % 32 == 0),
+                    "accumulate_color" ": sample_major=%d (0, 1, or 2 with B a multiple of 32; B=%d)", sample_major, B);
     if (B == 0) return 0;
     RT_REQ(pts_dif && pts_spec && pts_alpha && transp && z_vals && dif && spec && depth, "accumulate_color");
-    hipLaunchKernelGGL(k_accumulate_color, dim3(stream_grid((int64_t)B * 64, 256)), dim3(256), 0, (hipStream_t)stream, pts_dif,
-                       pts_spec, pts_alpha, transp, z_vals, dif, spec, depth, B, S);
+    if (sample_major)
+        hipLaunchKernelGGL(k_accumulate_color_sm, dim3(stream_grid(B, 256)), dim3(256), 0, (hipStream_t)stream, pts_dif, pts_spec,
+                           pts_alpha, transp, z_vals, dif, spec, depth, B, S, sample_major);
+    else
+        hipLaunchKernelGGL(k_accumulate_color, dim3(stream_grid((int64_t)B * 64, 256)), dim3(256), 0, (hipStream_t)stream, pts_dif,
+                           pts_spec, pts_alpha, transp, z_vals, dif, spec, depth, B, S);
     return check_launch("accumulate_color");
 }
 
 SCANERF_API int scanerf_render_inverse_z_sampling(const float *inter, const int16_t *related_bidx, float *z_vals,
-                                                  float sample_range, int B, int S, int nb, scanerf_stream_t stream)
+                                                  float sample_range, int B, int S, int nb, int sample_major,
+                                                  scanerf_stream_t stream)
 {
     RT_REQ(B >= 0 && S >= 2 && nb >= 1, "inverse_z_sampling");
+    SCANERF_REQUIRE(sample_major >= 0 && sample_major <= 2 && (sample_major != 2 || B % 32 == 0),
+                    "inverse_z_sampling" ": sample_major=%d (0, 1, or 2 with B a multiple of 32; B=%d)", sample_major, B);
     if (B == 0) return 0;
     RT_REQ(inter && related_bidx && z_vals, "inverse_z_sampling");
     hipLaunchKernelGGL(k_render_inverse_z, dim3(stream_grid((int64_t)B * S, 256)), dim3(256), 0, (hipStream_t)stream, inter,
-                       related_bidx, S, nb, sample_range, z_vals, B);
+                       related_bidx, S, nb, sample_range, z_vals, B, sample_major);
     return check_launch("inverse_z_sampling");
 }
 

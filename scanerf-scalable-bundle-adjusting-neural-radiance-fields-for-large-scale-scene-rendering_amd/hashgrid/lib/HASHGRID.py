@@ -148,27 +148,32 @@ def ray_block_intersection(rays_o, rays_d, block_corners, block_sizes, intersect
                                                _I(block_corners.shape[0]), stream()), "ray_block_intersection")
 
 
+def _S(z_vals, sample_major):
+    """per-sample arrays: [B,S] (0, the reference's), [S,B] (1) or [B/32,S,32] (2) -- scanerf_hip.h `sample_major`"""
+    return _I(z_vals.shape[0] if int(sample_major) == 1 else z_vals.shape[1])
+
+
 def sample_points(rays_o, rays_d, block_corners, block_sizes, grid_occupied, grid_starts, grid_log2dim, tracing_blocks,
-                  intersections, tracing_idx, z_start, z_vals, dists):
+                  intersections, tracing_idx, z_start, z_vals, dists, sample_major=False):
     check(lib().scanerf_render_sample_points(
         dev_ptr(rays_o, _f32, "rays_o"), dev_ptr(rays_d, _f32, "rays_d"), dev_ptr(block_corners, _f32, "block_corners"),
         dev_ptr(block_sizes, _f32, "block_sizes"), dev_ptr(grid_occupied, _bool, "grid_occupied"),
         dev_ptr(grid_starts, _i64, "grid_starts"), dev_ptr(grid_log2dim, _i32, "grid_log2dim"),
         dev_ptr(tracing_blocks, _i32, "tracing_blocks"), dev_ptr(intersections, _f32, "intersections"),
         dev_ptr(tracing_idx, _i32, "tracing_idx"), dev_ptr(z_start, _f32, "z_start"), dev_ptr(z_vals, _f32, "z_vals"),
-        dev_ptr(dists, _f32, "dists"), _I(rays_d.shape[0]), _I(z_vals.shape[1]), _I(block_corners.shape[0]), stream()),
-        "sample_points")
+        dev_ptr(dists, _f32, "dists"), _I(rays_d.shape[0]), _S(z_vals, sample_major), _I(block_corners.shape[0]),
+        _I(int(sample_major)), stream()), "sample_points")
 
 
-def prepare_points(z_vals, runing_mask, intersections, block_idxs):
+def prepare_points(z_vals, runing_mask, intersections, block_idxs, sample_major=False):
     check(lib().scanerf_prepare_points(dev_ptr(z_vals, _f32, "z_vals"), dev_ptr(runing_mask, _bool, "runing_mask"),
                                        dev_ptr(intersections, _f32, "intersections"),
-                                       dev_ptr(block_idxs, _i16, "block_idxs"), _I(z_vals.shape[0]), _I(z_vals.shape[1]),
-                                       _I(intersections.shape[1]), stream()), "prepare_points")
+                                       dev_ptr(block_idxs, _i16, "block_idxs"), _I(intersections.shape[0]), _S(z_vals, sample_major),
+                                       _I(intersections.shape[1]), _I(int(sample_major)), stream()), "prepare_points")
 
 
 def pts_inference(rays_o, rays_d, z_vals, dists, block_idxs, features_tables, params, resolution, grid_occupied,
-                  grid_starts, grid_log2dim, block_corners, block_sizes, diffuse, specular, alpha):
+                  grid_starts, grid_log2dim, block_corners, block_sizes, diffuse, specular, alpha, sample_major=False):
     img = _packed_images(params)
     check(lib().scanerf_pts_inference(
         dev_ptr(rays_o, _f32, "rays_o"), dev_ptr(rays_d, _f32, "rays_d"), dev_ptr(z_vals, _f32, "z_vals"),
@@ -178,28 +183,28 @@ def pts_inference(rays_o, rays_d, z_vals, dists, block_idxs, features_tables, pa
         dev_ptr(grid_starts, _i64, "grid_starts"), dev_ptr(grid_log2dim, _i32, "grid_log2dim"),
         dev_ptr(block_corners, _f32, "block_corners"), dev_ptr(block_sizes, _f32, "block_sizes"),
         dev_ptr(diffuse, _f32, "diffuse"), dev_ptr(specular, _f32, "specular"), dev_ptr(alpha, _f32, "alpha"),
-        _I(rays_d.shape[0]), _I(z_vals.shape[1]), _I(features_tables.shape[2]), _I(block_corners.shape[0]), stream()),
-        "pts_inference")
+        _I(rays_d.shape[0]), _S(z_vals, sample_major), _I(features_tables.shape[2]), _I(block_corners.shape[0]),
+        _I(int(sample_major)), stream()), "pts_inference")
 
 
-def accumulate_color(pts_diffuse, pts_specular, pts_alpha, transparency, z_vals, diffuse, specular, depth):
+def accumulate_color(pts_diffuse, pts_specular, pts_alpha, transparency, z_vals, diffuse, specular, depth, sample_major=False):
     check(lib().scanerf_accumulate_color(
         dev_ptr(pts_diffuse, _f32, "pts_diffuse"), dev_ptr(pts_specular, _f32, "pts_specular"),
         dev_ptr(pts_alpha, _f32, "pts_alpha"), dev_ptr(transparency, _f32, "transparency"), dev_ptr(z_vals, _f32, "z_vals"),
         dev_ptr(diffuse, _f32, "diffuse"), dev_ptr(specular, _f32, "specular"), dev_ptr(depth, _f32, "depth"),
-        _I(z_vals.shape[0]), _I(z_vals.shape[1]), stream()), "accumulate_color")
+        _I(transparency.shape[0]), _S(z_vals, sample_major), _I(int(sample_major)), stream()), "accumulate_color")
 
 
-def inverse_z_sampling(intersections, related_bidx, z_vals, sample_range):
+def inverse_z_sampling(intersections, related_bidx, z_vals, sample_range, sample_major=False):
     check(lib().scanerf_render_inverse_z_sampling(dev_ptr(intersections, _f32, "intersections"),
                                                   dev_ptr(related_bidx, _i16, "related_bidx"),
                                                   dev_ptr(z_vals, _f32, "z_vals"), ctypes.c_float(sample_range),
-                                                  _I(intersections.shape[0]), _I(z_vals.shape[1]),
-                                                  _I(intersections.shape[1]), stream()), "inverse_z_sampling")
+                                                  _I(intersections.shape[0]), _S(z_vals, sample_major),
+                                                  _I(intersections.shape[1]), _I(int(sample_major)), stream()), "inverse_z_sampling")
 
 
 def bg_pts_inference_v2(rays_o, rays_d, z_vals, bg_idxs, step, block_corners, block_sizes, resolution, features_tables,
-                        params, diffuse, specular, alpha):
+                        params, diffuse, specular, alpha, sample_major=False):
     img = _packed_images(params)
     check(lib().scanerf_bg_pts_inference_v2(
         dev_ptr(rays_o, _f32, "rays_o"), dev_ptr(rays_d, _f32, "rays_d"), dev_ptr(z_vals, _f32, "z_vals"),
@@ -207,8 +212,8 @@ def bg_pts_inference_v2(rays_o, rays_d, z_vals, bg_idxs, step, block_corners, bl
         dev_ptr(block_sizes, _f32, "block_sizes"), dev_ptr(resolution, _i32, "resolution"),
         dev_ptr(features_tables, torch.float16, "features_tables"), dev_ptr(img, _f32, "images"),
         dev_ptr(diffuse, _f32, "diffuse"), dev_ptr(specular, _f32, "specular"), dev_ptr(alpha, _f32, "alpha"),
-        _I(rays_d.shape[0]), _I(z_vals.shape[1]), _I(features_tables.shape[2]), _I(block_corners.shape[0]), stream()),
-        "bg_pts_inference_v2")
+        _I(rays_d.shape[0]), _S(z_vals, sample_major), _I(features_tables.shape[2]), _I(block_corners.shape[0]),
+        _I(int(sample_major)), stream()), "bg_pts_inference_v2")
 
 
 def bg_pts_inference(*args, **kwargs):

@@ -75,8 +75,22 @@ class TileSetRenderer:
         return o, d
 
     @torch.no_grad()
-    def render_rays(self, rays_o, rays_d, num_sample=128, num_bg_sample=128, sample_range=1e6):
-        dev, B, nb = self.device, rays_o.shape[0], self.block_corner.shape[0]
+    def render_rays(self, rays_o, rays_d, num_sample=128, num_bg_sample=128, sample_range=1e6, layout=2):
+        """layout of the per-sample work arrays between the ops (same ops, same arithmetic per sample; scanerf_hip.h
+        `sample_major`): 0 = the reference's [B,S]; 2 (default) = [B/32,S,32]: a wave of the inference kernel holds ONE depth
+        index of 32 neighbouring rays -- neighbouring pixels share their cells down to the fine levels, so the table gathers of
+        a wave fall on a few lines instead of 32 per level -- and walks along those rays; 1 = [S,B] (measured slower: every
+        CU on the same depth slab)."""
+        dev, nb = self.device, self.block_corner.shape[0]
+        lay = int(os.environ.get("SCANERF_RENDER_LAYOUT", layout))  # (env: A/B timing)
+        n_rays = rays_o.shape[0]
+        if lay == 2 and n_rays % 32:  # pad with copies of the last ray
+            pad = 32 - n_rays % 32
+            rays_o = torch.cat([rays_o, rays_o[-1:].expand(pad, 3)]).contiguous()
+            rays_d = torch.cat([rays_d, rays_d[-1:].expand(pad, 3)]).contiguous()
+        B = rays_o.shape[0]
+        sm = lay
+        shp = {0: lambda S, *tail: (B, S, *tail), 1: lambda S, *tail: (S, B, *tail), 2: lambda S, *tail: (B // 32, S, 32, *tail)}[lay]
         inter = torch.full((B, nb, 2), 1e7, device=dev)
         ray_block_intersection(rays_o, rays_d, self.block_corner, self.block_size, inter)
         tracing_blocks = torch.argsort(inter[..., 0], dim=-1, stable=True).int().contiguous()
@@ -85,22 +99,22 @@ class TileSetRenderer:
         dif, spec, depth = torch.zeros(B, 3, device=dev), torch.zeros(B, 3, device=dev), torch.zeros(B, 1, device=dev)
         tracing_idx = torch.zeros(B, 1, dtype=torch.int32, device=dev)
         z_start = torch.zeros(B, 1, device=dev)
-        pd = torch.empty(B, num_sample, 3, device=dev)
-        ps = torch.empty(B, num_sample, 3, device=dev)
-        pa = torch.empty(B, num_sample, 1, device=dev)
+        pd = torch.empty(shp(num_sample, 3), device=dev)
+        ps = torch.empty(shp(num_sample, 3), device=dev)
+        pa = torch.empty(shp(num_sample, 1), device=dev)
         for _ in range(max_tracing):
             running = ((tracing_idx < max_tracing) & (transp > 1e-5))[:, 0].contiguous()
             if running.sum() == 0:
                 break
-            z = torch.full((B, num_sample), -1.0, device=dev)
-            dd = torch.full((B, num_sample), -1.0, device=dev)
+            z = torch.full(shp(num_sample), -1.0, device=dev)
+            dd = torch.full(shp(num_sample), -1.0, device=dev)
             sample_points(rays_o, rays_d, self.block_corner, self.block_size, self.fake_occupied_grid, self.grid_starts,
-                          self.grid_log2dim, tracing_blocks, inter, tracing_idx, z_start, z, dd)
-            bi = torch.full((B, num_sample, 4), -1, dtype=torch.int16, device=dev)
-            prepare_points(z, running, inter, bi)
+                          self.grid_log2dim, tracing_blocks, inter, tracing_idx, z_start, z, dd, sample_major=sm)
+            bi = torch.full(shp(num_sample, 4), -1, dtype=torch.int16, device=dev)
+            prepare_points(z, running, inter, bi, sample_major=sm)
             pts_inference(rays_o, rays_d, z, dd, bi, self.feature_tables, self.packed, self.resolution, self.occupied_grid,
-                          self.grid_starts, self.grid_log2dim, self.block_corner, self.block_size, pd, ps, pa)
-            accumulate_color(pd, ps, pa, transp, z, dif, spec, depth)
+                          self.grid_starts, self.grid_log2dim, self.block_corner, self.block_size, pd, ps, pa, sample_major=sm)
+            accumulate_color(pd, ps, pa, transp, z, dif, spec, depth, sample_major=sm)
         # blended backgrounds of the exit tile(s)
         bg_b = torch.full((B, 4), -1, dtype=torch.int16, device=dev)
         bg_w = torch.zeros(B, 4, device=dev)
@@ -113,23 +127,24 @@ class TileSetRenderer:
         n_blend = int((bg_w > 0).sum(dim=-1).max().cpu())
         bgd, bgs, bgz = torch.zeros(B, 3, device=dev), torch.zeros(B, 3, device=dev), torch.zeros(B, 1, device=dev)
         if num_bg_sample != num_sample:
-            pd = torch.empty(B, num_bg_sample, 3, device=dev)
-            ps = torch.empty(B, num_bg_sample, 3, device=dev)
-            pa = torch.empty(B, num_bg_sample, 1, device=dev)
+            pd = torch.empty(shp(num_bg_sample, 3), device=dev)
+            ps = torch.empty(shp(num_bg_sample, 3), device=dev)
+            pa = torch.empty(shp(num_bg_sample, 1), device=dev)
         for i in range(n_blend):
-            zb = torch.full((B, num_bg_sample), -1.0, device=dev)
-            inverse_z_sampling(inter, bg_b[:, i].contiguous(), zb, sample_range)
+            zb = torch.full(shp(num_bg_sample), -1.0, device=dev)
+            inverse_z_sampling(inter, bg_b[:, i].contiguous(), zb, sample_range, sample_major=sm)
             pd.zero_(), ps.zero_(), pa.zero_()
             bg_pts_inference_v2(rays_o, rays_d, zb, bg_b, i, self.block_corner, self.block_size, self.resolution,
-                                self.feature_tables, self.packed, pd, ps, pa)
+                                self.feature_tables, self.packed, pd, ps, pa, sample_major=sm)
             t1 = torch.ones(B, 1, device=dev)
             td, ts, tz = torch.zeros(B, 3, device=dev), torch.zeros(B, 3, device=dev), torch.zeros(B, 1, device=dev)
-            accumulate_color(pd, ps, pa, t1, zb, td, ts, tz)
+            accumulate_color(pd, ps, pa, t1, zb, td, ts, tz, sample_major=sm)
             w = torch.nan_to_num(bg_w[:, i:i + 1])  # rays with no exit tile: 0/0 in the reference's normalisation
             bgd += td * w
             bgs += ts * w
             bgz += tz * w
-        return dif + transp * bgd, spec + transp * bgs, depth + transp * bgz, transp
+        out = (dif + transp * bgd, spec + transp * bgs, depth + transp * bgz, transp)
+        return tuple(t[:n_rays] for t in out) if B != n_rays else out
 
     def render(self, H, W, K, c2w, **kw):
         o, d = self.compute_rays(H, W, K, c2w)

@@ -215,6 +215,14 @@ def test_renderer_end_to_end_and_tile_formats(tmp_path):
     K = np.float32([[30, 0, 14], [0, 30, 10], [0, 0, 1]])
     c2w = np.float32([[0, 0, 1, -9], [0, 1, 0, 0.3], [-1, 0, 0, 0.2]])  # looking down +x from x = -9
     dif, spec, depth, transp = rnd.render(H, W, K, c2w, num_sample=64, num_bg_sample=32)
+    # (default: ray-block work arrays [B/32,S,32] between the ops; the reference's [B,S] layout and [S,B] give the same image --
+    # the per-sample arithmetic is the same, the per-ray accumulation runs in sample order instead of as a wave scan)
+    for lay in (0, 1):
+        for a_, b_ in zip((dif, spec, depth, transp), rnd.render(H, W, K, c2w, num_sample=64, num_bg_sample=32, layout=lay)):
+            np.testing.assert_allclose(a_.cpu().numpy(), b_.cpu().numpy(), rtol=1e-5, atol=1e-6)
+    ragged = rnd.render_rays(*(t[:333].contiguous() for t in rnd.compute_rays(H, W, K, c2w)), num_sample=64, num_bg_sample=32)
+    for a_, b_ in zip((dif, spec, depth, transp), ragged):   # 333 rays: padded to a multiple of 32 inside
+        assert torch.equal(a_.reshape(H * W, -1)[:333], b_)
     # ---- the same loop on the oracle
     o, d = (t.cpu().numpy() for t in rnd.compute_rays(H, W, K, c2w))
     o_ref, d_ref = O.compute_ray_forward(np.stack([np.zeros(H * W), np.tile(np.arange(W), H), np.repeat(np.arange(H), W)], 1),
