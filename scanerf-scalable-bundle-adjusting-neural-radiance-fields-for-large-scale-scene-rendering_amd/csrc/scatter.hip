@@ -701,7 +701,8 @@ int scatter_plan_finish(void *workspace, size_t workspace_bytes, int B, int S, i
 {
     BinGeom g;
     BinWorkspace w;
-    if (!fused_geom(B, S, T, g, arith) || !bin_workspace_carve(workspace, workspace_bytes, 16 * g.NB, g.W, w)) return 1;
+    SCANERF_REQUIRE(fused_geom(B, S, T, g, arith) && bin_workspace_carve(workspace, workspace_bytes, 16 * g.NB, g.W, w),
+                    "render_forward_plan: workspace / shape mismatch (B=%d S=%d T=%d, %zu B)", B, S, T, workspace_bytes);
     const int nbins = 16 * g.NB;
     hipStream_t st = (hipStream_t)stream;
     note_plan_format(workspace, g.rec8);
