@@ -87,7 +87,7 @@ __device__ __forceinline__ void make_pairs(const float p[3], const int32_t *res,
 // idx0 ^ idx1 = (x ^ (x+1)) & mask for all four pairs, so "straddles a bucket boundary" is ONE test per (sample, level);
 // the common case is 4 cursor atomics issued back to back and 4 predicated 16-B stores, no branch; straddling lanes and
 // workspace overflow share one rarely taken, wave-uniform branch.
-template <int DBG = 0>  // timing experiments only: 1 = no record stores, 2 = no cursor atomics, 3 = neither
+template <int DBG = 0>  // timing experiments only (-DSCANERF_BWD_EXPERIMENTS): 1 = no record stores, 2 = no cursor atomics, 3 = neither, 4 / 8 = store shapes
 __device__ __forceinline__ void emit_pairs(const Pairs &pr, float gix, float giy, uint32_t *cursor_level, int bucket_log,
                                            uint32_t capacity, Rec *recs, float *grad_level)
 {
@@ -105,8 +105,12 @@ __device__ __forceinline__ void emit_pairs(const Pairs &pr, float gix, float giy
     };
     uint32_t pos[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
-        pos[q] = (DBG == 2 || DBG == 3) ? cursor_level[pr.idx0[q] >> bucket_log] + (threadIdx.x & 15) : atomicAdd(&cursor_level[pr.idx0[q] >> bucket_log], 1u);
+    for (int q = 0; q < 4; ++q) {
+#ifdef SCANERF_BWD_EXPERIMENTS
+        if (DBG == 2 || DBG == 3) { pos[q] = cursor_level[pr.idx0[q] >> bucket_log] + (threadIdx.x & 15); continue; }
+#endif
+        pos[q] = atomicAdd(&cursor_level[pr.idx0[q] >> bucket_log], 1u);
+    }
     const float txr = straddle ? 0.0f : pr.tx;
     bool rare = straddle;
 #pragma unroll
@@ -115,13 +119,16 @@ __device__ __forceinline__ void emit_pairs(const Pairs &pr, float gix, float giy
         const uint32_t hdr = straddle ? l0 * 0x10001u : (l0 | ((l0 ^ pr.xm) << 16));
         const float gx = pr.wyz[q] * gix, gy = pr.wyz[q] * giy;
         const float ax = straddle ? a0 * gx : gx, ay = straddle ? a0 * gy : gy;
+#ifdef SCANERF_BWD_EXPERIMENTS
         if (DBG & 1) {
             if (pos[q] == 0xffffffffu && ax == 1.2345f) reinterpret_cast<float4 *>(recs)[0] = make_float4(__uint_as_float(hdr), txr, ax, ay);
         } else if (DBG == 4) {  // 8-byte stores at 8-byte stride (is the cost per request or per byte?)
             if (pos[q] < capacity) reinterpret_cast<float2 *>(recs)[pos[q]] = make_float2(__uint_as_float(hdr) + txr, ax + ay);
         } else if (DBG == 8) {  // 16-byte stores, every lane group's 16 records contiguous whatever the bins (is it the scatter?)
             reinterpret_cast<float4 *>(recs)[(size_t)blockIdx.x * 65536 + (threadIdx.x & 1023) * 4 + q] = make_float4(__uint_as_float(hdr), txr, ax, ay);
-        } else if (pos[q] < capacity) store_rec(recs, pos[q], hdr, txr, ax, ay);
+        } else
+#endif
+        if (pos[q] < capacity) store_rec(recs, pos[q], hdr, txr, ax, ay);
         rare |= pos[q] >= capacity;
     }
     if (DBG == 0 && __builtin_expect(__any(rare), 0)) {
