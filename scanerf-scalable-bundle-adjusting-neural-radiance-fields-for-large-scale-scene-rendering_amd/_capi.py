@@ -103,12 +103,14 @@ def feat_dtype_code(t):
 _workspaces = {}
 
 
-def workspace(device, nbytes):
-    """Grow-only scratch buffer per (device, stream) (torch's caching allocator owns the memory; the C ABI never
+def workspace(device, nbytes, tag="plan"):
+    """Grow-only scratch buffer per (device, stream, tag) (torch's caching allocator owns the memory; the C ABI never
     allocates).  Keyed by the CURRENT stream: work queued on one stream never shares scratch with another stream's, and a
     buffer that is replaced by a larger one is released to the allocator on the stream all of its users were queued on,
-    so it cannot be handed out again while they are still in flight."""
-    key = (str(device), torch.cuda.current_stream(device).cuda_stream if str(device).startswith("cuda") else 0)
+    so it cannot be handed out again while they are still in flight.  tag: a fused plan lives in its buffer from
+    scatter_plan / render_forward(plan=True) until the accumulate; the stand-alone scatter (one call, "scatter") has its own
+    buffer so that it cannot land between the two."""
+    key = (str(device), torch.cuda.current_stream(device).cuda_stream if str(device).startswith("cuda") else 0, tag)
     buf = _workspaces.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = None

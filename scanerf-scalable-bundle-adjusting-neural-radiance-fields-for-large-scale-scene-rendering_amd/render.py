@@ -286,7 +286,7 @@ def scatter_table_grad(points, dfeat, grad_features, resolutions):
     need = lib().scanerf_embedding_bwd_workspace_bytes(ctypes.c_int(N), ctypes.c_int(L), ctypes.c_int(T))
     if not need:
         raise RuntimeError("scanerf: shape not supported by the binned scatter")
-    ws = _capi.workspace(points.device, need)
+    ws = _capi.workspace(points.device, need, "scatter")
     check(lib().scanerf_embedding_bg_backward_binned(
         dev_ptr(points, _f32, "points"), dev_ptr(dfeat, _f32, "dfeat"), dev_ptr(grad_features, _f32, "grad_features"),
         dev_ptr(resolutions, torch.int32, "resolutions"), ctypes.c_int(N), ctypes.c_int(L), ctypes.c_int(T),
@@ -302,7 +302,7 @@ def scatter_table_grad_adam(points, dfeat, resolutions, params, exp_avg, exp_avg
     need = lib().scanerf_embedding_bwd_workspace_bytes(ctypes.c_int(N), ctypes.c_int(L), ctypes.c_int(T))
     if not need:
         raise RuntimeError("scanerf: shape not supported by the binned scatter")
-    ws = _capi.workspace(points.device, need)
+    ws = _capi.workspace(points.device, need, "scatter")
     check(lib().scanerf_embedding_bg_backward_binned_adam(
         dev_ptr(points, _f32, "points"), dev_ptr(dfeat, _f32, "dfeat"), dev_ptr(resolutions, torch.int32, "resolutions"),
         ctypes.c_int(N), ctypes.c_int(L), ctypes.c_int(T), ctypes.c_int(1), ctypes.c_void_p(ws.data_ptr()), ctypes.c_size_t(ws.numel()),

@@ -1095,3 +1095,69 @@ def test_forward_counts_the_scatter_plan(S, monkeypatch):
         res[tag] = (losses, m.features.detach().clone(), m.exp_avg.clone())
     assert res["forward"][0] == res["separate"][0]
     assert torch.equal(res["forward"][1], res["separate"][1]) and torch.equal(res["forward"][2], res["separate"][2])
+
+
+@pytest.mark.parametrize("log2_T,scale", [(10, 1.0), (12, 1.0), (21, 1.0), (14, 1e22), (14, 1e-22), (14, 0.0)])
+def test_fused_records_table_sizes_and_gradient_ranges(S, log2_T, scale):
+    """The default (t16, 8-byte records, counts in the forward kernel) table-gradient path at the ends of its geometry -- one
+    bucket per level (T = 2^10, 2^12), 256 buckets per level (2^21) -- and of the value range: upstream gradients scaled by
+    1e22 / 1e-22 (the records carry their own exponent, the image's fixed point follows the launch maximum) and all-zero
+    gradients; half of the rays invalid.  Against the exact scatter of the same dfeat."""
+    from scanerf_amd import network, render
+    from scanerf_amd.tile_model import TileModel
+    torch.manual_seed(31)
+    B, S_ = 2500, 48
+    m = TileModel([-4, -4, -4], [8, 8, 8], DEV, log2_T=log2_T, seed=2)
+    with torch.no_grad():
+        m.features.mul_(30.0 if log2_T < 20 else 300.0)
+    o = torch.rand(B, 3, device=DEV) * 8 - 4
+    d = torch.nn.functional.normalize(torch.randn(B, 3, device=DEV), dim=-1)
+    z, dist = m.sample(o, d, S_)
+    valid = torch.rand(B, device=DEV) < 0.5
+    wf = network.weight_feature(3000, DEV)
+    m.packed.pack(m.decoder.blob(), wf)
+    box = (m.min_bbox.tolist(), m.bbox_size.tolist(), render.FORE, False)
+    T = m.features.shape[1]
+    tile_T = torch.empty(B, (S_ + 15) // 16, device=DEV)
+    xs = torch.empty(B * S_, 32, device=DEV)
+    assert render.backward_arith(True, False) == render._capi.ARITH_T16 and render.forward_plan_supported(B, S_, T)
+    out, _, ws = render.render_forward(o, d, z, dist, m.features, m.resolution, m.packed, *box, ray_valid=valid, want_weights=False,
+                                       tile_T=tile_T, xstash=xs, plan=True)
+    gout = torch.randn(B, 16, device=DEV) * scale
+    args = (o, d, z, dist, m.features, m.resolution, m.packed, wf, *box, out, tile_T, gout)
+    dfeat, _ = render.render_backward(*args, ray_valid=valid, xstash=xs)
+    pts = ((o[:, None, :] + z[:, :, None] * d[:, None, :]).reshape(-1, 3) - m._min_dev) / m._size_dev * 4.0 - 2.0
+    # (the stand-alone scatter between the plan and its backward: it has a workspace of its own)
+    g1 = render.scatter_table_grad(pts.contiguous(), dfeat, torch.zeros_like(m.features), m.resolution)
+    g2 = torch.zeros_like(m.features)
+    render.render_backward(*args, ray_valid=valid, xstash=xs, scatter=(ws, g2), want_dfeat=False)
+    render.scatter_accumulate(ws, g2, B, S_)
+    torch.cuda.synchronize()
+    assert torch.isfinite(g2).all()
+    if scale == 0.0:
+        assert float(g1.abs().max()) == 0.0 and float(g2.abs().max()) == 0.0
+        return
+    sc = float(g1.abs().max())
+    assert sc > 0 and np.isfinite(sc)
+    l2 = float(((g2 - g1).double()).norm() / g1.double().norm())
+    print(f"T=2^{log2_T}, gradients x {scale:g}: fused records vs dfeat scatter max err {float((g2 - g1).abs().max()) / sc:.2e} of max, relative L2 {l2:.2e}")
+    np.testing.assert_allclose((g2 / sc).cpu().numpy(), (g1 / sc).cpu().numpy(), rtol=5e-4, atol=5e-4)
+    assert l2 < 3e-4
+
+
+def test_fused_step_with_no_valid_ray(S):
+    """A batch in which no ray meets occupied space (hashgrid/__init__.py:419-434 then renders nothing): the fused step runs on
+    zero records, the loss is finite, table and moments do not move."""
+    from scanerf_amd.tile_model import TileModel, train_step_fused
+    torch.manual_seed(3)
+    B, S_ = 4096, 64
+    m = TileModel([-4, -4, -4], [8, 8, 8], DEV, log2_T=14, seed=1)
+    o = torch.rand(B, 3, device=DEV) * 2 + 20.0                      # far outside the tile, looking away
+    d = torch.nn.functional.normalize(torch.rand(B, 3, device=DEV) + 0.1, dim=-1)
+    tgt = torch.rand(B, 3, device=DEV)
+    before = m.features.detach().clone()
+    opt = torch.optim.Adam(m.decoder.parameters(), lr=1e-3, betas=(0.9, 0.99), eps=1e-15)
+    loss = train_step_fused(m, opt, o, d, tgt, S_, 20000)
+    torch.cuda.synchronize()
+    assert np.isfinite(float(loss))
+    assert torch.equal(m.features.detach(), before) and float(m.exp_avg.abs().max()) == 0.0
