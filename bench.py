@@ -44,8 +44,8 @@ SYN_ITERS = 100                                           # config/default.yaml:
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--path", default=os.environ.get("SCANERF_BENCH_PATH", "auto"), choices=["auto", "fused", "ops"])
     ap.add_argument("--rays", type=int, default=65536)
     ap.add_argument("--samples", type=int, default=128)
