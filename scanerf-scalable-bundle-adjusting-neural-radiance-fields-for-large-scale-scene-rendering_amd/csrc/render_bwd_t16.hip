@@ -308,10 +308,25 @@ __global__ void __launch_bounds__(kThreads, 2) k_render_bwd_t16(BwdArgs a)
                 const int4 r = *reinterpret_cast<const int4 *>(lres + 4 * level);
                 const int32_t rr[3] = { r.x, r.y, r.z };
                 Pairs pr;
+#ifdef SCANERF_BWD_EXPERIMENTS
+                if ((a.f.dbg & 15) == 6) {  // no index arithmetic: made-up pairs
+#pragma unroll
+                    for (int q2 = 0; q2 < 4; ++q2) {
+                        pr.idx0[q2] = (uint32_t)(ln * 977 + q2 * 131 + level * 7919 + s * 31) & mask;
+                        pr.wyz[q2] = 0.25f;
+                    }
+                    pr.xm = 1u;
+                    pr.tx = 0.5f;
+                } else
+#endif
                 make_pairs(pe, rr, mask, pr);
                 gmax = fmaxf(gmax, fmaxf(fabsf(gx), fabsf(gy)));
                 uint32_t *cl = cursor + level * a.bins.NB;
                 float *gl = a.grad_features + (size_t)level * a.f.T * 2;
+#ifdef SCANERF_BWD_EXPERIMENTS
+                if (REC8 && (a.f.dbg & 15) == 5) emit_pairs8<5>(pr, gx, gy, cl, a.bins.bucket_log, rec_capacity(a.bins.capacity, true), a.recs, gl);
+                else
+#endif
                 if (REC8) emit_pairs8(pr, gx, gy, cl, a.bins.bucket_log, rec_capacity(a.bins.capacity, true), a.recs, gl);
                 else if ((a.f.dbg & 15) == 0) emit_pairs(pr, gx, gy, cl, a.bins.bucket_log, a.bins.capacity, a.recs, gl);
 #ifdef SCANERF_BWD_EXPERIMENTS

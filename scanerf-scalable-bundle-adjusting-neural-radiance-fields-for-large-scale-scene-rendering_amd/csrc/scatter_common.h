@@ -256,6 +256,7 @@ __device__ __forceinline__ void store_rec8(Rec *recs, uint32_t pos, uint2 r) { r
 
 // emit_pairs for the Rec8 stream: same ranges, same cursors, same rare paths (count_pairs is its histogram as well);
 // capacity counts 8-byte records here.
+template <int DBG = 0>  // timing experiments only (-DSCANERF_BWD_EXPERIMENTS): 5 = records not packed (raw bits)
 __device__ __forceinline__ void emit_pairs8(const Pairs &pr, float gix, float giy, uint32_t *cursor_level, int bucket_log,
                                             uint32_t capacity, Rec *recs, float *grad_level)
 {
@@ -281,6 +282,11 @@ __device__ __forceinline__ void emit_pairs8(const Pairs &pr, float gix, float gi
     for (int q = 0; q < 4; ++q) {
         const float gx = pr.wyz[q] * gix, gy = pr.wyz[q] * giy;
         const float ax = straddle ? a0 * gx : gx, ay = straddle ? a0 * gy : gy;
+#ifdef SCANERF_BWD_EXPERIMENTS
+        if (DBG == 5) {
+            if (pos[q] < capacity) store_rec8(recs, pos[q], make_uint2((pr.idx0[q] & lmask) | (k << 13) | (t << 17), __float_as_uint(ax) ^ __float_as_uint(ay)));
+        } else
+#endif
         if (pos[q] < capacity) store_rec8(recs, pos[q], pack_rec8(pr.idx0[q] & lmask, k, t, ax, ay));
         rare |= pos[q] >= capacity;
     }
