@@ -1,4 +1,5 @@
-"""Fused table-gradient path (plan -> backward emits records -> accumulate) against the exact scatter of the same dfeat, for\nupstream gradients scaled by 1, 1e10, 1e22, 1e-22 and both backward arithmetics (t16: 8-byte records; h3: 16-byte)."""
+"""Fused table-gradient path (plan -> backward emits records -> accumulate) against the exact scatter of the same dfeat, for
+upstream gradients scaled by 1, 1e10, 1e22, 1e-22 and both backward arithmetics (t16: 8-byte records; h3: 16-byte)."""
 import os, sys, torch, numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import scanerf_amd
