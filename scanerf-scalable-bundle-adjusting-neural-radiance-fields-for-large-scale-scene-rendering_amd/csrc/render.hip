@@ -292,7 +292,8 @@ constexpr int kH3LdsBytes = H3_BYTES + 64 * 4;  // + resolutions [16][4] i32
 
 constexpr int kPlanHistWords = 16 * 256;  // scatter bins of the fused count: NB <= 256 buckets per level
 
-template <int DT, bool COUNT>  // COUNT: also count the backward's scatter records (RenderArgs::plan_counts)
+// COUNT: also count the backward's scatter records (RenderArgs::plan_counts); JST: also write RenderArgs::jstash
+template <int DT, bool COUNT, bool JST = false>
 __global__ void __launch_bounds__(kRenderThreads, 2) k_render_fwd_h3(RenderArgs a)
 {
     __shared__ __attribute__((aligned(16))) char lds[kH3LdsBytes];
@@ -363,7 +364,9 @@ __global__ void __launch_bounds__(kRenderThreads, 2) k_render_fwd_h3(RenderArgs 
 #pragma unroll
                 for (int g = 0; g < 16; ++g) x[g] = p[g % 3] * (0.01f * g);
             } else {
-                encode8<DT, FWD_GATHER_BATCH, true, COUNT>(a, lds_res, h, p, x, hist, live);
+                // (dead lanes of the last tile write their own, unused, slots: no branch around the stores)
+                float *jrow = JST ? a.jstash + ((size_t)ray * ntiles + tile) * (8 * 6 * 64) + 2 * lane : nullptr;
+                encode8<DT, JST ? 1 : FWD_GATHER_BATCH, true, COUNT, JST>(a, lds_res, h, p, x, hist, live, jrow);
             }
             if (a.xstash && live) {  // (plain stores: streaming / nontemporal ones measured 3.16 -> 3.41 ms)
                 float4 *xs = reinterpret_cast<float4 *>(a.xstash + ((size_t)ray * S + s) * 32 + 16 * h);
@@ -451,8 +454,8 @@ SCANERF_API int scanerf_pack_decoder(const float *mlp_blob, const float *weight_
 static int render_forward(const float *rays_o, const float *rays_d, const float *z_vals, const float *dists,
                           const void *features, int feat_dtype, const int32_t *resolutions, const float *packed,
                           const scanerf_render_cfg *cfg, const uint8_t *ray_valid, float *out_ray, float *weights,
-                          float *tile_T, float *xstash, int B, int S, int T, void *scatter_ws, size_t scatter_ws_bytes,
-                          scanerf_stream_t stream)
+                          float *tile_T, float *xstash, float *jstash, int B, int S, int T, void *scatter_ws,
+                          size_t scatter_ws_bytes, scanerf_stream_t stream)
 {
     SCANERF_REQUIRE(B >= 0 && S >= 1, "render_forward: B=%d S=%d", B, S);
     SCANERF_REQUIRE(T >= 2 && (T & (T - 1)) == 0, "render_forward: T=%d must be a power of two", T);
@@ -466,7 +469,7 @@ static int render_forward(const float *rays_o, const float *rays_d, const float 
     RenderArgs a;
     a.rays_o = rays_o; a.rays_d = rays_d; a.z_vals = z_vals; a.dists = dists;
     a.features = features; a.resolutions = resolutions; a.packed = packed; a.ray_valid = ray_valid;
-    a.out_ray = out_ray; a.weights = weights; a.tile_T = tile_T; a.xstash = xstash;
+    a.out_ray = out_ray; a.weights = weights; a.tile_T = tile_T; a.xstash = xstash; a.jstash = jstash;
     a.B = B; a.S = S; a.T = T;
     a.contract_mode = cfg->contract_mode; a.infinity = cfg->infinity;
     for (int k = 0; k < 3; ++k) {
@@ -490,7 +493,11 @@ static int render_forward(const float *rays_o, const float *rays_d, const float 
         if (int e = scatter_plan_attach(scatter_ws, scatter_ws_bytes, B, S, T, cfg->arith, blocks, a)) return e;
     }
     if (cfg->arith != SCANERF_ARITH_F32) {  // (H3 and T16 differ in the backward kernel only)
-        if (a.plan_counts) {
+        if (a.jstash) {
+            SCANERF_REQUIRE(feat_dtype == SCANERF_F32, "render_forward: the position-Jacobian stash is written from fp32 tables only");
+            if (a.plan_counts) hipLaunchKernelGGL((k_render_fwd_h3<SCANERF_F32, true, true>), grid, block, 0, st, a);
+            else hipLaunchKernelGGL((k_render_fwd_h3<SCANERF_F32, false, true>), grid, block, 0, st, a);
+        } else if (a.plan_counts) {
             if (feat_dtype == SCANERF_F32) hipLaunchKernelGGL((k_render_fwd_h3<SCANERF_F32, true>), grid, block, 0, st, a);
             else if (feat_dtype == SCANERF_F16) hipLaunchKernelGGL((k_render_fwd_h3<SCANERF_F16, true>), grid, block, 0, st, a);
             else hipLaunchKernelGGL((k_render_fwd_h3<SCANERF_BF16, true>), grid, block, 0, st, a);
@@ -512,23 +519,24 @@ SCANERF_API int scanerf_render_forward_packed(const float *rays_o, const float *
                                               int T, scanerf_stream_t stream)
 {
     return render_forward(rays_o, rays_d, z_vals, dists, features, feat_dtype, resolutions, packed, cfg, ray_valid, out_ray,
-                          weights, tile_T, xstash, B, S, T, nullptr, 0, stream);
+                          weights, tile_T, xstash, nullptr, B, S, T, nullptr, 0, stream);
 }
 
 // The same launch, also doing scanerf_render_scatter_plan's work for the t16 backward of these rays (counts in the forward
 // kernel, where the hash indices already are; then the scan): call INSTEAD of scanerf_render_scatter_plan, with that
 // function's workspace.  Only where scanerf_render_forward_plan_supported(B, S, T) (equal forward and backward grids).
+// jstash (may be NULL; fp32 tables): [B][ceil(S/32)][8][3][64][2] f32, the encoder's position Jacobians for scanerf_render_backward's g_raypos.
 SCANERF_API int scanerf_render_forward_packed_plan(const float *rays_o, const float *rays_d, const float *z_vals,
                                                    const float *dists, const void *features, int feat_dtype,
                                                    const int32_t *resolutions, const float *packed,
                                                    const scanerf_render_cfg *cfg, const uint8_t *ray_valid,
-                                                   float *out_ray, float *weights, float *tile_T, float *xstash, int B,
-                                                   int S, int T, void *scatter_ws, size_t scatter_ws_bytes,
-                                                   scanerf_stream_t stream)
+                                                   float *out_ray, float *weights, float *tile_T, float *xstash,
+                                                   float *jstash, int B, int S, int T, void *scatter_ws,
+                                                   size_t scatter_ws_bytes, scanerf_stream_t stream)
 {
-    SCANERF_REQUIRE(scatter_ws, "render_forward_plan: scatter workspace is null");
+    // (scatter_ws may be NULL: the plain forward with the jstash output)
     return render_forward(rays_o, rays_d, z_vals, dists, features, feat_dtype, resolutions, packed, cfg, ray_valid, out_ray,
-                          weights, tile_T, xstash, B, S, T, scatter_ws, scatter_ws_bytes, stream);
+                          weights, tile_T, xstash, jstash, B, S, T, scatter_ws, scatter_ws_bytes, stream);
 }
 
 SCANERF_API int scanerf_render_forward_plan_supported(int B, int S, int T)

@@ -15,6 +15,8 @@ struct BwdArgs {
     const float *xstash;       // optional [B*S][2][16]: the forward's encoder outputs (skips the re-gather)
     float *g_dnorm;            // optional [B, ntiles]: dL/d|d| partials (through delta = dist*|d|)
     float *g_rowsum;           // optional [B, 2, 64]: sum_s dL/d(dir layer-0 pre-activation), for dL/dSH
+    float *g_raypos;           // optional [B, 6] (t16 kernel, needs f.jstash): dL/d(rays_o), dL/d(rays_d) through the sample
+                               // positions (feature gradients x the forward's position Jacobians x the contraction's)
     // fused table-gradient producer (scatter.hip): when recs != nullptr the kernel appends the scatter
     // records itself (the stores hide under the MFMA work) and dfeat becomes optional
     BinGeom bins;

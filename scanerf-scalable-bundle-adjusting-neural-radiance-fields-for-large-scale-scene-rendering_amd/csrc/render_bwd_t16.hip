@@ -186,7 +186,9 @@ __device__ __forceinline__ void wgrad(v4f *acc, float &rowsum, const char *stage
     }
 }
 
-template <int DT, bool REC8>  // REC8: the scatter records are 8 bytes (scatter_common.h: Rec8), else 16 (Rec)
+// REC8: the scatter records are 8 bytes (scatter_common.h: Rec8), else 16 (Rec).  POSE: also the two per-ray sums the pose
+// refinement needs (render_bwd_common.h g_dnorm / g_rowsum; csrc/render_bwd_h3.hip is the other kernel that produces them)
+template <int DT, bool REC8, bool POSE>
 __global__ void __launch_bounds__(kThreads, 2) k_render_bwd_t16(BwdArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -285,6 +287,14 @@ __global__ void __launch_bounds__(kThreads, 2) k_render_bwd_t16(BwdArgs a)
             }
         }
         float Rcarry = 0.0f;              // sum of a_j w_j over all later tiles of the ray
+        // POSE: sum over the ray's samples of dL/d(delta) * dist (this lane's samples; -> dL/d|d|) and of the Directional layer-0
+        // pre-activation gradient (under the scale 2^K; -> dL/dSH), reduce-scattered over the 16 lanes of a group every tile so that
+        // ONE register carries it (16 accumulators per lane cost 80 spilled registers)
+        float pose_dn = 0.0f, pose_rs = 0.0f;   // pose_rs: lane (c, q) owns unit 16 (c >> 2) + 4 q + (c & 3)
+        // ... and, with the forward's position Jacobians (f.jstash), the gradient through the sample positions: this lane's
+        // levels of the tile being emitted, chained to the ray through the contraction
+        float pose_go[3] = { 0, 0, 0 }, pose_gd[3] = { 0, 0, 0 };
+        float ppz = 0.0f;                 // the emitted tile's sample depth
 
         // Feature gradients of one tile: dfeat rows and / or the scatter records (scatter.hip) into the ranges the plan
         // reserved, ONE LEVEL PER CALL.  e0 / e1 = dX blocks 0 / 1: register g of block e = x-stash position 8q + 4e + g =
@@ -303,6 +313,54 @@ __global__ void __launch_bounds__(kThreads, 2) k_render_bwd_t16(BwdArgs a)
             const float gx = jj == 0 ? e0[0] : (jj == 1 ? e0[2] : (jj == 2 ? e1[0] : e1[2]));
             const float gy = jj == 0 ? e0[1] : (jj == 1 ? e0[3] : (jj == 2 ? e1[1] : e1[3]));
             if (a.dfeat) reinterpret_cast<float2 *>(a.dfeat)[(size_t)level * a.f.B * S + (size_t)ray * S + s] = make_float2(gx, gy);
+            if (POSE && a.g_raypos && jj == 3) {
+                // position path, once per tile: this lane's four levels' Jacobians (12 loads in flight together), contracted with
+                // its dX.  The forward's lane 32 h + (s & 31) wrote its 8 levels 4 (j >> 1) + 2 h + (j & 1) into the 32-sample
+                // tile's [8][3][64] float2 block.
+                float2 jv[4][3];
+#pragma unroll
+                for (int lv = 0; lv < 4; ++lv) {
+                    const int j8l = 4 * (q & 1) + lv, lvl = 4 * (j8l >> 1) + 2 * (q >> 1) + (j8l & 1);
+                    const int hh = (lvl >> 1) & 1, j = 2 * (lvl >> 2) + (lvl & 1);
+                    const float2 *jr = reinterpret_cast<const float2 *>(a.f.jstash) +
+                                       (((size_t)ray * ((S + 31) >> 5) + (s >> 5)) * 8 + j) * (3 * 64) + 32 * hh + (s & 31);
+                    jv[lv][0] = jr[0]; jv[lv][1] = jr[64]; jv[lv][2] = jr[128];
+                }
+                float pose_gp[3] = { 0, 0, 0 };
+#pragma unroll
+                for (int lv = 0; lv < 4; ++lv) {
+                    const float fx = lv == 0 ? e0[0] : (lv == 1 ? e0[2] : (lv == 2 ? e1[0] : e1[2]));
+                    const float fy = lv == 0 ? e0[1] : (lv == 1 ? e0[3] : (lv == 2 ? e1[1] : e1[3]));
+                    pose_gp[0] += fx * jv[lv][0].x + fy * jv[lv][1].y;
+                    pose_gp[1] += fx * jv[lv][0].y + fy * jv[lv][2].x;
+                    pose_gp[2] += fx * jv[lv][1].x + fy * jv[lv][2].y;
+                }
+                if (jj == 3) {  // the lane's four levels are in: through the contraction to the ray
+                    float gxk[3] = { pose_gp[0], pose_gp[1], pose_gp[2] };
+                    if (a.f.contract_mode == 1) {
+                        float xk[3];
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) xk[k] = (o[k] + ppz * d[k] - a.f.min_bbox[k]) * a.f.inv_size4[k] - 2.0f;
+                        const float ax = fabsf(xk[0]), ay = fabsf(xk[1]), az = fabsf(xk[2]);
+                        const float linf = fmaxf(ax, fmaxf(ay, az));
+                        const int mk = (ax >= ay && ax >= az) ? 0 : (ay >= az ? 1 : 2);   // torch.max: the first maximum
+                        const float il = 1.0f / linf, r = (2.0f - il) * il, dr = (-2.0f + 2.0f * il) * il * il;
+                        const float dot = gxk[0] * xk[0] + gxk[1] * xk[1] + gxk[2] * xk[2];
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) gxk[k] *= r;
+                        const float extra = dot * dr * (xk[mk] < 0.0f ? -1.0f : 1.0f);
+                        gxk[0] += mk == 0 ? extra : 0.0f;
+                        gxk[1] += mk == 1 ? extra : 0.0f;
+                        gxk[2] += mk == 2 ? extra : 0.0f;
+                    }
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        const float gk = gxk[k] * a.f.inv_size4[k];
+                        pose_go[k] += gk;
+                        pose_gd[k] += ppz * gk;
+                    }
+                }
+            }
             if (a.recs) {
                 const uint32_t mask = (uint32_t)a.f.T - 1u;
                 const int4 r = *reinterpret_cast<const int4 *>(lres + 4 * level);
@@ -505,6 +563,8 @@ __global__ void __launch_bounds__(kThreads, 2) k_render_bwd_t16(BwdArgs a)
             float dalpha = Ti * ai - (suffix + ((s < S - 1) ? gTl * Tl : 0.0f)) / fi;
             if (!live) dalpha = 0.0f;
             const float dsigma = dalpha * delta * ex;
+            if (POSE && active && q == 0)  // (the infinity sample's delta is a constant)
+                pose_dn += dalpha * sigma * ex * ((a.f.infinity && s == S - 1) ? 0.0f : dist_i);
             float gh[7], gs3[3];  // gradients w.r.t. the head / rgb pre-activations
             gh[0] = dsigma * dsig_dpre;
 #pragma unroll
@@ -550,6 +610,7 @@ __global__ void __launch_bounds__(kThreads, 2) k_render_bwd_t16(BwdArgs a)
                     for (int i = 0; i < 2; ++i) { gW_D1[i] *= r; gW_L1[i] *= r; }
                     gW_D0[0] *= r; gW_D0[1] *= r; gW_L0[0] *= r; gW_nar[0] *= r;
                     gB_D1 *= r; gB_L1 *= r; gB_D0 *= r; gB_L0 *= r; gB_nar *= r;
+                    if (POSE) pose_rs *= r;
                 }
 #pragma unroll
                 for (int k = 0; k < 7; ++k) gh[k] *= sc;
@@ -611,6 +672,21 @@ __global__ void __launch_bounds__(kThreads, 2) k_render_bwd_t16(BwdArgs a)
                 t16_chain<4, 2>(dc, lds, T16T_D1, L.lo16, dyB);
 #pragma unroll
                 for (int b = 0; b < 4; ++b) dc[b] = mul_dg(dc[b], dgv0[b]);   // dv0
+                if (POSE) {  // 16 values x 16 samples -> lane c keeps the tile's sum of value c (= block c >> 2, register c & 3)
+                    float v[16];
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) v[i] = dc[i >> 2][i & 3];
+#pragma unroll
+                    for (int off = 8, half = 8; off > 0; off >>= 1, half >>= 1) {
+                        const bool up = (c & off) != 0;
+#pragma unroll
+                        for (int j = 0; j < half; ++j) {
+                            const float mine = up ? v[j + half] : v[j], send = up ? v[j] : v[j + half];
+                            v[j] = mine + __shfl_xor(send, off, 16);
+                        }
+                    }
+                    pose_rs += v[0];
+                }
                 dyB[0] = t16_hi(dc[0], dc[1]);
                 dyB[1] = t16_hi(dc[2], dc[3]);
             }
@@ -686,10 +762,41 @@ __global__ void __launch_bounds__(kThreads, 2) k_render_bwd_t16(BwdArgs a)
             pdx0 = dx[0];
             pdx1 = dx[1];
             ptile = tile;
+            ppz = z;
             if (a.recs) contract_point(a.f, o, d, z, ppe);
         }
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) emit_level(ptile, jj, pdx0, pdx1, ppe);   // the ray's first tile
+        if (POSE && active) {  // the ray's pose-gradient sums
+            const int ln = fresh(lane), c = ln & 15, q = ln >> 4;
+#pragma unroll
+            for (int off = 8; off > 0; off >>= 1) pose_dn += __shfl_xor(pose_dn, off, 16);
+            float *rsum = a.g_rowsum + (size_t)ray * 2 * 64;   // [2][64]: the second partial row is the h3 kernel's other half-wave
+            const int unit = 16 * (c >> 2) + 4 * q + (c & 3);
+            rsum[unit] = pose_rs * isc;
+            rsum[64 + unit] = 0.0f;
+            if (a.g_raypos) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k)
+#pragma unroll
+                    for (int off = 32; off > 0; off >>= 1) {
+                        pose_go[k] += __shfl_xor(pose_go[k], off, 64);
+                        pose_gd[k] += __shfl_xor(pose_gd[k], off, 64);
+                    }
+                if (ln == 0) {
+                    float2 *gr = reinterpret_cast<float2 *>(a.g_raypos + (size_t)ray * 6);
+                    gr[0] = make_float2(pose_go[0], pose_go[1]);
+                    gr[1] = make_float2(pose_go[2], pose_gd[0]);
+                    gr[2] = make_float2(pose_gd[1], pose_gd[2]);
+                }
+            }
+            if (ln == 0) {
+                const int ncol = (S + 31) >> 5;                 // [B][ceil(S/32)] partials: all of it in column 0
+                a.g_dnorm[(size_t)ray * ncol] = pose_dn;
+                for (int t = 1; t < ncol; ++t) a.g_dnorm[(size_t)ray * ncol + t] = 0.0f;
+            }
+            SCANERF_STORE_GUARD();
+        }
     }
 
     if (a.recs) {  // launch-wide max |dL/dfeature| for the fixed-point scale of the accumulate pass
@@ -770,18 +877,24 @@ int launch_render_bwd_t16(const BwdArgs &a, int feat_dtype, int blocks, size_t l
 {
     const size_t lds_bytes = (size_t)kLdsCursor + lds_extra;
     SCANERF_REQUIRE(lds_bytes <= 160 * 1024, "render_backward(t16): %zu B of LDS needed (table too large for the fused scatter)", lds_bytes);
-    SCANERF_REQUIRE(a.xstash && !a.g_dnorm && !a.g_rowsum, "render_backward(t16): needs the x-stash and has no pose-gradient outputs");
-#define SCANERF_LAUNCH_BWD(DT, R8)                                                                                 \
+    SCANERF_REQUIRE(a.xstash, "render_backward(t16): needs the x-stash");
+    SCANERF_REQUIRE((a.g_dnorm != nullptr) == (a.g_rowsum != nullptr), "render_backward(t16): g_dnorm and g_rowsum come together");
+    SCANERF_REQUIRE(!a.g_raypos || (a.g_dnorm && a.f.jstash), "render_backward(t16): g_raypos needs g_dnorm / g_rowsum and the forward's jstash");
+#define SCANERF_LAUNCH_BWD(DT, R8, PO)                                                                             \
     {                                                                                                              \
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_render_bwd_t16<DT, R8>),              \
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_render_bwd_t16<DT, R8, PO>),          \
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);            \
         SCANERF_REQUIRE(e == hipSuccess, "render_backward(t16): cannot reserve %zu B of LDS: %s", lds_bytes,        \
                         hipGetErrorString(e));                                                                     \
-        hipLaunchKernelGGL((k_render_bwd_t16<DT, R8>), dim3(blocks), dim3(kThreads), lds_bytes, st, a);             \
+        hipLaunchKernelGGL((k_render_bwd_t16<DT, R8, PO>), dim3(blocks), dim3(kThreads), lds_bytes, st, a);         \
     }
     (void)feat_dtype;  // the table is only read through the x-stash here
-    if (a.recs && a.bins.rec8) SCANERF_LAUNCH_BWD(SCANERF_F32, true)
-    else SCANERF_LAUNCH_BWD(SCANERF_F32, false)
+    const bool r8 = a.recs && a.bins.rec8;
+    if (a.g_dnorm) {
+        if (r8) SCANERF_LAUNCH_BWD(SCANERF_F32, true, true)
+        else SCANERF_LAUNCH_BWD(SCANERF_F32, false, true)
+    } else if (r8) SCANERF_LAUNCH_BWD(SCANERF_F32, true, false)
+    else SCANERF_LAUNCH_BWD(SCANERF_F32, false, false)
 #undef SCANERF_LAUNCH_BWD
     return 0;
 }

@@ -122,6 +122,11 @@ struct RenderArgs {
     float *out_ray, *weights;
     float *tile_T;            // optional [B, ceil(S/16)]: transmittance entering each 16-sample tile (for backward)
     float *xstash;            // optional [B*S][2][16]: encoder outputs per (sample, half-wave) (for backward)
+    float *jstash;            // optional [B][ceil(S/32)][8][3][64][2]: d(encoder outputs)/d(contracted position) per (ray, 32-sample
+                              // tile, level j = 0..7 of the half-wave, component pair, forward lane = 32 h + (s & 31)); the six
+                              // components = (feature 0: d/dx, d/dy, d/dz; feature 1: ...).  Lane-fastest so that every store of
+                              // the wave is 512 contiguous bytes.  Lets the t16 backward form the pose gradient without gathering
+                              // the table again
     int B, S, T;
     int contract_mode, infinity;
     float min_bbox[3], inv_size4[3];  // 4/bbox_size
@@ -142,9 +147,10 @@ struct RenderArgs {
 // PAIRED: fetch x-neighbour pairs with one load where the hash puts them side by side (gather_cell; half-precision tables)
 // hist (may be null): this workgroup's [16][NB] record counters in LDS -- one per (y,z) corner pair, two when the
 // x-neighbours fall into different buckets, exactly scatter_common.h count_pairs; count = this lane's sample is a real one
-template <int DT, int GATHER_BATCH = 2, bool PAIRED = false, bool COUNT = false>
+// jrow (may be null): this lane's float2 column of the tile's [8][3][64][2] block of RenderArgs::jstash
+template <int DT, int GATHER_BATCH = 2, bool PAIRED = false, bool COUNT = false, bool JST = false>
 __device__ __forceinline__ void encode8(const RenderArgs &a, const int *lds_res, int h, const float p[3], v16f &x,
-                                        uint32_t *hist = nullptr, bool count = false)
+                                        uint32_t *hist = nullptr, bool count = false, float *jrow = nullptr)
 {
     const uint32_t mask = (uint32_t)a.T - 1u;
 #pragma unroll
@@ -152,10 +158,10 @@ __device__ __forceinline__ void encode8(const RenderArgs &a, const int *lds_res,
         const int level = 4 * (j >> 1) + 2 * h + (j & 1);
         const int4 res = reinterpret_cast<const int4 *>(lds_res)[level];
         int b[3];
-        float t[3], sc;
-        locate_bg(p[0], res.x, b[0], t[0], sc);
-        locate_bg(p[1], res.y, b[1], t[1], sc);
-        locate_bg(p[2], res.z, b[2], t[2], sc);
+        float t[3], sc[3];
+        locate_bg(p[0], res.x, b[0], t[0], sc[0]);
+        locate_bg(p[1], res.y, b[1], t[1], sc[1]);
+        locate_bg(p[2], res.z, b[2], t[2], sc[2]);
         uint32_t idx[8];
         float w[8];
         corner_indices(idx, b[0], b[1], b[2], mask);
@@ -186,6 +192,36 @@ __device__ __forceinline__ void encode8(const RenderArgs &a, const int *lds_res,
         }
         x[2 * j] = ax;
         x[2 * j + 1] = ay;
+        if constexpr (JST) {
+            // d(out)/d(p) = scale * sum_c f_c * dw_c/dt (csrc/hashgrid.hip k_embed_bwd's point gradient, before the contraction
+            // with the upstream gradient): corner c = (dx << 2) | (dy << 1) | dz.  Formed as differences along each axis of the
+            // bilinear interpolations on the two faces (6 face values per feature instead of 12 weight products held at once).
+            const float tx = t[0], ty = t[1], tz = t[2];
+            float2 *jr = reinterpret_cast<float2 *>(jrow) + 3 * j * 64;   // [3 component pairs][64 lanes] float2 per level
+            float jv[6];
+#pragma unroll
+            for (int ft = 0; ft < 2; ++ft) {
+                float v[8];
+#pragma unroll
+                for (int c = 0; c < 8; ++c) v[c] = ft ? f[c].y : f[c].x;
+                // along z first: e[dx][dy] = lerp_z, dz[dx][dy] = difference
+                const float e00 = fmaf(tz, v[1] - v[0], v[0]), e01 = fmaf(tz, v[3] - v[2], v[2]), e10 = fmaf(tz, v[5] - v[4], v[4]),
+                            e11 = fmaf(tz, v[7] - v[6], v[6]);
+                const float d00 = v[1] - v[0], d01 = v[3] - v[2], d10 = v[5] - v[4], d11 = v[7] - v[6];
+                // d/dz = bilinear(x, y) of the z-differences
+                const float dz0 = fmaf(ty, d01 - d00, d00), dz1 = fmaf(ty, d11 - d10, d10);
+                const float gz = fmaf(tx, dz1 - dz0, dz0);
+                // d/dy = lerp_x of (e?1 - e?0); d/dx = lerp_y of (e1? - e0?)
+                const float gy = fmaf(tx, (e11 - e10) - (e01 - e00), e01 - e00);
+                const float gx = fmaf(ty, (e11 - e01) - (e10 - e00), e10 - e00);
+                jv[3 * ft + 0] = sc[0] * gx;
+                jv[3 * ft + 1] = sc[1] * gy;
+                jv[3 * ft + 2] = sc[2] * gz;
+            }
+            jr[0] = make_float2(jv[0], jv[1]);
+            jr[64] = make_float2(jv[2], jv[3]);
+            jr[128] = make_float2(jv[4], jv[5]);
+        }
         if ((j + 1) % GATHER_BATCH == 0) __builtin_amdgcn_sched_barrier(0);  // bound the gathers in flight per lane
     }
 }

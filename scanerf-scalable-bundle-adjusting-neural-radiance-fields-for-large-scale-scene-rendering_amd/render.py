@@ -28,8 +28,9 @@ def set_arith(name):
 
 
 def backward_arith(have_xstash=True, pose_grads=False):
-    """The arithmetic code one training step's scatter_plan / render_backward / scatter_accumulate must agree on."""
-    if ARITH == _capi.ARITH_T16 and (not have_xstash or pose_grads):
+    """The arithmetic code one training step's scatter_plan / render_backward / scatter_accumulate must agree on
+    (t16 needs the forward's x-stash; it produces the pose-gradient sums as well)."""
+    if ARITH == _capi.ARITH_T16 and not have_xstash:
         return _capi.ARITH_H3
     return ARITH
 
@@ -68,6 +69,12 @@ def _cfg(min_bbox, bbox_size, contract_mode, infinity, arith=None):
     return c
 
 
+def jstash_shape(B, S):
+    """Shape of render_forward's jstash output (position Jacobians per ray, 32-sample tile, level of the half-wave, component,
+    forward lane)."""
+    return (B, (S + 31) // 32, 8, 3, 64, 2)
+
+
 def forward_plan_supported(B, S, T):
     """render_forward(plan=True) can do scatter_plan's work for the t16 backward of the same rays (equal kernel grids)."""
     return bool(lib().scanerf_render_forward_plan_supported(ctypes.c_int(B), ctypes.c_int(S), ctypes.c_int(T)))
@@ -75,11 +82,13 @@ def forward_plan_supported(B, S, T):
 
 def render_forward(rays_o, rays_d, z_vals, dists, features, resolutions, packed, min_bbox, bbox_size, contract_mode,
                    infinity, ray_valid=None, want_weights=True, out_ray=None, weights=None, tile_T=None, xstash=None,
-                   plan=False, plan_workspace=None):
+                   plan=False, plan_workspace=None, jstash=None):
     """-> out_ray [B,16] (see column constants), weights [B,S] or None.
     min_bbox / bbox_size: host sequences of 3 floats (the HashGrid 2x box).
     plan=True (only where forward_plan_supported): the launch also reserves the t16 backward's scatter-record ranges for these
-    rays -- call it INSTEAD of scatter_plan; returns (out_ray, weights, workspace)."""
+    rays -- call it INSTEAD of scatter_plan; returns (out_ray, weights, workspace).
+    jstash (fp32 tables): jstash_shape(B, S) f32 that receives the encoder's position Jacobians, for
+    render_backward(ray_pos_grad=...) (pose refinement without a second pass over the table)."""
     B, S = z_vals.shape
     if features.shape[0] != 16 or features.shape[2] != 2:
         raise RuntimeError("scanerf: fused path needs a [16,T,2] table (the reference hard-codes 16 levels)")
@@ -95,15 +104,20 @@ def render_forward(rays_o, rays_d, z_vals, dists, features, resolutions, packed,
     tail = (dev_ptr(ray_valid, (torch.bool, torch.uint8), "ray_valid", allow_none=True), dev_ptr(out_ray, _f32, "out_ray"),
             dev_ptr(weights, _f32, "weights", allow_none=True), dev_ptr(tile_T, _f32, "tile_T", allow_none=True),
             dev_ptr(xstash, _f32, "xstash", allow_none=True), ctypes.c_int(B), ctypes.c_int(S), ctypes.c_int(T))
-    if plan:
-        need = lib().scanerf_render_scatter_workspace_bytes(ctypes.c_int(B), ctypes.c_int(S), ctypes.c_int(T))
-        if not need or not forward_plan_supported(B, S, T):
-            raise RuntimeError(f"scanerf: render_forward(plan=True) does not support B={B} S={S} T={T}")
-        ws = _capi.workspace(z_vals.device, need) if plan_workspace is None else plan_workspace
+    if plan or jstash is not None:
+        ws = None
+        if plan:
+            need = lib().scanerf_render_scatter_workspace_bytes(ctypes.c_int(B), ctypes.c_int(S), ctypes.c_int(T))
+            if not need or not forward_plan_supported(B, S, T):
+                raise RuntimeError(f"scanerf: render_forward(plan=True) does not support B={B} S={S} T={T}")
+            ws = _capi.workspace(z_vals.device, need) if plan_workspace is None else plan_workspace
         cfg = _cfg(min_bbox, bbox_size, contract_mode, infinity, _capi.ARITH_T16)
-        check(lib().scanerf_render_forward_packed_plan(*args, ctypes.byref(cfg), *tail, ctypes.c_void_p(ws.data_ptr()),
-                                                       ctypes.c_size_t(ws.numel()), stream()), "render_forward(plan)")
-        return out_ray, weights, ws
+        tail = tail[:5] + (dev_ptr(jstash, _f32, "jstash", allow_none=True),) + tail[5:]
+        check(lib().scanerf_render_forward_packed_plan(*args, ctypes.byref(cfg), *tail,
+                                                       ctypes.c_void_p(ws.data_ptr() if ws is not None else None),
+                                                       ctypes.c_size_t(ws.numel() if ws is not None else 0), stream()),
+              "render_forward(plan)")
+        return (out_ray, weights, ws) if plan else (out_ray, weights)
     cfg = _cfg(min_bbox, bbox_size, contract_mode, infinity)
     check(lib().scanerf_render_forward_packed(*args, ctypes.byref(cfg), *tail, stream()), "render_forward")
     return out_ray, weights
@@ -111,11 +125,13 @@ def render_forward(rays_o, rays_d, z_vals, dists, features, resolutions, packed,
 
 def render_backward(rays_o, rays_d, z_vals, dists, features, resolutions, packed, weight_feature, min_bbox, bbox_size,
                     contract_mode, infinity, out_ray, tile_T, grad_out, ray_valid=None, grad_blob=None, xstash=None,
-                    ray_grad_buffers=None, scatter=None, want_dfeat=True, arith=None):
+                    ray_grad_buffers=None, scatter=None, want_dfeat=True, arith=None, jstash=None, ray_pos_grad=None):
     """Adjoint of render_forward -> (dfeat [16, B*S, 2] level-major, grad_blob [13994]).
     scatter = (workspace, grad_features) from scatter_plan(): the kernel emits the table-gradient records
     itself; finish with scatter_accumulate().  dfeat is then only produced if want_dfeat.
-    arith: as given to scatter_plan (default: backward_arith() of this call's inputs)."""
+    arith: as given to scatter_plan (default: backward_arith() of this call's inputs).
+    jstash + ray_pos_grad ([B,6] zeros; t16 kernel, with ray_grad_buffers): the kernel also writes dL/d(rays_o), dL/d(rays_d)
+    through the sample positions, from the forward's position Jacobians (see ray_gradients_fused)."""
     B, S = z_vals.shape
     dev = z_vals.device
     if arith is None:
@@ -138,6 +154,7 @@ def render_backward(rays_o, rays_d, z_vals, dists, features, resolutions, packed
         dev_ptr(xstash, _f32, "xstash", allow_none=True), dev_ptr(dfeat, _f32, "dfeat", allow_none=True), dev_ptr(dw_partial, _f32, "dw_partial"), dev_ptr(grad_blob, _f32, "grad_blob"),
         dev_ptr(ray_grad_buffers[0] if ray_grad_buffers else None, _f32, "g_dnorm", allow_none=True),
         dev_ptr(ray_grad_buffers[1] if ray_grad_buffers else None, _f32, "g_rowsum", allow_none=True),
+        dev_ptr(jstash, _f32, "jstash", allow_none=True), dev_ptr(ray_pos_grad, _f32, "ray_pos_grad", allow_none=True),
         ctypes.c_void_p(scatter[0].data_ptr() if scatter else None), ctypes.c_size_t(scatter[0].numel() if scatter else 0),
         dev_ptr(scatter[1] if scatter else None, _f32, "grad_features", allow_none=True),
         ctypes.c_int(B), ctypes.c_int(S), ctypes.c_int(features.shape[1]), stream()), "render_backward")
@@ -311,6 +328,26 @@ def scatter_table_grad_adam(points, dfeat, resolutions, params, exp_avg, exp_avg
         ctypes.c_int(feat_dtype_code(half_table) if half_table is not None else 0), dev_ptr(overflow_grad, _f32, "overflow_grad"),
         ctypes.c_float(lr), ctypes.c_float(beta1), ctypes.c_float(beta2), ctypes.c_float(eps), ctypes.c_int(step), stream()),
         "scatter_table_grad_adam")
+
+
+def ray_gradients_fused(rays_o, rays_d, blob, ray_pos_grad, g_dnorm, g_rowsum, ray_valid=None):
+    """dL/d(rays_o), dL/d(rays_d) when the backward kernel produced the position path itself (render_backward(jstash=...,
+    ray_pos_grad=...)): adds the two per-ray paths -- |d| through delta = dist * |d| and SH(d / |d|) of the decoder -- by
+    autograd on [B]-sized tensors.  Same result as ray_gradients()."""
+    from . import tile_model
+    d = rays_d.detach().clone().requires_grad_(True)
+    with torch.enable_grad():
+        dn = d.norm(2, dim=-1, keepdim=True)
+        sh = tile_model.sh3(d / (dn + 1e-8))
+    w_sh = blob[6503 + 64 + 32 * 64: 6503 + 64 + 48 * 64].reshape(16, 64)  # Directional_MLP.mlp.0 weight^T rows 32..47
+    g_sh = g_rowsum.sum(1) @ w_sh.t()
+    g_dn = g_dnorm.sum(1, keepdim=True)
+    g_o, g_dpos = ray_pos_grad[:, 0:3], ray_pos_grad[:, 3:6]
+    if ray_valid is not None:
+        keep = ray_valid[:, None].to(_f32)
+        g_sh, g_dn, g_o, g_dpos = g_sh * keep, g_dn * keep, g_o * keep, g_dpos * keep
+    torch.autograd.backward([sh, dn], [g_sh, g_dn])
+    return g_o.contiguous(), d.grad + g_dpos
 
 
 def ray_gradients(rays_o, rays_d, z_vals, features, resolutions, blob, min_bbox, bbox_size, contract_mode, dfeat,

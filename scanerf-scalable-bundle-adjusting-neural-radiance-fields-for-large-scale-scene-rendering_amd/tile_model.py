@@ -414,10 +414,16 @@ def train_step_fused(model, dec_opt, rays_o, rays_d, target, S, global_step, tab
                   B * S * MLP_FLOPS_PER_SAMPLE):
             # t16 backward on the same grid as the forward: the forward kernel counts the scatter records itself (its hash
             # indices are the plan's) -- no separate plan launch (0.25 ms at configs[1])
+            jstash = None
             if (fused and ws is None and bwd_arith == render._capi.ARITH_T16 and render.forward_plan_supported(B, S, T)
                     and not os.environ.get("SCANERF_NO_FORWARD_PLAN")):
+                # pose refinement: the forward also stashes the encoder's position Jacobians (it has the corner values in
+                # registers), so that the backward can chain the feature gradients to the rays without a second pass over the table
+                if pose_grads and table.dtype == torch.float32 and not os.environ.get("SCANERF_NO_JSTASH"):
+                    jstash = torch.empty(render.jstash_shape(B, S), device=dev)
                 out, _, ws = render.render_forward(rays_o, rays_d, z, dist, table, model.resolution, model.packed, *box,
-                                                   ray_valid=valid, want_weights=False, tile_T=tile_T, xstash=xstash, plan=True)
+                                                   ray_valid=valid, want_weights=False, tile_T=tile_T, xstash=xstash, plan=True,
+                                                   jstash=jstash)
             else:
                 out, _ = render.render_forward(rays_o, rays_d, z, dist, table, model.resolution, model.packed, *box,
                                                ray_valid=valid, want_weights=False, tile_T=tile_T, xstash=xstash)
@@ -438,11 +444,15 @@ def train_step_fused(model, dec_opt, rays_o, rays_d, target, S, global_step, tab
             torch.cuda.current_stream().wait_event(plan_done)
         # forward recompute + activation gradients + weight gradients = 3x the forward MLP FLOPs
         with _sec(timer, "render_backward", B * (24 + 20 + S * 16 * 8 * 2 * 4 + S * 16 * 8), 3 * B * S * MLP_FLOPS_PER_SAMPLE):
+            ray_pos = torch.zeros(B, 6, device=dev) if jstash is not None else None
             dfeat, _ = render.render_backward(rays_o, rays_d, z, dist, table, model.resolution, model.packed, wf,
                                               *box, out, tile_T, grad_out, ray_valid=valid, grad_blob=gblob, xstash=xstash,
                                               ray_grad_buffers=ray_bufs, scatter=(ws, gtab) if fused else None,
-                                              want_dfeat=pose_grads or not fused, arith=bwd_arith)
-        if pose_grads:
+                                              want_dfeat=(pose_grads and jstash is None) or not fused, arith=bwd_arith,
+                                              jstash=jstash, ray_pos_grad=ray_pos)
+        if pose_grads and jstash is not None:
+            g_o, g_d = render.ray_gradients_fused(rays_o, rays_d, blob, ray_pos, ray_bufs[0], ray_bufs[1], ray_valid=valid)
+        elif pose_grads:
             g_o, g_d = render.ray_gradients(rays_o, rays_d, z, model.features, model.resolution, blob, box[0], box[1],
                                             box[2], dfeat, ray_bufs[0], ray_bufs[1], ray_valid=valid)
         if adam_epilogue and fused:
