@@ -544,16 +544,22 @@ def fgbg_gradients(model, rays_o, rays_d, target, S_fg, S_bg, global_step, inval
 
 
 def train_step_fgbg(model, dec_opt, rays_o, rays_d, target, S_fg, S_bg, global_step, table_lr=1e-2,
-                    invalid_underground=False, timer=None):
+                    invalid_underground=False, timer=None, pose_grads=False, dec_step=True):
     """One complete training iteration of a tile (tile.py:880-1015: foreground + T_left * background, tile.py:639-692) on the
     fused kernels: both branches' forward, ONE loss launch pair for the merged prediction, both branches' backward emitting
     their scatter records, and ONE accumulate + sparse Adam over both record sets (the two gradients meet in one Adam step).
-    Falls back to gradient tables + adam_step_cuda where the fused scatter does not apply (tables above 2^21 entries)."""
+    Falls back to gradient tables + adam_step_cuda where the fused scatter does not apply (tables above 2^21 entries).
+    pose_grads=True (fp32 tables, t16 backward): also returns dL/d(rays_o), dL/d(rays_d) of the merged prediction -- the sum of
+    the two branches' ray gradients, each formed inside its backward launch from the forward's position Jacobians
+    (-> (loss, g_o, g_d)); dec_step=False: the caller steps the decoder's optimiser (it holds the camera parameters too)."""
     B = rays_o.shape[0]
     dev = model.device
     T = model.features.shape[1]
     fused = T <= (1 << 21) and render.scatter_supported(B, S_fg, T) and render.scatter_supported(B, S_bg, T) \
         and render.backward_arith() != render._capi.ARITH_F32
+    if pose_grads and not (fused and render.backward_arith(True, True) == render._capi.ARITH_T16
+                           and model.gather_table().dtype == torch.float32):
+        raise RuntimeError("scanerf: train_step_fgbg(pose_grads=True) needs the fused t16 path on an fp32 table")
     if not fused:
         loss, gtab, gblob = fgbg_gradients(model, rays_o, rays_d, target, S_fg, S_bg, global_step, invalid_underground, timer)
         with torch.no_grad():
@@ -582,22 +588,31 @@ def train_step_fgbg(model, dec_opt, rays_o, rays_d, target, S_fg, S_bg, global_s
             # (the forward launch reserves the backward's record ranges as well where the two kernels share a grid)
             in_fwd = (render.backward_arith(True, False) == render._capi.ARITH_T16 and render.forward_plan_supported(B, S, T)
                       and not os.environ.get("SCANERF_NO_FORWARD_PLAN"))
+            js = torch.empty(render.jstash_shape(B, S), device=dev) if pose_grads else None
             with _sec(timer, "render_forward", B * (24 + 20 + S * 16 * 8 * 2 * table.element_size()), B * S * MLP_FLOPS_PER_SAMPLE):
                 r = render.render_forward(rays_o, rays_d, z_, d_, table, model.resolution, model.packed, *box, mode, inf,
-                                          ray_valid=v_, want_weights=False, tile_T=tile_T, xstash=xs, plan=in_fwd, plan_workspace=wsbuf)
+                                          ray_valid=v_, want_weights=False, tile_T=tile_T, xstash=xs, plan=in_fwd, plan_workspace=wsbuf,
+                                          jstash=js)
             outs.append(r[0])
-            state.append((tile_T, xs, r[2] if in_fwd else None))
+            state.append((tile_T, xs, r[2] if in_fwd else None, js))
         loss, gfg, gbg = render.photometric_loss_grad_fgbg(outs[0], outs[1], target, vf, vb, 0.01)
         gblob = torch.zeros(network.PARAMSIZE, device=dev)
         overflow = model.overflow_grad()
         wss = []
-        for (z_, d_, v_, mode, inf, S), out, g, (tile_T, xs, ws), wsbuf in zip(branches, outs, (gfg, gbg), state, (None, model._ws_bg)):
+        g_o = g_d = None
+        for (z_, d_, v_, mode, inf, S), out, g, (tile_T, xs, ws, js), wsbuf in zip(branches, outs, (gfg, gbg), state, (None, model._ws_bg)):
             if ws is None:
                 with _sec(timer, "scatter_plan", B * S * 4):
                     ws = render.scatter_plan(rays_o, rays_d, z_, model.resolution, T, *box, mode, inf, ray_valid=v_, workspace=wsbuf)
+            bufs = (torch.zeros(B, (S + 31) // 32, device=dev), torch.zeros(B, 2, 64, device=dev)) if pose_grads else None
+            rp = torch.zeros(B, 6, device=dev) if pose_grads else None
             with _sec(timer, "render_backward", B * (24 + 20 + S * 16 * 8 * 2 * 4 + S * 16 * 8), 3 * B * S * MLP_FLOPS_PER_SAMPLE):
                 render.render_backward(rays_o, rays_d, z_, d_, table, model.resolution, model.packed, wf, *box, mode, inf, out,
-                                       tile_T, g, ray_valid=v_, grad_blob=gblob, xstash=xs, scatter=(ws, overflow), want_dfeat=False)
+                                       tile_T, g, ray_valid=v_, grad_blob=gblob, xstash=xs, scatter=(ws, overflow), want_dfeat=False,
+                                       ray_grad_buffers=bufs, jstash=js, ray_pos_grad=rp)
+            if pose_grads:
+                go_b, gd_b = render.ray_gradients_fused(rays_o, rays_d, model.decoder.blob().detach(), rp, bufs[0], bufs[1], ray_valid=v_)
+                g_o, g_d = (go_b, gd_b) if g_o is None else (g_o + go_b, g_d + gd_b)
             wss.append(ws)
         with _sec(timer, "table_grad_accumulate_adam", B * (S_fg + S_bg) * 16 * 64 + model.features.numel() * 28):
             render.scatter_accumulate_adam2(wss[0], S_fg, wss[1], S_bg, model.features.data, model.exp_avg, model.exp_avg_sq,
@@ -605,5 +620,6 @@ def train_step_fgbg(model, dec_opt, rays_o, rays_d, target, S_fg, S_bg, global_s
                                             overflow_grad=overflow)
         model.adam_step += 1
         model.decoder.params.grad = gblob
-        dec_opt.step()
-    return loss[0]
+        if dec_step:
+            dec_opt.step()
+    return (loss[0], g_o, g_d) if pose_grads else loss[0]

@@ -194,8 +194,13 @@ class TileTrainer:
         cams = self.cameras
         cams.se3_refine.grad = None
         rays_o, rays_d = cams.get_rays(locs)
-        loss, g_o, g_d = train_step_fused(self.model, self.dec_opt, rays_o.detach(), rays_d.detach(), target, self.num_sample,
-                                          self.global_step, table_lr=self.table_lr, pose_grads=True, dec_step=False)
+        if self.num_bg_sample > 0:   # the complete iteration (foreground + T_left * background), tile.py:639-692
+            loss, g_o, g_d = train_step_fgbg(self.model, self.dec_opt, rays_o.detach(), rays_d.detach(), target, self.num_sample,
+                                             self.num_bg_sample, self.global_step, table_lr=self.table_lr, pose_grads=True,
+                                             dec_step=False)
+        else:
+            loss, g_o, g_d = train_step_fused(self.model, self.dec_opt, rays_o.detach(), rays_d.detach(), target, self.num_sample,
+                                              self.global_step, table_lr=self.table_lr, pose_grads=True, dec_step=False)
         torch.autograd.backward([rays_o, rays_d], [g_o, g_d])
         if self.admm and self.consensus is not None and bool(self.consensus.overlap_flags.any()):
             self.consensus.camera_loss(cams.se3_refine).backward()

@@ -336,3 +336,30 @@ def test_train_export_render_pipeline_consistent():
     r = demo.novel_view_check(model, H=60, W=80, samples=64, step=40000, dev=DEV)
     assert r["psnr_render_vs_train"] > 45.0 and r["ssim_render_vs_train"] > 0.99, r
     assert r["psnr_render_vs_gt"] > 15.0 and abs(r["psnr_render_vs_gt"] - r["psnr_train_vs_gt"]) < 1.0, r
+
+
+def test_trainer_refines_poses_through_the_complete_iteration():
+    """TileTrainer with cameras AND background samples (the reference's default: BG_MODE "IZ", CAMOPT enabled): the step is the
+    foreground + T_left * background iteration with both branches' ray gradients (train_step_fgbg(pose_grads=True)); the pose
+    parameters receive gradients and move, the table and the decoder train."""
+    import scanerf_amd  # noqa
+    from scanerf_amd import cameras as CM, trainer
+    from scanerf_amd.tile_model import TileModel
+    torch.manual_seed(1)
+    H, W, C, S_ = 32, 48, 2, 32
+    m = TileModel([-4, -4, -4], [8, 8, 8], DEV, log2_T=13, seed=3)
+    with torch.no_grad():
+        m.features.mul_(100.0)
+    eye = torch.eye(3)
+    c2w = torch.stack([torch.cat([eye, torch.tensor([[x0], [0.0], [-3.0]])], -1) for x0 in (-1.0, 1.0)])
+    ks = torch.tensor([[50.0, 0, W / 2, 0, 50.0, H / 2, 0, 0, 1]]).repeat(C, 1).reshape(C, 3, 3)
+    cams = CM.CameraSet(ks, c2w, DEV, noise=torch.randn(C, 6) * 0.01)
+    locs = CM.pixel_locs(C, torch.arange(H * W), W, DEV)
+    tgt = torch.rand(locs.shape[0], 3, device=DEV)
+    tr = trainer.TileTrainer(m, lambda s: (locs, tgt), total_step=20, num_sample=S_, num_bg_sample=24, adjust_step=1000,
+                             cameras=cams, eta_cam=1e-3)
+    before = (m.features.detach().clone(), m.decoder.blob().detach().clone(), cams.se3_refine.detach().clone())
+    losses = [float(tr.train_one_step()) for _ in range(4)]
+    assert all(np.isfinite(losses)) and tr.global_step == 4
+    assert not torch.equal(m.features.detach(), before[0]) and not torch.equal(m.decoder.blob().detach(), before[1])
+    assert float((cams.se3_refine.detach() - before[2]).abs().max()) > 0

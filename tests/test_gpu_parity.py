@@ -1204,3 +1204,41 @@ def test_fused_step_with_no_valid_ray(S):
     torch.cuda.synchronize()
     assert np.isfinite(float(loss))
     assert torch.equal(m.features.detach(), before) and float(m.exp_avg.abs().max()) == 0.0
+
+
+def test_fgbg_iteration_ray_gradients_vs_oracle(S):
+    """The complete iteration with pose refinement (tile.py:639-692 under CAMOPT): dL/d(rays_o), dL/d(rays_d) of the merged
+    foreground + T_left * background prediction from train_step_fgbg(pose_grads=True) -- both branches' ray gradients formed
+    inside their backward launches -- against autograd through the oracle's render_rays (sample depths are constants on both
+    sides: they come out of non-differentiable samplers)."""
+    from scanerf_amd.tile_model import TileModel, train_step_fgbg
+    rng = np.random.default_rng(33)
+    B, Sf, Sb = 256, 64, 40
+    m = TileModel([-4, -4, -4], [8, 8, 8], DEV, log2_T=12, seed=4)
+    with torch.no_grad():
+        m.features.mul_(200.0)
+    occ = rng.random((16, 16, 16)) < 0.6
+    m.occupied_grid = g(occ)
+    o = rng.uniform(-3.9, 3.9, (B, 3)).astype(np.float32)
+    d = rng.normal(size=(B, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    d *= rng.uniform(0.7, 1.4, (B, 1)).astype(np.float32)
+    tgt = rng.random((B, 3)).astype(np.float32)
+    step = 6000
+    # oracle first (the step below moves the table)
+    tile = O.Tile([-4, -4, -4], [8, 8, 8], log2_T=12)
+    tile.occ = torch.from_numpy(occ)
+    Ft = m.features.detach().cpu().clone()
+    sd = {k: v.detach().cpu().clone() for k, v in m.decoder.ref_state_dict().items()}
+    to, td = torch.from_numpy(o).requires_grad_(True), torch.from_numpy(d).requires_grad_(True)
+    ref = O.render_rays(tile, Ft, sd, to, td, Sf, Sb, O.TRAIN, step, invalid_underground=True)
+    lref = torch.nn.functional.mse_loss(ref["pred_color"], torch.from_numpy(tgt)) + 0.01 * ref["l2_reg_specular"]
+    lref.backward()
+    opt = torch.optim.SGD(m.decoder.parameters(), lr=0.0)
+    loss, g_o, g_d = train_step_fgbg(m, opt, g(o), g(d), g(tgt), Sf, Sb, step, table_lr=0.0, invalid_underground=True, pose_grads=True)
+    np.testing.assert_allclose(float(loss), lref.item(), rtol=2e-5)
+    for got, want, name in ((g_o, to.grad, "rays_o"), (g_d, td.grad, "rays_d")):
+        sc = float(want.abs().max())
+        err = (got.cpu() - want).abs() / sc
+        print(f"fg+bg ray gradient {name}: mean err {float(err.mean()):.2e}, max {float(err.max()):.2e} of max")
+        assert float(err.mean()) < 6e-4 and float((err > 5e-3).float().mean()) < 0.01, (name, float(err.mean()), float(err.max()))

@@ -20,3 +20,12 @@ for ar in ("t16", "h3"):
         for i in range(10): train_step_fused(m, opt, o, d, tgt, S, 20010 + i, pose_grads=pose)
         torch.cuda.synchronize()
         print(f"arith {ar} pose_grads={pose}: {(time.perf_counter() - t0) * 100:.2f} ms per step")
+# the reference's default iteration: foreground + background + pose refinement
+from scanerf_amd.tile_model import train_step_fgbg
+render.set_arith("t16")
+for pose in (False, True):
+    for i in range(3): train_step_fgbg(m, opt, o, d, tgt, S, S, 20100 + i, pose_grads=pose)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for i in range(10): train_step_fgbg(m, opt, o, d, tgt, S, S, 20110 + i, pose_grads=pose)
+    torch.cuda.synchronize()
+    print(f"fg + bg iteration (128 + 128 samples), pose_grads={pose}: {(time.perf_counter() - t0) * 100:.2f} ms per step")
