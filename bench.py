@@ -59,6 +59,9 @@ def parse():
     ap.add_argument("--scatter", default="auto", choices=["auto", "fused", "dfeat"],
                     help="table-gradient records emitted by the backward kernel (fused, default) or by the stand-alone "
                          "binned scatter from a level-major dfeat (tuning comparison)")
+    ap.add_argument("--pose-grads", action="store_true",
+                    help="with --workload configs1 / configs1-fgbg: the iteration also returns dL/d(rays_o), dL/d(rays_d) (the "
+                         "reference's default: CAMOPT.ENABLE)")
     ap.add_argument("--workload", default="configs1", choices=["configs1", "configs1-fgbg", "configs2", "configs4-render"],
                     help="configs1 (default, the metric's configuration): fp32 table, fully occupied sampler grid; "
                          "configs1-fgbg: the reference's complete iteration (tile.py:639-692, config/default.yaml:15-18): foreground + "
@@ -319,10 +322,14 @@ def main():
     if path == "auto":
         path = "fused" if hasattr(tm, "train_step_fused") else "ops"
     step_fn = tm.train_step_fused if path == "fused" else tm.train_step_ops
+    if path == "fused" and args.pose_grads:
+        import functools
+        step_fn = functools.partial(tm.train_step_fused, pose_grads=True)
     fgbg = args.workload == "configs1-fgbg"
     if fgbg:
         path = "fused"
-        step_fn = lambda m_, o_, ro, rd, tg, S_, st, timer=None: tm.train_step_fgbg(m_, o_, ro, rd, tg, S_, S_, st, timer=timer)
+        step_fn = lambda m_, o_, ro, rd, tg, S_, st, timer=None: tm.train_step_fgbg(m_, o_, ro, rd, tg, S_, S_, st, timer=timer,
+                                                                                    pose_grads=args.pose_grads)
     if path == "fused" and args.scatter != "auto":
         import functools
         step_fn = functools.partial(tm.train_step_fused, fused_scatter=args.scatter == "fused")
@@ -425,7 +432,7 @@ def main():
                                     f"(sample+encode+decode+composite fwd, bwd, sparse Adam); foreground branch"),
                        "path": path, "rays_per_step": B, "valid_ray_fraction": valid_frac, "samples": S, "tiles_per_gpu": ntile,
                        "parallelism": f"tile-per-gpu x{world}", "syn_iters": SYN_ITERS},
-            "f32_arith_ms_per_step": f32_ms, "h3_grad_ms_per_step": h3_ms,
+            "pose_grads": bool(args.pose_grads), "f32_arith_ms_per_step": f32_ms, "h3_grad_ms_per_step": h3_ms,
             "consensus_ms": consensus_ms,
             "consensus_frac_of_iteration": consensus_ms / (SYN_ITERS * ms_per_step),
         }
