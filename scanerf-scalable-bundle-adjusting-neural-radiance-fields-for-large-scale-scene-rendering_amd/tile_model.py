@@ -313,7 +313,9 @@ class KernelTimer:
     def dominant(self, *_):
         """(name, avg ms, algorithmic bytes, algorithmic flops) of the section with the largest time."""
         s = self.summary()
-        cand = {k: v for k, v in s.items() if self.bytes.get(k, 0) > 0}
+        cand = {k: v for k, v in s.items() if self.bytes.get(k, 0) > 0} or s   # (sections without a byte count: time only)
+        if not cand:
+            return None, 0.0, 0, 0
         name = max(cand, key=cand.get)
         return name, cand[name], self.bytes[name], self.flops.get(name, 0)
 
@@ -486,14 +488,20 @@ def train_step_fused(model, dec_opt, rays_o, rays_d, target, S, global_step, tab
     return (loss[0], g_o, g_d) if pose_grads else loss[0]
 
 
-def fgbg_gradients(model, rays_o, rays_d, target, S_fg, S_bg, global_step, invalid_underground=False, timer=None):
+def fgbg_gradients(model, rays_o, rays_d, target, S_fg, S_bg, global_step, invalid_underground=False, timer=None,
+                   pose_grads=False, collect=None):
     """Loss and parameter gradients of the complete per-tile render of tile.py:639-692 / :880-1015: foreground
     (occupancy-sampled, contract_fore) + T_left * background (inverse-z, contract_bg, infinity), MSE on the merged colour
     over all rays + 0.01 * (l2_reg_specular of both branches) -- two fused forward/backward pairs over the same table and
-    decoder.  Returns (loss, grad_table [16,T,2], grad_blob [13994])."""
+    decoder.  Returns (loss, grad_table [16,T,2], grad_blob [13994]) (+ dL/d(rays_o), dL/d(rays_d) with pose_grads: t16
+    backward on the fp32 table, any table size).  collect: a list that receives (contracted points [N,3], dfeat [16,N,2]) of
+    each branch INSTEAD of their scatter into the gradient table (the caller scatters them together: large tables)."""
     B = rays_o.shape[0]
     dev = model.device
     T = model.features.shape[1]
+    if pose_grads and render.backward_arith(True, True) != render._capi.ARITH_T16:
+        raise RuntimeError("scanerf: fgbg pose gradients need the t16 backward (render.set_arith)")
+    g_o = g_d = None
     with torch.no_grad():
         wf = model.weight_feature(global_step)
         model.packed.pack(model.decoder.blob(), wf)
@@ -508,10 +516,11 @@ def fgbg_gradients(model, rays_o, rays_d, target, S_fg, S_bg, global_step, inval
             S = z_.shape[1]
             tile_T = torch.empty((B, render.tile_T_columns(S)), device=dev)
             xs = torch.empty((B * S, 32), device=dev)
+            js = torch.empty(render.jstash_shape(B, S), device=dev) if pose_grads else None
             out, _ = render.render_forward(rays_o, rays_d, z_, d_, model.features, model.resolution, model.packed, *box, mode, inf,
-                                           ray_valid=v_, want_weights=False, tile_T=tile_T, xstash=xs)
+                                           ray_valid=v_, want_weights=False, tile_T=tile_T, xstash=xs, jstash=js)
             outs.append(out)
-            state.append((tile_T, xs))
+            state.append((tile_T, xs, js))
     # merge and loss on the per-ray outputs (tile.py:666-690; criterions.py:142-144; tile.py:999), two HIP launches
     vf, vbg = branches[0][2], branches[1][2]
     loss, gfg, gbg = render.photometric_loss_grad_fgbg(outs[0], outs[1], target, vf, vbg, 0.01)
@@ -521,16 +530,22 @@ def fgbg_gradients(model, rays_o, rays_d, target, S_fg, S_bg, global_step, inval
             self.grad = g
     fg, bg = _Leaf(gfg), _Leaf(gbg)
     with torch.no_grad():
-        gtab = torch.zeros_like(model.features)
+        gtab = torch.zeros_like(model.features) if collect is None else None
         gblob = torch.zeros(network.PARAMSIZE, device=dev)
-        for (z_, d_, v_, mode, inf), out, leaf, (tile_T, xs) in zip(branches, outs, (fg, bg), state):
+        for (z_, d_, v_, mode, inf), out, leaf, (tile_T, xs, js) in zip(branches, outs, (fg, bg), state):
             S = z_.shape[1]
-            fused = T <= (1 << 21) and render.scatter_supported(B, S, T)  # (see train_step_fused)
+            fused = T <= (1 << 21) and render.scatter_supported(B, S, T) and collect is None  # (see train_step_fused)
             ws = render.scatter_plan(rays_o, rays_d, z_, model.resolution, T, *box, mode, inf, ray_valid=v_) if fused else None
+            bufs = (torch.zeros(B, (S + 31) // 32, device=dev), torch.zeros(B, 2, 64, device=dev)) if pose_grads else None
+            rp = torch.zeros(B, 6, device=dev) if pose_grads else None
             with _sec(timer, "render_backward"):
                 dfeat, _ = render.render_backward(rays_o, rays_d, z_, d_, model.features, model.resolution, model.packed, wf, *box,
                                                   mode, inf, out, tile_T, leaf.grad.contiguous(), ray_valid=v_, grad_blob=gblob,
-                                                  xstash=xs, scatter=(ws, gtab) if fused else None, want_dfeat=not fused)
+                                                  xstash=xs, scatter=(ws, gtab) if fused else None, want_dfeat=not fused,
+                                                  ray_grad_buffers=bufs, jstash=js, ray_pos_grad=rp)
+            if pose_grads:
+                go_b, gd_b = render.ray_gradients_fused(rays_o, rays_d, model.decoder.blob().detach(), rp, bufs[0], bufs[1], ray_valid=v_)
+                g_o, g_d = (go_b, gd_b) if g_o is None else (g_o + go_b, g_d + gd_b)
             if fused:
                 render.scatter_accumulate(ws, gtab, B, S)
             else:
@@ -539,8 +554,11 @@ def fgbg_gradients(model, rays_o, rays_d, target, S_fg, S_bg, global_step, inval
                 if mode == render.BG:
                     linf = pts.abs().amax(-1, keepdim=True)
                     pts = pts * ((2.0 - 1.0 / linf) / linf)
-                render.scatter_table_grad(pts.contiguous(), dfeat, gtab, model.resolution)
-    return loss[0].detach(), gtab, gblob
+                if collect is not None:
+                    collect.append((pts.contiguous(), dfeat))
+                else:
+                    render.scatter_table_grad(pts.contiguous(), dfeat, gtab, model.resolution)
+    return (loss[0].detach(), gtab, gblob, g_o, g_d) if pose_grads else (loss[0].detach(), gtab, gblob)
 
 
 def train_step_fgbg(model, dec_opt, rays_o, rays_d, target, S_fg, S_bg, global_step, table_lr=1e-2,
@@ -557,17 +575,31 @@ def train_step_fgbg(model, dec_opt, rays_o, rays_d, target, S_fg, S_bg, global_s
     T = model.features.shape[1]
     fused = T <= (1 << 21) and render.scatter_supported(B, S_fg, T) and render.scatter_supported(B, S_bg, T) \
         and render.backward_arith() != render._capi.ARITH_F32
-    if pose_grads and not (fused and render.backward_arith(True, True) == render._capi.ARITH_T16
-                           and model.gather_table().dtype == torch.float32):
-        raise RuntimeError("scanerf: train_step_fgbg(pose_grads=True) needs the fused t16 path on an fp32 table")
+    if pose_grads and model.gather_table().dtype != torch.float32:
+        raise RuntimeError("scanerf: train_step_fgbg(pose_grads=True) gathers from the fp32 table")
     if not fused:
-        loss, gtab, gblob = fgbg_gradients(model, rays_o, rays_d, target, S_fg, S_bg, global_step, invalid_underground, timer)
+        # tables above 2^21 entries (the reference's default is 2^24): the two branches' feature gradients go through ONE
+        # stand-alone binned scatter that ends in the sparse Adam (no gradient table, no zero-fill, no dense optimiser scan)
+        binned = T > (1 << 21) and render.backward_arith() != render._capi.ARITH_F32 and model._half_table is None
+        parts = [] if binned else None
+        r = fgbg_gradients(model, rays_o, rays_d, target, S_fg, S_bg, global_step, invalid_underground, timer, pose_grads=pose_grads,
+                           collect=parts)
+        loss, gtab, gblob = r[:3]
         with torch.no_grad():
-            model.features.grad = gtab
-            model.table_adam(table_lr)
+            if binned:
+                pts = torch.cat([p_ for p_, _ in parts], 0)
+                dfe = torch.cat([f_ for _, f_ in parts], 1).contiguous()
+                with _sec(timer, "table_grad_scatter_adam", pts.shape[0] * 16 * (8 + 16 * 8)):
+                    render.scatter_table_grad_adam(pts, dfe, model.resolution, model.features.data, model.exp_avg, model.exp_avg_sq,
+                                                   table_lr, 0.9, 0.99, 1e-15, model.adam_step, overflow_grad=model.overflow_grad())
+                model.adam_step += 1
+            else:
+                model.features.grad = gtab
+                model.table_adam(table_lr)
             model.decoder.params.grad = gblob
-            dec_opt.step()
-        return loss
+            if dec_step:
+                dec_opt.step()
+        return (loss, r[3], r[4]) if pose_grads else loss
     with torch.no_grad():
         wf = model.weight_feature(global_step)
         model.packed.pack(model.decoder.blob(), wf)

@@ -962,10 +962,13 @@ def test_compact_rays_equals_boolean_mask_indexing(S, B, S_, p_valid):
     assert torch.equal(idx.long(), torch.nonzero(want)[:, 0])
 
 
-def test_train_step_fgbg_one_adam_step_over_both_branches(S):
+@pytest.mark.parametrize("log2_T", [14, 22])
+def test_train_step_fgbg_one_adam_step_over_both_branches(S, log2_T):
     """train_step_fgbg (both branches' records into ONE accumulate + sparse Adam) against the unfused route (fgbg_gradients ->
     gradient table -> adam_step_cuda): same loss, and the same table / moments up to the rounding of where the two branches'
-    gradients are added (one fixed-point image vs two f32 additions)."""
+    gradients are added (one fixed-point image vs two f32 additions).  T = 2^22 (tables too large for the backward's own
+    record emission; the reference's default is 2^24): both branches' feature gradients through ONE stand-alone binned scatter
+    ending in the Adam epilogue."""
     from scanerf_amd.tile_model import TileModel, fgbg_gradients, train_step_fgbg
     torch.manual_seed(13)
     B, Sf, Sb = 2048, 64, 48
@@ -975,9 +978,9 @@ def test_train_step_fgbg_one_adam_step_over_both_branches(S):
     occ = torch.rand(16, 16, 16, device=DEV) < 0.7
     res = {}
     for fused in (True, False):
-        m = TileModel([-4, -4, -4], [8, 8, 8], DEV, log2_T=14, seed=4)
+        m = TileModel([-4, -4, -4], [8, 8, 8], DEV, log2_T=log2_T, seed=4)
         with torch.no_grad():
-            m.features.mul_(100.0)
+            m.features.mul_(100.0 if log2_T < 20 else 1000.0)
         m.set_occupancy(occ)
         opt = torch.optim.Adam(m.decoder.parameters(), lr=1e-3, betas=(0.9, 0.99), eps=1e-15)
         if fused:
@@ -1235,7 +1238,11 @@ def test_fgbg_iteration_ray_gradients_vs_oracle(S):
     lref = torch.nn.functional.mse_loss(ref["pred_color"], torch.from_numpy(tgt)) + 0.01 * ref["l2_reg_specular"]
     lref.backward()
     opt = torch.optim.SGD(m.decoder.parameters(), lr=0.0)
+    # (the unfused route -- what tables above 2^21 entries take -- gives the same ray gradients)
+    from scanerf_amd.tile_model import fgbg_gradients
+    _, _, _, g_o_u, g_d_u = fgbg_gradients(m, g(o), g(d), g(tgt), Sf, Sb, step, invalid_underground=True, pose_grads=True)
     loss, g_o, g_d = train_step_fgbg(m, opt, g(o), g(d), g(tgt), Sf, Sb, step, table_lr=0.0, invalid_underground=True, pose_grads=True)
+    assert torch.equal(g_o, g_o_u) and torch.equal(g_d, g_d_u)
     np.testing.assert_allclose(float(loss), lref.item(), rtol=2e-5)
     for got, want, name in ((g_o, to.grad, "rays_o"), (g_d, td.grad, "rays_d")):
         sc = float(want.abs().max())
