@@ -281,13 +281,15 @@ __global__ void __launch_bounds__(kThreads) k_bin_accumulate(const Rec *__restri
             const uint32_t e0 = (hdr & 0xffffu) - wbase, e1 = (hdr >> 16) - wbase;  // unsigned: outside the window = huge
             const float w1 = r.y, w0 = 1.0f - w1;
             unsigned long long *a = reinterpret_cast<unsigned long long *>(acc64);
+            const uint32_t oa = threadIdx.x & 1u, ob = oa ^ 1u;   // (odd lanes start with the y word: see apply8)
+            const float ga = oa ? r.w : r.z, gb = oa ? r.z : r.w;
             if (e0 < (uint32_t)ws) {
-                atomicAdd(&a[2 * e0], fx(w0 * r.z));
-                atomicAdd(&a[2 * e0 + 1], fx(w0 * r.w));
+                atomicAdd(&a[2 * e0 + oa], fx(w0 * ga));
+                atomicAdd(&a[2 * e0 + ob], fx(w0 * gb));
             }
             if (e1 < (uint32_t)ws) {
-                atomicAdd(&a[2 * e1], fx(w1 * r.z));
-                atomicAdd(&a[2 * e1 + 1], fx(w1 * r.w));
+                atomicAdd(&a[2 * e1 + oa], fx(w1 * ga));
+                atomicAdd(&a[2 * e1 + ob], fx(w1 * gb));
             }
         };
         // Rec8 (scatter_common.h): integers end to end.  p = m * weight < 2^25 in magnitude, value = p * 2^(E - 25), on the
@@ -302,11 +304,16 @@ __global__ void __launch_bounds__(kThreads) k_bin_accumulate(const Rec *__restri
             // 2^-18 of the launch's largest gradient and smaller, by less than 2^-43 of it each)
             auto fi = [&](int p) { return (unsigned long long)(((long long)p << 32) >> rs); };
             unsigned long long *a = reinterpret_cast<unsigned long long *>(acc64);
-            atomicAdd(&a[2 * l0], fi(mx * (8192 - t)));
-            atomicAdd(&a[2 * l0 + 1], fi(my * (8192 - t)));
+            // Odd lanes add their y component first, even lanes their x: the x words of all entries (8-byte word 2 l) lie on
+            // the LDS banks 0,1 mod 4 and the y words on 2,3 mod 4, so an instruction in which every lane adds an x word has
+            // half of the banks to spread over (measured: three quarters of the LDS's active cycles were bank conflicts).
+            const uint32_t oa = threadIdx.x & 1u, ob = oa ^ 1u;
+            const int ma = oa ? my : mx, mb = oa ? mx : my;
+            atomicAdd(&a[2 * l0 + oa], fi(ma * (8192 - t)));
+            atomicAdd(&a[2 * l0 + ob], fi(mb * (8192 - t)));
             if (l1 < (uint32_t)ws) {
-                atomicAdd(&a[2 * l1], fi(mx * t));
-                atomicAdd(&a[2 * l1 + 1], fi(my * t));
+                atomicAdd(&a[2 * l1 + oa], fi(ma * t));
+                atomicAdd(&a[2 * l1 + ob], fi(mb * t));
             }
         };
         for (int set = 0; set < (two ? 2 : 1); ++set) {   // (one copy of the streaming code for both record sets)
