@@ -1249,3 +1249,48 @@ def test_fgbg_iteration_ray_gradients_vs_oracle(S):
         err = (got.cpu() - want).abs() / sc
         print(f"fg+bg ray gradient {name}: mean err {float(err.mean()):.2e}, max {float(err.max()):.2e} of max")
         assert float(err.mean()) < 6e-4 and float((err > 5e-3).float().mean()) < 0.01, (name, float(err.mean()), float(err.max()))
+
+
+@pytest.mark.parametrize("B,S_", [(1, 1), (9, 17), (255, 16), (2049, 33), (4100, 130), (2048, 15)])
+def test_fused_default_path_odd_shapes(S, B, S_):
+    """The default fused path at the ragged ends of its shapes: one ray, one sample, sample counts that are not multiples of
+    16 or 32 (partial tiles), ray counts just past a multiple of the 8 rays a workgroup visits, with and without the plan in
+    the forward kernel.  Feature-gradient records against the exact scatter of the same dfeat."""
+    from scanerf_amd import network, render
+    from scanerf_amd.tile_model import TileModel
+    torch.manual_seed(B * 131 + S_)
+    m = TileModel([-4, -4, -4], [8, 8, 8], DEV, log2_T=12, seed=2)
+    with torch.no_grad():
+        m.features.mul_(30.0)
+    o = torch.rand(B, 3, device=DEV) * 8 - 4
+    d = torch.nn.functional.normalize(torch.randn(B, 3, device=DEV), dim=-1)
+    z, dist = m.sample(o, d, S_)
+    valid = torch.rand(B, device=DEV) < 0.8
+    valid[0] = True
+    wf = network.weight_feature(3000, DEV)
+    m.packed.pack(m.decoder.blob(), wf)
+    box = (m.min_bbox.tolist(), m.bbox_size.tolist(), render.FORE, False)
+    T = m.features.shape[1]
+    tile_T = torch.empty(B, (S_ + 15) // 16, device=DEV)
+    xs = torch.empty(B * S_, 32, device=DEV)
+    plan = render.forward_plan_supported(B, S_, T)
+    assert plan == (min((B + 7) // 8, 256) == min(B, 256))   # forward and backward grids agree: B >= 2048, or a single workgroup
+    r = render.render_forward(o, d, z, dist, m.features, m.resolution, m.packed, *box, ray_valid=valid, tile_T=tile_T, xstash=xs, plan=plan)
+    out, w = r[0], r[1]
+    ws = r[2] if plan else render.scatter_plan(o, d, z, m.resolution, T, *box, ray_valid=valid)
+    assert torch.isfinite(out).all() and torch.isfinite(w).all()
+    gout = torch.randn(B, 16, device=DEV)
+    args = (o, d, z, dist, m.features, m.resolution, m.packed, wf, *box, out, tile_T, gout)
+    g2 = torch.zeros_like(m.features)
+    _, gb2 = render.render_backward(*args, ray_valid=valid, xstash=xs, scatter=(ws, g2), want_dfeat=False)
+    render.scatter_accumulate(ws, g2, B, S_)
+    dfeat, gb1 = render.render_backward(*args, ray_valid=valid, xstash=xs)
+    pts = ((o[:, None, :] + z[:, :, None] * d[:, None, :]).reshape(-1, 3) - m._min_dev) / m._size_dev * 4.0 - 2.0
+    g1 = render.scatter_table_grad(pts.contiguous(), dfeat, torch.zeros_like(m.features), m.resolution)
+    torch.cuda.synchronize()
+    assert torch.isfinite(g2).all() and torch.equal(gb1, gb2)
+    sc = float(g1.abs().max())
+    if sc > 0:
+        np.testing.assert_allclose((g2 / sc).cpu().numpy(), (g1 / sc).cpu().numpy(), rtol=5e-4, atol=5e-4)
+    else:
+        assert float(g2.abs().max()) == 0.0
