@@ -294,7 +294,6 @@ __global__ void __launch_bounds__(kThreads, 2) k_render_bwd_t16(BwdArgs a)
         // ... and, with the forward's position Jacobians (f.jstash), the gradient through the sample positions: this lane's
         // levels of the tile being emitted, chained to the ray through the contraction
         float pose_go[3] = { 0, 0, 0 }, pose_gd[3] = { 0, 0, 0 };
-        float ppz = 0.0f;                 // the emitted tile's sample depth
 
         // Feature gradients of one tile: dfeat rows and / or the scatter records (scatter.hip) into the ranges the plan
         // reserved, ONE LEVEL PER CALL.  e0 / e1 = dX blocks 0 / 1: register g of block e = x-stash position 8q + 4e + g =
@@ -313,54 +312,6 @@ __global__ void __launch_bounds__(kThreads, 2) k_render_bwd_t16(BwdArgs a)
             const float gx = jj == 0 ? e0[0] : (jj == 1 ? e0[2] : (jj == 2 ? e1[0] : e1[2]));
             const float gy = jj == 0 ? e0[1] : (jj == 1 ? e0[3] : (jj == 2 ? e1[1] : e1[3]));
             if (a.dfeat) reinterpret_cast<float2 *>(a.dfeat)[(size_t)level * a.f.B * S + (size_t)ray * S + s] = make_float2(gx, gy);
-            if (POSE && a.g_raypos && jj == 3) {
-                // position path, once per tile: this lane's four levels' Jacobians (12 loads in flight together), contracted with
-                // its dX.  The forward's lane 32 h + (s & 31) wrote its 8 levels 4 (j >> 1) + 2 h + (j & 1) into the 32-sample
-                // tile's [8][3][64] float2 block.
-                float2 jv[4][3];
-#pragma unroll
-                for (int lv = 0; lv < 4; ++lv) {
-                    const int j8l = 4 * (q & 1) + lv, lvl = 4 * (j8l >> 1) + 2 * (q >> 1) + (j8l & 1);
-                    const int hh = (lvl >> 1) & 1, j = 2 * (lvl >> 2) + (lvl & 1);
-                    const float2 *jr = reinterpret_cast<const float2 *>(a.f.jstash) +
-                                       (((size_t)ray * ((S + 31) >> 5) + (s >> 5)) * 8 + j) * (3 * 64) + 32 * hh + (s & 31);
-                    jv[lv][0] = jr[0]; jv[lv][1] = jr[64]; jv[lv][2] = jr[128];
-                }
-                float pose_gp[3] = { 0, 0, 0 };
-#pragma unroll
-                for (int lv = 0; lv < 4; ++lv) {
-                    const float fx = lv == 0 ? e0[0] : (lv == 1 ? e0[2] : (lv == 2 ? e1[0] : e1[2]));
-                    const float fy = lv == 0 ? e0[1] : (lv == 1 ? e0[3] : (lv == 2 ? e1[1] : e1[3]));
-                    pose_gp[0] += fx * jv[lv][0].x + fy * jv[lv][1].y;
-                    pose_gp[1] += fx * jv[lv][0].y + fy * jv[lv][2].x;
-                    pose_gp[2] += fx * jv[lv][1].x + fy * jv[lv][2].y;
-                }
-                if (jj == 3) {  // the lane's four levels are in: through the contraction to the ray
-                    float gxk[3] = { pose_gp[0], pose_gp[1], pose_gp[2] };
-                    if (a.f.contract_mode == 1) {
-                        float xk[3];
-#pragma unroll
-                        for (int k = 0; k < 3; ++k) xk[k] = (o[k] + ppz * d[k] - a.f.min_bbox[k]) * a.f.inv_size4[k] - 2.0f;
-                        const float ax = fabsf(xk[0]), ay = fabsf(xk[1]), az = fabsf(xk[2]);
-                        const float linf = fmaxf(ax, fmaxf(ay, az));
-                        const int mk = (ax >= ay && ax >= az) ? 0 : (ay >= az ? 1 : 2);   // torch.max: the first maximum
-                        const float il = 1.0f / linf, r = (2.0f - il) * il, dr = (-2.0f + 2.0f * il) * il * il;
-                        const float dot = gxk[0] * xk[0] + gxk[1] * xk[1] + gxk[2] * xk[2];
-#pragma unroll
-                        for (int k = 0; k < 3; ++k) gxk[k] *= r;
-                        const float extra = dot * dr * (xk[mk] < 0.0f ? -1.0f : 1.0f);
-                        gxk[0] += mk == 0 ? extra : 0.0f;
-                        gxk[1] += mk == 1 ? extra : 0.0f;
-                        gxk[2] += mk == 2 ? extra : 0.0f;
-                    }
-#pragma unroll
-                    for (int k = 0; k < 3; ++k) {
-                        const float gk = gxk[k] * a.f.inv_size4[k];
-                        pose_go[k] += gk;
-                        pose_gd[k] += ppz * gk;
-                    }
-                }
-            }
             if (a.recs) {
                 const uint32_t mask = (uint32_t)a.f.T - 1u;
                 const int4 r = *reinterpret_cast<const int4 *>(lres + 4 * level);
@@ -755,6 +706,50 @@ __global__ void __launch_bounds__(kThreads, 2) k_render_bwd_t16(BwdArgs a)
             t16_chain<2, 2>(dx, lds, T16T_L0, L.lo16, dyB);
             dx[0] *= isc;
             dx[1] *= isc;
+            if (POSE && a.g_raypos && live && active) {
+                // position path (here, where only dX is live): this lane's four levels' Jacobians (12 loads in flight together),
+                // contracted with its dX.  The forward's lane 32 h + (s & 31) wrote its 8 levels 4 (j >> 1) + 2 h + (j & 1) into
+                // the 32-sample tile's [8][3][64] float2 block; register g of dX block e = feature g & 1 of level jj = 2e + (g >> 1).
+                float2 jv[4][3];
+#pragma unroll
+                for (int lv = 0; lv < 4; ++lv) {
+                    const int j8l = 4 * (q & 1) + lv, lvl = 4 * (j8l >> 1) + 2 * (q >> 1) + (j8l & 1);
+                    const int hh = (lvl >> 1) & 1, j = 2 * (lvl >> 2) + (lvl & 1);
+                    const float2 *jr = reinterpret_cast<const float2 *>(a.f.jstash) +
+                                       (((size_t)ray * ((S + 31) >> 5) + (s >> 5)) * 8 + j) * (3 * 64) + 32 * hh + (s & 31);
+                    jv[lv][0] = jr[0]; jv[lv][1] = jr[64]; jv[lv][2] = jr[128];
+                }
+                float gxk[3] = { 0, 0, 0 };
+#pragma unroll
+                for (int lv = 0; lv < 4; ++lv) {
+                    const float fx = dx[lv >> 1][2 * (lv & 1)], fy = dx[lv >> 1][2 * (lv & 1) + 1];
+                    gxk[0] += fx * jv[lv][0].x + fy * jv[lv][1].y;
+                    gxk[1] += fx * jv[lv][0].y + fy * jv[lv][2].x;
+                    gxk[2] += fx * jv[lv][1].x + fy * jv[lv][2].y;
+                }
+                if (a.f.contract_mode == 1) {  // through contract_bg: r g + (g . x) r' sign(x_m) e_m, r = (2 - 1/|x|_inf) / |x|_inf
+                    float xk[3];
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) xk[k] = (o[k] + z * d[k] - a.f.min_bbox[k]) * a.f.inv_size4[k] - 2.0f;
+                    const float ax = fabsf(xk[0]), ay = fabsf(xk[1]), az = fabsf(xk[2]);
+                    const float linf = fmaxf(ax, fmaxf(ay, az));
+                    const int mk = (ax >= ay && ax >= az) ? 0 : (ay >= az ? 1 : 2);   // torch.max: the first maximum
+                    const float il = 1.0f / linf, r = (2.0f - il) * il, dr = (-2.0f + 2.0f * il) * il * il;
+                    const float dot = gxk[0] * xk[0] + gxk[1] * xk[1] + gxk[2] * xk[2];
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) gxk[k] *= r;
+                    const float extra = dot * dr * (xk[mk] < 0.0f ? -1.0f : 1.0f);
+                    gxk[0] += mk == 0 ? extra : 0.0f;
+                    gxk[1] += mk == 1 ? extra : 0.0f;
+                    gxk[2] += mk == 2 ? extra : 0.0f;
+                }
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const float gk = gxk[k] * a.f.inv_size4[k];
+                    pose_go[k] += gk;
+                    pose_gd[k] += z * gk;
+                }
+            }
             // (no barrier here: the next tile's staging writes come after its barrier S)
 
             if (tile > 0) nxt = load_tile(tile - 1);   // before this tile's record stores (see load_tile)
@@ -762,7 +757,6 @@ __global__ void __launch_bounds__(kThreads, 2) k_render_bwd_t16(BwdArgs a)
             pdx0 = dx[0];
             pdx1 = dx[1];
             ptile = tile;
-            ppz = z;
             if (a.recs) contract_point(a.f, o, d, z, ppe);
         }
 #pragma unroll
