@@ -312,9 +312,10 @@ def scatter_table_grad(points, dfeat, grad_features, resolutions):
 
 
 def scatter_table_grad_adam(points, dfeat, resolutions, params, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, step,
-                            half_table=None, overflow_grad=None):
+                            half_table=None, overflow_grad=None, compact_records=False):
     """scatter_table_grad ending in the fused sparse Adam (no gradient table): the table path of tables too large for the
-    backward kernel's own record emission.  overflow_grad: zero table like params (required by the C ABI)."""
+    backward kernel's own record emission.  overflow_grad: zero table like params (required by the C ABI).
+    compact_records: 8-byte records (for dfeat out of the t16 backward; scatter_common.h Rec8)."""
     N, (L, T) = points.shape[0], params.shape[:2]
     need = lib().scanerf_embedding_bwd_workspace_bytes(ctypes.c_int(N), ctypes.c_int(L), ctypes.c_int(T))
     if not need:
@@ -326,8 +327,8 @@ def scatter_table_grad_adam(points, dfeat, resolutions, params, exp_avg, exp_avg
         dev_ptr(params, _f32, "params"), dev_ptr(exp_avg, _f32, "exp_avg"), dev_ptr(exp_avg_sq, _f32, "exp_avg_sq"),
         dev_ptr(half_table, (torch.float16, torch.bfloat16), "half_table", allow_none=True),
         ctypes.c_int(feat_dtype_code(half_table) if half_table is not None else 0), dev_ptr(overflow_grad, _f32, "overflow_grad"),
-        ctypes.c_float(lr), ctypes.c_float(beta1), ctypes.c_float(beta2), ctypes.c_float(eps), ctypes.c_int(step), stream()),
-        "scatter_table_grad_adam")
+        ctypes.c_float(lr), ctypes.c_float(beta1), ctypes.c_float(beta2), ctypes.c_float(eps), ctypes.c_int(step),
+        ctypes.c_int(int(compact_records)), stream()), "scatter_table_grad_adam")
 
 
 def ray_gradients_fused(rays_o, rays_d, blob, ray_pos_grad, g_dnorm, g_rowsum, ray_valid=None):

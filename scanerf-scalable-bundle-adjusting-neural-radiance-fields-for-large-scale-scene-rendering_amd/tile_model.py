@@ -468,7 +468,8 @@ def train_step_fused(model, dec_opt, rays_o, rays_d, target, S, global_step, tab
             with _sec(timer, "table_grad_scatter_adam", B * S * 16 * (8 + 16 * 8)):
                 render.scatter_table_grad_adam(pts.contiguous(), dfeat, model.resolution, model.features.data, model.exp_avg,
                                                model.exp_avg_sq, table_lr, 0.9, 0.99, 1e-15, model.adam_step,
-                                               half_table=model._half_table, overflow_grad=gtab)
+                                               half_table=model._half_table, overflow_grad=gtab,
+                                               compact_records=bwd_arith == render._capi.ARITH_T16)
             model.adam_step += 1
         elif fused:
             with _sec(timer, "table_grad_accumulate", B * S * 16 * 64):
@@ -591,7 +592,8 @@ def train_step_fgbg(model, dec_opt, rays_o, rays_d, target, S_fg, S_bg, global_s
                 dfe = torch.cat([f_ for _, f_ in parts], 1).contiguous()
                 with _sec(timer, "table_grad_scatter_adam", pts.shape[0] * 16 * (8 + 16 * 8)):
                     render.scatter_table_grad_adam(pts, dfe, model.resolution, model.features.data, model.exp_avg, model.exp_avg_sq,
-                                                   table_lr, 0.9, 0.99, 1e-15, model.adam_step, overflow_grad=model.overflow_grad())
+                                                   table_lr, 0.9, 0.99, 1e-15, model.adam_step, overflow_grad=model.overflow_grad(),
+                                                   compact_records=render.backward_arith() == render._capi.ARITH_T16)
                 model.adam_step += 1
             else:
                 model.features.grad = gtab

@@ -995,18 +995,23 @@ def test_train_step_fgbg_one_adam_step_over_both_branches(S, log2_T):
         res[fused] = (float(loss), m.exp_avg.clone(), m.exp_avg_sq.clone(), m.features.detach().clone(), m.decoder.params.detach().clone())
     assert res[True][0] == res[False][0]
     m1, m0 = res[True][1], res[False][1]            # first moments = 0.1 * gradient
-    assert float((m1 - m0).abs().max()) <= 2e-6 * float(m0.abs().max())
+    # (T = 2^14: both routes sum the same 8-byte records; 2^22: the binned scatter's 8-byte records against the unfused route's
+    # 16-byte ones -- 13-bit significands, scatter_common.h)
+    assert float((m1 - m0).abs().max()) <= (2e-6 if log2_T == 14 else 5e-4) * float(m0.abs().max())
     n_zero_mismatch = int(((m1 != 0) != (m0 != 0)).sum())
     assert n_zero_mismatch <= 2e-4 * m0.numel(), n_zero_mismatch   # gradients that cancel, or lie below the image resolution in one route only
     assert torch.equal(res[True][4], res[False][4])  # decoder: same gradient blob, same torch Adam
     dfe = (res[True][3] - res[False][3]).abs() / res[False][3].abs().max()
-    assert int((dfe > 1e-4).sum()) <= 1e-4 * dfe.numel()   # (those entries move by +-lr: see the compaction test)
+    assert int((dfe > 1e-4).sum()) <= (1e-4 if log2_T == 14 else 2e-3) * dfe.numel()   # (those entries move by +-lr: see the compaction test)
 
 
-def test_train_step_large_table_adam_epilogue(S):
+def test_train_step_large_table_adam_epilogue(S, monkeypatch):
     """Tables above 2^21 entries (the reference's default is 2^24) take the stand-alone binned scatter from dfeat; with
-    fused_adam it ends in the same Adam epilogue (no gradient table): bit-identical to accumulate -> adam_step_cuda."""
+    fused_adam it ends in the same Adam epilogue (no gradient table): bit-identical to accumulate -> adam_step_cuda (on the
+    same 16-byte records: SCANERF_REC16; the default 8-byte ones of this route are compared in
+    test_train_step_fgbg_one_adam_step_over_both_branches[22])."""
     from scanerf_amd.tile_model import TileModel, train_step_fused
+    monkeypatch.setenv("SCANERF_REC16", "1")
     torch.manual_seed(21)
     B, S_ = 2048, 64
     o = torch.rand(B, 3, device=DEV) * 8 - 4
