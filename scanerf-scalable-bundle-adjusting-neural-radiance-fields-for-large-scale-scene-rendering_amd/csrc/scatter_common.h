@@ -217,6 +217,8 @@ __device__ __forceinline__ void commit_pairs(const Pairs &pr, const PairSlots &s
 // Rounding: half a unit of the significand (2^-13 .. 2^-12 of the larger component) and 2^-14 in the weight -- measured through
 // the fused path: 1.3e-4 relative L2 against 7e-4 for the products' own noise (tests/test_gpu_parity.py); the
 // accumulate (k_bin_accumulate) works on the integers, so the sum stays bit-reproducible.  Buckets of at most 2^13 entries.
+// (Not representable: inf / NaN gradients -- they come out as finite garbage instead of poisoning the entry as f32 records would;
+// the loss of such a step is already non-finite.)
 constexpr int kRec8MaxBucketLog = 13;
 inline bool fused_rec8(int arith, int bucket_log)
 {
