@@ -36,7 +36,8 @@ SYMBOLS = [
 
 class RenderCfg(ctypes.Structure):
     _fields_ = [("contract_mode", ctypes.c_int), ("infinity", ctypes.c_int),
-                ("min_bbox", ctypes.c_float * 3), ("bbox_size", ctypes.c_float * 3), ("arith", ctypes.c_int)]
+                ("min_bbox", ctypes.c_float * 3), ("bbox_size", ctypes.c_float * 3), ("arith", ctypes.c_int),
+                ("skip_levels", ctypes.c_uint)]
 
 
 ARITH_F32, ARITH_H3, ARITH_T16 = 0, 1, 2

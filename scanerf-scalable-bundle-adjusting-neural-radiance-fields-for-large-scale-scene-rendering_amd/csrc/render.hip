@@ -472,6 +472,7 @@ static int render_forward(const float *rays_o, const float *rays_d, const float 
     a.out_ray = out_ray; a.weights = weights; a.tile_T = tile_T; a.xstash = xstash; a.jstash = jstash;
     a.B = B; a.S = S; a.T = T;
     a.contract_mode = cfg->contract_mode; a.infinity = cfg->infinity;
+    a.skip_levels = getenv("SCANERF_NO_LEVEL_SKIP") ? 0u : cfg->skip_levels;
     for (int k = 0; k < 3; ++k) {
         a.min_bbox[k] = cfg->min_bbox[k];
         a.bbox_size[k] = cfg->bbox_size[k];

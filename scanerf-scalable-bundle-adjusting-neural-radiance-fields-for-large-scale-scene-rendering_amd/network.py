@@ -51,6 +51,12 @@ def xavier_blob(seed=0, device="cpu", bias_scale=0.0, in_channel=32):
     return blob_from_state_dict(sd, in_channel).to(device)
 
 
+def skip_levels(global_step):
+    """Bit l set: weight_feature(global_step) is exactly zero on level l (levels >= alpha of the coarse-to-fine schedule)."""
+    w = weight_feature(global_step)[::2]
+    return int(sum(1 << l for l in range(16) if float(w[l]) == 0.0))
+
+
 def weight_feature(global_step, device="cpu"):
     """Coarse-to-fine level mask of hashgrid/__init__.py:228-235, repeated per feature -> [32]."""
     alpha = max(min(global_step / 10000 * 8 + 8, 16), 0)

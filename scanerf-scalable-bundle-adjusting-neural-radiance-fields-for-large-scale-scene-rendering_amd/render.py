@@ -51,18 +51,24 @@ class PackedDecoder:
     def __init__(self, device):
         self.workspace = torch.empty(lib().scanerf_render_workspace_floats(), dtype=_f32, device=device)
 
-    def pack(self, blob, weight_feature):
+    skip_levels = 0
+
+    def pack(self, blob, weight_feature, skip_levels=0):
+        """skip_levels: bit l = weight_feature is exactly zero on level l (network.skip_levels): render_forward then leaves
+        that level's table alone."""
         if blob.numel() != _capi.PARAMSIZE or weight_feature.numel() != 32:
             raise RuntimeError(f"scanerf: blob must hold {_capi.PARAMSIZE} floats and weight_feature 32")
+        self.skip_levels = int(skip_levels)
         check(lib().scanerf_pack_decoder(dev_ptr(blob, _f32, "mlp_blob"), dev_ptr(weight_feature, _f32, "weight_feature"),
                                          dev_ptr(self.workspace, _f32, "workspace"), stream()), "pack_decoder")
         return self
 
 
-def _cfg(min_bbox, bbox_size, contract_mode, infinity, arith=None):
+def _cfg(min_bbox, bbox_size, contract_mode, infinity, arith=None, skip_levels=0):
     c = RenderCfg()
     c.contract_mode, c.infinity = int(contract_mode), int(bool(infinity))
     c.arith = ARITH if arith is None else arith
+    c.skip_levels = int(skip_levels)
     for k in range(3):
         c.min_bbox[k] = float(min_bbox[k])
         c.bbox_size[k] = float(bbox_size[k])
@@ -111,14 +117,14 @@ def render_forward(rays_o, rays_d, z_vals, dists, features, resolutions, packed,
             if not need or not forward_plan_supported(B, S, T):
                 raise RuntimeError(f"scanerf: render_forward(plan=True) does not support B={B} S={S} T={T}")
             ws = _capi.workspace(z_vals.device, need) if plan_workspace is None else plan_workspace
-        cfg = _cfg(min_bbox, bbox_size, contract_mode, infinity, _capi.ARITH_T16)
+        cfg = _cfg(min_bbox, bbox_size, contract_mode, infinity, _capi.ARITH_T16, getattr(packed, "skip_levels", 0))
         tail = tail[:5] + (dev_ptr(jstash, _f32, "jstash", allow_none=True),) + tail[5:]
         check(lib().scanerf_render_forward_packed_plan(*args, ctypes.byref(cfg), *tail,
                                                        ctypes.c_void_p(ws.data_ptr() if ws is not None else None),
                                                        ctypes.c_size_t(ws.numel() if ws is not None else 0), stream()),
               "render_forward(plan)")
         return (out_ray, weights, ws) if plan else (out_ray, weights)
-    cfg = _cfg(min_bbox, bbox_size, contract_mode, infinity)
+    cfg = _cfg(min_bbox, bbox_size, contract_mode, infinity, skip_levels=getattr(packed, "skip_levels", 0))
     check(lib().scanerf_render_forward_packed(*args, ctypes.byref(cfg), *tail, stream()), "render_forward")
     return out_ray, weights
 

@@ -203,7 +203,7 @@ class TileModel(nn.Module):
     def render_fore_fused(self, rays_o, rays_d, S, global_step):
         z, dist = self.sample(rays_o, rays_d, S)
         valid = torch.all(z != -1, dim=-1)
-        self.packed.pack(self.decoder.blob(), network.weight_feature(global_step, self.device))
+        self.packed.pack(self.decoder.blob(), network.weight_feature(global_step, self.device), network.skip_levels(global_step))
         table = self.gather_table()
         out, w = render.render_forward(rays_o, rays_d, z, dist, table, self.resolution, self.packed,
                                        self.min_bbox.tolist(), self.bbox_size.tolist(), render.FORE, False,
@@ -234,7 +234,7 @@ class TileModel(nn.Module):
     def render_rays_fused(self, rays_o, rays_d, S_fg, S_bg, global_step, invalid_underground=False):
         """tile.py:639-692 on the fused kernels: foreground (occupancy-sampled, contract_fore) and
         background (inverse-z, contract_bg, infinity) renders, merged with the foreground's T_left."""
-        self.packed.pack(self.decoder.blob(), network.weight_feature(global_step, self.device))
+        self.packed.pack(self.decoder.blob(), network.weight_feature(global_step, self.device), network.skip_levels(global_step))
         table = self.gather_table()
         box = (self.min_bbox.tolist(), self.bbox_size.tolist())
         z, dist = self.sample(rays_o, rays_d, S_fg)
@@ -386,7 +386,7 @@ def train_step_fused(model, dec_opt, rays_o, rays_d, target, S, global_step, tab
                 return torch.zeros((), device=dev)
         wf = model.weight_feature(global_step)
         blob = model.decoder.blob()
-        model.packed.pack(blob, wf)
+        model.packed.pack(blob, wf, network.skip_levels(global_step))
         ntile = (S + 31) // 32
         tile_T = torch.empty((B, render.tile_T_columns(S)), device=dev)
         bwd_arith = render.backward_arith(True, pose_grads)
@@ -505,7 +505,7 @@ def fgbg_gradients(model, rays_o, rays_d, target, S_fg, S_bg, global_step, inval
     g_o = g_d = None
     with torch.no_grad():
         wf = model.weight_feature(global_step)
-        model.packed.pack(model.decoder.blob(), wf)
+        model.packed.pack(model.decoder.blob(), wf, network.skip_levels(global_step))
         box = (model.min_bbox.tolist(), model.bbox_size.tolist())
         branches = []
         z, dist = model.sample(rays_o, rays_d, S_fg)
@@ -604,7 +604,7 @@ def train_step_fgbg(model, dec_opt, rays_o, rays_d, target, S_fg, S_bg, global_s
         return (loss, r[3], r[4]) if pose_grads else loss
     with torch.no_grad():
         wf = model.weight_feature(global_step)
-        model.packed.pack(model.decoder.blob(), wf)
+        model.packed.pack(model.decoder.blob(), wf, network.skip_levels(global_step))
         box = (model.min_bbox.tolist(), model.bbox_size.tolist())
         table = model.gather_table()
         with _sec(timer, "sample_points_grid", B * (24 + 2 * 4 * S_fg)):

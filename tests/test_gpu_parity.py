@@ -1299,3 +1299,46 @@ def test_fused_default_path_odd_shapes(S, B, S_):
         np.testing.assert_allclose((g2 / sc).cpu().numpy(), (g1 / sc).cpu().numpy(), rtol=5e-4, atol=5e-4)
     else:
         assert float(g2.abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("step", [0, 3100, 9999])
+def test_coarse_to_fine_level_skip_is_bit_identical(S, step, monkeypatch):
+    """Coarse-to-fine phase (hashgrid/__init__.py:228-235: 8 -> 16 levels over 10 000 iterations): the forward leaves the
+    tables of levels whose mask is exactly zero alone (cfg.skip_levels).  Outputs, weights and the whole training step --
+    table, moments, decoder, pose gradients -- are bit-identical to the run that gathers every level."""
+    from scanerf_amd import network, render
+    from scanerf_amd.tile_model import TileModel, train_step_fused
+    sk = network.skip_levels(step)
+    wfc = network.weight_feature(step)
+    assert all(((sk >> l) & 1) == int(float(wfc[2 * l]) == 0.0) for l in range(16)) and (sk != 0) == (step < 8750)
+    torch.manual_seed(5)
+    B, S_ = 4096, 64
+    o = torch.rand(B, 3, device=DEV) * 8 - 4
+    d = torch.nn.functional.normalize(torch.randn(B, 3, device=DEV), dim=-1)
+    tgt = torch.rand(B, 3, device=DEV)
+    res = {}
+    for tag in ("skip", "all"):
+        if tag == "all":
+            monkeypatch.setenv("SCANERF_NO_LEVEL_SKIP", "1")
+        m = TileModel([-4, -4, -4], [8, 8, 8], DEV, log2_T=14, seed=1)
+        with torch.no_grad():
+            m.features.mul_(30.0)
+        z, dist = m.sample(o, d, S_)
+        m.packed.pack(m.decoder.blob(), network.weight_feature(step, DEV), network.skip_levels(step))
+        box = (m.min_bbox.tolist(), m.bbox_size.tolist(), render.FORE, False)
+        xs = torch.empty(B * S_, 32, device=DEV)
+        out, w = render.render_forward(o, d, z, dist, m.features, m.resolution, m.packed, *box, xstash=xs)
+        opt = torch.optim.Adam(m.decoder.parameters(), lr=1e-3, betas=(0.9, 0.99), eps=1e-15)
+        r = [train_step_fused(m, opt, o, d, tgt, S_, step + i, pose_grads=True) for i in range(2)]
+        res[tag] = (out.clone(), w.clone(), m.features.detach().clone(), m.exp_avg.clone(), m.decoder.blob().detach().clone(),
+                    float(r[-1][0]), r[-1][1].clone(), r[-1][2].clone(), xs.clone())
+    for k in range(8):
+        a_, b_ = res["skip"][k], res["all"][k]
+        assert (a_ == b_) if isinstance(a_, float) else torch.equal(a_, b_), k
+    if sk:   # the skipped levels' encoder outputs are zero in the stash, the others equal
+        xa, xb = res["skip"][8].view(-1, 2, 8, 2), res["all"][8].view(-1, 2, 8, 2)
+        for h in range(2):
+            for j in range(8):
+                lv = 4 * (j >> 1) + 2 * h + (j & 1)
+                both = (sk >> (4 * (j >> 1) + (j & 1))) & (sk >> (4 * (j >> 1) + 2 + (j & 1))) & 1
+                assert torch.equal(xa[:, h, j], torch.zeros_like(xa[:, h, j]) if both else xb[:, h, j]), (h, j, lv)
