@@ -305,6 +305,7 @@ __global__ void __launch_bounds__(kRenderThreads, 2) k_render_fwd_h3(RenderArgs 
             *a.plan_maxbits = 0;
             *a.plan_overflow = 0;
             a.plan_overflow[-1] = (uint32_t)a.plan_rec8;  // scatter_common.h format_word()
+            a.plan_overflow[-2] = a.skip_levels;          // skip_word(): the levels the counts below leave out
         }
     }
     {
@@ -472,7 +473,7 @@ static int render_forward(const float *rays_o, const float *rays_d, const float 
     a.out_ray = out_ray; a.weights = weights; a.tile_T = tile_T; a.xstash = xstash; a.jstash = jstash;
     a.B = B; a.S = S; a.T = T;
     a.contract_mode = cfg->contract_mode; a.infinity = cfg->infinity;
-    a.skip_levels = getenv("SCANERF_NO_LEVEL_SKIP") ? 0u : cfg->skip_levels;
+    a.skip_levels = getenv("SCANERF_NO_LEVEL_SKIP") ? 0u : pair_masked_levels(cfg->skip_levels);
     for (int k = 0; k < 3; ++k) {
         a.min_bbox[k] = cfg->min_bbox[k];
         a.bbox_size[k] = cfg->bbox_size[k];

@@ -639,7 +639,7 @@ SCANERF_API int scanerf_render_backward(const float *rays_o, const float *rays_d
     a.f.rays_o = rays_o; a.f.rays_d = rays_d; a.f.z_vals = z_vals; a.f.dists = dists;
     a.f.features = features; a.f.resolutions = resolutions; a.f.packed = workspace; a.f.ray_valid = ray_valid;
     a.f.out_ray = const_cast<float *>(out_ray); a.f.weights = nullptr; a.f.tile_T = nullptr; a.f.xstash = nullptr;
-    a.f.skip_levels = 0;  // (the re-gathering backward kernels read every level: their x is multiplied by the same zero weights)
+    a.f.skip_levels = 0;  // (the re-gathering kernels read every level; which levels get records is the plan's word in the workspace)
     a.f.B = B; a.f.S = S; a.f.T = T;
     a.f.contract_mode = cfg->contract_mode; a.f.infinity = cfg->infinity;
     for (int k = 0; k < 3; ++k) {

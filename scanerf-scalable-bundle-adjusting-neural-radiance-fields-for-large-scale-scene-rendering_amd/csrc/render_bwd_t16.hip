@@ -218,6 +218,7 @@ __global__ void __launch_bounds__(kThreads, 2) k_render_bwd_t16(BwdArgs a)
     const char *stage = lds + kLdsStage;
     char *stY = lds + kLdsStage + wv * T16_STAGE_WAVE, *stX = stY + T16_STAGE_MAT;
     const int S = a.f.S, nt16 = (S + 15) >> 4;
+    const uint32_t plan_skip = a.recs ? __builtin_amdgcn_readfirstlane(*skip_word(a.recs)) : 0u;   // levels the plan left out
     __builtin_amdgcn_s_setreg(1 | (23 << 6), 1);  // hwreg(HW_REG_MODE, 23, 1) = FP16_OVFL: f16 conversions saturate
 
     // ---- ownership of the weight-gradient blocks
@@ -312,7 +313,7 @@ __global__ void __launch_bounds__(kThreads, 2) k_render_bwd_t16(BwdArgs a)
             const float gx = jj == 0 ? e0[0] : (jj == 1 ? e0[2] : (jj == 2 ? e1[0] : e1[2]));
             const float gy = jj == 0 ? e0[1] : (jj == 1 ? e0[3] : (jj == 2 ? e1[1] : e1[3]));
             if (a.dfeat) reinterpret_cast<float2 *>(a.dfeat)[(size_t)level * a.f.B * S + (size_t)ray * S + s] = make_float2(gx, gy);
-            if (a.recs) {
+            if (a.recs && !((plan_skip >> level) & 1u)) {   // (a masked level's gradient is exactly zero: no records, as planned)
                 const uint32_t mask = (uint32_t)a.f.T - 1u;
                 const int4 r = *reinterpret_cast<const int4 *>(lres + 4 * level);
                 const int32_t rr[3] = { r.x, r.y, r.z };

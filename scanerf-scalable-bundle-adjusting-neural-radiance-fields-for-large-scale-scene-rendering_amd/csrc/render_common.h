@@ -102,4 +102,11 @@ __host__ __device__ constexpr int nmap(int g, int h) { return (g & 3) + 8 * (g >
 __host__ __device__ constexpr int nmap_g(int i5) { return (i5 & 3) + 4 * (i5 >> 3); }
 __host__ __device__ constexpr int nmap_h(int i5) { return (i5 >> 2) & 1; }
 
+// Coarse-to-fine mask -> the levels the kernels leave out: level l only together with l ^ 2, the level the other half-wave
+// handles in the same register pair (encode8), so that the decision is uniform per wave.
+inline unsigned pair_masked_levels(unsigned masked)
+{
+    return masked & (((masked >> 2) & 0x3333u) | ((masked << 2) & 0xccccu));
+}
+
 }  // namespace scanerf

@@ -132,7 +132,8 @@ struct RenderArgs {
     float min_bbox[3], inv_size4[3];  // 4/bbox_size
     float bbox_size[3];
     int dbg;                  // timing experiments only (SCANERF_DEBUG_FWD): 1 = encode only, 2 = decode only
-    uint32_t skip_levels;     // bit l: level l meets exactly-zero weights (coarse-to-fine mask): the forward skips its gathers
+    uint32_t skip_levels;     // bit l: level l AND its half-wave partner l ^ 2 meet exactly-zero weights (coarse-to-fine mask,
+                              // pair_masked_levels): no gathers, no scatter records for them
     // optional: the forward kernel also counts the scatter records the t16 backward will emit for these rays (scatter.hip
     // k_bin_count_rays' job: the hash indices are already in registers here).  counts [16 * NB][W], this workgroup's column
     uint32_t *plan_counts, *plan_maxbits, *plan_overflow;   // (launch maximum and overflow flag are zeroed here; plan_overflow[-1] = format)
@@ -157,6 +158,18 @@ __device__ __forceinline__ void encode8(const RenderArgs &a, const int *lds_res,
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const int level = 4 * (j >> 1) + 2 * h + (j & 1);
+        // coarse-to-fine: skip_levels is symmetric in the two half-waves' levels of a j (render_common.h pair_masked_levels), so
+        // this is wave-uniform -- the table is not touched, no records are counted; the zero weights give the same contribution
+        // for x = 0 as for the features
+        if ((a.skip_levels >> (4 * (j >> 1) + (j & 1))) & 1u) {
+            x[2 * j] = 0.0f;
+            x[2 * j + 1] = 0.0f;
+            if constexpr (JST) {
+                float2 *jr = reinterpret_cast<float2 *>(jrow) + 3 * j * 64;
+                jr[0] = jr[64] = jr[128] = make_float2(0.0f, 0.0f);
+            }
+            continue;
+        }
         const int4 res = reinterpret_cast<const int4 *>(lds_res)[level];
         int b[3];
         float t[3], sc[3];
@@ -176,17 +189,6 @@ __device__ __forceinline__ void encode8(const RenderArgs &a, const int *lds_res,
             const uint32_t two = ((idx[0] ^ idx[4]) >> a.plan_bucket_log) != 0u ? one : 0u;
 #pragma unroll
             for (int q = 0; q < 4; ++q) atomicAdd(&hl[idx[4 + q] >> a.plan_bucket_log], two);
-        }
-        // coarse-to-fine: both half-waves' levels of this j masked (wave-uniform) -> the table is not touched; the zero weights
-        // give the same contribution for x = 0 as for the features
-        if (a.skip_levels != 0u && ((a.skip_levels >> (4 * (j >> 1) + (j & 1))) & (a.skip_levels >> (4 * (j >> 1) + 2 + (j & 1))) & 1u)) {
-            x[2 * j] = 0.0f;
-            x[2 * j + 1] = 0.0f;
-            if constexpr (JST) {
-                float2 *jr = reinterpret_cast<float2 *>(jrow) + 3 * j * 64;
-                jr[0] = jr[64] = jr[128] = make_float2(0.0f, 0.0f);
-            }
-            continue;
         }
         const char *slice = (const char *)a.features + (size_t)level * a.T * TableElem<DT>::bytes;
         float2 f[8];

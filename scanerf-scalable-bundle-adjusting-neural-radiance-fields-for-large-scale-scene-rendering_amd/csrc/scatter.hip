@@ -449,6 +449,7 @@ __global__ void __launch_bounds__(1024) k_bin_count_rays(RenderArgs f, BinGeom g
         *maxbits = 0;
         *overflow = 0;
         overflow[-1] = (uint32_t)g.rec8;  // format_word(): what the backward will emit and the accumulate must decode
+        overflow[-2] = f.skip_levels;     // skip_word(): the levels left out below
     }
     const int nbins = 16 * g.NB;
     for (int i = threadIdx.x; i < nbins; i += 1024) hist[i] = 0;
@@ -474,6 +475,7 @@ __global__ void __launch_bounds__(1024) k_bin_count_rays(RenderArgs f, BinGeom g
         }
         contract_point(f, o, d, f.z_vals[(size_t)ray * f.S + s], p);
         for (int l = 0; l < 16; ++l) {
+            if ((f.skip_levels >> l) & 1u) continue;   // coarse-to-fine: a masked level's gradients are exactly zero, no records
             Pairs pr;
             make_pairs(p, f.resolutions + 3 * l, mask, pr);
             count_pairs(pr, hist + l * g.NB, g.bucket_log);
@@ -525,7 +527,7 @@ SCANERF_API size_t scanerf_embedding_bwd_workspace_bytes(int N, int L, int T)
     if ((int64_t)N * L * 4 + (1 << 20) >= (int64_t)1 << 31) return 0;  // 32-bit record offsets
     const int W = 1024;
     const size_t recs = ((size_t)N * L * 4 + (size_t)N * L / 8 + 4096) * sizeof(Rec);
-    return recs + (size_t)nbins * W * 4 + (size_t)(2 * nbins + 4) * 4 + 256;
+    return recs + (size_t)nbins * W * 4 + (size_t)(2 * nbins + 6) * 4 + 256;
 }
 
 // grad_features += scatter(grad_in) through the binned path.  grad_layout: 0 = [N][L][2], 1 = [L][N][2].
@@ -689,6 +691,8 @@ SCANERF_API int scanerf_render_scatter_plan(const float *rays_o, const float *ra
     f.rays_o = rays_o; f.rays_d = rays_d; f.z_vals = z_vals; f.resolutions = resolutions; f.ray_valid = ray_valid;
     f.B = B; f.S = S; f.T = T;
     f.contract_mode = cfg->contract_mode; f.infinity = cfg->infinity;
+    // (only the t16 backward leaves masked levels' records out; the other two emit every level)
+    f.skip_levels = (cfg->arith == SCANERF_ARITH_T16 && !getenv("SCANERF_NO_LEVEL_SKIP")) ? pair_masked_levels(cfg->skip_levels) : 0u;
     for (int k = 0; k < 3; ++k) {
         f.min_bbox[k] = cfg->min_bbox[k];
         f.bbox_size[k] = cfg->bbox_size[k];

@@ -38,6 +38,9 @@ __host__ __device__ inline uint32_t *overflow_flag(Rec *recs) { return reinterpr
 // The word before that: the record format the plan chose (0 = Rec, 1 = Rec8); the accumulate of a fused plan reads it, so
 // plan, producer and consumer cannot disagree about the stream they share.
 __host__ __device__ inline uint32_t *format_word(Rec *recs) { return reinterpret_cast<uint32_t *>(recs) - 2; }
+// ... and before that: the levels the plan left out (coarse-to-fine mask: their gradients are exactly zero); the t16 backward
+// reads it here and emits no records for them.
+__host__ __device__ inline uint32_t *skip_word(Rec *recs) { return reinterpret_cast<uint32_t *>(recs) - 3; }
 
 // One 16-byte record store.  Plain (write-back) stores: measured in the two-waves-per-SIMD backward kernel, non-temporal
 // stores of the same records take 2.7x the kernel's time (14.2 vs 5.2 ms) and sc1 (write-through) ones 1.5x: the records of
@@ -328,10 +331,10 @@ struct BinWorkspace {
     Rec *recs;
     uint32_t capacity;
 };
-// [counts nbins*W][totals nbins][starts nbins+1][maxbits][... pad ...][format word][overflow flag = the word right before the records]
+// [counts nbins*W][totals nbins][starts nbins+1][maxbits][... pad ...][skipped levels][format word][overflow flag = the word right before the records]
 inline size_t bin_workspace_head(int nbins, int W)
 {
-    size_t head = ((size_t)nbins * W + 2 * (size_t)nbins + 4) * 4;
+    size_t head = ((size_t)nbins * W + 2 * (size_t)nbins + 6) * 4;
     return (head + 255) & ~(size_t)255;
 }
 // (capacity counts 16-byte records; a Rec8 stream holds twice as many: rec_capacity())

@@ -256,7 +256,7 @@ def scatter_supported(B, S, T):
 
 
 def scatter_plan(rays_o, rays_d, z_vals, resolutions, T, min_bbox, bbox_size, contract_mode, infinity, ray_valid=None,
-                 arith=None, workspace=None):
+                 arith=None, workspace=None, skip_levels=0):
     """Reserve the record ranges of the fused table-gradient path for this batch (count + scan).
     Returns the workspace tensor to hand to render_backward(scatter=(ws, grad_features)) and scatter_accumulate.
     The workspace is a per-(device, stream) cache: one plan/backward/accumulate sequence at a time.
@@ -269,7 +269,8 @@ def scatter_plan(rays_o, rays_d, z_vals, resolutions, T, min_bbox, bbox_size, co
     # (workspace: a caller-owned uint8 tensor instead of the cached one; smaller than `need` = overflow records take the
     # atomic path -- tests)
     ws = _capi.workspace(z_vals.device, need) if workspace is None else workspace
-    cfg = _cfg(min_bbox, bbox_size, contract_mode, infinity, backward_arith() if arith is None else arith)
+    # skip_levels (PackedDecoder.skip_levels): masked levels get no records; the plan notes it in the workspace for the backward
+    cfg = _cfg(min_bbox, bbox_size, contract_mode, infinity, backward_arith() if arith is None else arith, skip_levels)
     check(lib().scanerf_render_scatter_plan(
         dev_ptr(rays_o, _f32, "rays_o"), dev_ptr(rays_d, _f32, "rays_d"), dev_ptr(z_vals, _f32, "z_vals"),
         dev_ptr(resolutions, torch.int32, "resolutions"), ctypes.byref(cfg),

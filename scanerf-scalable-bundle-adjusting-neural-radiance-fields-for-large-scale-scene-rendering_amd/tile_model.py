@@ -407,7 +407,7 @@ def train_step_fused(model, dec_opt, rays_o, rays_d, target, S, global_step, tab
             # so it is off by default
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
-                ws = render.scatter_plan(rays_o, rays_d, z, model.resolution, T, *box, ray_valid=valid, arith=bwd_arith)
+                ws = render.scatter_plan(rays_o, rays_d, z, model.resolution, T, *box, ray_valid=valid, arith=bwd_arith, skip_levels=model.packed.skip_levels)
                 plan_done = torch.cuda.Event()
                 plan_done.record(side)
         # gather table: the fp32 master itself, or its resident bf16/f16 copy (configs[2]: half the gather bytes, fp32 accumulate)
@@ -441,7 +441,7 @@ def train_step_fused(model, dec_opt, rays_o, rays_d, target, S, global_step, tab
         if fused and ws is None:
             # count + scan of the scatter records (depends on the sample positions only)
             with _sec(timer, "scatter_plan", B * S * 4):
-                ws = render.scatter_plan(rays_o, rays_d, z, model.resolution, T, *box, ray_valid=valid, arith=bwd_arith)
+                ws = render.scatter_plan(rays_o, rays_d, z, model.resolution, T, *box, ray_valid=valid, arith=bwd_arith, skip_levels=model.packed.skip_levels)
         elif plan_done is not None:
             torch.cuda.current_stream().wait_event(plan_done)
         # forward recompute + activation gradients + weight gradients = 3x the forward MLP FLOPs
@@ -536,7 +536,7 @@ def fgbg_gradients(model, rays_o, rays_d, target, S_fg, S_bg, global_step, inval
         for (z_, d_, v_, mode, inf), out, leaf, (tile_T, xs, js) in zip(branches, outs, (fg, bg), state):
             S = z_.shape[1]
             fused = T <= (1 << 21) and render.scatter_supported(B, S, T) and collect is None  # (see train_step_fused)
-            ws = render.scatter_plan(rays_o, rays_d, z_, model.resolution, T, *box, mode, inf, ray_valid=v_) if fused else None
+            ws = render.scatter_plan(rays_o, rays_d, z_, model.resolution, T, *box, mode, inf, ray_valid=v_, skip_levels=model.packed.skip_levels) if fused else None
             bufs = (torch.zeros(B, (S + 31) // 32, device=dev), torch.zeros(B, 2, 64, device=dev)) if pose_grads else None
             rp = torch.zeros(B, 6, device=dev) if pose_grads else None
             with _sec(timer, "render_backward"):
@@ -637,7 +637,7 @@ def train_step_fgbg(model, dec_opt, rays_o, rays_d, target, S_fg, S_bg, global_s
         for (z_, d_, v_, mode, inf, S), out, g, (tile_T, xs, ws, js), wsbuf in zip(branches, outs, (gfg, gbg), state, (None, model._ws_bg)):
             if ws is None:
                 with _sec(timer, "scatter_plan", B * S * 4):
-                    ws = render.scatter_plan(rays_o, rays_d, z_, model.resolution, T, *box, mode, inf, ray_valid=v_, workspace=wsbuf)
+                    ws = render.scatter_plan(rays_o, rays_d, z_, model.resolution, T, *box, mode, inf, ray_valid=v_, workspace=wsbuf, skip_levels=model.packed.skip_levels)
             bufs = (torch.zeros(B, (S + 31) // 32, device=dev), torch.zeros(B, 2, 64, device=dev)) if pose_grads else None
             rp = torch.zeros(B, 6, device=dev) if pose_grads else None
             with _sec(timer, "render_backward", B * (24 + 20 + S * 16 * 8 * 2 * 4 + S * 16 * 8), 3 * B * S * MLP_FLOPS_PER_SAMPLE):
