@@ -339,6 +339,9 @@ int scanerf_update_outgoing_bidx(const float *rays_o, const float *rays_d, const
 int scanerf_update_outgoing_bidx_v2(const float *rays_o, const float *corners, const float *sizes,
                                     int16_t *inside_bidxs, float *blend_weights, int B, int nb,
                                     scanerf_stream_t stream);                                  /* :1406-1474 */
+/* The tile order rendering.py:301 gets from torch.argsort(intersections[..., 0], dim=-1) (stable): order [B,nb] i32 = the
+ * ray's tiles by entry distance (misses, 1e7, last; equal distances by tile index).  nb <= 64. */
+int scanerf_sort_tracing_blocks(const float *inter, int32_t *order, int B, int nb, scanerf_stream_t stream);
 int scanerf_get_last_block(const int32_t *tracing_blocks, int32_t *bidxs, const float *intersections, int B,
                            int nb, scanerf_stream_t stream);                                   /* :1212-1260 */
 int scanerf_ray_firsthit_block(const float *rays_o, const float *rays_d, const float *corners, const float *sizes,

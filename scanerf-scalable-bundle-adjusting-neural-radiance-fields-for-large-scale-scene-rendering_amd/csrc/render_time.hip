@@ -1013,6 +1013,36 @@ SCANERF_API int scanerf_update_outgoing_bidx_v2(const float *rays_o, const float
     return check_launch("update_outgoing_bidx_v2");
 }
 
+// Tile order per ray = torch.argsort(intersections[..., 0], dim=-1, stable=True) (rendering.py:301 sorts the tiles a ray
+// meets by their entry distance; misses hold 1e7): one thread per ray, stable insertion sort of its nb <= 64 entries.
+namespace {
+__global__ void __launch_bounds__(256) k_sort_tracing_blocks(const float *__restrict__ inter, int32_t *__restrict__ order, int nb, int B)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < B; i += gridDim.x * blockDim.x) {
+        const float2 *ci = reinterpret_cast<const float2 *>(inter) + (size_t)i * nb;
+        int32_t *out = order + (size_t)i * nb;
+        for (int b = 0; b < nb; ++b) {
+            const float key = ci[b].x;
+            int pos = b;
+            while (pos > 0 && ci[out[pos - 1]].x > key) {   // strictly greater: equal keys keep their index order
+                out[pos] = out[pos - 1];
+                --pos;
+            }
+            out[pos] = b;
+        }
+    }
+}
+}  // namespace
+
+SCANERF_API int scanerf_sort_tracing_blocks(const float *inter, int32_t *order, int B, int nb, scanerf_stream_t stream)
+{
+    RT_REQ(B >= 0 && nb >= 1 && nb <= 64, "sort_tracing_blocks");
+    if (B == 0) return 0;
+    RT_REQ(inter && order, "sort_tracing_blocks");
+    hipLaunchKernelGGL(k_sort_tracing_blocks, dim3(stream_grid(B, 256)), dim3(256), 0, (hipStream_t)stream, inter, order, nb, B);
+    return check_launch("sort_tracing_blocks");
+}
+
 SCANERF_API int scanerf_get_last_block(const int32_t *tracing_blocks, int32_t *bidxs, const float *inter, int B, int nb,
                                        scanerf_stream_t stream)
 {

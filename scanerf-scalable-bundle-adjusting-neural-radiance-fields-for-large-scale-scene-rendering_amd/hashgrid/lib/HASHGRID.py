@@ -153,6 +153,17 @@ def _S(z_vals, sample_major):
     return _I(z_vals.shape[0] if int(sample_major) == 1 else z_vals.shape[1])
 
 
+def sort_tracing_blocks(intersections):
+    """torch.argsort(intersections[..., 0], dim=-1, stable=True).int() (rendering.py:301) in one launch: [B,nb] i32."""
+    B, nb = intersections.shape[:2]
+    if nb > 64:
+        return torch.argsort(intersections[..., 0], dim=-1, stable=True).int().contiguous()
+    order = torch.empty((B, nb), dtype=torch.int32, device=intersections.device)
+    check(lib().scanerf_sort_tracing_blocks(dev_ptr(intersections, _f32, "intersections"), dev_ptr(order, _i32, "order"), _I(B), _I(nb),
+                                            stream()), "sort_tracing_blocks")
+    return order
+
+
 def sample_points(rays_o, rays_d, block_corners, block_sizes, grid_occupied, grid_starts, grid_log2dim, tracing_blocks,
                   intersections, tracing_idx, z_start, z_vals, dists, sample_major=False):
     check(lib().scanerf_render_sample_points(

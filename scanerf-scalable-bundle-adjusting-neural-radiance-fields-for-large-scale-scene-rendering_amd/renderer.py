@@ -14,7 +14,7 @@ import torch
 from . import network
 from .cuda import compute_ray_forward
 from .hashgrid import (accumulate_color, bg_pts_inference_v2, inverse_z_sampling, prepare_points, process_occupied_grid,
-                       pts_inference, ray_block_intersection, sample_points, update_outgoing_bidx)
+                       pts_inference, ray_block_intersection, sample_points, sort_tracing_blocks, update_outgoing_bidx)
 
 
 def export_tile(path, model):
@@ -93,7 +93,7 @@ class TileSetRenderer:
         shp = {0: lambda S, *tail: (B, S, *tail), 1: lambda S, *tail: (S, B, *tail), 2: lambda S, *tail: (B // 32, S, 32, *tail)}[lay]
         inter = torch.full((B, nb, 2), 1e7, device=dev)
         ray_block_intersection(rays_o, rays_d, self.block_corner, self.block_size, inter)
-        tracing_blocks = torch.argsort(inter[..., 0], dim=-1, stable=True).int().contiguous()
+        tracing_blocks = sort_tracing_blocks(inter)   # = torch.argsort(inter[..., 0], dim=-1, stable=True)
         max_tracing = int(torch.mean((inter != 1e7).float(), dim=-1).sum(dim=-1).max().cpu())
         transp = torch.ones(B, 1, device=dev)
         dif, spec, depth = torch.zeros(B, 3, device=dev), torch.zeros(B, 3, device=dev), torch.zeros(B, 1, device=dev)

@@ -310,3 +310,20 @@ def test_packed_decoders_follow_their_owner_not_an_address():
     assert torch.equal(infer(p2), out2) and torch.equal(infer(p3), out3) and len(HG._images) == 2
     p3.mul_(0.5)
     assert not torch.equal(infer(p3), out3)
+
+
+def test_sort_tracing_blocks_equals_stable_argsort():
+    """The renderer's per-ray tile order (rendering.py:301) in one launch: identical to torch.argsort(near, stable=True),
+    with misses (1e7), equal distances and nb from 1 to 64."""
+    import scanerf_amd  # noqa
+    from scanerf_amd import hashgrid as H
+    gen = torch.Generator(device=DEV).manual_seed(3)
+    for B, nb in ((1, 1), (1000, 2), (70001, 4), (513, 9), (300, 64)):
+        inter = torch.rand(B, nb, 2, device=DEV, generator=gen) * 20
+        inter[torch.rand(B, nb, device=DEV, generator=gen) < 0.4] = 1e7            # tiles the ray misses
+        dup = torch.rand(B, device=DEV, generator=gen) < 0.3
+        if nb > 1:
+            inter[dup, nb - 1, 0] = inter[dup, 0, 0]                               # equal entry distances
+        got = H.sort_tracing_blocks(inter.contiguous())
+        want = torch.argsort(inter[..., 0], dim=-1, stable=True).int()
+        assert got.dtype == torch.int32 and torch.equal(got, want), (B, nb)
