@@ -111,7 +111,10 @@ __device__ __forceinline__ v4f t16_mfma(const t16_h8 &a, const t16_h8 &b, const 
 template <int NB, int KS>
 __device__ __forceinline__ void t16_layer(v4f u[NB], const char *img, int base, int lo16, const T16HL B[KS])
 {
-    constexpr int G = NB < 2 ? NB : 2;  // blocks per group: their A operands (hi, lo) are the registers in flight
+#ifndef T16_GROUP
+#define T16_GROUP 2
+#endif
+    constexpr int G = NB < T16_GROUP ? NB : T16_GROUP;  // blocks per group: their A operands (hi, lo) are the registers in flight
 #pragma unroll
     for (int b0 = 0; b0 < NB; b0 += G)
 #pragma unroll
