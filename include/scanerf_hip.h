@@ -148,8 +148,7 @@ typedef struct {
                   on hi/lo-split operands, three products per term: f32-equivalent results, csrc/render_h3.h) or
                   SCANERF_ARITH_T16 (forward as H3; backward on 16-sample tiles at two waves per SIMD with the
                   forward recompute in H3 and the gradient products on one f16 MFMA per term, csrc/render_t16.h;
-                  needs the x-stash, has no pose-gradient outputs).  plan / backward / accumulate of one step
-                  must be given the same value */
+                  needs the x-stash).  plan / backward / accumulate of one step must be given the same value */
     unsigned skip_levels; /* bit l set: level l's inputs meet exactly-zero first-layer weights (the coarse-to-fine mask,
                              hashgrid/__init__.py:228-235, folded into the packed decoder), so scanerf_render_forward* may
                              leave the level's table alone (its encoder outputs become 0: same results bit for bit).  0 = none */
