@@ -316,8 +316,9 @@ __global__ void __launch_bounds__(256, 2) k_pts_inference(InferArgs a)
             for (int c = 0; c < 3; ++c) { dif[c] /= weight; spc[c] /= weight; }
             alpha /= weight;
         }
-        // fg writes every sample (zeros when no tile applies, :569-571); bg only rays with a tile (:1032-1036)
-        const bool wr = in_range && h == 0 && (!BG || a.block_idxs[i * kMaxPtsBlocks + a.step] != -1);
+        // every sample is written: fg zeros when no tile applies (:569-571); bg rays without a tile at this blend step -- which
+        // the reference leaves as its caller cleared them (:1032-1036, rendering.py:493-495) -- get their zeros here
+        const bool wr = in_range && h == 0;
         if (wr) {
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
@@ -375,7 +376,16 @@ __global__ void __launch_bounds__(kChunkThreads, 1) k_pts_inference_chunks(Infer
                 if (BG) {
                     int ri, rs;
                     pt_decompose(e32, (uint32_t)a.B, (uint32_t)a.S, a.sm, ri, rs);
-                    mark(a.block_idxs[ri * kMaxPtsBlocks + a.step]);
+                    const int tb = a.block_idxs[ri * kMaxPtsBlocks + a.step];
+                    mark(tb);
+                    if (tb < 0) {  // no background tile at this blend step: the sample's outputs are zero (the caller need not clear them)
+                        a.out_alpha[e] = 0.0f;
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) {
+                            a.out_dif[3 * e + c] = 0.0f;
+                            a.out_spec[3 * e + c] = 0.0f;
+                        }
+                    }
                 } else {
                     const uint2 raw = *reinterpret_cast<const uint2 *>(a.block_idxs + (size_t)e32 * kMaxPtsBlocks);
                     const int s0 = (int16_t)(raw.x & 0xffffu), s1 = (int16_t)(raw.x >> 16), s2 = (int16_t)(raw.y & 0xffffu),

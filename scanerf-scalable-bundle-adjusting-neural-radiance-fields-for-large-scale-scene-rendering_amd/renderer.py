@@ -84,6 +84,11 @@ class TileSetRenderer:
         dev, nb = self.device, self.block_corner.shape[0]
         lay = int(os.environ.get("SCANERF_RENDER_LAYOUT", layout))  # (env: A/B timing)
         n_rays = rays_o.shape[0]
+        # the single-pass comparison kernel (SCANERF_RENDER_ARITH=f32; also what > 64 tiles or >= 2^31 samples fall back to)
+        # reads the reference's [B,S] arrays only
+        if (os.environ.get("SCANERF_RENDER_ARITH", "").startswith("f") or nb > 64
+                or (n_rays + 31) * max(num_sample, num_bg_sample) >= 2 ** 31):
+            lay = 0
         if lay == 2 and n_rays % 32:  # pad with copies of the last ray
             pad = 32 - n_rays % 32
             rays_o = torch.cat([rays_o, rays_o[-1:].expand(pad, 3)]).contiguous()
@@ -133,7 +138,7 @@ class TileSetRenderer:
         for i in range(n_blend):
             zb = torch.full(shp(num_bg_sample), -1.0, device=dev)
             inverse_z_sampling(inter, bg_b[:, i].contiguous(), zb, sample_range, sample_major=sm)
-            pd.zero_(), ps.zero_(), pa.zero_()
+            # (bg_pts_inference_v2 writes every sample: zeros where the ray has no background tile at this blend step)
             bg_pts_inference_v2(rays_o, rays_d, zb, bg_b, i, self.block_corner, self.block_size, self.resolution,
                                 self.feature_tables, self.packed, pd, ps, pa, sample_major=sm)
             t1 = torch.ones(B, 1, device=dev)
