@@ -343,6 +343,16 @@ def test_trainer_refines_poses_through_the_complete_iteration():
     foreground + T_left * background iteration with both branches' ray gradients (train_step_fgbg(pose_grads=True)); the pose
     parameters receive gradients and move, the table and the decoder train."""
     import scanerf_amd  # noqa
+    from scanerf_amd import cameras as CM, render, trainer
+    from scanerf_amd.tile_model import TileModel
+    render.set_arith("t16")   # (the in-kernel pose path of both branches is the t16 backward's)
+    try:
+        _trainer_complete_iteration_case()
+    finally:
+        render.set_arith(render.DEFAULT_ARITH)
+
+
+def _trainer_complete_iteration_case():
     from scanerf_amd import cameras as CM, trainer
     from scanerf_amd.tile_model import TileModel
     torch.manual_seed(1)

@@ -18,6 +18,23 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
+def _with_arith(name):
+    """Decorator: run the test under render.set_arith(name), whatever SCANERF_ARITH says, and restore the default after."""
+    import functools
+
+    def deco(fn):
+        @functools.wraps(fn)
+        def wrapper(*a, **k):
+            from scanerf_amd import render
+            render.set_arith(name)
+            try:
+                return fn(*a, **k)
+            finally:
+                render.set_arith(render.DEFAULT_ARITH)
+        return wrapper
+    return deco
+
+
 @pytest.fixture(scope="module")
 def S():
     import scanerf_amd  # noqa: F401
@@ -658,6 +675,15 @@ def test_ray_gradients_vs_oracle_autograd(S, bg, arith):
     h3: the 32-sample-tile backward re-gathering its inputs; t16: the default backward (x-stash, f16 gradient products), whose
     per-ray sums (g_dnorm, g_rowsum) are also compared with the h3 kernel's."""
     from scanerf_amd import network, render
+    render.set_arith(arith)
+    try:
+        _ray_gradients_case(bg, arith)
+    finally:
+        render.set_arith(render.DEFAULT_ARITH)
+
+
+def _ray_gradients_case(bg, arith):
+    from scanerf_amd import network, render
     rng = np.random.default_rng(14)
     B, S_, T = 150, 64, 2 ** 12
     o, d, z, dist, feat = _render_inputs(rng, B, S_, T, bg)
@@ -1093,6 +1119,7 @@ def test_rec8_codec_against_its_restatement(S):
         assert np.all(np.abs(o[:, col1] - w1_true * v) <= big * (2.0 ** -12 + 2.0 ** -14) + 2.0 ** -139)
 
 
+@_with_arith("t16")
 def test_forward_counts_the_scatter_plan(S, monkeypatch):
     """render_forward(plan=True): the forward kernel fills the t16 backward's record plan itself (csrc/render.hip COUNT).
     Same workspace head (counts, totals, starts, format word, flags) as scatter_plan, same outputs; and the training step
@@ -1149,6 +1176,7 @@ def test_forward_counts_the_scatter_plan(S, monkeypatch):
 
 
 @pytest.mark.parametrize("log2_T,scale", [(10, 1.0), (12, 1.0), (21, 1.0), (14, 1e22), (14, 1e-22), (14, 0.0)])
+@_with_arith("t16")
 def test_fused_records_table_sizes_and_gradient_ranges(S, log2_T, scale):
     """The default (t16, 8-byte records, counts in the forward kernel) table-gradient path at the ends of its geometry -- one
     bucket per level (T = 2^10, 2^12), 256 buckets per level (2^21) -- and of the value range: upstream gradients scaled by
@@ -1196,6 +1224,7 @@ def test_fused_records_table_sizes_and_gradient_ranges(S, log2_T, scale):
     assert l2 < 3e-4
 
 
+@_with_arith("t16")
 def test_fused_step_with_no_valid_ray(S):
     """A batch in which no ray meets occupied space (hashgrid/__init__.py:419-434 then renders nothing): the fused step runs on
     zero records, the loss is finite, table and moments do not move."""
@@ -1214,6 +1243,7 @@ def test_fused_step_with_no_valid_ray(S):
     assert torch.equal(m.features.detach(), before) and float(m.exp_avg.abs().max()) == 0.0
 
 
+@_with_arith("t16")
 def test_fgbg_iteration_ray_gradients_vs_oracle(S):
     """The complete iteration with pose refinement (tile.py:639-692 under CAMOPT): dL/d(rays_o), dL/d(rays_d) of the merged
     foreground + T_left * background prediction from train_step_fgbg(pose_grads=True) -- both branches' ray gradients formed
@@ -1257,6 +1287,7 @@ def test_fgbg_iteration_ray_gradients_vs_oracle(S):
 
 
 @pytest.mark.parametrize("B,S_", [(1, 1), (9, 17), (255, 16), (2049, 33), (4100, 130), (2048, 15)])
+@_with_arith("t16")
 def test_fused_default_path_odd_shapes(S, B, S_):
     """The default fused path at the ragged ends of its shapes: one ray, one sample, sample counts that are not multiples of
     16 or 32 (partial tiles), ray counts just past a multiple of the 8 rays a workgroup visits, with and without the plan in
@@ -1302,6 +1333,7 @@ def test_fused_default_path_odd_shapes(S, B, S_):
 
 
 @pytest.mark.parametrize("step", [0, 3100, 9999])
+@_with_arith("t16")
 def test_coarse_to_fine_level_skip_is_bit_identical(S, step, monkeypatch):
     """Coarse-to-fine phase (hashgrid/__init__.py:228-235: 8 -> 16 levels over 10 000 iterations): the forward leaves the
     tables of levels whose mask is exactly zero alone (cfg.skip_levels).  Outputs, weights and the whole training step --
