@@ -1162,6 +1162,7 @@ def test_forward_counts_the_scatter_plan(S, monkeypatch):
     d = torch.nn.functional.normalize(torch.randn(B, 3, device=DEV), dim=-1) * (0.5 + torch.rand(B, 1, device=DEV))
     tgt = torch.rand(B, 3, device=DEV)
     res = {}
+    monkeypatch.delenv("SCANERF_NO_FORWARD_PLAN", raising=False)
     for tag in ("forward", "separate"):
         if tag == "separate":
             monkeypatch.setenv("SCANERF_NO_FORWARD_PLAN", "1")
@@ -1349,6 +1350,7 @@ def test_coarse_to_fine_level_skip_is_bit_identical(S, step, monkeypatch):
     d = torch.nn.functional.normalize(torch.randn(B, 3, device=DEV), dim=-1)
     tgt = torch.rand(B, 3, device=DEV)
     res = {}
+    monkeypatch.delenv("SCANERF_NO_LEVEL_SKIP", raising=False)
     for tag in ("skip", "all"):
         if tag == "all":
             monkeypatch.setenv("SCANERF_NO_LEVEL_SKIP", "1")
