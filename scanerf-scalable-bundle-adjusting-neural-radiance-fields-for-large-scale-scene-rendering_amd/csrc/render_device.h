@@ -350,7 +350,11 @@ __device__ __forceinline__ SampleOut decode_tile(const float *lds, int lane, con
 
 // hash-encode 8 levels at p01 in [0,1]^3 (rendering_kernel.cu:79-114: v = p01*(res-1), no (p+2)/4 step);
 // same register<->level map as encode8.  Lanes with active == false issue no loads.
-template <int DT, int GATHER_BATCH = 2>
+// STRAIGHT: no branch anywhere -- inactive lanes gather too (any in-table address) and get zeros, the corners come through
+// eight single loads whatever the parity of x.  The render-time kernels' gathers are bound by their round trips (with one lane
+// in eight gathering the frame takes the same time), and only straight-line code lets the loads of GATHER_BATCH levels go out
+// together.
+template <int DT, int GATHER_BATCH = 2, bool STRAIGHT = false>
 __device__ __forceinline__ void encode8_01(const void *table, const int32_t *res, int T, int h, const float p01[3],
                                            bool active, v16f &x)
 {
@@ -359,7 +363,7 @@ __device__ __forceinline__ void encode8_01(const void *table, const int32_t *res
     for (int j = 0; j < 8; ++j) {
         const int level = 4 * (j >> 1) + 2 * h + (j & 1);
         float ax = 0.0f, ay = 0.0f;
-        if (active) {
+        if (STRAIGHT || active) {
 #pragma clang fp contract(off)
             int b[3];
             float t[3];
@@ -375,7 +379,7 @@ __device__ __forceinline__ void encode8_01(const void *table, const int32_t *res
             trilinear_weights(w, t[0], t[1], t[2]);
             const char *slice = (const char *)table + (size_t)level * T * TableElem<DT>::bytes;
             float2 f[8];
-            if constexpr (DT != SCANERF_F32) {
+            if constexpr (DT != SCANERF_F32 && !STRAIGHT) {
                 gather_cell<DT>(slice, idx, b[0] & 1, f);
             } else {
 #pragma unroll
@@ -386,6 +390,7 @@ __device__ __forceinline__ void encode8_01(const void *table, const int32_t *res
                 ax = fmaf(w[c], f[c].x, ax);
                 ay = fmaf(w[c], f[c].y, ay);
             }
+            if (STRAIGHT && !active) ax = ay = 0.0f;
         }
         x[2 * j] = ax;
         x[2 * j + 1] = ay;

@@ -344,7 +344,10 @@ __global__ void __launch_bounds__(256, 2) k_pts_inference(InferArgs a)
 // 8 waves share one staged image (two per SIMD; with 4, the 104 KB image left one wave per SIMD and the decoder's dependent
 // MFMA chains exposed: 3.3e9 samples/s whatever the gathers did)
 #ifndef RT_GATHER_BATCH
-#define RT_GATHER_BATCH 2
+#define RT_GATHER_BATCH 8
+#endif
+#ifndef RT_STRAIGHT
+#define RT_STRAIGHT true
 #endif
 constexpr int kChunkThreads = 512, kChunkWaves = kChunkThreads / 64, kChunkWaveGroups = 16;
 template <bool BG>
@@ -506,9 +509,12 @@ __global__ void __launch_bounds__(kChunkThreads, 1) k_pts_inference_chunks(Infer
         if (a.dbg == 2) {
 #pragma unroll
             for (int g2 = 0; g2 < 16; ++g2) x[g2] = p01[g2 % 3] * (0.01f * g2);
+        } else if (a.dbg == 3 || a.dbg == 4) {  // only one lane in 8 (3) / 4 (4) gathers: what would fewer lane-loads buy?
+            encode8_01<SCANERF_F16, RT_GATHER_BATCH>((const char *)a.tables + (size_t)b * 16 * a.T * 4, a.res + (size_t)b * 48, a.T, h, p01,
+                                                      run && ((lane & (a.dbg == 3 ? 7 : 3)) == 0), x);
         } else
 #endif
-        encode8_01<SCANERF_F16, RT_GATHER_BATCH>((const char *)a.tables + (size_t)b * 16 * a.T * 4, a.res + (size_t)b * 48, a.T, h, p01, run, x);
+        encode8_01<SCANERF_F16, RT_GATHER_BATCH, RT_STRAIGHT>((const char *)a.tables + (size_t)b * 16 * a.T * 4, a.res + (size_t)b * 48, a.T, h, p01, run, x);
         v16f dinit[2];
         {
             float sh[16];
