@@ -31,7 +31,14 @@ typedef float f2v __attribute__((ext_vector_type(2)));
 namespace scanerf {
 
 __host__ __device__ constexpr int h3_ku(int t, int h, int j) { return 16 * t + 8 * (j >> 2) + 4 * h + (j & 3); }
-__device__ __forceinline__ int h3_lane_off(int lane) { return (lane & 31) * 16 + (lane >> 5) * 576; }
+// (opaque to the optimiser: seeing lane >> 5 as a 0/1 value it otherwise turns every `image offset + lane offset` into its own
+// select of two constants -- one address register per weight read, ~35 of them live across the sample loop)
+__device__ __forceinline__ int h3_lane_off(int lane)
+{
+    int r = (lane & 31) * 16 + (lane >> 5) * 576;
+    asm volatile("" : "+v"(r));
+    return r;
+}
 
 // ---- operand split
 struct HL {
@@ -153,9 +160,13 @@ __device__ __forceinline__ v16f h3_ld16(const char *img, int byte_off)  // 16 f3
     const float4 a = p[0], b = p[1], c = p[2], d = p[3];
     return v16f{ a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w, d.x, d.y, d.z, d.w };
 }
+// (the f32 tail lies past 64 KB, beyond the immediate of an LDS read: one opaque base register for all of them, or each of the
+// 32 reads keeps an address register of its own live across the sample loop)
 __device__ __forceinline__ v16f h3_bias(const char *img, int layer, int blk, int h)
 {
-    return h3_ld16(img, H3_BIAS + (((layer * 2 + blk) * 2 + h) * 16) * 4);
+    int base = H3_BIAS + h * 64;
+    asm("" : "+v"(base));
+    return h3_ld16(img + base, (layer * 2 + blk) * 128);
 }
 
 // ------------------------------------------------------------------ backward primitives

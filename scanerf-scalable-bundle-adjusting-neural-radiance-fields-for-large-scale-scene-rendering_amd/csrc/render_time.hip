@@ -330,6 +330,188 @@ __global__ void __launch_bounds__(256, 2) k_pts_inference(InferArgs a)
     }
 }
 
+
+// ---- pieces of the software-pipelined group loop of k_pts_inference_chunks ------------------------------------------------
+// acc + w * (float)(low / high half of an f16 pair): one instruction instead of a conversion and an fma; the value is the same
+__device__ __forceinline__ float fma_mix_lo(uint32_t h2, float w, float acc)
+{
+    float r;
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h2), "v"(w), "v"(acc));
+    return r;
+}
+__device__ __forceinline__ float fma_mix_hi(uint32_t h2, float w, float acc)
+{
+    float r;
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h2), "v"(w), "v"(acc));
+    return r;
+}
+
+// what one 32-sample group reads from the per-sample arrays (loaded one group ahead of its use)
+struct GroupIn {
+    float z, aux;     // depth; fg: dists, bg: the next sample's depth
+    uint32_t s0, s1;  // fg: the four 16-bit slots; bg: s0 = the ray's background tile at this blend step (sign-extended)
+    uint32_t e;       // element index (clamped into range)
+    int i;            // ray
+    bool in_range, last;
+};
+// a group found to have samples in the staged tile: what its decoder and output stage needs
+struct GroupPrep {
+    uint32_t e;
+    bool run;
+};
+
+template <bool BG>
+__device__ __forceinline__ void group_load(const InferArgs &a, int64_t total, int64_t base, int sl, GroupIn &in)
+{
+    const int64_t e = base + sl;
+    in.in_range = e < total;
+    const uint32_t ec = (uint32_t)(in.in_range ? e : total - 1);
+    int s;
+    pt_decompose(ec, (uint32_t)a.B, (uint32_t)a.S, a.sm, in.i, s);
+    in.e = ec;
+    in.z = a.z_vals[ec];
+    if (BG) {
+        in.last = s == a.S - 1;
+        in.aux = a.z_vals[in.last ? ec : ec + (uint32_t)pt_sample_stride(a.B, a.sm)];
+        in.s0 = (uint32_t)(int)a.block_idxs[in.i * kMaxPtsBlocks + a.step];
+        in.s1 = 0;
+    } else {
+        in.last = false;
+        in.aux = a.dists[ec];
+        const uint2 raw = *reinterpret_cast<const uint2 *>(a.block_idxs + (size_t)ec * kMaxPtsBlocks);
+        in.s0 = raw.x;
+        in.s1 = raw.y;
+    }
+}
+
+// Same arithmetic as the group loop below (rendering_kernel.cu:499-557 / :1040-1060).  Returns whether any sample of the
+// group runs the decoder of tile b (wave-uniform).
+template <bool BG>
+__device__ __forceinline__ bool group_prep(const InferArgs &a, int b, const float cb[3], const float sb[3], const GroupIn &in,
+                                           GroupPrep &P, float p01[3], float (*park)[64], int lane)
+{
+    // (direction, depth step, blend weight and 1/sum of weights wait in LDS for the output stage -- registers the compiler
+    // would otherwise spill to scratch, whose reloads wait behind the gathers in flight)
+    float d[3], delta;
+    int16_t slot[kMaxPtsBlocks] = { -1, -1, -1, -1 };
+    bool mine = false;
+    if (BG) {
+        mine = in.in_range && (int)in.s0 == b;
+    } else if (in.in_range) {
+        slot[0] = (int16_t)(in.s0 & 0xffffu); slot[1] = (int16_t)(in.s0 >> 16);
+        slot[2] = (int16_t)(in.s1 & 0xffffu); slot[3] = (int16_t)(in.s1 >> 16);
+        bool ended = false;
+#pragma unroll
+        for (int k = 0; k < kMaxPtsBlocks; ++k) {
+            ended |= slot[k] == -1;
+            if (ended) slot[k] = -1;
+            mine |= slot[k] == b;
+        }
+    }
+    P.run = false;
+    if (!__any(mine)) return false;
+    float o[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        o[k] = a.rays_o[3 * in.i + k];
+        d[k] = a.rays_d[3 * in.i + k];
+    }
+    const float z = in.z;
+    float w_b = 0.0f, weight = 0.0f;
+    bool run = mine;
+    if (BG) {
+        delta = in.last ? 10000000.0f : in.aux - z;  // :1045-1047: raw depth step
+        float q[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) q[c] = 2.0f * ((o[c] + z * d[c]) - cb[c]) / sb[c] - 1.0f;
+        const float linf = fmaxf(fabsf(q[0]), fmaxf(fabsf(q[1]), fabsf(q[2])));
+        const float ratio = (2.0f - 1.0f / linf) / linf;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) p01[c] = (q[c] * ratio + 2.0f) / 4.0f;
+    } else {
+        const float dnorm = sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+        delta = in.aux * dnorm;  // :557
+#pragma unroll
+        for (int k = 0; k < kMaxPtsBlocks; ++k) {
+            const int bk = slot[k];
+            if (bk == -1) continue;
+            float dis[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float sz = a.t.sizes[3 * bk + c];
+                const float pt = ((o[c] + z * d[c]) - a.t.corners[3 * bk + c]) / sz;
+                dis[c] = (0.5f - fabsf(pt - 0.5f)) * sz;
+            }
+            const float w = xz_weight(dis[0], dis[2]);
+            weight += w;
+            if (bk == b) w_b = w;
+        }
+        int loc[3];
+        const int l2d[3] = { a.t.log2dim[3 * b], a.t.log2dim[3 * b + 1], a.t.log2dim[3 * b + 2] };
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float pt = ((o[c] + z * d[c]) - cb[c]) / sb[c];
+            const int r = 1 << l2d[c];
+            const int cc = (int)(pt * (float)r);
+            loc[c] = cc < 0 ? 0 : (cc > r - 1 ? r - 1 : cc);
+            p01[c] = pt / 2.0f + 0.25f;
+        }
+        if (mine) run = a.t.occ[a.t.grid_starts[b] + cell_offset(loc, l2d[1], l2d[2])] != 0;
+    }
+    P.e = in.e;
+    P.run = run;
+    park[0][lane] = d[0]; park[1][lane] = d[1]; park[2][lane] = d[2];
+    park[3][lane] = delta; park[4][lane] = w_b; park[5][lane] = weight > 0 ? 1.0f / weight : 1.0f;
+    return __any(run);
+}
+
+// First half of encode8_01<F16, 8, STRAIGHT>: the 64 corner loads of a group go out (raw f16 pairs; uniform level base + a
+// 32-bit lane offset) and the interpolation offsets are parked in LDS; nothing here waits for memory.  Level by level (fenced),
+// so that only one level's addresses are live beside the 64 destinations.
+__device__ __forceinline__ void gather_issue(const char *table, const float *rs, int T, int h, const float p01[3],
+                                             uint32_t raw[64], float (*tp)[64], int lane)
+{
+    const uint32_t mask = (uint32_t)T - 1u, hoff = (uint32_t)(2 * h) * (uint32_t)T;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int lu = 4 * (j >> 1) + (j & 1);  // level lu + 2h
+        int bc[3];
+        {
+#pragma clang fp contract(off)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const float v = p01[k] * rs[3 * lu + k];  // rs = (float)(res - 1) of this half's levels (staged in LDS with the tile's image)
+                bc[k] = (int)v;
+                tp[3 * j + k][lane] = v - (float)bc[k];
+            }
+        }
+        uint32_t idx[8];
+        corner_indices(idx, bc[0], bc[1], bc[2], mask);
+        const char *base = table + (size_t)lu * T * 4;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) raw[8 * j + c] = *reinterpret_cast<const uint32_t *>(base + (size_t)((hoff + idx[c]) * 4u));
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// Second half: trilinear interpolation of the loaded corners (same sums, in the same order, as encode8_01)
+__device__ __forceinline__ void gather_finish(const uint32_t raw[64], float (*tp)[64], int lane, bool active, v16f &x)
+{
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        float w[8];
+        trilinear_weights(w, tp[3 * j][lane], tp[3 * j + 1][lane], tp[3 * j + 2][lane]);
+        float ax = 0.0f, ay = 0.0f;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            ax = fma_mix_lo(raw[8 * j + c], w[c], ax);
+            ay = fma_mix_hi(raw[8 * j + c], w[c], ay);
+        }
+        x[2 * j] = active ? ax : 0.0f;
+        x[2 * j + 1] = active ? ay : 0.0f;
+    }
+}
+
 // ---- pts_inference / bg_pts_inference_v2, chunk-major with the tile's decoder in LDS (default) ---------------------------
 // The kernel above reads every MFMA operand of whichever tile a sample references from global memory and multiplies on
 // the f32 matrix pipe (1.5e9 samples/s).  Here a workgroup takes a chunk of 64 consecutive 32-sample groups (16 rays at
@@ -350,11 +532,20 @@ __global__ void __launch_bounds__(256, 2) k_pts_inference(InferArgs a)
 #define RT_STRAIGHT true
 #endif
 constexpr int kChunkThreads = 512, kChunkWaves = kChunkThreads / 64, kChunkWaveGroups = 16;
-template <bool BG>
+template <bool BG, bool PIPE>
 __global__ void __launch_bounds__(kChunkThreads, 1) k_pts_inference_chunks(InferArgs a)
 {
-    __shared__ __attribute__((aligned(16))) char lds[H3_BYTES];
-    __shared__ uint32_t tileset[2];
+    // One block of LDS, the decoder image first: its reads then are `lane base + 16-bit immediate` (with the image behind the
+    // other arrays every read past 64 KB took an address register of its own, ~25 live across the group loop).
+    // PIPE: tpark = interpolation offsets of the group whose gathers are in flight; ppark = direction, depth step and blend
+    // weights of the two groups in the pipeline; rscale = (float)(res - 1) of the staged tile's 16 levels
+    constexpr int kImg = (H3_BYTES + 15) & ~15, kTp = PIPE ? kChunkWaves * 24 * 64 * 4 : 0, kPp = PIPE ? kChunkWaves * 2 * 6 * 64 * 4 : 0;
+    __shared__ __attribute__((aligned(16))) char smem[kImg + kTp + kPp + 48 * 4 + 8];
+    char *const lds = smem;
+    float (*const tpark)[24][64] = reinterpret_cast<float (*)[24][64]>(smem + kImg);
+    float (*const ppark)[2][6][64] = reinterpret_cast<float (*)[2][6][64]>(smem + kImg + kTp);
+    float *const rscale = reinterpret_cast<float *>(smem + kImg + kTp + kPp);
+    uint32_t *const tileset = reinterpret_cast<uint32_t *>(smem + kImg + kTp + kPp + 48 * 4);
     const int lane = threadIdx.x & 63, sl = lane & 31, h = lane >> 5, wave = threadIdx.x >> 6;
     const int64_t total = (int64_t)a.B * a.S;
     constexpr int kWaveGroups = kChunkWaveGroups, kChunkGroups = kChunkWaves * kWaveGroups;
@@ -417,6 +608,7 @@ __global__ void __launch_bounds__(kChunkThreads, 1) k_pts_inference_chunks(Infer
             const float4 *src = reinterpret_cast<const float4 *>(a.images + (size_t)b * WS_FLOATS + PK_TOTAL);
             float4 *dst = reinterpret_cast<float4 *>(lds);
             for (int i = threadIdx.x; i < H3_BYTES / 16; i += kChunkThreads) dst[i] = src[i];
+            if (PIPE && threadIdx.x < 48) rscale[threadIdx.x] = (float)(a.res[(size_t)b * 48 + threadIdx.x] - 1);
         }
         __syncthreads();
         float cb[3], sb[3];
@@ -425,6 +617,76 @@ __global__ void __launch_bounds__(kChunkThreads, 1) k_pts_inference_chunks(Infer
             cb[c] = a.t.corners[3 * b + c];
             sb[c] = a.t.sizes[3 * b + c];
         }
+      if constexpr (PIPE) {
+        // Software pipeline over the wave's groups that run this tile's decoder: while group g is decoded, the 64 corner
+        // loads of the next running group and the per-sample inputs of the group after it are in flight (the kernel is bound
+        // by the round trips of these loads, not by their number -- DESIGN.md 4.8).
+        const int64_t rem = total - wbase;
+        const int ng = rem <= 0 ? 0 : (int)(rem >= (int64_t)kWaveGroups * 32 ? kWaveGroups : (rem + 31) / 32);
+        const char *table = (const char *)a.tables + (size_t)b * 16 * a.T * 4;
+        int rso = 6 * h;  // (opaque, or every rscale address becomes its own lane-dependent register instead of base + immediate)
+        asm volatile("" : "+v"(rso));
+        const float *rsh = rscale + rso;
+        GroupIn in;
+        GroupPrep cur, nxt;
+        uint32_t raw[64];
+        float p01[3];
+        int g_in = 0, slot_cur = 0;
+        if (ng > 0) group_load<BG>(a, total, wbase, sl, in);
+        auto advance = [&](GroupPrep &P, int sl_) -> bool {  // the next group with samples to decode; keeps one group of inputs ahead
+            while (g_in < ng) {
+                const bool r = group_prep<BG>(a, b, cb, sb, in, P, p01, ppark[wave][sl_], lane);
+                ++g_in;
+                if (g_in < ng) group_load<BG>(a, total, wbase + (int64_t)g_in * 32, sl, in);
+                if (r) return true;
+            }
+            return false;
+        };
+        bool have = advance(cur, 0);
+        if (have) gather_issue(table, rsh, a.T, h, p01, raw, tpark[wave], lane);
+        while (have) {
+            v16f x;
+            gather_finish(raw, tpark[wave], lane, cur.run, x);
+            __builtin_amdgcn_sched_barrier(0);  // the next group's loads go out after this group's corners are consumed ...
+            const bool more = advance(nxt, slot_cur ^ 1);
+            if (more) gather_issue(table, rsh, a.T, h, p01, raw, tpark[wave], lane);
+            __builtin_amdgcn_sched_barrier(0);  // ... and before its decoder starts
+            float (*pk)[64] = ppark[wave][slot_cur];
+            v16f dinit[2];
+            {
+                const float d[3] = { pk[0][lane], pk[1][lane], pk[2][lane] };
+                const float dnorm = sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+                float sh[16];
+                ray_sh(d, dnorm, sh, 0.0f);
+                h3_dinit(lds, lane, sh, dinit);
+            }
+            const SampleOut so = decode_tile_h3(lds, lane, x, dinit);
+            if (cur.run && h == 0) {
+                const uint32_t e = cur.e;
+                const float delta = pk[3][lane], w_b = pk[4][lane], inv = pk[5][lane];
+                const float pa = 1.0f - expf(-1.0f * so.sigma * delta);
+                if (BG) {
+                    a.out_alpha[e] = pa;
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        a.out_dif[3 * (size_t)e + c] = pa * so.dif[c];
+                        a.out_spec[3 * (size_t)e + c] = pa * (so.tint[c] * so.spec[c]);
+                    }
+                } else {
+                    a.out_alpha[e] += (w_b * pa) * inv;
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        a.out_dif[3 * (size_t)e + c] += (w_b * pa * so.dif[c]) * inv;
+                        a.out_spec[3 * (size_t)e + c] += (w_b * pa * (so.tint[c] * so.spec[c])) * inv;
+                    }
+                }
+            }
+            SCANERF_STORE_GUARD();
+            cur = nxt;
+            slot_cur ^= 1;
+            have = more;
+        }
+      } else {
 #pragma unroll 1
       for (int g = 0; g < kWaveGroups; ++g) {
         const int64_t base = wbase + g * 32;
@@ -552,6 +814,7 @@ __global__ void __launch_bounds__(kChunkThreads, 1) k_pts_inference_chunks(Infer
         SCANERF_STORE_GUARD();
       }
       }
+      }
     }
 }
 
@@ -561,6 +824,13 @@ inline bool render_single_pass(int64_t total, int nb)
     const char *e = getenv("SCANERF_RENDER_ARITH");
     // the chunk-major kernel indexes samples in 32 bits and keeps a chunk's tile set in 64 bits
     return (e && e[0] == 'f') || total >= ((int64_t)1 << 31) || nb > 64;
+}
+
+// SCANERF_RENDER_PIPE=0: the group loop without the software pipeline (comparison; the two give the same bits)
+inline bool render_pipelined()
+{
+    const char *e = getenv("SCANERF_RENDER_PIPE");
+    return !(e && e[0] == '0');
 }
 
 // ---- rendering_kernel.cu:624-702: front-to-back accumulation, one wave per ray ------------------------
@@ -936,7 +1206,8 @@ SCANERF_API int scanerf_pts_inference(const float *rays_o, const float *rays_d, 
     for (hipError_t e : ce) SCANERF_REQUIRE(e == hipSuccess, "pts_inference: clearing the outputs failed: %s", hipGetErrorString(e));
     const int64_t per_chunk = kChunkWaves * kChunkWaveGroups, nchunks = (tiles32 + per_chunk - 1) / per_chunk;
     blocks = (int)(nchunks < kNumCU * 8 ? nchunks : kNumCU * 8);
-    hipLaunchKernelGGL((k_pts_inference_chunks<false>), dim3(blocks), dim3(kChunkThreads), 0, (hipStream_t)stream, a);
+    if (render_pipelined()) hipLaunchKernelGGL((k_pts_inference_chunks<false, true>), dim3(blocks), dim3(kChunkThreads), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((k_pts_inference_chunks<false, false>), dim3(blocks), dim3(kChunkThreads), 0, (hipStream_t)stream, a);
     return check_launch("pts_inference");
 }
 
@@ -968,7 +1239,8 @@ SCANERF_API int scanerf_bg_pts_inference_v2(const float *rays_o, const float *ra
     }
     const int64_t per_chunk = kChunkWaves * kChunkWaveGroups, nchunks = (tiles32 + per_chunk - 1) / per_chunk;
     blocks = (int)(nchunks < kNumCU * 8 ? nchunks : kNumCU * 8);
-    hipLaunchKernelGGL((k_pts_inference_chunks<true>), dim3(blocks), dim3(kChunkThreads), 0, (hipStream_t)stream, a);
+    if (render_pipelined()) hipLaunchKernelGGL((k_pts_inference_chunks<true, true>), dim3(blocks), dim3(kChunkThreads), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((k_pts_inference_chunks<true, false>), dim3(blocks), dim3(kChunkThreads), 0, (hipStream_t)stream, a);
     return check_launch("bg_pts_inference_v2");
 }
 

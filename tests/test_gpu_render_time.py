@@ -138,6 +138,47 @@ def test_render_loop_stage_by_stage():
             assert (ob_ref[:, 0] != -1).sum() > B // 2 and ra_.max() > 0.05
 
 
+def test_pipelined_group_loop_gives_the_bits_of_the_plain_one(monkeypatch):
+    """The chunk kernel's software pipeline (next group's corner loads in flight during a group's decoder) reorders memory
+    traffic only: fg (overlapping tiles, occupancy skips, ragged end) and bg outputs equal SCANERF_RENDER_PIPE=0 bit for bit."""
+    import scanerf_amd  # noqa
+    from scanerf_amd import hashgrid as H
+    rng = np.random.default_rng(5)
+    sc = _scene(rng)
+    B, S, nb = 1000, 72, 3
+    o, d = _rays(rng, B)
+    C, Z, OCC, ST, L2 = g(sc["corners"]), g(sc["sizes"]), g(sc["occ"]), g(sc["starts"]), g(sc["l2d"])
+    RO, RD, TAB, PAR, RES = g(o), g(d), g(sc["tables"]), g(sc["params"]), g(sc["res"])
+    inter = torch.full((B, nb, 2), 1e7, device=DEV)
+    H.ray_block_intersection(RO, RD, C, Z, inter)
+    TB = torch.argsort(inter[..., 0], dim=-1, stable=True).int().contiguous()
+    TI, ZS = torch.zeros(B, dtype=torch.int32, device=DEV), torch.zeros(B, device=DEV)
+    z, dd = torch.full((B, S), -1.0, device=DEV), torch.full((B, S), -1.0, device=DEV)
+    H.sample_points(RO, RD, C, Z, OCC, ST, L2, TB, inter, TI, ZS, z, dd)
+    bi = torch.full((B, S, 4), -1, dtype=torch.int16, device=DEV)
+    H.prepare_points(z, torch.ones(B, dtype=torch.bool, device=DEV), inter, bi)
+    ob = torch.full((B, 4), -1, dtype=torch.int16, device=DEV)
+    bw = torch.zeros((B, 4), device=DEV)
+    H.update_outgoing_bidx(RO, RD, C, Z, TB, inter, ob, bw, 0.12, False)
+    zb = torch.full((B, S), -1.0, device=DEV)
+    H.inverse_z_sampling(inter, ob[:, 0].contiguous(), zb, 1e6)
+
+    def run():
+        fg = [torch.zeros(B, S, 3, device=DEV), torch.zeros(B, S, 3, device=DEV), torch.zeros(B, S, 1, device=DEV)]
+        H.pts_inference(RO, RD, z, dd, bi, TAB, PAR, RES, OCC, ST, L2, C, Z, *fg)
+        bg = [torch.full((B, S, 3), 7.0, device=DEV), torch.full((B, S, 3), 7.0, device=DEV), torch.full((B, S, 1), 7.0, device=DEV)]
+        H.bg_pts_inference_v2(RO, RD, zb, ob, 0, C, Z, RES, TAB, PAR, *bg)
+        return [t.cpu().numpy() for t in fg + bg]
+
+    monkeypatch.delenv("SCANERF_RENDER_PIPE", raising=False)
+    piped = run()
+    monkeypatch.setenv("SCANERF_RENDER_PIPE", "0")
+    plain = run()
+    assert piped[2].max() > 0.05 and piped[5].max() > 0.05
+    for a, b in zip(piped, plain):
+        assert np.array_equal(a, b)
+
+
 def test_ray_firsthit_block():
     """rendering_kernel.cu:705-813 through the HASHGRID binding name, bit-exact against the oracle's restatement: the tile
     with the nearest far bound among those whose occupancy the ray touches, else the last tile crossed, else -1."""
