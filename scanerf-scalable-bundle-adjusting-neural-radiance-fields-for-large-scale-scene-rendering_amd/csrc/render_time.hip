@@ -332,18 +332,18 @@ __global__ void __launch_bounds__(256, 2) k_pts_inference(InferArgs a)
 
 
 // ---- pieces of the software-pipelined group loop of k_pts_inference_chunks ------------------------------------------------
-// acc + w * (float)(low / high half of an f16 pair): one instruction instead of a conversion and an fma; the value is the same
+// acc += w * (float)(low / high half of an f16 pair): one instruction instead of a conversion and an fma, the same value.  The
+// result stays in acc's register, which ordinary instructions have written before (render_h3.h, h3_residual_lo: inline asm is
+// invisible to the hazard recogniser, so it must not be handed a register that a matrix instruction in flight may own).
 __device__ __forceinline__ float fma_mix_lo(uint32_t h2, float w, float acc)
 {
-    float r;
-    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h2), "v"(w), "v"(acc));
-    return r;
+    asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "+v"(acc) : "v"(h2), "v"(w));
+    return acc;
 }
 __device__ __forceinline__ float fma_mix_hi(uint32_t h2, float w, float acc)
 {
-    float r;
-    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h2), "v"(w), "v"(acc));
-    return r;
+    asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(acc) : "v"(h2), "v"(w));
+    return acc;
 }
 
 // what one 32-sample group reads from the per-sample arrays (loaded one group ahead of its use)
