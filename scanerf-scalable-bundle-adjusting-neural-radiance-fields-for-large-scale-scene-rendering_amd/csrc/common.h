@@ -40,6 +40,20 @@ inline int check_launch(const char *what)
 // the forward kernel picked up, in its last quarter-wave, a register that later code (the next layer's MFMA results are
 // allocated over the stored values) had already rewritten -- nothing in the generated code holds such writers back.  Sixteen
 // wait states behind the stores, fenced for the scheduler, and no launch in 600 differed.
+// After the last of a batch of gathers has been consumed, before other code reuses the loads' destination registers.  Measured on
+// MI355X / ROCm 7.2 (tools/fwd_fault_rate.py): the forward kernel copies its 16 encoder outputs into the registers that the last
+// level's eight corner loads had returned into (v_mov_b64, a dozen instructions behind the s_waitcnt that released the last
+// load's consumer); in 5 of 59 first launches on cold caches ONE such copy came out wrong in its low register, lanes 48-63 --
+// the value a late part of the load's return had written over it, as far as can be told.  With sixteen wait states between the
+// encoder and whatever follows: 0 of 119.  (Same family as SCANERF_STORE_GUARD: vector memory still touches a register a few
+// cycles after the counters say it is done with it.)
+#define SCANERF_LOAD_GUARD()                     \
+    do {                                         \
+        __builtin_amdgcn_sched_barrier(0);       \
+        asm volatile("s_nop 7\n\ts_nop 7");      \
+        __builtin_amdgcn_sched_barrier(0);       \
+    } while (0)
+
 #define SCANERF_STORE_GUARD()                    \
     do {                                         \
         __builtin_amdgcn_sched_barrier(0);       \

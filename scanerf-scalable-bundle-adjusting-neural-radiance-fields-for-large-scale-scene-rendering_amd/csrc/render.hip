@@ -366,7 +366,7 @@ __global__ void __launch_bounds__(kRenderThreads, 2) k_render_fwd_h3(RenderArgs 
                 for (int g = 0; g < 16; ++g) x[g] = p[g % 3] * (0.01f * g);
             } else {
                 // (dead lanes of the last tile write their own, unused, slots: no branch around the stores)
-                float *jrow = JST ? a.jstash + ((size_t)ray * ntiles + tile) * (8 * 6 * 64) + 2 * lane : nullptr;
+                uint32_t *jrow = JST ? a.jstash + ((size_t)ray * ntiles + tile) * (8 * 3 * 64) + lane : nullptr;
                 encode8<DT, JST ? 1 : FWD_GATHER_BATCH, true, COUNT, JST>(a, lds_res, h, p, x, hist, live, jrow);
             }
             if (a.xstash && live) {  // (plain stores: streaming / nontemporal ones measured 3.16 -> 3.41 ms)
@@ -455,7 +455,7 @@ SCANERF_API int scanerf_pack_decoder(const float *mlp_blob, const float *weight_
 static int render_forward(const float *rays_o, const float *rays_d, const float *z_vals, const float *dists,
                           const void *features, int feat_dtype, const int32_t *resolutions, const float *packed,
                           const scanerf_render_cfg *cfg, const uint8_t *ray_valid, float *out_ray, float *weights,
-                          float *tile_T, float *xstash, float *jstash, int B, int S, int T, void *scatter_ws,
+                          float *tile_T, float *xstash, void *jstash, int B, int S, int T, void *scatter_ws,
                           size_t scatter_ws_bytes, scanerf_stream_t stream)
 {
     SCANERF_REQUIRE(B >= 0 && S >= 1, "render_forward: B=%d S=%d", B, S);
@@ -470,7 +470,7 @@ static int render_forward(const float *rays_o, const float *rays_d, const float 
     RenderArgs a;
     a.rays_o = rays_o; a.rays_d = rays_d; a.z_vals = z_vals; a.dists = dists;
     a.features = features; a.resolutions = resolutions; a.packed = packed; a.ray_valid = ray_valid;
-    a.out_ray = out_ray; a.weights = weights; a.tile_T = tile_T; a.xstash = xstash; a.jstash = jstash;
+    a.out_ray = out_ray; a.weights = weights; a.tile_T = tile_T; a.xstash = xstash; a.jstash = static_cast<uint32_t *>(jstash);
     a.B = B; a.S = S; a.T = T;
     a.contract_mode = cfg->contract_mode; a.infinity = cfg->infinity;
     a.skip_levels = getenv("SCANERF_NO_LEVEL_SKIP") ? 0u : pair_masked_levels(cfg->skip_levels);
@@ -527,13 +527,13 @@ SCANERF_API int scanerf_render_forward_packed(const float *rays_o, const float *
 // The same launch, also doing scanerf_render_scatter_plan's work for the t16 backward of these rays (counts in the forward
 // kernel, where the hash indices already are; then the scan): call INSTEAD of scanerf_render_scatter_plan, with that
 // function's workspace.  Only where scanerf_render_forward_plan_supported(B, S, T) (equal forward and backward grids).
-// jstash (may be NULL; fp32 tables): [B][ceil(S/32)][8][3][64][2] f32, the encoder's position Jacobians for scanerf_render_backward's g_raypos.
+// jstash (may be NULL; fp32 tables): [B][ceil(S/32)][8][3][64][2] f16, the encoder's position Jacobians for scanerf_render_backward's g_raypos.
 SCANERF_API int scanerf_render_forward_packed_plan(const float *rays_o, const float *rays_d, const float *z_vals,
                                                    const float *dists, const void *features, int feat_dtype,
                                                    const int32_t *resolutions, const float *packed,
                                                    const scanerf_render_cfg *cfg, const uint8_t *ray_valid,
                                                    float *out_ray, float *weights, float *tile_T, float *xstash,
-                                                   float *jstash, int B, int S, int T, void *scatter_ws,
+                                                   void *jstash, int B, int S, int T, void *scatter_ws,
                                                    size_t scatter_ws_bytes, scanerf_stream_t stream)
 {
     // (scatter_ws may be NULL: the plain forward with the jstash output)

@@ -622,7 +622,7 @@ SCANERF_API int scanerf_render_backward(const float *rays_o, const float *rays_d
                                         const scanerf_render_cfg *cfg, const uint8_t *ray_valid, const float *out_ray,
                                         const float *tile_T, const float *grad_out, const float *xstash, float *dfeat,
                                         float *dw_partial, float *grad_blob, float *g_dnorm, float *g_rowsum,
-                                        const float *jstash, float *g_raypos,
+                                        const void *jstash, float *g_raypos,
                                         void *scatter_ws, size_t scatter_ws_bytes, float *grad_features, int B, int S,
                                         int T, scanerf_stream_t stream)
 {
@@ -650,7 +650,7 @@ SCANERF_API int scanerf_render_backward(const float *rays_o, const float *rays_d
     { const char *e = getenv("SCANERF_DEBUG_BWD"); a.f.dbg = e ? atoi(e) : 0; }  // timing experiments only (-DSCANERF_BWD_EXPERIMENTS builds)
     a.grad_out = grad_out; a.tile_T = tile_T; a.dfeat = dfeat; a.dw_partial = dw_partial; a.xstash = xstash;
     a.g_dnorm = g_dnorm; a.g_rowsum = g_rowsum; a.g_raypos = g_raypos;
-    a.f.jstash = const_cast<float *>(jstash);
+    a.f.jstash = static_cast<uint32_t *>(const_cast<void *>(jstash));
     SCANERF_REQUIRE(cfg->arith >= SCANERF_ARITH_F32 && cfg->arith <= SCANERF_ARITH_T16, "render_backward: arith=%d", cfg->arith);
     const bool h3 = cfg->arith == SCANERF_ARITH_H3, t16 = cfg->arith == SCANERF_ARITH_T16;
     SCANERF_REQUIRE(!t16 || xstash, "render_backward: arith T16 needs the forward's x-stash (use SCANERF_ARITH_H3 to re-gather)");

@@ -710,15 +710,14 @@ __global__ void __launch_bounds__(kThreads, 2) k_render_bwd_t16(BwdArgs a)
             if (POSE && a.g_raypos && live && active) {
                 // position path (here, where only dX is live): this lane's four levels' Jacobians (12 loads in flight together),
                 // contracted with its dX.  The forward's lane 32 h + (s & 31) wrote its 8 levels 4 (j >> 1) + 2 h + (j & 1) into
-                // the 32-sample tile's [8][3][64] float2 block; register g of dX block e = feature g & 1 of level jj = 2e + (g >> 1).
+                // the 32-sample tile's [8][3][64] block of f16 pairs; register g of dX block e = feature g & 1 of level jj = 2e + (g >> 1).
                 float2 jv[4][3];
 #pragma unroll
                 for (int lv = 0; lv < 4; ++lv) {
                     const int j8l = 4 * (q & 1) + lv, lvl = 4 * (j8l >> 1) + 2 * (q >> 1) + (j8l & 1);
                     const int hh = (lvl >> 1) & 1, j = 2 * (lvl >> 2) + (lvl & 1);
-                    const float2 *jr = reinterpret_cast<const float2 *>(a.f.jstash) +
-                                       (((size_t)ray * ((S + 31) >> 5) + (s >> 5)) * 8 + j) * (3 * 64) + 32 * hh + (s & 31);
-                    jv[lv][0] = jr[0]; jv[lv][1] = jr[64]; jv[lv][2] = jr[128];
+                    const uint32_t *jr = a.f.jstash + (((size_t)ray * ((S + 31) >> 5) + (s >> 5)) * 8 + j) * (3 * 64) + 32 * hh + (s & 31);
+                    jv[lv][0] = unpack_f16x2(jr[0]); jv[lv][1] = unpack_f16x2(jr[64]); jv[lv][2] = unpack_f16x2(jr[128]);
                 }
                 float gxk[3] = { 0, 0, 0 };
 #pragma unroll

@@ -122,10 +122,11 @@ struct RenderArgs {
     float *out_ray, *weights;
     float *tile_T;            // optional [B, ceil(S/16)]: transmittance entering each 16-sample tile (for backward)
     float *xstash;            // optional [B*S][2][16]: encoder outputs per (sample, half-wave) (for backward)
-    float *jstash;            // optional [B][ceil(S/32)][8][3][64][2]: d(encoder outputs)/d(contracted position) per (ray, 32-sample
+    uint32_t *jstash;         // optional [B][ceil(S/32)][8][3][64] f16 pairs: d(encoder outputs)/d(contracted position) per (ray, 32-sample
                               // tile, level j = 0..7 of the half-wave, component pair, forward lane = 32 h + (s & 31)); the six
                               // components = (feature 0: d/dx, d/dy, d/dz; feature 1: ...).  Lane-fastest so that every store of
-                              // the wave is 512 contiguous bytes.  Lets the t16 backward form the pose gradient without gathering
+                              // the wave is 256 contiguous bytes.  Half precision (the t16 backward that reads it multiplies f16
+                              // gradient operands anyway): 1.6 instead of 3.2 GB written and read per 65 536 x 128 samples.  Lets the t16 backward form the pose gradient without gathering
                               // the table again
     int B, S, T;
     int contract_mode, infinity;
@@ -140,6 +141,20 @@ struct RenderArgs {
     int plan_NB, plan_bucket_log, plan_W, plan_rec8;
 };
 
+// two f32 -> one word of two IEEE halves (round to nearest) and back
+__device__ __forceinline__ uint32_t pack_f16x2(float a, float b)
+{
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    const h2 v = { (_Float16)a, (_Float16)b };
+    return __builtin_bit_cast(uint32_t, v);
+}
+__device__ __forceinline__ float2 unpack_f16x2(uint32_t w)
+{
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    const h2 v = __builtin_bit_cast(h2, w);
+    return make_float2((float)v[0], (float)v[1]);
+}
+
 // hash-encode 8 levels of one sample: register 2j+f of half h holds feature f of level
 // 4(j>>1) + 2h + (j&1), i.e. input unit nmap(2j+f, h) = 2*level + f -- the same register<->unit
 // map as every other layer, and the layout in which the backward pass produces dL/dx.
@@ -149,10 +164,10 @@ struct RenderArgs {
 // PAIRED: fetch x-neighbour pairs with one load where the hash puts them side by side (gather_cell; half-precision tables)
 // hist (may be null): this workgroup's [16][NB] record counters in LDS -- one per (y,z) corner pair, two when the
 // x-neighbours fall into different buckets, exactly scatter_common.h count_pairs; count = this lane's sample is a real one
-// jrow (may be null): this lane's float2 column of the tile's [8][3][64][2] block of RenderArgs::jstash
+// jrow (may be null): this lane's f16-pair column of the tile's [8][3][64] block of RenderArgs::jstash
 template <int DT, int GATHER_BATCH = 2, bool PAIRED = false, bool COUNT = false, bool JST = false>
 __device__ __forceinline__ void encode8(const RenderArgs &a, const int *lds_res, int h, const float p[3], v16f &x,
-                                        uint32_t *hist = nullptr, bool count = false, float *jrow = nullptr)
+                                        uint32_t *hist = nullptr, bool count = false, uint32_t *jrow = nullptr)
 {
     const uint32_t mask = (uint32_t)a.T - 1u;
 #pragma unroll
@@ -165,8 +180,8 @@ __device__ __forceinline__ void encode8(const RenderArgs &a, const int *lds_res,
             x[2 * j] = 0.0f;
             x[2 * j + 1] = 0.0f;
             if constexpr (JST) {
-                float2 *jr = reinterpret_cast<float2 *>(jrow) + 3 * j * 64;
-                jr[0] = jr[64] = jr[128] = make_float2(0.0f, 0.0f);
+                uint32_t *jr = jrow + 3 * j * 64;
+                jr[0] = jr[64] = jr[128] = 0u;
             }
             continue;
         }
@@ -211,7 +226,7 @@ __device__ __forceinline__ void encode8(const RenderArgs &a, const int *lds_res,
             // with the upstream gradient): corner c = (dx << 2) | (dy << 1) | dz.  Formed as differences along each axis of the
             // bilinear interpolations on the two faces (6 face values per feature instead of 12 weight products held at once).
             const float tx = t[0], ty = t[1], tz = t[2];
-            float2 *jr = reinterpret_cast<float2 *>(jrow) + 3 * j * 64;   // [3 component pairs][64 lanes] float2 per level
+            uint32_t *jr = jrow + 3 * j * 64;   // [3 component pairs][64 lanes] f16 pairs per level
             float jv[6];
 #pragma unroll
             for (int ft = 0; ft < 2; ++ft) {
@@ -232,12 +247,13 @@ __device__ __forceinline__ void encode8(const RenderArgs &a, const int *lds_res,
                 jv[3 * ft + 1] = sc[1] * gy;
                 jv[3 * ft + 2] = sc[2] * gz;
             }
-            jr[0] = make_float2(jv[0], jv[1]);
-            jr[64] = make_float2(jv[2], jv[3]);
-            jr[128] = make_float2(jv[4], jv[5]);
+            jr[0] = pack_f16x2(jv[0], jv[1]);
+            jr[64] = pack_f16x2(jv[2], jv[3]);
+            jr[128] = pack_f16x2(jv[4], jv[5]);
         }
         if ((j + 1) % GATHER_BATCH == 0) __builtin_amdgcn_sched_barrier(0);  // bound the gathers in flight per lane
     }
+    SCANERF_LOAD_GUARD();
 }
 
 __device__ __forceinline__ void contract_point(const RenderArgs &a, const float o[3], const float d[3], float z,
@@ -396,6 +412,7 @@ __device__ __forceinline__ void encode8_01(const void *table, const int32_t *res
         x[2 * j + 1] = ay;
         if ((j + 1) % GATHER_BATCH == 0) __builtin_amdgcn_sched_barrier(0);
     }
+    SCANERF_LOAD_GUARD();
 }
 
 // decode_tile with the SH part of the directional layer computed inline (per-lane direction):

@@ -44,21 +44,6 @@ __device__ __forceinline__ int h3_lane_off(int lane)
 struct HL {
     h8 hi, lo;
 };
-// x - (float)(low / high half of an f16 pair) as one mixed-precision fma: the same single rounding as the conversion and
-// subtraction it replaces, a third of the split's instructions.  The compiler emits v_fma_mix_f32 only from inline asm, which
-// its hazard recogniser cannot see into; the result therefore overwrites x's own register (or a copy the compiler makes with
-// an ordinary move): that register was read by the conversion producing `hi`, so no matrix instruction in flight owns it.
-// (With a free result register 1 training step in ~6 differed -- tests/test_gpu_determinism.py.)
-__device__ __forceinline__ float h3_residual_lo(h2v hi, float x)
-{
-    asm("v_fma_mix_f32 %0, %1, -1.0, %0 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "+v"(x) : "v"(hi));
-    return x;
-}
-__device__ __forceinline__ float h3_residual_hi(h2v hi, float x)
-{
-    asm("v_fma_mix_f32 %0, %1, -1.0, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(x) : "v"(hi));
-    return x;
-}
 // registers 8t .. 8t+7 of an accumulator block -> B operand of k-step t
 __device__ __forceinline__ HL split8(const v16f &v, int t)
 {
@@ -67,7 +52,11 @@ __device__ __forceinline__ HL split8(const v16f &v, int t)
     for (int q = 0; q < 4; ++q) {
         const f2v x = { v[8 * t + 2 * q], v[8 * t + 2 * q + 1] };
         const h2v hi = __builtin_convertvector(x, h2v);
-        const f2v r = { h3_residual_lo(hi, x[0]), h3_residual_hi(hi, x[1]) };
+        // (x - (float)hi is one v_fma_mix_f32, which the compiler only emits from inline asm; tried, -4 % on the render-time frame,
+        // and withdrawn: the training step then differed between runs -- an asm statement is invisible to the hazard recogniser,
+        // and a packed conversion's result read by the very next VOP3P / matrix instruction is the hazard of the note below)
+        const f2v back = __builtin_convertvector(hi, f2v);
+        const f2v r = { x[0] - back[0], x[1] - back[1] };
         const h2v lo = __builtin_convertvector(r, h2v);
         o.hi[2 * q] = hi[0];
         o.hi[2 * q + 1] = hi[1];

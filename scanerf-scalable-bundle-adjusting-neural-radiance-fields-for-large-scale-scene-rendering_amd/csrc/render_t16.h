@@ -61,9 +61,8 @@ __device__ __forceinline__ T16HL t16_split(const v4f &a, const v4f &b)
     for (int p = 0; p < 4; ++p) {
         const t16_f2 x = p < 2 ? t16_f2{ a[2 * p], a[2 * p + 1] } : t16_f2{ b[2 * p - 4], b[2 * p - 3] };
         const t16_h2 hi = __builtin_convertvector(x, t16_h2);
-        t16_f2 r = x;  // x - (float)hi in x's own registers (render_h3.h: h3_residual_lo)
-        asm("v_fma_mix_f32 %0, %1, -1.0, %0 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "+v"(r[0]) : "v"(hi));
-        asm("v_fma_mix_f32 %0, %1, -1.0, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(r[1]) : "v"(hi));
+        const t16_f2 back = __builtin_convertvector(hi, t16_f2);
+        const t16_f2 r = { x[0] - back[0], x[1] - back[1] };
         const t16_h2 lo = __builtin_convertvector(r, t16_h2);
         o.hi[2 * p] = hi[0];
         o.hi[2 * p + 1] = hi[1];

@@ -510,6 +510,7 @@ __device__ __forceinline__ void gather_finish(const uint32_t raw[64], float (*tp
         x[2 * j] = active ? ax : 0.0f;
         x[2 * j + 1] = active ? ay : 0.0f;
     }
+    SCANERF_LOAD_GUARD();
 }
 
 // ---- pts_inference / bg_pts_inference_v2, chunk-major with the tile's decoder in LDS (default) ---------------------------

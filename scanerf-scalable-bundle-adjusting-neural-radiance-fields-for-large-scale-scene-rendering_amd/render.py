@@ -75,6 +75,9 @@ def _cfg(min_bbox, bbox_size, contract_mode, infinity, arith=None, skip_levels=0
     return c
 
 
+JSTASH_DTYPE = torch.float16
+
+
 def jstash_shape(B, S):
     """Shape of render_forward's jstash output (position Jacobians per ray, 32-sample tile, level of the half-wave, component,
     forward lane)."""
@@ -93,7 +96,7 @@ def render_forward(rays_o, rays_d, z_vals, dists, features, resolutions, packed,
     min_bbox / bbox_size: host sequences of 3 floats (the HashGrid 2x box).
     plan=True (only where forward_plan_supported): the launch also reserves the t16 backward's scatter-record ranges for these
     rays -- call it INSTEAD of scatter_plan; returns (out_ray, weights, workspace).
-    jstash (fp32 tables): jstash_shape(B, S) f32 that receives the encoder's position Jacobians, for
+    jstash (fp32 tables): jstash_shape(B, S) JSTASH_DTYPE (f16) that receives the encoder's position Jacobians, for
     render_backward(ray_pos_grad=...) (pose refinement without a second pass over the table)."""
     B, S = z_vals.shape
     if features.shape[0] != 16 or features.shape[2] != 2:
@@ -118,7 +121,7 @@ def render_forward(rays_o, rays_d, z_vals, dists, features, resolutions, packed,
                 raise RuntimeError(f"scanerf: render_forward(plan=True) does not support B={B} S={S} T={T}")
             ws = _capi.workspace(z_vals.device, need) if plan_workspace is None else plan_workspace
         cfg = _cfg(min_bbox, bbox_size, contract_mode, infinity, _capi.ARITH_T16, getattr(packed, "skip_levels", 0))
-        tail = tail[:5] + (dev_ptr(jstash, _f32, "jstash", allow_none=True),) + tail[5:]
+        tail = tail[:5] + (dev_ptr(jstash, JSTASH_DTYPE, "jstash", allow_none=True),) + tail[5:]
         check(lib().scanerf_render_forward_packed_plan(*args, ctypes.byref(cfg), *tail,
                                                        ctypes.c_void_p(ws.data_ptr() if ws is not None else None),
                                                        ctypes.c_size_t(ws.numel() if ws is not None else 0), stream()),
@@ -160,7 +163,7 @@ def render_backward(rays_o, rays_d, z_vals, dists, features, resolutions, packed
         dev_ptr(xstash, _f32, "xstash", allow_none=True), dev_ptr(dfeat, _f32, "dfeat", allow_none=True), dev_ptr(dw_partial, _f32, "dw_partial"), dev_ptr(grad_blob, _f32, "grad_blob"),
         dev_ptr(ray_grad_buffers[0] if ray_grad_buffers else None, _f32, "g_dnorm", allow_none=True),
         dev_ptr(ray_grad_buffers[1] if ray_grad_buffers else None, _f32, "g_rowsum", allow_none=True),
-        dev_ptr(jstash, _f32, "jstash", allow_none=True), dev_ptr(ray_pos_grad, _f32, "ray_pos_grad", allow_none=True),
+        dev_ptr(jstash, JSTASH_DTYPE, "jstash", allow_none=True), dev_ptr(ray_pos_grad, _f32, "ray_pos_grad", allow_none=True),
         ctypes.c_void_p(scatter[0].data_ptr() if scatter else None), ctypes.c_size_t(scatter[0].numel() if scatter else 0),
         dev_ptr(scatter[1] if scatter else None, _f32, "grad_features", allow_none=True),
         ctypes.c_int(B), ctypes.c_int(S), ctypes.c_int(features.shape[1]), stream()), "render_backward")

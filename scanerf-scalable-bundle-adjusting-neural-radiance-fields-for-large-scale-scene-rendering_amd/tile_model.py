@@ -422,7 +422,7 @@ def train_step_fused(model, dec_opt, rays_o, rays_d, target, S, global_step, tab
                 # pose refinement: the forward also stashes the encoder's position Jacobians (it has the corner values in
                 # registers), so that the backward can chain the feature gradients to the rays without a second pass over the table
                 if pose_grads and table.dtype == torch.float32 and not os.environ.get("SCANERF_NO_JSTASH"):
-                    jstash = torch.empty(render.jstash_shape(B, S), device=dev)
+                    jstash = torch.empty(render.jstash_shape(B, S), dtype=render.JSTASH_DTYPE, device=dev)
                 out, _, ws = render.render_forward(rays_o, rays_d, z, dist, table, model.resolution, model.packed, *box,
                                                    ray_valid=valid, want_weights=False, tile_T=tile_T, xstash=xstash, plan=True,
                                                    jstash=jstash)
@@ -517,7 +517,7 @@ def fgbg_gradients(model, rays_o, rays_d, target, S_fg, S_bg, global_step, inval
             S = z_.shape[1]
             tile_T = torch.empty((B, render.tile_T_columns(S)), device=dev)
             xs = torch.empty((B * S, 32), device=dev)
-            js = torch.empty(render.jstash_shape(B, S), device=dev) if pose_grads else None
+            js = torch.empty(render.jstash_shape(B, S), dtype=render.JSTASH_DTYPE, device=dev) if pose_grads else None
             out, _ = render.render_forward(rays_o, rays_d, z_, d_, model.features, model.resolution, model.packed, *box, mode, inf,
                                            ray_valid=v_, want_weights=False, tile_T=tile_T, xstash=xs, jstash=js)
             outs.append(out)
@@ -622,7 +622,7 @@ def train_step_fgbg(model, dec_opt, rays_o, rays_d, target, S_fg, S_bg, global_s
             # (the forward launch reserves the backward's record ranges as well where the two kernels share a grid)
             in_fwd = (render.backward_arith(True, False) == render._capi.ARITH_T16 and render.forward_plan_supported(B, S, T)
                       and not os.environ.get("SCANERF_NO_FORWARD_PLAN"))
-            js = torch.empty(render.jstash_shape(B, S), device=dev) if pose_grads else None
+            js = torch.empty(render.jstash_shape(B, S), dtype=render.JSTASH_DTYPE, device=dev) if pose_grads else None
             with _sec(timer, "render_forward", B * (24 + 20 + S * 16 * 8 * 2 * table.element_size()), B * S * MLP_FLOPS_PER_SAMPLE):
                 r = render.render_forward(rays_o, rays_d, z_, d_, table, model.resolution, model.packed, *box, mode, inf,
                                           ray_valid=v_, want_weights=False, tile_T=tile_T, xstash=xs, plan=in_fwd, plan_workspace=wsbuf,

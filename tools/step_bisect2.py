@@ -1,0 +1,36 @@
+"""tests/test_gpu_determinism.py::test_whole_training_step_is_bit_reproducible with per-iteration digests of every piece of
+state: which one differs first?"""
+import hashlib, os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import scanerf_amd  # noqa
+from scanerf_amd.tile_model import TileModel, train_step_fgbg, train_step_fused
+DEV = "cuda:0"
+torch.manual_seed(11)
+B, S = 8192, 128
+o = torch.rand(B, 3, device=DEV) * 8 - 4
+d = torch.nn.functional.normalize(torch.randn(B, 3, device=DEV), dim=-1) * (0.5 + torch.rand(B, 1, device=DEV))
+tgt = torch.rand(B, 3, device=DEV)
+dig = lambda t: hashlib.sha256(t.detach().cpu().numpy().tobytes()).hexdigest()[:6]
+for fgbg in (False, True):
+    rows = []
+    for rep in range(int(os.environ.get("REPS", 8))):
+        m = TileModel([-4, -4, -4], [8, 8, 8], DEV, log2_T=16, seed=1)
+        with torch.no_grad():
+            m.features.mul_(100.0)
+        opt = torch.optim.Adam(m.decoder.parameters(), lr=1e-3, betas=(0.9, 0.99), eps=1e-15)
+        row = []
+        for i in range(3):
+            loss = train_step_fgbg(m, opt, o, d, tgt, S, S, 20000 + i) if fgbg else train_step_fused(m, opt, o, d, tgt, S, 20000 + i)
+            row += [dig(loss), dig(m.decoder.params.grad), dig(m.decoder.blob()), dig(m.features), dig(m.exp_avg_sq)]
+        rows.append(row)
+    names = [f"{n}{i}" for i in range(3) for n in ("loss", "gblob", "dec", "table", "v")]
+    print("fgbg" if fgbg else "fused")
+    print(" ".join(f"{n:>7s}" for n in names))
+    for r in rows:
+        print(" ".join(f"{x:>7s}" for x in r))
+    for k, n in enumerate(names):
+        if len(set(r[k] for r in rows)) > 1:
+            print("FIRST DIFFERING:", n, len(set(r[k] for r in rows)), "distinct")
+            break
+    else:
+        print("identical")

@@ -7,7 +7,8 @@ from scanerf_amd import network, render
 from scanerf_amd.tile_model import TileModel, train_step_fused
 DEV = "cuda:0"
 torch.manual_seed(9)
-B, S = int(os.environ.get("B", 4096)), 64
+B, S = int(os.environ.get("B", 4096)), int(os.environ.get("S", 64))
+PLAN = bool(int(os.environ.get("PLAN", "0")))  # the forward that also counts the scatter plan (k_render_fwd_h3<.., COUNT>)
 o = torch.rand(B, 3, device=DEV) * 8 - 4
 d = torch.nn.functional.normalize(torch.randn(B, 3, device=DEV), dim=-1) * (0.5 + torch.rand(B, 1, device=DEV))
 tgt = torch.rand(B, 3, device=DEV)
@@ -25,10 +26,14 @@ table = m.gather_table()
 ref_out = ref_xs = None
 n_out = n_xs = 0
 detail = 0
+FLUSH = int(os.environ.get("FLUSH", "0"))  # MB written before every launch: the table is then cold in L2 / Infinity Cache
+flush_buf = torch.empty(FLUSH << 20, dtype=torch.uint8, device=DEV) if FLUSH else None
 for it in range(int(os.environ.get("N", 60))):
+    if FLUSH:
+        flush_buf.fill_(it & 255)
     tile_T = torch.empty(B, render.tile_T_columns(S), device=DEV)
     xs = torch.empty(B * S, 32, device=DEV)
-    out, _ = render.render_forward(o, d, z, dist, table, m.resolution, m.packed, *box, want_weights=False, tile_T=tile_T, xstash=xs)
+    out = render.render_forward(o, d, z, dist, table, m.resolution, m.packed, *box, want_weights=False, tile_T=tile_T, xstash=xs, plan=PLAN)[0]
     if ref_out is None:
         ref_out, ref_xs = out.clone(), xs.clone()
         continue
