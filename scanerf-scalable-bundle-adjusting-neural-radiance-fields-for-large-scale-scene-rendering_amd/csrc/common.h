@@ -44,14 +44,21 @@ inline int check_launch(const char *what)
 // MI355X / ROCm 7.2 (tools/fwd_fault_rate.py): the forward kernel copies its 16 encoder outputs into the registers that the last
 // level's eight corner loads had returned into (v_mov_b64, a dozen instructions behind the s_waitcnt that released the last
 // load's consumer); in 5 of 59 first launches on cold caches ONE such copy came out wrong in its low register, lanes 48-63 --
-// the value a late part of the load's return had written over it, as far as can be told.  With sixteen wait states between the
-// encoder and whatever follows: 0 of 119.  (Same family as SCANERF_STORE_GUARD: vector memory still touches a register a few
+// the value a late part of the load's return had written over it, as far as can be told.  With wait states between the
+// encoder and whatever follows: 0 of 119 (sixteen; thirty-two now, and sixteen between the encoder's level groups, whose
+// registers are reused the same way).  (Same family as SCANERF_STORE_GUARD: vector memory still touches a register a few
 // cycles after the counters say it is done with it.)
-#define SCANERF_LOAD_GUARD()                     \
-    do {                                         \
-        __builtin_amdgcn_sched_barrier(0);       \
-        asm volatile("s_nop 7\n\ts_nop 7");      \
-        __builtin_amdgcn_sched_barrier(0);       \
+#define SCANERF_LOAD_GUARD()                                                         \
+    do {                                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                           \
+        asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7");                    \
+        __builtin_amdgcn_sched_barrier(0);                                           \
+    } while (0)
+// The same wait placed BEHIND the arrival of particular loads: the asm names the loaded registers, so the compiler's s_waitcnt
+// for them comes first (a guard without operands would be scheduled in front of the wait it is meant to follow).
+#define SCANERF_LOAD_GUARD_ON2(r0, r1)                                               \
+    do {                                                                             \
+        asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7" : "+v"(r0), "+v"(r1)); \
     } while (0)
 
 #define SCANERF_STORE_GUARD()                    \

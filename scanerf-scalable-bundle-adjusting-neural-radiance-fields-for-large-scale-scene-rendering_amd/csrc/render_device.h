@@ -251,7 +251,12 @@ __device__ __forceinline__ void encode8(const RenderArgs &a, const int *lds_res,
             jr[64] = pack_f16x2(jv[2], jv[3]);
             jr[128] = pack_f16x2(jv[4], jv[5]);
         }
-        if ((j + 1) % GATHER_BATCH == 0) __builtin_amdgcn_sched_barrier(0);  // bound the gathers in flight per lane
+        if ((j + 1) % GATHER_BATCH == 0) {  // bound the gathers in flight per lane
+            __builtin_amdgcn_sched_barrier(0);
+            // (the next group's arithmetic reuses this group's load destinations: common.h SCANERF_LOAD_GUARD)
+            if (j + 1 < 8) asm volatile("s_nop 7\n\ts_nop 7");
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
     SCANERF_LOAD_GUARD();
 }
