@@ -386,7 +386,6 @@ __global__ void __launch_bounds__(kThreads, 2) k_render_bwd_t16(BwdArgs a)
             T16Lane L = t16_lane(ln);
             const int s = tile * 16 + c;
             const bool live = s < S;
-            SCANERF_LOAD_GUARD_ON2(nxt.xa, nxt.xb);  // (the tile's inputs were loaded one tile ahead; xb is the last of them)
             const float z = nxt.z, dist_i = nxt.dist, tile_T_in = nxt.tT;
             float delta = dist_i * dnorm;
             if (a.f.infinity && s == S - 1) delta = 1e10f;

@@ -251,14 +251,8 @@ __device__ __forceinline__ void encode8(const RenderArgs &a, const int *lds_res,
             jr[64] = pack_f16x2(jv[2], jv[3]);
             jr[128] = pack_f16x2(jv[4], jv[5]);
         }
-        if ((j + 1) % GATHER_BATCH == 0) {  // bound the gathers in flight per lane
-            __builtin_amdgcn_sched_barrier(0);
-            // (the next group's arithmetic reuses this group's load destinations: common.h SCANERF_LOAD_GUARD)
-            if (j + 1 < 8) asm volatile("s_nop 7\n\ts_nop 7");
-            __builtin_amdgcn_sched_barrier(0);
-        }
+        if ((j + 1) % GATHER_BATCH == 0) __builtin_amdgcn_sched_barrier(0);  // bound the gathers in flight per lane
     }
-    SCANERF_LOAD_GUARD();
 }
 
 __device__ __forceinline__ void contract_point(const RenderArgs &a, const float o[3], const float d[3], float z,

@@ -31,12 +31,23 @@ typedef float f2v __attribute__((ext_vector_type(2)));
 namespace scanerf {
 
 __host__ __device__ constexpr int h3_ku(int t, int h, int j) { return 16 * t + 8 * (j >> 2) + 4 * h + (j & 3); }
-// (opaque to the optimiser: seeing lane >> 5 as a 0/1 value it otherwise turns every `image offset + lane offset` into its own
-// select of two constants -- one address register per weight read, ~35 of them live across the sample loop)
+// H3_OPAQUE_ADDR (set by render_time.hip only): lane offsets and the base of the f32 tail are made opaque to the optimiser.
+// Seeing lane >> 5 as a 0/1 value it otherwise turns every `image offset + lane offset` into its own select of two constants, and
+// the f32 tail lies past 64 KB, beyond the immediate of an LDS read: one address register per weight / bias read, ~35 of them
+// live across the sample loop (render-time kernel 25 -> 4 spilled registers, frame 105 -> 99 ms).  NOT for the training
+// kernels: with the registers this frees, the forward kernel (51 -> 8 spills, 3.33 -> 3.11 ms) produced a wrong encoder output
+// in ~1 of 500 launches of 8 192 rays on cold caches (tools/fwd_fault_rate.py, tools/step_bisect2.py) and no
+// amount of wait states behind its loads removed that; their listing is therefore kept as it was when 800 full-size steps and
+// 800 cold starts were bit-identical.
+#ifndef H3_OPAQUE_ADDR
+#define H3_OPAQUE_ADDR 0
+#endif
 __device__ __forceinline__ int h3_lane_off(int lane)
 {
     int r = (lane & 31) * 16 + (lane >> 5) * 576;
+#if H3_OPAQUE_ADDR
     asm volatile("" : "+v"(r));
+#endif
     return r;
 }
 
@@ -163,13 +174,15 @@ __device__ __forceinline__ v16f h3_ld16(const char *img, int byte_off)  // 16 f3
     const float4 a = p[0], b = p[1], c = p[2], d = p[3];
     return v16f{ a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w, d.x, d.y, d.z, d.w };
 }
-// (the f32 tail lies past 64 KB, beyond the immediate of an LDS read: one opaque base register for all of them, or each of the
-// 32 reads keeps an address register of its own live across the sample loop)
 __device__ __forceinline__ v16f h3_bias(const char *img, int layer, int blk, int h)
 {
-    int base = H3_BIAS + h * 64;
+#if H3_OPAQUE_ADDR
+    int base = H3_BIAS + h * 64;  // (one opaque base register for the 32 reads of the f32 tail: see h3_lane_off)
     asm("" : "+v"(base));
     return h3_ld16(img + base, (layer * 2 + blk) * 128);
+#else
+    return h3_ld16(img, H3_BIAS + (((layer * 2 + blk) * 2 + h) * 16) * 4);
+#endif
 }
 
 // ------------------------------------------------------------------ backward primitives

@@ -22,6 +22,7 @@
 
 #include "dda_device.h"
 #include "render_device.h"
+#define H3_OPAQUE_ADDR 1  // (render_h3.h: one base register for the decoder image reads; measured clean on this kernel, tools/render_soak.py)
 #include "render_h3.h"
 
 using namespace scanerf;
