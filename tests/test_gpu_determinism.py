@@ -107,12 +107,14 @@ def test_forward_as_the_training_step_calls_it_is_bit_reproducible(dt):
             assert torch.equal(out, ref[0]) and torch.equal(xs, ref[1]) and torch.equal(tile_T, ref[2]), f"launch {it} differs (table {dt})"
 
 
-@pytest.mark.parametrize("fgbg", [False, True])
-def test_whole_training_step_is_bit_reproducible(fgbg):
+@pytest.mark.parametrize("fgbg,pose", [(False, False), (True, False), (False, True), (True, True)])
+def test_whole_training_step_is_bit_reproducible(fgbg, pose):
     """The default step end to end -- forward that counts the scatter plan, t16 backward emitting 8-byte records, integer
-    accumulate + sparse Adam -- run six times from the same state on 8 192 rays x 128 samples: table, moments and decoder
-    after three iterations agree bit for bit (no float atomics anywhere on the path; the reference's scatter is not
-    reproducible).  Also the foreground + background iteration (two record sets, one Adam)."""
+    accumulate + sparse Adam -- run six times from the same state on 8 192 rays x 128 samples, each time on a FRESH model (cold
+    caches, new allocations: the context in which a re-allocated forward kernel failed once in ~500 launches):
+    table, moments and decoder after three iterations agree bit for bit (no float atomics anywhere on the path; the
+    reference's scatter is not reproducible).  Also the foreground + background iteration (two record sets, one Adam), and both
+    with pose gradients (Jacobian-stash forward, POSE backward; the ray gradients are hashed too)."""
     import hashlib
 
     import scanerf_amd  # noqa: F401
@@ -124,18 +126,19 @@ def test_whole_training_step_is_bit_reproducible(fgbg):
     tgt = torch.rand(B, 3, device=DEV)
     digests = set()
     for rep in range(6):
+        h = r = None
         m = TileModel([-4, -4, -4], [8, 8, 8], DEV, log2_T=16, seed=1)
         with torch.no_grad():
             m.features.mul_(100.0)
         opt = torch.optim.Adam(m.decoder.parameters(), lr=1e-3, betas=(0.9, 0.99), eps=1e-15)
         for i in range(3):
             if fgbg:
-                train_step_fgbg(m, opt, o, d, tgt, S, S, 20000 + i)
+                r = train_step_fgbg(m, opt, o, d, tgt, S, S, 20000 + i, pose_grads=pose)
             else:
-                train_step_fused(m, opt, o, d, tgt, S, 20000 + i)
+                r = train_step_fused(m, opt, o, d, tgt, S, 20000 + i, pose_grads=pose)
         torch.cuda.synchronize()
         h = hashlib.sha256()
-        for t in (m.features.detach(), m.exp_avg, m.exp_avg_sq, m.decoder.blob().detach()):
+        for t in (m.features.detach(), m.exp_avg, m.exp_avg_sq, m.decoder.blob().detach()) + ((r[1], r[2]) if pose else ()):
             h.update(t.cpu().numpy().tobytes())
         digests.add(h.hexdigest())
     assert len(digests) == 1, f"{len(digests)} distinct results over 6 runs"
