@@ -10,6 +10,7 @@ B, S = 8192, 128
 o = torch.rand(B, 3, device=DEV) * 8 - 4
 d = torch.nn.functional.normalize(torch.randn(B, 3, device=DEV), dim=-1) * (0.5 + torch.rand(B, 1, device=DEV))
 tgt = torch.rand(B, 3, device=DEV)
+POSE = bool(int(os.environ.get("POSE", "0")))  # pose_grads=True: Jacobian-stash forward, POSE backward
 dig = lambda t: hashlib.sha256(t.detach().cpu().numpy().tobytes()).hexdigest()[:6]
 for fgbg in ((False, True) if os.environ.get("WHICH", "both") == "both" else (os.environ["WHICH"] == "fgbg",)):
     rows = []
@@ -20,11 +21,15 @@ for fgbg in ((False, True) if os.environ.get("WHICH", "both") == "both" else (os
         opt = torch.optim.Adam(m.decoder.parameters(), lr=1e-3, betas=(0.9, 0.99), eps=1e-15)
         row = []
         for i in range(3):
-            loss = train_step_fgbg(m, opt, o, d, tgt, S, S, 20000 + i) if fgbg else train_step_fused(m, opt, o, d, tgt, S, 20000 + i)
+            r = (train_step_fgbg(m, opt, o, d, tgt, S, S, 20000 + i, pose_grads=POSE) if fgbg
+                 else train_step_fused(m, opt, o, d, tgt, S, 20000 + i, pose_grads=POSE))
+            loss = r[0] if POSE else r
             row += [dig(loss), dig(m.decoder.params.grad), dig(m.decoder.blob()), dig(m.features), dig(m.exp_avg_sq)]
+            if POSE:
+                row[-1] = dig(torch.cat([m.exp_avg_sq.flatten()[:1024], r[1].flatten(), r[2].flatten()]))  # (+ the ray gradients)
         rows.append(row)
     names = [f"{n}{i}" for i in range(3) for n in ("loss", "gblob", "dec", "table", "v")]
-    print("fgbg" if fgbg else "fused")
+    print(("fgbg" if fgbg else "fused") + ("+pose" if POSE else ""))
     from collections import Counter
     major = [Counter(r[k] for r in rows).most_common(1)[0][0] for k in range(len(names))]
     odd = [(i, [names[k] for k in range(len(names)) if r[k] != major[k]]) for i, r in enumerate(rows)]
