@@ -496,7 +496,7 @@ __device__ __forceinline__ void gather_issue(const char *table, const float *rs,
 }
 
 // Second half: trilinear interpolation of the loaded corners (same sums, in the same order, as encode8_01)
-__device__ __forceinline__ void gather_finish(const uint32_t raw[64], float (*tp)[64], int lane, bool active, v16f &x)
+__device__ __forceinline__ void gather_finish(const uint32_t raw[64], float (*tp)[64], int lane, v16f &x)
 {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -508,8 +508,8 @@ __device__ __forceinline__ void gather_finish(const uint32_t raw[64], float (*tp
             ax = fma_mix_lo(raw[8 * j + c], w[c], ax);
             ay = fma_mix_hi(raw[8 * j + c], w[c], ay);
         }
-        x[2 * j] = active ? ax : 0.0f;
-        x[2 * j + 1] = active ? ay : 0.0f;
+        x[2 * j] = ax;  // (lanes without a live sample decode whatever their valid-address loads returned; nothing of theirs is written)
+        x[2 * j + 1] = ay;
     }
     SCANERF_LOAD_GUARD();
 }
@@ -648,7 +648,7 @@ __global__ void __launch_bounds__(kChunkThreads, 1) k_pts_inference_chunks(Infer
         if (have) gather_issue(table, rsh, a.T, h, p01, raw, tpark[wave], lane);
         while (have) {
             v16f x;
-            gather_finish(raw, tpark[wave], lane, cur.run, x);
+            gather_finish(raw, tpark[wave], lane, x);
             __builtin_amdgcn_sched_barrier(0);  // the next group's loads go out after this group's corners are consumed ...
             const bool more = advance(nxt, slot_cur ^ 1);
             if (more) gather_issue(table, rsh, a.T, h, p01, raw, tpark[wave], lane);
