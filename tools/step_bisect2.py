@@ -10,12 +10,13 @@ B, S = 8192, 128
 o = torch.rand(B, 3, device=DEV) * 8 - 4
 d = torch.nn.functional.normalize(torch.randn(B, 3, device=DEV), dim=-1) * (0.5 + torch.rand(B, 1, device=DEV))
 tgt = torch.rand(B, 3, device=DEV)
+TABLE = {"table_dtype": {"bf16": torch.bfloat16, "f16": torch.float16}[os.environ["TABLE"]]} if os.environ.get("TABLE") else {}  # resident half-precision gather table (configs[2])
 POSE = bool(int(os.environ.get("POSE", "0")))  # pose_grads=True: Jacobian-stash forward, POSE backward
 dig = lambda t: hashlib.sha256(t.detach().cpu().numpy().tobytes()).hexdigest()[:6]
 for fgbg in ((False, True) if os.environ.get("WHICH", "both") == "both" else (os.environ["WHICH"] == "fgbg",)):
     rows = []
     for rep in range(int(os.environ.get("REPS", 8))):
-        m = TileModel([-4, -4, -4], [8, 8, 8], DEV, log2_T=16, seed=1)
+        m = TileModel([-4, -4, -4], [8, 8, 8], DEV, log2_T=int(os.environ.get("LOG2T", 16)), seed=1, **TABLE)
         with torch.no_grad():
             m.features.mul_(100.0)
         opt = torch.optim.Adam(m.decoder.parameters(), lr=1e-3, betas=(0.9, 0.99), eps=1e-15)
