@@ -256,6 +256,13 @@ int scanerf_compact_rays(const uint8_t *valid, int B, int S, const float *rays_o
  *   loss [1] = (sum_valid |rgb - target|^2 + reg_weight * sum_valid out_ray[:,14]) / (3 * n_valid)
  *   grad_out [B,16] = its gradient w.r.t. out_ray (all 16 columns written; invalid rays zero)
  * scratch: scanerf_photometric_loss_scratch_floats() f32.  Deterministic (fixed reduction order). */
+/* Ray gradients of a scanerf_render_backward call that produced g_raypos (render.py ray_gradients_fused; replaces autograd through
+ * network.py:38-77 sh_encoding and the direction normalisation of :177): g_o = g_raypos[:,0:3]; g_d = g_raypos[:,3:6] + the |d|
+ * path (g_dnorm [B,ceil(S/32)] summed) + the SH path (g_rowsum [B,2,64] x Directional_MLP.mlp.0 weight rows 32..47 of mlp_blob).
+ * Rays with ray_valid == 0 get zeros. */
+int scanerf_ray_grad_epilogue(const float *rays_d, const float *mlp_blob, const float *g_raypos, const float *g_dnorm,
+                              const float *g_rowsum, const uint8_t *ray_valid, float *g_o, float *g_d, int B, int S,
+                              scanerf_stream_t stream);
 int scanerf_photometric_loss_scratch_floats(void);
 int scanerf_photometric_loss_grad(const float *out_ray, const float *target /*[B,3]*/, const uint8_t *ray_valid,
                                   float reg_weight, float *grad_out, float *loss, float *scratch, int B,

@@ -139,7 +139,87 @@ __global__ void __launch_bounds__(kThreads) k_loss_grad_fgbg(const float *__rest
     }
 }
 
+// ---- ray-gradient epilogue of the fused backward with the in-kernel position path ------------------------------------------
+// dL/d(rays_o) = g_raypos[:, 0:3]; dL/d(rays_d) = g_raypos[:, 3:6] + the two per-ray paths the backward kernel leaves as sums:
+// |d| (delta = dist |d|: g_dnorm summed over the tiles) and SH(d / (|d| + 1e-8)) of the decoder's directional layer
+// (g_rowsum [B,2,64] = the row sums of its layer-0 pre-activation gradient -> times W[:, 32:48]^T -> through the degree-3
+// harmonics and the normalisation).  One wave per ray; what render.ray_gradients_fused did with ~150 torch kernels of
+// autograd on [B]-sized tensors (network.py:38-77, 177 for the harmonics and the normalisation).
+__global__ void __launch_bounds__(256) k_ray_grad_epilogue(const float *__restrict__ rays_d, const float *__restrict__ blob,
+                                                           const float *__restrict__ g_raypos, const float *__restrict__ g_dnorm,
+                                                           const float *__restrict__ g_rowsum, const uint8_t *__restrict__ ray_valid,
+                                                           float *__restrict__ g_o, float *__restrict__ g_d, int B, int ntile)
+{
+    const int lane = threadIdx.x & 63;
+    const int nw = gridDim.x * (blockDim.x >> 6);
+    constexpr int kWsh = 6503 + 64 + 32 * 64;  // Directional_MLP.mlp.0: [bias 64][W^T 48 x 64]; rows 32..47 take the harmonics
+    float w[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) w[i] = blob[kWsh + i * 64 + lane];
+    for (int b = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); b < B; b += nw) {
+        const bool keep = !ray_valid || ray_valid[b];
+        const float r = g_rowsum[(size_t)b * 128 + lane] + g_rowsum[(size_t)b * 128 + 64 + lane];
+        float gsh[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            float v = r * w[i];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+            gsh[i] = v;
+        }
+        float gdn = lane < ntile ? g_dnorm[(size_t)b * ntile + lane] : 0.0f;   // (ntile <= 64: S <= 2048)
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) gdn += __shfl_xor(gdn, off, 64);
+        if (lane != 0) continue;
+        if (!keep) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) g_o[3 * b + k] = g_d[3 * b + k] = 0.0f;
+            continue;
+        }
+        const float d[3] = { rays_d[3 * b], rays_d[3 * b + 1], rays_d[3 * b + 2] };
+        const float dn = sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]), inv = 1.0f / (dn + 1e-8f);
+        const float x = d[0] * inv, y = d[1] * inv, z = d[2] * inv;
+        const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+        constexpr float C1 = 0.4886025119029199f, C20 = 1.0925484305920792f, C21 = -1.0925484305920792f, C22 = 0.31539156525252005f,
+                        C23 = -1.0925484305920792f, C24 = 0.5462742152960396f, C30 = -0.5900435899266435f, C31 = 2.890611442640554f,
+                        C32 = -0.4570457994644658f, C33 = 0.3731763325901154f, C34 = -0.4570457994644658f, C35 = 1.445305721320277f,
+                        C36 = -0.5900435899266435f;
+        // g_u = J^T g_sh, J = d(harmonics)/d(x, y, z) in render_device.h ray_sh's order
+        const float gx = gsh[3] * C1 + gsh[4] * C20 * y - gsh[6] * 2.0f * C22 * x + gsh[7] * C23 * z + gsh[8] * 2.0f * C24 * x +
+                         gsh[9] * 6.0f * C30 * xy + gsh[10] * C31 * yz - gsh[11] * 2.0f * C32 * xy - gsh[12] * 6.0f * C33 * xz +
+                         gsh[13] * C34 * (4.0f * zz - 3.0f * xx - yy) + gsh[14] * 2.0f * C35 * xz + gsh[15] * C36 * (3.0f * xx - 3.0f * yy);
+        const float gy = gsh[1] * C1 + gsh[4] * C20 * x + gsh[5] * C21 * z - gsh[6] * 2.0f * C22 * y - gsh[8] * 2.0f * C24 * y +
+                         gsh[9] * C30 * (3.0f * xx - 3.0f * yy) + gsh[10] * C31 * xz + gsh[11] * C32 * (4.0f * zz - xx - 3.0f * yy) -
+                         gsh[12] * 6.0f * C33 * yz - gsh[13] * 2.0f * C34 * xy - gsh[14] * 2.0f * C35 * yz - gsh[15] * 6.0f * C36 * xy;
+        const float gz = gsh[2] * C1 + gsh[5] * C21 * y + gsh[6] * 4.0f * C22 * z + gsh[7] * C23 * x + gsh[10] * C31 * xy +
+                         gsh[11] * 8.0f * C32 * yz + gsh[12] * C33 * (6.0f * zz - 3.0f * xx - 3.0f * yy) + gsh[13] * 8.0f * C34 * xz +
+                         gsh[14] * C35 * (xx - yy);
+        // u = d / (|d| + eps): g_d = g_u inv - (g_u . d) inv^2 d / |d|;  |d|: + g_dn d / |d|
+        const float gu[3] = { gx, gy, gz };
+        const float dot = gu[0] * d[0] + gu[1] * d[1] + gu[2] * d[2];
+        const float coef = dn > 0.0f ? (gdn - dot * inv * inv) / dn : 0.0f;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            g_o[3 * b + k] = g_raypos[6 * b + k];
+            g_d[3 * b + k] = gu[k] * inv + coef * d[k] + g_raypos[6 * b + 3 + k];
+        }
+    }
+}
+
 }  // namespace
+
+SCANERF_API int scanerf_ray_grad_epilogue(const float *rays_d, const float *mlp_blob, const float *g_raypos, const float *g_dnorm,
+                                          const float *g_rowsum, const uint8_t *ray_valid, float *g_o, float *g_d, int B, int S,
+                                          scanerf_stream_t stream)
+{
+    SCANERF_REQUIRE(B >= 0 && S >= 1 && S <= 2048, "ray_grad_epilogue: B=%d S=%d (S <= 2048)", B, S);
+    if (B == 0) return 0;
+    SCANERF_REQUIRE(rays_d && mlp_blob && g_raypos && g_dnorm && g_rowsum && g_o && g_d, "ray_grad_epilogue: null pointer");
+    const int blocks = (B + 3) / 4 < 1024 ? (B + 3) / 4 : 1024;
+    hipLaunchKernelGGL(k_ray_grad_epilogue, dim3(blocks), dim3(256), 0, (hipStream_t)stream, rays_d, mlp_blob, g_raypos, g_dnorm,
+                       g_rowsum, ray_valid, g_o, g_d, B, (S + 31) / 32);
+    return check_launch("ray_grad_epilogue");
+}
 
 SCANERF_API int scanerf_photometric_loss_scratch_floats(void) { return kBlocks * 5; }
 

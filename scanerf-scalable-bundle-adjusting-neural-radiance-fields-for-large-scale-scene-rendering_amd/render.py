@@ -343,8 +343,22 @@ def scatter_table_grad_adam(points, dfeat, resolutions, params, exp_avg, exp_avg
 
 def ray_gradients_fused(rays_o, rays_d, blob, ray_pos_grad, g_dnorm, g_rowsum, ray_valid=None):
     """dL/d(rays_o), dL/d(rays_d) when the backward kernel produced the position path itself (render_backward(jstash=...,
-    ray_pos_grad=...)): adds the two per-ray paths -- |d| through delta = dist * |d| and SH(d / |d|) of the decoder -- by
-    autograd on [B]-sized tensors.  Same result as ray_gradients()."""
+    ray_pos_grad=...)): adds the two per-ray paths -- |d| through delta = dist * |d| and SH(d / |d|) of the decoder -- in one
+    launch (scanerf_ray_grad_epilogue).  Same result as ray_gradients() / ray_gradients_fused_autograd()."""
+    B = rays_d.shape[0]
+    g_o, g_d = torch.empty_like(rays_o, dtype=_f32), torch.empty_like(rays_d, dtype=_f32)
+    S = g_dnorm.shape[1] * 32
+    check(lib().scanerf_ray_grad_epilogue(
+        dev_ptr(rays_d, _f32, "rays_d"), dev_ptr(blob.detach(), _f32, "mlp_blob"), dev_ptr(ray_pos_grad, _f32, "ray_pos_grad"),
+        dev_ptr(g_dnorm, _f32, "g_dnorm"), dev_ptr(g_rowsum, _f32, "g_rowsum"),
+        dev_ptr(ray_valid, (torch.bool, torch.uint8), "ray_valid", allow_none=True), dev_ptr(g_o, _f32, "g_o"), dev_ptr(g_d, _f32, "g_d"),
+        ctypes.c_int(B), ctypes.c_int(S), stream()), "ray_grad_epilogue")
+    return g_o, g_d
+
+
+def ray_gradients_fused_autograd(rays_o, rays_d, blob, ray_pos_grad, g_dnorm, g_rowsum, ray_valid=None):
+    """ray_gradients_fused by torch autograd on [B]-sized tensors (what it was before the epilogue kernel: ~150 small launches);
+    kept as the reference the tests compare the kernel with."""
     from . import tile_model
     d = rays_d.detach().clone().requires_grad_(True)
     with torch.enable_grad():

@@ -733,6 +733,16 @@ def _ray_gradients_case(bg, arith):
         render.render_backward(RO, RD, Z, DI, F, R, pk, wf, *box, out, tile_T, gout, ray_grad_buffers=bufs2, xstash=xs,
                                jstash=js, ray_pos_grad=rp)
         go2, gd2 = render.ray_gradients_fused(RO, RD, blob, rp, *bufs2)
+        # (one epilogue launch; the same two per-ray paths by torch autograd through the harmonics and the normalisation)
+        go3, gd3 = render.ray_gradients_fused_autograd(RO, RD, blob, rp, *bufs2)
+        assert torch.equal(go2, go3)
+        e = float((gd2 - gd3).abs().max() / gd3.abs().max())
+        print(f"ray-gradient epilogue kernel vs autograd, rays_d (bg={bg}): max err {e:.2e} of max")
+        assert e < 2e-6, e
+        vmask = torch.rand(B, device=DEV) < 0.7
+        gom, gdm = render.ray_gradients_fused(RO, RD, blob, rp, *bufs2, ray_valid=vmask)
+        goa, gda = render.ray_gradients_fused_autograd(RO, RD, blob, rp, *bufs2, ray_valid=vmask)
+        assert torch.equal(gom, goa) and float((gdm - gda).abs().max() / gd3.abs().max()) < 2e-6 and float(gdm[~vmask].abs().max()) == 0.0
         for a_, b_, name in ((go2, go, "rays_o"), (gd2, gd, "rays_d")):
             e = float((a_ - b_).abs().max() / b_.abs().max())
             print(f"in-kernel position path vs dfeat route, {name} (bg={bg}): max err {e:.2e} of max")
