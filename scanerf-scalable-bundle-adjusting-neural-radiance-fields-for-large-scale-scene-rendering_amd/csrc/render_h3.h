@@ -36,9 +36,10 @@ __host__ __device__ constexpr int h3_ku(int t, int h, int j) { return 16 * t + 8
 // the f32 tail lies past 64 KB, beyond the immediate of an LDS read: one address register per weight / bias read, ~35 of them
 // live across the sample loop (render-time kernel 25 -> 4 spilled registers, frame 105 -> 99 ms).  NOT for the training
 // kernels: with the registers this frees, the forward kernel (51 -> 8 spills, 3.33 -> 3.11 ms) produced a wrong encoder output
-// in ~1 of 500 launches of 8 192 rays on cold caches (tools/fwd_fault_rate.py, tools/step_bisect2.py) and no
-// amount of wait states behind its loads removed that; their listing is therefore kept as it was when 800 full-size steps and
-// 800 cold starts were bit-identical.
+// in ~6 % of the forward launches that open a training run (tools/fwd_fault_rate.py, tests/debug/fault_values.py; DESIGN.md 4.10;
+// a corner load consumed before its last quarter-wave had landed) and wait states around its loads lowered that to ~0.2 % but
+// did not remove it; their listing is therefore kept as it was when 800 full-size steps and, this round, 4 000 fresh-model
+// starts were bit-identical.
 #ifndef H3_OPAQUE_ADDR
 #define H3_OPAQUE_ADDR 0
 #endif

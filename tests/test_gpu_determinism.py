@@ -111,7 +111,7 @@ def test_forward_as_the_training_step_calls_it_is_bit_reproducible(dt):
 def test_whole_training_step_is_bit_reproducible(fgbg, pose):
     """The default step end to end -- forward that counts the scatter plan, t16 backward emitting 8-byte records, integer
     accumulate + sparse Adam -- run six times from the same state on 8 192 rays x 128 samples, each time on a FRESH model (cold
-    caches, new allocations: the context in which a re-allocated forward kernel failed once in ~500 launches):
+    caches, new allocations: the context in which a re-allocated forward kernel failed in ~6 % of the first launches):
     table, moments and decoder after three iterations agree bit for bit (no float atomics anywhere on the path; the
     reference's scatter is not reproducible).  Also the foreground + background iteration (two record sets, one Adam), and both
     with pose gradients (Jacobian-stash forward, POSE backward; the ray gradients are hashed too)."""
