@@ -167,7 +167,8 @@ __global__ void __launch_bounds__(256) k_ray_grad_epilogue(const float *__restri
             for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
             gsh[i] = v;
         }
-        float gdn = lane < ntile ? g_dnorm[(size_t)b * ntile + lane] : 0.0f;   // (ntile <= 64: S <= 2048)
+        float gdn = 0.0f;
+        for (int t = lane; t < ntile; t += 64) gdn += g_dnorm[(size_t)b * ntile + t];
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) gdn += __shfl_xor(gdn, off, 64);
         if (lane != 0) continue;
@@ -212,7 +213,7 @@ SCANERF_API int scanerf_ray_grad_epilogue(const float *rays_d, const float *mlp_
                                           const float *g_rowsum, const uint8_t *ray_valid, float *g_o, float *g_d, int B, int S,
                                           scanerf_stream_t stream)
 {
-    SCANERF_REQUIRE(B >= 0 && S >= 1 && S <= 2048, "ray_grad_epilogue: B=%d S=%d (S <= 2048)", B, S);
+    SCANERF_REQUIRE(B >= 0 && S >= 1, "ray_grad_epilogue: B=%d S=%d", B, S);
     if (B == 0) return 0;
     SCANERF_REQUIRE(rays_d && mlp_blob && g_raypos && g_dnorm && g_rowsum && g_o && g_d, "ray_grad_epilogue: null pointer");
     const int blocks = (B + 3) / 4 < 1024 ? (B + 3) / 4 : 1024;
