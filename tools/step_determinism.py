@@ -1,6 +1,6 @@
 """Distinct results of N launches of the forward (with x-stash and tile_T outputs, as the training step calls it) on the same
 inputs after PRE training steps; must be 1."""
-import hashlib, os, sys, torch
+import hashlib, os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import scanerf_amd
 from scanerf_amd import network, render
@@ -8,14 +8,15 @@ from scanerf_amd.tile_model import TileModel, train_step_fused
 DEV = "cuda:0"
 torch.manual_seed(9)
 B, S = int(os.environ.get("B", 4096)), int(os.environ.get("S", 64))
+VALID = bool(int(os.environ.get("VALID", "0")))  # pass the ray_valid mask as the training step does
 PLAN = bool(int(os.environ.get("PLAN", "0")))  # the forward that also counts the scatter plan (k_render_fwd_h3<.., COUNT>)
 o = torch.rand(B, 3, device=DEV) * 8 - 4
 d = torch.nn.functional.normalize(torch.randn(B, 3, device=DEV), dim=-1) * (0.5 + torch.rand(B, 1, device=DEV))
 tgt = torch.rand(B, 3, device=DEV)
 dt = {"bf16": torch.bfloat16, "f32": torch.float32, "f16": torch.float16}[os.environ.get("DT", "bf16")]
-m = TileModel([-4, -4, -4], [8, 8, 8], DEV, log2_T=14, seed=1, table_dtype=dt)
+m = TileModel([-4, -4, -4], [8, 8, 8], DEV, log2_T=int(os.environ.get("LOG2T", 14)), seed=1, table_dtype=dt)
 with torch.no_grad():
-    m.features.mul_(30.0)
+    m.features.mul_(float(os.environ.get("SCALE", 30.0)))
 opt = torch.optim.Adam(m.decoder.parameters(), lr=1e-3, betas=(0.9, 0.99), eps=1e-15)
 for i in range(int(os.environ.get("PRE", 2))):
     train_step_fused(m, opt, o, d, tgt, S, 20000 + i)
@@ -23,6 +24,9 @@ z, dist = m.sample(o, d, S)
 m.packed.pack(m.decoder.blob(), m.weight_feature(20000))
 box = (m.min_bbox.tolist(), m.bbox_size.tolist(), render.FORE, False)
 table = m.gather_table()
+valid = render.ray_valid(z) if VALID else None
+IDLE_US = int(os.environ.get("IDLE_US", "-1"))
+REPACK = bool(int(os.environ.get("REPACK", "0")))  # re-pack the decoder image before every launch (as every step does)
 ref_out = ref_xs = None
 n_out = n_xs = 0
 detail = 0
@@ -33,7 +37,13 @@ for it in range(int(os.environ.get("N", 60))):
         flush_buf.fill_(it & 255)
     tile_T = torch.empty(B, render.tile_T_columns(S), device=DEV)
     xs = torch.empty(B * S, 32, device=DEV)
-    out = render.render_forward(o, d, z, dist, table, m.resolution, m.packed, *box, want_weights=False, tile_T=tile_T, xstash=xs, plan=PLAN)[0]
+    if IDLE_US >= 0:  # let the GPU run dry before the launch (the training step does: compact_rays reads a count on the host)
+        torch.cuda.synchronize()
+        time.sleep(IDLE_US * 1e-6)
+    if REPACK:
+        m.packed.pack(m.decoder.blob(), m.weight_feature(20000))
+    out = render.render_forward(o, d, z, dist, table, m.resolution, m.packed, *box, want_weights=False, tile_T=tile_T, xstash=xs, plan=PLAN,
+                                ray_valid=valid)[0]
     if ref_out is None:
         ref_out, ref_xs = out.clone(), xs.clone()
         continue
