@@ -107,6 +107,44 @@ def test_forward_as_the_training_step_calls_it_is_bit_reproducible(dt):
             assert torch.equal(out, ref[0]) and torch.equal(xs, ref[1]) and torch.equal(tile_T, ref[2]), f"launch {it} differs (table {dt})"
 
 
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_forward_with_cold_instruction_caches_is_bit_reproducible(dt):
+    """The forward that also counts the scatter plan, 8 192 rays x 128 samples, 100 launches with some thirty OTHER kernels run
+    before each one, so that its own instructions are no longer in the instruction caches: the condition under which a
+    differently register-allocated build of this kernel wrote a wrong encoder output in 4-6 % of the launches (DESIGN.md 4.10;
+    tools/step_determinism.py EVICT=1).  Back-to-back launches of one kernel never showed it."""
+    from scanerf_amd import render
+    from scanerf_amd.tile_model import TileModel
+    torch.manual_seed(9)
+    B, S = 8192, 128
+    o = torch.rand(B, 3, device=DEV) * 8 - 4
+    d = torch.nn.functional.normalize(torch.randn(B, 3, device=DEV), dim=-1) * (0.5 + torch.rand(B, 1, device=DEV))
+    m = TileModel([-4, -4, -4], [8, 8, 8], DEV, log2_T=16, seed=1, table_dtype=dt)
+    with torch.no_grad():
+        m.features.mul_(100.0)
+    z, dist = m.sample(o, d, S)
+    m.packed.pack(m.decoder.blob(), m.weight_feature(20000))
+    box = (m.min_bbox.tolist(), m.bbox_size.tolist(), render.FORE, False)
+    table = m.gather_table()
+    ev = torch.rand(1 << 16, device=DEV)
+    ref = None
+    for it in range(100):
+        t = ev
+        for f in (torch.sin, torch.cos, torch.exp, torch.erf, torch.tanh, torch.sigmoid, torch.sqrt, torch.abs, torch.floor, torch.ceil,
+                  torch.log1p, torch.atan, torch.sinh, torch.cosh, torch.round, torch.trunc, torch.neg, torch.reciprocal, torch.square, torch.sign):
+            t = f(t.abs() + 1.0)
+        t = torch.sort(torch.cumsum(t, 0))[0].half().float()
+        t = torch.softmax(t.view(256, -1) @ t.view(-1, 256), -1).to(torch.bfloat16).to(torch.float64).sum()
+        tile_T = torch.empty(B, render.tile_T_columns(S), device=DEV)
+        xs = torch.empty(B * S, 32, device=DEV)
+        out = render.render_forward(o, d, z, dist, table, m.resolution, m.packed, *box, want_weights=False, tile_T=tile_T, xstash=xs,
+                                    plan=render.forward_plan_supported(B, S, table.shape[1]))[0]
+        if ref is None:
+            ref = (out.clone(), xs.clone(), tile_T.clone())
+        else:
+            assert torch.equal(out, ref[0]) and torch.equal(xs, ref[1]) and torch.equal(tile_T, ref[2]), f"launch {it} differs (table {dt})"
+
+
 @pytest.mark.parametrize("fgbg,pose", [(False, False), (True, False), (False, True), (True, True)])
 def test_whole_training_step_is_bit_reproducible(fgbg, pose):
     """The default step end to end -- forward that counts the scatter plan, t16 backward emitting 8-byte records, integer
