@@ -60,7 +60,7 @@ for it in range(int(os.environ.get("N", 60))):
         n_out += 1
     if not torch.equal(xs, ref_xs):
         n_xs += 1
-        if detail < 3:
+        if detail < int(os.environ.get("DETAIL", 3)):
             detail += 1
             dif = torch.nonzero(xs != ref_xs)
             rows = dif[:, 0].unique()
