@@ -56,18 +56,28 @@ for rep in range(REPS):
         row["bwd gblob"] = dig(gblob)
         torch.cuda.synchronize()
         # the records as a multiset (their order within a bucket may differ legitimately? no: fixed cursors) -- hash the raw stream
-        row["bwd recs"] = dig(ws)
+        if os.environ.get("RECS"):   # (hundreds of MB through the host: slow; the order within a bucket differs legitimately)
+            row["bwd recs"] = dig(ws)
         render.scatter_accumulate_adam(ws, m.features.data, m.exp_avg, m.exp_avg_sq, 1e-2, 0.9, 0.99, 1e-15, m.adam_step, B, S,
                                        half_table=m._half_table, overflow_grad=gtab)
         row["table"] = dig(m.features, m.exp_avg, m.exp_avg_sq)
     rows.append(row)
+    if rep % 50 == 49:
+        print(f"  {rep + 1} repeats", flush=True)
 keys = list(rows[0].keys())
-print(" ".join(f"{k:>10s}" for k in keys))
-for r in rows:
-    print(" ".join(f"{r[k]:>10s}" for k in keys))
+if not os.environ.get("QUIET"):
+    print(" ".join(f"{k:>10s}" for k in keys))
+    for r in rows:
+        print(" ".join(f"{r[k]:>10s}" for k in keys))
+from collections import Counter
+for k in keys:
+    if k != "bwd recs":
+        c = Counter(r[k] for r in rows)
+        if len(c) > 1:
+            print(f"  stage {k}: {len(c)} distinct; odd runs {[i for i, r in enumerate(rows) if r[k] != c.most_common(1)[0][0]]}")
 for k in keys:
     n = len(set(r[k] for r in rows))
-    if n > 1:
+    if n > 1 and k != "bwd recs":
         print(f"FIRST DIFFERING STAGE: {k} ({n} distinct of {REPS})")
         break
 else:
