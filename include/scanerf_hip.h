@@ -268,8 +268,9 @@ int scanerf_photometric_loss_grad(const float *out_ray, const float *target /*[B
                                   float reg_weight, float *grad_out, float *loss, float *scratch, int B,
                                   scanerf_stream_t stream);
 /* The same for the complete per-tile render (tile.py:666-690 merge, tile.py:880-1015 loss): pred = fg.rgb + fg.T_left * bg.rgb,
- * loss [1] = mean over all rays x 3 of (pred - target)^2 + reg_weight * (l2_reg_specular of the fg-valid rays + of the
- * bg-valid rays); grad_fg / grad_bg [B,16] = its gradients w.r.t. the two branches' out_ray (fg: rgb, T_left and column 14;
+ * loss [1] = mean over the rays valid in either branch (criterions.py:121-138: valid = fore_valid | bg_valid) x 3 of
+ * (pred - target)^2 + reg_weight * (l2_reg_specular of the fg-valid rays + of the bg-valid rays); rays invalid in both
+ * branches get zero gradients; grad_fg / grad_bg [B,16] = its gradients w.r.t. the two branches' out_ray (fg: rgb, T_left and column 14;
  * bg: rgb and column 14).  scratch as above. */
 int scanerf_photometric_loss_grad_fgbg(const float *out_fg, const float *out_bg, const float *target,
                                        const uint8_t *valid_fg, const uint8_t *valid_bg, float reg_weight, float *grad_fg,

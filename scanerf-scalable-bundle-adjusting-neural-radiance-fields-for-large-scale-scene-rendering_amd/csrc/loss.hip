@@ -70,36 +70,42 @@ __global__ void __launch_bounds__(kThreads) k_loss_grad(const float *__restrict_
 }
 
 // ---- the complete per-tile render: foreground + T_left * background (tile.py:666-690), loss of tile.py:880-1015 ----------
-// pred = fg.rgb + fg.T_left * bg.rgb;  loss = mean over ALL rays x 3 of (pred - target)^2
+// pred = fg.rgb + fg.T_left * bg.rgb;  loss = mean over the rays VALID IN EITHER BRANCH (criterions.py:121-138:
+//        input[valid], target[valid] with valid = fore_valid | bg_valid) x 3 of (pred - target)^2
 //        + reg * (sum_{fg-valid} fg[:,14] / (3 n_fg) + sum_{bg-valid} bg[:,14] / (3 n_bg)).
-// partials per block: [se, w2_fg, n_fg, w2_bg, n_bg]
+// A ray invalid in both branches (under-ground invalidation, occlusion masks) contributes nothing and gets a zero gradient.
+// partials per block: [se, w2_fg, n_fg, w2_bg, n_bg, n_union]
 __global__ void __launch_bounds__(kThreads) k_loss_partials_fgbg(const float *__restrict__ fg, const float *__restrict__ bg,
                                                                  const float *__restrict__ target, const uint8_t *__restrict__ vfg,
                                                                  const uint8_t *__restrict__ vbg, int B, float *__restrict__ partials)
 {
-    float acc[5] = { 0, 0, 0, 0, 0 };
+    float acc[6] = { 0, 0, 0, 0, 0, 0 };
     for (int r = blockIdx.x * kThreads + threadIdx.x; r < B; r += kBlocks * kThreads) {
         const float *f = fg + (size_t)r * SCANERF_RAY_OUT, *b = bg + (size_t)r * SCANERF_RAY_OUT;
         const float T = f[4];
+        const bool in_fg = !vfg || vfg[r], in_bg = !vbg || vbg[r];
+        if (in_fg || in_bg) {
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const float e = f[c] + T * b[c] - target[3 * r + c];
-            acc[0] += e * e;
+            for (int c = 0; c < 3; ++c) {
+                const float e = f[c] + T * b[c] - target[3 * r + c];
+                acc[0] += e * e;
+            }
+            acc[5] += 1.0f;
         }
-        if (!vfg || vfg[r]) { acc[1] += f[14]; acc[2] += 1.0f; }
-        if (!vbg || vbg[r]) { acc[3] += b[14]; acc[4] += 1.0f; }
+        if (in_fg) { acc[1] += f[14]; acc[2] += 1.0f; }
+        if (in_bg) { acc[3] += b[14]; acc[4] += 1.0f; }
     }
-    __shared__ float red[5][kThreads];
+    __shared__ float red[6][kThreads];
 #pragma unroll
-    for (int k = 0; k < 5; ++k) red[k][threadIdx.x] = acc[k];
+    for (int k = 0; k < 6; ++k) red[k][threadIdx.x] = acc[k];
     __syncthreads();
     for (int s = kThreads / 2; s > 0; s >>= 1) {  // fixed tree: deterministic
         if ((int)threadIdx.x < s)
 #pragma unroll
-            for (int k = 0; k < 5; ++k) red[k][threadIdx.x] += red[k][threadIdx.x + s];
+            for (int k = 0; k < 6; ++k) red[k][threadIdx.x] += red[k][threadIdx.x + s];
         __syncthreads();
     }
-    if (threadIdx.x < 5) partials[blockIdx.x * 5 + threadIdx.x] = red[threadIdx.x][0];
+    if (threadIdx.x < 6) partials[blockIdx.x * 6 + threadIdx.x] = red[threadIdx.x][0];
 }
 
 __global__ void __launch_bounds__(kThreads) k_loss_grad_fgbg(const float *__restrict__ fg, const float *__restrict__ bg,
@@ -108,34 +114,36 @@ __global__ void __launch_bounds__(kThreads) k_loss_grad_fgbg(const float *__rest
                                                              const float *__restrict__ partials, float *__restrict__ gfg,
                                                              float *__restrict__ gbg, float *__restrict__ loss)
 {
-    __shared__ float tot[5];
-    if (threadIdx.x < 5) {
+    __shared__ float tot[6];
+    if (threadIdx.x < 6) {
         float s = 0.0f;
-        for (int b = 0; b < kBlocks; ++b) s += partials[b * 5 + threadIdx.x];
+        for (int b = 0; b < kBlocks; ++b) s += partials[b * 6 + threadIdx.x];
         tot[threadIdx.x] = s;
     }
     __syncthreads();
-    const float n3 = 3.0f * (float)B;
+    const float n3 = 3.0f * tot[5];   // rays valid in either branch
+    const float in3 = n3 > 0.0f ? 1.0f / n3 : 0.0f;
     const float l2f = tot[2] > 0.0f ? 1.0f / (3.0f * tot[2]) : 0.0f, l2b = tot[4] > 0.0f ? 1.0f / (3.0f * tot[4]) : 0.0f;
-    if (blockIdx.x == 0 && threadIdx.x == 0) *loss = tot[0] / n3 + reg * (tot[1] * l2f + tot[3] * l2b);
+    if (blockIdx.x == 0 && threadIdx.x == 0) *loss = tot[0] * in3 + reg * (tot[1] * l2f + tot[3] * l2b);
     for (int r = blockIdx.x * kThreads + threadIdx.x; r < B; r += gridDim.x * kThreads) {
         const float *f = fg + (size_t)r * SCANERF_RAY_OUT, *b = bg + (size_t)r * SCANERF_RAY_OUT;
         const float T = f[4];
+        const bool in_fg = !vfg || vfg[r], in_bg = !vbg || vbg[r];
         float gp[3], gT = 0.0f;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            gp[c] = 2.0f * (f[c] + T * b[c] - target[3 * r + c]) / n3;
+            gp[c] = (in_fg || in_bg) ? 2.0f * (f[c] + T * b[c] - target[3 * r + c]) * in3 : 0.0f;
             gT += gp[c] * b[c];
         }
         float4 *g = reinterpret_cast<float4 *>(gfg + (size_t)r * SCANERF_RAY_OUT), *h = reinterpret_cast<float4 *>(gbg + (size_t)r * SCANERF_RAY_OUT);
         g[0] = make_float4(gp[0], gp[1], gp[2], 0.0f);
         g[1] = make_float4(gT, 0, 0, 0);   // column 4 = T_left
         g[2] = make_float4(0, 0, 0, 0);
-        g[3] = make_float4(0, 0, (!vfg || vfg[r]) ? reg * l2f : 0.0f, 0);
+        g[3] = make_float4(0, 0, in_fg ? reg * l2f : 0.0f, 0);
         h[0] = make_float4(gp[0] * T, gp[1] * T, gp[2] * T, 0.0f);
         h[1] = make_float4(0, 0, 0, 0);
         h[2] = make_float4(0, 0, 0, 0);
-        h[3] = make_float4(0, 0, (!vbg || vbg[r]) ? reg * l2b : 0.0f, 0);
+        h[3] = make_float4(0, 0, in_bg ? reg * l2b : 0.0f, 0);
     }
 }
 
@@ -222,10 +230,10 @@ SCANERF_API int scanerf_ray_grad_epilogue(const float *rays_d, const float *mlp_
     return check_launch("ray_grad_epilogue");
 }
 
-SCANERF_API int scanerf_photometric_loss_scratch_floats(void) { return kBlocks * 5; }
+SCANERF_API int scanerf_photometric_loss_scratch_floats(void) { return kBlocks * 6; }
 
 // Loss of the complete per-tile render and its gradients w.r.t. the two branches' per-ray outputs, two launches:
-// pred = fg.rgb + fg.T_left * bg.rgb (tile.py:666-690), MSE over all rays (criterions.py:142-144) + reg * the two branches'
+// pred = fg.rgb + fg.T_left * bg.rgb (tile.py:666-690), MSE over the rays valid in either branch (criterions.py:121-138,142-144) + reg * the two branches'
 // l2_reg_specular (tile.py:999).  Rays a branch does not render hold (0, .., T_left = 1) (render_forward's invalid-ray output).
 SCANERF_API int scanerf_photometric_loss_grad_fgbg(const float *out_fg, const float *out_bg, const float *target,
                                                    const uint8_t *valid_fg, const uint8_t *valid_bg, float reg_weight,

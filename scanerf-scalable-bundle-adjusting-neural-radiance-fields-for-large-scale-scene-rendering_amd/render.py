@@ -188,7 +188,7 @@ def photometric_loss_grad(out_ray, target, ray_valid=None, reg_weight=0.01, grad
 
 
 def photometric_loss_grad_fgbg(out_fg, out_bg, target, valid_fg=None, valid_bg=None, reg_weight=0.01):
-    """Loss of the complete per-tile render (tile.py:666-690: pred = fg.rgb + fg.T_left * bg.rgb; MSE over all rays +
+    """Loss of the complete per-tile render (tile.py:666-690: pred = fg.rgb + fg.T_left * bg.rgb; MSE over the rays valid in either branch, criterions.py:121-138, +
     reg_weight * both branches' l2_reg_specular, tile.py:999) and its gradients w.r.t. the two branches' out_ray, without a
     torch graph -> (loss [1], grad_fg [B,16], grad_bg [B,16])."""
     B = out_fg.shape[0]

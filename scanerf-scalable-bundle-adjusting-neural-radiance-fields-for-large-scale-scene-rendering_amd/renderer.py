@@ -36,6 +36,12 @@ def load_tile(path):
             "blob": network.blob_from_state_dict(sd).numpy()}
 
 
+def render_box(block_corner, block_size):
+    """feature.npz stores the 2x HashGrid box (hashgrid/__init__.py:50,254-255); the renderer traces the inner tile box:
+    corner + size / 4, size / 2 (rendering.py:164-165)."""
+    return block_corner + block_size / 4.0, block_size / 2.0
+
+
 class TileSetRenderer:
     def __init__(self, device, tiles):
         """tiles: dicts as returned by load_tile (block_corner / block_size describe the 2x HashGrid box;
@@ -55,8 +61,7 @@ class TileSetRenderer:
         self.occupied_grid = t(np.concatenate(grids), torch.bool)
         corner = t(np.stack([x["block_corner"] for x in tiles]), torch.float32)
         size = t(np.stack([x["block_size"] for x in tiles]), torch.float32)
-        self.block_corner = (corner + size / 4.0).contiguous()
-        self.block_size = (size / 2.0).contiguous()
+        self.block_corner, self.block_size = (x.contiguous() for x in render_box(corner, size))
         # sampling grid: each tile's occupancy dilated into the tiles it overlaps (rendering.py:168-173)
         self.fake_occupied_grid = self.occupied_grid.clone()
         for i in range(len(tiles)):
@@ -75,8 +80,13 @@ class TileSetRenderer:
         return o, d
 
     @torch.no_grad()
-    def render_rays(self, rays_o, rays_d, num_sample=128, num_bg_sample=128, sample_range=1e6, layout=2):
-        """layout of the per-sample work arrays between the ops (same ops, same arithmetic per sample; scanerf_hip.h
+    def render_rays(self, rays_o, rays_d, num_sample=128, num_bg_sample=128, sample_range=1e6, layout=2,
+                    skip_saturated_background=False):
+        """skip_saturated_background: False (default) = the reference's behaviour, every ray gets its blended background
+        (rendering.py:534-536); True = rays whose foreground transmittance is <= 1e-5 (the threshold at which rendering.py:356
+        stops tracing them) get none: colour changes by <= 1e-5, but the returned DEPTH loses transparency * bg_depth, which can
+        reach ~1e-5 * sample_range = 10 units (tests/test_gpu_render_time.py bounds both).
+        layout of the per-sample work arrays between the ops (same ops, same arithmetic per sample; scanerf_hip.h
         `sample_major`): 0 = the reference's [B,S]; 2 (default) = [B/32,S,32]: a wave of the inference kernel holds ONE depth
         index of 32 neighbouring rays -- neighbouring pixels share their cells down to the fine levels, so the table gathers of
         a wave fall on a few lines instead of 32 per level -- and walks along those rays; 1 = [S,B] (measured slower: every
@@ -125,10 +135,10 @@ class TileSetRenderer:
         bg_w = torch.zeros(B, 4, device=dev)
         update_outgoing_bidx(rays_o, rays_d, self.block_corner, self.block_size, tracing_blocks, inter, bg_b, bg_w, 0.12, False)
         bg_w = bg_w / torch.sum(bg_w, dim=-1, keepdim=True)
-        # rays the foreground has saturated (transmittance <= 1e-5, the threshold at which rendering.py:356 stops tracing them)
-        # get no background: it would enter the pixel with weight <= 1e-5 -- 400x below one 8-bit step -- and on an opaque
-        # scene it is most of the frame's decoder work
-        bg_b[(transp <= 1e-5)[:, 0]] = -1
+        if skip_saturated_background:
+            # rays the foreground has saturated get no background: it would enter the pixel with weight <= 1e-5 -- 400x below
+            # one 8-bit step -- and on an opaque scene it is most of the frame's decoder work
+            bg_b[(transp <= 1e-5)[:, 0]] = -1
         n_blend = int((bg_w > 0).sum(dim=-1).max().cpu())
         bgd, bgs, bgz = torch.zeros(B, 3, device=dev), torch.zeros(B, 3, device=dev), torch.zeros(B, 1, device=dev)
         if num_bg_sample != num_sample:

@@ -608,7 +608,8 @@ def test_fgbg_training_gradients_vs_oracle(S):
     Ft = m.features.detach().cpu().clone().requires_grad_(True)
     sd = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in m.decoder.ref_state_dict().items()}
     ref = O.render_rays(tile, Ft, sd, torch.from_numpy(o), torch.from_numpy(d), Sf, Sb, O.TRAIN, step, invalid_underground=True)
-    lref = torch.nn.functional.mse_loss(ref["pred_color"], torch.from_numpy(tgt)) + 0.01 * ref["l2_reg_specular"]
+    vu = ref["fore_valid"] | ref["bg_valid"]   # criterions.py:121-138: the RGB loss sees input[valid], target[valid]
+    lref = torch.nn.functional.mse_loss(ref["pred_color"][vu], torch.from_numpy(tgt)[vu]) + 0.01 * ref["l2_reg_specular"]
     lref.backward()
     np.testing.assert_allclose(loss.item(), lref.item(), rtol=2e-5)
     from scanerf_amd import render
@@ -639,6 +640,43 @@ def test_photometric_loss_grad_vs_autograd(S):
         loss, g_out = render.photometric_loss_grad(out, tgt, valid, 0.01)
         np.testing.assert_allclose(loss.item(), ref.item(), rtol=2e-6)
         np.testing.assert_allclose(g_out.cpu().numpy(), leaf.grad.cpu().numpy(), rtol=1e-6, atol=1e-12)
+
+
+def test_photometric_loss_grad_fgbg_masks_rays_invalid_in_both_branches(S):
+    """csrc/loss.hip fg+bg form against the torch graph of the reference: pred = fg.rgb + T_left * bg.rgb (tile.py:666-690),
+    RGB loss over input[valid], target[valid] with valid = fore_valid | bg_valid (criterions.py:121-138), l2_reg of each
+    branch over its own valid rays (hashgrid/__init__.py:593, tile.py:999).  Rays invalid in both get zero gradients."""
+    from scanerf_amd import render
+    torch.manual_seed(12)
+    for B in (5, 777, 70000):
+        fg = torch.rand(B, 16, device=DEV)
+        bg = torch.rand(B, 16, device=DEV)
+        tgt = torch.rand(B, 3, device=DEV)
+        vf = torch.rand(B, device=DEV) < 0.6
+        vb = torch.rand(B, device=DEV) < 0.6
+        vf[0], vb[0] = True, False
+        vf[1], vb[1] = False, False
+        # what the forward writes for rays a branch does not render (render.hip: zeros, T_left = 1)
+        with torch.no_grad():
+            fg[~vf] = 0.0
+            fg[~vf, 4] = 1.0
+            bg[~vb] = 0.0
+            bg[~vb, 4] = 1.0
+        lf, lb = fg.clone().requires_grad_(True), bg.clone().requires_grad_(True)
+        pred = lf[:, 0:3] + lf[:, 4:5] * lb[:, 0:3]
+        vu = vf | vb
+        ref = torch.nn.functional.mse_loss(pred[vu], tgt[vu]) + 0.01 * (lf[:, 14][vf].sum() / (3 * vf.sum()) + lb[:, 14][vb].sum() / (3 * vb.sum()))
+        ref.backward()
+        loss, gfg, gbg = render.photometric_loss_grad_fgbg(fg, bg, tgt, vf, vb, 0.01)
+        np.testing.assert_allclose(loss.item(), ref.item(), rtol=3e-6)
+        np.testing.assert_allclose(gfg.cpu().numpy(), lf.grad.cpu().numpy(), rtol=1e-6, atol=1e-12)
+        np.testing.assert_allclose(gbg.cpu().numpy(), lb.grad.cpu().numpy(), rtol=1e-6, atol=1e-12)
+        both = ~vu
+        assert int(both.sum()) > 0 and float(gfg[both].abs().max()) == 0.0 and float(gbg[both].abs().max()) == 0.0
+    # no masks at all: every ray counts
+    fg, bg, tgt = torch.rand(64, 16, device=DEV), torch.rand(64, 16, device=DEV), torch.rand(64, 3, device=DEV)
+    loss, _, _ = render.photometric_loss_grad_fgbg(fg, bg, tgt, None, None, 0.0)
+    np.testing.assert_allclose(loss.item(), torch.nn.functional.mse_loss(fg[:, 0:3] + fg[:, 4:5] * bg[:, 0:3], tgt).item(), rtol=3e-6)
 
 
 def test_render_rays_fg_bg_merge_vs_oracle(S):
@@ -1282,7 +1320,8 @@ def test_fgbg_iteration_ray_gradients_vs_oracle(S):
     sd = {k: v.detach().cpu().clone() for k, v in m.decoder.ref_state_dict().items()}
     to, td = torch.from_numpy(o).requires_grad_(True), torch.from_numpy(d).requires_grad_(True)
     ref = O.render_rays(tile, Ft, sd, to, td, Sf, Sb, O.TRAIN, step, invalid_underground=True)
-    lref = torch.nn.functional.mse_loss(ref["pred_color"], torch.from_numpy(tgt)) + 0.01 * ref["l2_reg_specular"]
+    vu = ref["fore_valid"] | ref["bg_valid"]   # criterions.py:121-138: the RGB loss sees input[valid], target[valid]
+    lref = torch.nn.functional.mse_loss(ref["pred_color"][vu], torch.from_numpy(tgt)[vu]) + 0.01 * ref["l2_reg_specular"]
     lref.backward()
     opt = torch.optim.SGD(m.decoder.parameters(), lr=0.0)
     # (the unfused route -- what tables above 2^21 entries take -- gives the same ray gradients)

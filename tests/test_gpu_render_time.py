@@ -273,6 +273,15 @@ def test_renderer_end_to_end_and_tile_formats(tmp_path):
     ragged = rnd.render_rays(*(t[:333].contiguous() for t in rnd.compute_rays(H, W, K, c2w)), num_sample=64, num_bg_sample=32)
     for a_, b_ in zip((dif, spec, depth, transp), ragged):   # 333 rays: padded to a multiple of 32 inside
         assert torch.equal(a_.reshape(H * W, -1)[:333], b_)
+    # opt-in skip of the backgrounds of saturated rays (not the reference's behaviour: rendering.py:534-536 adds
+    # transparency * background for every ray): identical wherever the transmittance is above 1e-5, colour within 1e-5 and
+    # depth within 1e-5 * sample_range elsewhere
+    sk = rnd.render(H, W, K, c2w, num_sample=64, num_bg_sample=32, skip_saturated_background=True)
+    sat = (transp <= 1e-5)[..., 0]
+    for a_, b_, bound in zip((dif, spec, depth), sk[:3], (1e-5, 1e-5, 1e-5 * 1e6)):
+        assert torch.equal(a_[~sat], b_[~sat])
+        if bool(sat.any()):
+            assert float((a_[sat] - b_[sat]).abs().max()) <= bound * 1.001
     # ---- the same loop on the oracle
     o, d = (t.cpu().numpy() for t in rnd.compute_rays(H, W, K, c2w))
     o_ref, d_ref = O.compute_ray_forward(np.stack([np.zeros(H * W), np.tile(np.arange(W), H), np.repeat(np.arange(H), W)], 1),

@@ -254,3 +254,45 @@ def test_metrics_match_reference_golden_g11(golden, tmp_path):
     assert txt[0].startswith("img 0 psnr ") and "\tssim " in txt[0] and txt[2].startswith("mean psnr ")
     np.testing.assert_allclose(rows[0][1], float(g["psnr_ab0"]), rtol=1e-5)
     np.testing.assert_allclose(ms, float(g["ssim_ab"]), rtol=1e-3)
+
+
+def test_tile_export_read_from_the_reference_writers_files_golden_g12(golden, tmp_path):
+    """f3: tests/golden/g12_tile/ was written by the REFERENCE's own code (HashGrid.export, hashgrid/__init__.py:248-257,
+    and tile.py:521's torch.save of the decoder state dict; tests/golden/make_golden_formats.py).  renderer.load_tile must
+    give what the reference's consumer makes of those files (rendering.py:101-112 blob via tools.utils.extract_MLP_para,
+    :164-165 box rule -- both captured in g12_expected.npz), and this repo's writer must produce the same file layout."""
+    import scanerf_amd  # noqa
+    from scanerf_amd import renderer as R
+    exp = golden("g12_expected")
+    t = R.load_tile(os.path.join(ROOT, "tests", "golden", "g12_tile"))
+    assert t["blob"].dtype == np.float32 and np.array_equal(t["blob"], exp["blob"])          # layer order, [bias, W^T]
+    assert t["features"].dtype == np.float16 and t["features"].shape == (16, 64, 2)
+    assert np.array_equal(t["features"], exp["features_f32"].astype(np.float16))
+    assert t["occupied_grid"].dtype == np.bool_ and np.array_equal(t["occupied_grid"], exp["occupied_grid"])
+    assert t["resolution"].dtype == np.int32 and np.array_equal(t["resolution"], exp["resolution"])
+    assert t["grid_log2dim"].dtype == np.int32 and np.array_equal(t["grid_log2dim"], exp["grid_log2dim"])
+    # the file stores the 2x box; the renderer's box rule gives back the tile itself
+    c, z = R.render_box(torch.from_numpy(t["block_corner"]), torch.from_numpy(t["block_size"]))
+    assert np.array_equal(c.numpy(), exp["render_block_corner"]) and np.array_equal(z.numpy(), exp["render_block_size"])
+    assert np.allclose(c.numpy(), exp["tile_corner"]) and np.allclose(z.numpy(), exp["tile_size"])
+    # this repo's writer: same keys, dtypes and shapes as the reference's file, and a model restored from the
+    # reference's file exports the same arrays
+    from scanerf_amd.tile_model import TileModel
+    m = TileModel(exp["tile_corner"].tolist(), exp["tile_size"].tolist(), "cpu", log2_T=6, seed=1, grid_resolution=(4, 64), sampler_log2dim=3)
+    assert np.array_equal(m.log2dim.cpu().numpy(), exp["grid_log2dim"])
+    with torch.no_grad():
+        m.features.copy_(torch.from_numpy(exp["features_f32"]))
+        m.decoder.params.copy_(torch.from_numpy(exp["blob"]))
+    m.set_occupancy(torch.from_numpy(exp["occupied_grid"]))
+    assert np.array_equal(m.resolution.cpu().numpy(), exp["resolution"])
+    R.export_tile(str(tmp_path / "mine"), m)
+    ref_f, my_f = np.load(os.path.join(ROOT, "tests", "golden", "g12_tile", "feature.npz")), np.load(tmp_path / "mine" / "feature.npz")
+    assert sorted(ref_f.files) == sorted(my_f.files)
+    for k in ref_f.files:
+        assert ref_f[k].dtype == my_f[k].dtype and ref_f[k].shape == my_f[k].shape, k
+        assert np.array_equal(ref_f[k], my_f[k]), k
+    ref_sd = torch.load(os.path.join(ROOT, "tests", "golden", "g12_tile", "decoder.pth"), map_location="cpu")
+    my_sd = torch.load(tmp_path / "mine" / "decoder.pth", map_location="cpu")
+    assert list(ref_sd.keys()) == list(my_sd.keys())                                          # the consumer walks the keys IN ORDER
+    for k in ref_sd:
+        assert ref_sd[k].shape == my_sd[k].shape and torch.equal(ref_sd[k], my_sd[k]), k
