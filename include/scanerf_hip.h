@@ -281,6 +281,10 @@ int scanerf_photometric_loss_grad_fgbg(const float *out_fg, const float *out_bg,
  * = row sums of dy. */
 int scanerf_h3_selftest(const float *workspace, const float *dy, const float *x, float *out_dx, float *out_dw,
                         float *out_rs, scanerf_stream_t stream);
+/* Test infrastructure: one launch of ~300 KB of straight-line code on every CU, after which no other kernel's instructions are
+ * left in the instruction caches (no reference counterpart; tests/test_gpu_determinism.py, tools/fault_probe.py: faults that only
+ * show on cold instruction caches). */
+int scanerf_icache_sweep(scanerf_stream_t stream);
 /* Test infrastructure: the 8-byte scatter-record codec (csrc/scatter_common.h Rec8) on n values.  words [n][2] = the packed
  * records; out [n][8] = l0, l1, the four contributions the accumulate adds (x, y to l0; x, y to l1), E - 25, t. */
 int scanerf_rec8_selftest(const float *gx, const float *gy, const float *tx, const uint32_t *l0, const uint32_t *k, int n,

@@ -80,7 +80,23 @@ __global__ void __launch_bounds__(64) k_h3_selftest(const float *packed, const f
     }
 }
 
+// ~300 KB of straight-line code on every CU (no LDS, three registers): after it no other kernel's instructions are left in the
+// 64 KB instruction caches.  Test infrastructure: launch-to-launch comparisons with this in between are the screen for faults
+// that only show when a kernel starts on cold instruction caches (tools/fault_probe.py).
+__global__ void __launch_bounds__(512, 2) k_icache_sweep(float *sink, int never)
+{
+    float a = (float)threadIdx.x, b = 1.0f;
+    asm volatile(".rept 75000\n v_add_f32 %0, %0, %1\n .endr\n" : "+v"(a) : "v"(b));
+    if (never) sink[threadIdx.x] = a;
+}
+
 }  // namespace
+
+SCANERF_API int scanerf_icache_sweep(scanerf_stream_t stream)
+{
+    hipLaunchKernelGGL(k_icache_sweep, dim3(2 * kNumCU), dim3(512), 0, (hipStream_t)stream, nullptr, 0);
+    return check_launch("icache_sweep");
+}
 
 SCANERF_API int scanerf_h3_selftest(const float *packed, const float *dy, const float *x, float *out_dx, float *out_dw,
                                     float *out_rs, scanerf_stream_t stream)

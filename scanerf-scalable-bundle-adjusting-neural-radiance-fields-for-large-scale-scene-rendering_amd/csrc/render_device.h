@@ -214,10 +214,20 @@ __device__ __forceinline__ void encode8(const RenderArgs &a, const int *lds_res,
             for (int c = 0; c < 8; ++c) f[c] = TableElem<DT>::load(slice, idx[c]);
         }
         float ax = 0.0f, ay = 0.0f;
+#ifndef ENC_INTERP
+#define ENC_INTERP 0
+#endif
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
+#if ENC_INTERP == 1   // every weight one opaque register: no (w, w) pairs for packed multiply-adds
+            asm volatile("" : "+v"(w[c]));
+#endif
             ax = fmaf(w[c], f[c].x, ax);
             ay = fmaf(w[c], f[c].y, ay);
+#if ENC_INTERP == 2   // the two sums kept apart: no packed multiply-adds at all
+            asm volatile("" : "+v"(ax));
+            asm volatile("" : "+v"(ay));
+#endif
         }
         x[2 * j] = ax;
         x[2 * j + 1] = ay;

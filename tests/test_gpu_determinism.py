@@ -107,13 +107,14 @@ def test_forward_as_the_training_step_calls_it_is_bit_reproducible(dt):
             assert torch.equal(out, ref[0]) and torch.equal(xs, ref[1]) and torch.equal(tile_T, ref[2]), f"launch {it} differs (table {dt})"
 
 
-@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
-def test_forward_with_cold_instruction_caches_is_bit_reproducible(dt):
-    """The forward that also counts the scatter plan, 8 192 rays x 128 samples, 100 launches with some thirty OTHER kernels run
-    before each one, so that its own instructions are no longer in the instruction caches: the condition under which a
-    differently register-allocated build of this kernel wrote a wrong encoder output in 4-6 % of the launches (DESIGN.md 4.10;
-    tools/step_determinism.py EVICT=1).  Back-to-back launches of one kernel never showed it."""
-    from scanerf_amd import render
+@pytest.mark.parametrize("dt,pose", [(torch.float32, False), (torch.bfloat16, False), (torch.float32, True)])
+def test_forward_with_cold_instruction_caches_is_bit_reproducible(dt, pose):
+    """The forward that also counts the scatter plan (and, pose: writes the position-Jacobian stash), 8 192 rays x 128 samples,
+    300 launches with the instruction caches swept before each one (scanerf_icache_sweep: 300 KB of straight-line code on every
+    CU).  This is the condition under which the forward built with packed-f32 (w, w) weight pairs lost one corner's term in lanes
+    48-63 of a tile in 8 % of the launches (tools/fault_probe.py: the sweep alone brings the fault out, poisoning
+    every register and all LDS between launches does not).  Back-to-back launches of one kernel never showed it."""
+    from scanerf_amd import _capi, render
     from scanerf_amd.tile_model import TileModel
     torch.manual_seed(9)
     B, S = 8192, 128
@@ -126,23 +127,19 @@ def test_forward_with_cold_instruction_caches_is_bit_reproducible(dt):
     m.packed.pack(m.decoder.blob(), m.weight_feature(20000))
     box = (m.min_bbox.tolist(), m.bbox_size.tolist(), render.FORE, False)
     table = m.gather_table()
-    ev = torch.rand(1 << 16, device=DEV)
     ref = None
-    for it in range(100):
-        t = ev
-        for f in (torch.sin, torch.cos, torch.exp, torch.erf, torch.tanh, torch.sigmoid, torch.sqrt, torch.abs, torch.floor, torch.ceil,
-                  torch.log1p, torch.atan, torch.sinh, torch.cosh, torch.round, torch.trunc, torch.neg, torch.reciprocal, torch.square, torch.sign):
-            t = f(t.abs() + 1.0)
-        t = torch.sort(torch.cumsum(t, 0))[0].half().float()
-        t = torch.softmax(t.view(256, -1) @ t.view(-1, 256), -1).to(torch.bfloat16).to(torch.float64).sum()
+    for it in range(300):
+        _capi.check(_capi.lib().scanerf_icache_sweep(_capi.stream()), "icache_sweep")
         tile_T = torch.empty(B, render.tile_T_columns(S), device=DEV)
         xs = torch.empty(B * S, 32, device=DEV)
+        js = torch.empty(render.jstash_shape(B, S), dtype=render.JSTASH_DTYPE, device=DEV) if pose else None
         out = render.render_forward(o, d, z, dist, table, m.resolution, m.packed, *box, want_weights=False, tile_T=tile_T, xstash=xs,
-                                    plan=render.forward_plan_supported(B, S, table.shape[1]))[0]
+                                    plan=render.forward_plan_supported(B, S, table.shape[1]), jstash=js)[0]
+        got = (out, xs, tile_T) + ((js,) if pose else ())
         if ref is None:
-            ref = (out.clone(), xs.clone(), tile_T.clone())
+            ref = tuple(t.clone() for t in got)
         else:
-            assert torch.equal(out, ref[0]) and torch.equal(xs, ref[1]) and torch.equal(tile_T, ref[2]), f"launch {it} differs (table {dt})"
+            assert all(torch.equal(a, b) for a, b in zip(got, ref)), f"launch {it} differs (table {dt}, pose {pose})"
 
 
 @pytest.mark.parametrize("fgbg,pose", [(False, False), (True, False), (False, True), (True, True)])
@@ -180,3 +177,39 @@ def test_whole_training_step_is_bit_reproducible(fgbg, pose):
             h.update(t.cpu().numpy().tobytes())
         digests.add(h.hexdigest())
     assert len(digests) == 1, f"{len(digests)} distinct results over 12 runs"
+
+
+@pytest.mark.parametrize("fgbg,pose", [(False, False), (True, True)])
+def test_whole_training_step_with_the_instruction_caches_swept_between_all_kernels(fgbg, pose):
+    """As test_whole_training_step_is_bit_reproducible, with the instruction caches swept after EVERY library call
+    (_capi.SWEEP_ICACHE): every kernel of the step -- sampler, forward, loss, backward, accumulate + Adam -- starts on cold
+    instruction caches in every iteration, and the state after three iterations must be the one the plain runs give."""
+    import hashlib
+
+    import scanerf_amd  # noqa: F401
+    from scanerf_amd import _capi
+    from scanerf_amd.tile_model import TileModel, train_step_fgbg, train_step_fused
+    torch.manual_seed(11)
+    B, S = 8192, 128
+    o = torch.rand(B, 3, device=DEV) * 8 - 4
+    d = torch.nn.functional.normalize(torch.randn(B, 3, device=DEV), dim=-1) * (0.5 + torch.rand(B, 1, device=DEV))
+    tgt = torch.rand(B, 3, device=DEV)
+    digests = {}
+    try:
+        for rep in range(10):
+            _capi.SWEEP_ICACHE = rep >= 2
+            m = TileModel([-4, -4, -4], [8, 8, 8], DEV, log2_T=16, seed=1)
+            with torch.no_grad():
+                m.features.mul_(100.0)
+            opt = torch.optim.Adam(m.decoder.parameters(), lr=1e-3, betas=(0.9, 0.99), eps=1e-15)
+            for i in range(3):
+                r = (train_step_fgbg(m, opt, o, d, tgt, S, S, 20000 + i, pose_grads=pose) if fgbg
+                     else train_step_fused(m, opt, o, d, tgt, S, 20000 + i, pose_grads=pose))
+            torch.cuda.synchronize()
+            h = hashlib.sha256()
+            for t in (m.features.detach(), m.exp_avg, m.exp_avg_sq, m.decoder.blob().detach()) + ((r[1], r[2]) if pose else ()):
+                h.update(t.cpu().numpy().tobytes())
+            digests.setdefault(h.hexdigest(), []).append(rep)
+    finally:
+        _capi.SWEEP_ICACHE = False
+    assert len(digests) == 1, f"runs by result (0, 1 = plain; 2.. = swept): {sorted(digests.values())}"

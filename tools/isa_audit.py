@@ -1,0 +1,112 @@
+#!/usr/bin/env python3
+"""ISA audit of the hazard-sensitive kernels: the training / render-time kernels have been validated
+launch-to-launch bit-identical for ONE compiled listing each.  This tool pins those listings: per kernel of the audited
+translation units the spilled-register count, the instruction count and a digest of the instruction stream, next to the
+compiler version, in <pkg>/csrc/isa_manifest.json.
+
+    tools/isa_audit.py --check    (run by `make`: fails if a listing differs from the validated one)
+    tools/isa_audit.py --update   (after re-validating on the GPU: tests/test_gpu_determinism.py + tools/fault_probe.py)
+
+Rules checked besides the digests (each found the hard way):
+  * the training forward (k_render_fwd_h3*) holds NO packed-f32 arithmetic (v_pk_mul/add/fma_f32): render.hip is compiled with
+    -fno-slp-vectorize.
+It reads the code objects out of the built .o files (llvm-objdump --offloading), never recompiles.
+"""
+import hashlib, json, os, re, shutil, subprocess, sys, tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "scanerf-scalable-bundle-adjusting-neural-radiance-fields-for-large-scale-scene-rendering_amd")
+OBJ = os.path.join(PKG, "lib", "obj")
+MANIFEST = os.path.join(PKG, "csrc", "isa_manifest.json")
+LLVM = "/opt/rocm/lib/llvm/bin"
+UNITS = ["render", "render_bwd_t16", "render_bwd_h3", "render_bwd", "render_time", "scatter"]
+NO_PACKED_F32 = re.compile(r"k_render_fwd_h3")
+PACKED = re.compile(r"^v_pk_(mul|add|fma)_f32\b")
+
+
+def compiler_version():
+    out = subprocess.run(["/opt/rocm/bin/hipcc", "--version"], capture_output=True, text=True).stdout
+    return " | ".join(l.strip() for l in out.splitlines() if l.startswith(("HIP version", "AMD clang version")))
+
+
+def code_object(unit, tmp):
+    src = os.path.join(OBJ, unit + ".o")
+    if not os.path.exists(src):
+        raise SystemExit(f"isa_audit: {src} is missing (build first)")
+    dst = os.path.join(tmp, unit + ".o")
+    shutil.copy(src, dst)
+    subprocess.run([f"{LLVM}/llvm-objdump", "--offloading", dst], check=True, capture_output=True)
+    cos = [f for f in os.listdir(tmp) if f.startswith(unit + ".o.") and "gfx950" in f]
+    if len(cos) != 1:
+        raise SystemExit(f"isa_audit: expected one gfx950 code object in {unit}.o, found {cos}")
+    return os.path.join(tmp, cos[0])
+
+
+def audit_unit(unit, tmp):
+    co = code_object(unit, tmp)
+    notes = subprocess.run([f"{LLVM}/llvm-readelf", "--notes", co], check=True, capture_output=True, text=True).stdout
+    meta = {}
+    for m in re.finditer(r"\.name:\s+(\S+)\n(.*?)\.vgpr_spill_count:\s+(\d+)", notes, re.S):
+        meta[m.group(1)] = int(m.group(3))
+    dis = subprocess.run([f"{LLVM}/llvm-objdump", "-d", "--no-show-raw-insn", "--no-leading-addr", co], check=True,
+                         capture_output=True, text=True).stdout
+    kernels = {}
+    for blk in re.split(r"\n(?=<[^>]+>:\n)", dis):
+        m = re.match(r"<([^>]+)>:\n", blk)
+        if not m or m.group(1) not in meta:
+            continue
+        ins = []
+        for l in blk.split("\n")[1:]:
+            l = l.split("//")[0].strip()
+            if l and not l.startswith("<"):
+                ins.append(re.sub(r"\s+", " ", re.sub(r"<[^>]+>", "", l)).strip())   # (branch-target symbols dropped: offsets stay)
+        name = m.group(1)
+        kernels[name] = {"spills": meta[name], "instructions": len(ins), "packed_f32": sum(1 for i in ins if PACKED.match(i)),
+                         "sha256": hashlib.sha256("\n".join(ins).encode()).hexdigest()[:24]}
+    return kernels
+
+
+def main():
+    mode = sys.argv[1] if len(sys.argv) > 1 else "--check"
+    with tempfile.TemporaryDirectory() as tmp:
+        now = {"compiler": compiler_version(), "units": {u: audit_unit(u, tmp) for u in UNITS}}
+    bad = []
+    for u, ks in now["units"].items():
+        for k, v in ks.items():
+            if NO_PACKED_F32.search(k) and v["packed_f32"]:
+                bad.append(f"{u}: {k}: {v['packed_f32']} packed-f32 instructions in the training forward (needs -fno-slp-vectorize)")
+    if mode == "--update":
+        if bad:
+            raise SystemExit("isa_audit: refusing to record a listing that breaks a rule:\n  " + "\n  ".join(bad))
+        json.dump(now, open(MANIFEST, "w"), indent=1, sort_keys=True)
+        n = sum(len(k) for k in now["units"].values())
+        print(f"isa_audit: recorded {n} kernels of {len(UNITS)} units under {now['compiler']}")
+        return
+    if not os.path.exists(MANIFEST):
+        raise SystemExit(f"isa_audit: {MANIFEST} is missing: run tools/isa_audit.py --update after validating on the GPU")
+    ref = json.load(open(MANIFEST))
+    if ref["compiler"] != now["compiler"]:
+        bad.append(f"compiler changed: validated under [{ref['compiler']}], building with [{now['compiler']}]")
+    for u in UNITS:
+        r, n = ref["units"].get(u, {}), now["units"][u]
+        for k in sorted(set(r) | set(n)):
+            if k not in n:
+                bad.append(f"{u}: kernel {k} disappeared")
+            elif k not in r:
+                bad.append(f"{u}: new kernel {k} (spills {n[k]['spills']}) has no validated listing")
+            elif r[k] != n[k]:
+                bad.append(f"{u}: {k}: listing differs from the validated one (spills {r[k]['spills']} -> {n[k]['spills']}, "
+                           f"instructions {r[k]['instructions']} -> {n[k]['instructions']})")
+    if bad:
+        msg = ("isa_audit: the built kernels are not the validated listings (DESIGN.md 4.10):\n  " + "\n  ".join(bad) +
+               "\nRe-validate on the GPU (python -m pytest tests/test_gpu_determinism.py; python tools/fault_probe.py) and then run "
+               "tools/isa_audit.py --update; SCANERF_SKIP_ISA_AUDIT=1 builds anyway.")
+        if os.environ.get("SCANERF_SKIP_ISA_AUDIT") == "1":
+            print(msg + "\n(SCANERF_SKIP_ISA_AUDIT=1: continuing)", file=sys.stderr)
+            return
+        raise SystemExit(msg)
+    print(f"isa_audit: {sum(len(k) for k in now['units'].values())} kernels match their validated listings")
+
+
+if __name__ == "__main__":
+    main()
