@@ -35,38 +35,34 @@ inline int check_launch(const char *what)
         }                                          \
     } while (0)
 
-// After global stores in kernels that also run matrix instructions.  A vector-memory store reads its data registers for a few
-// cycles after it issues.  Measured on MI355X / ROCm 7.2 (tools/step_determinism.py): in 1 of ~4e5 tiles the x-stash store of
-// the forward kernel picked up, in its last quarter-wave, a register that later code (the next layer's MFMA results are
-// allocated over the stored values) had already rewritten -- nothing in the generated code holds such writers back.  Sixteen
-// wait states behind the stores, fenced for the scheduler, and no launch in 600 differed.
-// After the last of a batch of gathers has been consumed, before other code reuses the loads' destination registers.  Measured on
-// MI355X / ROCm 7.2 (tools/fwd_fault_rate.py): the forward kernel copies its 16 encoder outputs into the registers that the last
-// level's eight corner loads had returned into (v_mov_b64, a dozen instructions behind the s_waitcnt that released the last
-// load's consumer); in 5 of 59 first launches on cold caches ONE such copy came out wrong in its low register, lanes 48-63 --
-// the value a late part of the load's return had written over it, as far as can be told.  With wait states between the
-// encoder and whatever follows: 0 of 119 (sixteen; thirty-two now, and sixteen between the encoder's level groups, whose
-// registers are reused the same way).  (Same family as SCANERF_STORE_GUARD: vector memory still touches a register a few
-// cycles after the counters say it is done with it.)
+// Wait-state guards of rounds 1-2, COMPILED OUT (SCANERF_GUARDS = 0).  They were placed behind global stores
+// (SCANERF_STORE_GUARD: 16 states), behind gathers (SCANERF_LOAD_GUARD: 32) and around matrix instructions (render_h3.h
+// H3_REGIONS, render_t16.h T16_REGION_*, the operand guards of the splits) after launch-to-launch differences that came and went
+// with the register allocation.  Round 3 found what those differences have in common: packed-f32 instructions
+// (v_pk_mul/add/fma_f32, formed by the SLP vectoriser) in a kernel that also runs matrix instructions.  Without them no guard is
+// needed (0 differing launches of 1 200 with every guard off, instruction caches swept or not; with them and no guards 199 of
+// 199: tools/guard_probe.py), so the kernels are compiled with -fno-slp-vectorize (csrc/Makefile, tools/isa_audit.py) and carry no
+// guards.  -DSCANERF_GUARDS=1 -DH3_REGIONS=1 rebuilds the guarded listings for that experiment matrix (tools/build_variant.py).
+#ifndef SCANERF_GUARDS
+#define SCANERF_GUARDS 0
+#endif
+#if SCANERF_GUARDS
 #define SCANERF_LOAD_GUARD()                                                         \
     do {                                                                             \
         __builtin_amdgcn_sched_barrier(0);                                           \
         asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7");                    \
         __builtin_amdgcn_sched_barrier(0);                                           \
     } while (0)
-// The same wait placed BEHIND the arrival of particular loads: the asm names the loaded registers, so the compiler's s_waitcnt
-// for them comes first (a guard without operands would be scheduled in front of the wait it is meant to follow).
-#define SCANERF_LOAD_GUARD_ON2(r0, r1)                                               \
-    do {                                                                             \
-        asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7" : "+v"(r0), "+v"(r1)); \
-    } while (0)
-
 #define SCANERF_STORE_GUARD()                    \
     do {                                         \
         __builtin_amdgcn_sched_barrier(0);       \
         asm volatile("s_nop 7\n\ts_nop 7");      \
         __builtin_amdgcn_sched_barrier(0);       \
     } while (0)
+#else
+#define SCANERF_LOAD_GUARD() do { } while (0)
+#define SCANERF_STORE_GUARD() do { } while (0)
+#endif
 
 inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 

@@ -31,15 +31,13 @@ typedef float f2v __attribute__((ext_vector_type(2)));
 namespace scanerf {
 
 __host__ __device__ constexpr int h3_ku(int t, int h, int j) { return 16 * t + 8 * (j >> 2) + 4 * h + (j & 3); }
-// H3_OPAQUE_ADDR (set by render_time.hip only): lane offsets and the base of the f32 tail are made opaque to the optimiser.
+// H3_OPAQUE_ADDR (render.hip and render_time.hip): lane offsets and the base of the f32 tail are made opaque to the optimiser.
 // Seeing lane >> 5 as a 0/1 value it otherwise turns every `image offset + lane offset` into its own select of two constants, and
 // the f32 tail lies past 64 KB, beyond the immediate of an LDS read: one address register per weight / bias read, ~35 of them
-// live across the sample loop (render-time kernel 25 -> 4 spilled registers, frame 105 -> 99 ms).  NOT for the training
-// kernels: with the registers this frees, the forward kernel (51 -> 8 spills, 3.33 -> 3.11 ms) produced a wrong encoder output
-// in ~6 % of the forward launches that open a training run (tools/fwd_fault_rate.py, tests/debug/fault_values.py; DESIGN.md 4.10;
-// a corner load consumed before its last quarter-wave had landed) and wait states around its loads lowered that to ~0.2 % but
-// did not remove it; their listing is therefore kept as it was when 800 full-size steps and, this round, 4 000 fresh-model
-// starts were bit-identical.
+// live across the sample loop (render-time kernel 25 -> 4 spilled registers, frame 105 -> 99 ms; training forward 51 -> 0 spills
+// together with -fno-slp-vectorize, 3.35 -> 3.10 ms).  Round 2 withdrew it from the training forward because that build wrote a
+// wrong encoder output in ~6 % of cold first launches; round 3 traced the fault to packed-f32 weight pairs, not to
+// this addressing.
 #ifndef H3_OPAQUE_ADDR
 #define H3_OPAQUE_ADDR 0
 #endif
@@ -64,9 +62,8 @@ __device__ __forceinline__ HL split8(const v16f &v, int t)
     for (int q = 0; q < 4; ++q) {
         const f2v x = { v[8 * t + 2 * q], v[8 * t + 2 * q + 1] };
         const h2v hi = __builtin_convertvector(x, h2v);
-        // (x - (float)hi is one v_fma_mix_f32, which the compiler only emits from inline asm; tried, -4 % on the render-time frame,
-        // and withdrawn: the training step then differed between runs -- an asm statement is invisible to the hazard recogniser,
-        // and a packed conversion's result read by the very next VOP3P / matrix instruction is the hazard of the note below)
+        // (x - (float)hi is one v_fma_mix_f32, which the compiler only emits from inline asm; tried in round 2, -4 % on the
+        // render-time frame, and withdrawn: the training step then differed between runs)
         const f2v back = __builtin_convertvector(hi, f2v);
         const f2v r = { x[0] - back[0], x[1] - back[1] };
         const h2v lo = __builtin_convertvector(r, h2v);
@@ -75,7 +72,7 @@ __device__ __forceinline__ HL split8(const v16f &v, int t)
         o.lo[2 * q] = lo[0];
         o.lo[2 * q + 1] = lo[1];
     }
-#if !(defined(H3_REGIONS) && H3_REGIONS)
+#if !(defined(H3_REGIONS) && H3_REGIONS) && SCANERF_GUARDS
     asm volatile("s_nop 1" : "+v"(o.hi), "+v"(o.lo));  // operand guard, see "operand hazard" below
 #endif
     return o;
@@ -91,15 +88,12 @@ __device__ __forceinline__ HL2 split16(const v16f &v)
     return o;
 }
 
-// ---- operand hazard.
-// Measured on MI355X (ROCm 7.2 hipcc): with the f16 MFMAs scheduled freely among the VALU code that produces their
-// B operands, about 3e-4 of the 32-sample tiles came out wrong in lanes 16-31, differently on every launch
-// (tests/debug/h3_debug.py: ~10 wrong tiles per 16 384).  The listing shows the hazard recogniser leaving two wait states
-// between the last v_cvt_pk_f16_f32 of an operand and the MFMA that reads it; that is not enough for this producer.
-// Every VALU-made operand therefore passes through a guard where it is produced (split8: two more wait states, and
-// the MFMAs depend on the guard's outputs): 0 wrong tiles in 393 216.  Operands that come from LDS (weights,
-// transposed reads) need nothing.  H3_REGIONS=1 instead fences every MFMA group off as a closed scheduling region
-// (equally clean, but a lone wave per SIMD then cannot overlap its own VALU and matrix work).
+// ---- "operand hazard" (rounds 1-2; guards compiled out, see common.h SCANERF_GUARDS).
+// With the f16 MFMAs scheduled freely among the VALU code that produces their B operands, 3e-4 of the 32-sample tiles came out
+// wrong in lanes 16-31, differently on every launch.  Rounds 1-2 answered with wait states where an operand is produced (split8)
+// or with closed scheduling regions around every MFMA group (H3_REGIONS = 1).  Round 3: the differences need packed-f32
+// instructions in the kernel (the splits' x - (float)hi had become v_pk_add_f32); compiled with -fno-slp-vectorize the kernels
+// are bit-reproducible without either (tools/guard_probe.py), which is how they are built.
 typedef HL A2;  // an A operand (weights): the same pair of parts
 __device__ __forceinline__ A2 h3_lda(const char *sub)  // `sub` = address of this lane's 16 B of the hi part
 {

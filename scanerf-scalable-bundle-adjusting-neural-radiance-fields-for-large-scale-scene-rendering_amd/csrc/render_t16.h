@@ -69,7 +69,9 @@ __device__ __forceinline__ T16HL t16_split(const v4f &a, const v4f &b)
         o.lo[2 * p] = lo[0];
         o.lo[2 * p + 1] = lo[1];
     }
+#if SCANERF_GUARDS
     asm volatile("s_nop 1" : "+v"(o.hi), "+v"(o.lo));  // operand guard (render_h3.h, "operand hazard")
+#endif
     return o;
 }
 // hi part only (gradient operands)
@@ -83,7 +85,9 @@ __device__ __forceinline__ t16_h8 t16_hi(const v4f &a, const v4f &b)
         o[2 * p] = hi[0];
         o[2 * p + 1] = hi[1];
     }
+#if SCANERF_GUARDS
     asm volatile("s_nop 1" : "+v"(o));
+#endif
     return o;
 }
 __device__ __forceinline__ t16_h4 t16_hi4(const v4f &a)
@@ -96,15 +100,18 @@ __device__ __forceinline__ v4f t16_mfma(const t16_h8 &a, const t16_h8 &b, const 
 {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
 }
-// Every group of MFMAs is a CLOSED scheduling region followed by wait states.  Measured on MI355X (ROCm 7.2 hipcc,
-// tools/fwd_determinism.py): with f16 MFMAs scheduled freely among the vector code around them, about 1e-5 .. 3e-3 of the
-// 32-sample tiles of the forward kernel (by table type, i.e. by the code around the MFMAs) come out wrong in sample columns
-// 16-31, differently on every launch and only in the second wave of a SIMD; the listing shows vector instructions that
-// REWRITE an MFMA's A / B source registers (or loads into them) right behind it.  Fenced like this: 0 in 10^6 tiles.
+// Rounds 1-2 made every group of MFMAs a closed scheduling region followed by wait states (1e-5 .. 3e-3 of the forward's tiles
+// came out wrong in sample columns 16-31 otherwise).  Compiled out since round 3 (common.h SCANERF_GUARDS): without packed-f32
+// instructions in the kernel (-fno-slp-vectorize) nothing differs between launches with the MFMAs scheduled freely.
+#if SCANERF_GUARDS
 #define T16_REGION_BEGIN() __builtin_amdgcn_sched_barrier(0)
 #define T16_REGION_END()       \
     asm volatile("s_nop 3");   \
     __builtin_amdgcn_sched_barrier(0)
+#else
+#define T16_REGION_BEGIN()
+#define T16_REGION_END()
+#endif
 
 // forward layer: u[b] += W[b] X over KS k-steps (three products per term, small ones first).  `img` + `base` =
 // the layer's first pair, `lo16` = 16 * lane.

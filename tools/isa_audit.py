@@ -7,9 +7,9 @@ compiler version, in <pkg>/csrc/isa_manifest.json.
     tools/isa_audit.py --check    (run by `make`: fails if a listing differs from the validated one)
     tools/isa_audit.py --update   (after re-validating on the GPU: tests/test_gpu_determinism.py + tools/fault_probe.py)
 
-Rules checked besides the digests (each found the hard way):
-  * the training forward (k_render_fwd_h3*) holds NO packed-f32 arithmetic (v_pk_mul/add/fma_f32): render.hip is compiled with
-    -fno-slp-vectorize.
+Rule checked besides the digests (found the hard way):
+  * no kernel of a unit that runs matrix instructions holds packed-f32 arithmetic (v_pk_mul/add/fma_f32): those units are
+    compiled with -fno-slp-vectorize.
 It reads the code objects out of the built .o files (llvm-objdump --offloading), never recompiles.
 """
 import hashlib, json, os, re, shutil, subprocess, sys, tempfile
@@ -19,8 +19,8 @@ PKG = os.path.join(ROOT, "scanerf-scalable-bundle-adjusting-neural-radiance-fiel
 OBJ = os.path.join(PKG, "lib", "obj")
 MANIFEST = os.path.join(PKG, "csrc", "isa_manifest.json")
 LLVM = "/opt/rocm/lib/llvm/bin"
-UNITS = ["render", "render_bwd_t16", "render_bwd_h3", "render_bwd", "render_time", "scatter"]
-NO_PACKED_F32 = re.compile(r"k_render_fwd_h3")
+UNITS = ["render", "render_bwd_t16", "render_bwd_h3", "render_bwd", "render_time", "scatter", "hashgrid", "rays", "adam", "loss", "compact", "voxelize", "h3_selftest"]
+NO_PACKED_F32_UNITS = tuple(UNITS)
 PACKED = re.compile(r"^v_pk_(mul|add|fma)_f32\b")
 
 
@@ -73,8 +73,8 @@ def main():
     bad = []
     for u, ks in now["units"].items():
         for k, v in ks.items():
-            if NO_PACKED_F32.search(k) and v["packed_f32"]:
-                bad.append(f"{u}: {k}: {v['packed_f32']} packed-f32 instructions in the training forward (needs -fno-slp-vectorize)")
+            if u in NO_PACKED_F32_UNITS and v["packed_f32"]:
+                bad.append(f"{u}: {k}: {v['packed_f32']} packed-f32 instructions in a matrix-instruction unit (needs -fno-slp-vectorize)")
     if mode == "--update":
         if bad:
             raise SystemExit("isa_audit: refusing to record a listing that breaks a rule:\n  " + "\n  ".join(bad))

@@ -5,6 +5,7 @@ import hashlib, os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import scanerf_amd  # noqa
+from scanerf_amd import _capi
 from scanerf_amd import renderer as R
 from scanerf_amd.tile_model import TileModel
 dev = "cuda:0"
@@ -31,7 +32,9 @@ scratch = torch.empty(512 << 20, dtype=torch.uint8, device=dev)
 ref, bad = None, 0
 for i in range(N):
     scratch.fill_(i & 255)
+    _capi.SWEEP_ICACHE = os.environ.get("SWEEP", "0") == "1" and i > 0   # instruction caches swept after every library call
     out = rnd.render(H, W, K, c2w)
+    _capi.SWEEP_ICACHE = False
     torch.cuda.synchronize()
     if ref is None:
         ref = [t.clone() for t in out]

@@ -3,8 +3,14 @@ the same state; every run must end in bit-identical table / moments / decoder (a
 import hashlib, os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import scanerf_amd  # noqa
+from scanerf_amd import _capi
 from scanerf_amd.tile_model import TileModel, train_step_fgbg, train_step_fused
 DEV = "cuda:0"
+SWEEP = os.environ.get("SWEEP", "0")   # 1: the instruction caches are swept after every library call in every run but the first
+ARITHS = os.environ.get("ARITH", "")  # e.g. "h3": also set the arithmetic (scanerf_amd.render.set_arith)
+if ARITHS:
+    from scanerf_amd import render as _r
+    _r.set_arith(ARITHS)
 B, S = int(os.environ.get("B", 65536)), 128
 STEPS, RUNS = int(os.environ.get("STEPS", 40)), int(os.environ.get("RUNS", 3))
 torch.manual_seed(1)
@@ -14,6 +20,7 @@ tgt = torch.rand(B, 3, device=DEV)
 for name in ("fused", "fgbg+pose"):
     digests = []
     for run in range(RUNS):
+        _capi.SWEEP_ICACHE = SWEEP == "1" and run > 0
         m = TileModel([-4, -4, -4], [8, 8, 8], DEV, log2_T=19, seed=1)
         with torch.no_grad():
             m.features.mul_(100.0)
@@ -32,4 +39,5 @@ for name in ("fused", "fgbg+pose"):
             h.update(t.cpu().numpy().tobytes())
         digests.append(h.hexdigest()[:16])
     print(f"{name}: {RUNS} runs x {STEPS} steps of {B} rays: digests {digests} -> {'identical' if len(set(digests)) == 1 else 'DIFFERENT'}", flush=True)
+    _capi.SWEEP_ICACHE = False
     assert len(set(digests)) == 1
