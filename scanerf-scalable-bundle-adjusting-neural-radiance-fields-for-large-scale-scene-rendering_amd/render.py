@@ -18,6 +18,7 @@ FORE, BG = 0, 1
 #           outputs) run the "h3" backward: see backward_arith().
 import os as _os
 _ARITH_CODES = {"f32": _capi.ARITH_F32, "h3": _capi.ARITH_H3, "t16": _capi.ARITH_T16}
+ARITH_NAMES = tuple(_ARITH_CODES)
 DEFAULT_ARITH = _os.environ.get("SCANERF_ARITH", "t16")
 ARITH = _ARITH_CODES[DEFAULT_ARITH]
 
@@ -25,6 +26,10 @@ ARITH = _ARITH_CODES[DEFAULT_ARITH]
 def set_arith(name):
     global ARITH
     ARITH = _ARITH_CODES[name]
+
+
+def arith_name():
+    return next(k for k, v in _ARITH_CODES.items() if v == ARITH)
 
 
 def backward_arith(have_xstash=True, pose_grads=False):

@@ -373,3 +373,24 @@ def _trainer_complete_iteration_case():
     assert all(np.isfinite(losses)) and tr.global_step == 4
     assert not torch.equal(m.features.detach(), before[0]) and not torch.equal(m.decoder.blob().detach(), before[1])
     assert float((cams.se3_refine.detach() - before[2]).abs().max()) > 0
+
+
+def test_training_arithmetics_converge_alike_on_the_procedural_scene():
+    """A/B of the training arithmetics: the same seeds, the same procedural scene (tools/train_demo.py), 400
+    iterations of 16 384 rays under every arithmetic the library offers -- exact f32 MFMA, split-f16 everywhere ("h3"), and the
+    default -- must end within 0.2 dB of the exact-f32 run's held-out PSNR (and all must have learnt the scene)."""
+    import importlib.util
+    import os
+    from scanerf_amd import render
+    spec = importlib.util.spec_from_file_location("train_demo", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                                                              "tools", "train_demo.py"))
+    td = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(td)
+    res = {}
+    for ar in render.ARITH_NAMES:
+        p0, p1, losses = td.run(steps=400, rays=16384, log2_T=16, verbose=False, arith=ar)
+        res[ar] = p1
+        print(f"arith {ar}: held-out PSNR {p0:.2f} -> {p1:.2f} dB, final loss {losses[-1]:.5f}")
+    assert res["f32"] > 20.0, res
+    for ar, p in res.items():
+        assert abs(p - res["f32"]) < 0.2, res

@@ -39,10 +39,17 @@ def psnr(a, b):
     return 10.0 * math.log10(255.0 ** 2 / (mse + 1e-8))
 
 
-def run(steps=400, rays=16384, log2_T=19, samples=128, dev="cuda:0", verbose=True, return_model=False):
+def run(steps=400, rays=16384, log2_T=19, samples=128, dev="cuda:0", verbose=True, return_model=False, arith=None):
+    """arith: None = the library's default; "f32" / "h3" / "t16" / ... = train under that arithmetic (render.set_arith)."""
     import scanerf_amd  # noqa: F401
-    from scanerf_amd import trainer
+    from scanerf_amd import render, trainer
     from scanerf_amd.tile_model import TileModel
+    if arith is not None:
+        render.set_arith(arith)
+        try:
+            return run(steps, rays, log2_T, samples, dev, verbose, return_model)
+        finally:
+            render.set_arith(render.DEFAULT_ARITH)
     gen = torch.Generator(device=dev).manual_seed(0)
     model = TileModel([-4, -4, -4], [8, 8, 8], dev, log2_T=log2_T, seed=0)
     test_o, test_d = random_rays(8192, dev, gen)
@@ -68,7 +75,7 @@ def run(steps=400, rays=16384, log2_T=19, samples=128, dev="cuda:0", verbose=Tru
     p1 = evaluate(steps)
     losses = [float(l) for l in losses]
     if verbose:
-        print(f"procedural sphere, {steps} steps x {rays} rays x {samples} samples, T=2^{log2_T}: "
+        print(f"[{render.arith_name()}] procedural sphere, {steps} steps x {rays} rays x {samples} samples, T=2^{log2_T}: "
               f"held-out PSNR {p0:.2f} -> {p1:.2f} dB, loss {losses[0]:.4f} -> {losses[-1]:.4f}, "
               f"{dt / steps * 1e3:.2f} ms/step ({rays * steps / dt:.3e} rays/s incl. ray generation), "
               f"occupied cells {int(model.occupied_grid.sum())}/{model.occupied_grid.numel()} at log2dim {model.log2dim.tolist()}")
@@ -108,8 +115,9 @@ if __name__ == "__main__":
     ap.add_argument("--steps", type=int, default=400)
     ap.add_argument("--rays", type=int, default=16384)
     ap.add_argument("--log2-T", type=int, default=19)
+    ap.add_argument("--arith", default=None, help="f32 | h3 | t16 | ...: training arithmetic (default: the library's)")
     ap.add_argument("--render", action="store_true", help="also export the tile and render a novel view through the render-time path")
     a = ap.parse_args()
-    res = run(a.steps, a.rays, a.log2_T, return_model=a.render)
+    res = run(a.steps, a.rays, a.log2_T, return_model=a.render, arith=a.arith)
     if a.render:
         print("novel view 160x120:", {k: round(v, 3) for k, v in novel_view_check(res[3], step=max(a.steps, 10000)).items()})
