@@ -148,7 +148,9 @@ typedef struct {
                   on hi/lo-split operands, three products per term: f32-equivalent results, csrc/render_h3.h) or
                   SCANERF_ARITH_T16 (forward as H3; backward on 16-sample tiles at two waves per SIMD with the
                   forward recompute in H3 and the gradient products on one f16 MFMA per term, csrc/render_t16.h;
-                  needs the x-stash).  plan / backward / accumulate of one step must be given the same value */
+                  needs the x-stash) or SCANERF_ARITH_T16S (the T16 kernel with every gradient product split as well --
+                  three MFMAs per term, G' in f32, f32 table-gradient records: f32-equivalent gradients at the T16
+                  structure's speed; needs the x-stash).  plan / backward / accumulate of one step must be given the same value */
     unsigned skip_levels; /* bit l set: level l's inputs meet exactly-zero first-layer weights (the coarse-to-fine mask,
                              hashgrid/__init__.py:228-235, folded into the packed decoder), so scanerf_render_forward* may
                              leave the level's table alone (its encoder outputs become 0: same results bit for bit).  0 = none */
@@ -156,6 +158,7 @@ typedef struct {
 #define SCANERF_ARITH_F32 0
 #define SCANERF_ARITH_H3 1
 #define SCANERF_ARITH_T16 2
+#define SCANERF_ARITH_T16S 3
 
 /* Packs the decoder blob (+ weight_feature folded into the first layer) into the LDS image
  * the fused kernels stage (csrc/render_common.h).  workspace: scanerf_render_workspace_floats()

@@ -40,7 +40,8 @@ class RenderCfg(ctypes.Structure):
                 ("skip_levels", ctypes.c_uint)]
 
 
-ARITH_F32, ARITH_H3, ARITH_T16 = 0, 1, 2
+ARITH_F32, ARITH_H3, ARITH_T16, ARITH_T16S = 0, 1, 2, 3
+T16_FAMILY = (ARITH_T16, ARITH_T16S)   # backward on 16-sample tiles: x-stash, plan counted by the forward, in-kernel pose path
 
 
 def lib():

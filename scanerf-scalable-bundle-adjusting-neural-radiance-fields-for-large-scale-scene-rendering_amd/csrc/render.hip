@@ -485,12 +485,12 @@ static int render_forward(const float *rays_o, const float *rays_d, const float 
     if (blocks > kNumCU) blocks = kNumCU;  // one resident 512-thread workgroup per CU (VGPR-bound), persistent
     dim3 grid(blocks), block(kRenderThreads);
     hipStream_t st = (hipStream_t)stream;
-    SCANERF_REQUIRE(cfg->arith >= SCANERF_ARITH_F32 && cfg->arith <= SCANERF_ARITH_T16, "render_forward: arith=%d", cfg->arith);
+    SCANERF_REQUIRE(cfg->arith >= SCANERF_ARITH_F32 && cfg->arith <= SCANERF_ARITH_T16S, "render_forward: arith=%d", cfg->arith);
     a.plan_counts = nullptr;
     if (scatter_ws) {
         // The t16 backward visits ray (wg + i W) 8 + r; this kernel's wave w of workgroup b visits (b + i grid) 8 + w: the same
         // rays per workgroup when the grids are equal, so this launch can fill the plan's count matrix itself.
-        SCANERF_REQUIRE(cfg->arith == SCANERF_ARITH_T16, "render_forward_plan: the fused count is the t16 backward's plan (arith=%d)", cfg->arith);
+        SCANERF_REQUIRE(cfg->arith == SCANERF_ARITH_T16 || cfg->arith == SCANERF_ARITH_T16S, "render_forward_plan: the fused count is the t16 / t16s backward's plan (arith=%d)", cfg->arith);
         SCANERF_REQUIRE(scanerf_render_forward_plan_supported(B, S, T), "render_forward_plan: B=%d S=%d T=%d not supported", B, S, T);
         if (int e = scatter_plan_attach(scatter_ws, scatter_ws_bytes, B, S, T, cfg->arith, blocks, a)) return e;
     }

@@ -651,9 +651,9 @@ SCANERF_API int scanerf_render_backward(const float *rays_o, const float *rays_d
     a.grad_out = grad_out; a.tile_T = tile_T; a.dfeat = dfeat; a.dw_partial = dw_partial; a.xstash = xstash;
     a.g_dnorm = g_dnorm; a.g_rowsum = g_rowsum; a.g_raypos = g_raypos;
     a.f.jstash = static_cast<uint32_t *>(const_cast<void *>(jstash));
-    SCANERF_REQUIRE(cfg->arith >= SCANERF_ARITH_F32 && cfg->arith <= SCANERF_ARITH_T16, "render_backward: arith=%d", cfg->arith);
-    const bool h3 = cfg->arith == SCANERF_ARITH_H3, t16 = cfg->arith == SCANERF_ARITH_T16;
-    SCANERF_REQUIRE(!t16 || xstash, "render_backward: arith T16 needs the forward's x-stash (use SCANERF_ARITH_H3 to re-gather)");
+    SCANERF_REQUIRE(cfg->arith >= SCANERF_ARITH_F32 && cfg->arith <= SCANERF_ARITH_T16S, "render_backward: arith=%d", cfg->arith);
+    const bool h3 = cfg->arith == SCANERF_ARITH_H3, t16s = cfg->arith == SCANERF_ARITH_T16S, t16 = cfg->arith == SCANERF_ARITH_T16 || t16s;
+    SCANERF_REQUIRE(!t16 || xstash, "render_backward: arith T16 / T16S needs the forward's x-stash (use SCANERF_ARITH_H3 to re-gather)");
     SCANERF_REQUIRE(!g_raypos || t16, "render_backward: g_raypos is produced by the t16 kernel only");
     const int blocks = scanerf_render_backward_grid(B);
     size_t lds_extra = 0;
@@ -682,7 +682,7 @@ SCANERF_API int scanerf_render_backward(const float *rays_o, const float *rays_d
     const int prows = t16 ? blocks : blocks * 4;
     hipError_t me = hipMemsetAsync(dw_partial, 0, (size_t)prows * SCANERF_PARAMSIZE * sizeof(float), st);
     SCANERF_REQUIRE(me == hipSuccess, "render_backward: memset failed: %s", hipGetErrorString(me));
-    if (int e = t16 ? launch_render_bwd_t16(a, feat_dtype, blocks, lds_extra, st)
+    if (int e = t16 ? launch_render_bwd_t16(a, feat_dtype, blocks, lds_extra, st, t16s)
               : h3 ? launch_render_bwd_h3(a, feat_dtype, blocks, lds_extra, st)
                    : launch_render_bwd_f32(a, feat_dtype, blocks, lds_extra, st))
         return e;

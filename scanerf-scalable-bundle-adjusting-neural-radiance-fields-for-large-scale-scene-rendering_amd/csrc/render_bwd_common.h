@@ -47,6 +47,6 @@ __device__ __forceinline__ float opaque1(float v)
 // launchers of the two arithmetics (defined next to their kernels); lds_extra = bytes of record cursors
 int launch_render_bwd_f32(const BwdArgs &a, int feat_dtype, int blocks, size_t lds_extra, hipStream_t st);
 int launch_render_bwd_h3(const BwdArgs &a, int feat_dtype, int blocks, size_t lds_extra, hipStream_t st);
-int launch_render_bwd_t16(const BwdArgs &a, int feat_dtype, int blocks, size_t lds_extra, hipStream_t st);
+int launch_render_bwd_t16(const BwdArgs &a, int feat_dtype, int blocks, size_t lds_extra, hipStream_t st, bool split);
 
 }  // namespace scanerf

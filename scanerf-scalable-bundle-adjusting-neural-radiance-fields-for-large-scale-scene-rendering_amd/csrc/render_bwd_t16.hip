@@ -31,57 +31,103 @@ namespace {
 
 constexpr int kThreads = 512;
 constexpr int kWaves = 8;
-constexpr int kLdsRes = T16_BYTES;                            // resolutions [16][4] i32
-constexpr int kLdsDinit = kLdsRes + 256;                      // 8 waves x 64 f32: Dir layer-0 accumulator start of the wave's ray (unit order)
-constexpr int kLdsSh = kLdsDinit + kWaves * 256;              // 8 waves x SH[16]
-constexpr int kLdsMx = kLdsSh + kWaves * 64;                  // 8 floats
-constexpr int kLdsStage = kLdsMx + 64;                        // 8 waves x {Y, X}
-constexpr int kLdsCursor = kLdsStage + kWaves * T16_STAGE_WAVE;  // record cursors (fused scatter producer only)
-static_assert(kLdsStage % 16 == 0 && kLdsCursor % 16 == 0, "LDS carve alignment");
+// LDS carve (SPLIT = the t16s variant: its own images, staging of hi AND lo parts)
+template <bool SPLIT>
+struct Lds {
+    static constexpr int kImg = SPLIT ? S16_BYTES : T16_BYTES;
+    static constexpr int kBias = SPLIT ? S16_BIAS : T16_BIAS;
+    static constexpr int kStageWave = SPLIT ? 2 * T16_STAGE_WAVE : T16_STAGE_WAVE;   // {Y, X} (, {Y lo, X lo})
+    static constexpr int kRes = kImg;                             // resolutions [16][4] i32
+    static constexpr int kDinit = kRes + 256;                     // 8 waves x 64 f32: Dir layer-0 accumulator start of the wave's ray (unit order)
+    static constexpr int kSh = kDinit + kWaves * 256;             // 8 waves x SH[16]
+    static constexpr int kMx = kSh + kWaves * 64;                 // 8 floats
+    static constexpr int kStage = kMx + 64;                       // 8 waves x staging
+    static constexpr int kCursor = kStage + kWaves * kStageWave;  // record cursors (fused scatter producer only)
+    static_assert(kStage % 16 == 0 && kCursor % 16 == 0, "LDS carve alignment");
+};
 
-// ------------------------------------------------------------------ pack: blob -> t16 images
+// ------------------------------------------------------------------ pack: blob -> t16 / t16s images
+__device__ __forceinline__ float pk_W(const float *blob, int base, int n_out, int n, int k) { return blob[base + n_out + k * n_out + n]; }
+// element j of lane (m, q) of forward pair `pair`: W[n][unit of slot (q, j)]
+__device__ __forceinline__ float t16_fwd_weight(const float *blob, const float *wf, int pair, int lane, int j)
+{
+    const int m = lane & 15, q = lane >> 4;
+    int pp = pair, layer, ks;
+    if (pp < 4) { layer = 0; ks = 1; }
+    else if ((pp -= 4) < 8) { layer = 1; ks = 2; }
+    else if ((pp -= 8) < 2) { layer = 2; ks = 1; }
+    else if ((pp -= 2) < 8) { layer = 3; ks = 2; }
+    else if ((pp -= 8) < 8) { layer = 4; ks = 2; }
+    else { pp -= 8; layer = 5; ks = 2; }
+    const int b = pp / ks, t = pp % ks;
+    const int n = 16 * b + m, ku = t16_ku(t, q, j);
+    float w = 0.0f;
+    if (layer == 0) {
+        const int k = t16_pos_to_input(8 * q + j);
+        w = pk_W(blob, BLOB_S0, 64, n, k) * wf[k];
+    } else if (layer == 1) w = pk_W(blob, BLOB_S1, 64, n, ku);
+    else if (layer == 2) {  // heads on H[:32] (k-step 0 of H): rows replicated in every q
+        const int r = m & 3;
+        if (b == 0) w = r == 0 ? pk_W(blob, BLOB_SIG, 1, 0, ku) : pk_W(blob, BLOB_DIF, 3, r - 1, ku);
+        else if (r < 3) w = pk_W(blob, BLOB_TINT, 3, r, ku);
+    } else if (layer == 3) {
+        if (t == 0) w = pk_W(blob, BLOB_D0, 64, n, ku);                      // input k = H[32 + k], slot unit ku(0, q, j) - 0
+        else if (q < 2) w = pk_W(blob, BLOB_D0, 64, n, 32 + 8 * q + j);      // SH part
+    } else if (layer == 4) w = pk_W(blob, BLOB_D1, 64, n, ku);
+    else {
+        const int r = m & 3;
+        if (r < 3) w = pk_W(blob, BLOB_D2, 3, r, ku);
+    }
+    return w;
+}
+// element j of lane (m, q) of a TRANSPOSED sub-image of `layer` (input block bi, k-step t of the layer's output units):
+// W[n = ku(t, q, j)][i = 16 bi + m]
+__device__ __forceinline__ float t16_T_weight(const float *blob, const float *wf, int layer, int bi, int t, int lane, int j)
+{
+    const int m = lane & 15, q = lane >> 4;
+    const int n = t16_ku(t, q, j), i = 16 * bi + m;
+    float w = 0.0f;
+    if (layer == 5) {           // narrow rows 8..10 = rgb
+        if (n >= 8 && n < 11) w = pk_W(blob, BLOB_D2, 3, n - 8, i);
+    } else if (layer == 4) w = pk_W(blob, BLOB_D1, 64, n, i);
+    else if (layer == 3) w = pk_W(blob, BLOB_D0, 64, n, i);      // i = 16 b_in + m in 0..31 <-> H[32 + i]
+    else if (layer == 2) {      // narrow rows 0..6 = sigma, dif, tint; i = H unit 0..31
+        if (n == 0) w = pk_W(blob, BLOB_SIG, 1, 0, i);
+        else if (n < 4) w = pk_W(blob, BLOB_DIF, 3, n - 1, i);
+        else if (n < 7) w = pk_W(blob, BLOB_TINT, 3, n - 4, i);
+    } else if (layer == 1) w = pk_W(blob, BLOB_S1, 64, n, i);
+    else {
+        const int k = t16_pos_to_input(t16_l0_row_to_pos(bi, m));
+        w = pk_W(blob, BLOB_S0, 64, n, k) * wf[k];
+    }
+    return w;
+}
+__device__ __forceinline__ float t16_tail_value(const float *blob, int t)   // f32 tail: [L0 64][L1 64][D0 64][D1 64][headA 4][headB 4][D2 4][pad 4]
+{
+    if (t < 256) {
+        const int bases[4] = { BLOB_S0, BLOB_S1, BLOB_D0, BLOB_D1 };
+        return blob[bases[t >> 6] + (t & 63)];
+    }
+    if (t < 260) return t == 256 ? blob[BLOB_SIG] : blob[BLOB_DIF + t - 257];
+    if (t < 264) return t < 263 ? blob[BLOB_TINT + t - 260] : 0.0f;
+    if (t < 268) return t < 267 ? blob[BLOB_D2 + t - 264] : 0.0f;
+    return 0.0f;
+}
+
 __global__ void __launch_bounds__(256) k_pack_decoder_t16(const float *__restrict__ blob, const float *__restrict__ wf,
                                                           char *__restrict__ out)
 {
-    auto W = [&](int base, int n_out, int n, int k) { return blob[base + n_out + k * n_out + n]; };
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e < 32 * 512) {  // forward image: one thread per (pair, lane, j)
         const int pair = e >> 9, lane = (e >> 3) & 63, j = e & 7;
-        const int m = lane & 15, q = lane >> 4;
-        int pp = pair, layer, ks;
-        if (pp < 4) { layer = 0; ks = 1; }
-        else if ((pp -= 4) < 8) { layer = 1; ks = 2; }
-        else if ((pp -= 8) < 2) { layer = 2; ks = 1; }
-        else if ((pp -= 2) < 8) { layer = 3; ks = 2; }
-        else if ((pp -= 8) < 8) { layer = 4; ks = 2; }
-        else { pp -= 8; layer = 5; ks = 2; }
-        const int b = pp / ks, t = pp % ks;
-        const int n = 16 * b + m, ku = t16_ku(t, q, j);
-        float w = 0.0f;
-        if (layer == 0) {
-            const int k = t16_pos_to_input(8 * q + j);
-            w = W(BLOB_S0, 64, n, k) * wf[k];
-        } else if (layer == 1) w = W(BLOB_S1, 64, n, ku);
-        else if (layer == 2) {  // heads on H[:32] (k-step 0 of H): rows replicated in every q
-            const int r = m & 3;
-            if (b == 0) w = r == 0 ? W(BLOB_SIG, 1, 0, ku) : W(BLOB_DIF, 3, r - 1, ku);
-            else if (r < 3) w = W(BLOB_TINT, 3, r, ku);
-        } else if (layer == 3) {
-            if (t == 0) w = W(BLOB_D0, 64, n, ku);                      // input k = H[32 + k], slot unit ku(0, q, j) - 0
-            else if (q < 2) w = W(BLOB_D0, 64, n, 32 + 8 * q + j);      // SH part
-        } else if (layer == 4) w = W(BLOB_D1, 64, n, ku);
-        else {
-            const int r = m & 3;
-            if (r < 3) w = W(BLOB_D2, 3, r, ku);
-        }
+        const float w = t16_fwd_weight(blob, wf, pair, lane, j);
         const _Float16 hi = (_Float16)w, lo = (_Float16)(w - (float)hi);
         char *p = out + pair * T16_PAIR + lane * 16 + j * 2;
         *reinterpret_cast<_Float16 *>(p) = hi;
         *reinterpret_cast<_Float16 *>(p + T16_SUB) = lo;
-    } else if (e < 32 * 512 + 30 * 512) {  // transposed image (hi only): lane (m, q), j: W[n = ku(t, q, j)][i = 16 b_in + m]
+    } else if (e < 32 * 512 + 30 * 512) {  // transposed image (hi only)
         const int f = e - 32 * 512;
         const int sub = f >> 9, lane = (f >> 3) & 63, j = f & 7;
-        const int m = lane & 15, q = lane >> 4;
         int ss = sub, layer, ks;
         if (ss < 4) { layer = 5; ks = 1; }
         else if ((ss -= 4) < 8) { layer = 4; ks = 2; }
@@ -89,33 +135,38 @@ __global__ void __launch_bounds__(256) k_pack_decoder_t16(const float *__restric
         else if ((ss -= 4) < 2) { layer = 2; ks = 1; }
         else if ((ss -= 2) < 8) { layer = 1; ks = 2; }
         else { ss -= 8; layer = 0; ks = 2; }
-        const int bi = ss / ks, t = ss % ks;
-        const int n = t16_ku(t, q, j), i = 16 * bi + m;
-        float w = 0.0f;
-        if (layer == 5) {           // narrow rows 8..10 = rgb
-            if (n >= 8 && n < 11) w = W(BLOB_D2, 3, n - 8, i);
-        } else if (layer == 4) w = W(BLOB_D1, 64, n, i);
-        else if (layer == 3) w = W(BLOB_D0, 64, n, i);      // i = 16 b_in + m in 0..31 <-> H[32 + i]
-        else if (layer == 2) {      // narrow rows 0..6 = sigma, dif, tint; i = H unit 0..31
-            if (n == 0) w = W(BLOB_SIG, 1, 0, i);
-            else if (n < 4) w = W(BLOB_DIF, 3, n - 1, i);
-            else if (n < 7) w = W(BLOB_TINT, 3, n - 4, i);
-        } else if (layer == 1) w = W(BLOB_S1, 64, n, i);
-        else {
-            const int k = t16_pos_to_input(t16_l0_row_to_pos(bi, m));
-            w = W(BLOB_S0, 64, n, k) * wf[k];
-        }
+        const float w = t16_T_weight(blob, wf, layer, ss / ks, ss % ks, lane, j);
         *reinterpret_cast<_Float16 *>(out + T16_FWD_BYTES + sub * T16_SUB + lane * 16 + j * 2) = (_Float16)w;
     } else if (e < 62 * 512 + 272) {
         const int t = e - 62 * 512;
-        float v = 0.0f;
-        if (t < 256) {
-            const int bases[4] = { BLOB_S0, BLOB_S1, BLOB_D0, BLOB_D1 };
-            v = blob[bases[t >> 6] + (t & 63)];
-        } else if (t < 260) v = t == 256 ? blob[BLOB_SIG] : blob[BLOB_DIF + t - 257];
-        else if (t < 264) v = t < 263 ? blob[BLOB_TINT + t - 260] : 0.0f;
-        else if (t < 268) v = t < 267 ? blob[BLOB_D2 + t - 264] : 0.0f;
-        reinterpret_cast<float *>(out + T16_BIAS)[t] = v;
+        reinterpret_cast<float *>(out + T16_BIAS)[t] = t16_tail_value(blob, t);
+    }
+}
+
+// t16s images (render_common.h S16_*): the forward pairs in the swizzled two-half layout (render_t16.h s16_pos), the narrow
+// layers' transposed sub-images as (hi, lo) pairs, the f32 tail
+__global__ void __launch_bounds__(256) k_pack_decoder_s16(const float *__restrict__ blob, const float *__restrict__ wf,
+                                                          char *__restrict__ out)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < 32 * 512) {
+        const int pair = e >> 9, lane = (e >> 3) & 63, j = e & 7;
+        const float w = t16_fwd_weight(blob, wf, pair, lane, j);
+        const _Float16 hi = (_Float16)w, lo = (_Float16)(w - (float)hi);
+        char *p = out + pair * T16_PAIR + (j >> 2) * 512 + s16_pos(lane) * 8 + (j & 3) * 2;
+        *reinterpret_cast<_Float16 *>(p) = hi;
+        *reinterpret_cast<_Float16 *>(p + T16_SUB) = lo;
+    } else if (e < 32 * 512 + 6 * 512) {
+        const int f = e - 32 * 512;
+        const int sub = f >> 9, lane = (f >> 3) & 63, j = f & 7;
+        const float w = sub < 4 ? t16_T_weight(blob, wf, 5, sub, 0, lane, j) : t16_T_weight(blob, wf, 2, sub - 4, 0, lane, j);
+        const _Float16 hi = (_Float16)w, lo = (_Float16)(w - (float)hi);
+        char *p = out + S16T_D2 + sub * T16_PAIR + lane * 16 + j * 2;
+        *reinterpret_cast<_Float16 *>(p) = hi;
+        *reinterpret_cast<_Float16 *>(p + T16_SUB) = lo;
+    } else if (e < 38 * 512 + 272) {
+        const int t = e - 38 * 512;
+        reinterpret_cast<float *>(out + S16_BIAS)[t] = t16_tail_value(blob, t);
     }
 }
 
@@ -136,6 +187,8 @@ __device__ __forceinline__ T16Lane fresh_lane(const T16Lane &L)
     r.w1 = fresh(L.w1);
     r.r1 = fresh(L.r1);
     r.r2 = fresh(L.r2);
+    r.pos8 = fresh(L.pos8);
+    r.trp = fresh(L.trp);
     return r;
 }
 template <int N>
@@ -165,47 +218,86 @@ __device__ __forceinline__ t16_h4 hi4(const t16_h8 &v) { return __builtin_shuffl
 
 // Weight-gradient blocks owned by this wave: acc[i] += sum over the 4 tile pairs of dY[yb] X[xb0 + i]^T (operands read back
 // transposed from the pairs' staging images).  ROWSUM: also accumulate this lane's row sums of dY (bias gradients).
-template <int NX, bool ROWSUM, int XSTRIDE = 1>
+// SPLIT: hi and lo parts of both operands staged ({Y, X, Y lo, X lo} per wave), three products per term.
+template <int NX, bool ROWSUM, int XSTRIDE = 1, bool SPLIT = false>
 __device__ __forceinline__ void wgrad(v4f *acc, float &rowsum, const char *stage, const T16Lane &L, int yb, int x_mat_off, int xb0)
 {
 #ifdef T16_NO_WGRAD
     return;
 #endif
+    constexpr int kWave = SPLIT ? 2 * T16_STAGE_WAVE : T16_STAGE_WAVE, kLo = 2 * T16_STAGE_MAT;
 #pragma unroll
     for (int P = 0; P < 4; ++P) {
-        const char *pm = stage + P * 2 * T16_STAGE_WAVE;
+        const char *pm = stage + P * 2 * kWave;
         const t16_h8 a = t16_stage_get(pm, L, yb);
         t16_h8 b[NX];
 #pragma unroll
         for (int i = 0; i < NX; ++i) b[i] = t16_stage_get(pm + x_mat_off, L, xb0 + i * XSTRIDE);
         if (ROWSUM) rowsum = t16_sum8(a, rowsum);
-        T16_REGION_BEGIN();
+        if constexpr (SPLIT) {
+            const t16_h8 alo = t16_stage_get(pm + kLo, L, yb);
+            t16_h8 blo[NX];
 #pragma unroll
-        for (int i = 0; i < NX; ++i) acc[i] = t16_mfma(a, b[i], acc[i]);
-        T16_REGION_END();
+            for (int i = 0; i < NX; ++i) blo[i] = t16_stage_get(pm + x_mat_off + kLo, L, xb0 + i * XSTRIDE);
+            if (ROWSUM) rowsum = t16_sum8(alo, rowsum);
+            T16_REGION_BEGIN();
+#pragma unroll
+            for (int i = 0; i < NX; ++i) acc[i] = t16_mfma(alo, b[i], acc[i]);
+#pragma unroll
+            for (int i = 0; i < NX; ++i) acc[i] = t16_mfma(a, blo[i], acc[i]);
+#pragma unroll
+            for (int i = 0; i < NX; ++i) acc[i] = t16_mfma(a, b[i], acc[i]);
+            T16_REGION_END();
+        } else {
+            T16_REGION_BEGIN();
+#pragma unroll
+            for (int i = 0; i < NX; ++i) acc[i] = t16_mfma(a, b[i], acc[i]);
+            T16_REGION_END();
+        }
+    }
+}
+// a split operand (hi, lo) of this lane's sample into blocks b, b + 1 of a staged matrix and of its lo twin
+__device__ __forceinline__ void stage_put2(char *mat, const T16Lane &L, int b, const T16HL &v)
+{
+    t16_stage_put(mat, L, b, __builtin_shufflevector(v.hi, v.hi, 0, 1, 2, 3));
+    t16_stage_put(mat, L, b + 1, __builtin_shufflevector(v.hi, v.hi, 4, 5, 6, 7));
+    t16_stage_put(mat + 2 * T16_STAGE_MAT, L, b, __builtin_shufflevector(v.lo, v.lo, 0, 1, 2, 3));
+    t16_stage_put(mat + 2 * T16_STAGE_MAT, L, b + 1, __builtin_shufflevector(v.lo, v.lo, 4, 5, 6, 7));
+}
+// Gaussian activation of a block from its pre-activation, and G'(u) = -100 u G(u) in f32
+__device__ __forceinline__ void act_and_deriv(const v4f &u, v4f &a, v4f &d)
+{
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        a[g] = gauss_fast(u[g]);
+        d[g] = -100.0f * u[g] * a[g];
     }
 }
 
 // REC8: the scatter records are 8 bytes (scatter_common.h: Rec8), else 16 (Rec).  POSE: also the two per-ray sums the pose
 // refinement needs (render_bwd_common.h g_dnorm / g_rowsum; csrc/render_bwd_h3.hip is the other kernel that produces them)
-template <int DT, bool REC8, bool POSE>
+// SPLIT ("t16s"): the gradient products split as well -- dY, W^T (read transposed out of the forward image) and both operands of
+// the weight gradients as hi + lo, three MFMAs per term; G'(u) in f32 (pre-activations are held, activations recomputed); f32
+// records.  Same structure, same barriers; fp32-equivalent gradients (tests/test_gpu_parity.py).
+template <int DT, bool REC8, bool POSE, bool SPLIT = false>
 __global__ void __launch_bounds__(kThreads, 2) k_render_bwd_t16(BwdArgs a)
 {
+    using LD = Lds<SPLIT>;
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    int *lres = reinterpret_cast<int *>(lds + kLdsRes);
-    uint32_t *cursor = reinterpret_cast<uint32_t *>(lds + kLdsCursor);
-    float *shbuf = reinterpret_cast<float *>(lds + kLdsSh);
-    float *mxbuf = reinterpret_cast<float *>(lds + kLdsMx);
+    int *lres = reinterpret_cast<int *>(lds + LD::kRes);
+    uint32_t *cursor = reinterpret_cast<uint32_t *>(lds + LD::kCursor);
+    float *shbuf = reinterpret_cast<float *>(lds + LD::kSh);
+    float *mxbuf = reinterpret_cast<float *>(lds + LD::kMx);
     {
-        const float4 *src = reinterpret_cast<const float4 *>(a.f.packed + WS_T16);
+        const float4 *src = reinterpret_cast<const float4 *>(a.f.packed + (SPLIT ? WS_S16 : WS_T16));
         float4 *dst = reinterpret_cast<float4 *>(lds);
-        for (int i = threadIdx.x; i < T16_BYTES / 16; i += kThreads) dst[i] = src[i];
+        for (int i = threadIdx.x; i < LD::kImg / 16; i += kThreads) dst[i] = src[i];
         if (threadIdx.x < 64) {
             const int lv = threadIdx.x >> 2, c = threadIdx.x & 3;
             lres[threadIdx.x] = c < 3 ? a.f.resolutions[3 * lv + c] : 0;
         }
-        float4 *stz = reinterpret_cast<float4 *>(lds + kLdsStage);  // finite contents wherever a step leaves a block unwritten
-        for (int i = threadIdx.x; i < kWaves * T16_STAGE_WAVE / 16; i += kThreads) stz[i] = make_float4(0, 0, 0, 0);
+        float4 *stz = reinterpret_cast<float4 *>(lds + LD::kStage);  // finite contents wherever a step leaves a block unwritten
+        for (int i = threadIdx.x; i < kWaves * LD::kStageWave / 16; i += kThreads) stz[i] = make_float4(0, 0, 0, 0);
         if (a.recs) {
             const int nbins = 16 * a.bins.NB;
             for (int i = threadIdx.x; i < nbins; i += kThreads)
@@ -215,8 +307,8 @@ __global__ void __launch_bounds__(kThreads, 2) k_render_bwd_t16(BwdArgs a)
     __syncthreads();
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: ray index, per-ray loads and branches go scalar
-    const char *stage = lds + kLdsStage;
-    char *stY = lds + kLdsStage + wv * T16_STAGE_WAVE, *stX = stY + T16_STAGE_MAT;
+    const char *stage = lds + LD::kStage;
+    char *stY = lds + LD::kStage + wv * LD::kStageWave, *stX = stY + T16_STAGE_MAT;   // (SPLIT: their lo twins 2 matrices further)
     const int S = a.f.S, nt16 = (S + 15) >> 4;
     const uint32_t plan_skip = a.recs ? __builtin_amdgcn_readfirstlane(*skip_word(a.recs)) : 0u;   // levels the plan left out
     __builtin_amdgcn_s_setreg(1 | (23 << 6), 1);  // hwreg(HW_REG_MODE, 23, 1) = FP16_OVFL: f16 conversions saturate
@@ -251,7 +343,7 @@ __global__ void __launch_bounds__(kThreads, 2) k_render_bwd_t16(BwdArgs a)
         const float *fo = a.f.out_ray + (size_t)rayc * SCANERF_RAY_OUT;
         {   // per ray: SH (published for the owners of the SH part) and the Dir layer-0 accumulator start, parked in LDS
             const int ln = fresh(lane), c = ln & 15, q = ln >> 4;
-            const T16Lane L = t16_lane(ln);
+            const T16Lane L = t16_lane(ln, LD::kStageWave);
             float sh[16];
             ray_sh(d, dnorm, sh);
             v4f s0, s1;  // B operand of the SH k-step: slot (q, j) = SH[8q + j] for q < 2, zero above
@@ -263,12 +355,13 @@ __global__ void __launch_bounds__(kThreads, 2) k_render_bwd_t16(BwdArgs a)
             const T16HL shB = t16_split(s0, s1);
             v4f dinit[4];
 #pragma unroll
-            for (int b = 0; b < 4; ++b) dinit[b] = t16_bias(lds, 2, b, q);
+            for (int b = 0; b < 4; ++b) dinit[b] = t16_bias(lds, 2, b, q, LD::kBias);
             // k-step 1 of the D0 pairs
 #pragma unroll
             for (int b = 0; b < 4; ++b) {
-                const char *p = lds + T16_D0 + (b * 2 + 1) * T16_PAIR + L.lo16;
-                const t16_h8 ahi = *reinterpret_cast<const t16_h8 *>(p), alo = *reinterpret_cast<const t16_h8 *>(p + T16_SUB);
+                const char *p = lds + T16_D0 + (b * 2 + 1) * T16_PAIR + (SPLIT ? L.pos8 : L.lo16);
+                const t16_h8 ahi = SPLIT ? s16_lda(p) : *reinterpret_cast<const t16_h8 *>(p);
+                const t16_h8 alo = SPLIT ? s16_lda(p + T16_SUB) : *reinterpret_cast<const t16_h8 *>(p + T16_SUB);
                 T16_REGION_BEGIN();
                 dinit[b] = t16_mfma(alo, shB.hi, dinit[b]);
                 dinit[b] = t16_mfma(ahi, shB.lo, dinit[b]);
@@ -276,7 +369,7 @@ __global__ void __launch_bounds__(kThreads, 2) k_render_bwd_t16(BwdArgs a)
                 T16_REGION_END();
             }
             if (c == 0) {
-                float4 *dp = reinterpret_cast<float4 *>(lds + kLdsDinit + wv * 256);
+                float4 *dp = reinterpret_cast<float4 *>(lds + LD::kDinit + wv * 256);
 #pragma unroll
                 for (int b = 0; b < 4; ++b) dp[4 * b + q] = make_float4(dinit[b][0], dinit[b][1], dinit[b][2], dinit[b][3]);
             }
@@ -383,7 +476,7 @@ __global__ void __launch_bounds__(kThreads, 2) k_render_bwd_t16(BwdArgs a)
         for (int tile = nt16 - 1; tile >= 0; --tile) {
             const int ln = fresh(lane);               // this tile's lane terms (not loop invariants: see fresh())
             const int c = ln & 15, q = ln >> 4;
-            T16Lane L = t16_lane(ln);
+            T16Lane L = t16_lane(ln, LD::kStageWave);
             const int s = tile * 16 + c;
             const bool live = s < S;
             const float z = nxt.z, dist_i = nxt.dist, tile_T_in = nxt.tT;
@@ -392,10 +485,85 @@ __global__ void __launch_bounds__(kThreads, 2) k_render_bwd_t16(BwdArgs a)
 
             // ================= forward recompute =================
             const v4f xa = nxt.xa, xb = nxt.xb;
-            t16_h8 xh, a0h[2], c0h[2], c1h[2], Hh[2];   // hi parts kept for the weight gradients
-            t16_h4 dg0[4], dgv0[4], dgv1[4];           // G'(u0), G'(v0), G'(v1)
+            t16_h8 xh, a0h[2], c0h[2], c1h[2], Hh[2];   // (!SPLIT) hi parts kept for the weight gradients
+            t16_h4 dg0[4], dgv0[4], dgv1[4];           // (!SPLIT) G'(u0), G'(v0), G'(v1) as f16
+            v4f ku0[4], khh[4], kv0[4], kv1[4];        // (SPLIT) pre-activations of the three Gaussian layers and H, f32: the
+                                                       // activations, their splits and G' are formed again where they are used
             float sigma, dsig_dpre, dif[3], tint[3], spec[3];
-            {
+            if constexpr (SPLIT) {
+                T16HL HB[2];
+                {
+                    const T16HL xB = t16_split(xa, xb);
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) ku0[b] = t16_bias(lds, 0, b, q, LD::kBias);
+                    s16_layer<4, 1>(ku0, lds, T16_L0, L.pos8, &xB);
+                    v4f act[4];
+#pragma unroll
+                    for (int b = 0; b < 4; ++b)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) act[b][g] = gauss_fast(ku0[b][g]);
+                    const T16HL aB[2] = { t16_split(act[0], act[1]), t16_split(act[2], act[3]) };
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) khh[b] = t16_bias(lds, 1, b, q, LD::kBias);
+                    s16_layer<4, 2>(khh, lds, T16_L1, L.pos8, aB);
+                    HB[0] = t16_split(khh[0], khh[1]);
+                    HB[1] = t16_split(khh[2], khh[3]);
+                }
+                emit_level(ptile, 0, pdx0, pdx1, ppe);
+                {   // heads on H[:32]
+                    v4f hd[2] = { t16_ld4(lds, LD::kBias + 256 * 4), t16_ld4(lds, LD::kBias + 260 * 4) };
+                    s16_layer<2, 1>(hd, lds, T16_HEAD, L.pos8, &HB[0]);
+                    sigma = softplus_(hd[0][0]);
+                    dsig_dpre = hd[0][0] > 20.0f ? 1.0f : sigmoid_fast(hd[0][0]);
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        dif[k] = sigmoid_fast(hd[0][1 + k]);
+                        tint[k] = sigmoid_fast(hd[1][k]);
+                    }
+                }
+                T16HL cB[2];
+                {   // Directional_MLP.mlp.0: H[32:64] part; SH part + bias in dinit
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) kv0[b] = t16_ld4(lds, LD::kDinit + wv * 256 + (16 * b + 4 * q) * 4);
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) {  // k-step 0 of the D0 pairs
+                        const char *p = lds + T16_D0 + (b * 2) * T16_PAIR + L.pos8;
+                        const t16_h8 ahi = s16_lda(p), alo = s16_lda(p + T16_SUB);
+                        T16_REGION_BEGIN();
+                        kv0[b] = t16_mfma(alo, HB[1].hi, kv0[b]);
+                        kv0[b] = t16_mfma(ahi, HB[1].lo, kv0[b]);
+                        kv0[b] = t16_mfma(ahi, HB[1].hi, kv0[b]);
+                        T16_REGION_END();
+                    }
+                    v4f act[4];
+#pragma unroll
+                    for (int b = 0; b < 4; ++b)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) act[b][g] = gauss_fast(kv0[b][g]);
+                    cB[0] = t16_split(act[0], act[1]);
+                    cB[1] = t16_split(act[2], act[3]);
+                }
+                emit_level(ptile, 1, pdx0, pdx1, ppe);
+                {
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) kv1[b] = t16_bias(lds, 3, b, q, LD::kBias);
+                    s16_layer<4, 2>(kv1, lds, T16_D1, L.pos8, cB);
+                    v4f act[4];
+#pragma unroll
+                    for (int b = 0; b < 4; ++b)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) act[b][g] = gauss_fast(kv1[b][g]);
+                    cB[0] = t16_split(act[0], act[1]);
+                    cB[1] = t16_split(act[2], act[3]);
+                }
+                emit_level(ptile, 2, pdx0, pdx1, ppe);
+                {
+                    v4f r[1] = { t16_ld4(lds, LD::kBias + 264 * 4) };
+                    s16_layer<1, 2>(r, lds, T16_D2, L.pos8, cB);
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) spec[k] = sigmoid_fast(r[0][k]);
+                }
+            } else {
                 T16HL HB[2];
                 {
                     const T16HL xB = t16_split(xa, xb);
@@ -434,7 +602,7 @@ __global__ void __launch_bounds__(kThreads, 2) k_render_bwd_t16(BwdArgs a)
                 {   // Directional_MLP.mlp.0: H[32:64] part; SH part + bias in dinit
                     v4f v[4];
 #pragma unroll
-                    for (int b = 0; b < 4; ++b) v[b] = t16_ld4(lds, kLdsDinit + wv * 256 + (16 * b + 4 * q) * 4);
+                    for (int b = 0; b < 4; ++b) v[b] = t16_ld4(lds, LD::kDinit + wv * 256 + (16 * b + 4 * q) * 4);
 #pragma unroll
                     for (int b = 0; b < 4; ++b) {  // k-step 0 of the D0 pairs
                         const char *p = lds + T16_D0 + (b * 2) * T16_PAIR + L.lo16;
@@ -569,61 +737,69 @@ __global__ void __launch_bounds__(kThreads, 2) k_render_bwd_t16(BwdArgs a)
 #pragma unroll
                 for (int k = 0; k < 3; ++k) gs3[k] *= sc;
             }
-            // ================= narrow layers: heads (32 -> 7) and rgb (64 -> 3) =================
-            L = fresh_lane(L);
-            // one 16-row block: rows 0-3 sigma, dif; 4-6 tint; 8-10 rgb  (lane group q holds rows 4q .. 4q+3)
-            t16_h8 narB;   // B operand of the transposed products (second block of the k-step = zeros)
-            {
-                v4f nar;
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const float r1 = g < 3 ? gh[4 + g] : 0.0f, r2 = g < 3 ? gs3[g] : 0.0f;
-                    nar[g] = q == 0 ? gh[g] : (q == 1 ? r1 : (q == 2 ? r2 : 0.0f));
-                }
+            v4f dx[2];
+            zero4(dx);
+            if constexpr (SPLIT) {
+                constexpr int kLo = 2 * T16_STAGE_MAT;
                 const v4f zero = { 0, 0, 0, 0 };
-                narB = t16_hi(nar, zero);
-                t16_stage_put(stY, L, 0, lo4(narB));
-                t16_stage_put(stY, L, 2, lo4(Hh[0]));   // X operand of the heads' weight gradient: H[:32] in blocks 2, 3 of Y
-                t16_stage_put(stY, L, 3, hi4(Hh[0]));
-                t16_stage_put(stX, L, 0, lo4(c1h[0]));  // X operand of the rgb layer's weight gradient
-                t16_stage_put(stX, L, 1, hi4(c1h[0]));
-                t16_stage_put(stX, L, 2, lo4(c1h[1]));
-                t16_stage_put(stX, L, 3, hi4(c1h[1]));
-            }
-            STEP_BARRIER();  // ---- A1
-            if (wv == 0) wgrad<1, true>(gW_nar, gB_nar, stage, L, 0, 0, 2);          // heads: x = H[0:16]
-            else if (wv == 1) { float dummy = 0.0f; wgrad<1, false>(gW_nar, dummy, stage, L, 0, 0, 3); }   // heads: x = H[16:32]
-            else if (wv < 6) { float dummy = 0.0f; wgrad<1, false>(gW_nar, dummy, stage, L, 0, T16_STAGE_MAT, wv - 2); }  // rgb: x = c1 block wv-2
-            // dv1 = (W_rgb^T gs3) * G'(v1)
-            t16_h8 dyB[2];
-            {
-                v4f dc[4];
-                zero4(dc);
-                t16_chain<4, 1>(dc, lds, T16T_D2, L.lo16, &narB);
+                // ================= narrow layers: heads (32 -> 7) and rgb (64 -> 3) =================
+                L = fresh_lane(L);
+                // one 16-row block: rows 0-3 sigma, dif; 4-6 tint; 8-10 rgb  (lane group q holds rows 4q .. 4q+3)
+                T16HL narS;   // B operand of the transposed products (second block of the k-step = zeros)
+                v4f dgq[4];   // G' of the Gaussian layer the current step goes through, f32
+                {
+                    v4f nar;
 #pragma unroll
-                for (int b = 0; b < 4; ++b) dc[b] = mul_dg(dc[b], dgv1[b]);
-                dyB[0] = t16_hi(dc[0], dc[1]);
-                dyB[1] = t16_hi(dc[2], dc[3]);
-            }
-            STEP_BARRIER();  // ---- B1
-            // ================= Directional_MLP.mlp.2 (64 -> 64) =================
-            L = fresh_lane(L);
+                    for (int g = 0; g < 4; ++g) {
+                        const float r1 = g < 3 ? gh[4 + g] : 0.0f, r2 = g < 3 ? gs3[g] : 0.0f;
+                        nar[g] = q == 0 ? gh[g] : (q == 1 ? r1 : (q == 2 ? r2 : 0.0f));
+                    }
+                    narS = t16_split(nar, zero);
+                    t16_stage_put(stY, L, 0, lo4(narS.hi));
+                    t16_stage_put(stY + kLo, L, 0, lo4(narS.lo));
+                    stage_put2(stY, L, 2, t16_split(khh[0], khh[1]));   // X operand of the heads' weight gradient: H[:32] in blocks 2, 3 of Y
+                    v4f c1[4];
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                t16_stage_put(stY, L, 2 * t, lo4(dyB[t]));
-                t16_stage_put(stY, L, 2 * t + 1, hi4(dyB[t]));
-                t16_stage_put(stX, L, 2 * t, lo4(c0h[t]));
-                t16_stage_put(stX, L, 2 * t + 1, hi4(c0h[t]));
-            }
-            STEP_BARRIER();  // ---- A2
-            if (cb == 0) wgrad<2, true>(gW_D1, gB_D1, stage, L, rb, T16_STAGE_MAT, 0);
-            else { float dummy = 0.0f; wgrad<2, false>(gW_D1, dummy, stage, L, rb, T16_STAGE_MAT, 2); }
-            {
-                v4f dc[4];
-                zero4(dc);
-                t16_chain<4, 2>(dc, lds, T16T_D1, L.lo16, dyB);
+                    for (int b = 0; b < 4; ++b) act_and_deriv(kv1[b], c1[b], dgq[b]);
+                    stage_put2(stX, L, 0, t16_split(c1[0], c1[1]));     // X operand of the rgb layer's weight gradient
+                    stage_put2(stX, L, 2, t16_split(c1[2], c1[3]));
+                }
+                STEP_BARRIER();  // ---- A1
+                if (wv == 0) wgrad<1, true, 1, true>(gW_nar, gB_nar, stage, L, 0, 0, 2);          // heads: x = H[0:16]
+                else if (wv == 1) { float dummy = 0.0f; wgrad<1, false, 1, true>(gW_nar, dummy, stage, L, 0, 0, 3); }   // heads: x = H[16:32]
+                else if (wv < 6) { float dummy = 0.0f; wgrad<1, false, 1, true>(gW_nar, dummy, stage, L, 0, T16_STAGE_MAT, wv - 2); }  // rgb: x = c1 block wv-2
+                // dv1 = (W_rgb^T gs3) * G'(v1)
+                T16HL dyS[2];
+                {
+                    v4f dc[4];
+                    zero4(dc);
+                    s16_chain_narrow<4>(dc, lds, S16T_D2, L.lo16, narS);
 #pragma unroll
-                for (int b = 0; b < 4; ++b) dc[b] = mul_dg(dc[b], dgv0[b]);   // dv0
+                    for (int b = 0; b < 4; ++b) dc[b] *= dgq[b];
+                    dyS[0] = t16_split(dc[0], dc[1]);
+                    dyS[1] = t16_split(dc[2], dc[3]);
+                }
+                STEP_BARRIER();  // ---- B1
+                // ================= Directional_MLP.mlp.2 (64 -> 64) =================
+                L = fresh_lane(L);
+                {
+                    v4f c0[4];
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) act_and_deriv(kv0[b], c0[b], dgq[b]);
+                    stage_put2(stY, L, 0, dyS[0]);
+                    stage_put2(stY, L, 2, dyS[1]);
+                    stage_put2(stX, L, 0, t16_split(c0[0], c0[1]));
+                    stage_put2(stX, L, 2, t16_split(c0[2], c0[3]));
+                }
+                STEP_BARRIER();  // ---- A2
+                if (cb == 0) wgrad<2, true, 1, true>(gW_D1, gB_D1, stage, L, rb, T16_STAGE_MAT, 0);
+                else { float dummy = 0.0f; wgrad<2, false, 1, true>(gW_D1, dummy, stage, L, rb, T16_STAGE_MAT, 2); }
+                {
+                    v4f dc[4];
+                    zero4(dc);
+                    s16_chain<4, 2, 2>(dc, lds, T16_D1, L.trp, dyS);
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) dc[b] *= dgq[b];   // dv0
                 if (POSE) {  // 16 values x 16 samples -> lane c keeps the tile's sum of value c (= block c >> 2, register c & 3)
                     float v[16];
 #pragma unroll
@@ -639,72 +815,202 @@ __global__ void __launch_bounds__(kThreads, 2) k_render_bwd_t16(BwdArgs a)
                     }
                     pose_rs += v[0];
                 }
-                dyB[0] = t16_hi(dc[0], dc[1]);
-                dyB[1] = t16_hi(dc[2], dc[3]);
-            }
-            STEP_BARRIER();  // ---- B2
-            // ================= Directional_MLP.mlp.0 (32 of its 48 inputs; the SH part per ray) =================
-            L = fresh_lane(L);
+                    dyS[0] = t16_split(dc[0], dc[1]);
+                    dyS[1] = t16_split(dc[2], dc[3]);
+                }
+                STEP_BARRIER();  // ---- B2
+                // ================= Directional_MLP.mlp.0 (32 of its 48 inputs; the SH part per ray) =================
+                L = fresh_lane(L);
+                stage_put2(stY, L, 0, dyS[0]);
+                stage_put2(stY, L, 2, dyS[1]);
+                stage_put2(stX, L, 0, t16_split(khh[2], khh[3]));
+                {   // the SH part of the layer's input is constant along the ray: staged as 16 more "units" (block 2 of X)
+                    const float4 shq = *reinterpret_cast<const float4 *>(shbuf + wv * 16 + 4 * q);
+                    const T16HL shS = t16_split(v4f{ shq.x, shq.y, shq.z, shq.w }, zero);
+                    t16_stage_put(stX, L, 2, lo4(shS.hi));
+                    t16_stage_put(stX + kLo, L, 2, lo4(shS.lo));
+                }
+                STEP_BARRIER();  // ---- A3
+                if (cb == 0) wgrad<2, true, 2, true>(gW_D0, gB_D0, stage, L, rb, T16_STAGE_MAT, 0);   // x = H[32:48] and SH
+                else { float dummy = 0.0f; wgrad<1, false, 1, true>(gW_D0, dummy, stage, L, rb, T16_STAGE_MAT, 1); }   // x = H[48:64]
+                {
+                    v4f dH[4];
+                    zero4(dH);
+                    s16_chain<2, 2, 2>(&dH[2], lds, T16_D0, L.trp, dyS);        // dH[32:64] = W_D0[:, :32]^T dv0 (input k-step 0 of the D0 pairs)
+                    s16_chain_narrow<2>(&dH[0], lds, S16T_HEAD, L.lo16, narS);  // dH[0:32] = heads^T gh
+                    dyS[0] = t16_split(dH[0], dH[1]);
+                    dyS[1] = t16_split(dH[2], dH[3]);
+                }
+                STEP_BARRIER();  // ---- B3
+                // ================= Spatial_MLP.mlp.2 (64 -> 64, linear) =================
+                L = fresh_lane(L);
+                {
+                    v4f a0[4];
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                t16_stage_put(stY, L, 2 * t, lo4(dyB[t]));
-                t16_stage_put(stY, L, 2 * t + 1, hi4(dyB[t]));
-            }
-            t16_stage_put(stX, L, 0, lo4(Hh[1]));
-            t16_stage_put(stX, L, 1, hi4(Hh[1]));
-            {   // the SH part of the layer's input is constant along the ray: staged as 16 more "units" (block 2 of X)
-                const float4 shq = *reinterpret_cast<const float4 *>(shbuf + wv * 16 + 4 * q);
-                t16_stage_put(stX, L, 2, t16_hi4(v4f{ shq.x, shq.y, shq.z, shq.w }));
-            }
-            STEP_BARRIER();  // ---- A3
-            if (cb == 0) wgrad<2, true, 2>(gW_D0, gB_D0, stage, L, rb, T16_STAGE_MAT, 0);   // x = H[32:48] and SH
-            else { float dummy = 0.0f; wgrad<1, false>(gW_D0, dummy, stage, L, rb, T16_STAGE_MAT, 1); }   // x = H[48:64]
-            {
-                v4f dH[4];
-                zero4(dH);
-                t16_chain<2, 2>(&dH[2], lds, T16T_D0, L.lo16, dyB);     // dH[32:64] = W_D0[:, :32]^T dv0
-                t16_chain<2, 1>(&dH[0], lds, T16T_HEAD, L.lo16, &narB);  // dH[0:32] = heads^T gh
-                dyB[0] = t16_hi(dH[0], dH[1]);
-                dyB[1] = t16_hi(dH[2], dH[3]);
-            }
-            STEP_BARRIER();  // ---- B3
-            // ================= Spatial_MLP.mlp.2 (64 -> 64, linear) =================
-            L = fresh_lane(L);
+                    for (int b = 0; b < 4; ++b) act_and_deriv(ku0[b], a0[b], dgq[b]);
+                    stage_put2(stY, L, 0, dyS[0]);
+                    stage_put2(stY, L, 2, dyS[1]);
+                    stage_put2(stX, L, 0, t16_split(a0[0], a0[1]));
+                    stage_put2(stX, L, 2, t16_split(a0[2], a0[3]));
+                }
+                STEP_BARRIER();  // ---- A4
+                if (cb == 0) wgrad<2, true, 1, true>(gW_L1, gB_L1, stage, L, rb, T16_STAGE_MAT, 0);
+                else { float dummy = 0.0f; wgrad<2, false, 1, true>(gW_L1, dummy, stage, L, rb, T16_STAGE_MAT, 2); }
+                {
+                    v4f dc[4];
+                    zero4(dc);
+                    s16_chain<4, 2, 2>(dc, lds, T16_L1, L.trp, dyS);
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                t16_stage_put(stY, L, 2 * t, lo4(dyB[t]));
-                t16_stage_put(stY, L, 2 * t + 1, hi4(dyB[t]));
-                t16_stage_put(stX, L, 2 * t, lo4(a0h[t]));
-                t16_stage_put(stX, L, 2 * t + 1, hi4(a0h[t]));
+                    for (int b = 0; b < 4; ++b) dc[b] *= dgq[b];   // du0
+                    dyS[0] = t16_split(dc[0], dc[1]);
+                    dyS[1] = t16_split(dc[2], dc[3]);
+                }
+                STEP_BARRIER();  // ---- B4
+                // ================= Spatial_MLP.mlp.0 (32 -> 64) =================
+                L = fresh_lane(L);
+                stage_put2(stY, L, 0, dyS[0]);
+                stage_put2(stY, L, 2, dyS[1]);
+                stage_put2(stX, L, 0, t16_split(xa, xb));
+                STEP_BARRIER();  // ---- A5
+                if (cb == 0) wgrad<1, true, 1, true>(gW_L0, gB_L0, stage, L, rb, T16_STAGE_MAT, 0);
+                else { float dummy = 0.0f; wgrad<1, false, 1, true>(gW_L0, dummy, stage, L, rb, T16_STAGE_MAT, 1); }
+                s16_chain<2, 2, 1>(dx, lds, T16_L0, L.trp, dyS);
+            } else {
+                // ================= narrow layers: heads (32 -> 7) and rgb (64 -> 3) =================
+                L = fresh_lane(L);
+                // one 16-row block: rows 0-3 sigma, dif; 4-6 tint; 8-10 rgb  (lane group q holds rows 4q .. 4q+3)
+                t16_h8 narB;   // B operand of the transposed products (second block of the k-step = zeros)
+                {
+                    v4f nar;
+    #pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const float r1 = g < 3 ? gh[4 + g] : 0.0f, r2 = g < 3 ? gs3[g] : 0.0f;
+                        nar[g] = q == 0 ? gh[g] : (q == 1 ? r1 : (q == 2 ? r2 : 0.0f));
+                    }
+                    const v4f zero = { 0, 0, 0, 0 };
+                    narB = t16_hi(nar, zero);
+                    t16_stage_put(stY, L, 0, lo4(narB));
+                    t16_stage_put(stY, L, 2, lo4(Hh[0]));   // X operand of the heads' weight gradient: H[:32] in blocks 2, 3 of Y
+                    t16_stage_put(stY, L, 3, hi4(Hh[0]));
+                    t16_stage_put(stX, L, 0, lo4(c1h[0]));  // X operand of the rgb layer's weight gradient
+                    t16_stage_put(stX, L, 1, hi4(c1h[0]));
+                    t16_stage_put(stX, L, 2, lo4(c1h[1]));
+                    t16_stage_put(stX, L, 3, hi4(c1h[1]));
+                }
+                STEP_BARRIER();  // ---- A1
+                if (wv == 0) wgrad<1, true>(gW_nar, gB_nar, stage, L, 0, 0, 2);          // heads: x = H[0:16]
+                else if (wv == 1) { float dummy = 0.0f; wgrad<1, false>(gW_nar, dummy, stage, L, 0, 0, 3); }   // heads: x = H[16:32]
+                else if (wv < 6) { float dummy = 0.0f; wgrad<1, false>(gW_nar, dummy, stage, L, 0, T16_STAGE_MAT, wv - 2); }  // rgb: x = c1 block wv-2
+                // dv1 = (W_rgb^T gs3) * G'(v1)
+                t16_h8 dyB[2];
+                {
+                    v4f dc[4];
+                    zero4(dc);
+                    t16_chain<4, 1>(dc, lds, T16T_D2, L.lo16, &narB);
+    #pragma unroll
+                    for (int b = 0; b < 4; ++b) dc[b] = mul_dg(dc[b], dgv1[b]);
+                    dyB[0] = t16_hi(dc[0], dc[1]);
+                    dyB[1] = t16_hi(dc[2], dc[3]);
+                }
+                STEP_BARRIER();  // ---- B1
+                // ================= Directional_MLP.mlp.2 (64 -> 64) =================
+                L = fresh_lane(L);
+    #pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    t16_stage_put(stY, L, 2 * t, lo4(dyB[t]));
+                    t16_stage_put(stY, L, 2 * t + 1, hi4(dyB[t]));
+                    t16_stage_put(stX, L, 2 * t, lo4(c0h[t]));
+                    t16_stage_put(stX, L, 2 * t + 1, hi4(c0h[t]));
+                }
+                STEP_BARRIER();  // ---- A2
+                if (cb == 0) wgrad<2, true>(gW_D1, gB_D1, stage, L, rb, T16_STAGE_MAT, 0);
+                else { float dummy = 0.0f; wgrad<2, false>(gW_D1, dummy, stage, L, rb, T16_STAGE_MAT, 2); }
+                {
+                    v4f dc[4];
+                    zero4(dc);
+                    t16_chain<4, 2>(dc, lds, T16T_D1, L.lo16, dyB);
+    #pragma unroll
+                    for (int b = 0; b < 4; ++b) dc[b] = mul_dg(dc[b], dgv0[b]);   // dv0
+                    if (POSE) {  // 16 values x 16 samples -> lane c keeps the tile's sum of value c (= block c >> 2, register c & 3)
+                        float v[16];
+    #pragma unroll
+                        for (int i = 0; i < 16; ++i) v[i] = dc[i >> 2][i & 3];
+    #pragma unroll
+                        for (int off = 8, half = 8; off > 0; off >>= 1, half >>= 1) {
+                            const bool up = (c & off) != 0;
+    #pragma unroll
+                            for (int j = 0; j < half; ++j) {
+                                const float mine = up ? v[j + half] : v[j], send = up ? v[j] : v[j + half];
+                                v[j] = mine + __shfl_xor(send, off, 16);
+                            }
+                        }
+                        pose_rs += v[0];
+                    }
+                    dyB[0] = t16_hi(dc[0], dc[1]);
+                    dyB[1] = t16_hi(dc[2], dc[3]);
+                }
+                STEP_BARRIER();  // ---- B2
+                // ================= Directional_MLP.mlp.0 (32 of its 48 inputs; the SH part per ray) =================
+                L = fresh_lane(L);
+    #pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    t16_stage_put(stY, L, 2 * t, lo4(dyB[t]));
+                    t16_stage_put(stY, L, 2 * t + 1, hi4(dyB[t]));
+                }
+                t16_stage_put(stX, L, 0, lo4(Hh[1]));
+                t16_stage_put(stX, L, 1, hi4(Hh[1]));
+                {   // the SH part of the layer's input is constant along the ray: staged as 16 more "units" (block 2 of X)
+                    const float4 shq = *reinterpret_cast<const float4 *>(shbuf + wv * 16 + 4 * q);
+                    t16_stage_put(stX, L, 2, t16_hi4(v4f{ shq.x, shq.y, shq.z, shq.w }));
+                }
+                STEP_BARRIER();  // ---- A3
+                if (cb == 0) wgrad<2, true, 2>(gW_D0, gB_D0, stage, L, rb, T16_STAGE_MAT, 0);   // x = H[32:48] and SH
+                else { float dummy = 0.0f; wgrad<1, false>(gW_D0, dummy, stage, L, rb, T16_STAGE_MAT, 1); }   // x = H[48:64]
+                {
+                    v4f dH[4];
+                    zero4(dH);
+                    t16_chain<2, 2>(&dH[2], lds, T16T_D0, L.lo16, dyB);     // dH[32:64] = W_D0[:, :32]^T dv0
+                    t16_chain<2, 1>(&dH[0], lds, T16T_HEAD, L.lo16, &narB);  // dH[0:32] = heads^T gh
+                    dyB[0] = t16_hi(dH[0], dH[1]);
+                    dyB[1] = t16_hi(dH[2], dH[3]);
+                }
+                STEP_BARRIER();  // ---- B3
+                // ================= Spatial_MLP.mlp.2 (64 -> 64, linear) =================
+                L = fresh_lane(L);
+    #pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    t16_stage_put(stY, L, 2 * t, lo4(dyB[t]));
+                    t16_stage_put(stY, L, 2 * t + 1, hi4(dyB[t]));
+                    t16_stage_put(stX, L, 2 * t, lo4(a0h[t]));
+                    t16_stage_put(stX, L, 2 * t + 1, hi4(a0h[t]));
+                }
+                STEP_BARRIER();  // ---- A4
+                if (cb == 0) wgrad<2, true>(gW_L1, gB_L1, stage, L, rb, T16_STAGE_MAT, 0);
+                else { float dummy = 0.0f; wgrad<2, false>(gW_L1, dummy, stage, L, rb, T16_STAGE_MAT, 2); }
+                {
+                    v4f dc[4];
+                    zero4(dc);
+                    t16_chain<4, 2>(dc, lds, T16T_L1, L.lo16, dyB);
+    #pragma unroll
+                    for (int b = 0; b < 4; ++b) dc[b] = mul_dg(dc[b], dg0[b]);   // du0
+                    dyB[0] = t16_hi(dc[0], dc[1]);
+                    dyB[1] = t16_hi(dc[2], dc[3]);
+                }
+                STEP_BARRIER();  // ---- B4
+                // ================= Spatial_MLP.mlp.0 (32 -> 64) =================
+                L = fresh_lane(L);
+    #pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    t16_stage_put(stY, L, 2 * t, lo4(dyB[t]));
+                    t16_stage_put(stY, L, 2 * t + 1, hi4(dyB[t]));
+                }
+                t16_stage_put(stX, L, 0, lo4(xh));
+                t16_stage_put(stX, L, 1, hi4(xh));
+                STEP_BARRIER();  // ---- A5
+                if (cb == 0) wgrad<1, true>(gW_L0, gB_L0, stage, L, rb, T16_STAGE_MAT, 0);
+                else { float dummy = 0.0f; wgrad<1, false>(gW_L0, dummy, stage, L, rb, T16_STAGE_MAT, 1); }
+                t16_chain<2, 2>(dx, lds, T16T_L0, L.lo16, dyB);
             }
-            STEP_BARRIER();  // ---- A4
-            if (cb == 0) wgrad<2, true>(gW_L1, gB_L1, stage, L, rb, T16_STAGE_MAT, 0);
-            else { float dummy = 0.0f; wgrad<2, false>(gW_L1, dummy, stage, L, rb, T16_STAGE_MAT, 2); }
-            {
-                v4f dc[4];
-                zero4(dc);
-                t16_chain<4, 2>(dc, lds, T16T_L1, L.lo16, dyB);
-#pragma unroll
-                for (int b = 0; b < 4; ++b) dc[b] = mul_dg(dc[b], dg0[b]);   // du0
-                dyB[0] = t16_hi(dc[0], dc[1]);
-                dyB[1] = t16_hi(dc[2], dc[3]);
-            }
-            STEP_BARRIER();  // ---- B4
-            // ================= Spatial_MLP.mlp.0 (32 -> 64) =================
-            L = fresh_lane(L);
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                t16_stage_put(stY, L, 2 * t, lo4(dyB[t]));
-                t16_stage_put(stY, L, 2 * t + 1, hi4(dyB[t]));
-            }
-            t16_stage_put(stX, L, 0, lo4(xh));
-            t16_stage_put(stX, L, 1, hi4(xh));
-            STEP_BARRIER();  // ---- A5
-            if (cb == 0) wgrad<1, true>(gW_L0, gB_L0, stage, L, rb, T16_STAGE_MAT, 0);
-            else { float dummy = 0.0f; wgrad<1, false>(gW_L0, dummy, stage, L, rb, T16_STAGE_MAT, 1); }
-            v4f dx[2];
-            zero4(dx);
-            t16_chain<2, 2>(dx, lds, T16T_L0, L.lo16, dyB);
             dx[0] *= isc;
             dx[1] *= isc;
             if (POSE && a.g_raypos && live && active) {
@@ -864,31 +1170,37 @@ namespace scanerf {
 int launch_pack_decoder_t16(const float *blob, const float *wf, char *out, hipStream_t st)
 {
     hipLaunchKernelGGL(k_pack_decoder_t16, dim3((62 * 512 + 272 + 255) / 256), dim3(256), 0, st, blob, wf, out);
+    // ... and the images of its split-gradient variant, right behind (render_common.h WS_S16)
+    hipLaunchKernelGGL(k_pack_decoder_s16, dim3((38 * 512 + 272 + 255) / 256), dim3(256), 0, st, blob, wf, out + T16_BYTES);
     return 0;
 }
 
-int launch_render_bwd_t16(const BwdArgs &a, int feat_dtype, int blocks, size_t lds_extra, hipStream_t st)
+int launch_render_bwd_t16(const BwdArgs &a, int feat_dtype, int blocks, size_t lds_extra, hipStream_t st, bool split)
 {
-    const size_t lds_bytes = (size_t)kLdsCursor + lds_extra;
+    const size_t lds_bytes = (size_t)(split ? Lds<true>::kCursor : Lds<false>::kCursor) + lds_extra;
     SCANERF_REQUIRE(lds_bytes <= 160 * 1024, "render_backward(t16): %zu B of LDS needed (table too large for the fused scatter)", lds_bytes);
     SCANERF_REQUIRE(a.xstash, "render_backward(t16): needs the x-stash");
     SCANERF_REQUIRE((a.g_dnorm != nullptr) == (a.g_rowsum != nullptr), "render_backward(t16): g_dnorm and g_rowsum come together");
     SCANERF_REQUIRE(!a.g_raypos || (a.g_dnorm && a.f.jstash), "render_backward(t16): g_raypos needs g_dnorm / g_rowsum and the forward's jstash");
-#define SCANERF_LAUNCH_BWD(DT, R8, PO)                                                                             \
+#define SCANERF_LAUNCH_BWD(DT, R8, PO, SP)                                                                         \
     {                                                                                                              \
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_render_bwd_t16<DT, R8, PO>),          \
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_render_bwd_t16<DT, R8, PO, SP>),      \
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);            \
         SCANERF_REQUIRE(e == hipSuccess, "render_backward(t16): cannot reserve %zu B of LDS: %s", lds_bytes,        \
                         hipGetErrorString(e));                                                                     \
-        hipLaunchKernelGGL((k_render_bwd_t16<DT, R8, PO>), dim3(blocks), dim3(kThreads), lds_bytes, st, a);         \
+        hipLaunchKernelGGL((k_render_bwd_t16<DT, R8, PO, SP>), dim3(blocks), dim3(kThreads), lds_bytes, st, a);     \
     }
     (void)feat_dtype;  // the table is only read through the x-stash here
     const bool r8 = a.recs && a.bins.rec8;
-    if (a.g_dnorm) {
-        if (r8) SCANERF_LAUNCH_BWD(SCANERF_F32, true, true)
-        else SCANERF_LAUNCH_BWD(SCANERF_F32, false, true)
-    } else if (r8) SCANERF_LAUNCH_BWD(SCANERF_F32, true, false)
-    else SCANERF_LAUNCH_BWD(SCANERF_F32, false, false)
+    SCANERF_REQUIRE(!(split && r8), "render_backward(t16s): the split variant emits f32 records");
+    if (split) {
+        if (a.g_dnorm) SCANERF_LAUNCH_BWD(SCANERF_F32, false, true, true)
+        else SCANERF_LAUNCH_BWD(SCANERF_F32, false, false, true)
+    } else if (a.g_dnorm) {
+        if (r8) SCANERF_LAUNCH_BWD(SCANERF_F32, true, true, false)
+        else SCANERF_LAUNCH_BWD(SCANERF_F32, false, true, false)
+    } else if (r8) SCANERF_LAUNCH_BWD(SCANERF_F32, true, false, false)
+    else SCANERF_LAUNCH_BWD(SCANERF_F32, false, false, false)
 #undef SCANERF_LAUNCH_BWD
     return 0;
 }

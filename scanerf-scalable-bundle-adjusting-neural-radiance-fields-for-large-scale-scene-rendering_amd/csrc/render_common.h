@@ -92,9 +92,20 @@ static_assert(T16_BYTES % 16 == 0, "t16 image is copied as float4");
 constexpr int T16_FLOATS = T16_BYTES / 4;
 
 
-// packed workspace = [fp32 image PK_TOTAL floats][h3 image H3_FLOATS floats][t16 images T16_FLOATS floats]
+// ---- images of the split-gradient variant of that kernel ("t16s", render_t16.h): ONE image serves the forward recompute and
+// the transposed products (sub-images of two 512-byte halves with XOR-swizzled lane slots), hi and lo parts; the narrow layers'
+// transposed sub-images (hi, lo) as extra pairs; the same f32 tail
+constexpr int S16T_D2 = T16_FWD_BYTES;                  // 4 pairs: [input block b_in], k = narrow rows (8..10 = rgb)
+constexpr int S16T_HEAD = S16T_D2 + 4 * T16_PAIR;       // 2 pairs: dH blocks 0, 1; k = narrow rows (0..6 = sigma, dif, tint)
+constexpr int S16_BIAS = S16T_HEAD + 2 * T16_PAIR;
+constexpr int S16_BYTES = S16_BIAS + (256 + 16) * 4;
+static_assert(S16_BYTES % 16 == 0, "t16s image is copied as float4");
+constexpr int S16_FLOATS = S16_BYTES / 4;
+
+// packed workspace = [fp32 image PK_TOTAL floats][h3 image H3_FLOATS floats][t16 images T16_FLOATS floats][t16s images S16_FLOATS floats]
 constexpr int WS_T16 = PK_TOTAL + H3_FLOATS;
-constexpr int WS_FLOATS = WS_T16 + T16_FLOATS;
+constexpr int WS_S16 = WS_T16 + T16_FLOATS;
+constexpr int WS_FLOATS = WS_S16 + S16_FLOATS;
 
 __host__ __device__ constexpr int nmap(int g, int h) { return (g & 3) + 8 * (g >> 2) + 4 * h; }
 

@@ -158,12 +158,86 @@ __device__ __forceinline__ void t16_chain(v4f dx[NBI], const char *img, int base
         T16_REGION_END();
     }
 }
+// ---- "t16s": the same layers with the gradient products split as well (hi + lo of W^T and of dY, three MFMAs per term) ----
+// A operand of a forward product from the swizzled image: `p` = sub-image + L.pos8
+__device__ __forceinline__ t16_h8 s16_lda(const char *p)
+{
+    const t16_h4 a = *reinterpret_cast<const t16_h4 *>(p), b = *reinterpret_cast<const t16_h4 *>(p + 512);
+    return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+template <int NB, int KS>
+__device__ __forceinline__ void s16_layer(v4f u[NB], const char *img, int base, int pos8, const T16HL B[KS])
+{
+    constexpr int G = NB < T16_GROUP ? NB : T16_GROUP;
+#pragma unroll
+    for (int b0 = 0; b0 < NB; b0 += G)
+#pragma unroll
+        for (int t = 0; t < KS; ++t) {
+            t16_h8 ahi[G], alo[G];
+#pragma unroll
+            for (int b = 0; b < G; ++b) {
+                const char *p = img + base + ((b0 + b) * KS + t) * T16_PAIR + pos8;
+                ahi[b] = s16_lda(p);
+                alo[b] = s16_lda(p + T16_SUB);
+            }
+            T16_REGION_BEGIN();
+#pragma unroll
+            for (int b = 0; b < G; ++b) u[b0 + b] = t16_mfma(alo[b], B[t].hi, u[b0 + b]);
+#pragma unroll
+            for (int b = 0; b < G; ++b) u[b0 + b] = t16_mfma(ahi[b], B[t].lo, u[b0 + b]);
+#pragma unroll
+            for (int b = 0; b < G; ++b) u[b0 + b] = t16_mfma(ahi[b], B[t].hi, u[b0 + b]);
+            T16_REGION_END();
+        }
+}
+__device__ __forceinline__ t16_h4 t16_tr4(const char *p);
+// Transposed product dx[b_in] += W^T[b_in] dY from the FORWARD image of the layer (`base`, KSIN k-steps per output block), over
+// KS k-steps of its output units.  A operand of (b_in, t): lane (m, q) needs W[n = 32t + 16(j >> 2) + 4q + (j & 3)][i = 16 b_in + m]:
+// rows n = 32t + 4q + r (r = 0..3) of output block 2t, then of block 2t + 1; in the image those are lanes (m' = 4q + r, q' = p)
+// of the pair (block, input k-step b_in >> 1), half b_in & 1 -- 8 bytes each, which ds_read_b64_tr_b16 delivers transposed.
+template <int NBI, int KS, int KSIN>
+__device__ __forceinline__ void s16_chain(v4f dx[NBI], const char *img, int base, int trp, const T16HL dY[KS])
+{
+#pragma unroll
+    for (int t = 0; t < KS; ++t)
+#pragma unroll
+        for (int bi = 0; bi < NBI; ++bi) {
+            const char *a0 = img + base + ((2 * t) * KSIN + (bi >> 1)) * T16_PAIR + (bi & 1) * 512 + trp;
+            const char *a1 = a0 + KSIN * T16_PAIR;
+            const t16_h8 ahi = __builtin_shufflevector(t16_tr4(a0), t16_tr4(a1), 0, 1, 2, 3, 4, 5, 6, 7);
+            const t16_h8 alo = __builtin_shufflevector(t16_tr4(a0 + T16_SUB), t16_tr4(a1 + T16_SUB), 0, 1, 2, 3, 4, 5, 6, 7);
+            T16_REGION_BEGIN();
+            dx[bi] = t16_mfma(alo, dY[t].hi, dx[bi]);
+            dx[bi] = t16_mfma(ahi, dY[t].lo, dx[bi]);
+            dx[bi] = t16_mfma(ahi, dY[t].hi, dx[bi]);
+            T16_REGION_END();
+        }
+}
+// ... of a narrow layer (heads, rgb): its own transposed pairs (hi, lo), lane l's 16 B at 16 l, one k-step
+template <int NBI>
+__device__ __forceinline__ void s16_chain_narrow(v4f dx[NBI], const char *img, int base, int lo16, const T16HL &dY)
+{
+#pragma unroll
+    for (int b = 0; b < NBI; ++b) {
+        const char *p = img + base + b * T16_PAIR + lo16;
+        const t16_h8 ahi = *reinterpret_cast<const t16_h8 *>(p), alo = *reinterpret_cast<const t16_h8 *>(p + T16_SUB);
+        T16_REGION_BEGIN();
+        dx[b] = t16_mfma(alo, dY.hi, dx[b]);
+        dx[b] = t16_mfma(ahi, dY.lo, dx[b]);
+        dx[b] = t16_mfma(ahi, dY.hi, dx[b]);
+        T16_REGION_END();
+    }
+}
+
 __device__ __forceinline__ v4f t16_ld4(const char *img, int byte_off)
 {
     const float4 v = *reinterpret_cast<const float4 *>(img + byte_off);
     return v4f{ v.x, v.y, v.z, v.w };
 }
-__device__ __forceinline__ v4f t16_bias(const char *img, int layer, int b, int q) { return t16_ld4(img, T16_BIAS + (layer * 64 + 16 * b + 4 * q) * 4); }
+__device__ __forceinline__ v4f t16_bias(const char *img, int layer, int b, int q, int bias_base = T16_BIAS)
+{
+    return t16_ld4(img, bias_base + (layer * 64 + 16 * b + 4 * q) * 4);
+}
 
 // ---- staging image of one wave's tile for the sample-reduction products (dW = dY X^T): a matrix of 64 units x 16
 // samples of f16 kept as [sample s][16 chunks of 4 units] with chunk position  chunk ^ g(s),
@@ -186,16 +260,25 @@ struct T16Lane {
     int lo16;   // 16 * lane: this lane's 16 B of an operand sub-image
     int w1;     // staging write: block b of this lane's sample goes to  mat + (w1 ^ (32 b))
     int r1, r2; // staging reads: operand of unit block b', tile pair P, matrix M:  tr(P*2*WAVE + M*MAT + (r1 ^ (32 b'))) ++ tr(... r2 ...)
+    int pos8;   // t16s image: this lane's 8-byte slot of a half sub-image (s16_pos)
+    int trp;    // t16s image: the slot this lane ADDRESSES in a transposed read (s16_lda_T)
 };
-__device__ __forceinline__ T16Lane t16_lane(int lane)
+// t16s image: lane l's two 8-byte halves of a sub-image sit at  s16_pos(l) * 8  and  512 + s16_pos(l) * 8.  The XOR makes
+// both walks of the image conflict-free for 8-byte accesses (32 lanes = 64 banks per pass): the forward's (lanes 0-31 /
+// 32-63 each cover one 256-byte run) and the transposed one (the 32 lanes of a pass address the slots of lanes
+// {4q + r + 16p: q in a pair of groups, r, p = 0..3}, which the XOR spreads over 32 distinct slots mod 32).
+__host__ __device__ constexpr int s16_pos(int l) { return l ^ ((l >> 5) << 3); }
+__device__ __forceinline__ T16Lane t16_lane(int lane, int stage_wave = T16_STAGE_WAVE)
 {
     T16Lane L;
     const int c = lane & 15, q = lane >> 4, a = (lane >> 2) & 3, p = lane & 3;
     L.lo16 = lane * 16;
     L.w1 = c * 128 + ((q ^ t16_g(c)) << 3);
     const int s1 = 8 * (q & 1) + a, s2 = s1 + 4;  // samples this lane addresses in the two transposed reads
-    L.r1 = (q >> 1) * T16_STAGE_WAVE + s1 * 128 + ((p ^ t16_g(s1)) << 3);
-    L.r2 = (q >> 1) * T16_STAGE_WAVE + s2 * 128 + ((p ^ t16_g(s2)) << 3);
+    L.r1 = (q >> 1) * stage_wave + s1 * 128 + ((p ^ t16_g(s1)) << 3);
+    L.r2 = (q >> 1) * stage_wave + s2 * 128 + ((p ^ t16_g(s2)) << 3);
+    L.pos8 = s16_pos(lane) * 8;
+    L.trp = s16_pos(4 * q + a + 16 * p) * 8;   // row a of the group's 4 x 16 block = image lane (m' = 4q + a, q' = p)
     return L;
 }
 __device__ __forceinline__ void t16_stage_put(char *mat, const T16Lane &L, int b, const t16_h4 &v)

@@ -497,7 +497,7 @@ bool fused_geom(int B, int S, int T, BinGeom &g, int arith = SCANERF_ARITH_F32)
     g.NB = T >> g.bucket_log;
     g.W = scanerf_render_backward_grid(B);
     g.per_wg = 0;
-    g.rpg = arith == SCANERF_ARITH_T16 ? 8 : (arith == SCANERF_ARITH_H3 ? 4 : 1);
+    g.rpg = (arith == SCANERF_ARITH_T16 || arith == SCANERF_ARITH_T16S) ? 8 : (arith == SCANERF_ARITH_H3 ? 4 : 1);
     g.capacity = 0;
     g.rec8 = fused_rec8(arith, g.bucket_log) ? 1 : 0;
     return true;
@@ -692,7 +692,7 @@ SCANERF_API int scanerf_render_scatter_plan(const float *rays_o, const float *ra
     f.B = B; f.S = S; f.T = T;
     f.contract_mode = cfg->contract_mode; f.infinity = cfg->infinity;
     // (only the t16 backward leaves masked levels' records out; the other two emit every level)
-    f.skip_levels = (cfg->arith == SCANERF_ARITH_T16 && !getenv("SCANERF_NO_LEVEL_SKIP")) ? pair_masked_levels(cfg->skip_levels) : 0u;
+    f.skip_levels = ((cfg->arith == SCANERF_ARITH_T16 || cfg->arith == SCANERF_ARITH_T16S) && !getenv("SCANERF_NO_LEVEL_SKIP")) ? pair_masked_levels(cfg->skip_levels) : 0u;
     for (int k = 0; k < 3; ++k) {
         f.min_bbox[k] = cfg->min_bbox[k];
         f.bbox_size[k] = cfg->bbox_size[k];

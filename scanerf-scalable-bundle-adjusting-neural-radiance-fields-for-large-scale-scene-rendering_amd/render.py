@@ -17,7 +17,7 @@ FORE, BG = 0, 1
 #           products on one f16 MFMA per term (csrc/render_t16.h).  Calls it cannot serve (no x-stash, pose-gradient
 #           outputs) run the "h3" backward: see backward_arith().
 import os as _os
-_ARITH_CODES = {"f32": _capi.ARITH_F32, "h3": _capi.ARITH_H3, "t16": _capi.ARITH_T16}
+_ARITH_CODES = {"f32": _capi.ARITH_F32, "h3": _capi.ARITH_H3, "t16": _capi.ARITH_T16, "t16s": _capi.ARITH_T16S}
 ARITH_NAMES = tuple(_ARITH_CODES)
 DEFAULT_ARITH = _os.environ.get("SCANERF_ARITH", "t16")
 ARITH = _ARITH_CODES[DEFAULT_ARITH]
@@ -35,7 +35,7 @@ def arith_name():
 def backward_arith(have_xstash=True, pose_grads=False):
     """The arithmetic code one training step's scatter_plan / render_backward / scatter_accumulate must agree on
     (t16 needs the forward's x-stash; it produces the pose-gradient sums as well)."""
-    if ARITH == _capi.ARITH_T16 and not have_xstash:
+    if ARITH in _capi.T16_FAMILY and not have_xstash:
         return _capi.ARITH_H3
     return ARITH
 
@@ -125,7 +125,8 @@ def render_forward(rays_o, rays_d, z_vals, dists, features, resolutions, packed,
             if not need or not forward_plan_supported(B, S, T):
                 raise RuntimeError(f"scanerf: render_forward(plan=True) does not support B={B} S={S} T={T}")
             ws = _capi.workspace(z_vals.device, need) if plan_workspace is None else plan_workspace
-        cfg = _cfg(min_bbox, bbox_size, contract_mode, infinity, _capi.ARITH_T16, getattr(packed, "skip_levels", 0))
+        cfg = _cfg(min_bbox, bbox_size, contract_mode, infinity, ARITH if ARITH in _capi.T16_FAMILY else _capi.ARITH_T16,
+                   getattr(packed, "skip_levels", 0))
         tail = tail[:5] + (dev_ptr(jstash, JSTASH_DTYPE, "jstash", allow_none=True),) + tail[5:]
         check(lib().scanerf_render_forward_packed_plan(*args, ctypes.byref(cfg), *tail,
                                                        ctypes.c_void_p(ws.data_ptr() if ws is not None else None),

@@ -417,7 +417,7 @@ def train_step_fused(model, dec_opt, rays_o, rays_d, target, S, global_step, tab
             # t16 backward on the same grid as the forward: the forward kernel counts the scatter records itself (its hash
             # indices are the plan's) -- no separate plan launch (0.25 ms at configs[1])
             jstash = None
-            if (fused and ws is None and bwd_arith == render._capi.ARITH_T16 and render.forward_plan_supported(B, S, T)
+            if (fused and ws is None and bwd_arith in render._capi.T16_FAMILY and render.forward_plan_supported(B, S, T)
                     and not os.environ.get("SCANERF_NO_FORWARD_PLAN")):
                 # pose refinement: the forward also stashes the encoder's position Jacobians (it has the corner values in
                 # registers), so that the backward can chain the feature gradients to the rays without a second pass over the table
@@ -500,7 +500,7 @@ def fgbg_gradients(model, rays_o, rays_d, target, S_fg, S_bg, global_step, inval
     B = rays_o.shape[0]
     dev = model.device
     T = model.features.shape[1]
-    if pose_grads and render.backward_arith(True, True) != render._capi.ARITH_T16:
+    if pose_grads and render.backward_arith(True, True) not in render._capi.T16_FAMILY:
         raise RuntimeError("scanerf: fgbg pose gradients need the t16 backward (render.set_arith)")
     g_o = g_d = None
     with torch.no_grad():
@@ -620,7 +620,7 @@ def train_step_fgbg(model, dec_opt, rays_o, rays_d, target, S_fg, S_bg, global_s
             tile_T = torch.empty((B, render.tile_T_columns(S)), device=dev)
             xs = torch.empty((B * S, 32), device=dev)
             # (the forward launch reserves the backward's record ranges as well where the two kernels share a grid)
-            in_fwd = (render.backward_arith(True, False) == render._capi.ARITH_T16 and render.forward_plan_supported(B, S, T)
+            in_fwd = (render.backward_arith(True, False) in render._capi.T16_FAMILY and render.forward_plan_supported(B, S, T)
                       and not os.environ.get("SCANERF_NO_FORWARD_PLAN"))
             js = torch.empty(render.jstash_shape(B, S), dtype=render.JSTASH_DTYPE, device=dev) if pose_grads else None
             with _sec(timer, "render_forward", B * (24 + 20 + S * 16 * 8 * 2 * table.element_size()), B * S * MLP_FLOPS_PER_SAMPLE):

@@ -48,7 +48,7 @@ def test_forward_is_bit_reproducible(dt, S, bg):
             assert nbad == 0, f"launch {it}: {nbad} of {B} rays differ from launch 0 (table {dt}, S={S}, bg={bg})"
 
 
-@pytest.mark.parametrize("arith", ["t16", "h3"])
+@pytest.mark.parametrize("arith", ["t16", "h3", "t16s"])
 def test_backward_is_bit_reproducible(arith):
     from scanerf_amd import render
     render.set_arith(arith)
