@@ -236,18 +236,15 @@ __device__ __forceinline__ void wgrad(v4f *acc, float &rowsum, const char *stage
         if (ROWSUM) rowsum = t16_sum8(a, rowsum);
         if constexpr (SPLIT) {
             const t16_h8 alo = t16_stage_get(pm + kLo, L, yb);
-            t16_h8 blo[NX];
-#pragma unroll
-            for (int i = 0; i < NX; ++i) blo[i] = t16_stage_get(pm + x_mat_off + kLo, L, xb0 + i * XSTRIDE);
             if (ROWSUM) rowsum = t16_sum8(alo, rowsum);
-            T16_REGION_BEGIN();
 #pragma unroll
-            for (int i = 0; i < NX; ++i) acc[i] = t16_mfma(alo, b[i], acc[i]);
-#pragma unroll
-            for (int i = 0; i < NX; ++i) acc[i] = t16_mfma(a, blo[i], acc[i]);
-#pragma unroll
-            for (int i = 0; i < NX; ++i) acc[i] = t16_mfma(a, b[i], acc[i]);
-            T16_REGION_END();
+            for (int i = 0; i < NX; ++i) {
+                const t16_h8 blo = t16_stage_get(pm + x_mat_off + kLo, L, xb0 + i * XSTRIDE);
+                acc[i] = t16_mfma(alo, b[i], acc[i]);
+                acc[i] = t16_mfma(a, blo, acc[i]);
+                acc[i] = t16_mfma(a, b[i], acc[i]);
+            }
+            __builtin_amdgcn_sched_barrier(0);   // (bounds the operands in flight: the pairs' reads are not hoisted over each other)
         } else {
             T16_REGION_BEGIN();
 #pragma unroll
@@ -264,13 +261,27 @@ __device__ __forceinline__ void stage_put2(char *mat, const T16Lane &L, int b, c
     t16_stage_put(mat + 2 * T16_STAGE_MAT, L, b, __builtin_shufflevector(v.lo, v.lo, 0, 1, 2, 3));
     t16_stage_put(mat + 2 * T16_STAGE_MAT, L, b + 1, __builtin_shufflevector(v.lo, v.lo, 4, 5, 6, 7));
 }
-// Gaussian activation of a block from its pre-activation, and G'(u) = -100 u G(u) in f32
-__device__ __forceinline__ void act_and_deriv(const v4f &u, v4f &a, v4f &d)
+// G'(u) = -100 u G(u) of a block, f32, from its pre-activation (the activation is formed again: 4 exponentials against 4 more
+// registers held across the weight-gradient products)
+__device__ __forceinline__ v4f gauss_deriv(const v4f &u)
+{
+    v4f d;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) d[g] = -100.0f * u[g] * gauss_fast(u[g]);
+    return d;
+}
+// the Gaussian activations of a layer (64 units from their pre-activations), split and staged as blocks 0..3 of X and X lo
+__device__ __forceinline__ void stage_act(char *stX, const T16Lane &L, const v4f u[4])
 {
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        a[g] = gauss_fast(u[g]);
-        d[g] = -100.0f * u[g] * a[g];
+    for (int t = 0; t < 2; ++t) {
+        v4f a0, a1;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            a0[g] = gauss_fast(u[2 * t][g]);
+            a1[g] = gauss_fast(u[2 * t + 1][g]);
+        }
+        stage_put2(stX, L, 2 * t, t16_split(a0, a1));
     }
 }
 
@@ -494,14 +505,14 @@ __global__ void __launch_bounds__(kThreads, 2) k_render_bwd_t16(BwdArgs a)
                 T16HL HB[2];
                 {
                     const T16HL xB = t16_split(xa, xb);
+                    v4f act[4];   // (u0 is formed again in the backward: not kept)
 #pragma unroll
-                    for (int b = 0; b < 4; ++b) ku0[b] = t16_bias(lds, 0, b, q, LD::kBias);
-                    s16_layer<4, 1>(ku0, lds, T16_L0, L.pos8, &xB);
-                    v4f act[4];
+                    for (int b = 0; b < 4; ++b) act[b] = t16_bias(lds, 0, b, q, LD::kBias);
+                    s16_layer<4, 1>(act, lds, T16_L0, L.pos8, &xB);
 #pragma unroll
                     for (int b = 0; b < 4; ++b)
 #pragma unroll
-                        for (int g = 0; g < 4; ++g) act[b][g] = gauss_fast(ku0[b][g]);
+                        for (int g = 0; g < 4; ++g) act[b][g] = gauss_fast(act[b][g]);
                     const T16HL aB[2] = { t16_split(act[0], act[1]), t16_split(act[2], act[3]) };
 #pragma unroll
                     for (int b = 0; b < 4; ++b) khh[b] = t16_bias(lds, 1, b, q, LD::kBias);
@@ -509,7 +520,6 @@ __global__ void __launch_bounds__(kThreads, 2) k_render_bwd_t16(BwdArgs a)
                     HB[0] = t16_split(khh[0], khh[1]);
                     HB[1] = t16_split(khh[2], khh[3]);
                 }
-                emit_level(ptile, 0, pdx0, pdx1, ppe);
                 {   // heads on H[:32]
                     v4f hd[2] = { t16_ld4(lds, LD::kBias + 256 * 4), t16_ld4(lds, LD::kBias + 260 * 4) };
                     s16_layer<2, 1>(hd, lds, T16_HEAD, L.pos8, &HB[0]);
@@ -543,7 +553,6 @@ __global__ void __launch_bounds__(kThreads, 2) k_render_bwd_t16(BwdArgs a)
                     cB[0] = t16_split(act[0], act[1]);
                     cB[1] = t16_split(act[2], act[3]);
                 }
-                emit_level(ptile, 1, pdx0, pdx1, ppe);
                 {
 #pragma unroll
                     for (int b = 0; b < 4; ++b) kv1[b] = t16_bias(lds, 3, b, q, LD::kBias);
@@ -556,7 +565,6 @@ __global__ void __launch_bounds__(kThreads, 2) k_render_bwd_t16(BwdArgs a)
                     cB[0] = t16_split(act[0], act[1]);
                     cB[1] = t16_split(act[2], act[3]);
                 }
-                emit_level(ptile, 2, pdx0, pdx1, ppe);
                 {
                     v4f r[1] = { t16_ld4(lds, LD::kBias + 264 * 4) };
                     s16_layer<1, 2>(r, lds, T16_D2, L.pos8, cB);
@@ -642,7 +650,7 @@ __global__ void __launch_bounds__(kThreads, 2) k_render_bwd_t16(BwdArgs a)
                 }
             }
 
-            emit_level(ptile, 3, pdx0, pdx1, ppe);
+            if constexpr (!SPLIT) emit_level(ptile, 3, pdx0, pdx1, ppe);
 
             // ================= compositing: recompute and adjoint (16-lane scans, identical in the 4 lane groups) =================
             const float ex = live ? expf(-sigma * delta) : 1.0f;  // 1 - alpha
@@ -746,7 +754,6 @@ __global__ void __launch_bounds__(kThreads, 2) k_render_bwd_t16(BwdArgs a)
                 L = fresh_lane(L);
                 // one 16-row block: rows 0-3 sigma, dif; 4-6 tint; 8-10 rgb  (lane group q holds rows 4q .. 4q+3)
                 T16HL narS;   // B operand of the transposed products (second block of the k-step = zeros)
-                v4f dgq[4];   // G' of the Gaussian layer the current step goes through, f32
                 {
                     v4f nar;
 #pragma unroll
@@ -758,11 +765,7 @@ __global__ void __launch_bounds__(kThreads, 2) k_render_bwd_t16(BwdArgs a)
                     t16_stage_put(stY, L, 0, lo4(narS.hi));
                     t16_stage_put(stY + kLo, L, 0, lo4(narS.lo));
                     stage_put2(stY, L, 2, t16_split(khh[0], khh[1]));   // X operand of the heads' weight gradient: H[:32] in blocks 2, 3 of Y
-                    v4f c1[4];
-#pragma unroll
-                    for (int b = 0; b < 4; ++b) act_and_deriv(kv1[b], c1[b], dgq[b]);
-                    stage_put2(stX, L, 0, t16_split(c1[0], c1[1]));     // X operand of the rgb layer's weight gradient
-                    stage_put2(stX, L, 2, t16_split(c1[2], c1[3]));
+                    stage_act(stX, L, kv1);     // X operand of the rgb layer's weight gradient: c1 = G(v1)
                 }
                 STEP_BARRIER();  // ---- A1
                 if (wv == 0) wgrad<1, true, 1, true>(gW_nar, gB_nar, stage, L, 0, 0, 2);          // heads: x = H[0:16]
@@ -775,22 +778,16 @@ __global__ void __launch_bounds__(kThreads, 2) k_render_bwd_t16(BwdArgs a)
                     zero4(dc);
                     s16_chain_narrow<4>(dc, lds, S16T_D2, L.lo16, narS);
 #pragma unroll
-                    for (int b = 0; b < 4; ++b) dc[b] *= dgq[b];
+                    for (int b = 0; b < 4; ++b) dc[b] *= gauss_deriv(kv1[b]);
                     dyS[0] = t16_split(dc[0], dc[1]);
                     dyS[1] = t16_split(dc[2], dc[3]);
                 }
                 STEP_BARRIER();  // ---- B1
                 // ================= Directional_MLP.mlp.2 (64 -> 64) =================
                 L = fresh_lane(L);
-                {
-                    v4f c0[4];
-#pragma unroll
-                    for (int b = 0; b < 4; ++b) act_and_deriv(kv0[b], c0[b], dgq[b]);
-                    stage_put2(stY, L, 0, dyS[0]);
-                    stage_put2(stY, L, 2, dyS[1]);
-                    stage_put2(stX, L, 0, t16_split(c0[0], c0[1]));
-                    stage_put2(stX, L, 2, t16_split(c0[2], c0[3]));
-                }
+                stage_put2(stY, L, 0, dyS[0]);
+                stage_put2(stY, L, 2, dyS[1]);
+                stage_act(stX, L, kv0);
                 STEP_BARRIER();  // ---- A2
                 if (cb == 0) wgrad<2, true, 1, true>(gW_D1, gB_D1, stage, L, rb, T16_STAGE_MAT, 0);
                 else { float dummy = 0.0f; wgrad<2, false, 1, true>(gW_D1, dummy, stage, L, rb, T16_STAGE_MAT, 2); }
@@ -799,7 +796,7 @@ __global__ void __launch_bounds__(kThreads, 2) k_render_bwd_t16(BwdArgs a)
                     zero4(dc);
                     s16_chain<4, 2, 2>(dc, lds, T16_D1, L.trp, dyS);
 #pragma unroll
-                    for (int b = 0; b < 4; ++b) dc[b] *= dgq[b];   // dv0
+                    for (int b = 0; b < 4; ++b) dc[b] *= gauss_deriv(kv0[b]);   // dv0
                 if (POSE) {  // 16 values x 16 samples -> lane c keeps the tile's sum of value c (= block c >> 2, register c & 3)
                     float v[16];
 #pragma unroll
@@ -844,15 +841,15 @@ __global__ void __launch_bounds__(kThreads, 2) k_render_bwd_t16(BwdArgs a)
                 STEP_BARRIER();  // ---- B3
                 // ================= Spatial_MLP.mlp.2 (64 -> 64, linear) =================
                 L = fresh_lane(L);
-                {
-                    v4f a0[4];
+                stage_put2(stY, L, 0, dyS[0]);
+                stage_put2(stY, L, 2, dyS[1]);
+                {   // u0 = W0 x + b0 again (12 MFMAs against 16 registers held through the whole tile)
+                    const T16HL xB = t16_split(xa, xb);
 #pragma unroll
-                    for (int b = 0; b < 4; ++b) act_and_deriv(ku0[b], a0[b], dgq[b]);
-                    stage_put2(stY, L, 0, dyS[0]);
-                    stage_put2(stY, L, 2, dyS[1]);
-                    stage_put2(stX, L, 0, t16_split(a0[0], a0[1]));
-                    stage_put2(stX, L, 2, t16_split(a0[2], a0[3]));
+                    for (int b = 0; b < 4; ++b) ku0[b] = t16_bias(lds, 0, b, q, LD::kBias);
+                    s16_layer<4, 1>(ku0, lds, T16_L0, L.pos8, &xB);
                 }
+                stage_act(stX, L, ku0);
                 STEP_BARRIER();  // ---- A4
                 if (cb == 0) wgrad<2, true, 1, true>(gW_L1, gB_L1, stage, L, rb, T16_STAGE_MAT, 0);
                 else { float dummy = 0.0f; wgrad<2, false, 1, true>(gW_L1, dummy, stage, L, rb, T16_STAGE_MAT, 2); }
@@ -861,7 +858,7 @@ __global__ void __launch_bounds__(kThreads, 2) k_render_bwd_t16(BwdArgs a)
                     zero4(dc);
                     s16_chain<4, 2, 2>(dc, lds, T16_L1, L.trp, dyS);
 #pragma unroll
-                    for (int b = 0; b < 4; ++b) dc[b] *= dgq[b];   // du0
+                    for (int b = 0; b < 4; ++b) dc[b] *= gauss_deriv(ku0[b]);   // du0
                     dyS[0] = t16_split(dc[0], dc[1]);
                     dyS[1] = t16_split(dc[2], dc[3]);
                 }
@@ -1059,14 +1056,25 @@ __global__ void __launch_bounds__(kThreads, 2) k_render_bwd_t16(BwdArgs a)
             // (no barrier here: the next tile's staging writes come after its barrier S)
 
             if (tile > 0) nxt = load_tile(tile - 1);   // before this tile's record stores (see load_tile)
-            // ================= feature gradients: emitted during the next tile (emit_level) =================
-            pdx0 = dx[0];
-            pdx1 = dx[1];
-            ptile = tile;
-            if (a.recs) contract_point(a.f, o, d, z, ppe);
-        }
+            if constexpr (SPLIT) {
+                // ================= feature gradients: emitted here (the split kernel has no registers to carry them into the
+                // next tile: 11 held across its forward recompute cost more in spills than the overlap gains)
+                float pe[3] = { 0, 0, 0 };
+                if (a.recs) contract_point(a.f, o, d, z, pe);
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj) emit_level(ptile, jj, pdx0, pdx1, ppe);   // the ray's first tile
+                for (int jj = 0; jj < 4; ++jj) emit_level(tile, jj, dx[0], dx[1], pe);
+            } else {
+                // ================= feature gradients: emitted during the next tile (emit_level) =================
+                pdx0 = dx[0];
+                pdx1 = dx[1];
+                ptile = tile;
+                if (a.recs) contract_point(a.f, o, d, z, ppe);
+            }
+        }
+        if constexpr (!SPLIT) {
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) emit_level(ptile, jj, pdx0, pdx1, ppe);   // the ray's first tile
+        }
         if (POSE && active) {  // the ray's pose-gradient sums
             const int ln = fresh(lane), c = ln & 15, q = ln >> 4;
 #pragma unroll

@@ -206,11 +206,10 @@ __device__ __forceinline__ void s16_chain(v4f dx[NBI], const char *img, int base
             const char *a1 = a0 + KSIN * T16_PAIR;
             const t16_h8 ahi = __builtin_shufflevector(t16_tr4(a0), t16_tr4(a1), 0, 1, 2, 3, 4, 5, 6, 7);
             const t16_h8 alo = __builtin_shufflevector(t16_tr4(a0 + T16_SUB), t16_tr4(a1 + T16_SUB), 0, 1, 2, 3, 4, 5, 6, 7);
-            T16_REGION_BEGIN();
             dx[bi] = t16_mfma(alo, dY[t].hi, dx[bi]);
             dx[bi] = t16_mfma(ahi, dY[t].lo, dx[bi]);
             dx[bi] = t16_mfma(ahi, dY[t].hi, dx[bi]);
-            T16_REGION_END();
+            if (bi & 1) __builtin_amdgcn_sched_barrier(0);   // (two input blocks' operands in flight at a time)
         }
 }
 // ... of a narrow layer (heads, rgb): its own transposed pairs (hi, lo), lane l's 16 B at 16 l, one k-step
