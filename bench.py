@@ -1,7 +1,11 @@
 #!/usr/bin/env python3
 """bench.py -- training rays/s of the per-tile volume-rendering hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--path fused|ops] [--rays B]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--path fused|ops] [--rays B] [--arith f32|h3|t16|t16s]
+
+`value` / `ms_per_step` are measured under the fastest F32-EQUIVALENT decoder arithmetic (render.FP32_EQUIV_ARITH; gradient
+error against the oracle ~5e-6 relative L2, reported live as `arith_evidence`); the reduced-precision "t16" step and the
+other arithmetics are timed beside it under their own keys.
 
 One "step" = one full training iteration of one tile on a synthetic ray batch
 (BASELINE.json configs[1]: L=16, T=2^19 fp32 table, 2-hidden x 64 decoder, 65 536 rays x
@@ -59,6 +63,10 @@ def parse():
     ap.add_argument("--scatter", default="auto", choices=["auto", "fused", "dfeat"],
                     help="table-gradient records emitted by the backward kernel (fused, default) or by the stand-alone "
                          "binned scatter from a level-major dfeat (tuning comparison)")
+    ap.add_argument("--arith", default=None, choices=["f32", "h3", "t16", "t16s"],
+                    help="decoder arithmetic of the timed step (default: the fastest f32-equivalent one, render.FP32_EQUIV_ARITH; "
+                         "\"t16\" is the reduced-precision option and is reported under its own name, never as the metric)")
+    ap.add_argument("--arith-side-off", action="store_true", help="skip the side timings of the other arithmetics (profiling passes)")
     ap.add_argument("--pose-grads", action="store_true",
                     help="with --workload configs1 / configs1-fgbg: the iteration also returns dL/d(rays_o), dL/d(rays_d) (the "
                          "reference's default: CAMOPT.ENABLE)")
@@ -76,6 +84,11 @@ def launch_ranks(args):
     that has initialised the GPU must not start others that share it by exec; children are plain subprocesses)."""
     import socket
     import subprocess
+    if any(k.startswith(("ROCPROFILER_", "ROCPROF_")) for k in os.environ) or "rocprofiler" in os.environ.get("LD_PRELOAD", ""):
+        # under rocprofv3 the preloaded profiler has initialised the GPU in THIS process already: starting ranks from it is the
+        # exec-after-GPU-init the pool forbids.  Profile one rank (--gpus 1), or profile under torchrun's own ranks.
+        print("bench.py: refusing to launch ranks from a profiled process (profile with --gpus 1)", file=sys.stderr)
+        sys.exit(2)
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
@@ -100,35 +113,76 @@ def launch_ranks(args):
 
 
 def dry_run_cpu(args, world, rank):
-    """The launcher's and the consensus exchange's rehearsal on gloo: same process-group bring-up, barrier, MAX-reduce of
-    the elapsed time and all-reduce consensus as the real run, CPU tensors, no kernels."""
+    """The launcher's and BOTH exchanges' rehearsal on gloo: same process-group bring-up, barrier and MAX-reduce of the elapsed
+    time as the real run, CPU tensors, no kernels.  What runs is the real multi-tile driver (admm.AdmmDriver: consensus
+    all-reduce + shared-depth MIN exchange once per stretch on every rank) over configs[4]'s tile -> rank map with UNEQUAL tile
+    counts (4 * world + 1 tiles round-robin, admm_trainer.py:74-83: rank 0 owns one tile more), with stand-in tile trainers."""
+    import types
+
+    from scanerf_amd import admm
     from scanerf_amd import consensus as cons
+    from scanerf_amd import occlusion
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo")
+    n_tiles = 4 * world + 1
     n_cam_per, overlap = 120, 24
-    n_cam = (n_cam_per - overlap) * world + overlap
-    cam_idx = torch.arange(n_cam_per) + rank * (n_cam_per - overlap)
-    admm = cons.ConsensusState(n_cam, cam_idx, "cpu")
-    se3 = torch.randn(n_cam_per, 6) * 1e-3
+    n_cam = (n_cam_per - overlap) * n_tiles + overlap
+    mine = admm.tiles_of_rank(n_tiles, rank, world)
+
+    class StandIn:   # a TileTrainer without kernels: the interface AdmmDriver drives
+        def __init__(self, t):
+            g = torch.Generator().manual_seed(t)
+            idx = torch.arange(n_cam_per) + t * (n_cam_per - overlap)
+            self.tile, self.cam_idx = t, idx
+            self.cameras = types.SimpleNamespace(se3_refine=torch.nn.Parameter(torch.randn(n_cam_per, 6, generator=g) * 1e-3))
+            self.consensus = cons.ConsensusState(n_cam, idx, "cpu")
+            self.admm, self.steps = False, 0
+
+        def maybe_prune(self):
+            pass
+
+        def train_one_step(self):
+            self.steps += 1
+
+    trainers = [StandIn(t) for t in mine]
+    depth = torch.full((n_cam, 4, 6), occlusion.NO_DEPTH)   # half-resolution depth maps, one publisher per camera
+
+    def publish(tr):   # every tile publishes the maps of the cameras it owns outright (the first n_cam_per - overlap)
+        cams = tr.cam_idx[: n_cam_per - overlap].tolist()
+        for c in cams:
+            depth[c] = float(tr.tile + 1)
+        return cams
+
+    syn = max(1, min(SYN_ITERS, args.steps))
+    drv = admm.AdmmDriver(trainers, total_step=args.steps, syn_iters=syn, depth_hooks=(publish, lambda tr: None, depth))
     if world > 1:
         dist.barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        admm.exchange(se3)
+    hist = drv.run()
     if world > 1:
         dist.barrier()
     t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    # every rank must have received every tile's maps, and stepped its own tiles only
+    owned = torch.zeros(n_cam, dtype=torch.bool)
+    for tt in range(n_tiles):
+        owned[torch.arange(n_cam_per - overlap) + tt * (n_cam_per - overlap)] = True
+    ok = bool((depth[owned] != occlusion.NO_DEPTH).all()) and all(tr.steps == sum(drv.stretches) for tr in trainers)
     if rank == 0:
         print(json.dumps({"metric": "training rays/s per GPU (128 samples, L=16 hash)", "value": 0.0, "unit": "rays/s",
                           "n_gpus": world, "rccl_world_size": dist.get_world_size() if world > 1 else 1, "dry_run": True,
-                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": float(t.item()) / args.steps * 1e3,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": float(t.item()) / sum(drv.stretches) * 1e3,
                           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "none (dry run)",
-                          "data": "synthetic", "config": {"workload": "launcher + gloo consensus rehearsal, no kernels"}}))
+                          "data": "synthetic",
+                          "config": {"workload": "launcher + gloo rehearsal of the multi-tile driver: consensus all-reduce and shared-depth MIN "
+                                                 "exchange per stretch, no kernels",
+                                     "tiles": n_tiles, "tiles_of_rank0": len(mine), "exchanges": len(hist), "exchange_ok": ok}}))
     if world > 1:
         dist.destroy_process_group()
+    if not ok:
+        sys.exit(3)
 
 
 def cpu_baseline(samples):
@@ -143,7 +197,7 @@ def cpu_baseline(samples):
     os.environ["OMP_NUM_THREADS"] = str(cores)  # the C oracle's OpenMP loops (set before it is loaded)
     torch.set_num_threads(cores)
     rng = np.random.default_rng(0)
-    B = 256
+    B = 2048   # 1/32 of the step's 65 536 rays, same samples / table / decoder: ~1 s of host work per iteration
     tile = O.Tile([-4, -4, -4], [8, 8, 8], log2_T=19)
     o = rng.uniform(-4, 4, (B, 3)).astype(np.float32)
     d = rng.normal(size=(B, 3)).astype(np.float32)
@@ -189,7 +243,8 @@ def cpu_baseline(samples):
     return {"value": B / dt, "unit": "rays/s", "cores": cores, "kind": "port", "forward_only_rays_per_s": B / dt_fwd,
             "psnr_vs_oracle_db": psnr_vs_oracle(samples),
             "sample": f"{WARM} warm-up + {TIMED} timed training iterations (forward + backward + sparse Adam; forward-only timed the "
-                      f"same way) of {B} rays x {samples} samples (same tile config, T=2^19), oracle/ on {cores} host threads"}
+                      f"same way) of {B} rays x {samples} samples = 1/{65536 // B} of the step's rays (same tile config, T=2^19), "
+                      f"oracle/ on {cores} host threads; a reported baseline, not a target"}
 
 
 def psnr_vs_oracle(samples, B=2048, log2_T=15):
@@ -277,6 +332,122 @@ def bench_render(args, world, rank, dev):
         dist.destroy_process_group()
 
 
+# rocprof kernel names of the timer's sections, per arithmetic (profiles/r03_kernel_stats.txt lists them with their durations)
+KERNEL_OF = {
+    "render_forward": lambda ar: "k_render_fwd<0>" if ar == "f32" else ("k_render_fwd_h3<0, true, false>" if ar in ("t16", "t16s") else "k_render_fwd_h3<0, false, false>"),
+    "render_backward": lambda ar: {"f32": "k_render_bwd<0>", "h3": "k_render_bwd_h3<0>", "t16": "k_render_bwd_t16<0, true, false, false>",
+                                   "t16s": "k_render_bwd_t16<0, false, false, true>"}[ar],
+    "table_grad_accumulate_adam": lambda ar: "k_bin_accumulate<512, 32, true, true>" if ar == "t16" else "k_bin_accumulate<256, 32, true, true>",
+}
+
+
+def roofline(timer, arith, args, B, S, valid_frac, fgbg, ms_per_step):
+    """`roofline` of the JSON line.  For every kernel of the step: the live HIP-event duration, SURVEY.md 8(d)'s algorithmic
+    bytes (strictly: bytes_fwd = 24 + 20 + S*L*8*F*4 per ray for the forward; for the backward + accumulate the reference
+    ALGORITHM's S*L*(8 + 64 + 16*8) = 409 600 B per ray -- grad-in read, feature re-gather, 16 RMW atomics -- which this design
+    does not perform: it is reported because 8(d) defines it, next to what the counters saw), and from the committed rocprofv3
+    passes (profiles/r03_pmc.json: FETCH_SIZE + WRITE_SIZE per launch, matrix-pipe busy cycles, wait cycles) the counter-based
+    fractions.  The top-level fields describe the dominant kernel."""
+    rays = B * valid_frac
+    secs = timer.summary()
+    pmc = {}
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc.json")))
+    except (OSError, ValueError):
+        pass
+    same_cfg = args.workload == "configs1" and B == 65536 and S == 128 and args.log2_T == 19 and not args.pose_grads
+    alg = {"render_forward": rays * BYTES_FWD_PER_RAY * S / 128.0,
+           "render_backward": rays * BYTES_BWD_PER_RAY * S / 128.0}
+    kernels = {}
+    for name, ms in secs.items():
+        k = {"avg_launch_ms": ms}
+        if name in KERNEL_OF:
+            k["kernel"] = KERNEL_OF[name](arith)
+        if name in alg:
+            k["algorithmic_bytes"] = alg[name]
+            k["achieved_GBps"] = alg[name] / (ms * 1e-3) / 1e9
+            k["frac"] = k["achieved_GBps"] / HBM_PEAK_GBS
+        c = pmc.get("kernels", {}).get(k.get("kernel", ""), None) if same_cfg else None
+        if c:
+            k["traffic"] = c["fetch_bytes"] + c["write_bytes"]
+            k["frac_counter"] = k["traffic"] / (ms * 1e-3) / (HBM_PEAK_GBS * 1e9)
+            k["rocprof_avg_us"] = c.get("avg_us")
+            for key in ("mfma_busy", "wait_any", "valu_active", "lds_bank_conflict"):
+                if key in c:
+                    k[key] = c[key]
+        kernels[name] = k
+    name = max((n for n in kernels if "algorithmic_bytes" in kernels[n]), key=lambda n: kernels[n]["avg_launch_ms"])
+    d = kernels[name]
+    roof = {"bound": "hbm", "achieved": d["achieved_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": d["frac"],
+            "traffic": d.get("traffic"), "kernel": d.get("kernel", name), "section": name, "avg_launch_ms": d["avg_launch_ms"],
+            "algorithmic_bytes_per_launch": d["algorithmic_bytes"],
+            "algorithmic_bytes_is": ("SURVEY.md 8(d) bytes_bwd: the REFERENCE algorithm's backward traffic (re-gather + 16 RMW atomics per "
+                                     "(sample, level)); this design replaces it by the x-stash + records, see traffic / frac_counter")
+            if name == "render_backward" else "SURVEY.md 8(d) bytes_fwd",
+            "frac_counter": d.get("frac_counter"), "mfma_busy": d.get("mfma_busy"), "wait_any": d.get("wait_any"),
+            "counters_source": "profiles/r03_pmc.json (rocprofv3 --pmc passes of this command; tools/profile_r03.sh)" if "traffic" in d else None,
+            "kernels": kernels}
+    if S == 128:
+        whole = rays * (BYTES_FWD_PER_RAY + BYTES_BWD_PER_RAY) * (2 if fgbg else 1)
+        roof["whole_step"] = {"bytes": whole, "ms": ms_per_step, "frac": whole / (ms_per_step * 1e-3) / (HBM_PEAK_GBS * 1e9),
+                              "note": "8(d) bytes of forward + backward per ray / step time; the backward part is the reference algorithm's"}
+    return roof
+
+
+def arith_evidence(samples, B=512, log2_T=14):
+    """Why the headline's arithmetic counts as f32-equivalent: on B rays the fused step's table and decoder gradients under every
+    arithmetic against autograd through the oracle (torch f32 on the CPU), as relative L2 errors; and the render's outputs against
+    the oracle's.  Part of the cpu_baseline leg (rank 0, N = 1): the oracle is the checker here."""
+    import numpy as np
+
+    import scanerf_amd  # noqa: F401
+    from oracle import oracle as O
+    from scanerf_amd import network, render
+    dev = "cuda:0"
+    rng = np.random.default_rng(3)
+    T = 2 ** log2_T
+    o = rng.uniform(-3.5, 3.5, (B, 3)).astype(np.float32)
+    d = rng.normal(size=(B, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    z = np.sort(rng.uniform(0.2, 3.0, (B, samples)).astype(np.float32), axis=1)
+    dist_ = np.concatenate([z[:, 1:] - z[:, :-1], np.full((B, 1), 0.03, np.float32)], 1)
+    feat = (rng.normal(size=(16, T, 2)) * 0.4).astype(np.float32)
+    sd = {k: v.clone().requires_grad_(True) for k, v in O.init_mlp(seed=7, bias_scale=0.05).items()}
+    res = O.level_resolutions(torch.tensor([32, 32, 32]), torch.tensor([2048, 2048, 2048]))
+    mn, sz = torch.tensor([-8.0, -8.0, -8.0]), torch.tensor([16.0, 16.0, 16.0])
+    F = torch.from_numpy(feat).requires_grad_(True)
+    step = 20000
+    ref = O.render_batch_rays(torch.from_numpy(o), torch.from_numpy(d), torch.from_numpy(z), torch.from_numpy(dist_), F, res, sd, O.TRAIN,
+                              lambda x: O.contract_fore(x, mn, sz), step)
+    tgt = torch.from_numpy(rng.random((B, 3)).astype(np.float32))
+    (torch.nn.functional.mse_loss(ref["rgb"], tgt) + 0.01 * ref["l2_reg_specular"]).backward()
+    gb_ref, gF_ref = O.pack_blob({k: v.grad for k, v in sd.items()}).numpy(), F.grad.numpy()
+    t = lambda a: torch.as_tensor(a).to(dev).contiguous()
+    blob = O.pack_blob({k: v.detach() for k, v in sd.items()}).to(dev)
+    wf = network.weight_feature(step, dev)
+    pk = render.PackedDecoder(dev).pack(blob, wf)
+    box = (mn.tolist(), sz.tolist(), render.FORE, False)
+    pts = O.contract_fore((torch.from_numpy(o)[:, None, :] + torch.from_numpy(z)[..., None] * torch.from_numpy(d)[:, None, :]).reshape(-1, 3), mn, sz).numpy()
+    out = {}
+    keep = render.ARITH
+    try:
+        for ar in render.ARITH_NAMES:
+            render.set_arith(ar)
+            tile_T = torch.empty(B, render.tile_T_columns(samples), device=dev)
+            xs = torch.empty(B * samples, 32, device=dev)
+            o_r, _ = render.render_forward(t(o), t(d), t(z), t(dist_), t(feat), t(res.numpy()), pk, *box, tile_T=tile_T, xstash=xs)
+            loss, gout = render.photometric_loss_grad(o_r, t(tgt.numpy()), None, 0.01)
+            dfeat, gblob = render.render_backward(t(o), t(d), t(z), t(dist_), t(feat), t(res.numpy()), pk, wf, *box, o_r, tile_T, gout, xstash=xs)
+            gF = render.scatter_table_grad(t(pts), dfeat, torch.zeros(16, T, 2, device=dev), t(res.numpy())).cpu().numpy()
+            l2 = lambda a, b: float(np.linalg.norm(a - b) / np.linalg.norm(b))
+            out[ar] = {"table_grad_rel_l2_vs_oracle": l2(gF, gF_ref), "decoder_grad_rel_l2_vs_oracle": l2(gblob.cpu().numpy(), gb_ref),
+                       "rgb_max_abs_err_vs_oracle": float((o_r[:, 0:3].cpu() - ref["rgb"].detach()).abs().max())}
+    finally:
+        render.ARITH = keep
+    out["sample"] = f"{B} rays x {samples} samples, T=2^{log2_T}, oracle = torch f32 autograd on the host (its own rounding ~1e-6)"
+    return out
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "RANK" not in os.environ:
@@ -332,8 +503,16 @@ def main():
                                                                                     pose_grads=args.pose_grads)
     if path == "fused" and args.scatter != "auto":
         import functools
-        step_fn = functools.partial(tm.train_step_fused, fused_scatter=args.scatter == "fused")
+        if fgbg:
+            print("bench.py: --scatter applies to the foreground-only step (configs1 / configs2), not to configs1-fgbg", file=sys.stderr)
+            sys.exit(2)
+        step_fn = functools.partial(tm.train_step_fused, fused_scatter=args.scatter == "fused", pose_grads=bool(args.pose_grads))
     timer = tm.KernelTimer() if hasattr(tm, "KernelTimer") else None
+    # decoder arithmetic of the timed step: the fastest f32-equivalent one unless --arith says otherwise
+    from scanerf_amd import render as _render
+    arith = args.arith or _render.FP32_EQUIV_ARITH
+    if path == "fused":
+        _render.set_arith(arith)
 
     # ADMM consensus state: N_cam cameras, each tile sees M of them, 20 % shared with the next tile
     n_cam_per, overlap = 120, 24
@@ -379,43 +558,38 @@ def main():
     elapsed = float(t.item())
     ms_per_step = elapsed / args.steps * 1e3
 
-    # the same step with the exact-f32 decoder arithmetic (f32-input MFMA), timed the same way, printed beside the headline
-    from scanerf_amd import render as _render
-    h3_run = path == "fused" and _render.ARITH != 0
-    dtype_label = ("f32 tables/compositing; decoder GEMMs split-f16 x3 MFMA, f32 accumulate (22-bit operands); backward gradient "
-                   "products f16 MFMA + 13-bit table-gradient records, summed in 64-bit fixed point (gradient error vs oracle 7e-4 "
-                   "rel. L2; h3_grad_ms_per_step = the same step with 22-bit gradient products and f32 records, 1e-5)"
-                   if h3_run and _render.ARITH == 2 else
-                   "f32 tables/accumulate/compositing; decoder GEMMs split-f16 x3 MFMA, f32 accumulate (22-bit operands)"
-                   if h3_run else "f32")
+    # the same step under the other arithmetics, timed the same way, printed beside the headline under their own names
+    fused = path == "fused"
+    dtype_label = _render.ARITH_DTYPE[arith] if fused else "f32 (op-by-op path)"
     if occ:
         dtype_label = "bf16 gather table, fp32 master + accumulate; " + dtype_label
-    f32_ms = h3_ms = None
-    if h3_run and not occ and not fgbg:
-        for other in ("f32", "h3"):
+    side_ms = {}
+    if fused and not occ and not fgbg and not args.arith and not args.arith_side_off:
+        for other in ("t16", "h3", "f32"):
+            if other == arith:
+                continue
             _render.set_arith(other)
             try:
                 for i in range(2):
                     step_fn(models[i % ntile], dec_opts[i % ntile], rays_o, rays_d, target, S, step0 + i)
                 sync()
                 f0 = time.perf_counter()
-                for i in range(args.steps):
+                n_side = max(args.steps // 2, 5)
+                for i in range(n_side):
                     step_fn(models[i % ntile], dec_opts[i % ntile], rays_o, rays_d, target, S, step0 + i)
                 sync()
-                ms = (time.perf_counter() - f0) / args.steps * 1e3
-                if other == "f32":
-                    f32_ms = ms
-                else:
-                    h3_ms = ms
+                side_ms[other] = (time.perf_counter() - f0) / n_side * 1e3
             finally:
-                _render.set_arith(_render.DEFAULT_ARITH)
+                _render.set_arith(arith)
 
     with torch.no_grad():  # rays that meet no occupied cell are skipped by every kernel: they are not counted as work
         valid_frac = float((model.sample(rays_o, rays_d, S)[0] != -1).all(1).float().mean())
     if rank == 0:
         value = world * B * valid_frac * args.steps / elapsed
+        f32_equiv = (not fused) or arith in ("f32", "h3", "t16s")
         line = {
-            "metric": "training rays/s per GPU (128 samples, L=16 hash)",
+            "metric": "training rays/s per GPU (128 samples, L=16 hash)" if f32_equiv else
+                      "training rays/s per GPU (128 samples, L=16 hash) -- REDUCED-PRECISION gradient arithmetic (t16), not the metric",
             "value": value, "value_is": "whole-job aggregate over n_gpus (one tile per GPU)", "value_per_gpu": value / world,
             "unit": "rays/s", "n_gpus": world, "rccl_world_size": dist.get_world_size() if world > 1 else 1,
             "steps": args.steps, "warmup": args.warmup,
@@ -430,48 +604,21 @@ def main():
                                     f"configs[1]: single 8m^3 tile per GPU, L=16 T=2^{args.log2_T} fp32 hash grid, 2-hidden x 64 "
                                     f"decoder, {B} rays x {S} samples, full training iteration "
                                     f"(sample+encode+decode+composite fwd, bwd, sparse Adam); foreground branch"),
-                       "path": path, "rays_per_step": B, "valid_ray_fraction": valid_frac, "samples": S, "tiles_per_gpu": ntile,
-                       "parallelism": f"tile-per-gpu x{world}", "syn_iters": SYN_ITERS},
-            "pose_grads": bool(args.pose_grads), "f32_arith_ms_per_step": f32_ms, "h3_grad_ms_per_step": h3_ms,
+                       "path": path, "arith": arith if fused else "ops", "rays_per_step": B, "valid_ray_fraction": valid_frac, "samples": S,
+                       "tiles_per_gpu": ntile, "parallelism": f"tile-per-gpu x{world}", "syn_iters": SYN_ITERS},
+            "pose_grads": bool(args.pose_grads),
+            # the same step under the other arithmetics (ms): t16 = reduced-precision gradient products + 13-bit records;
+            # h3 = round 1's 32-sample-tile split kernel; f32 = exact f32-input MFMA
+            "t16_ms_per_step": side_ms.get("t16"), "h3_ms_per_step": side_ms.get("h3"), "f32_arith_ms_per_step": side_ms.get("f32"),
             "consensus_ms": consensus_ms,
             "consensus_frac_of_iteration": consensus_ms / (SYN_ITERS * ms_per_step),
         }
         if timer and timer.count:
-            name, avg_ms, alg_bytes, alg_flops = timer.dominant()
-            from scanerf_amd import render as _render
-            h3 = _render.ARITH != 0 and path == "fused"
-            # matrix-pipe floor of the launch: f32-input MFMA, or 3 f16 MFMAs per term for the split arithmetic
-            mfma_peak = MFMA_F16_PEAK_TFLOPS if h3 else MFMA_F32_PEAK_TFLOPS
-            t_hbm, t_mfma = alg_bytes / (HBM_PEAK_GBS * 1e9), (3 if h3 else 1) * alg_flops / (mfma_peak * 1e12)
-            line["config"]["decoder_arith"] = ("f32 MFMA" if not h3 else "split f16 x3 MFMA, f32 accumulate (csrc/render_h3.h)" if _render.ARITH == 1
-                                               else "forward + backward recompute: split f16 x3 MFMA, f32 accumulate; gradient products: f16 MFMA, f32 "
-                                                    "accumulate, power-of-two scaled (csrc/render_t16.h); table-gradient records 8 bytes: 13-bit "
-                                                    "significands under a per-record exponent (csrc/scatter_common.h)")
-            if t_mfma > t_hbm:  # the kernel's floor is set by the matrix pipe, not by HBM
-                ach = alg_flops / (avg_ms * 1e-3) / 1e12
-                roof = {"bound": "mfma", "achieved": ach, "peak": mfma_peak, "unit": "TFLOP/s",
-                        "frac": ach / mfma_peak, "algorithmic_flops_per_launch": alg_flops}
-            else:
-                ach = alg_bytes / (avg_ms * 1e-3) / 1e9
-                roof = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS}
-            # HBM-side bytes of that kernel per launch: rocprofv3 PMC passes of this same command, committed under profiles/
-            traffic = None
-            try:
-                pm = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))
-                if h3 and name in pm and args.workload == "configs1" and B == 65536 and S == 128 and args.log2_T == 19:
-                    traffic = pm[name]["fetch_bytes"] + pm[name]["write_bytes"]
-                    roof["traffic_source"] = "profiles/r02_pmc_traffic.json (FETCH_SIZE + WRITE_SIZE of " + pm[name]["kernel"] + ")"
-            except (OSError, ValueError, KeyError):
-                pass
-            # SURVEY.md 8(d) bytes of the WHOLE step (forward + backward per ray) against the step time
-            whole = B * valid_frac * (BYTES_FWD_PER_RAY + BYTES_BWD_PER_RAY) * (2 if fgbg else 1) if S == 128 else None
-            if whole:
-                roof["whole_step"] = {"bytes": whole, "ms": ms_per_step, "frac": whole / (ms_per_step * 1e-3) / (HBM_PEAK_GBS * 1e9)}
-            roof.update({"kernel": name, "traffic": traffic, "avg_launch_ms": avg_ms,
-                         "algorithmic_bytes_per_launch": alg_bytes, "all_kernels_ms": timer.summary()})
-            line["roofline"] = roof
+            line["roofline"] = roofline(timer, arith if fused else "f32", args, B, S, valid_frac, fgbg, ms_per_step)
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(S)
+            if fused and not occ and not fgbg:
+                line["arith_evidence"] = arith_evidence(S)
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()

@@ -668,7 +668,7 @@ SCANERF_API int scanerf_render_backward(const float *rays_o, const float *rays_d
         a.bins.W = blocks;
         a.bins.per_wg = 0;
         a.bins.rpg = t16 ? 8 : (h3 ? 4 : 1);
-        a.bins.rec8 = fused_rec8(cfg->arith, a.bins.bucket_log) ? 1 : 0;  // as the plan decided (scatter.hip: fused_geom)
+        a.bins.rec8 = fused_rec8(cfg->arith, a.bins.bucket_log);  // as the plan decided (scatter.hip: fused_geom)
         BinWorkspace w;
         SCANERF_REQUIRE(bin_workspace_carve(scatter_ws, scatter_ws_bytes, 16 * a.bins.NB, blocks, w),
                         "render_backward: scatter workspace too small (%zu B)", scatter_ws_bytes);

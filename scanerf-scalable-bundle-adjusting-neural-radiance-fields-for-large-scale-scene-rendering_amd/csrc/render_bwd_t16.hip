@@ -285,12 +285,12 @@ __device__ __forceinline__ void stage_act(char *stX, const T16Lane &L, const v4f
     }
 }
 
-// REC8: the scatter records are 8 bytes (scatter_common.h: Rec8), else 16 (Rec).  POSE: also the two per-ray sums the pose
+// REC: format of the scatter records (scatter_common.h): 0 = Rec (16 bytes), 1 = Rec8 (8 bytes), 2 = Rec12 (12 bytes).  POSE: also the two per-ray sums the pose
 // refinement needs (render_bwd_common.h g_dnorm / g_rowsum; csrc/render_bwd_h3.hip is the other kernel that produces them)
 // SPLIT ("t16s"): the gradient products split as well -- dY, W^T (read transposed out of the forward image) and both operands of
 // the weight gradients as hi + lo, three MFMAs per term; G'(u) in f32 (pre-activations are held, activations recomputed); f32
 // records.  Same structure, same barriers; fp32-equivalent gradients (tests/test_gpu_parity.py).
-template <int DT, bool REC8, bool POSE, bool SPLIT = false>
+template <int DT, int REC, bool POSE, bool SPLIT = false>
 __global__ void __launch_bounds__(kThreads, 2) k_render_bwd_t16(BwdArgs a)
 {
     using LD = Lds<SPLIT>;
@@ -438,10 +438,11 @@ __global__ void __launch_bounds__(kThreads, 2) k_render_bwd_t16(BwdArgs a)
                 uint32_t *cl = cursor + level * a.bins.NB;
                 float *gl = a.grad_features + (size_t)level * a.f.T * 2;
 #ifdef SCANERF_BWD_EXPERIMENTS
-                if (REC8 && (a.f.dbg & 15) == 5) emit_pairs8<5>(pr, gx, gy, cl, a.bins.bucket_log, rec_capacity(a.bins.capacity, true), a.recs, gl);
+                if (REC == 1 && (a.f.dbg & 15) == 5) emit_pairs8<5>(pr, gx, gy, cl, a.bins.bucket_log, rec_capacity(a.bins.capacity, 1), a.recs, gl);
                 else
 #endif
-                if (REC8) emit_pairs8(pr, gx, gy, cl, a.bins.bucket_log, rec_capacity(a.bins.capacity, true), a.recs, gl);
+                if (REC == 1) emit_pairs8(pr, gx, gy, cl, a.bins.bucket_log, rec_capacity(a.bins.capacity, 1), a.recs, gl);
+                else if (REC == 2) emit_pairs12(pr, gx, gy, cl, a.bins.bucket_log, rec_capacity(a.bins.capacity, 2), a.recs, gl);
                 else if ((a.f.dbg & 15) == 0) emit_pairs(pr, gx, gy, cl, a.bins.bucket_log, a.bins.capacity, a.recs, gl);
 #ifdef SCANERF_BWD_EXPERIMENTS
                 else if ((a.f.dbg & 15) == 1) emit_pairs<1>(pr, gx, gy, cl, a.bins.bucket_log, a.bins.capacity, a.recs, gl);
@@ -1199,16 +1200,19 @@ int launch_render_bwd_t16(const BwdArgs &a, int feat_dtype, int blocks, size_t l
         hipLaunchKernelGGL((k_render_bwd_t16<DT, R8, PO, SP>), dim3(blocks), dim3(kThreads), lds_bytes, st, a);     \
     }
     (void)feat_dtype;  // the table is only read through the x-stash here
-    const bool r8 = a.recs && a.bins.rec8;
-    SCANERF_REQUIRE(!(split && r8), "render_backward(t16s): the split variant emits f32 records");
+    const int rec = a.recs ? a.bins.rec8 : 0;   // record format as the plan decided (scatter_common.h fused_rec8)
+    SCANERF_REQUIRE(!(split && rec == 1) && !(!split && rec == 2), "render_backward(t16): record format %d does not belong to this arithmetic", rec);
     if (split) {
-        if (a.g_dnorm) SCANERF_LAUNCH_BWD(SCANERF_F32, false, true, true)
-        else SCANERF_LAUNCH_BWD(SCANERF_F32, false, false, true)
+        if (a.g_dnorm) {
+            if (rec == 2) SCANERF_LAUNCH_BWD(SCANERF_F32, 2, true, true)
+            else SCANERF_LAUNCH_BWD(SCANERF_F32, 0, true, true)
+        } else if (rec == 2) SCANERF_LAUNCH_BWD(SCANERF_F32, 2, false, true)
+        else SCANERF_LAUNCH_BWD(SCANERF_F32, 0, false, true)
     } else if (a.g_dnorm) {
-        if (r8) SCANERF_LAUNCH_BWD(SCANERF_F32, true, true, false)
-        else SCANERF_LAUNCH_BWD(SCANERF_F32, false, true, false)
-    } else if (r8) SCANERF_LAUNCH_BWD(SCANERF_F32, true, false, false)
-    else SCANERF_LAUNCH_BWD(SCANERF_F32, false, false, false)
+        if (rec == 1) SCANERF_LAUNCH_BWD(SCANERF_F32, 1, true, false)
+        else SCANERF_LAUNCH_BWD(SCANERF_F32, 0, true, false)
+    } else if (rec == 1) SCANERF_LAUNCH_BWD(SCANERF_F32, 1, false, false)
+    else SCANERF_LAUNCH_BWD(SCANERF_F32, 0, false, false)
 #undef SCANERF_LAUNCH_BWD
     return 0;
 }

@@ -251,8 +251,9 @@ __global__ void __launch_bounds__(kThreads) k_bin_accumulate(const Rec *__restri
     // they stay in L2 -- and applies the entries that fall inside it.
     const int wl = g.bucket_log < 13 ? g.bucket_log : 13, ws = 1 << wl;
     // record format (uniform): the fused plan wrote it next to the records; both sets of a two-branch step share it
-    const bool rec8 = g.rec8 < 0 ? *format_word(const_cast<Rec *>(recs)) != 0u : g.rec8 != 0;
-    const uint32_t cap1 = rec_capacity(g.capacity, rec8), cap2 = rec_capacity(ad.capacity2, rec8);
+    const int fmt = g.rec8 < 0 ? (int)*format_word(const_cast<Rec *>(recs)) : g.rec8;   // 0 = Rec, 1 = Rec8, 2 = Rec12
+    const bool rec8 = fmt == 1;
+    const uint32_t cap1 = rec_capacity(g.capacity, fmt), cap2 = rec_capacity(ad.capacity2, fmt);
     const uint32_t lo1 = min(starts[blockIdx.x], cap1), hi1 = min(starts[blockIdx.x + 1], cap1);
     const bool two = ADAM && ad.recs2 != nullptr;
     const uint32_t lo2 = two ? min(ad.starts2[blockIdx.x], cap2) : 0u, hi2 = two ? min(ad.starts2[blockIdx.x + 1], cap2) : 0u;
@@ -321,9 +322,48 @@ __global__ void __launch_bounds__(kThreads) k_bin_accumulate(const Rec *__restri
                 atomicAdd(&a[2 * l1 + ob], fi(mb * t));
             }
         };
+        // Rec12 (scatter_common.h): f32 components, 23-bit weight; through the same fixed-point conversion as the 16-byte records
+        auto apply12 = [&](uint32_t w0, uint32_t w1, uint32_t w2) {
+            const Rec12Fields f = unpack_rec12(w0, w1, w2);
+            const float wa = 1.0f - f.w1;
+            unsigned long long *a = reinterpret_cast<unsigned long long *>(acc64);
+            const uint32_t oa = threadIdx.x & 1u, ob = oa ^ 1u;   // (odd lanes start with the y word: see apply8)
+            const float ga = oa ? f.gy : f.gx, gb = oa ? f.gx : f.gy;
+            atomicAdd(&a[2 * f.l0 + oa], fx(wa * ga));
+            atomicAdd(&a[2 * f.l0 + ob], fx(wa * gb));
+            if (f.l1 < (uint32_t)ws) {
+                atomicAdd(&a[2 * f.l1 + oa], fx(f.w1 * ga));
+                atomicAdd(&a[2 * f.l1 + ob], fx(f.w1 * gb));
+            }
+        };
         for (int set = 0; set < (two ? 2 : 1); ++set) {   // (one copy of the streaming code for both record sets)
         const float4 *r4 = reinterpret_cast<const float4 *>(set ? ad.recs2 : recs);
         const uint32_t lo = set ? lo2 : lo1, hi = set ? hi2 : hi1;
+        if (fmt == 2) {
+            // each lane takes runs of 4 consecutive records = three aligned 16-byte loads, U / 4 runs in flight (the bin's range
+            // may start anywhere: runs start at multiples of 4 records, partial runs go one record at a time)
+            const uint32_t *r1 = reinterpret_cast<const uint32_t *>(r4);
+            const uint4 *u4 = reinterpret_cast<const uint4 *>(r4);
+            constexpr int RUNS = U / 4 > 0 ? U / 4 : 1;
+            for (uint32_t c = (lo & ~3u) + threadIdx.x * 4 * RUNS; c < hi; c += 4 * RUNS * kThreads) {
+                if (c >= lo && c + 4 * RUNS <= hi) {
+                    uint4 r[3 * RUNS];
+#pragma unroll
+                    for (int u = 0; u < 3 * RUNS; ++u) r[u] = u4[(size_t)(c >> 2) * 3 + u];
+#pragma unroll
+                    for (int u = 0; u < RUNS; ++u) {
+                        const uint4 &a0 = r[3 * u], &a1 = r[3 * u + 1], &a2 = r[3 * u + 2];
+                        apply12(a0.x, a0.y, a0.z);
+                        apply12(a0.w, a1.x, a1.y);
+                        apply12(a1.z, a1.w, a2.x);
+                        apply12(a2.y, a2.z, a2.w);
+                    }
+                } else {
+                    for (uint32_t j = c < lo ? lo : c; j < hi && j < c + 4 * RUNS; ++j) apply12(r1[(size_t)j * 3], r1[(size_t)j * 3 + 1], r1[(size_t)j * 3 + 2]);
+                }
+            }
+            continue;
+        }
         if (rec8) {
             const uint2 *r2 = reinterpret_cast<const uint2 *>(r4);
             if (LANE_OWNS_RUN) {
@@ -499,7 +539,7 @@ bool fused_geom(int B, int S, int T, BinGeom &g, int arith = SCANERF_ARITH_F32)
     g.per_wg = 0;
     g.rpg = (arith == SCANERF_ARITH_T16 || arith == SCANERF_ARITH_T16S) ? 8 : (arith == SCANERF_ARITH_H3 ? 4 : 1);
     g.capacity = 0;
-    g.rec8 = fused_rec8(arith, g.bucket_log) ? 1 : 0;
+    g.rec8 = fused_rec8(arith, g.bucket_log);
     return true;
 }
 
@@ -653,11 +693,11 @@ static void note_plan_format(const void *workspace, int rec8)
     if (g_plan_rec8.size() > 64) g_plan_rec8.clear();
     g_plan_rec8[workspace] = rec8;
 }
-static bool plan_was_rec8(const void *workspace)
+static int plan_format(const void *workspace)
 {
     std::lock_guard<std::mutex> lock(g_hint_mutex);
     auto it = g_plan_rec8.find(workspace);
-    return it != g_plan_rec8.end() && it->second != 0;
+    return it != g_plan_rec8.end() ? it->second : 0;
 }
 
 // ---- fused producer: plan (count + scan) before k_render_bwd, accumulate after it ---------------
@@ -844,7 +884,9 @@ static int accumulate_adam(float *params, float *exp_avg, float *exp_avg_sq, voi
     // measured (configs[1], MI355X), threads x 16-byte loads per lane: 16-byte records 256x32 2.28 ms, 512x32 2.55, 768x32 2.59;
     // 8-byte records 256x32 1.77, 512x16 1.58, 1024x8 1.70, 1024x16 1.55, 768x32 1.51, 512x48 1.53, 512x32 1.47
     const char *ve = getenv("SCANERF_ACC_VARIANT");  // tuning experiments only
-    const int variant = ve ? atoi(ve) : (plan_was_rec8(workspace) ? 4 : 0);
+    // 12-byte records (t16s), threads x records per lane: 256x32 1.72 ms, 512x32 1.74, 768x32 1.67, 1024x16 1.53, 512x8 1.52, 512x16 1.43
+    const int pf = plan_format(workspace);
+    const int variant = ve ? atoi(ve) : (pf == 1 ? 4 : (pf == 2 ? 1 : 0));
     if (variant == 1) SCANERF_LAUNCH_ACC_ADAM(512, 16)
     else if (variant == 2) SCANERF_LAUNCH_ACC_ADAM(1024, 8)
     else if (variant == 3) SCANERF_LAUNCH_ACC_ADAM(256, 16)

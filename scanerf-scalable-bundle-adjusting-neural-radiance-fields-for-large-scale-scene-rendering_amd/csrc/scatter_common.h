@@ -23,7 +23,7 @@ struct BinGeom {
     int per_wg;       // samples per producer workgroup
     int rpg;          // fused producer: rays per workgroup visit (ray = (wg + i*W)*rpg + r): 1 f32 kernel, 4 h3 kernel
     uint32_t capacity;  // records that fit the workspace
-    int rec8;         // record format: 0 = Rec (16 bytes), 1 = Rec8 (8 bytes), -1 = read format_word() (accumulate of a fused plan)
+    int rec8;         // record format: 0 = Rec (16 bytes), 1 = Rec8 (8 bytes), 2 = Rec12 (12 bytes), -1 = read format_word() (accumulate of a fused plan)
 };
 
 struct Rec {
@@ -223,10 +223,12 @@ __device__ __forceinline__ void commit_pairs(const Pairs &pr, const PairSlots &s
 // (Not representable: inf / NaN gradients -- they come out as finite garbage instead of poisoning the entry as f32 records would;
 // the loss of such a step is already non-finite.)
 constexpr int kRec8MaxBucketLog = 13;
-inline bool fused_rec8(int arith, int bucket_log)
+// record format of a fused plan by the backward's arithmetic: 1 (Rec8) for T16, 2 (Rec12) for T16S, else 0 (Rec, 16 bytes)
+inline int fused_rec8(int arith, int bucket_log)
 {
-    if (getenv("SCANERF_REC16")) return false;  // experiments: the t16 kernel on 16-byte records
-    return arith == 2 /* SCANERF_ARITH_T16 */ && bucket_log <= kRec8MaxBucketLog;
+    if (getenv("SCANERF_REC16")) return 0;  // experiments: the 16-sample-tile kernels on 16-byte records
+    if (bucket_log > kRec8MaxBucketLog) return 0;
+    return arith == 2 /* SCANERF_ARITH_T16 */ ? 1 : (arith == 3 /* SCANERF_ARITH_T16S */ ? 2 : 0);
 }
 __device__ __forceinline__ uint2 pack_rec8(uint32_t l0, uint32_t k, uint32_t t, float gx, float gy)
 {
@@ -314,6 +316,82 @@ __device__ __forceinline__ void emit_pairs8(const Pairs &pr, float gix, float gi
     }
 }
 
+// ---- 12-byte records: the stream of the split-gradient 16-sample-tile backward ("t16s") ---------------------------------
+// Its gradients are f32-equivalent, so the records keep f32 accuracy -- in 12 instead of 16 bytes (6.4 instead of 8.6 GB per
+// configs[1] step, written and read back):
+//   word0: l0 [12:0] | k [16:13] | t bits 22:8 [31:17]        (l1 = l0 ^ ((2 << k) - 1), k = 15: no second entry, as Rec8)
+//   word1: gx as f32, mantissa rounded to 19 bits; its low 4 bits carry t bits 7:4
+//   word2: gy likewise; low 4 bits = t bits 3:0
+// t = round(tx * 2^23) (23 bits: weight error 2^-24), gradient components 2^-21 relative.
+__device__ __forceinline__ uint32_t rec12_round(float g) { return (__float_as_uint(g) + 8u) & ~15u; }   // (round to nearest on 19 mantissa bits; inf / NaN stay what they are)
+__device__ __forceinline__ void store_rec12(Rec *recs, uint32_t pos, uint32_t l0, uint32_t k, uint32_t t, float gx, float gy)
+{
+    struct __attribute__((aligned(4))) W3 { uint32_t a, b, c; };   // (one global_store_dwordx3; 4-byte aligned)
+    *reinterpret_cast<W3 *>(reinterpret_cast<uint32_t *>(recs) + (size_t)pos * 3) =
+        W3{ l0 | (k << 13) | ((t >> 8) << 17), rec12_round(gx) | ((t >> 4) & 15u), rec12_round(gy) | (t & 15u) };
+}
+struct Rec12Fields {
+    uint32_t l0, l1;
+    float w1, gx, gy;   // weight of l1 (1 - w1 of l0)
+};
+__device__ __forceinline__ Rec12Fields unpack_rec12(uint32_t w0, uint32_t w1, uint32_t w2)
+{
+    Rec12Fields f;
+    f.l0 = w0 & 0x1fffu;
+    f.l1 = f.l0 ^ ((2u << ((w0 >> 13) & 15u)) - 1u);
+    const uint32_t t = ((w0 >> 17) << 8) | ((w1 & 15u) << 4) | (w2 & 15u);
+    f.w1 = (float)t * 0x1p-23f;
+    f.gx = __uint_as_float(w1 & ~15u);
+    f.gy = __uint_as_float(w2 & ~15u);
+    return f;
+}
+// emit_pairs for the Rec12 stream: same ranges, same cursors, same rare paths; capacity counts 12-byte records here
+__device__ __forceinline__ void emit_pairs12(const Pairs &pr, float gix, float giy, uint32_t *cursor_level, int bucket_log,
+                                             uint32_t capacity, Rec *recs, float *grad_level)
+{
+    const uint32_t lmask = (1u << bucket_log) - 1u;
+    const bool straddle = (pr.xm >> bucket_log) != 0u;
+    const float a0 = 1.0f - pr.tx;
+    auto fallback = [&](uint32_t bkt, uint32_t e0, uint32_t e1, float tx, float ax, float ay) {
+        *overflow_flag(recs) = 1u;
+        float *gs = grad_level + ((size_t)bkt << bucket_log) * 2;
+        unsafeAtomicAdd(gs + 2 * e0, (1.0f - tx) * ax);
+        unsafeAtomicAdd(gs + 2 * e0 + 1, (1.0f - tx) * ay);
+        unsafeAtomicAdd(gs + 2 * e1, tx * ax);
+        unsafeAtomicAdd(gs + 2 * e1 + 1, tx * ay);
+    };
+    uint32_t pos[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) pos[q] = atomicAdd(&cursor_level[pr.idx0[q] >> bucket_log], 1u);
+    const uint32_t k = straddle ? 15u : (uint32_t)(31 - __clz((int)pr.xm));
+    const uint32_t t = straddle ? 0u : (uint32_t)min(__float2int_rn(pr.tx * 8388608.0f), 8388607);
+    bool rare = straddle;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float gx = pr.wyz[q] * gix, gy = pr.wyz[q] * giy;
+        const float ax = straddle ? a0 * gx : gx, ay = straddle ? a0 * gy : gy;
+        if (pos[q] < capacity) store_rec12(recs, pos[q], pr.idx0[q] & lmask, k, t, ax, ay);
+        rare |= pos[q] >= capacity;
+    }
+    if (__builtin_expect(__any(rare), 0)) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint32_t l0 = pr.idx0[q] & lmask, b0 = pr.idx0[q] >> bucket_log;
+            const float gx = pr.wyz[q] * gix, gy = pr.wyz[q] * giy;
+            if (pos[q] >= capacity) {
+                if (straddle) fallback(b0, l0, l0, 0.0f, a0 * gx, a0 * gy);
+                else fallback(b0, l0, l0 ^ pr.xm, pr.tx, gx, gy);
+            }
+            if (straddle) {  // second record: the x+1 neighbour in its own bucket
+                const uint32_t i1 = pr.idx0[q] ^ pr.xm, b1 = i1 >> bucket_log, l1 = i1 & lmask;
+                const uint32_t p1 = atomicAdd(&cursor_level[b1], 1u);
+                if (p1 < capacity) store_rec12(recs, p1, l1, 15u, 0u, pr.tx * gx, pr.tx * gy);
+                else fallback(b1, l1, l1, 0.0f, pr.tx * gx, pr.tx * gy);
+            }
+        }
+    }
+}
+
 // histogram counterpart of emit_pairs (must stay in lock-step with it)
 __device__ __forceinline__ void count_pairs(const Pairs &pr, uint32_t *hist_level, int bucket_log)
 {
@@ -351,7 +429,10 @@ inline bool bin_workspace_carve(void *workspace, size_t bytes, int nbins, int W,
     w.capacity = cap > 0x7ffffff0u ? 0x7ffffff0u : (uint32_t)cap;
     return true;
 }
-__host__ __device__ inline uint32_t rec_capacity(uint32_t capacity16, bool rec8) { return rec8 ? capacity16 * 2u : capacity16; }
+__host__ __device__ inline uint32_t rec_capacity(uint32_t capacity16, int fmt)
+{
+    return fmt == 1 ? capacity16 * 2u : (fmt == 2 ? capacity16 + capacity16 / 3u : capacity16);   // 8- / 12- / 16-byte records in the same bytes
+}
 // bucket size of the FUSED producer (k_render_bwd* emits, scanerf_render_scatter_accumulate consumes): log2 entries
 inline int fused_bucket_log(int T);
 inline int bin_ilog2(int v)

@@ -9,18 +9,34 @@ from ._capi import RAY_OUT, RenderCfg, check, dev_ptr, feat_dtype_code, lib, str
 _f32 = torch.float32
 FORE, BG = 0, 1
 
-# Decoder arithmetic of the fused kernels (module-level switch, also SCANERF_ARITH=f32|h3|t16 in the environment):
-#   "f32" = the f32-input MFMA (exact f32);
-#   "h3"  = f16 matrix cores on hi/lo-split operands, three products per term, f32 accumulate: results as close to fp64 as
-#           the f32 evaluation (csrc/render_h3.h), forward and backward;
-#   "t16" = (default) forward as "h3"; backward on 16-sample tiles at two waves per SIMD, forward recompute in h3, gradient
-#           products on one f16 MFMA per term (csrc/render_t16.h).  Calls it cannot serve (no x-stash, pose-gradient
-#           outputs) run the "h3" backward: see backward_arith().
+# Decoder arithmetic of the fused kernels (module-level switch, also SCANERF_ARITH=f32|h3|t16|t16s in the environment):
+#   "f32"  = the f32-input MFMA (exact f32);
+#   "h3"   = f16 matrix cores on hi/lo-split operands, three products per term, f32 accumulate: results as close to fp64 as
+#            the f32 evaluation (csrc/render_h3.h), forward and backward (32-sample tiles, one wave per SIMD);
+#   "t16s" = (default) forward as "h3"; backward on 16-sample tiles at two waves per SIMD with EVERY product split like h3's
+#            (csrc/render_t16.h): f32-equivalent gradients (4e-6 relative L2 against the oracle) at 5.5 instead of 6.2 ms;
+#   "t16"  = the same backward with the gradient products on ONE f16 MFMA per term and 8-byte table-gradient records
+#            (7e-4 relative L2): the fast, reduced-precision option (3.9 ms); converges like the others on the procedural
+#            scene (tests/test_gpu_harness.py: 27.1 dB each) but is not what the reference computes.
+#   Calls the 16-sample-tile kernels cannot serve (no x-stash) run the "h3" backward: see backward_arith().
 import os as _os
 _ARITH_CODES = {"f32": _capi.ARITH_F32, "h3": _capi.ARITH_H3, "t16": _capi.ARITH_T16, "t16s": _capi.ARITH_T16S}
 ARITH_NAMES = tuple(_ARITH_CODES)
-DEFAULT_ARITH = _os.environ.get("SCANERF_ARITH", "t16")
+FP32_EQUIV_ARITH = "t16s"   # the fastest arithmetic whose gradients are f32-equivalent: what bench.py's headline runs
+DEFAULT_ARITH = _os.environ.get("SCANERF_ARITH", FP32_EQUIV_ARITH)
 ARITH = _ARITH_CODES[DEFAULT_ARITH]
+# what each arithmetic computes in, for bench.py's `dtype`
+ARITH_DTYPE = {
+    "f32": "f32 throughout (f32-input MFMA; f32 table-gradient records summed in 64-bit fixed point)",
+    "h3": "f32 tables / compositing / accumulate; every decoder product (forward, gradient chains, weight gradients) on f16 MFMA "
+          "with hi+lo split operands (22-bit), three products per term, f32 accumulate; f32 table-gradient records summed in "
+          "64-bit fixed point",
+    "t16s": "f32 tables / compositing / accumulate; every decoder product (forward, gradient chains, weight gradients) on f16 MFMA "
+            "with hi+lo split operands (22-bit), three products per term, f32 accumulate; G' in f32; f32 table-gradient records "
+            "summed in 64-bit fixed point",
+    "t16": "f32 tables / compositing; forward + backward recompute split-f16 x3 MFMA (22-bit operands); gradient products ONE f16 "
+           "MFMA per term (11-bit operands); 13-bit table-gradient records summed in 64-bit fixed point -- REDUCED precision",
+}
 
 
 def set_arith(name):

@@ -26,6 +26,10 @@ def test_gpus_2_spawns_two_ranks_and_relays_rank0_line():
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["rccl_world_size"] == 2 and line["dry_run"] is True
     assert line["steps"] == 4 and line["ms_per_step"] > 0
+    # configs[4]'s tile -> rank map with unequal counts: 9 tiles on 2 ranks (rank 0 owns 5), both exchanges of the real driver
+    # (consensus all-reduce, shared-depth MIN) once per stretch plus the initial one, every published depth map received
+    cfg = line["config"]
+    assert cfg["tiles"] == 9 and cfg["tiles_of_rank0"] == 5 and cfg["exchanges"] == 2 and cfg["exchange_ok"] is True
 
 
 def test_single_rank_line_unchanged_without_launcher():

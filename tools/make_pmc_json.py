@@ -1,0 +1,69 @@
+"""rocprofv3 output of tools/profile_r03.sh -> the JSON bench.py's `roofline` reads (stdout) and a readable table (stderr).
+Per kernel, per launch: average duration (kernel_stats.csv of the --stats pass), FETCH_SIZE / WRITE_SIZE in bytes (the counters
+report KB: x 1024, MI355X_MICROARCH.md), SQ counters summed over the launch; derived: mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES /
+(1024 SIMDs x duration x SCLK) with the SCLK taken as SQ_BUSY_CYCLES' own clock = 2.1 GHz nominal under load (stated, not
+measured), wait_any = SQ_WAIT_ANY / SQ_WAVE_CYCLES, valu_active = SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES,
+lds_bank_conflict = SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE."""
+import collections, csv, glob, json, sys
+
+d = sys.argv[1]
+KEEP = ("k_render_fwd", "k_render_bwd", "k_bin_accumulate", "k_sample_points_grid", "k_reduce_dw", "k_bin_rowscan", "k_loss")
+
+
+def short(name):   # "void (anonymous namespace)::k_render_bwd_t16<0, false, false, true>(scanerf::BwdArgs)" -> "k_render_bwd_t16<0, false, false, true>"
+    n = name.replace("void ", "").replace("(anonymous namespace)::", "")
+    depth = 0
+    for i, ch in enumerate(n):
+        depth += ch == "<"
+        depth -= ch == ">"
+        if ch == "(" and depth == 0:
+            return n[:i].strip()
+    return n.strip()
+
+
+kern = collections.defaultdict(dict)
+f = glob.glob(f"{d}/stats/**/*kernel_stats.csv", recursive=True)
+if f:
+    for r in csv.DictReader(open(f[0])):
+        k = short(r["Name"])
+        if k.startswith(KEEP):
+            kern[k]["avg_us"] = float(r["AverageNs"]) / 1e3
+            kern[k]["calls"] = int(r["Calls"])
+for f in glob.glob(f"{d}/p*/**/*counter_collection.csv", recursive=True):
+    acc = collections.defaultdict(lambda: [0.0, 0])
+    for r in csv.DictReader(open(f)):
+        k = short(r["Kernel_Name"])
+        if k.startswith(KEEP):
+            a = acc[(k, r["Counter_Name"])]
+            a[0] += float(r["Counter_Value"])
+            a[1] += 1
+    for (k, c), (v, n) in acc.items():
+        kern[k][c] = v / n
+SCLK = 2.1e9
+out = {"_source": "rocprofv3 --kernel-trace --stats and --pmc passes (separate; tools/profile_r03.sh) of `python3 bench.py --gpus 1 --no-cpu-baseline`: per-launch averages, MI355X, configs[1]",
+       "_corrections": "FETCH_SIZE / WRITE_SIZE: reported KB x 1024 (MI355X_MICROARCH.md); FETCH_SIZE tallies the 128-B requests of 16-B/lane streams as 64 B (the accumulate's record stream: x2 where noted); SQ_* are sums over the launch; mfma_busy assumes SCLK 2.1 GHz under load",
+       "kernels": {}}
+for k, v in sorted(kern.items(), key=lambda kv: -kv[1].get("avg_us", 0)):
+    e = {"avg_us": v.get("avg_us"), "calls": v.get("calls")}
+    if "FETCH_SIZE" in v:
+        e["fetch_bytes"] = v["FETCH_SIZE"] * 1024
+    if "WRITE_SIZE" in v:
+        e["write_bytes"] = v["WRITE_SIZE"] * 1024
+    for c in ("SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_INSTS_VALU", "SQ_INSTS_MFMA", "SQ_INSTS_LDS", "SQ_INSTS_VMEM", "SQ_INSTS_SALU",
+              "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_LDS", "SQ_LDS_IDX_ACTIVE", "SQ_LDS_BANK_CONFLICT",
+              "SQ_WAIT_INST_LDS", "SQ_WAIT_INST_ANY", "SQ_BUSY_CYCLES"):
+        if c in v:
+            e[c] = v[c]
+    if "SQ_VALU_MFMA_BUSY_CYCLES" in v and v.get("avg_us"):
+        e["mfma_busy"] = v["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024 * v["avg_us"] * 1e-6 * SCLK)
+    if "SQ_WAIT_ANY" in v and v.get("SQ_WAVE_CYCLES"):
+        e["wait_any"] = v["SQ_WAIT_ANY"] / v["SQ_WAVE_CYCLES"]
+    if "SQ_ACTIVE_INST_VALU" in v and v.get("SQ_WAVE_CYCLES"):
+        e["valu_active"] = v["SQ_ACTIVE_INST_VALU"] / v["SQ_WAVE_CYCLES"]
+    if "SQ_LDS_BANK_CONFLICT" in v and v.get("SQ_LDS_IDX_ACTIVE"):
+        e["lds_bank_conflict"] = v["SQ_LDS_BANK_CONFLICT"] / v["SQ_LDS_IDX_ACTIVE"]
+    out["kernels"][k] = e
+    print(f"{k[:64]:66s} {e.get('avg_us') or 0:9.1f} us  fetch {e.get('fetch_bytes', 0) / 1e9:6.2f} GB  write {e.get('write_bytes', 0) / 1e9:6.2f} GB  "
+          f"mfma {e.get('mfma_busy', 0):.3f}  wait {e.get('wait_any', 0):.3f}  valu {e.get('valu_active', 0):.3f}  ldsconf {e.get('lds_bank_conflict', 0):.3f}  "
+          f"VALU/MFMA/LDS/VMEM insts {v.get('SQ_INSTS_VALU', 0):.3g}/{v.get('SQ_INSTS_MFMA', 0):.3g}/{v.get('SQ_INSTS_LDS', 0):.3g}/{v.get('SQ_INSTS_VMEM', 0):.3g}", file=sys.stderr)
+json.dump(out, sys.stdout, indent=1)
