@@ -107,9 +107,11 @@ struct TableElem<SCANERF_BF16> {
 // L2, 55-80 G/s beyond it, the same for 8-byte and 16-byte loads).  idx(x+1) = idx(x) ^ ((x ^ (x+1)) & mask): for even x
 // the two x-neighbours of a (y,z) corner are the entries i and i^1 -- one aligned two-entry chunk, one load; only for odd
 // x does the neighbour live elsewhere: 6 requests per cell on average instead of 8.  Two exclusive paths write the same
-// 8 results.  Used for the 4-byte-entry tables only: with 8-byte entries the chunk loads are 16 bytes per lane and the
-// extra registers spill the (register-bound) forward kernel -- measured 3.2 -> 4.3 ms there, against 1.24 -> 1.03 ms
-// (bf16, configs[2]) here.  f[c] in corner_indices order (c = dx<<2 | dy<<1 | dz).
+// 8 results.  Half-precision tables: 1.24 -> 1.03 ms (bf16, configs[2]).  fp32 tables (16-byte chunk loads): round 2 measured
+// 3.2 -> 4.3 ms in the then register-bound forward (spills); round 3's forward has registers to spare (no packed arithmetic,
+// opaque LDS addressing: 0 spills) and takes them at 3.10 -> 3.03 ms (-DSCANERF_PAIRED_F32=1, csrc/Makefile) -- little,
+// because the x-neighbours share their 64-byte line anyway: the kernel is bound by L2 MISSES (lines), not by requests.
+// f[c] in corner_indices order (c = dx<<2 | dy<<1 | dz).
 template <int DT>
 __device__ __forceinline__ void gather_cell(const void *slice, const uint32_t idx[8], bool x_odd, float2 f[8])
 {

@@ -345,10 +345,13 @@ __device__ __forceinline__ Rec12Fields unpack_rec12(uint32_t w0, uint32_t w1, ui
     f.gy = __uint_as_float(w2 & ~15u);
     return f;
 }
-// emit_pairs for the Rec12 stream: same ranges, same cursors, same rare paths; capacity counts 12-byte records here
-__device__ __forceinline__ void emit_pairs12(const Pairs &pr, float gix, float giy, uint32_t *cursor_level, int bucket_log,
-                                             uint32_t capacity, Rec *recs, float *grad_level)
+// emit_pairs for the Rec12 stream: same ranges, same cursors, same rare paths; capacity counts 12-byte records here.  In two
+// halves (as reserve_pairs / commit_pairs): the four cursor atomics, then the records -- a caller can have the round trips of
+// several (sample, level)s in flight before it stores anything.
+__device__ __forceinline__ void commit_pairs12(const Pairs &pr, const PairSlots &sl, float gix, float giy, uint32_t *cursor_level,
+                                               int bucket_log, uint32_t capacity, Rec *recs, float *grad_level)
 {
+    const uint32_t *pos = sl.pos;
     const uint32_t lmask = (1u << bucket_log) - 1u;
     const bool straddle = (pr.xm >> bucket_log) != 0u;
     const float a0 = 1.0f - pr.tx;
@@ -360,9 +363,6 @@ __device__ __forceinline__ void emit_pairs12(const Pairs &pr, float gix, float g
         unsafeAtomicAdd(gs + 2 * e1, tx * ax);
         unsafeAtomicAdd(gs + 2 * e1 + 1, tx * ay);
     };
-    uint32_t pos[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) pos[q] = atomicAdd(&cursor_level[pr.idx0[q] >> bucket_log], 1u);
     const uint32_t k = straddle ? 15u : (uint32_t)(31 - __clz((int)pr.xm));
     const uint32_t t = straddle ? 0u : (uint32_t)min(__float2int_rn(pr.tx * 8388608.0f), 8388607);
     bool rare = straddle;
@@ -390,6 +390,14 @@ __device__ __forceinline__ void emit_pairs12(const Pairs &pr, float gix, float g
             }
         }
     }
+}
+
+__device__ __forceinline__ void emit_pairs12(const Pairs &pr, float gix, float giy, uint32_t *cursor_level, int bucket_log,
+                                             uint32_t capacity, Rec *recs, float *grad_level)
+{
+    PairSlots sl;
+    reserve_pairs(pr, cursor_level, bucket_log, sl);
+    commit_pairs12(pr, sl, gix, giy, cursor_level, bucket_log, capacity, recs, grad_level);
 }
 
 // histogram counterpart of emit_pairs (must stay in lock-step with it)
