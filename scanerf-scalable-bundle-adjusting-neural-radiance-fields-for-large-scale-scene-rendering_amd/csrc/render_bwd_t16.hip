@@ -657,14 +657,12 @@ __global__ void __launch_bounds__(kThreads, 2) k_render_bwd_t16(BwdArgs a)
             const float ex = live ? expf(-sigma * delta) : 1.0f;  // 1 - alpha
             const float alpha = 1.0f - ex;
             const float fi = 1.0f - alpha + 1e-6f;
-            float incl = fi;
-#pragma unroll
-            for (int off = 1; off < 16; off <<= 1) {
-                const float t = __shfl_up(incl, off, 16);
-                if (c >= off) incl *= t;
-            }
-            float excl = __shfl_up(incl, 1, 16);
-            if (c == 0) excl = 1.0f;
+            float incl = fi;   // inclusive prefix product over the row (DPP row shifts, identity shifted in)
+            incl *= row_shr<1>(incl, 1.0f);
+            incl *= row_shr<2>(incl, 1.0f);
+            incl *= row_shr<4>(incl, 1.0f);
+            incl *= row_shr<8>(incl, 1.0f);
+            const float excl = row_shr<1>(incl, 1.0f);
             const float Ti = tile_T_in * excl;
             const float w = alpha * Ti;
             float gD[3], gS[3], gTi[3];
@@ -682,13 +680,13 @@ __global__ void __launch_bounds__(kThreads, 2) k_render_bwd_t16(BwdArgs a)
             for (int k = 0; k < 3; ++k) ai += gD[k] * dif[k] + gS[k] * tint[k] * spec[k] + gTi[k] * tint[k];
             const float aw = live ? ai * w : 0.0f;
             float rs = aw;  // inclusive suffix sum inside the tile
-#pragma unroll
-            for (int off = 1; off < 16; off <<= 1) {
-                const float t = __shfl_down(rs, off, 16);
-                if (c + off < 16) rs += t;
-            }
+            rs += row_shl<1>(rs, 0.0f);
+            rs += row_shl<2>(rs, 0.0f);
+            rs += row_shl<4>(rs, 0.0f);
+            rs += row_shl<8>(rs, 0.0f);
             const float suffix = Rcarry + rs - aw;
-            Rcarry += __shfl(rs, 0, 16);
+            // the tile's total = lane 0's suffix sum (the four rows hold the same samples), through a scalar register
+            Rcarry += __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, rs)));
             float dalpha = Ti * ai - (suffix + ((s < S - 1) ? gTl * Tl : 0.0f)) / fi;
             if (!live) dalpha = 0.0f;
             const float dsigma = dalpha * delta * ex;
@@ -714,8 +712,10 @@ __global__ void __launch_bounds__(kThreads, 2) k_render_bwd_t16(BwdArgs a)
                 for (int k = 0; k < 7; ++k) mx = fmaxf(mx, fabsf(gh[k]));
 #pragma unroll
                 for (int k = 0; k < 3; ++k) mx = fmaxf(mx, fabsf(gs3[k]));
-#pragma unroll
-                for (int off = 8; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 16));
+                mx = fmaxf(mx, row_ror<8>(mx));
+                mx = fmaxf(mx, row_ror<4>(mx));
+                mx = fmaxf(mx, row_ror<2>(mx));
+                mx = fmaxf(mx, row_ror<1>(mx));
                 if (lane == 0) mxbuf[wv] = mx;
             }
             STEP_BARRIER();  // ---- S: tile maxima visible; every wave is done with the previous tile's staged operands

@@ -96,6 +96,25 @@ __device__ __forceinline__ t16_h4 t16_hi4(const v4f &a)
     return t16_h4{ p0[0], p0[1], p1[0], p1[1] };
 }
 
+// ---- row operations: a "row" = the 16 lanes of a group (lane & 15 = sample) = one DPP row.  One vector instruction each,
+// where __shfl_* within 16 lanes goes through the LDS crossbar (ds_bpermute: an LDS round trip per step of a dependent scan).
+// (tools/probe/dpp_rows_test.hip checks the three against a host evaluation.)
+template <int N>
+__device__ __forceinline__ float row_shr(float v, float fill)   // lane c <- v of lane c - N (fill where c < N)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, fill), __builtin_bit_cast(int, v), 0x110 + N, 0xf, 0xf, false));
+}
+template <int N>
+__device__ __forceinline__ float row_shl(float v, float fill)   // lane c <- v of lane c + N (fill where c + N > 15)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, fill), __builtin_bit_cast(int, v), 0x100 + N, 0xf, 0xf, false));
+}
+template <int N>
+__device__ __forceinline__ float row_ror(float v)               // lane c <- v of lane (c - N) mod 16
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x120 + N, 0xf, 0xf, false));
+}
+
 __device__ __forceinline__ v4f t16_mfma(const t16_h8 &a, const t16_h8 &b, const v4f &c)
 {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
