@@ -751,6 +751,8 @@ __global__ void __launch_bounds__(kThreads, 2) k_render_bwd_t16(BwdArgs a)
             if constexpr (SPLIT) {
                 constexpr int kLo = 2 * T16_STAGE_MAT;
                 const v4f zero = { 0, 0, 0, 0 };
+                // (tried: the two waves of a SIMD running every interval's weight-gradient products and chain in opposite orders,
+                // so that one's vector work meets the other's matrix / LDS work: 5.13 -> 5.18 ms, not kept)
                 // ================= narrow layers: heads (32 -> 7) and rgb (64 -> 3) =================
                 L = fresh_lane(L);
                 // one 16-row block: rows 0-3 sigma, dif; 4-6 tint; 8-10 rgb  (lane group q holds rows 4q .. 4q+3)
