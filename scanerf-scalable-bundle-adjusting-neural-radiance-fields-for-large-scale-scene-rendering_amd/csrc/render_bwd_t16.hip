@@ -20,7 +20,7 @@
 using namespace scanerf;
 
 // timing experiments only (results are wrong): -DT16_NO_BARRIER drops the per-step workgroup barriers, -DT16_NO_WGRAD the
-// weight-gradient products
+// weight-gradient products, -DT16_NO_EMIT the records / dfeat
 #ifdef T16_NO_BARRIER
 #define STEP_BARRIER() __builtin_amdgcn_sched_barrier(0)
 #else
@@ -410,6 +410,9 @@ __global__ void __launch_bounds__(kThreads, 2) k_render_bwd_t16(BwdArgs a)
         // while nothing computes: removing the barriers or the weight-gradient products did not change the kernel's time.
         // Spread over the next tile's layers the same stores overlap its matrix work.
         auto emit_level = [&](int tile_e, int jj, const v4f &e0, const v4f &e1, const float pe[3]) {
+#ifdef T16_NO_EMIT   // timing experiments only (results are wrong): no records, no dfeat
+            return;
+#endif
             const int ln = fresh(lane), c = ln & 15, q = ln >> 4;
             const int s = tile_e * 16 + c;
             if (tile_e < 0 || !(s < S) || !active) return;
