@@ -108,8 +108,9 @@ int scanerf_embedding_bg_backward_binned(const float *points, const float *grad_
 /* The same ending in the fused sparse Adam (the bucket images are the touched-entry list: no gradient table, no zero-fill, no
  * scan; per element the IEEE sequence of scanerf_adam_step, `step` = previous count).  half_table (may be NULL): f16 / bf16
  * gather copy refreshed where params change.  overflow_grad: zero [L][T][2] f32 table, written (and consumed) only if the
- * workspace overflows.  compact_records (grad_layout 1): 8-byte records (13-bit significands, csrc/scatter_common.h) -- for
- * feature gradients that come out of the t16 backward's f16 products; 0 = 16-byte records, exact. */
+ * workspace overflows.  compact_records (grad_layout 1): 1 = 8-byte records (13-bit significands, csrc/scatter_common.h) -- for
+ * feature gradients that come out of the t16 backward's f16 products; 2 = 12-byte records (f32 components less 4 bits, 23-bit
+ * weight: behind the t16s backward); 0 = 16-byte records, exact. */
 int scanerf_embedding_bg_backward_binned_adam(const float *points, const float *grad_in, const int32_t *resolutions, int N,
                                               int L, int T, int grad_layout, void *workspace, size_t workspace_bytes,
                                               float *params, float *exp_avg, float *exp_avg_sq, void *half_table,

@@ -145,8 +145,9 @@ __global__ void __launch_bounds__(1024) k_bin_starts(const uint32_t *__restrict_
 
 // ---- pass 2: scatter records ---------------------------------------------------------------
 // LEVEL_MAJOR_GRAD: grad_in is [L][N][2] (two-kernel render path) instead of [N][L][2].
-// REC8: 8-byte records (scatter_common.h Rec8: gradients that come out of the t16 backward's f16 products anyway)
-template <bool LEVEL_MAJOR_GRAD, bool PER_LEVEL = false, bool REC8 = false>
+// REC: record format (scatter_common.h): 0 = Rec (16 bytes), 1 = Rec8 (gradients that come out of the t16 backward's f16 products
+// anyway), 2 = Rec12 (f32-grade in 12 bytes: behind the t16s backward)
+template <bool LEVEL_MAJOR_GRAD, bool PER_LEVEL = false, int REC = 0>
 __global__ void __launch_bounds__(1024) k_bin_scatter(const float *__restrict__ points,
                                                           const float2 *__restrict__ grad_in,
                                                           const int32_t *__restrict__ resolutions, BinGeom g,
@@ -171,9 +172,12 @@ __global__ void __launch_bounds__(1024) k_bin_scatter(const float *__restrict__ 
         gmax = fmaxf(gmax, fmaxf(fabsf(gi.x), fabsf(gi.y)));
         Pairs pr;
         make_pairs(p, resolutions + 3 * l, mask, pr);
-        if (REC8)
-            emit_pairs8(pr, gi.x, gi.y, PER_LEVEL ? cursor : cursor + l * g.NB, g.bucket_log, rec_capacity(g.capacity, true), recs,
+        if (REC == 1)
+            emit_pairs8(pr, gi.x, gi.y, PER_LEVEL ? cursor : cursor + l * g.NB, g.bucket_log, rec_capacity(g.capacity, 1), recs,
                         grad_features + (size_t)l * g.T * 2);
+        else if (REC == 2)
+            emit_pairs12(pr, gi.x, gi.y, PER_LEVEL ? cursor : cursor + l * g.NB, g.bucket_log, rec_capacity(g.capacity, 2), recs,
+                         grad_features + (size_t)l * g.T * 2);
         else
             emit_pairs(pr, gi.x, gi.y, PER_LEVEL ? cursor : cursor + l * g.NB, g.bucket_log, g.capacity, recs,
                        grad_features + (size_t)l * g.T * 2);
@@ -574,7 +578,7 @@ SCANERF_API size_t scanerf_embedding_bwd_workspace_bytes(int N, int L, int T)
 // grad_features: the table the image is added to -- or, with an Adam epilogue, the overflow table (ad->overflow_grad)
 static int binned_backward(const float *points, const float *grad_in, float *grad_features, const int32_t *resolutions, int N,
                            int L, int T, int grad_layout, void *workspace, size_t workspace_bytes, const AdamEpilogue *ad,
-                           scanerf_stream_t stream, bool compact_records = false)
+                           scanerf_stream_t stream, int compact_records = 0)
 {
     SCANERF_REQUIRE(N >= 0 && L >= 1, "embedding_bg_backward_binned: N=%d L=%d", N, L);
     if (N == 0) return 0;
@@ -589,8 +593,8 @@ static int binned_backward(const float *points, const float *grad_in, float *gra
     g.N = N; g.L = L; g.T = T;
     g.rpg = 1;
     g.bucket_log = standalone_bucket_log(T);
-    // 16-byte records, or on request (level-major gradients out of the t16 backward) the 8-byte ones
-    g.rec8 = (compact_records && grad_layout == 1 && g.bucket_log <= kRec8MaxBucketLog && !getenv("SCANERF_REC16")) ? 1 : 0;
+    // 16-byte records, or on request (level-major gradients out of the 16-sample-tile backward kernels) the 8- / 12-byte ones
+    g.rec8 = (compact_records >= 1 && compact_records <= 2 && grad_layout == 1 && g.bucket_log <= kRec8MaxBucketLog && !getenv("SCANERF_REC16")) ? compact_records : 0;
     g.NB = T >> g.bucket_log;
     // producer workgroups: every one of them writes and reads a counter per bin, so with the tens of thousands of bins of a
     // large table fewer, longer-running workgroups are cheaper (T = 2^24, 2.1 M points: count 0.62 -> see DESIGN.md)
@@ -615,11 +619,17 @@ static int binned_backward(const float *points, const float *grad_in, float *gra
         hipLaunchKernelGGL((k_bin_count<false>), dim3(g.W), dim3(kThreads), lds_bins, st, points, resolutions, g, counts, maxbits, overflow_flag(recs));
     hipLaunchKernelGGL(k_bin_rowscan, dim3(nbins), dim3(kThreads), 0, st, counts, totals, g.W);
     hipLaunchKernelGGL(k_bin_starts, dim3(1), dim3(1024), 0, st, totals, starts, nbins);
-    if (g.rec8 && per_level)
-        hipLaunchKernelGGL((k_bin_scatter<true, true, true>), dim3(g.W), dim3(1024), lds_bins, st, points, gi, resolutions, g,
+    if (g.rec8 == 1 && per_level)
+        hipLaunchKernelGGL((k_bin_scatter<true, true, 1>), dim3(g.W), dim3(1024), lds_bins, st, points, gi, resolutions, g,
                            counts, starts, recs, grad_features, maxbits);
-    else if (g.rec8)
-        hipLaunchKernelGGL((k_bin_scatter<true, false, true>), dim3(g.W), dim3(kThreads), lds_bins, st, points, gi, resolutions, g,
+    else if (g.rec8 == 1)
+        hipLaunchKernelGGL((k_bin_scatter<true, false, 1>), dim3(g.W), dim3(kThreads), lds_bins, st, points, gi, resolutions, g,
+                           counts, starts, recs, grad_features, maxbits);
+    else if (g.rec8 == 2 && per_level)
+        hipLaunchKernelGGL((k_bin_scatter<true, true, 2>), dim3(g.W), dim3(1024), lds_bins, st, points, gi, resolutions, g,
+                           counts, starts, recs, grad_features, maxbits);
+    else if (g.rec8 == 2)
+        hipLaunchKernelGGL((k_bin_scatter<true, false, 2>), dim3(g.W), dim3(kThreads), lds_bins, st, points, gi, resolutions, g,
                            counts, starts, recs, grad_features, maxbits);
     else if (per_level && grad_layout == 0)
         hipLaunchKernelGGL((k_bin_scatter<false, true>), dim3(g.W), dim3(1024), lds_bins, st, points, gi, resolutions, g,
@@ -680,7 +690,7 @@ SCANERF_API int scanerf_embedding_bg_backward_binned_adam(const float *points, c
     const AdamEpilogue ad{ nullptr, nullptr, nullptr, 0u, params, exp_avg, exp_avg_sq, half_table, half_dtype, overflow_grad,
                            make_adam_args(lr, beta1, beta2, eps, step) };
     return binned_backward(points, grad_in, overflow_grad, resolutions, N, L, T, grad_layout, workspace, workspace_bytes, &ad, stream,
-                           compact_records != 0);
+                           compact_records);
 }
 
 // Launch-shape hint for the accumulate: which record format the last plan on a workspace chose.  The kernel decodes by the

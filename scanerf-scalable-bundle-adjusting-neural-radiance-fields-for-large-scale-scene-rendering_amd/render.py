@@ -56,6 +56,13 @@ def backward_arith(have_xstash=True, pose_grads=False):
     return ARITH
 
 
+def compact_record_format(arith_code):
+    """`compact_records` of scatter_table_grad_adam for feature gradients out of a backward run under `arith_code`:
+    8-byte records behind t16 (its gradients are f16 products anyway), 12-byte ones behind t16s (f32-grade), else the
+    16-byte ones."""
+    return {_capi.ARITH_T16: 1, _capi.ARITH_T16S: 2}.get(arith_code, 0)
+
+
 def tile_T_columns(S):
     """Columns of the forward's tile_T output: transmittance entering each 16-sample tile."""
     return (S + 15) // 16
@@ -344,10 +351,11 @@ def scatter_table_grad(points, dfeat, grad_features, resolutions):
 
 
 def scatter_table_grad_adam(points, dfeat, resolutions, params, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, step,
-                            half_table=None, overflow_grad=None, compact_records=False):
+                            half_table=None, overflow_grad=None, compact_records=0):
     """scatter_table_grad ending in the fused sparse Adam (no gradient table): the table path of tables too large for the
     backward kernel's own record emission.  overflow_grad: zero table like params (required by the C ABI).
-    compact_records: 8-byte records (for dfeat out of the t16 backward; scatter_common.h Rec8)."""
+    compact_records: 1 = 8-byte records (for dfeat out of the t16 backward; scatter_common.h Rec8), 2 = 12-byte records
+    (f32-grade, behind the t16s backward; Rec12), 0 = 16-byte records."""
     N, (L, T) = points.shape[0], params.shape[:2]
     need = lib().scanerf_embedding_bwd_workspace_bytes(ctypes.c_int(N), ctypes.c_int(L), ctypes.c_int(T))
     if not need:

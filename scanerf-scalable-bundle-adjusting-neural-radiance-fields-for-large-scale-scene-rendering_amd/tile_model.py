@@ -469,7 +469,7 @@ def train_step_fused(model, dec_opt, rays_o, rays_d, target, S, global_step, tab
                 render.scatter_table_grad_adam(pts.contiguous(), dfeat, model.resolution, model.features.data, model.exp_avg,
                                                model.exp_avg_sq, table_lr, 0.9, 0.99, 1e-15, model.adam_step,
                                                half_table=model._half_table, overflow_grad=gtab,
-                                               compact_records=bwd_arith == render._capi.ARITH_T16)
+                                               compact_records=render.compact_record_format(bwd_arith))
             model.adam_step += 1
         elif fused:
             with _sec(timer, "table_grad_accumulate", B * S * 16 * 64):
@@ -593,7 +593,7 @@ def train_step_fgbg(model, dec_opt, rays_o, rays_d, target, S_fg, S_bg, global_s
                 with _sec(timer, "table_grad_scatter_adam", pts.shape[0] * 16 * (8 + 16 * 8)):
                     render.scatter_table_grad_adam(pts, dfe, model.resolution, model.features.data, model.exp_avg, model.exp_avg_sq,
                                                    table_lr, 0.9, 0.99, 1e-15, model.adam_step, overflow_grad=model.overflow_grad(),
-                                                   compact_records=render.backward_arith() == render._capi.ARITH_T16)
+                                                   compact_records=render.compact_record_format(render.backward_arith()))
                 model.adam_step += 1
             else:
                 model.features.grad = gtab

@@ -407,6 +407,37 @@ def test_binned_scatter_matches_oracle_and_atomics(S, layout, log2_T):
         np.testing.assert_allclose(gf.cpu().numpy(), gf_ref, rtol=1e-3, atol=3e-4)
 
 
+@pytest.mark.parametrize("log2_T", [13, 22])
+def test_binned_scatter_adam_record_formats(S, log2_T):
+    """scanerf_embedding_bg_backward_binned_adam's three record formats (compact_records 0 / 1 / 2 = 16- / 8- / 12-byte records,
+    csrc/scatter_common.h) on the same level-major gradients: the first moment after one step (= 0.1 * table gradient) against
+    the oracle's sequential scatter.  16-byte: exact products summed in fixed point; 12-byte: f32 components less 4 bits
+    (2^-20 relative each) and a 23-bit weight; 8-byte: 13-bit significands."""
+    from scanerf_amd import render
+    rng = np.random.default_rng(23)
+    N, L, T = 20011, 16, 2 ** log2_T
+    res = O.level_resolutions(torch.tensor([32, 32, 32]), torch.tensor([2048, 2048, 2048])).numpy()
+    pts = rng.uniform(-2, 2, (N, 3)).astype(np.float32)
+    pts[:50] = 2.0
+    gin = (rng.normal(size=(N, L, 2)) * np.exp(rng.uniform(-6, 0, (N, L, 1)))).astype(np.float32)
+    feat = np.zeros((L, T, 2), np.float32)
+    _, gf_ref = O.embedding_backward(pts, gin, feat, res)
+    P, R, gi = g(pts), g(res), g(np.ascontiguousarray(gin.transpose(1, 0, 2)))
+    scale = float(np.abs(gf_ref).max())
+    lim = {0: 1e-6, 2: 4e-6, 1: 5e-4}
+    moments = {}
+    for fmt in (0, 1, 2):
+        params, m1, m2 = (torch.zeros(L, T, 2, device=DEV) for _ in range(3))
+        over = torch.zeros(L, T, 2, device=DEV)
+        render.scatter_table_grad_adam(P, gi, R, params, m1, m2, 1e-2, 0.9, 0.99, 1e-15, 0, overflow_grad=over, compact_records=fmt)
+        assert not bool(over.any())
+        got = m1.cpu().numpy() * 10.0
+        err = float(np.abs(got - gf_ref).max()) / scale
+        assert err <= lim[fmt], (fmt, err)
+        moments[fmt] = err
+    assert moments[2] < moments[1]   # (the 12-byte records really are the finer ones)
+
+
 @pytest.mark.parametrize("arith", ["h3", "t16", "t16s"])
 @pytest.mark.parametrize("bg,S_", [(False, 64), (True, 40), (False, 128)])
 def test_render_backward_vs_oracle_autograd(S, bg, S_, arith):
