@@ -160,7 +160,13 @@ struct PairSlots {
 __device__ __forceinline__ void reserve_pairs(const Pairs &pr, uint32_t *cursor_level, int bucket_log, PairSlots &sl)
 {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) sl.pos[q] = atomicAdd(&cursor_level[pr.idx0[q] >> bucket_log], 1u);
+    for (int q = 0; q < 4; ++q) {
+#if defined(T16_EMIT_DBG) && (T16_EMIT_DBG & 2)   // timing experiments only: no cursor atomics
+        sl.pos[q] = cursor_level[pr.idx0[q] >> bucket_log] + (threadIdx.x & 15);
+        continue;
+#endif
+        sl.pos[q] = atomicAdd(&cursor_level[pr.idx0[q] >> bucket_log], 1u);
+    }
 }
 __device__ __forceinline__ void commit_pairs(const Pairs &pr, const PairSlots &sl, float gix, float giy, uint32_t *cursor_level,
                                              int bucket_log, uint32_t capacity, Rec *recs, float *grad_level)
@@ -370,7 +376,15 @@ __device__ __forceinline__ void commit_pairs12(const Pairs &pr, const PairSlots 
     for (int q = 0; q < 4; ++q) {
         const float gx = pr.wyz[q] * gix, gy = pr.wyz[q] * giy;
         const float ax = straddle ? a0 * gx : gx, ay = straddle ? a0 * gy : gy;
+#if defined(T16_EMIT_DBG) && (T16_EMIT_DBG & 1)   // timing experiments only: no record stores (the values stay live)
+        if (pos[q] == 0xffffffffu && ax == 1.2345f) store_rec12(recs, 0, pr.idx0[q] & lmask, k, t, ax, ay);
+#elif defined(T16_EMIT_DBG) && (T16_EMIT_DBG == 8)  // one lane's slot, the others next to it: contiguous 768-B runs at fresh addresses
+        store_rec12(recs, (uint32_t)(__builtin_amdgcn_readfirstlane((int)pos[q]) & ~63) + (threadIdx.x & 63u), pr.idx0[q] & lmask, k, t, ax, ay);
+#elif defined(T16_EMIT_DBG) && (T16_EMIT_DBG & 4)  // every lane group's records contiguous whatever the bins (is it the scatter?)
+        store_rec12(recs, ((blockIdx.x * 1024u + (threadIdx.x & 960u)) * 64u + (pos[q] & 15u) * 256u + q * 64u + (threadIdx.x & 63u)), pr.idx0[q] & lmask, k, t, ax, ay);
+#else
         if (pos[q] < capacity) store_rec12(recs, pos[q], pr.idx0[q] & lmask, k, t, ax, ay);
+#endif
         rare |= pos[q] >= capacity;
     }
     if (__builtin_expect(__any(rare), 0)) {
