@@ -54,6 +54,20 @@ def test_argument_validation_without_a_gpu():
     assert lib.scanerf_embedding_bwd_workspace_bytes(1000, 16, 1000) == 0     # not a power of two
 
 
+def test_arithmetic_names_and_record_formats():
+    """The arithmetic codes of include/scanerf_hip.h, their names, the f32-equivalent default, and which record format of the
+    stand-alone binned scatter goes behind which backward (csrc/scatter_common.h: Rec 16 B / Rec8 / Rec12)."""
+    import scanerf_amd  # noqa
+    from scanerf_amd import _capi, render
+    hdr = open(os.path.join(ROOT, "include", "scanerf_hip.h")).read()
+    for name, code in (("F32", 0), ("H3", 1), ("T16", 2), ("T16S", 3)):
+        assert re.search(rf"#define\s+SCANERF_ARITH_{name}\s+{code}\b", hdr), name
+        assert getattr(_capi, f"ARITH_{name}") == code
+    assert render.FP32_EQUIV_ARITH == "t16s" and _capi.T16_FAMILY == (_capi.ARITH_T16, _capi.ARITH_T16S)
+    assert [render.compact_record_format(c) for c in (0, 1, 2, 3)] == [0, 0, 1, 2]
+    assert "11-bit" in render.ARITH_DTYPE["t16"] or "reduced" in render.ARITH_DTYPE["t16"]   # the narrow arithmetic says so in the bench line
+
+
 def test_binding_surface_names_match_the_reference():
     import scanerf_amd  # noqa
     from scanerf_amd.cuda.lib import CUDA_EXT
