@@ -172,6 +172,40 @@ def test_full_size_slice_vs_oracle_autograd(full, first):
     assert l2t < 2e-3 and l2b < 2e-3
 
 
+def test_reference_default_table_size_scatter_adam_conservation_and_formats():
+    """config/default.yaml:2 ships T = 2^24 with 16 384 rays x 128 samples: above 2^21 entries the table gradient goes through
+    the stand-alone binned scatter ending in the sparse Adam (scanerf_embedding_bg_backward_binned_adam).  At that size, on one
+    random point set with level-major gradients spanning 2^-9 .. 1: per (level, feature) the sum of the first moments x 10 (= the
+    table gradient after one step from zero moments) equals the sum of the samples' gradients (the 8 trilinear weights sum to
+    one) -- for the exact 16-byte records and for the 12-byte records that go behind the t16s backward; the two formats agree
+    entry by entry to the records' rounding; the entries that moved are the entries with a gradient; nothing overflowed."""
+    import scanerf_amd  # noqa: F401
+    from scanerf_amd import render
+    N, L, T = 16384 * 128, 16, 1 << 24
+    gen = torch.Generator(device=DEV).manual_seed(24)
+    res = torch.from_numpy(O.level_resolutions(torch.tensor([32, 32, 32]), torch.tensor([2048, 2048, 2048])).numpy()).to(DEV)
+    pts = (torch.rand(N, 3, device=DEV, generator=gen) * 4 - 2).contiguous()
+    dfe = (torch.randn(L, N, 2, device=DEV, generator=gen) * torch.exp2(-9 * torch.rand(L, N, 1, device=DEV, generator=gen))).contiguous()
+    want = dfe.double().sum(1)                                   # [L][2]
+    scale = dfe.double().abs().sum(1)
+    m1s = {}
+    for fmt in (0, 2):
+        params, m1, m2, over = (torch.zeros(L, T, 2, device=DEV) for _ in range(4))
+        render.scatter_table_grad_adam(pts, dfe, res, params, m1, m2, 1e-2, 0.9, 0.99, 1e-15, 0, overflow_grad=over, compact_records=fmt)
+        torch.cuda.synchronize()
+        assert not bool(over.any()), fmt
+        got = m1.double().sum(1) * 10.0
+        err = float(((got - want).abs() / scale).max())
+        assert err <= 2e-6, (fmt, err)                           # (f32 moments: 0.1 g rounded once per entry)
+        assert bool(torch.equal(m1 != 0, params != 0))           # sparse Adam: an entry moves iff it has a gradient
+        m1s[fmt] = m1
+        del params, m2, over
+    diff = float((m1s[0] - m1s[2]).abs().max()) / float(m1s[0].abs().max())
+    assert diff <= 4e-6, diff
+    frac = float((m1s[0][8:] != 0).float().mean())               # hashed levels: 2.1e6 samples x 8 corners over 1.7e7 entries
+    assert 0.3 < frac < 0.8, frac
+
+
 def test_configs0_L8_render_on_the_hip_ops_path():
     """BASELINE.json configs[0]: single 8 m^3 tile, 4 096 random rays x 64 samples, L=8 hash grid (decoder in_channel 16),
     forward only -- at its own size on the HIP path.  The fused kernels hard-code 16 levels like the reference
