@@ -1262,12 +1262,22 @@ def test_forward_counts_the_scatter_plan(S, monkeypatch):
 
 
 @pytest.mark.parametrize("log2_T,scale", [(10, 1.0), (12, 1.0), (21, 1.0), (14, 1e22), (14, 1e-22), (14, 0.0)])
-@_with_arith("t16")
-def test_fused_records_table_sizes_and_gradient_ranges(S, log2_T, scale):
-    """The default (t16, 8-byte records, counts in the forward kernel) table-gradient path at the ends of its geometry -- one
-    bucket per level (T = 2^10, 2^12), 256 buckets per level (2^21) -- and of the value range: upstream gradients scaled by
-    1e22 / 1e-22 (the records carry their own exponent, the image's fixed point follows the launch maximum) and all-zero
-    gradients; half of the rays invalid.  Against the exact scatter of the same dfeat."""
+@pytest.mark.parametrize("arith", ["t16", "t16s"])
+def test_fused_records_table_sizes_and_gradient_ranges(S, log2_T, scale, arith):
+    """The table-gradient path of the 16-sample-tile backward kernels (t16: 8-byte records; t16s, the default: 12-byte records;
+    counts in the forward kernel) at the ends of its geometry -- one bucket per level (T = 2^10, 2^12), 256 buckets per level
+    (2^21) -- and of the value range: upstream gradients scaled by 1e22 / 1e-22 (the records carry their own exponents, the
+    image's fixed point follows the launch maximum) and all-zero gradients; half of the rays invalid.  Against the exact
+    scatter of the same dfeat."""
+    from scanerf_amd import render
+    render.set_arith(arith)
+    try:
+        _fused_records_case(log2_T, scale, arith)
+    finally:
+        render.set_arith(render.DEFAULT_ARITH)
+
+
+def _fused_records_case(log2_T, scale, arith):
     from scanerf_amd import network, render
     from scanerf_amd.tile_model import TileModel
     torch.manual_seed(31)
@@ -1285,7 +1295,7 @@ def test_fused_records_table_sizes_and_gradient_ranges(S, log2_T, scale):
     T = m.features.shape[1]
     tile_T = torch.empty(B, (S_ + 15) // 16, device=DEV)
     xs = torch.empty(B * S_, 32, device=DEV)
-    assert render.backward_arith(True, False) == render._capi.ARITH_T16 and render.forward_plan_supported(B, S_, T)
+    assert render.backward_arith(True, False) == render._ARITH_CODES[arith] and render.forward_plan_supported(B, S_, T)
     out, _, ws = render.render_forward(o, d, z, dist, m.features, m.resolution, m.packed, *box, ray_valid=valid, want_weights=False,
                                        tile_T=tile_T, xstash=xs, plan=True)
     gout = torch.randn(B, 16, device=DEV) * scale
@@ -1306,8 +1316,9 @@ def test_fused_records_table_sizes_and_gradient_ranges(S, log2_T, scale):
     assert sc > 0 and np.isfinite(sc)
     l2 = float(((g2 - g1).double()).norm() / g1.double().norm())
     print(f"T=2^{log2_T}, gradients x {scale:g}: fused records vs dfeat scatter max err {float((g2 - g1).abs().max()) / sc:.2e} of max, relative L2 {l2:.2e}")
-    np.testing.assert_allclose((g2 / sc).cpu().numpy(), (g1 / sc).cpu().numpy(), rtol=5e-4, atol=5e-4)
-    assert l2 < 3e-4
+    tol, l2_lim = (5e-4, 3e-4) if arith == "t16" else (4e-6, 2e-6)   # 13-bit significands / f32 less 4 bits
+    np.testing.assert_allclose((g2 / sc).cpu().numpy(), (g1 / sc).cpu().numpy(), rtol=tol, atol=tol)
+    assert l2 < l2_lim
 
 
 @_with_arith("t16")
