@@ -257,9 +257,20 @@ __device__ __forceinline__ void encode8(const RenderArgs &a, const int *lds_res,
                 jv[3 * ft + 1] = sc[1] * gy;
                 jv[3 * ft + 2] = sc[2] * gz;
             }
+#if defined(JST_DBG) && JST_DBG == 1   // timing experiments only: the Jacobians formed, not stored
+            {
+                uint32_t k0 = pack_f16x2(jv[0], jv[1]), k1 = pack_f16x2(jv[2], jv[3]), k2 = pack_f16x2(jv[4], jv[5]);
+                asm volatile("" :: "v"(k0), "v"(k1), "v"(k2));
+            }
+#elif defined(JST_DBG) && JST_DBG == 2   // timing experiments only: stored, not formed
+            jr[0] = __float_as_uint(f[0].x);
+            jr[64] = __float_as_uint(f[1].x);
+            jr[128] = __float_as_uint(f[2].x);
+#else
             jr[0] = pack_f16x2(jv[0], jv[1]);
             jr[64] = pack_f16x2(jv[2], jv[3]);
             jr[128] = pack_f16x2(jv[4], jv[5]);
+#endif
         }
         if ((j + 1) % GATHER_BATCH == 0) __builtin_amdgcn_sched_barrier(0);  // bound the gathers in flight per lane
     }
