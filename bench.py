@@ -55,6 +55,8 @@ def parse():
     ap.add_argument("--samples", type=int, default=128)
     ap.add_argument("--log2-T", type=int, default=19, help="hash-table entries per level (configs[1]: 19; the reference's default.yaml: 24)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-side-legs", action="store_true",
+                    help="skip the two extra timings of the default run (ops_path_ms_per_step, render_ms_per_frame)")
     ap.add_argument("--dry-run-cpu", action="store_true",
                     help="launcher / collective rehearsal on gloo + CPU tensors: no kernels, no measurement")
     ap.add_argument("--tiles-per-gpu", type=int, default=1,
@@ -280,9 +282,10 @@ def psnr_vs_oracle(samples, B=2048, log2_T=15):
     return 10.0 * float(np.log10(255.0 ** 2 / (mse + 1e-8)))
 
 
-def bench_render(args, world, rank, dev):
+def time_render(args, world, rank, dev, steps, warmup):
     """configs[4] render leg: 4 tiles per GPU (admm_trainer.py:74-83 round-robin), background shells, one 1920x1080 view
-    per step through the multi-tile renderer (rendering.py:286-544 counterpart).  value = rendered rays (pixels) per second."""
+    per step through the multi-tile renderer (rendering.py:286-544 counterpart).  -> (seconds for `steps` frames, MAX over ranks;
+    H, W, ntile, fraction of opaque pixels)."""
     import tempfile
 
     from scanerf_amd import renderer as R
@@ -307,18 +310,23 @@ def bench_render(args, world, rank, dev):
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         rend.render(H, W, K, c2w, num_sample=args.samples, num_bg_sample=args.samples)
     sync()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         out = rend.render(H, W, K, c2w, num_sample=args.samples, num_bg_sample=args.samples)
     sync()
     elapsed = time.perf_counter() - t0
     t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
+    return float(t.item()), H, W, ntile, float((out[3] < 0.5).float().mean())
+
+
+def bench_render(args, world, rank, dev):
+    """`--workload configs4-render`: value = rendered rays (pixels) per second."""
+    elapsed, H, W, ntile, opaque = time_render(args, world, rank, dev, args.steps, args.warmup)
     if rank == 0:
         print(json.dumps({
             "metric": "novel-view render rays/s per GPU (128 samples, L=16 hash)", "value": world * H * W * args.steps / elapsed,
@@ -327,37 +335,95 @@ def bench_render(args, world, rank, dev):
             "dtype": "f32 (f16 tables)", "data": "synthetic",
             "config": {"workload": f"configs[4] render leg: {ntile} tiles per GPU (f16 tables T=2^{args.log2_T}, shell occupancy) + "
                                    f"blended backgrounds, one {W}x{H} view per step, {args.samples} fg + {args.samples} bg samples",
-                       "opaque_fraction": float((out[3] < 0.5).float().mean())}}))
+                       "opaque_fraction": opaque}}))
     if world > 1:
         dist.destroy_process_group()
 
 
-# rocprof kernel names of the timer's sections, per arithmetic (profiles/r03_kernel_stats.txt lists them with their durations)
+def side_legs(args, dev, rays_o, rays_d, target, S, step0):
+    """Two more timings inside the default run, so that they are on the driver's clock too (rank 0, N = 1, configs[1] only;
+    `--no-side-legs` skips them):
+      ops_path_ms_per_step -- the same training iteration through the binding-surface ops one by one (`--path ops`: sampler,
+        `embedding_bg_forward/backward_cuda` via the autograd wrapper, torch decoder, `adam_step_cuda`): the route a caller
+        takes that keeps `tile.py` / `hashgrid/__init__.py` unchanged;
+      render_ms_per_frame -- configs[4]'s render leg (4 resident tiles + backgrounds, one 1920x1080 view)."""
+    from scanerf_amd import tile_model as tm
+    out = {}
+    m = tm.TileModel([-4.0, -4, -4], [8, 8, 8], dev, log2_T=args.log2_T, seed=17, sampler_log2dim=4)
+    opt = torch.optim.Adam(m.decoder.parameters(), lr=1e-3, betas=(0.9, 0.99), eps=1e-15)
+    tm.train_step_ops(m, opt, rays_o, rays_d, target, S, step0)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n_ops = 3
+    for i in range(n_ops):
+        tm.train_step_ops(m, opt, rays_o, rays_d, target, S, step0 + 1 + i)
+    torch.cuda.synchronize()
+    out["ops_path_ms_per_step"] = (time.perf_counter() - t0) / n_ops * 1e3
+    out["ops_path_is"] = (f"`--path ops`: the binding-surface ops called one by one + torch decoder and autograd, {rays_o.shape[0]} rays x {S} "
+                          f"samples, 1 warm-up + {n_ops} timed steps")
+    del m, opt
+    torch.cuda.empty_cache()
+    n_fr = 5
+    elapsed, H, W, ntile, opaque = time_render(args, 1, 0, dev, n_fr, 2)
+    out["render_ms_per_frame"] = elapsed / n_fr * 1e3
+    out["render_is"] = (f"configs[4] render leg: {ntile} resident tiles (f16 tables T=2^{args.log2_T}, shell occupancy) + blended backgrounds, "
+                        f"one {W}x{H} view, {args.samples} + {args.samples} samples, 2 warm-up + {n_fr} timed frames; opaque fraction {opaque:.3f}")
+    torch.cuda.empty_cache()
+    return out
+
+
+# rocprof kernel names of the timer's sections, per arithmetic (profiles/r04_kernel_stats.txt lists them with their durations)
 KERNEL_OF = {
     "render_forward": lambda ar: "k_render_fwd<0>" if ar == "f32" else ("k_render_fwd_h3<0, true, false>" if ar in ("t16", "t16s") else "k_render_fwd_h3<0, false, false>"),
     "render_backward": lambda ar: {"f32": "k_render_bwd<0>", "h3": "k_render_bwd_h3<0>", "t16": "k_render_bwd_t16<0, 1, false, false>",
                                    "t16s": "k_render_bwd_t16<0, 2, false, true>"}[ar],
     "table_grad_accumulate_adam": lambda ar: {"t16": "k_bin_accumulate<512, 32, true, true>", "t16s": "k_bin_accumulate<512, 16, true, true>"}.get(ar, "k_bin_accumulate<256, 32, true, true>"),
 }
+PMC_FILES = ("r04_pmc.json", "r03_pmc.json")   # the newest committed counter file wins
+
+
+def load_pmc():
+    for name in PMC_FILES:
+        try:
+            return json.load(open(os.path.join(ROOT, "profiles", name))), "profiles/" + name
+        except (OSError, ValueError):
+            continue
+    return {}, None
+
+
+def design_bytes(section, rays, S, arith, T):
+    """What THIS design moves per launch, by construction: the denominator of `amplification`.
+    forward: the table gathers (8(d)'s S*L*8*F*4) + rays/z/dists in + x-stash and tile_T out; backward: x-stash, z/dists, per-ray
+    rows in + the scatter records out (4 per (sample, level), 12 / 8 / 16 bytes by arithmetic; bucket straddles add < 1 %);
+    accumulate: the records in + the touched entries of table and both Adam moments read and written (bounded by the table)."""
+    rec = {"t16s": 12, "t16": 8}.get(arith, 16)
+    if section == "render_forward":
+        return {"table_gathers": rays * S * 16 * 8 * 2 * 4, "rays_z_dists_in": rays * (24 + 8 * S),
+                "xstash_out": rays * S * 32 * 4, "tile_T_out_ray_out": rays * (4 * ((S + 15) // 16) + 64)}
+    if section == "render_backward":
+        return {"xstash_in": rays * S * 32 * 4, "rays_z_dists_tile_T_rows_in": rays * (24 + 8 * S + 4 * ((S + 15) // 16) + 128),
+                "records_out": rays * S * 16 * 4 * rec}
+    if section == "table_grad_accumulate_adam":
+        return {"records_in": rays * S * 16 * 4 * rec, "table_and_moments_rmw_upper_bound": 16 * T * 2 * 4 * 3 * 2}
+    return None
 
 
 def roofline(timer, arith, args, B, S, valid_frac, fgbg, ms_per_step):
-    """`roofline` of the JSON line.  For every kernel of the step: the live HIP-event duration, SURVEY.md 8(d)'s algorithmic
-    bytes (strictly: bytes_fwd = 24 + 20 + S*L*8*F*4 per ray for the forward; for the backward + accumulate the reference
-    ALGORITHM's S*L*(8 + 64 + 16*8) = 409 600 B per ray -- grad-in read, feature re-gather, 16 RMW atomics -- which this design
-    does not perform: it is reported because 8(d) defines it, next to what the counters saw), and from the committed rocprofv3
-    passes (profiles/r03_pmc.json: FETCH_SIZE + WRITE_SIZE per launch, matrix-pipe busy cycles, wait cycles) the counter-based
-    fractions.  The top-level fields describe the dominant kernel."""
+    """`roofline` of the JSON line.  Live fields (HIP events of this very run): `avg_launch_ms`, `achieved`, `frac`.  Per kernel of
+    the step: SURVEY.md 8(d)'s algorithmic bytes (strictly: bytes_fwd = 24 + 20 + S*L*8*F*4 per ray for the forward; for the
+    backward the reference ALGORITHM's S*L*(8 + 64 + 16*8) = 409 600 B per ray -- grad-in read, feature re-gather, 16 RMW atomics
+    -- which this design does not perform: reported because 8(d) defines it), `design_bytes` (what this design moves by
+    construction) and, from the COMMITTED rocprofv3 passes (`counters_source`; fields prefixed `rocprof_` / named `traffic*`,
+    `frac_counter`, `mfma_busy`, `wait_any`, `valu_active`, `lds_bank_conflict` are read from that file, NOT measured in this
+    run): `traffic` = FETCH_SIZE + WRITE_SIZE per launch with the guide's x2 FETCH correction applied where the kernel's reads
+    are 16-B-per-lane streams (`fetch_x2` in the file), `amplification` = traffic / design bytes, `frac_at_rocprof_avg` = the 8(d)
+    fraction at the profile's average duration.  The top-level fields describe the dominant kernel."""
     rays = B * valid_frac
     secs = timer.summary()
-    pmc = {}
-    try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc.json")))
-    except (OSError, ValueError):
-        pass
+    pmc, pmc_src = load_pmc()
     same_cfg = args.workload == "configs1" and B == 65536 and S == 128 and args.log2_T == 19 and not args.pose_grads
-    alg = {"render_forward": rays * BYTES_FWD_PER_RAY * S / 128.0,
-           "render_backward": rays * BYTES_BWD_PER_RAY * S / 128.0}
+    alg = {"render_forward": rays * BYTES_FWD_PER_RAY * S / 128.0, "embedding_bg_forward": rays * BYTES_FWD_PER_RAY * S / 128.0,
+           "render_backward": rays * BYTES_BWD_PER_RAY * S / 128.0, "embedding_bg_backward": rays * BYTES_BWD_PER_RAY * S / 128.0}
     kernels = {}
     for name, ms in secs.items():
         k = {"avg_launch_ms": ms}
@@ -367,25 +433,39 @@ def roofline(timer, arith, args, B, S, valid_frac, fgbg, ms_per_step):
             k["algorithmic_bytes"] = alg[name]
             k["achieved_GBps"] = alg[name] / (ms * 1e-3) / 1e9
             k["frac"] = k["achieved_GBps"] / HBM_PEAK_GBS
+        db = design_bytes(name, rays, S, arith, 1 << args.log2_T)
+        if db:
+            k["design_bytes"] = dict(db, total=float(sum(db.values())))
         c = pmc.get("kernels", {}).get(k.get("kernel", ""), None) if same_cfg else None
-        if c:
-            k["traffic"] = c["fetch_bytes"] + c["write_bytes"]
-            k["frac_counter"] = k["traffic"] / (ms * 1e-3) / (HBM_PEAK_GBS * 1e9)
+        if c and "fetch_bytes" in c:
+            k["traffic"] = c.get("traffic_bytes", c["fetch_bytes"] * (2 if c.get("fetch_x2") else 1) + c["write_bytes"])
+            k["traffic_fetch_x2_applied"] = bool(c.get("fetch_x2"))
             k["rocprof_avg_us"] = c.get("avg_us")
+            k["frac_counter"] = k["traffic"] / (c["avg_us"] * 1e-6) / (HBM_PEAK_GBS * 1e9) if c.get("avg_us") else None
+            if db:
+                k["amplification"] = k["traffic"] / k["design_bytes"]["total"]
+            if name in alg and c.get("avg_us"):
+                k["frac_at_rocprof_avg"] = alg[name] / (c["avg_us"] * 1e-6) / (HBM_PEAK_GBS * 1e9)
             for key in ("mfma_busy", "wait_any", "valu_active", "lds_bank_conflict"):
                 if key in c:
                     k[key] = c[key]
         kernels[name] = k
-    name = max((n for n in kernels if "algorithmic_bytes" in kernels[n]), key=lambda n: kernels[n]["avg_launch_ms"])
+    with_alg = [n for n in kernels if "algorithmic_bytes" in kernels[n]]
+    # (a path whose sections carry no 8(d) byte count -- none today -- still gets a line: its slowest section, time only)
+    name = max(with_alg or kernels, key=lambda n: kernels[n]["avg_launch_ms"])
     d = kernels[name]
-    roof = {"bound": "hbm", "achieved": d["achieved_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": d["frac"],
+    roof = {"bound": "hbm", "achieved": d.get("achieved_GBps"), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": d.get("frac"),
             "traffic": d.get("traffic"), "kernel": d.get("kernel", name), "section": name, "avg_launch_ms": d["avg_launch_ms"],
-            "algorithmic_bytes_per_launch": d["algorithmic_bytes"],
+            "algorithmic_bytes_per_launch": d.get("algorithmic_bytes"),
             "algorithmic_bytes_is": ("SURVEY.md 8(d) bytes_bwd: the REFERENCE algorithm's backward traffic (re-gather + 16 RMW atomics per "
-                                     "(sample, level)); this design replaces it by the x-stash + records, see traffic / frac_counter")
-            if name == "render_backward" else "SURVEY.md 8(d) bytes_fwd",
+                                     "(sample, level)); this design replaces it by the x-stash + records: see design_bytes / traffic / frac_counter")
+            if name in ("render_backward", "embedding_bg_backward") else "SURVEY.md 8(d) bytes_fwd",
+            "live_fields": "avg_launch_ms, achieved, frac, kernels.*.avg_launch_ms / achieved_GBps / frac (HIP events of this run)",
+            "frac_at_rocprof_avg": d.get("frac_at_rocprof_avg"), "rocprof_avg_us": d.get("rocprof_avg_us"),
+            "design_bytes_per_launch": (d.get("design_bytes") or {}).get("total"), "amplification": d.get("amplification"),
             "frac_counter": d.get("frac_counter"), "mfma_busy": d.get("mfma_busy"), "wait_any": d.get("wait_any"),
-            "counters_source": "profiles/r03_pmc.json (rocprofv3 --pmc passes of this command; tools/profile_r03.sh)" if "traffic" in d else None,
+            "counters_source": (pmc_src + " (committed rocprofv3 --pmc / --stats passes of this command, tools/profile_bench.sh; NOT measured in "
+                                "this run)") if "traffic" in d else None,
             "kernels": kernels}
     if S == 128:
         whole = rays * (BYTES_FWD_PER_RAY + BYTES_BWD_PER_RAY) * (2 if fgbg else 1)
@@ -394,10 +474,12 @@ def roofline(timer, arith, args, B, S, valid_frac, fgbg, ms_per_step):
     return roof
 
 
-def arith_evidence(samples, B=512, log2_T=14):
+def arith_evidence(samples, B=16384, log2_T=19):
     """Why the headline's arithmetic counts as f32-equivalent: on B rays the fused step's table and decoder gradients under every
     arithmetic against autograd through the oracle (torch f32 on the CPU), as relative L2 errors; and the render's outputs against
-    the oracle's.  Part of the cpu_baseline leg (rank 0, N = 1): the oracle is the checker here."""
+    the oracle's.  B = 16 384 rays on the step's own table size (T = 2^19): thousands of records meet in one coarse entry, as in
+    the timed step (~10 s of host work, ~16 GB of host memory for the oracle's autograd graph).  Part of the cpu_baseline leg
+    (rank 0, N = 1): the oracle is the checker here."""
     import numpy as np
 
     import scanerf_amd  # noqa: F401
@@ -615,6 +697,11 @@ def main():
         }
         if timer and timer.count:
             line["roofline"] = roofline(timer, arith if fused else "f32", args, B, S, valid_frac, fgbg, ms_per_step)
+        if (world == 1 and fused and args.workload == "configs1" and not args.no_side_legs and not args.arith and not args.pose_grads
+                and ntile == 1 and args.scatter == "auto"):
+            del models, dec_opts, model, dec_opt
+            torch.cuda.empty_cache()
+            line.update(side_legs(args, dev, rays_o, rays_d, target, S, step0))
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(S)
             if fused and not occ and not fgbg:

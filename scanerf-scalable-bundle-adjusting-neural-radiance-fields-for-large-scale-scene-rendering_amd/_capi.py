@@ -60,7 +60,32 @@ def lib():
             if not hasattr(l, name):
                 raise RuntimeError(f"scanerf: {LIB_PATH} does not export {name}")
         _lib = l
+        st = audit_state()
+        if st["status"] != "passed":
+            import warnings
+            warnings.warn(f"scanerf: {LIB_PATH} is NOT the audited build (ISA audit: {st['status']}; {st.get('why', '')}).  Its kernels' "
+                          "listings were not checked against the validated ones (csrc/isa_manifest.json, DESIGN.md 4.10: no "
+                          "packed-f32 instructions, pinned listings): launch-to-launch reproducibility is not established for it.",
+                          RuntimeWarning, stacklevel=2)
     return _lib
+
+
+def audit_state():
+    """What tools/isa_audit.py (run by `make`) said about the library file this process loads: {"status": "passed" | "skipped"
+    (built with SCANERF_SKIP_ISA_AUDIT=1) | "failed" | "stale" (the file changed after the audit) | "missing"}."""
+    import hashlib
+    import json
+    side = os.path.join(os.path.dirname(LIB_PATH), "isa_audit.json")
+    if os.environ.get("SCANERF_LIB"):
+        return {"status": "variant", "why": "SCANERF_LIB selects an investigation build (tools/build_variant.py)"}
+    try:
+        st = json.load(open(side))
+    except (OSError, ValueError):
+        return {"status": "missing", "why": f"{side} not found: the library was not built by csrc/Makefile's `all`"}
+    sha = hashlib.sha256(open(LIB_PATH, "rb").read()).hexdigest()
+    if st.get("library_sha256") != sha:
+        return {"status": "stale", "why": "the library file is not the one the audit saw"}
+    return {"status": st.get("status", "missing"), "why": "; ".join(st.get("detail") or [])[:400], "compiler": st.get("compiler")}
 
 
 SWEEP_ICACHE = False   # tests only: evict the instruction caches after every library call (scanerf_icache_sweep)

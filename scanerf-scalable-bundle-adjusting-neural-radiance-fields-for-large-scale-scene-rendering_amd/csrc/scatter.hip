@@ -261,7 +261,10 @@ __global__ void __launch_bounds__(kThreads) k_bin_accumulate(const Rec *__restri
     const uint32_t lo1 = min(starts[blockIdx.x], cap1), hi1 = min(starts[blockIdx.x + 1], cap1);
     const bool two = ADAM && ad.recs2 != nullptr;
     const uint32_t lo2 = two ? min(ad.starts2[blockIdx.x], cap2) : 0u, hi2 = two ? min(ad.starts2[blockIdx.x + 1], cap2) : 0u;
-    const float M = two ? fmaxf(__uint_as_float(*maxbits), __uint_as_float(*ad.maxbits2)) : __uint_as_float(*maxbits);
+    float M = two ? fmaxf(__uint_as_float(*maxbits), __uint_as_float(*ad.maxbits2)) : __uint_as_float(*maxbits);
+    // Rec12 components are ROUNDED to 19 mantissa bits after the maximum was taken (scatter_common.h rec12_round): a value just
+    // below 2^eM may have become 2^eM.  One 19-bit unit on top of the maximum keeps "every |v| < 2^eM" true for the stored values.
+    if (fmt == 2 && M > 0.0f && M < 3.0e38f) M = __uint_as_float(__float_as_uint(M) + 16u);
     const bool overflowed = ADAM && ad.overflow_grad &&
                             (*overflow_flag(const_cast<Rec *>(recs)) != 0u || (two && *overflow_flag(const_cast<Rec *>(ad.recs2)) != 0u));  // uniform
     const uint32_t nrec = (hi1 - lo1) + (hi2 - lo2);
@@ -822,7 +825,7 @@ SCANERF_API int scanerf_render_scatter_accumulate(float *grad_features, int B, i
         hipLaunchKernelGGL((k_bin_accumulate<TH, UU, true>), dim3(nbins), dim3(TH), lds_bytes, (hipStream_t)stream, \
                            w.recs, w.starts, w.maxbits, g, grad_features, AdamEpilogue{});                          \
     }
-    // measured on MI355X (tools/bench_accum.py, 5.4e8 records = 8.6 GB): record i -> lane i (lane-interleaved) 256x8 3.61 ms,
+    // measured on MI355X (tools/bwd_emit_only.py + bench.py's table_grad_accumulate_adam section, 5.4e8 records = 8.6 GB): record i -> lane i (lane-interleaved) 256x8 3.61 ms,
     // 512x8 3.38, 1024x4 3.31; U consecutive records per lane 1024x4 2.21, 512x8 2.34, 1024x8 2.35, 1024x16 2.01-2.06,
     // 512x16 1.86, 256x16 1.86, 128x16 1.82, 512x32 1.95, 256x32 1.73-1.79 (default), 128x32 1.73, 64x32 1.78.  The
     // interleaved forms were bound by same-address serialisation in the LDS (coarse levels), not by the atomic rate itself

@@ -329,7 +329,14 @@ __device__ __forceinline__ void emit_pairs8(const Pairs &pr, float gix, float gi
 //   word1: gx as f32, mantissa rounded to 19 bits; its low 4 bits carry t bits 7:4
 //   word2: gy likewise; low 4 bits = t bits 3:0
 // t = round(tx * 2^23) (23 bits: weight error 2^-24), gradient components 2^-21 relative.
-__device__ __forceinline__ uint32_t rec12_round(float g) { return (__float_as_uint(g) + 8u) & ~15u; }   // (round to nearest on 19 mantissa bits; inf / NaN stay what they are)
+// Round to nearest on 19 mantissa bits, on the bits (add half a unit, clear the low four).  FINITE inputs only mean what they say:
+// +-inf stays +-inf, but a NaN may come out as an infinity, a zero or a finite value (a payload in the low bits is cleared; one
+// near 0x7fffff carries into exponent and sign), so a non-finite gradient does not reliably poison its table entry as a 16-byte
+// record would -- as with Rec8, the loss of such a step is non-finite already and is what a caller has to test.  Testing for the
+// exponent 0xff here would cost ~5 vector instructions per component in the backward kernel's emission (~6 % of its vector work).
+// A finite value just below a power of two may round UP to it: the accumulate takes the launch maximum one 19-bit unit larger
+// for this format (k_bin_accumulate: `M` for fmt == 2), so the fixed-point conversion's |v * 2^k| < 2^51 holds for rounded values.
+__device__ __forceinline__ uint32_t rec12_round(float g) { return (__float_as_uint(g) + 8u) & ~15u; }
 __device__ __forceinline__ void store_rec12(Rec *recs, uint32_t pos, uint32_t l0, uint32_t k, uint32_t t, float gx, float gy)
 {
     struct __attribute__((aligned(4))) W3 { uint32_t a, b, c; };   // (one global_store_dwordx3; 4-byte aligned)

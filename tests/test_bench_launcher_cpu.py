@@ -53,3 +53,53 @@ def test_failing_rank_makes_the_launcher_fail():
     r = _run("--gpus", "2", "--steps", "0", "--dry-run-cpu")
     assert r.returncode != 0
     assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+
+
+class _FakeTimer:   # tile_model.KernelTimer.summary() without a GPU
+    def __init__(self, secs):
+        self.secs = secs
+
+    def summary(self):
+        return dict(self.secs)
+
+
+def _args(**kw):
+    import types
+    base = dict(workload="configs1", log2_T=19, pose_grads=False)
+    base.update(kw)
+    return types.SimpleNamespace(**base)
+
+
+def test_roofline_of_the_ops_path_sections_gives_a_line():
+    # `python bench.py --path ops` records these sections (tile_model.train_step_ops + PyHashGridBG.TIMER); round 3's roofline()
+    # took max() over an empty sequence there and printed no JSON line
+    sys.path.insert(0, ROOT)
+    import bench
+    t = _FakeTimer({"forward_total": 60.0, "backward_total": 80.0, "sparse_adam": 0.06, "embedding_bg_forward": 5.5, "embedding_bg_backward": 7.0})
+    r = bench.roofline(t, "f32", _args(), 65536, 128, 1.0, False, 150.0)
+    assert r["section"] == "embedding_bg_backward" and r["frac"] > 0 and r["traffic"] is None and r["counters_source"] is None
+    # no section with an 8(d) byte count at all: the slowest section, time only
+    r = bench.roofline(_FakeTimer({"forward_total": 60.0, "backward_total": 80.0}), "f32", _args(), 65536, 128, 1.0, False, 150.0)
+    assert r["section"] == "backward_total" and r["frac"] is None and r["achieved"] is None
+    json.dumps(r)
+
+
+def test_roofline_fields_recompute_from_the_committed_counter_file():
+    sys.path.insert(0, ROOT)
+    import bench
+    pmc, src = bench.load_pmc()
+    assert src and src.startswith("profiles/")
+    secs = {"sample_points_grid": 0.13, "render_forward": 3.0, "render_backward": 5.0, "table_grad_accumulate_adam": 1.5}
+    r = bench.roofline(_FakeTimer(secs), "t16s", _args(), 65536, 128, 1.0, False, 9.8)
+    assert r["section"] == "render_backward" and r["kernel"] == "k_render_bwd_t16<0, 2, false, true>"
+    k = r["kernels"]["render_backward"]
+    assert abs(k["frac"] - 65536 * 409600 / 5.0e-3 / 8e12) < 1e-9            # live: 8(d) bytes / live duration / 8 TB/s
+    c = pmc["kernels"][k["kernel"]]
+    want = c.get("traffic_bytes", c["fetch_bytes"] * (2 if c.get("fetch_x2") else 1) + c["write_bytes"])
+    assert k["traffic"] == want and r["traffic"] == want
+    assert abs(k["frac_counter"] - want / (c["avg_us"] * 1e-6) / 8e12) < 1e-9   # counters: traffic / the PROFILE's duration
+    assert abs(k["amplification"] - want / k["design_bytes"]["total"]) < 1e-9
+    assert abs(k["design_bytes"]["records_out"] - 65536 * 128 * 16 * 4 * 12) < 1
+    # another configuration than the profiled one: no counter fields
+    r2 = bench.roofline(_FakeTimer(secs), "t16s", _args(pose_grads=True), 65536, 128, 1.0, False, 9.8)
+    assert r2["traffic"] is None and "frac_counter" not in r2["kernels"]["render_backward"]

@@ -32,6 +32,16 @@ def test_library_exports_every_declared_symbol():
     assert isinstance(lib.scanerf_last_error(), bytes)
 
 
+def test_built_library_carries_its_isa_audit_state():
+    # `make` (csrc/Makefile: all -> audit) leaves lib/isa_audit.json next to the library: the digest of the file the audit saw and
+    # its verdict; a library built with SCANERF_SKIP_ISA_AUDIT=1 says "skipped" and _capi.lib() warns about it
+    import scanerf_amd  # noqa
+    from scanerf_amd import _capi
+    st = _capi.audit_state()
+    assert st["status"] == "passed", st
+    assert "roc-7.2" in st["compiler"] or "7.2" in st["compiler"]
+
+
 def test_argument_validation_without_a_gpu():
     """Shape / pointer validation happens before any launch, so it is testable on CPU."""
     import scanerf_amd  # noqa

@@ -10,6 +10,15 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
+def test_the_library_under_test_is_the_audited_build():
+    """The reproducibility these tests establish belongs to ONE compiled listing per kernel (csrc/isa_manifest.json; no packed-f32
+    arithmetic).  A library built around the audit (SCANERF_SKIP_ISA_AUDIT=1) or changed after it is refused here."""
+    import scanerf_amd  # noqa: F401
+    from scanerf_amd import _capi
+    st = _capi.audit_state()
+    assert st["status"] == "passed", st
+
+
 def _setup(B, S, mode_bg=False):
     import scanerf_amd  # noqa: F401
     from scanerf_amd import network, render

@@ -1,6 +1,7 @@
 """Which per-CU state does the withdrawn forward build's wrong encoder output depend on, and what IS the wrong value?
-(DESIGN.md 4.10.  Run with SCANERF_LIB=<pkg>/lib/debug/libscanerf_hip_opq.so -- `make -C <pkg>/csrc debug-opq` -- for the
-withdrawn build, without it for the shipped one.)
+(DESIGN.md 4.10.  Run with SCANERF_LIB=<pkg>/lib/debug/libscanerf_hip_<tag>.so -- built by
+`tools/build_variant.py <tag> render="-DH3_OPAQUE_ADDR=1 -fslp-vectorize"` -- for the withdrawn build, without it for the shipped
+one.  Needs tools/probe/libstate_poison.so: built here on first use, `hipcc --offload-arch=gfx950 -shared -fPIC`.)
 
 Back-to-back launches of the training forward (plan counts, x-stash, ray mask: k_render_fwd_h3<F32, COUNT>) on the same
 inputs; between two launches ONE of:
@@ -24,7 +25,12 @@ import scanerf_amd  # noqa
 from scanerf_amd import render
 from scanerf_amd.tile_model import TileModel, train_step_fused
 DEV = "cuda:0"
-P = ctypes.CDLL(os.path.join(ROOT, "tools", "probe", "libstate_poison.so"))
+_PSO = os.path.join(ROOT, "tools", "probe", "libstate_poison.so")
+if not os.path.exists(_PSO):   # (git-ignored build product)
+    import subprocess
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-O2", "-o", _PSO,
+                           os.path.join(ROOT, "tools", "probe", "state_poison.hip")])
+P = ctypes.CDLL(_PSO)
 torch.manual_seed(9)
 B, S = int(os.environ.get("B", 8192)), 128
 N = int(os.environ.get("N", 300))

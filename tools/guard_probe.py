@@ -1,7 +1,8 @@
 """Are the wait-state guards of the forward kernel (closed MFMA regions, operand guard, store guard: csrc/common.h, render_h3.h)
 still needed once the kernel holds no packed-f32 arithmetic?  Launch-to-launch comparison of the training forward (x-stash,
 tile_T, plan counts) per table type, back to back and with the instruction caches swept in between.  SCANERF_LIB selects the
-build (make -C <pkg>/csrc debug-opq OPQ_TAG=... OPQ_REGIONS=0/1 OPQ_EXTRA=...)."""
+build: tools/build_variant.py <tag> render="-DH3_OPAQUE_ADDR=1 [-DSCANERF_GUARDS=1 -DH3_REGIONS=1] [-fslp-vectorize ...]" writes
+<pkg>/lib/debug/libscanerf_hip_<tag>.so)."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import scanerf_amd  # noqa

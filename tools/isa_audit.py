@@ -19,6 +19,17 @@ PKG = os.path.join(ROOT, "scanerf-scalable-bundle-adjusting-neural-radiance-fiel
 OBJ = os.path.join(PKG, "lib", "obj")
 MANIFEST = os.path.join(PKG, "csrc", "isa_manifest.json")
 LLVM = "/opt/rocm/lib/llvm/bin"
+LIBSO = os.path.join(PKG, "lib", "libscanerf_hip.so")
+STATE = os.path.join(PKG, "lib", "isa_audit.json")   # the audit's verdict on THIS library file (read by _capi.audit_state())
+
+
+def write_state(status, now, detail=None):
+    """The audit state travels with the library: _capi.audit_state() compares the digest below with the file it loads, warns
+    loudly about a library that was built around the audit (SCANERF_SKIP_ISA_AUDIT=1) or after it, and
+    tests/test_gpu_determinism.py refuses such a build."""
+    sha = hashlib.sha256(open(LIBSO, "rb").read()).hexdigest() if os.path.exists(LIBSO) else None
+    json.dump({"status": status, "library_sha256": sha, "compiler": now["compiler"],
+               "kernels": sum(len(k) for k in now["units"].values()), "detail": detail}, open(STATE, "w"), indent=1)
 UNITS = ["render", "render_bwd_t16", "render_bwd_h3", "render_bwd", "render_time", "scatter", "hashgrid", "rays", "adam", "loss", "compact", "voxelize", "h3_selftest"]
 NO_PACKED_F32_UNITS = tuple(UNITS)
 PACKED = re.compile(r"^v_pk_(mul|add|fma)_f32\b")
@@ -102,9 +113,12 @@ def main():
                "\nRe-validate on the GPU (python -m pytest tests/test_gpu_determinism.py; python tools/fault_probe.py) and then run "
                "tools/isa_audit.py --update; SCANERF_SKIP_ISA_AUDIT=1 builds anyway.")
         if os.environ.get("SCANERF_SKIP_ISA_AUDIT") == "1":
-            print(msg + "\n(SCANERF_SKIP_ISA_AUDIT=1: continuing)", file=sys.stderr)
+            print(msg + "\n(SCANERF_SKIP_ISA_AUDIT=1: continuing; the library is marked UNAUDITED)", file=sys.stderr)
+            write_state("skipped", now, bad)
             return
+        write_state("failed", now, bad)
         raise SystemExit(msg)
+    write_state("passed", now)
     print(f"isa_audit: {sum(len(k) for k in now['units'].values())} kernels match their validated listings")
 
 

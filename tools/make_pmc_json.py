@@ -1,4 +1,4 @@
-"""rocprofv3 output of tools/profile_r03.sh -> the JSON bench.py's `roofline` reads (stdout) and a readable table (stderr).
+"""rocprofv3 output of tools/profile_bench.sh -> the JSON bench.py's `roofline` reads (stdout) and a readable table (stderr).
 Per kernel, per launch: average duration (kernel_stats.csv of the --stats pass), FETCH_SIZE / WRITE_SIZE in bytes (the counters
 report KB: x 1024, MI355X_MICROARCH.md), SQ counters summed over the launch; derived: mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES /
 (1024 SIMDs x duration x SCLK) with the SCLK taken as SQ_BUSY_CYCLES' own clock = 2.1 GHz nominal under load (stated, not
@@ -7,6 +7,10 @@ lds_bank_conflict = SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE."""
 import collections, csv, glob, json, sys
 
 d = sys.argv[1]
+# kernels whose reads are wide coalesced streams (16 B per lane): FETCH_SIZE tallies their 128-B requests at 64 B, so the guide
+# (MI355X_MICROARCH.md, HBM) says to double it.  k_bin_accumulate: the record stream (three aligned 16-byte loads per lane and run);
+# k_render_bwd_t16 / _h3: the x-stash (two float4 per lane).  The forward's reads are scattered 8-byte gathers: uncalibrated, left as read.
+FETCH_X2 = ("k_bin_accumulate", "k_render_bwd_t16", "k_render_bwd_h3")
 KEEP = ("k_render_fwd", "k_render_bwd", "k_bin_accumulate", "k_sample_points_grid", "k_reduce_dw", "k_bin_rowscan", "k_loss")
 
 
@@ -40,8 +44,8 @@ for f in glob.glob(f"{d}/p*/**/*counter_collection.csv", recursive=True):
     for (k, c), (v, n) in acc.items():
         kern[k][c] = v / n
 SCLK = 2.1e9
-out = {"_source": "rocprofv3 --kernel-trace --stats and --pmc passes (separate; tools/profile_r03.sh) of `python3 bench.py --gpus 1 --no-cpu-baseline`: per-launch averages, MI355X, configs[1]",
-       "_corrections": "FETCH_SIZE / WRITE_SIZE: reported KB x 1024 (MI355X_MICROARCH.md); FETCH_SIZE tallies the 128-B requests of 16-B/lane streams as 64 B (the accumulate's record stream: x2 where noted); SQ_* are sums over the launch; mfma_busy assumes SCLK 2.1 GHz under load",
+out = {"_source": "rocprofv3 --kernel-trace --stats and --pmc passes (separate; tools/profile_bench.sh) of `python3 bench.py --gpus 1 --no-cpu-baseline --no-side-legs`: per-launch averages, MI355X, configs[1]",
+       "_corrections": "FETCH_SIZE / WRITE_SIZE: reported KB x 1024 (MI355X_MICROARCH.md); FETCH_SIZE tallies the 128-B requests of 16-B/lane streams as 64 B: traffic_bytes = fetch_bytes x 2 + write_bytes for the kernels marked fetch_x2 (record stream of the accumulate, x-stash of the backward), fetch_bytes + write_bytes otherwise; SQ_* are sums over the launch; mfma_busy assumes SCLK 2.1 GHz under load",
        "kernels": {}}
 for k, v in sorted(kern.items(), key=lambda kv: -kv[1].get("avg_us", 0)):
     e = {"avg_us": v.get("avg_us"), "calls": v.get("calls")}
@@ -49,6 +53,9 @@ for k, v in sorted(kern.items(), key=lambda kv: -kv[1].get("avg_us", 0)):
         e["fetch_bytes"] = v["FETCH_SIZE"] * 1024
     if "WRITE_SIZE" in v:
         e["write_bytes"] = v["WRITE_SIZE"] * 1024
+    if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
+        e["fetch_x2"] = k.startswith(FETCH_X2)
+        e["traffic_bytes"] = e["fetch_bytes"] * (2 if e["fetch_x2"] else 1) + e["write_bytes"]
     for c in ("SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_INSTS_VALU", "SQ_INSTS_MFMA", "SQ_INSTS_LDS", "SQ_INSTS_VMEM", "SQ_INSTS_SALU",
               "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_LDS", "SQ_LDS_IDX_ACTIVE", "SQ_LDS_BANK_CONFLICT",
               "SQ_WAIT_INST_LDS", "SQ_WAIT_INST_ANY", "SQ_BUSY_CYCLES"):

@@ -1,12 +1,12 @@
 #!/bin/bash
 # rocprofv3 passes of the default bench command (separate passes: kernel stats, FETCH_SIZE, WRITE_SIZE, SQ counters) and the
-# JSON bench.py's `roofline` reads (profiles/r03_pmc.json).  Usage (GPU box): tools/profile_r03.sh <outdir under gpurun_out> [bench args]
+# JSON bench.py's `roofline` reads (profiles/rNN_pmc.json).  Usage (GPU box): tools/profile_bench.sh <outdir under gpurun_out> [bench args]
 # (one rank only: bench.py refuses to launch ranks from a profiled process)
 out=$GRAFT_REPO_ROOT/gpurun_out/$1
 shift
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-B="python3 $GRAFT_REPO_ROOT/bench.py --gpus 1 --no-cpu-baseline"
+B="python3 $GRAFT_REPO_ROOT/bench.py --gpus 1 --no-cpu-baseline --no-side-legs"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- $B --steps 10 --warmup 2 "$@" > $out/stats.log 2>&1 || echo "stats pass failed"
 python3 $GRAFT_REPO_ROOT/tools/summarize_prof.py stats $out/stats > $out/kernel_stats.txt 2>&1
 i=0
