@@ -499,11 +499,27 @@ def arith_evidence(samples, B=16384, log2_T=19):
     mn, sz = torch.tensor([-8.0, -8.0, -8.0]), torch.tensor([16.0, 16.0, 16.0])
     F = torch.from_numpy(feat).requires_grad_(True)
     step = 20000
-    ref = O.render_batch_rays(torch.from_numpy(o), torch.from_numpy(d), torch.from_numpy(z), torch.from_numpy(dist_), F, res, sd, O.TRAIN,
-                              lambda x: O.contract_fore(x, mn, sz), step)
     tgt = torch.from_numpy(rng.random((B, 3)).astype(np.float32))
-    (torch.nn.functional.mse_loss(ref["rgb"], tgt) + 0.01 * ref["l2_reg_specular"]).backward()
-    gb_ref, gF_ref = O.pack_blob({k: v.grad for k, v in sd.items()}).numpy(), F.grad.numpy()
+    # The oracle's f32 autograd in chunks of 1 024 rays, gradients summed over the chunks in float64: torch's CPU reductions over all
+    # 2.1e6 samples at once lose ~3e-4 of the decoder gradient to their own f32 running sums (every arithmetic, the exact-f32 kernels
+    # included, then shows the same 2.8e-4 against it); per chunk that error is ~1e-5 and the 16 partial sums add in float64.
+    CH = 1024
+    gb64, gF64, rgb_ref = torch.zeros(O.pack_blob(sd).numel(), dtype=torch.float64), torch.zeros(F.shape, dtype=torch.float64), []
+    for c0 in range(0, B, CH):
+        sl = slice(c0, min(c0 + CH, B))
+        n = sl.stop - sl.start
+        ref = O.render_batch_rays(torch.from_numpy(o[sl]), torch.from_numpy(d[sl]), torch.from_numpy(z[sl]), torch.from_numpy(dist_[sl]), F, res, sd,
+                                  O.TRAIN, lambda x: O.contract_fore(x, mn, sz), step)
+        # mean over all B rays = sum over chunks of (chunk mean) * n / B
+        ((torch.nn.functional.mse_loss(ref["rgb"], tgt[sl]) + 0.01 * ref["l2_reg_specular"]) * (n / B)).backward()
+        gb64 += O.pack_blob({k: v.grad for k, v in sd.items()}).double()
+        gF64 += F.grad.double()
+        rgb_ref.append(ref["rgb"].detach())
+        F.grad = None
+        for v in sd.values():
+            v.grad = None
+    ref = {"rgb": torch.cat(rgb_ref)}
+    gb_ref, gF_ref = gb64.numpy(), gF64.numpy()
     t = lambda a: torch.as_tensor(a).to(dev).contiguous()
     blob = O.pack_blob({k: v.detach() for k, v in sd.items()}).to(dev)
     wf = network.weight_feature(step, dev)
@@ -526,7 +542,8 @@ def arith_evidence(samples, B=16384, log2_T=19):
                        "rgb_max_abs_err_vs_oracle": float((o_r[:, 0:3].cpu() - ref["rgb"].detach()).abs().max())}
     finally:
         render.ARITH = keep
-    out["sample"] = f"{B} rays x {samples} samples, T=2^{log2_T}, oracle = torch f32 autograd on the host (its own rounding ~1e-6)"
+    out["sample"] = (f"{B} rays x {samples} samples, T=2^{log2_T}, oracle = torch f32 autograd on the host in chunks of {CH} rays, chunk gradients "
+                     "summed in float64 (its own rounding ~1e-6)")
     return out
 
 

@@ -27,6 +27,23 @@ using namespace scanerf;
 #define STEP_BARRIER() __syncthreads()
 #endif
 
+// -DT16_STAMPS (investigation builds, tools/build_variant.py; timing only): every wave sums the shader cycles it spends in each
+// interval of the tile loop (23 intervals: emission, forward recompute, compositing, and for each of the 10 workgroup barriers the
+// work before it and the wait in it) and writes the sums to row gridDim.x + blockIdx.x of dw_partial (32 floats per wave;
+// tools/bwd_stamps.py reads them).  s_memtime needs lgkmcnt(0): the stamps sit where the kernel drains the LDS anyway (barriers).
+#ifdef T16_STAMPS
+#define STAMP(i)                                                             \
+    do {                                                                     \
+        __builtin_amdgcn_sched_barrier(0);                                   \
+        const uint32_t now_ = (uint32_t)__builtin_amdgcn_s_memtime();        \
+        stamps[i] += now_ - tlast;                                           \
+        tlast = now_;                                                        \
+        __builtin_amdgcn_sched_barrier(0);                                   \
+    } while (0)
+#else
+#define STAMP(i)
+#endif
+
 namespace {
 
 constexpr int kThreads = 512;
@@ -333,6 +350,12 @@ __global__ void __launch_bounds__(kThreads, 2) k_render_bwd_t16(BwdArgs a)
     int K = 0;                             // gradient scale 2^K of the workgroup (identical in its 8 waves)
     float sc = 1.0f, isc = 1.0f;
 
+#ifdef T16_STAMPS
+    uint32_t stamps[23];
+#pragma unroll
+    for (int i = 0; i < 23; ++i) stamps[i] = 0;
+    uint32_t tlast = (uint32_t)__builtin_amdgcn_s_memtime();
+#endif
     const int ngroups_all = (a.f.B + kWaves - 1) / kWaves;
     for (int grp = blockIdx.x; grp < ngroups_all; grp += gridDim.x) {
         const int ray = kWaves * grp + wv;
@@ -489,6 +512,7 @@ __global__ void __launch_bounds__(kThreads, 2) k_render_bwd_t16(BwdArgs a)
         };
         TileIn nxt = load_tile(nt16 - 1);
         for (int tile = nt16 - 1; tile >= 0; --tile) {
+            STAMP(22);
             const int ln = fresh(lane);               // this tile's lane terms (not loop invariants: see fresh())
             const int c = ln & 15, q = ln >> 4;
             T16Lane L = t16_lane(ln, LD::kStageWave);
@@ -655,6 +679,7 @@ __global__ void __launch_bounds__(kThreads, 2) k_render_bwd_t16(BwdArgs a)
             }
 
             if constexpr (!SPLIT) emit_level(ptile, 3, pdx0, pdx1, ppe);
+            STAMP(0);
 
             // ================= compositing: recompute and adjoint (16-lane scans, identical in the 4 lane groups) =================
             const float ex = live ? expf(-sigma * delta) : 1.0f;  // 1 - alpha
@@ -721,7 +746,9 @@ __global__ void __launch_bounds__(kThreads, 2) k_render_bwd_t16(BwdArgs a)
                 mx = fmaxf(mx, row_ror<1>(mx));
                 if (lane == 0) mxbuf[wv] = mx;
             }
+            STAMP(1);
             STEP_BARRIER();  // ---- S: tile maxima visible; every wave is done with the previous tile's staged operands
+            STAMP(2);
             {   // gradient scale: keep the workgroup's largest |gradient| * 2^K in [2^2, 2^6): with single f16 operands the
                 // 8 tiles' smaller gradients need the room BELOW the maximum (full precision down to 2^-19 of it, subnormal to
                 // 2^-29), the chains' growth through G' <= 6 and the weights the 2^10 above it
@@ -773,7 +800,9 @@ __global__ void __launch_bounds__(kThreads, 2) k_render_bwd_t16(BwdArgs a)
                     stage_put2(stY, L, 2, t16_split(khh[0], khh[1]));   // X operand of the heads' weight gradient: H[:32] in blocks 2, 3 of Y
                     stage_act(stX, L, kv1);     // X operand of the rgb layer's weight gradient: c1 = G(v1)
                 }
+                STAMP(3);
                 STEP_BARRIER();  // ---- A1
+                STAMP(4);
                 if (wv == 0) wgrad<1, true, 1, true>(gW_nar, gB_nar, stage, L, 0, 0, 2);          // heads: x = H[0:16]
                 else if (wv == 1) { float dummy = 0.0f; wgrad<1, false, 1, true>(gW_nar, dummy, stage, L, 0, 0, 3); }   // heads: x = H[16:32]
                 else if (wv < 6) { float dummy = 0.0f; wgrad<1, false, 1, true>(gW_nar, dummy, stage, L, 0, T16_STAGE_MAT, wv - 2); }  // rgb: x = c1 block wv-2
@@ -788,13 +817,17 @@ __global__ void __launch_bounds__(kThreads, 2) k_render_bwd_t16(BwdArgs a)
                     dyS[0] = t16_split(dc[0], dc[1]);
                     dyS[1] = t16_split(dc[2], dc[3]);
                 }
+                STAMP(5);
                 STEP_BARRIER();  // ---- B1
+                STAMP(6);
                 // ================= Directional_MLP.mlp.2 (64 -> 64) =================
                 L = fresh_lane(L);
                 stage_put2(stY, L, 0, dyS[0]);
                 stage_put2(stY, L, 2, dyS[1]);
                 stage_act(stX, L, kv0);
+                STAMP(7);
                 STEP_BARRIER();  // ---- A2
+                STAMP(8);
                 if (cb == 0) wgrad<2, true, 1, true>(gW_D1, gB_D1, stage, L, rb, T16_STAGE_MAT, 0);
                 else { float dummy = 0.0f; wgrad<2, false, 1, true>(gW_D1, dummy, stage, L, rb, T16_STAGE_MAT, 2); }
                 {
@@ -821,7 +854,9 @@ __global__ void __launch_bounds__(kThreads, 2) k_render_bwd_t16(BwdArgs a)
                     dyS[0] = t16_split(dc[0], dc[1]);
                     dyS[1] = t16_split(dc[2], dc[3]);
                 }
+                STAMP(9);
                 STEP_BARRIER();  // ---- B2
+                STAMP(10);
                 // ================= Directional_MLP.mlp.0 (32 of its 48 inputs; the SH part per ray) =================
                 L = fresh_lane(L);
                 stage_put2(stY, L, 0, dyS[0]);
@@ -833,7 +868,9 @@ __global__ void __launch_bounds__(kThreads, 2) k_render_bwd_t16(BwdArgs a)
                     t16_stage_put(stX, L, 2, lo4(shS.hi));
                     t16_stage_put(stX + kLo, L, 2, lo4(shS.lo));
                 }
+                STAMP(11);
                 STEP_BARRIER();  // ---- A3
+                STAMP(12);
                 if (cb == 0) wgrad<2, true, 2, true>(gW_D0, gB_D0, stage, L, rb, T16_STAGE_MAT, 0);   // x = H[32:48] and SH
                 else { float dummy = 0.0f; wgrad<1, false, 1, true>(gW_D0, dummy, stage, L, rb, T16_STAGE_MAT, 1); }   // x = H[48:64]
                 {
@@ -844,7 +881,9 @@ __global__ void __launch_bounds__(kThreads, 2) k_render_bwd_t16(BwdArgs a)
                     dyS[0] = t16_split(dH[0], dH[1]);
                     dyS[1] = t16_split(dH[2], dH[3]);
                 }
+                STAMP(13);
                 STEP_BARRIER();  // ---- B3
+                STAMP(14);
                 // ================= Spatial_MLP.mlp.2 (64 -> 64, linear) =================
                 L = fresh_lane(L);
                 stage_put2(stY, L, 0, dyS[0]);
@@ -856,7 +895,9 @@ __global__ void __launch_bounds__(kThreads, 2) k_render_bwd_t16(BwdArgs a)
                     s16_layer<4, 1>(ku0, lds, T16_L0, L.pos8, &xB);
                 }
                 stage_act(stX, L, ku0);
+                STAMP(15);
                 STEP_BARRIER();  // ---- A4
+                STAMP(16);
                 if (cb == 0) wgrad<2, true, 1, true>(gW_L1, gB_L1, stage, L, rb, T16_STAGE_MAT, 0);
                 else { float dummy = 0.0f; wgrad<2, false, 1, true>(gW_L1, dummy, stage, L, rb, T16_STAGE_MAT, 2); }
                 {
@@ -868,13 +909,17 @@ __global__ void __launch_bounds__(kThreads, 2) k_render_bwd_t16(BwdArgs a)
                     dyS[0] = t16_split(dc[0], dc[1]);
                     dyS[1] = t16_split(dc[2], dc[3]);
                 }
+                STAMP(17);
                 STEP_BARRIER();  // ---- B4
+                STAMP(18);
                 // ================= Spatial_MLP.mlp.0 (32 -> 64) =================
                 L = fresh_lane(L);
                 stage_put2(stY, L, 0, dyS[0]);
                 stage_put2(stY, L, 2, dyS[1]);
                 stage_put2(stX, L, 0, t16_split(xa, xb));
+                STAMP(19);
                 STEP_BARRIER();  // ---- A5
+                STAMP(20);
                 if (cb == 0) wgrad<1, true, 1, true>(gW_L0, gB_L0, stage, L, rb, T16_STAGE_MAT, 0);
                 else { float dummy = 0.0f; wgrad<1, false, 1, true>(gW_L0, dummy, stage, L, rb, T16_STAGE_MAT, 1); }
                 s16_chain<2, 2, 1>(dx, lds, T16_L0, L.trp, dyS);
@@ -1060,6 +1105,7 @@ __global__ void __launch_bounds__(kThreads, 2) k_render_bwd_t16(BwdArgs a)
                 }
             }
             // (no barrier here: the next tile's staging writes come after its barrier S)
+            STAMP(21);
 
             if (tile > 0) nxt = load_tile(tile - 1);   // before this tile's record stores (see load_tile)
             if constexpr (SPLIT) {
@@ -1115,6 +1161,14 @@ __global__ void __launch_bounds__(kThreads, 2) k_render_bwd_t16(BwdArgs a)
         }
     }
 
+#ifdef T16_STAMPS
+    STAMP(22);
+    if (lane == 0) {
+        float *so = a.dw_partial + (size_t)(gridDim.x + blockIdx.x) * SCANERF_PARAMSIZE + wv * 32;
+#pragma unroll
+        for (int i = 0; i < 23; ++i) so[i] = (float)stamps[i];
+    }
+#endif
     if (a.recs) {  // launch-wide max |dL/dfeature| for the fixed-point scale of the accumulate pass
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) gmax = fmaxf(gmax, __shfl_xor(gmax, off, 64));

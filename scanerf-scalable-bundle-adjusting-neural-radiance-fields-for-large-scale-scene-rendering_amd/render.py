@@ -161,6 +161,9 @@ def render_forward(rays_o, rays_d, z_vals, dists, features, resolutions, packed,
     return out_ray, weights
 
 
+_KEEP_DW_PARTIAL = None
+
+
 def render_backward(rays_o, rays_d, z_vals, dists, features, resolutions, packed, weight_feature, min_bbox, bbox_size,
                     contract_mode, infinity, out_ray, tile_T, grad_out, ray_valid=None, grad_blob=None, xstash=None,
                     ray_grad_buffers=None, scatter=None, want_dfeat=True, arith=None, jstash=None, ray_pos_grad=None):
@@ -179,6 +182,8 @@ def render_backward(rays_o, rays_d, z_vals, dists, features, resolutions, packed
     dfeat = torch.empty((16, B * S, 2), dtype=_f32, device=dev) if want_dfeat else None
     nblk = lib().scanerf_render_backward_grid(ctypes.c_int(B))
     dw_partial = torch.empty((4 * nblk, _capi.PARAMSIZE), dtype=_f32, device=dev)
+    if _KEEP_DW_PARTIAL is not None:   # investigation hook (tools/bwd_stamps.py: the -DT16_STAMPS build parks its cycle sums there)
+        _KEEP_DW_PARTIAL[:] = [dw_partial, nblk]
     if grad_blob is None:
         grad_blob = torch.zeros(_capi.PARAMSIZE, dtype=_f32, device=dev)
     cfg = _cfg(min_bbox, bbox_size, contract_mode, infinity, arith)

@@ -246,3 +246,221 @@ def test_configs0_L8_render_on_the_hip_ops_path():
     np.testing.assert_allclose(out["weights"].cpu().numpy(), ref["weights"][..., 0].numpy(), rtol=1e-4, atol=1e-7)
     np.testing.assert_allclose(float(out["l2_reg_specular"]), float(ref["l2_reg_specular"]), rtol=1e-4)
     assert float(ref["weights"].sum(1).max()) > 0.5  # the volume is not empty
+
+
+# ------------------------------------------------------------------ BASELINE.json configs[2] at its own size
+@pytest.fixture(scope="module")
+def cfg2():
+    """configs[2] as bench.py --workload configs2 builds it: 65 536 rays x 128 samples, T = 2^19,
+    sphere-shell occupancy (r = 3 m, 0.5 m thick) at log2dim 7, bf16 gather table over the fp32 master, fused sparse Adam."""
+    import scanerf_amd  # noqa: F401
+    from scanerf_amd.tile_model import TileModel, sphere_shell_occupancy
+    torch.manual_seed(23)
+
+    def make():
+        m = TileModel([-4, -4, -4], [8, 8, 8], DEV, log2_T=LOG2_T, seed=5, sampler_log2dim=7, table_dtype=torch.bfloat16)
+        m.set_occupancy(sphere_shell_occupancy(m, 3.0, 0.5))
+        with torch.no_grad():
+            m.features.mul_(300.0)
+        return m
+
+    o = torch.rand(B, 3, device=DEV) * 8 - 4
+    d = torch.nn.functional.normalize(torch.randn(B, 3, device=DEV), dim=-1) * (0.5 + torch.rand(B, 1, device=DEV))
+    tgt = torch.rand(B, 3, device=DEV)
+    return dict(make=make, o=o, d=d, tgt=tgt, step=20000)
+
+
+def _cfg2_gradients(m, c, valid_extra=None):
+    """sampler -> valid-ray compaction -> forward on the bf16 gather table -> photometric loss -> backward emitting the records
+    -> accumulate into a gradient table (the pieces of train_step_fused, with the gradient table and dfeat kept)."""
+    from scanerf_amd import network, render
+    z, dist = m.sample(c["o"], c["d"], S_)
+    valid = render.ray_valid(z)
+    n, co, cd, ct, cz, cdist = render.compact_rays(valid, c["o"], c["d"], c["tgt"], z, dist)
+    co, cd, ct, cz, cdist = (t[:n].contiguous() for t in (co, cd, ct, cz, cdist))
+    wf = network.weight_feature(c["step"], DEV)
+    m.packed.pack(m.decoder.blob(), wf)
+    box = (m.min_bbox.tolist(), m.bbox_size.tolist(), render.FORE, False)
+    table = m.gather_table()
+    assert table.dtype == torch.bfloat16
+    T = m.features.shape[1]
+    tile_T = torch.empty(n, (S_ + 15) // 16, device=DEV)
+    xs = torch.empty(n * S_, 32, device=DEV)
+    rv = valid_extra(n) if valid_extra else None
+    out, w = render.render_forward(co, cd, cz, cdist, table, m.resolution, m.packed, *box, ray_valid=rv, want_weights=True, tile_T=tile_T, xstash=xs)
+    loss, gout = render.photometric_loss_grad(out, ct, rv, 0.01)
+    ws = render.scatter_plan(co, cd, cz, m.resolution, T, *box, ray_valid=rv)
+    gtab = torch.zeros_like(m.features)
+    dfeat, gblob = render.render_backward(co, cd, cz, cdist, table, m.resolution, m.packed, wf, *box, out, tile_T, gout, ray_valid=rv,
+                                          xstash=xs, scatter=(ws, gtab), want_dfeat=True)
+    render.scatter_accumulate(ws, gtab, n, S_)
+    torch.cuda.synchronize()
+    return dict(n=n, valid=valid, o=co, d=cd, tgt=ct, z=cz, dist=cdist, out=out, w=w, loss=loss, gout=gout, dfeat=dfeat, gtab=gtab, gblob=gblob, wf=wf)
+
+
+def test_configs2_full_size_under_the_default_arithmetic(cfg2):
+    """configs[2] AT ITS OWN SIZE under the default arithmetic (t16s; round 3 tested the configuration at 4 096 x 64, T = 2^14,
+    pinned to h3).  (a) compacting the valid rays == masking them inside the kernels; (b) per (level, feature) the table
+    gradient's sum over entries == the feature gradients' sum over samples; (c) the fused sparse Adam moves an entry iff it has a
+    gradient, and the resident bf16 gather table follows the fp32 master; (d) a 2 048-ray slice of the compacted batch, pushed
+    through the full-size launches with the other rays masked, against torch autograd through the oracle on the bf16-rounded table."""
+    from scanerf_amd import render
+    from scanerf_amd.tile_model import train_step_fused
+    assert render.DEFAULT_ARITH == "t16s" and render.arith_name() == "t16s"
+    c = cfg2
+    # ---- (b) conservation + what has a gradient
+    m = c["make"]()
+    g = _cfg2_gradients(m, c)
+    frac = g["n"] / B
+    assert 0.2 < frac < 0.7, frac            # the shell is met by ~40 % of a random batch: compaction really changes the launch
+    assert torch.isfinite(g["gtab"]).all() and torch.isfinite(g["gblob"]).all()
+    lhs, rhs = g["gtab"].double().sum(1).cpu().numpy(), g["dfeat"].double().sum(1).cpu().numpy()
+    mag = g["dfeat"].double().abs().sum(1).cpu().numpy()
+    np.testing.assert_allclose(lhs, rhs, rtol=0, atol=float(2e-6 * mag.max()))
+    # ---- (a) + (c): one whole training step, compacted and masked, from the same state
+    res = {}
+    for name, kw in (("compact", {"compact_rays": True}), ("masked", {"compact_rays": False})):
+        mm = c["make"]()
+        opt = torch.optim.Adam(mm.decoder.parameters(), lr=1e-3, betas=(0.9, 0.99), eps=1e-15)
+        before = mm.features.detach().clone()
+        loss = float(train_step_fused(mm, opt, c["o"], c["d"], c["tgt"], S_, c["step"], **kw))
+        torch.cuda.synchronize()
+        res[name] = (loss, mm.features.detach().clone(), mm.decoder.blob().detach().clone(), mm._half_table.clone())
+        moved = mm.features.detach() != before
+        if name == "compact":
+            np.testing.assert_allclose(loss, float(g["loss"][0]), rtol=1e-6)
+            # same rays, same arithmetic, same fixed-point image: the entries the epilogue moved are the entries with a gradient
+            # (an entry whose gradient is below ~1e-19 can have a second moment that underflows: allowed to stay, never the reverse)
+            has = g["gtab"] != 0
+            assert not bool((moved & ~has).any()), int((moved & ~has).sum())
+            assert int((has & ~moved).sum()) <= 1e-6 * has.numel(), (int((has & ~moved).sum()), int(has.sum()))
+            assert 0.05 < float(moved[8:].float().mean()) < 0.99   # (hashed levels: 27 000 rays x 128 samples x 8 corners over 5e5 entries)
+        # the resident bf16 gather table is the fp32 master rounded, everywhere
+        assert bool(torch.equal(mm._half_table, mm.features.detach().to(torch.bfloat16)))
+        del mm, opt
+    np.testing.assert_allclose(res["compact"][0], res["masked"][0], rtol=2e-5)
+    # "masked" differs from "compact" in which rays share a workgroup (the backward's power-of-two gradient scale is per
+    # workgroup) and in the record order: updated tables agree except where Adam turns rounding noise on a ~zero gradient into
+    # an lr-sized step
+    dfe = (res["compact"][1] - res["masked"][1]).abs() / res["masked"][1].abs().max()
+    db = float((res["compact"][2] - res["masked"][2]).abs().max() / res["masked"][2].abs().max())
+    n_off = int((dfe > 2e-4).sum())
+    print(f"configs[2] full size: {g['n']} of {B} rays valid; compact vs masked: {n_off} of {dfe.numel()} entries differ by more than 2e-4 of max, "
+          f"largest {float(dfe.max()):.2e}; decoder {db:.2e}")
+    assert n_off <= 1e-5 * dfe.numel() and float(dfe.max()) < 0.05 and db < 2e-4, (n_off, float(dfe.max()), db)
+    # ---- (d) slice vs the oracle's autograd
+    n_sl, first = 2048, g["n"] // 3
+
+    def only_slice(n):
+        v = torch.zeros(n, dtype=torch.bool, device=DEV)
+        v[first:first + n_sl] = True
+        return v
+
+    s = _cfg2_gradients(m, c, only_slice)
+    sl = slice(first, first + n_sl)
+    F = m.gather_table().float().cpu().clone().requires_grad_(True)       # the bf16-rounded table the kernels gathered from
+    sd = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in m.decoder.ref_state_dict().items()}
+    ref = O.render_batch_rays(s["o"][sl].cpu(), s["d"][sl].cpu(), s["z"][sl].cpu(), s["dist"][sl].cpu(), F, m.resolution.cpu(), sd, O.TRAIN,
+                              lambda x: O.contract_fore(x, m.min_bbox, m.bbox_size), c["step"])
+    loss_ref = torch.nn.functional.mse_loss(ref["rgb"], s["tgt"][sl].cpu()) + 0.01 * ref["l2_reg_specular"]
+    loss_ref.backward()
+    np.testing.assert_allclose(float(s["loss"][0]), float(loss_ref.detach()), rtol=1e-4)
+    got = s["out"][sl].cpu().numpy()
+    np.testing.assert_allclose(got[:, 0:3], ref["rgb"].detach().numpy(), rtol=1e-4, atol=5e-6)
+    np.testing.assert_allclose(got[:, 4], ref["T_left"].detach().numpy(), rtol=1e-4, atol=5e-6)
+    np.testing.assert_allclose(s["w"][sl].cpu().numpy(), ref["weights"][..., 0].detach().numpy(), rtol=1e-4, atol=2e-7)
+    gF, gT = F.grad.numpy(), s["gtab"].cpu().numpy()
+    gb_ref, gB = O.pack_blob({k: v.grad for k, v in sd.items()}).numpy(), s["gblob"].cpu().numpy()
+    fs, bs = np.abs(gF).max(), np.abs(gb_ref).max()
+    l2t, l2b = np.linalg.norm(gT - gF) / np.linalg.norm(gF), np.linalg.norm(gB - gb_ref) / np.linalg.norm(gb_ref)
+    print(f"configs[2] slice: table gradient max err {np.abs(gT - gF).max() / fs:.2e} of max, rel L2 {l2t:.2e}; decoder max err "
+          f"{np.abs(gB - gb_ref).max() / bs:.2e}, rel L2 {l2b:.2e}")
+    np.testing.assert_allclose(gT / fs, gF / fs, rtol=2e-3, atol=2e-5)
+    np.testing.assert_allclose(gB / bs, gb_ref / bs, rtol=2e-3, atol=2e-5)
+    assert l2t < 1e-4 and l2b < 1e-4
+
+
+# ------------------------------------------------------------------ BASELINE.json configs[4], the legs one GPU runs
+def test_configs4_four_resident_tiles_round_robin_equals_each_alone():
+    """configs[4] keeps 4 tiles resident per GPU and steps them round-robin (bench.py --tiles-per-gpu 4; the reference swaps them
+    through host memory, tile.py:574-636).  The tiles share every scratch buffer (plan workspace, record stream, packed-decoder
+    workspace per model): two rounds over the four tiles must leave every tile EXACTLY where two steps of that tile alone leave
+    it -- tables, Adam moments, decoders, bit for bit -- at the benchmark's size under the default arithmetic."""
+    import scanerf_amd  # noqa: F401
+    from scanerf_amd.tile_model import TileModel, train_step_fused
+    torch.manual_seed(41)
+    o = torch.rand(B, 3, device=DEV) * 8 - 4
+    d = torch.nn.functional.normalize(torch.randn(B, 3, device=DEV), dim=-1) * (0.5 + torch.rand(B, 1, device=DEV))
+    tgt = torch.rand(B, 3, device=DEV)
+
+    def make(t):
+        m = TileModel([-4, -4, -4], [8, 8, 8], DEV, log2_T=LOG2_T, seed=100 + t)
+        return m, torch.optim.Adam(m.decoder.parameters(), lr=1e-3, betas=(0.9, 0.99), eps=1e-15)
+
+    def state(m):
+        return [m.features.detach().clone(), m.exp_avg.clone(), m.exp_avg_sq.clone(), m.decoder.blob().detach().clone()]
+
+    rr = [make(t) for t in range(4)]
+    for i in range(8):
+        m, opt = rr[i % 4]
+        train_step_fused(m, opt, o, d, tgt, S_, 20000 + i // 4)
+    torch.cuda.synchronize()
+    for t in range(4):
+        m, opt = make(t)
+        init = m.features.detach().clone()
+        for k in range(2):
+            train_step_fused(m, opt, o, d, tgt, S_, 20000 + k)
+        torch.cuda.synchronize()
+        for a_, b_, what in zip(state(rr[t][0]), state(m), ("table", "exp_avg", "exp_avg_sq", "decoder")):
+            assert torch.equal(a_, b_), (t, what, float((a_ - b_).abs().max()))
+        assert float((m.features.detach() - init).abs().max()) > 0
+        del m, opt
+
+
+def test_configs4_full_hd_frame_is_bit_reproducible_and_a_crop_matches_the_oracle_loop(tmp_path):
+    """configs[4]'s render leg as bench.py --workload configs4-render builds it: 4 tiles (f16 tables, T = 2^19, shell occupancy
+    at log2dim 7) + blended backgrounds, one 1920 x 1080 view, 128 + 128 samples.  Two renders of the frame agree bit for bit;
+    a 24 x 32 crop across a shell's silhouette equals the oracle's restatement of rendering.py:286-544 on those rays (1e-4)."""
+    import scanerf_amd  # noqa: F401
+    from scanerf_amd import renderer as R
+    from scanerf_amd import tile_model as tm
+    from test_gpu_render_time import oracle_render_loop
+    H, W, ntile = 1080, 1920, 4
+    tiles = []
+    for t in range(ntile):
+        m = tm.TileModel([-4.0 * ntile + 8.0 * t, -4, -4], [8, 8, 8], DEV, log2_T=LOG2_T, seed=t, sampler_log2dim=7)
+        m.set_occupancy(tm.sphere_shell_occupancy(m, 3.0, 0.5))
+        with torch.no_grad():
+            m.features.mul_(300.0)
+        R.export_tile(str(tmp_path / f"tile{t}"), m)
+        tiles.append(R.load_tile(str(tmp_path / f"tile{t}")))
+        del m
+    rend = R.TileSetRenderer(DEV, tiles)
+    K = np.float32([1600.0, 0, W / 2, 0, 1600.0, H / 2, 0, 0, 1])
+    c2w = np.float32([[1.0, 0, 0, 0.0], [0, 1, 0, 0.5], [0, 0, 1, -14.0]])
+    f1 = rend.render(H, W, K, c2w, num_sample=128, num_bg_sample=128)
+    f2 = rend.render(H, W, K, c2w, num_sample=128, num_bg_sample=128)
+    for a_, b_ in zip(f1, f2):
+        assert torch.equal(a_, b_)
+        assert torch.isfinite(a_).all()
+    dif, spec, depth, transp = f1
+    opaque = (transp[..., 0] < 0.5)
+    assert 0.02 < float(opaque.float().mean()) < 0.5
+    # a crop across a silhouette: the row with the most opaque pixels, centred on its first opaque pixel
+    r0 = int(opaque.sum(1).argmax())
+    c0 = int(opaque[r0].float().argmax())
+    r0, c0 = min(max(r0 - 12, 0), H - 24), min(max(c0 - 16, 0), W - 32)
+    o_all, d_all = rend.compute_rays(H, W, K, c2w)
+    idx = (torch.arange(r0, r0 + 24, device=DEV)[:, None] * W + torch.arange(c0, c0 + 32, device=DEV)[None, :]).reshape(-1)
+    o, d = o_all[idx].cpu().numpy(), d_all[idx].cpu().numpy()
+    ref = oracle_render_loop(rend, o, d, 128, 128)
+    assert ref["T"].min() < 0.5 < ref["T"].max(), "the crop must contain both opaque and empty pixels"
+    n = idx.numel()
+    crop = lambda a: a.reshape(H * W, -1)[idx].cpu().numpy()
+    np.testing.assert_allclose(crop(transp), ref["T"], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(crop(dif), ref["dif"], rtol=1e-4, atol=3e-6)
+    np.testing.assert_allclose(crop(spec), ref["spec"], rtol=1e-4, atol=3e-6)
+    np.testing.assert_allclose(crop(depth), ref["depth"], rtol=1e-4, atol=1e-3 * max(1.0, float(np.abs(ref["depth"]).max()) / 100))
+    img_a = np.clip(crop(dif) + crop(spec), 0, 1).reshape(24, 32, 3) * 255
+    img_b = np.clip(ref["dif"] + ref["spec"], 0, 1).reshape(24, 32, 3) * 255
+    assert O.psnr(img_a, img_b) > 80.0 and n == 768

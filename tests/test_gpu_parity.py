@@ -871,8 +871,9 @@ def _fused_and_ops_agree():
     assert g_o.shape == (B, 3) and torch.isfinite(g_o).all() and torch.isfinite(g_d).all() and float(g_d.abs().max()) > 0
 
 
+@pytest.mark.parametrize("arith", ["h3", "t16s"])
 @pytest.mark.parametrize("table_dtype", [torch.float32, torch.bfloat16])
-def test_training_step_sparse_occupancy_compaction(S, table_dtype):
+def test_training_step_sparse_occupancy_compaction(S, table_dtype, arith):
     """BASELINE configs[2] shape of the iteration: sphere-shell occupancy (most rays of a random batch miss it), optional
     bf16 gather table.  Compacting the valid rays before the fused kernels (what the reference does: rays_o[valid]) must give
     the same loss and updates as masking them inside the kernels, and -- fp32 table -- the same as the op-by-op iteration."""
@@ -880,8 +881,9 @@ def test_training_step_sparse_occupancy_compaction(S, table_dtype):
     from scanerf_amd.tile_model import TileModel, sphere_shell_occupancy, train_step_fused, train_step_ops
     # Adam normalises every entry's step to ~lr whatever the gradient's size, so entries whose gradient is smaller than the
     # arithmetic's noise move by +-lr at random: the comparison of UPDATED tables below is meaningful only with the
-    # low-noise backward arithmetic (h3: 5e-6 of max; t16's 5e-4 flips such entries).  t16 is covered by the gradient tests.
-    render.set_arith("h3")
+    # low-noise backward arithmetics (h3 and the default t16s: 5e-6 of max; t16's 5e-4 flips such entries).  t16 is covered by the
+    # gradient tests.
+    render.set_arith(arith)
     try:
         _compaction_equivalence(table_dtype, TileModel, sphere_shell_occupancy, train_step_fused, train_step_ops)
     finally:

@@ -43,6 +43,40 @@ def _rays(rng, B):
     return o, d.astype(np.float32)
 
 
+def oracle_render_loop(rnd, o, d, num_sample, num_bg_sample):
+    """rendering.py:286-544's loop on the oracle's restatement of the render-time kernels, over the renderer's own scene arrays
+    (numpy rays o, d [B,3]) -> {"dif", "spec", "depth", "T"}: what TileSetRenderer.render_rays must reproduce."""
+    B = o.shape[0]
+    corners, sizes = rnd.block_corner.cpu().numpy(), rnd.block_size.cpu().numpy()
+    occ, fake = rnd.occupied_grid.cpu().numpy(), rnd.fake_occupied_grid.cpu().numpy()
+    starts, l2d = rnd.grid_starts.cpu().numpy(), rnd.grid_log2dim.cpu().numpy()
+    tabs, par, res = rnd.feature_tables.cpu().numpy(), rnd.params.cpu().numpy(), rnd.resolution.cpu().numpy()
+    inter = O.ray_block_intersection(o, d, corners, sizes)
+    tb = np.argsort(inter[..., 0], axis=-1, kind="stable").astype(np.int32)
+    max_tracing = int((inter != 1e7).astype(np.float32).mean(-1).sum(-1).max())
+    T_, dF, sF, zF = np.ones((B, 1), np.float32), np.zeros((B, 3), np.float32), np.zeros((B, 3), np.float32), np.zeros((B, 1), np.float32)
+    ti, zs = np.zeros(B, np.int32), np.zeros(B, np.float32)
+    for _ in range(max_tracing):
+        running = (ti < max_tracing) & (T_[:, 0] > 1e-5)
+        if running.sum() == 0:
+            break
+        z, dd = O.render_sample_points(o, d, corners, sizes, fake, starts, l2d, num_sample, tb, inter, ti, zs)
+        bi = O.prepare_points(z, running, inter)
+        pd, ps, pa = O.pts_inference(o, d, z, dd, bi, tabs, par, res, occ, starts, l2d, corners, sizes)
+        O.accumulate_color(pd, ps, pa, T_, z, dF, sF, zF)
+    ob, bw = O.update_outgoing_bidx(o, d, corners, sizes, tb, inter, 0.12, False)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        bwn = np.nan_to_num(bw / bw.sum(-1, keepdims=True))
+    bd, bs, bz = np.zeros((B, 3), np.float32), np.zeros((B, 3), np.float32), np.zeros((B, 1), np.float32)
+    for i in range(int((bwn > 0).sum(-1).max())):
+        zb = O.render_inverse_z_sampling(inter, ob[:, i], num_bg_sample, 1e6)
+        pd, ps, pa = O.bg_pts_inference_v2(o, d, zb, ob, i, corners, sizes, res, tabs, par)
+        t1, td, ts, tz = np.ones((B, 1), np.float32), np.zeros((B, 3), np.float32), np.zeros((B, 3), np.float32), np.zeros((B, 1), np.float32)
+        O.accumulate_color(pd, ps, pa, t1, zb, td, ts, tz)
+        bd += td * bwn[:, i:i + 1]; bs += ts * bwn[:, i:i + 1]; bz += tz * bwn[:, i:i + 1]
+    return {"dif": dF + T_ * bd, "spec": sF + T_ * bs, "depth": zF + T_ * bz, "T": T_}
+
+
 def test_render_loop_stage_by_stage():
     import scanerf_amd  # noqa
     from scanerf_amd import hashgrid as H
@@ -287,35 +321,8 @@ def test_renderer_end_to_end_and_tile_formats(tmp_path):
     o_ref, d_ref = O.compute_ray_forward(np.stack([np.zeros(H * W), np.tile(np.arange(W), H), np.repeat(np.arange(H), W)], 1),
                                          K.reshape(1, 9), c2w.reshape(1, 12))
     assert np.array_equal(o, o_ref) and np.array_equal(d, d_ref)
-    corners, sizes = rnd.block_corner.cpu().numpy(), rnd.block_size.cpu().numpy()
-    occ, fake = rnd.occupied_grid.cpu().numpy(), rnd.fake_occupied_grid.cpu().numpy()
-    starts, l2d = rnd.grid_starts.cpu().numpy(), rnd.grid_log2dim.cpu().numpy()
-    tabs, par, res = rnd.feature_tables.cpu().numpy(), rnd.params.cpu().numpy(), rnd.resolution.cpu().numpy()
     B = H * W
-    inter = O.ray_block_intersection(o, d, corners, sizes)
-    tb = np.argsort(inter[..., 0], axis=-1, kind="stable").astype(np.int32)
-    max_tracing = int((inter != 1e7).astype(np.float32).mean(-1).sum(-1).max())
-    T_, dF, sF, zF = np.ones((B, 1), np.float32), np.zeros((B, 3), np.float32), np.zeros((B, 3), np.float32), np.zeros((B, 1), np.float32)
-    ti, zs = np.zeros(B, np.int32), np.zeros(B, np.float32)
-    for _ in range(max_tracing):
-        running = (ti < max_tracing) & (T_[:, 0] > 1e-5)
-        if running.sum() == 0:
-            break
-        z, dd = O.render_sample_points(o, d, corners, sizes, fake, starts, l2d, 64, tb, inter, ti, zs)
-        bi = O.prepare_points(z, running, inter)
-        pd, ps, pa = O.pts_inference(o, d, z, dd, bi, tabs, par, res, occ, starts, l2d, corners, sizes)
-        O.accumulate_color(pd, ps, pa, T_, z, dF, sF, zF)
-    ob, bw = O.update_outgoing_bidx(o, d, corners, sizes, tb, inter, 0.12, False)
-    with np.errstate(invalid="ignore", divide="ignore"):
-        bwn = np.nan_to_num(bw / bw.sum(-1, keepdims=True))
-    bd, bs, bz = np.zeros((B, 3), np.float32), np.zeros((B, 3), np.float32), np.zeros((B, 1), np.float32)
-    for i in range(int((bwn > 0).sum(-1).max())):
-        zb = O.render_inverse_z_sampling(inter, ob[:, i], 32, 1e6)
-        pd, ps, pa = O.bg_pts_inference_v2(o, d, zb, ob, i, corners, sizes, res, tabs, par)
-        t1, td, ts, tz = np.ones((B, 1), np.float32), np.zeros((B, 3), np.float32), np.zeros((B, 3), np.float32), np.zeros((B, 1), np.float32)
-        O.accumulate_color(pd, ps, pa, t1, zb, td, ts, tz)
-        bd += td * bwn[:, i:i + 1]; bs += ts * bwn[:, i:i + 1]; bz += tz * bwn[:, i:i + 1]
-    ref = {"dif": dF + T_ * bd, "spec": sF + T_ * bs, "depth": zF + T_ * bz, "T": T_}
+    ref = oracle_render_loop(rnd, o, d, 64, 32)
     assert ref["T"].min() < 0.5 < ref["T"].max(), "view must contain both opaque and empty pixels"
     np.testing.assert_allclose(transp.cpu().numpy().reshape(B, 1), ref["T"], rtol=1e-4, atol=1e-6)
     np.testing.assert_allclose(dif.cpu().numpy().reshape(B, 3), ref["dif"], rtol=1e-4, atol=3e-6)
