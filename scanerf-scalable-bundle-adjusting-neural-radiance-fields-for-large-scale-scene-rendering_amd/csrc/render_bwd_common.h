@@ -24,6 +24,8 @@ struct BwdArgs {
     Rec *recs;
     uint32_t *maxbits;
     float *grad_features;      // only touched if the record workspace overflows
+    int park;                  // t16s kernel: waves 4-7 park a tile's feature gradients in LDS and emit its records behind the NEXT
+                               // tile's forward recompute (render_bwd_t16.hip "skewed emission"); set by its launcher when the LDS has room
 };
 
 __device__ __forceinline__ float dgauss(float u, float a) { return -100.0f * u * a; }  // d/du exp(-50 u^2)

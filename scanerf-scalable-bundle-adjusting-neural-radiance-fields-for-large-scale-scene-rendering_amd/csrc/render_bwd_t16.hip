@@ -44,6 +44,13 @@ using namespace scanerf;
 #define STAMP(i)
 #endif
 
+// where the t16s kernel issues the NEXT tile's input loads: 0 = at the tile's end (before the record stores), 2..5 = right behind
+// barrier A2..A5 (earlier: the loads of the second wave of a SIMD otherwise queue behind the first wave's record stores)
+// (measured, plan + backward at configs[1], same box: 0: 5.53-5.56 ms, 5: 5.45, 4: 5.44-5.45, 3: 5.42-5.48)
+#ifndef T16_LOAD_AT
+#define T16_LOAD_AT 4
+#endif
+
 namespace {
 
 constexpr int kThreads = 512;
@@ -59,7 +66,9 @@ struct Lds {
     static constexpr int kSh = kDinit + kWaves * 256;             // 8 waves x SH[16]
     static constexpr int kMx = kSh + kWaves * 64;                 // 8 floats
     static constexpr int kStage = kMx + 64;                       // 8 waves x staging
-    static constexpr int kCursor = kStage + kWaves * kStageWave;  // record cursors (fused scatter producer only)
+    static constexpr int kPark = kStage + kWaves * kStageWave;    // (SPLIT, a.park) waves 4-7: a tile's dX, 64 lanes x 32 B per wave
+    static constexpr int kParkBytes = 4 * 2048;
+    static constexpr int kCursor = kPark;                         // record cursors (fused scatter producer only); + kParkBytes when parking
     static_assert(kStage % 16 == 0 && kCursor % 16 == 0, "LDS carve alignment");
 };
 
@@ -313,7 +322,7 @@ __global__ void __launch_bounds__(kThreads, 2) k_render_bwd_t16(BwdArgs a)
     using LD = Lds<SPLIT>;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     int *lres = reinterpret_cast<int *>(lds + LD::kRes);
-    uint32_t *cursor = reinterpret_cast<uint32_t *>(lds + LD::kCursor);
+    uint32_t *cursor = reinterpret_cast<uint32_t *>(lds + LD::kCursor + (SPLIT && a.park ? LD::kParkBytes : 0));
     float *shbuf = reinterpret_cast<float *>(lds + LD::kSh);
     float *mxbuf = reinterpret_cast<float *>(lds + LD::kMx);
     {
@@ -355,6 +364,13 @@ __global__ void __launch_bounds__(kThreads, 2) k_render_bwd_t16(BwdArgs a)
 #pragma unroll
     for (int i = 0; i < 23; ++i) stamps[i] = 0;
     uint32_t tlast = (uint32_t)__builtin_amdgcn_s_memtime();
+#endif
+#ifdef T16_WG_STAGGER   // experiment: workgroups start T16_WG_STAGGER x 64 cycles apart in 8 phases (their record bursts then do not coincide chip-wide)
+    for (int i = 0; i < (int)((blockIdx.x >> 3) & 7u); ++i) __builtin_amdgcn_s_sleep(T16_WG_STAGGER);
+#endif
+#ifdef T16_SKEW_START   // timing experiments only (with -DT16_NO_BARRIER): the second wave of every SIMD starts T16_SKEW_START x 8 128 cycles late
+    if (wv >= 4)
+        for (int i = 0; i < T16_SKEW_START; ++i) __builtin_amdgcn_s_sleep(127);
 #endif
     const int ngroups_all = (a.f.B + kWaves - 1) / kWaves;
     for (int grp = blockIdx.x; grp < ngroups_all; grp += gridDim.x) {
@@ -483,6 +499,29 @@ __global__ void __launch_bounds__(kThreads, 2) k_render_bwd_t16(BwdArgs a)
         v4f pdx0 = { 0, 0, 0, 0 }, pdx1 = { 0, 0, 0, 0 };   // the previous tile's dX, emitted during this one
         float ppe[3] = { 0, 0, 0 };                         // ... and its samples' contracted positions (computed once per tile)
         int ptile = -1;
+        // SKEWED EMISSION (SPLIT, a.park).  All 8 waves storing their 16 x 64 records at the same moment is 128 fully divergent
+        // stores = ~8 000 cycles of the CU's address path (one 64-B line per clock) while nothing else runs: the interval was
+        // 27 % of the kernel, the younger wave of every SIMD finished it 4 400 cycles after the older one and the older ones
+        // waited that long in barrier S (tools/bwd_stamps.py).  Waves 4-7 (the second wave of every SIMD) therefore PARK their
+        // tile's dX in LDS (8 KB; the registers to carry it through the forward recompute do not exist) and emit
+        // its records behind the next tile's compositing, right before barrier S; waves 0-3 emit at the tile's end as before.
+        // Each SIMD then always has one wave in vector work while the other's stores drain, and the bursts halve.
+        const bool park_wave = SPLIT && a.park && wv >= 4;   // wave-uniform
+        float pz = 0.0f;                                     // sample depth of the parked tile (its position is formed again)
+        auto emit_parked = [&]() {
+            if constexpr (SPLIT) {
+                if (ptile < 0) return;
+                const int lp = fresh(lane);
+                const float4 *pk = reinterpret_cast<const float4 *>(lds + LD::kPark + (wv - 4) * 2048);
+                const float4 p0 = pk[lp], p1 = pk[64 + lp];
+                const v4f e0 = { p0.x, p0.y, p0.z, p0.w }, e1 = { p1.x, p1.y, p1.z, p1.w };
+                float pe[3] = { 0, 0, 0 };
+                if (a.recs) contract_point(a.f, o, d, pz, pe);
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) emit_level(ptile, jj, e0, e1, pe);
+                ptile = -1;
+            }
+        };
 
         // A tile's inputs are loaded ONE TILE AHEAD, before the previous tile's records are stored: vector-memory operations
         // complete in issue order, so a load issued behind the 16 record stores of a tile would not return before they
@@ -513,6 +552,14 @@ __global__ void __launch_bounds__(kThreads, 2) k_render_bwd_t16(BwdArgs a)
         TileIn nxt = load_tile(nt16 - 1);
         for (int tile = nt16 - 1; tile >= 0; --tile) {
             STAMP(22);
+#ifdef T16_DUMMY_VALU_TOP   // timing experiment: is the kernel bound by vector issue?  N dependent-free vector instructions per tile
+            {
+                float dmy = 1.0f;
+#pragma unroll
+                for (int i = 0; i < T16_DUMMY_VALU_TOP; ++i) asm volatile("v_mul_f32 %0, 1.0, %0" : "+v"(dmy));
+                asm volatile("" ::"v"(dmy));
+            }
+#endif
             const int ln = fresh(lane);               // this tile's lane terms (not loop invariants: see fresh())
             const int c = ln & 15, q = ln >> 4;
             T16Lane L = t16_lane(ln, LD::kStageWave);
@@ -746,6 +793,7 @@ __global__ void __launch_bounds__(kThreads, 2) k_render_bwd_t16(BwdArgs a)
                 mx = fmaxf(mx, row_ror<1>(mx));
                 if (lane == 0) mxbuf[wv] = mx;
             }
+            if (park_wave) emit_parked();   // the previous tile's records (see "skewed emission")
             STAMP(1);
             STEP_BARRIER();  // ---- S: tile maxima visible; every wave is done with the previous tile's staged operands
             STAMP(2);
@@ -828,6 +876,7 @@ __global__ void __launch_bounds__(kThreads, 2) k_render_bwd_t16(BwdArgs a)
                 STAMP(7);
                 STEP_BARRIER();  // ---- A2
                 STAMP(8);
+                if (T16_LOAD_AT == 2 && tile > 0) nxt = load_tile(tile - 1);   // (early: see load_tile)
                 if (cb == 0) wgrad<2, true, 1, true>(gW_D1, gB_D1, stage, L, rb, T16_STAGE_MAT, 0);
                 else { float dummy = 0.0f; wgrad<2, false, 1, true>(gW_D1, dummy, stage, L, rb, T16_STAGE_MAT, 2); }
                 {
@@ -857,6 +906,14 @@ __global__ void __launch_bounds__(kThreads, 2) k_render_bwd_t16(BwdArgs a)
                 STAMP(9);
                 STEP_BARRIER();  // ---- B2
                 STAMP(10);
+#ifdef T16_DUMMY_VALU_MID
+                {
+                    float dmy = 1.0f;
+#pragma unroll
+                    for (int i = 0; i < T16_DUMMY_VALU_MID; ++i) asm volatile("v_mul_f32 %0, 1.0, %0" : "+v"(dmy));
+                    asm volatile("" ::"v"(dmy));
+                }
+#endif
                 // ================= Directional_MLP.mlp.0 (32 of its 48 inputs; the SH part per ray) =================
                 L = fresh_lane(L);
                 stage_put2(stY, L, 0, dyS[0]);
@@ -871,6 +928,7 @@ __global__ void __launch_bounds__(kThreads, 2) k_render_bwd_t16(BwdArgs a)
                 STAMP(11);
                 STEP_BARRIER();  // ---- A3
                 STAMP(12);
+                if (T16_LOAD_AT == 3 && tile > 0) nxt = load_tile(tile - 1);   // (early: see load_tile)
                 if (cb == 0) wgrad<2, true, 2, true>(gW_D0, gB_D0, stage, L, rb, T16_STAGE_MAT, 0);   // x = H[32:48] and SH
                 else { float dummy = 0.0f; wgrad<1, false, 1, true>(gW_D0, dummy, stage, L, rb, T16_STAGE_MAT, 1); }   // x = H[48:64]
                 {
@@ -898,6 +956,7 @@ __global__ void __launch_bounds__(kThreads, 2) k_render_bwd_t16(BwdArgs a)
                 STAMP(15);
                 STEP_BARRIER();  // ---- A4
                 STAMP(16);
+                if (T16_LOAD_AT == 4 && tile > 0) nxt = load_tile(tile - 1);   // (early: see load_tile)
                 if (cb == 0) wgrad<2, true, 1, true>(gW_L1, gB_L1, stage, L, rb, T16_STAGE_MAT, 0);
                 else { float dummy = 0.0f; wgrad<2, false, 1, true>(gW_L1, dummy, stage, L, rb, T16_STAGE_MAT, 2); }
                 {
@@ -920,6 +979,7 @@ __global__ void __launch_bounds__(kThreads, 2) k_render_bwd_t16(BwdArgs a)
                 STAMP(19);
                 STEP_BARRIER();  // ---- A5
                 STAMP(20);
+                if (T16_LOAD_AT == 5 && tile > 0) nxt = load_tile(tile - 1);   // (early: see load_tile)
                 if (cb == 0) wgrad<1, true, 1, true>(gW_L0, gB_L0, stage, L, rb, T16_STAGE_MAT, 0);
                 else { float dummy = 0.0f; wgrad<1, false, 1, true>(gW_L0, dummy, stage, L, rb, T16_STAGE_MAT, 1); }
                 s16_chain<2, 2, 1>(dx, lds, T16_L0, L.trp, dyS);
@@ -1107,16 +1167,25 @@ __global__ void __launch_bounds__(kThreads, 2) k_render_bwd_t16(BwdArgs a)
             // (no barrier here: the next tile's staging writes come after its barrier S)
             STAMP(21);
 
-            if (tile > 0) nxt = load_tile(tile - 1);   // before this tile's record stores (see load_tile)
+            if (!(SPLIT && T16_LOAD_AT) && tile > 0) nxt = load_tile(tile - 1);   // before this tile's record stores (see load_tile)
             if constexpr (SPLIT) {
                 // ================= feature gradients: emitted here (the split kernel has no registers to carry them into the
                 // next tile: 11 held across its forward recompute cost more in spills than the overlap gains)
-                float pe[3] = { 0, 0, 0 };
-                if (a.recs) contract_point(a.f, o, d, z, pe);
-                // (tried: the cursor round trips of two or four levels in flight before the first record is stored -- 24 / 48 spilled
-                // registers, 5.2 -> 5.6 ms; the four levels go one after the other)
+                if (park_wave) {
+                    const int lp = fresh(lane);
+                    float4 *pk = reinterpret_cast<float4 *>(lds + LD::kPark + (wv - 4) * 2048);
+                    pk[lp] = make_float4(dx[0][0], dx[0][1], dx[0][2], dx[0][3]);
+                    pk[64 + lp] = make_float4(dx[1][0], dx[1][1], dx[1][2], dx[1][3]);
+                    pz = z;
+                    ptile = tile;
+                } else {
+                    float pe[3] = { 0, 0, 0 };
+                    if (a.recs) contract_point(a.f, o, d, z, pe);
+                    // (tried: the cursor round trips of two or four levels in flight before the first record is stored -- 24 / 48 spilled
+                    // registers, 5.2 -> 5.6 ms; the four levels go one after the other)
 #pragma unroll
-                for (int jj = 0; jj < 4; ++jj) emit_level(tile, jj, dx[0], dx[1], pe);
+                    for (int jj = 0; jj < 4; ++jj) emit_level(tile, jj, dx[0], dx[1], pe);
+                }
             } else {
                 // ================= feature gradients: emitted during the next tile (emit_level) =================
                 pdx0 = dx[0];
@@ -1128,7 +1197,7 @@ __global__ void __launch_bounds__(kThreads, 2) k_render_bwd_t16(BwdArgs a)
         if constexpr (!SPLIT) {
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) emit_level(ptile, jj, pdx0, pdx1, ppe);   // the ray's first tile
-        }
+        } else if (park_wave) emit_parked();   // the ray's first tile
         if (POSE && active) {  // the ray's pose-gradient sums
             const int ln = fresh(lane), c = ln & 15, q = ln >> 4;
 #pragma unroll
@@ -1245,9 +1314,15 @@ int launch_pack_decoder_t16(const float *blob, const float *wf, char *out, hipSt
     return 0;
 }
 
-int launch_render_bwd_t16(const BwdArgs &a, int feat_dtype, int blocks, size_t lds_extra, hipStream_t st, bool split)
+int launch_render_bwd_t16(const BwdArgs &a_in, int feat_dtype, int blocks, size_t lds_extra, hipStream_t st, bool split)
 {
-    const size_t lds_bytes = (size_t)(split ? Lds<true>::kCursor : Lds<false>::kCursor) + lds_extra;
+    size_t lds_bytes = (size_t)(split ? Lds<true>::kCursor : Lds<false>::kCursor) + lds_extra;
+    BwdArgs a = a_in;
+    // skewed emission (the t16s kernel's waves 4-7 park a tile's dX in LDS): whenever its 8 KB fit next to the record cursors
+    // (T <= 2^20 entries per level at 2^13-entry buckets); SCANERF_BWD_PARK=0 switches it off (A/B timing)
+    const char *pe_ = getenv("SCANERF_BWD_PARK");
+    a.park = split && a.recs && lds_bytes + Lds<true>::kParkBytes <= 160 * 1024 && !(pe_ && atoi(pe_) == 0);
+    if (a.park) lds_bytes += Lds<true>::kParkBytes;
     SCANERF_REQUIRE(lds_bytes <= 160 * 1024, "render_backward(t16): %zu B of LDS needed (table too large for the fused scatter)", lds_bytes);
     SCANERF_REQUIRE(a.xstash, "render_backward(t16): needs the x-stash");
     SCANERF_REQUIRE((a.g_dnorm != nullptr) == (a.g_rowsum != nullptr), "render_backward(t16): g_dnorm and g_rowsum come together");

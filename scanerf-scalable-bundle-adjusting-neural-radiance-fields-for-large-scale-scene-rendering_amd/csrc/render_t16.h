@@ -54,9 +54,43 @@ struct T16HL {
     t16_h8 hi, lo;
 };
 // k-step operand from two accumulator blocks (slots j < 4 from `a`, j >= 4 from `b`), split hi + lo
+//
+// T16_MIX_SPLIT (default): lo = (f16)(x - (float)hi) as ONE instruction per element -- v_fma_mixlo_f16 / v_fma_mixhi_f16 take the
+// f16 hi part as it is, multiply by -1.0, add the f32 x and round the (exact) f32 difference to f16 into one half of the
+// destination -- instead of v_cvt_f32_f16 + v_sub_f32 per element and a v_cvt_pk_f16_f32 per pair: 12 instead of 24 vector
+// instructions per 8-element operand, 29 operands per tile.  The same two roundings as the plain form (the difference is exact in
+// f32), so the same bits.  The compiler does not select these forms by itself (it folds fma(h, -1, x) back into a subtraction, and
+// prefers cvt_pk for a pair of truncations), hence inline asm; what the assembler cannot know is that a matrix instruction must not
+// read a register within two wait states of the vector instruction that wrote it (the hazard recogniser pads that case for
+// instructions it sees: `s_nop` after a v_mov feeding an MFMA), so the lo registers pass through one `s_nop 1` tied to them.
+#ifndef T16_MIX_SPLIT
+#define T16_MIX_SPLIT 1
+#endif
 __device__ __forceinline__ T16HL t16_split(const v4f &a, const v4f &b)
 {
     T16HL o;
+#if T16_MIX_SPLIT
+    uint32_t lo32[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const t16_f2 x = p < 2 ? t16_f2{ a[2 * p], a[2 * p + 1] } : t16_f2{ b[2 * p - 4], b[2 * p - 3] };
+        const t16_h2 hi = __builtin_convertvector(x, t16_h2);
+        const uint32_t hb = __builtin_bit_cast(uint32_t, hi);
+        uint32_t lb;
+        asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(lb) : "v"(hb), "v"(x[0]));
+        asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lb) : "v"(hb), "v"(x[1]));
+        lo32[p] = lb;
+        o.hi[2 * p] = hi[0];
+        o.hi[2 * p + 1] = hi[1];
+    }
+    asm("s_nop 1" : "+v"(lo32[0]), "+v"(lo32[1]), "+v"(lo32[2]), "+v"(lo32[3]));   // (see above: two wait states before an MFMA may read them)
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const t16_h2 lo = __builtin_bit_cast(t16_h2, lo32[p]);
+        o.lo[2 * p] = lo[0];
+        o.lo[2 * p + 1] = lo[1];
+    }
+#else
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
         const t16_f2 x = p < 2 ? t16_f2{ a[2 * p], a[2 * p + 1] } : t16_f2{ b[2 * p - 4], b[2 * p - 3] };
@@ -69,6 +103,7 @@ __device__ __forceinline__ T16HL t16_split(const v4f &a, const v4f &b)
         o.lo[2 * p] = lo[0];
         o.lo[2 * p + 1] = lo[1];
     }
+#endif
 #if SCANERF_GUARDS
     asm volatile("s_nop 1" : "+v"(o.hi), "+v"(o.lo));  // operand guard (render_h3.h, "operand hazard")
 #endif

@@ -45,8 +45,9 @@ print(f"backward (stamps build) {ms:.3f} ms; cycles per wave: mean {tot.mean():.
 mean = st.mean((0, 1))
 ntile = B * (S // 16) / (nblk * 8)
 waits = 0.0
+lo, hi = st[:, :4].mean((0, 1)) / ntile, st[:, 4:].mean((0, 1)) / ntile   # waves 0-3 (first wave of each SIMD) / 4-7
 for i, n in enumerate(names):
-    print(f"{i:2d} {n:44s} {mean[i] / ntile:9.0f} cyc/tile  {100 * mean[i] / tot.mean():5.1f} %")
+    print(f"{i:2d} {n:44s} {mean[i] / ntile:9.0f} cyc/tile  {100 * mean[i] / tot.mean():5.1f} %   waves 0-3: {lo[i]:7.0f}  4-7: {hi[i]:7.0f}")
     if n.startswith("wait"):
         waits += float(mean[i])
 print(f"barrier waits together {100 * waits / tot.mean():.1f} %; per tile {tot.mean() / ntile:.0f} cycles")
