@@ -185,7 +185,7 @@ int scanerf_render_forward_packed(const float *rays_o, const float *rays_d, cons
 int scanerf_render_forward_packed_plan(const float *rays_o, const float *rays_d, const float *z_vals, const float *dists,
                                        const void *features, int feat_dtype, const int32_t *resolutions, const float *workspace,
                                        const scanerf_render_cfg *cfg, const uint8_t *ray_valid, float *out_ray, float *weights,
-                                       float *tile_T, float *xstash, void *jstash /* [B,ceil(S/32),8,3,64,2] IEEE half, or NULL (fp32 tables) */,
+                                       float *tile_T, float *xstash, void *jstash /* [B,ceil(S/32),8,4,64] u32: six 20-bit significands + one exponent per (sample, level), or NULL (fp32 tables) */,
                                        int B, int S, int T, void *scatter_ws, size_t scatter_ws_bytes, scanerf_stream_t stream);
 int scanerf_render_forward_plan_supported(int B, int S, int T);
 
@@ -214,7 +214,7 @@ int scanerf_render_backward(const float *rays_o, const float *rays_d, const floa
                             const float *xstash /* forward's, or NULL */, float *dfeat, float *dw_partial,
                             float *grad_blob, float *g_dnorm /* [B,ceil(S/32)] or NULL */,
                             float *g_rowsum /* [B,2,64] or NULL */,
-                            const void *jstash /* forward's position Jacobians [B,ceil(S/32),8,3,64,2] IEEE half, or NULL */,
+                            const void *jstash /* forward's position Jacobians [B,ceil(S/32),8,4,64] u32, or NULL */,
                             float *g_raypos /* [B,6] dL/d(rays_o), dL/d(rays_d) through the sample positions (t16, needs jstash,
                                                g_dnorm and g_rowsum; zero-filled by the caller), or NULL */,
                             void *scatter_ws, size_t scatter_ws_bytes,

@@ -366,7 +366,7 @@ __global__ void __launch_bounds__(kRenderThreads, 2) k_render_fwd_h3(RenderArgs 
                 for (int g = 0; g < 16; ++g) x[g] = p[g % 3] * (0.01f * g);
             } else {
                 // (dead lanes of the last tile write their own, unused, slots: no branch around the stores)
-                uint32_t *jrow = JST ? a.jstash + ((size_t)ray * ntiles + tile) * (8 * 3 * 64) + lane : nullptr;
+                uint32_t *jrow = JST ? a.jstash + ((size_t)ray * ntiles + tile) * (8 * 4 * 64) + lane : nullptr;
                 encode8<DT, JST ? 1 : FWD_GATHER_BATCH, true, COUNT, JST>(a, lds_res, h, p, x, hist, live, jrow);
             }
             if (a.xstash && live) {  // (plain stores: streaming / nontemporal ones measured 3.16 -> 3.41 ms)
@@ -527,7 +527,7 @@ SCANERF_API int scanerf_render_forward_packed(const float *rays_o, const float *
 // The same launch, also doing scanerf_render_scatter_plan's work for the t16 backward of these rays (counts in the forward
 // kernel, where the hash indices already are; then the scan): call INSTEAD of scanerf_render_scatter_plan, with that
 // function's workspace.  Only where scanerf_render_forward_plan_supported(B, S, T) (equal forward and backward grids).
-// jstash (may be NULL; fp32 tables): [B][ceil(S/32)][8][3][64][2] f16, the encoder's position Jacobians for scanerf_render_backward's g_raypos.
+// jstash (may be NULL; fp32 tables): [B][ceil(S/32)][8][4][64] u32 (render_device.h jst_pack: six 20-bit significands under one exponent per (sample, level)), the encoder's position Jacobians for scanerf_render_backward's g_raypos.
 SCANERF_API int scanerf_render_forward_packed_plan(const float *rays_o, const float *rays_d, const float *z_vals,
                                                    const float *dists, const void *features, int feat_dtype,
                                                    const int32_t *resolutions, const float *packed,

@@ -543,7 +543,12 @@ __global__ void __launch_bounds__(kThreads, 2) k_render_bwd_t16(BwdArgs a)
             in.xb = v4f{ 0, 0, 0, 0 };
             if (active) {
                 const float4 *xs = reinterpret_cast<const float4 *>(a.xstash + ((size_t)ray * S + (live ? s : 0)) * 32 + 8 * q);
+#ifdef T16_NT_LOADS   // experiment: the x-stash (1 GB, read once) as non-temporal loads, so that it does not displace the records' partially written lines in L2
+                const v4f n0 = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(xs)), n1 = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(xs) + 1);
+                const float4 q0 = make_float4(n0[0], n0[1], n0[2], n0[3]), q1 = make_float4(n1[0], n1[1], n1[2], n1[3]);
+#else
                 const float4 q0 = xs[0], q1 = xs[1];
+#endif
                 in.xa = v4f{ q0.x, q0.y, q0.z, q0.w };
                 in.xb = v4f{ q1.x, q1.y, q1.z, q1.w };
             }
@@ -1124,22 +1129,25 @@ __global__ void __launch_bounds__(kThreads, 2) k_render_bwd_t16(BwdArgs a)
             if (POSE && a.g_raypos && live && active) {
                 // position path (here, where only dX is live): this lane's four levels' Jacobians (12 loads in flight together),
                 // contracted with its dX.  The forward's lane 32 h + (s & 31) wrote its 8 levels 4 (j >> 1) + 2 h + (j & 1) into
-                // the 32-sample tile's [8][3][64] block of f16 pairs; register g of dX block e = feature g & 1 of level jj = 2e + (g >> 1).
-                float2 jv[4][3];
+                // the 32-sample tile's [8][4][64] block of packed entries; register g of dX block e = feature g & 1 of level jj = 2e + (g >> 1).
+                uint4 jw[4];
 #pragma unroll
                 for (int lv = 0; lv < 4; ++lv) {
                     const int j8l = 4 * (q & 1) + lv, lvl = 4 * (j8l >> 1) + 2 * (q >> 1) + (j8l & 1);
                     const int hh = (lvl >> 1) & 1, j = 2 * (lvl >> 2) + (lvl & 1);
-                    const uint32_t *jr = a.f.jstash + (((size_t)ray * ((S + 31) >> 5) + (s >> 5)) * 8 + j) * (3 * 64) + 32 * hh + (s & 31);
-                    jv[lv][0] = unpack_f16x2(jr[0]); jv[lv][1] = unpack_f16x2(jr[64]); jv[lv][2] = unpack_f16x2(jr[128]);
+                    const uint32_t *jr = a.f.jstash + (((size_t)ray * ((S + 31) >> 5) + (s >> 5)) * 8 + j) * (4 * 64) + 32 * hh + (s & 31);
+                    jw[lv] = make_uint4(jr[0], jr[64], jr[128], jr[192]);
                 }
                 float gxk[3] = { 0, 0, 0 };
 #pragma unroll
                 for (int lv = 0; lv < 4; ++lv) {
-                    const float fx = dx[lv >> 1][2 * (lv & 1)], fy = dx[lv >> 1][2 * (lv & 1) + 1];
-                    gxk[0] += fx * jv[lv][0].x + fy * jv[lv][1].y;
-                    gxk[1] += fx * jv[lv][0].y + fy * jv[lv][2].x;
-                    gxk[2] += fx * jv[lv][1].x + fy * jv[lv][2].y;
+                    // entry = (df0/dx, df0/dy, df0/dz, df1/dx, df1/dy, df1/dz) * 2^(E - 19) (render_device.h jst_pack)
+                    float jq[6], jsc;
+                    jst_unpack(jw[lv].x, jw[lv].y, jw[lv].z, jw[lv].w, jq, jsc);
+                    const float fx = dx[lv >> 1][2 * (lv & 1)] * jsc, fy = dx[lv >> 1][2 * (lv & 1) + 1] * jsc;
+                    gxk[0] += fx * jq[0] + fy * jq[3];
+                    gxk[1] += fx * jq[1] + fy * jq[4];
+                    gxk[2] += fx * jq[2] + fy * jq[5];
                 }
                 if (a.f.contract_mode == 1) {  // through contract_bg: r g + (g . x) r' sign(x_m) e_m, r = (2 - 1/|x|_inf) / |x|_inf
                     float xk[3];

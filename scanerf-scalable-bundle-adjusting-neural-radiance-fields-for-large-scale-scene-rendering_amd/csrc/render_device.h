@@ -122,7 +122,7 @@ struct RenderArgs {
     float *out_ray, *weights;
     float *tile_T;            // optional [B, ceil(S/16)]: transmittance entering each 16-sample tile (for backward)
     float *xstash;            // optional [B*S][2][16]: encoder outputs per (sample, half-wave) (for backward)
-    uint32_t *jstash;         // optional [B][ceil(S/32)][8][3][64] f16 pairs: d(encoder outputs)/d(contracted position) per (ray, 32-sample
+    uint32_t *jstash;         // optional [B][ceil(S/32)][8][4][64] words (jst_pack): d(encoder outputs)/d(contracted position) per (ray, 32-sample
                               // tile, level j = 0..7 of the half-wave, component pair, forward lane = 32 h + (s & 31)); the six
                               // components = (feature 0: d/dx, d/dy, d/dz; feature 1: ...).  Lane-fastest so that every store of
                               // the wave is 256 contiguous bytes.  Half precision (the t16 backward that reads it multiplies f16
@@ -155,6 +155,39 @@ __device__ __forceinline__ float2 unpack_f16x2(uint32_t w)
     return make_float2((float)v[0], (float)v[1]);
 }
 
+// ---- Jacobian stash entry (RenderArgs::jstash): the six values d(feature f)/d(p_k) of one (sample, level) in 16 bytes --
+// six 20-bit two's-complement significands under ONE 8-bit exponent (that of the largest of the six): every value to 2^-20 of
+// the largest.  Round 3 stored them as three f16 pairs (12 bytes, 2^-11 each): the position path of the pose gradients was then
+// 2e-4 of the largest ray gradient off, 40x everything else in the t16s backward; an f32 stash would double the 1.6 GB.
+//   w0 = q0 | q1[11:0] << 20;  w1 = q1[19:12] | q2 << 8 | q3[3:0] << 28;  w2 = q3[19:4] | q4[15:0] << 16;
+//   w3 = q4[19:16] | q5 << 4 | (E + 128) << 24;      v_i = q_i * 2^(E - 19),  max |v_i| < 2^E
+__device__ __forceinline__ uint4 jst_pack(const float v[6])
+{
+    const float m = fmaxf(fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))), fmaxf(fabsf(v[4]), fabsf(v[5])));
+    int E = __builtin_amdgcn_frexp_expf(m);           // m < 2^E (0 for m = 0)
+    E = E < -100 ? -100 : (E > 100 ? 100 : E);          // (Jacobians of a table of finite features: far inside)
+    uint32_t q[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        int qi = __float2int_rn(__builtin_amdgcn_ldexpf(v[i], 19 - E));
+        qi = qi > 524287 ? 524287 : (qi < -524287 ? -524287 : qi);
+        q[i] = (uint32_t)qi & 0xfffffu;
+    }
+    return make_uint4(q[0] | (q[1] << 20), (q[1] >> 12) | (q[2] << 8) | (q[3] << 28), (q[3] >> 4) | (q[4] << 16),
+                      (q[4] >> 16) | (q[5] << 4) | ((uint32_t)(E + 128) << 24));
+}
+// -> the six significands as floats and the scale 2^(E - 19) they share
+__device__ __forceinline__ void jst_unpack(uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3, float q[6], float &scale)
+{
+    q[0] = (float)(int)__builtin_amdgcn_sbfe((int)w0, 0, 20);
+    q[1] = (float)(int)__builtin_amdgcn_sbfe((int)__builtin_amdgcn_alignbit(w1, w0, 20), 0, 20);
+    q[2] = (float)(int)__builtin_amdgcn_sbfe((int)w1, 8, 20);
+    q[3] = (float)(int)__builtin_amdgcn_sbfe((int)__builtin_amdgcn_alignbit(w2, w1, 28), 0, 20);
+    q[4] = (float)(int)__builtin_amdgcn_sbfe((int)__builtin_amdgcn_alignbit(w3, w2, 16), 0, 20);
+    q[5] = (float)(int)__builtin_amdgcn_sbfe((int)w3, 4, 20);
+    scale = __builtin_amdgcn_ldexpf(1.0f, (int)(w3 >> 24) - 128 - 19);
+}
+
 // hash-encode 8 levels of one sample: register 2j+f of half h holds feature f of level
 // 4(j>>1) + 2h + (j&1), i.e. input unit nmap(2j+f, h) = 2*level + f -- the same register<->unit
 // map as every other layer, and the layout in which the backward pass produces dL/dx.
@@ -164,7 +197,7 @@ __device__ __forceinline__ float2 unpack_f16x2(uint32_t w)
 // PAIRED: fetch x-neighbour pairs with one load where the hash puts them side by side (gather_cell; half-precision tables)
 // hist (may be null): this workgroup's [16][NB] record counters in LDS -- one per (y,z) corner pair, two when the
 // x-neighbours fall into different buckets, exactly scatter_common.h count_pairs; count = this lane's sample is a real one
-// jrow (may be null): this lane's f16-pair column of the tile's [8][3][64] block of RenderArgs::jstash
+// jrow (may be null): this lane's column of the tile's [8][4][64] block of RenderArgs::jstash (jst_pack)
 template <int DT, int GATHER_BATCH = 2, bool PAIRED = false, bool COUNT = false, bool JST = false>
 __device__ __forceinline__ void encode8(const RenderArgs &a, const int *lds_res, int h, const float p[3], v16f &x,
                                         uint32_t *hist = nullptr, bool count = false, uint32_t *jrow = nullptr)
@@ -180,8 +213,8 @@ __device__ __forceinline__ void encode8(const RenderArgs &a, const int *lds_res,
             x[2 * j] = 0.0f;
             x[2 * j + 1] = 0.0f;
             if constexpr (JST) {
-                uint32_t *jr = jrow + 3 * j * 64;
-                jr[0] = jr[64] = jr[128] = 0u;
+                uint32_t *jr = jrow + 4 * j * 64;
+                jr[0] = jr[64] = jr[128] = jr[192] = 0u;
             }
             continue;
         }
@@ -236,7 +269,7 @@ __device__ __forceinline__ void encode8(const RenderArgs &a, const int *lds_res,
             // with the upstream gradient): corner c = (dx << 2) | (dy << 1) | dz.  Formed as differences along each axis of the
             // bilinear interpolations on the two faces (6 face values per feature instead of 12 weight products held at once).
             const float tx = t[0], ty = t[1], tz = t[2];
-            uint32_t *jr = jrow + 3 * j * 64;   // [3 component pairs][64 lanes] f16 pairs per level
+            uint32_t *jr = jrow + 4 * j * 64;   // [4 words][64 lanes] per level (jst_pack)
             float jv[6];
 #pragma unroll
             for (int ft = 0; ft < 2; ++ft) {
@@ -267,9 +300,11 @@ __device__ __forceinline__ void encode8(const RenderArgs &a, const int *lds_res,
             jr[64] = __float_as_uint(f[1].x);
             jr[128] = __float_as_uint(f[2].x);
 #else
-            jr[0] = pack_f16x2(jv[0], jv[1]);
-            jr[64] = pack_f16x2(jv[2], jv[3]);
-            jr[128] = pack_f16x2(jv[4], jv[5]);
+            const uint4 jw = jst_pack(jv);
+            jr[0] = jw.x;
+            jr[64] = jw.y;
+            jr[128] = jw.z;
+            jr[192] = jw.w;
 #endif
         }
         if ((j + 1) % GATHER_BATCH == 0) __builtin_amdgcn_sched_barrier(0);  // bound the gathers in flight per lane

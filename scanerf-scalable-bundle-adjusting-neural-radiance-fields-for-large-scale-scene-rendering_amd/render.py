@@ -103,13 +103,14 @@ def _cfg(min_bbox, bbox_size, contract_mode, infinity, arith=None, skip_levels=0
     return c
 
 
-JSTASH_DTYPE = torch.float16
+JSTASH_DTYPE = torch.int32
 
 
 def jstash_shape(B, S):
-    """Shape of render_forward's jstash output (position Jacobians per ray, 32-sample tile, level of the half-wave, component,
-    forward lane)."""
-    return (B, (S + 31) // 32, 8, 3, 64, 2)
+    """Shape of render_forward's jstash output: per ray, 32-sample tile, level of the half-wave (8), word (4), forward lane (64):
+    the six position Jacobians d(feature)/d(p) of a (sample, level) as 20-bit significands under one exponent, 16 bytes
+    (csrc/render_device.h jst_pack)."""
+    return (B, (S + 31) // 32, 8, 4, 64)
 
 
 def forward_plan_supported(B, S, T):
@@ -124,7 +125,7 @@ def render_forward(rays_o, rays_d, z_vals, dists, features, resolutions, packed,
     min_bbox / bbox_size: host sequences of 3 floats (the HashGrid 2x box).
     plan=True (only where forward_plan_supported): the launch also reserves the t16 backward's scatter-record ranges for these
     rays -- call it INSTEAD of scatter_plan; returns (out_ray, weights, workspace).
-    jstash (fp32 tables): jstash_shape(B, S) JSTASH_DTYPE (f16) that receives the encoder's position Jacobians, for
+    jstash (fp32 tables): jstash_shape(B, S) JSTASH_DTYPE (packed words) that receives the encoder's position Jacobians, for
     render_backward(ray_pos_grad=...) (pose refinement without a second pass over the table)."""
     B, S = z_vals.shape
     if features.shape[0] != 16 or features.shape[2] != 2:

@@ -798,8 +798,8 @@ def _ray_gradients_case(bg, arith):
     go, gd = render.ray_gradients(RO, RD, Z, F, R, blob, mn.tolist(), sz.tolist(), box[2], dfeat, *bufs)
     if arith in ("t16", "t16s"):
         # the same gradients with the position path formed inside the backward kernel from the forward's position Jacobians
-        # (no second pass over the table, no dfeat): equal to the dfeat route up to summation order and the half precision of the
-        # stashed Jacobians (11 bits, as the t16 kernel's gradient operands)
+        # (no second pass over the table, no dfeat): equal to the dfeat route up to summation order and the stash's 2^-20 of each
+        # (sample, level)'s largest Jacobian entry
         js = torch.empty(render.jstash_shape(B, S_), dtype=render.JSTASH_DTYPE, device=DEV)
         out_j, _ = render.render_forward(RO, RD, Z, DI, F, R, pk, *box, tile_T=tile_T, xstash=xs, jstash=js)
         assert torch.equal(out_j, out)
@@ -820,9 +820,11 @@ def _ray_gradients_case(bg, arith):
         for a_, b_, name in ((go2, go, "rays_o"), (gd2, gd, "rays_d")):
             e = float((a_ - b_).abs().max() / b_.abs().max())
             print(f"in-kernel position path vs dfeat route, {name} (bg={bg}): max err {e:.2e} of max")
-            assert e < 1e-3, (name, e)
+            # t16s: f32-grade feature gradients x the 20-bit Jacobian stash (csrc/render_device.h jst_pack; round 3's f16 stash: 2.4e-4);
+            # t16: its gradient products are single f16 MFMAs
+            assert e < (2e-5 if arith == "t16s" else 1e-3), (name, e)
         go, gd = go2, gd2
-    tol_mean = 2e-4 if arith == "h3" else 6e-4
+    tol_mean = 2e-4 if arith in ("h3", "t16s") else 6e-4
     for got, want, name in ((go, to.grad, "rays_o"), (gd, td.grad, "rays_d")):
         sc = float(want.abs().max())
         # the encoder's point gradient has kinks at cell faces (fine levels): compare in the norm, allow a few outliers
