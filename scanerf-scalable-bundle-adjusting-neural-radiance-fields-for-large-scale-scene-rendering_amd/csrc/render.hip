@@ -483,6 +483,7 @@ static int render_forward(const float *rays_o, const float *rays_d, const float 
     const int waves_per_block = kRenderThreads / 64;
     int blocks = ceil_div(B, waves_per_block);
     if (blocks > kNumCU) blocks = kNumCU;  // one resident 512-thread workgroup per CU (VGPR-bound), persistent
+    if (const char *e = getenv("SCANERF_FWD_GRID")) { const int v = atoi(e); if (v >= 1 && v < blocks) blocks = v; }   // (render_bwd.hip scanerf_render_backward_grid)
     dim3 grid(blocks), block(kRenderThreads);
     hipStream_t st = (hipStream_t)stream;
     SCANERF_REQUIRE(cfg->arith >= SCANERF_ARITH_F32 && cfg->arith <= SCANERF_ARITH_T16S, "render_forward: arith=%d", cfg->arith);
@@ -544,7 +545,8 @@ SCANERF_API int scanerf_render_forward_packed_plan(const float *rays_o, const fl
 SCANERF_API int scanerf_render_forward_plan_supported(int B, int S, int T)
 {
     if (scanerf_render_scatter_workspace_bytes(B, S, T) == 0) return 0;
-    const int fwd_grid = ceil_div(B, kRenderThreads / 64) > kNumCU ? kNumCU : ceil_div(B, kRenderThreads / 64);
+    int fwd_grid = ceil_div(B, kRenderThreads / 64) > kNumCU ? kNumCU : ceil_div(B, kRenderThreads / 64);
+    if (const char *e = getenv("SCANERF_FWD_GRID")) { const int v = atoi(e); if (v >= 1 && v < fwd_grid) fwd_grid = v; }
     if (fwd_grid != scanerf_render_backward_grid(B)) return 0;
     return 1;  // (NB <= 256 buckets per level whatever T: scatter_common.h fused_bucket_log)
 }

@@ -613,7 +613,14 @@ int launch_render_bwd_f32(const BwdArgs &a, int feat_dtype, int blocks, size_t l
 }  // namespace scanerf
 
 // ---------------------------------------------------------------------------- C ABI
-SCANERF_API int scanerf_render_backward_grid(int B) { return B > kNumCU ? kNumCU : (B < 1 ? 1 : B); }
+// (SCANERF_BWD_GRID / SCANERF_FWD_GRID cap the persistent grids of the fused backward / forward: a tuning and experiment knob --
+// e.g. both kernels resident at once on disjoint CUs, tools/overlap_probe.py; the scatter plan follows this function)
+SCANERF_API int scanerf_render_backward_grid(int B)
+{
+    int cap = kNumCU;
+    if (const char *e = getenv("SCANERF_BWD_GRID")) { const int v = atoi(e); if (v >= 1 && v < cap) cap = v; }
+    return B > cap ? cap : (B < 1 ? 1 : B);
+}
 
 // dw_partial: [4 * scanerf_render_backward_grid(B)][13994] f32 scratch; grad_blob [13994] is accumulated into.
 SCANERF_API int scanerf_render_backward(const float *rays_o, const float *rays_d, const float *z_vals, const float *dists,
