@@ -55,15 +55,46 @@ struct HL {
     h8 hi, lo;
 };
 // registers 8t .. 8t+7 of an accumulator block -> B operand of k-step t
+// H3_MIX_SPLIT (default, round 4): lo = (f16)(x - (float)hi) as ONE instruction per element (v_fma_mixlo_f16 / v_fma_mixhi_f16:
+// the f16 hi part as it is, times -1.0, plus the f32 x, the exact f32 difference rounded to f16 into one half of the destination)
+// instead of v_cvt_f32_f16 + v_sub_f32 per element and a v_cvt_pk_f16_f32 per pair: 12 instead of 24 vector instructions per
+// operand -- the same roundings, the same bits (render_t16.h t16_split is the same form, with what it measured).  Inline asm,
+// because the compiler does not select these forms; the `s_nop 1` tied to the lo registers stands in for the two wait states the
+// hazard recogniser would put between a vector instruction it can see and a matrix instruction reading its result.
+// (Round 2 tried v_fma_mix_f32 here, -4 % on the render-time frame, and withdrew it because the training step then differed
+// between runs: that build still held packed-f32 instructions, the cause found in round 3 -- DESIGN.md 4.10.)
+#ifndef H3_MIX_SPLIT
+#define H3_MIX_SPLIT 1
+#endif
 __device__ __forceinline__ HL split8(const v16f &v, int t)
 {
     HL o;
+#if H3_MIX_SPLIT
+    uint32_t lo32[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const f2v x = { v[8 * t + 2 * q], v[8 * t + 2 * q + 1] };
         const h2v hi = __builtin_convertvector(x, h2v);
-        // (x - (float)hi is one v_fma_mix_f32, which the compiler only emits from inline asm; tried in round 2, -4 % on the
-        // render-time frame, and withdrawn: the training step then differed between runs)
+        const uint32_t hb = __builtin_bit_cast(uint32_t, hi);
+        uint32_t lb;
+        asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(lb) : "v"(hb), "v"(x[0]));
+        asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lb) : "v"(hb), "v"(x[1]));
+        lo32[q] = lb;
+        o.hi[2 * q] = hi[0];
+        o.hi[2 * q + 1] = hi[1];
+    }
+    asm("s_nop 1" : "+v"(lo32[0]), "+v"(lo32[1]), "+v"(lo32[2]), "+v"(lo32[3]));
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const h2v lo = __builtin_bit_cast(h2v, lo32[q]);
+        o.lo[2 * q] = lo[0];
+        o.lo[2 * q + 1] = lo[1];
+    }
+#else
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const f2v x = { v[8 * t + 2 * q], v[8 * t + 2 * q + 1] };
+        const h2v hi = __builtin_convertvector(x, h2v);
         const f2v back = __builtin_convertvector(hi, f2v);
         const f2v r = { x[0] - back[0], x[1] - back[1] };
         const h2v lo = __builtin_convertvector(r, h2v);
@@ -72,6 +103,7 @@ __device__ __forceinline__ HL split8(const v16f &v, int t)
         o.lo[2 * q] = lo[0];
         o.lo[2 * q + 1] = lo[1];
     }
+#endif
 #if !(defined(H3_REGIONS) && H3_REGIONS) && SCANERF_GUARDS
     asm volatile("s_nop 1" : "+v"(o.hi), "+v"(o.lo));  // operand guard, see "operand hazard" below
 #endif
