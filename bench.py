@@ -38,6 +38,10 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+# Requests per second the L2s exchange with the fabric (Infinity Cache / HBM side) -- MEASURED on this chip, not a spec: scattered
+# 8-byte gathers beyond the L2s 55-59 G/s (tools/gather_bench.hip), 12-byte record appends 54-65 G write requests/s whatever their mix of
+# 32- and 64-byte requests (tools/probe/record_store_bench.hip), the training forward 55 G/s.  DESIGN.md 4.11.
+FABRIC_REQ_CEILING_GPS = 57.0
 MFMA_F32_PEAK_TFLOPS = 157.3  # fp32-input MFMA = fp32 vector peak (MI355X_MICROARCH.md, Matrix cores)
 MFMA_F16_PEAK_TFLOPS = 2500.0  # dense f16/bf16 MFMA (MI355X_MICROARCH.md); the h3 arithmetic issues 3 f16 products per term
 BYTES_FWD_PER_RAY = 24 + 20 + 128 * 16 * 8 * 2 * 4        # 131 116 B (fp32, S=128, L=16)
@@ -446,9 +450,11 @@ def roofline(timer, arith, args, B, S, valid_frac, fgbg, ms_per_step):
                 k["amplification"] = k["traffic"] / k["design_bytes"]["total"]
             if name in alg and c.get("avg_us"):
                 k["frac_at_rocprof_avg"] = alg[name] / (c["avg_us"] * 1e-6) / (HBM_PEAK_GBS * 1e9)
-            for key in ("mfma_busy", "wait_any", "valu_active", "lds_bank_conflict"):
+            for key in ("mfma_busy", "wait_any", "valu_active", "lds_bank_conflict", "fabric_requests", "fabric_request_rate_Gps"):
                 if key in c:
                     k[key] = c[key]
+            if "fabric_request_rate_Gps" in c:
+                k["frac_fabric_request_ceiling"] = c["fabric_request_rate_Gps"] / FABRIC_REQ_CEILING_GPS
         kernels[name] = k
     with_alg = [n for n in kernels if "algorithmic_bytes" in kernels[n]]
     # (a path whose sections carry no 8(d) byte count -- none today -- still gets a line: its slowest section, time only)
@@ -467,6 +473,13 @@ def roofline(timer, arith, args, B, S, valid_frac, fgbg, ms_per_step):
             "counters_source": (pmc_src + " (committed rocprofv3 --pmc / --stats passes of this command, tools/profile_bench.sh; NOT measured in "
                                 "this run)") if "traffic" in d else None,
             "kernels": kernels}
+    req = [kernels.get(n, {}).get("fabric_requests") for n in ("render_forward", "render_backward", "table_grad_accumulate_adam")]
+    if all(r is not None for r in req):
+        # the roofline that binds this design: every kernel of the step lives on requests to the fabric; at the
+        # measured ceiling the step's requests alone take floor_ms
+        roof["fabric_requests"] = {"per_step": float(sum(req)), "ceiling_Gps": FABRIC_REQ_CEILING_GPS, "floor_ms": sum(req) / (FABRIC_REQ_CEILING_GPS * 1e9) * 1e3,
+                                   "step_ms": ms_per_step, "frac": sum(req) / (FABRIC_REQ_CEILING_GPS * 1e9) * 1e3 / ms_per_step,
+                                   "source": "request counts: " + (pmc_src or "") + " (committed counters); ceiling: measured micro-benchmarks, not a spec"}
     if S == 128:
         whole = rays * (BYTES_FWD_PER_RAY + BYTES_BWD_PER_RAY) * (2 if fgbg else 1)
         roof["whole_step"] = {"bytes": whole, "ms": ms_per_step, "frac": whole / (ms_per_step * 1e-3) / (HBM_PEAK_GBS * 1e9),

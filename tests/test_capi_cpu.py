@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     missing = [s for s in declared if not hasattr(lib, s)]
     assert not missing, missing
     assert set(_capi.SYMBOLS) <= set(declared), sorted(set(_capi.SYMBOLS) - set(declared))
-    assert lib.scanerf_abi_version() == 5
+    assert lib.scanerf_abi_version() == 6
     lib.scanerf_last_error.restype = ctypes.c_char_p
     assert isinstance(lib.scanerf_last_error(), bytes)
 

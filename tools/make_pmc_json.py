@@ -61,6 +61,16 @@ for k, v in sorted(kern.items(), key=lambda kv: -kv[1].get("avg_us", 0)):
               "SQ_WAIT_INST_LDS", "SQ_WAIT_INST_ANY", "SQ_BUSY_CYCLES"):
         if c in v:
             e[c] = v[c]
+    for c, key in (("TCC_EA0_RDREQ_sum", "fabric_read_requests"), ("TCC_EA0_RDREQ_32B_sum", "fabric_read_requests_32B"),
+                   ("TCC_EA0_WRREQ_sum", "fabric_write_requests"), ("TCC_EA0_WRREQ_64B_sum", "fabric_write_requests_64B"),
+                   ("TCC_REQ_sum", "l2_requests"), ("TCC_HIT_sum", "l2_hits"), ("TCC_MISS_sum", "l2_misses"), ("TCP_TCC_WRITE_REQ_sum", "l1_to_l2_write_requests")):
+        if c in v:
+            e[key] = v[c]
+    if "fabric_read_requests" in e and "fabric_write_requests" in e and v.get("avg_us"):
+        # requests between the L2s and the fabric (Infinity Cache / HBM side), reads (64 B, or 128 B tallied as one) + writes (32 / 64 B);
+        # the chip serves ~57 G of them per second whatever their size (gather / record-stream micro-benchmarks)
+        e["fabric_requests"] = e["fabric_read_requests"] + e["fabric_write_requests"]
+        e["fabric_request_rate_Gps"] = e["fabric_requests"] / (v["avg_us"] * 1e-6) / 1e9
     if "SQ_VALU_MFMA_BUSY_CYCLES" in v and v.get("avg_us"):
         e["mfma_busy"] = v["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024 * v["avg_us"] * 1e-6 * SCLK)
     if "SQ_WAIT_ANY" in v and v.get("SQ_WAVE_CYCLES"):
@@ -72,5 +82,6 @@ for k, v in sorted(kern.items(), key=lambda kv: -kv[1].get("avg_us", 0)):
     out["kernels"][k] = e
     print(f"{k[:64]:66s} {e.get('avg_us') or 0:9.1f} us  fetch {e.get('fetch_bytes', 0) / 1e9:6.2f} GB  write {e.get('write_bytes', 0) / 1e9:6.2f} GB  "
           f"mfma {e.get('mfma_busy', 0):.3f}  wait {e.get('wait_any', 0):.3f}  valu {e.get('valu_active', 0):.3f}  ldsconf {e.get('lds_bank_conflict', 0):.3f}  "
+          f"fabric req {e.get('fabric_requests', 0):.3g} ({e.get('fabric_request_rate_Gps', 0):.1f} G/s)  "
           f"VALU/MFMA/LDS/VMEM insts {v.get('SQ_INSTS_VALU', 0):.3g}/{v.get('SQ_INSTS_MFMA', 0):.3g}/{v.get('SQ_INSTS_LDS', 0):.3g}/{v.get('SQ_INSTS_VMEM', 0):.3g}", file=sys.stderr)
 json.dump(out, sys.stdout, indent=1)

@@ -14,7 +14,9 @@ for set in "FETCH_SIZE" "WRITE_SIZE" \
            "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY" \
            "SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS" \
            "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM" \
-           "SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_INSTS_SALU"; do
+           "SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_INSTS_SALU" \
+           "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum" \
+           "TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum TCP_TCC_WRITE_REQ_sum"; do
   i=$((i+1))
   timeout -k 10 300 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $out/p$i -- $B --steps 4 --warmup 1 --arith-side-off "$@" > $out/p$i.log 2>&1 || echo "pmc pass $i failed"
 done
