@@ -602,6 +602,7 @@ static int binned_backward(const float *points, const float *grad_in, float *gra
     // producer workgroups: every one of them writes and reads a counter per bin, so with the tens of thousands of bins of a
     // large table fewer, longer-running workgroups are cheaper (T = 2^24, 2.1 M points: count 0.62 -> see DESIGN.md)
     g.W = (size_t)L * g.NB * 4 > 64 * 1024 ? 256 : 1024;
+    if (const char *e = getenv("SCANERF_SCATTER_W")) { const int v = atoi(e); if (v >= 1 && v <= 1024) g.W = v; }   // tuning experiments
     if (g.W > (N + kThreads - 1) / kThreads) g.W = (N + kThreads - 1) / kThreads;
     g.per_wg = (N + g.W - 1) / g.W;
     const int nbins = L * g.NB;
