@@ -270,7 +270,9 @@ __device__ __forceinline__ void wgrad(v4f *acc, float &rowsum, const char *stage
                 acc[i] = t16_mfma(a, blo, acc[i]);
                 acc[i] = t16_mfma(a, b[i], acc[i]);
             }
+#ifndef T16_FREE_WGRAD   // (-DT16_FREE_WGRAD: experiment -- let the scheduler hoist the next pair's operand reads over this pair's products)
             __builtin_amdgcn_sched_barrier(0);   // (bounds the operands in flight: the pairs' reads are not hoisted over each other)
+#endif
         } else {
             T16_REGION_BEGIN();
 #pragma unroll

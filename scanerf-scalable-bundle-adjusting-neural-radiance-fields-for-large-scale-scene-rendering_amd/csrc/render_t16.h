@@ -263,7 +263,9 @@ __device__ __forceinline__ void s16_chain(v4f dx[NBI], const char *img, int base
             dx[bi] = t16_mfma(alo, dY[t].hi, dx[bi]);
             dx[bi] = t16_mfma(ahi, dY[t].lo, dx[bi]);
             dx[bi] = t16_mfma(ahi, dY[t].hi, dx[bi]);
+#ifndef T16_FREE_CHAIN   // (-DT16_FREE_CHAIN: experiment -- no bound on the operands in flight)
             if (bi & 1) __builtin_amdgcn_sched_barrier(0);   // (two input blocks' operands in flight at a time)
+#endif
         }
 }
 // ... of a narrow layer (heads, rgb): its own transposed pairs (hi, lo), lane l's 16 B at 16 l, one k-step
