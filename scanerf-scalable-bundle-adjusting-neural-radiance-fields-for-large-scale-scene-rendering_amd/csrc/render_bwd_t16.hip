@@ -8,10 +8,15 @@
 //     (28 accumulator registers per wave); one partial row per workgroup, reduced by k_reduce_dw;
 //   * forward recompute in split-f16 (three products per term); what the backward steps need from it is kept as
 //     f16 (hi parts of the activations, G'(u) of the three Gaussian layers): 48 registers, nothing is recomputed twice;
-//   * gradient products on ONE f16 MFMA per term under the workgroup's power-of-two scale (render_bwd_h3.hip);
-//   * the table-gradient scatter records are emitted here (scatter.hip), 4 levels per lane.
-// Not supported here (the caller falls back to render_bwd_h3.hip): pose-gradient outputs (g_dnorm / g_rowsum),
-// the re-gather without an x-stash.
+//   * gradient products on ONE f16 MFMA per term under the workgroup's power-of-two scale (render_bwd_h3.hip) -- "t16"; or,
+//     SPLIT = true ("t16s", the library's default and bench.py's headline): every gradient product split hi + lo like the
+//     recompute, pre-activations held in f32 and activations formed again where they are used: f32-equivalent gradients;
+//   * the table-gradient scatter records are emitted here (scatter.hip), 4 levels per lane; t16s: waves 0-3 at the tile's end,
+//     waves 4-7 from a copy of dX parked in LDS, behind the next tile's compositing ("skewed emission", below);
+//   * POSE = true: also the per-ray sums of the pose refinement (g_dnorm, g_rowsum) and, from the forward's Jacobian stash
+//     (render_device.h jst_pack), dL/d(rays_o), dL/d(rays_d) through the sample positions.
+// Needs the forward's x-stash (without one the caller falls back to render_bwd_h3.hip, which re-gathers).
+// What bounds it, measured: DESIGN.md 4.2a (cycle stamps: -DT16_STAMPS + tools/bwd_stamps.py).
 #include <stdlib.h>
 
 #include "render_bwd_common.h"
