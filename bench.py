@@ -412,6 +412,32 @@ def design_bytes(section, rays, S, arith, T):
     return None
 
 
+def fabric_ceiling_live(dev):
+    """The chip's L2 <-> fabric request rate for scattered accesses, measured NOW: 2^26 8-byte entries (512 MB, 16x the L2s),
+    4 x 256 workgroups x 512 threads x 256 scattered loads each; loads / second ~ requests / second (one L2 miss per lane-load up
+    to the 6 % that hit).  scanerf_gather_rate_probe is measurement infrastructure of the library (include/scanerf_hip.h)."""
+    import ctypes
+
+    from scanerf_amd import _capi
+    entries, blocks, per = 1 << 26, 1024, 256
+    table = torch.zeros(entries, 2, dtype=torch.float32, device=dev)
+    sink = torch.zeros(4, dtype=torch.int32, device=dev)
+    call = lambda: _capi.check(_capi.lib().scanerf_gather_rate_probe(
+        ctypes.c_void_p(table.data_ptr()), ctypes.c_longlong(entries), ctypes.c_int(blocks), ctypes.c_int(per),
+        ctypes.c_void_p(sink.data_ptr()), _capi.stream()), "gather_rate_probe")
+    call()
+    best = 1e9
+    for _ in range(3):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        call()
+        e1.record()
+        torch.cuda.synchronize()
+        best = min(best, e0.elapsed_time(e1))
+    del table
+    return blocks * 512 * per / (best * 1e-3) / 1e9
+
+
 def roofline(timer, arith, args, B, S, valid_frac, fgbg, ms_per_step):
     """`roofline` of the JSON line.  Live fields (HIP events of this very run): `avg_launch_ms`, `achieved`, `frac`.  Per kernel of
     the step: SURVEY.md 8(d)'s algorithmic bytes (strictly: bytes_fwd = 24 + 20 + S*L*8*F*4 per ray for the forward; for the
@@ -727,6 +753,14 @@ def main():
         }
         if timer and timer.count:
             line["roofline"] = roofline(timer, arith if fused else "f32", args, B, S, valid_frac, fgbg, ms_per_step)
+        if timer and timer.count and world == 1 and "fabric_requests" in line.get("roofline", {}):
+            try:   # the ceiling of roofline.fabric_requests, measured live beside the committed micro-benchmarks' 57 G/s
+                live = fabric_ceiling_live(dev)
+                fr = line["roofline"]["fabric_requests"]
+                fr["ceiling_live_Gps"] = live
+                fr["frac_at_live_ceiling"] = fr["per_step"] / (live * 1e9) * 1e3 / ms_per_step
+            except (RuntimeError, AttributeError) as e:
+                print(f"bench.py: fabric ceiling probe skipped: {e}", file=sys.stderr)
         if (world == 1 and fused and args.workload == "configs1" and not args.no_side_legs and not args.arith and not args.pose_grads
                 and ntile == 1 and args.scatter == "auto"):
             del models, dec_opts, model, dec_opt

@@ -289,6 +289,11 @@ int scanerf_h3_selftest(const float *workspace, const float *dy, const float *x,
  * left in the instruction caches (no reference counterpart; tests/test_gpu_determinism.py, tools/fault_probe.py: faults that only
  * show on cold instruction caches). */
 int scanerf_icache_sweep(scanerf_stream_t stream);
+/* Measurement infrastructure (no reference counterpart): blocks x 512 threads each issue loads_per_thread (multiple of 8) scattered
+ * 8-byte loads over table[0 .. entries) (entries: power of two; make it far larger than the 32 MB of L2).  Timed by the caller,
+ * loads / second = the chip's L2 <-> fabric request rate for scattered accesses (bench.py `roofline.fabric_requests`). */
+int scanerf_gather_rate_probe(const void *table, long long entries, int blocks, int loads_per_thread, unsigned *sink,
+                              scanerf_stream_t stream);
 /* Test infrastructure: the 8-byte scatter-record codec (csrc/scatter_common.h Rec8) on n values.  words [n][2] = the packed
  * records; out [n][8] = l0, l1, the four contributions the accumulate adds (x, y to l0; x, y to l1), E - 25, t. */
 int scanerf_rec8_selftest(const float *gx, const float *gy, const float *tx, const uint32_t *l0, const uint32_t *k, int n,

@@ -26,7 +26,7 @@ SYMBOLS = [
     "scanerf_render_workspace_floats", "scanerf_pack_decoder", "scanerf_render_forward_packed",
     "scanerf_embedding_bg_forward_ex", "scanerf_embedding_bwd_workspace_bytes",
     "scanerf_embedding_bg_backward_binned", "scanerf_embedding_bg_backward_binned_adam", "scanerf_render_backward_grid", "scanerf_render_backward",
-    "scanerf_h3_selftest", "scanerf_icache_sweep", "scanerf_sort_tracing_blocks", "scanerf_rec8_selftest", "scanerf_render_forward_packed_plan", "scanerf_render_forward_plan_supported", "scanerf_ray_grad_epilogue", "scanerf_photometric_loss_scratch_floats", "scanerf_photometric_loss_grad", "scanerf_render_scatter_workspace_bytes", "scanerf_render_scatter_plan", "scanerf_render_scatter_accumulate", "scanerf_render_scatter_accumulate_adam", "scanerf_render_scatter_accumulate_adam2", "scanerf_photometric_loss_grad_fgbg",
+    "scanerf_h3_selftest", "scanerf_icache_sweep", "scanerf_gather_rate_probe", "scanerf_sort_tracing_blocks", "scanerf_rec8_selftest", "scanerf_render_forward_packed_plan", "scanerf_render_forward_plan_supported", "scanerf_ray_grad_epilogue", "scanerf_photometric_loss_scratch_floats", "scanerf_photometric_loss_grad", "scanerf_render_scatter_workspace_bytes", "scanerf_render_scatter_plan", "scanerf_render_scatter_accumulate", "scanerf_render_scatter_accumulate_adam", "scanerf_render_scatter_accumulate_adam2", "scanerf_photometric_loss_grad_fgbg",
     "scanerf_ray_block_intersection", "scanerf_render_sample_points", "scanerf_prepare_points", "scanerf_pts_inference",
     "scanerf_accumulate_color", "scanerf_render_inverse_z_sampling", "scanerf_bg_pts_inference_v2",
     "scanerf_update_outgoing_bidx", "scanerf_update_outgoing_bidx_v2", "scanerf_get_last_block",

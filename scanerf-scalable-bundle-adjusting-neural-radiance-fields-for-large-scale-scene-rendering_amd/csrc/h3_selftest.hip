@@ -90,7 +90,39 @@ __global__ void __launch_bounds__(512, 2) k_icache_sweep(float *sink, int never)
     if (never) sink[threadIdx.x] = a;
 }
 
+// Scattered 8-byte loads over a table far larger than the L2s: every lane-load is (nearly) one L2 miss = one 64-byte request to
+// the fabric, so loads / second IS the chip's L2 <-> fabric request rate for this access pattern -- the ceiling the forward's
+// gathers and the backward's record stream run against.  bench.py times it live next to the step.
+__global__ void __launch_bounds__(512) k_gather_rate_probe(const uint2 *__restrict__ table, uint32_t mask, int iters, uint32_t *sink)
+{
+    uint32_t s = (blockIdx.x * 512u + threadIdx.x) * 2654435761u + 0x9e3779b9u;
+    uint32_t acc = 0;
+    for (int it = 0; it < iters; it += 8) {
+        uint2 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {   // eight independent loads in flight per lane
+            s = s * 1664525u + 1013904223u;
+            v[u] = table[(s >> 4) & mask];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc ^= v[u].x + v[u].y;
+    }
+    if (acc == 0x12345678u) sink[0] = acc;   // (keeps the loads; never true for a zero-filled or random table in practice)
+}
+
 }  // namespace
+
+// Test / measurement infrastructure: `loads_per_thread` (multiple of 8) scattered 8-byte loads by each of blocks x 512 threads over
+// table[0 .. entries) (entries a power of two, 8 bytes each).  The caller times the launch: blocks * 512 * loads_per_thread loads.
+SCANERF_API int scanerf_gather_rate_probe(const void *table, long long entries, int blocks, int loads_per_thread, unsigned *sink,
+                                          scanerf_stream_t stream)
+{
+    SCANERF_REQUIRE(table && sink && entries >= 2 && (entries & (entries - 1)) == 0 && entries <= (1ll << 32), "gather_rate_probe: entries=%lld must be a power of two", entries);
+    SCANERF_REQUIRE(blocks >= 1 && loads_per_thread >= 8 && loads_per_thread % 8 == 0, "gather_rate_probe: blocks=%d loads_per_thread=%d", blocks, loads_per_thread);
+    hipLaunchKernelGGL(k_gather_rate_probe, dim3(blocks), dim3(512), 0, (hipStream_t)stream, static_cast<const uint2 *>(table),
+                       (uint32_t)(entries - 1), loads_per_thread, sink);
+    return check_launch("gather_rate_probe");
+}
 
 SCANERF_API int scanerf_icache_sweep(scanerf_stream_t stream)
 {
