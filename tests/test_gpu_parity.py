@@ -836,6 +836,52 @@ def _ray_gradients_case(bg, arith):
         assert float(err.mean()) < tol_mean and float((err > 5e-3).float().mean()) < 0.01, (name, float(err.mean()), float(err.max()))
 
 
+def test_jacobian_stash_entries_against_the_oracle_point_gradient(S):
+    """The forward's position-Jacobian stash (csrc/render_device.h jst_pack: per (sample, level) six 20-bit significands under one
+    exponent, 16 bytes) decoded by a numpy restatement of the format and contracted with random feature gradients equals the
+    oracle's embedding_backward point gradient (hashgrid_bg_kernel.cu:182,220-222) -- to 2e-6 of the largest, the format's 2^-20."""
+    from scanerf_amd import network, render
+    rng = np.random.default_rng(41)
+    B, S_, T = 64, 64, 2 ** 12
+    o, d, z, dist, feat = _render_inputs(rng, B, S_, T, False)
+    sd = O.init_mlp(seed=6, bias_scale=0.05)
+    res = O.level_resolutions(torch.tensor([32, 32, 32]), torch.tensor([2048, 2048, 2048]))
+    mn, sz = torch.tensor([-8.0, -8.0, -8.0]), torch.tensor([16.0, 16.0, 16.0])
+    pk = render.PackedDecoder(DEV).pack(O.pack_blob(sd).to(DEV), network.weight_feature(20000, DEV))
+    js = torch.zeros(render.jstash_shape(B, S_), dtype=render.JSTASH_DTYPE, device=DEV)
+    tile_T, xs = torch.empty(B, (S_ + 15) // 16, device=DEV), torch.empty(B * S_, 32, device=DEV)
+    render.render_forward(g(o), g(d), g(z), g(dist), g(feat), g(res.numpy()), pk, mn.tolist(), sz.tolist(), render.FORE, False, tile_T=tile_T,
+                          xstash=xs, jstash=js)
+    torch.cuda.synchronize()
+    w = js.cpu().numpy().astype(np.int64) & 0xffffffff      # [B, S/32, 8 (j), 4 (word), 64 (forward lane)]
+
+    def sbfe(x, off, wd):
+        x = (x >> off) & ((1 << wd) - 1)
+        return np.where(x >> (wd - 1), x - (1 << wd), x)
+
+    def align(hi, lo, sh):
+        return (((hi << 32) | lo) >> sh) & 0xffffffff
+    w0, w1, w2, w3 = (w[:, :, :, i] for i in range(4))
+    q = np.stack([sbfe(w0, 0, 20), sbfe(align(w1, w0, 20), 0, 20), sbfe(w1, 8, 20), sbfe(align(w2, w1, 28), 0, 20),
+                  sbfe(align(w3, w2, 16), 0, 20), sbfe(w3, 4, 20)], -1).astype(np.float64)
+    J = q * np.exp2((w3 >> 24).astype(np.float64) - 128 - 19)[..., None]          # [B, S/32, 8, 64, 6] = (df0/dp, df1/dp)
+    # forward lane 32 h + (s & 31) holds sample s; its j-th level is 4 (j >> 1) + 2 h + (j & 1)
+    Jl = np.zeros((B, S_, 16, 6))
+    for h in range(2):
+        for j in range(8):
+            lvl = 4 * (j >> 1) + 2 * h + (j & 1)
+            for tl in range(S_ // 32):
+                Jl[:, 32 * tl:32 * tl + 32, lvl] = J[:, tl, j, 32 * h:32 * h + 32]
+    gin = rng.normal(size=(B * S_, 16, 2)).astype(np.float32)
+    got = np.einsum("nlf,nlfk->nk", gin.astype(np.float64), Jl.reshape(B * S_, 16, 2, 3))
+    pts = O.contract_fore((torch.from_numpy(o)[:, None, :] + torch.from_numpy(z)[..., None] * torch.from_numpy(d)[:, None, :]).reshape(-1, 3), mn, sz).numpy()
+    want, _ = O.embedding_backward(pts, gin, feat, res.numpy())
+    sc = np.abs(want).max()
+    err = np.abs(got - want).max() / sc
+    print(f"Jacobian stash entries x random feature gradients vs the oracle's point gradient: max err {err:.2e} of max")
+    assert err < 2e-6, err
+
+
 def test_fused_and_ops_training_steps_agree(S):
     """The fused iteration and the op-by-op iteration (reference structure: HIP encoder + torch decoder) start
     from the same state and must produce the same losses, table updates and ray gradients."""
