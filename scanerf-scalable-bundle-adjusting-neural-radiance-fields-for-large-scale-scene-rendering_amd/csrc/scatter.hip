@@ -714,14 +714,131 @@ static int plan_format(const void *workspace)
     return it != g_plan_rec8.end() ? it->second : 0;
 }
 
+namespace {
+// One workgroup per COARSE bucket (2^bucket_log entries, 16-byte records with 16-bit local entries): its records go, grouped by
+// window w = local entry >> 13, to the same index range of the fine area as 12-byte records (scatter_common.h Rec12) with 13-bit
+// local entries; starts_f[8 c + w] = where window w of bucket c begins.  The order inside a fine range depends on timing; the
+// accumulate sums in integers, so its result does not.
+// A pair whose two entries lie in DIFFERENT windows (x + 1 carries into bit 13: only where a level's resolution exceeds 8 192)
+// keeps its first entry as a single-entry record; the second entry's share goes to `overflow_table` by atomics and the overflow
+// flag is set, exactly as a record that did not fit the workspace (emit_pairs' fallback): correct, and slow only there.
+__global__ void __launch_bounds__(512) k_bin_split(const Rec *__restrict__ recs_c, const uint32_t *__restrict__ starts_c, uint32_t cap_c,
+                                                   Rec *__restrict__ recs_f, uint32_t *__restrict__ starts_f, int nbins_c, int wshift,
+                                                   float *__restrict__ overflow_table, int NB_c, int bucket_log, int T)
+{
+    __shared__ uint32_t cnt[8], base[8];
+    const int c = blockIdx.x, nwin = 1 << wshift;   // (wshift <= 3)
+    const uint32_t lo = min(starts_c[c], cap_c), hi = min(starts_c[c + 1], cap_c);
+    if (threadIdx.x < 8) cnt[threadIdx.x] = 0;
+    if (c == 0 && threadIdx.x == 0) {   // the words in front of the fine records: levels left out, format = Rec12, overflow flag
+        *skip_word(recs_f) = *skip_word(const_cast<Rec *>(recs_c));
+        *format_word(recs_f) = 2u;
+        atomicOr(overflow_flag(recs_f), *overflow_flag(const_cast<Rec *>(recs_c)));   // (zeroed by the host before this launch; other workgroups may set it)
+    }
+    __syncthreads();
+    const float4 *r4 = reinterpret_cast<const float4 *>(recs_c);
+    uint32_t cn[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+    for (uint32_t i = lo + threadIdx.x; i < hi; i += 512) {
+        const uint32_t w = (__float_as_uint(r4[i].x) & 0xffffu) >> 13;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) cn[k] += w == (uint32_t)k ? 1u : 0u;
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        uint32_t v = cn[k];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+        if ((threadIdx.x & 63) == 0 && v) atomicAdd(&cnt[k], v);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t run = lo;
+        for (int k = 0; k < nwin; ++k) {
+            base[k] = run;
+            starts_f[(size_t)c * nwin + k] = run;
+            run += cnt[k];
+        }
+        if (c == nbins_c - 1) starts_f[(size_t)nbins_c * nwin] = hi;
+    }
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63u;
+    for (uint32_t i0 = lo + (threadIdx.x & ~63u); i0 < hi; i0 += 512) {   // (whole waves iterate together: the ballots need every lane)
+        const uint32_t i = i0 + lane;
+        const bool live = i < hi;
+        float4 r = make_float4(0, 0, 0, 0);
+        if (live) r = r4[i];
+        const uint32_t hdr = __float_as_uint(r.x), l0 = hdr & 0xffffu, l1 = hdr >> 16;
+        const uint32_t w = l0 >> 13;
+        uint32_t pos = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const uint64_t m = __ballot(live && w == (uint32_t)k);
+            if (m == 0) continue;   // (wave-uniform)
+            uint32_t b = 0;
+            if (lane == (uint32_t)__builtin_ctzll(m)) b = atomicAdd(&base[k], (uint32_t)__builtin_popcountll(m));
+            b = (uint32_t)__shfl((int)b, __builtin_ctzll(m), 64);
+            if (live && w == (uint32_t)k) pos = b + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull));
+        }
+        if (live) {
+            const uint32_t xm = l0 ^ l1;   // 2^(k+1) - 1 for an x-neighbour pair, 0 for a single entry
+            if (xm >> 13) {   // the pair crosses a window: first entry here with its weight, second entry through the overflow table
+                const float w1 = r.y, w0 = 1.0f - w1;
+                store_rec12(recs_f, pos, l0 & 0x1fffu, 15u, 0u, w0 * r.z, w0 * r.w);
+                float *gs = overflow_table + ((size_t)(c / NB_c) * T + ((size_t)(c % NB_c) << bucket_log)) * 2;
+                unsafeAtomicAdd(gs + 2 * l1, w1 * r.z);
+                unsafeAtomicAdd(gs + 2 * l1 + 1, w1 * r.w);
+                atomicOr(overflow_flag(recs_f), 1u);
+            } else {
+                const uint32_t kk = xm ? (uint32_t)(31 - __clz((int)xm)) : 15u;
+                const uint32_t t = xm ? (uint32_t)min(__float2int_rn(r.y * 8388608.0f), 8388607) : 0u;
+                store_rec12(recs_f, pos, l0 & 0x1fffu, kk, t, r.z, r.w);
+            }
+        }
+    }
+}
+}  // namespace
+
 // ---- fused producer: plan (count + scan) before k_render_bwd, accumulate after it ---------------
 // Workspace bytes of the fused table-gradient path of scanerf_render_backward; 0 => shape unsupported
 // (use dfeat + scanerf_embedding_bg_backward_binned instead).
+// ---- large tables (buckets above 2^13 entries): the SPLIT pass ------------------------------------------------------------
+// The backward's LDS holds 256 cursors per level, so above 2^21 entries per level its buckets (T / 256 entries) outgrow the
+// accumulate's LDS image (2^13 entries).  Round 1 accumulated such a bucket in windows, every window pass re-reading ALL of the
+// bucket's records (T = 2^24: 8 passes, 6.9 ms per 16 384-ray step), and the training step went through dfeat + the stand-alone
+// binned scatter instead.  Round 4: one pass over the coarse records partitions every bucket's records by their window
+// (local entry >> 13) into a second record area -- as 12-byte records with 13-bit local entries, i.e. exactly the stream the
+// accumulate's fast path reads -- and writes the fine ranges' starts; the accumulate then runs on 2^13-entry buckets as for
+// small tables.  The second area lives in the same workspace, behind the budget of coarse records
+// (scanerf_render_scatter_workspace_bytes sizes both); a workspace without it (a caller's smaller buffer) keeps the windows.
+struct SplitLayout {
+    size_t coarse_bytes;    // head + budget of 16-byte records
+    size_t fine_off;        // offset of the fine area: [starts_f (nbins_f + 1)] ... [skip, format, overflow flag][records, 12 B each]
+    size_t fine_recs_off;   // offset of its records
+    size_t total_bytes;
+    uint32_t budget;        // records
+    int nbins_f;
+};
+static bool split_layout(int B, int S, const BinGeom &g, SplitLayout &L)
+{
+    if (g.bucket_log <= 13) return false;
+    const size_t n = (size_t)B * S * 16;
+    L.budget = (uint32_t)(n * 4 + n / 8 + 4096);
+    L.coarse_bytes = bin_workspace_head(16 * g.NB, g.W) + (size_t)L.budget * sizeof(Rec);
+    L.nbins_f = 16 * (g.NB << (g.bucket_log - 13));
+    L.fine_off = (L.coarse_bytes + 255) & ~(size_t)255;
+    const size_t head_f = (((size_t)L.nbins_f + 1 + 3) * 4 + 255) & ~(size_t)255;
+    L.fine_recs_off = L.fine_off + head_f;
+    L.total_bytes = L.fine_recs_off + (size_t)L.budget * 12 + 256;
+    return true;
+}
+
 SCANERF_API size_t scanerf_render_scatter_workspace_bytes(int B, int S, int T)
 {
     BinGeom g;
     if (!fused_geom(B, S, T, g)) return 0;
     const size_t n = (size_t)B * S * 16;
+    SplitLayout L;
+    if (split_layout(B, S, g, L)) return L.total_bytes;
     return bin_workspace_head(16 * g.NB, g.W) + (n * 4 + n / 8 + 4096) * sizeof(Rec);
 }
 
@@ -791,6 +908,33 @@ int scatter_plan_finish(void *workspace, size_t workspace_bytes, int B, int S, i
 }
 }  // namespace scanerf
 
+// Large tables: partition the coarse records of `workspace` into its fine area (k_bin_split) and rewrite (g, w) to describe the
+// fine stream (2^13-entry buckets, 12-byte records).  Returns false -- nothing launched, (g, w) untouched -- where the split does
+// not apply: small tables, a workspace without the fine area, no table for the rare window-crossing pairs, or SCANERF_NO_SPLIT=1
+// (the windows path stays, for A/B timing and as the fallback).
+static bool split_to_fine(int B, int S, BinGeom &g, BinWorkspace &w, void *workspace, size_t workspace_bytes, float *overflow_table,
+                          hipStream_t st)
+{
+    SplitLayout L;
+    if (!split_layout(B, S, g, L) || workspace_bytes < L.total_bytes || !overflow_table || getenv("SCANERF_NO_SPLIT")) return false;
+    if (plan_format(workspace) != 0) return false;   // (coarse records of a large table are the 16-byte ones)
+    char *base = static_cast<char *>(workspace);
+    uint32_t *starts_f = reinterpret_cast<uint32_t *>(base + L.fine_off);
+    Rec *recs_f = reinterpret_cast<Rec *>(base + L.fine_recs_off);
+    const int nbins_c = 16 * g.NB, wshift = g.bucket_log - 13;
+    const uint32_t cap_c = w.capacity < L.budget ? w.capacity : L.budget;
+    (void)hipMemsetAsync(overflow_flag(recs_f), 0, 4, st);
+    hipLaunchKernelGGL(k_bin_split, dim3(nbins_c), dim3(512), 0, st, w.recs, w.starts, cap_c, recs_f, starts_f, nbins_c, wshift,
+                       overflow_table, g.NB, g.bucket_log, g.T);
+    g.NB <<= wshift;
+    g.bucket_log = 13;
+    g.rec8 = 2;
+    g.capacity = 0x7ffffff0u;   // (the fine ranges hold exactly the records the split wrote)
+    w.recs = recs_f;
+    w.starts = starts_f;
+    return true;
+}
+
 // grad_features [16][T][2] += the records scanerf_render_backward emitted into `workspace`.
 SCANERF_API int scanerf_render_scatter_accumulate(float *grad_features, int B, int S, int T, void *workspace,
                                                   size_t workspace_bytes, scanerf_stream_t stream)
@@ -805,6 +949,8 @@ SCANERF_API int scanerf_render_scatter_accumulate(float *grad_features, int B, i
                     "render_scatter_accumulate: workspace too small (%zu B)", workspace_bytes);
     g.capacity = w.capacity;
     g.rec8 = -1;  // as the plan recorded it in the workspace
+    int nbins_acc = nbins;
+    if (split_to_fine(B, S, g, w, workspace, workspace_bytes, grad_features, (hipStream_t)stream)) nbins_acc = 16 * g.NB;
     const size_t lds_bytes = (size_t)(2 << (g.bucket_log < 13 ? g.bucket_log : 13)) * 8;
     const char *ve = getenv("SCANERF_ACC_VARIANT");  // tuning experiments only
     const int variant = ve ? atoi(ve) : 0;
@@ -814,7 +960,7 @@ SCANERF_API int scanerf_render_scatter_accumulate(float *grad_features, int B, i
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);             \
         SCANERF_REQUIRE(e == hipSuccess, "render_scatter_accumulate: cannot reserve %zu B of LDS: %s", lds_bytes,    \
                         hipGetErrorString(e));                                                                      \
-        hipLaunchKernelGGL((k_bin_accumulate<TH, UU>), dim3(nbins), dim3(TH), lds_bytes, (hipStream_t)stream, w.recs, \
+        hipLaunchKernelGGL((k_bin_accumulate<TH, UU>), dim3(nbins_acc), dim3(TH), lds_bytes, (hipStream_t)stream, w.recs, \
                            w.starts, w.maxbits, g, grad_features, AdamEpilogue{});                                  \
     }
 #define SCANERF_LAUNCH_ACC_RUN(TH, UU)                                                                              \
@@ -823,7 +969,7 @@ SCANERF_API int scanerf_render_scatter_accumulate(float *grad_features, int B, i
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);             \
         SCANERF_REQUIRE(e == hipSuccess, "render_scatter_accumulate: cannot reserve %zu B of LDS: %s", lds_bytes,    \
                         hipGetErrorString(e));                                                                      \
-        hipLaunchKernelGGL((k_bin_accumulate<TH, UU, true>), dim3(nbins), dim3(TH), lds_bytes, (hipStream_t)stream, \
+        hipLaunchKernelGGL((k_bin_accumulate<TH, UU, true>), dim3(nbins_acc), dim3(TH), lds_bytes, (hipStream_t)stream, \
                            w.recs, w.starts, w.maxbits, g, grad_features, AdamEpilogue{});                          \
     }
     // measured on MI355X (tools/bwd_emit_only.py + bench.py's table_grad_accumulate_adam section, 5.4e8 records = 8.6 GB): record i -> lane i (lane-interleaved) 256x8 3.61 ms,
@@ -874,32 +1020,46 @@ static int accumulate_adam(float *params, float *exp_avg, float *exp_avg_sq, voi
                     "render_scatter_accumulate_adam: workspace too small (%zu B)", workspace_bytes);
     g.capacity = w.capacity;
     g.rec8 = -1;  // as the plan recorded it in the workspace
-    const size_t lds_bytes = (size_t)(2 << (g.bucket_log < 13 ? g.bucket_log : 13)) * 8;
     AdamEpilogue ad{ nullptr, nullptr, nullptr, 0u, params, exp_avg, exp_avg_sq, half_table, half_dtype, overflow_grad,
                      make_adam_args(lr, beta1, beta2, eps, step) };
+    BinGeom g2;
+    BinWorkspace w2;
     if (workspace2) {  // the second branch's records: planned on the same B and T (same bins and producer grid), its own S
-        BinGeom g2;
         SCANERF_REQUIRE(fused_geom(B, S2, T, g2) && g2.NB == g.NB && g2.W == g.W,
                         "render_scatter_accumulate_adam2: second record set B=%d S=%d T=%d does not match the first", B, S2, T);
-        BinWorkspace w2;
         SCANERF_REQUIRE(bin_workspace_carve(workspace2, workspace2_bytes, nbins, g2.W, w2),
                         "render_scatter_accumulate_adam2: second workspace too small (%zu B)", workspace2_bytes);
-        ad.recs2 = w2.recs; ad.starts2 = w2.starts; ad.maxbits2 = w2.maxbits; ad.capacity2 = w2.capacity;
+        g2.capacity = w2.capacity;
     }
+    // large tables: both record sets through the split pass (both or neither: they meet in one image of one geometry)
+    int nbins_acc = nbins;
+    bool split = false;
+    {
+        SplitLayout L1, L2;
+        const bool can1 = split_layout(B, S, g, L1) && workspace_bytes >= L1.total_bytes && plan_format(workspace) == 0;
+        const bool can2 = !workspace2 || (split_layout(B, S2, g2, L2) && workspace2_bytes >= L2.total_bytes && plan_format(workspace2) == 0);
+        if (can1 && can2 && overflow_grad && !getenv("SCANERF_NO_SPLIT")) {
+            split = split_to_fine(B, S, g, w, workspace, workspace_bytes, overflow_grad, (hipStream_t)stream);
+            if (split && workspace2) split_to_fine(B, S2, g2, w2, workspace2, workspace2_bytes, overflow_grad, (hipStream_t)stream);
+            if (split) nbins_acc = 16 * g.NB;
+        }
+    }
+    if (workspace2) { ad.recs2 = w2.recs; ad.starts2 = w2.starts; ad.maxbits2 = w2.maxbits; ad.capacity2 = split ? 0x7ffffff0u : w2.capacity; }
+    const size_t lds_bytes = (size_t)(2 << (g.bucket_log < 13 ? g.bucket_log : 13)) * 8;
 #define SCANERF_LAUNCH_ACC_ADAM(TH, UU)                                                                                \
     {                                                                                                                 \
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bin_accumulate<TH, UU, true, true>),     \
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);               \
         SCANERF_REQUIRE(e == hipSuccess, "render_scatter_accumulate_adam: cannot reserve %zu B of LDS: %s", lds_bytes, \
                         hipGetErrorString(e));                                                                        \
-        hipLaunchKernelGGL((k_bin_accumulate<TH, UU, true, true>), dim3(nbins), dim3(TH), lds_bytes, (hipStream_t)stream, \
+        hipLaunchKernelGGL((k_bin_accumulate<TH, UU, true, true>), dim3(nbins_acc), dim3(TH), lds_bytes, (hipStream_t)stream, \
                            w.recs, w.starts, w.maxbits, g, (float *)nullptr, ad);                                     \
     }
     // measured (configs[1], MI355X), threads x 16-byte loads per lane: 16-byte records 256x32 2.28 ms, 512x32 2.55, 768x32 2.59;
     // 8-byte records 256x32 1.77, 512x16 1.58, 1024x8 1.70, 1024x16 1.55, 768x32 1.51, 512x48 1.53, 512x32 1.47
     const char *ve = getenv("SCANERF_ACC_VARIANT");  // tuning experiments only
     // 12-byte records (t16s), threads x records per lane: 256x32 1.72 ms, 512x32 1.74, 768x32 1.67, 1024x16 1.53, 512x8 1.52, 512x16 1.43
-    const int pf = plan_format(workspace);
+    const int pf = split ? 2 : plan_format(workspace);
     const int variant = ve ? atoi(ve) : (pf == 1 ? 4 : (pf == 2 ? 1 : 0));
     if (variant == 1) SCANERF_LAUNCH_ACC_ADAM(512, 16)
     else if (variant == 2) SCANERF_LAUNCH_ACC_ADAM(1024, 8)

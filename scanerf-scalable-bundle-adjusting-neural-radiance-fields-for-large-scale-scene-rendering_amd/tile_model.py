@@ -394,10 +394,12 @@ def train_step_fused(model, dec_opt, rays_o, rays_d, target, S, global_step, tab
         box = (model.min_bbox.tolist(), model.bbox_size.tolist(), render.FORE, False)
         T = model.features.shape[1]
         if fused_scatter is None:
-            # records emitted by the backward kernel need the level's cursors in ITS LDS (256 buckets per level): above
-            # 2^21 entries the buckets outgrow the accumulate's LDS image and are accumulated in windows that re-read the
-            # records (T = 2^24: 15.4 ms); there the stand-alone scatter from dfeat (2048 buckets per level) wins (10.6 ms)
-            fused_scatter = T <= (1 << 21)
+            # records emitted by the backward kernel need the level's cursors in ITS LDS (256 buckets per level): above 2^21
+            # entries its buckets (T / 256) outgrow the accumulate's LDS image.  Round 4 put a split pass in front of the
+            # accumulate (csrc/scatter.hip k_bin_split: T = 2^24, 16 384 rays: 9.6 -> 6.1 ms per step on the fused route), but
+            # the stand-alone scatter from dfeat, which emits straight into 2^13-entry buckets, is still ahead there (5.6 ms):
+            # it stays the default above 2^21; SCANERF_LARGE_T_ROUTE=fused selects the fused route
+            fused_scatter = T <= (1 << 21) or os.environ.get("SCANERF_LARGE_T_ROUTE", "dfeat") == "fused"
         fused = fused_scatter and render.scatter_supported(B, S, T)
         ws = plan_done = None
         side = model._side_stream if overlap_plan else None  # (the plan then has no timer section of its own)
@@ -574,8 +576,8 @@ def train_step_fgbg(model, dec_opt, rays_o, rays_d, target, S_fg, S_bg, global_s
     B = rays_o.shape[0]
     dev = model.device
     T = model.features.shape[1]
-    fused = T <= (1 << 21) and render.scatter_supported(B, S_fg, T) and render.scatter_supported(B, S_bg, T) \
-        and render.backward_arith() != render._capi.ARITH_F32
+    fused = (T <= (1 << 21) or os.environ.get("SCANERF_LARGE_T_ROUTE", "dfeat") == "fused") and render.scatter_supported(B, S_fg, T) \
+        and render.scatter_supported(B, S_bg, T) and render.backward_arith() != render._capi.ARITH_F32
     if pose_grads and model.gather_table().dtype != torch.float32:
         raise RuntimeError("scanerf: train_step_fgbg(pose_grads=True) gathers from the fp32 table")
     if not fused:
