@@ -575,18 +575,21 @@ def test_fused_scatter_equals_dfeat_scatter(S, arith, B, S_):
         render.set_arith(render.DEFAULT_ARITH)
 
 
-@pytest.mark.parametrize("log2_T", [20, 21, 22])
-def test_fused_scatter_large_table(S, log2_T):
+@pytest.mark.parametrize("log2_T,finest", [(20, 2048), (21, 2048), (22, 2048), (22, 20000)])
+def test_fused_scatter_large_table(S, log2_T, finest):
     """Tables above 2^21 entries (the reference's default is 2^24): buckets of T/256 entries are accumulated in LDS
     windows.  The fused path against the reference-style atomic kernel on the same dfeat.  2^20: the largest table whose record
     cursors (128 per level) leave room for the t16s backward's parked emission (163 712 of 163 840 B of LDS); 2^21: 256 cursors per
-    level, no room, every wave emits at the tile's end; 2^22: window passes in the accumulate."""
+    level, no room, every wave emits at the tile's end; 2^22: 2^14-entry buckets, partitioned by the split pass in front of the
+    accumulate (csrc/scatter.hip k_bin_split); finest resolution 20 000: x-neighbour pairs whose entries fall into different 2^13-entry
+    windows (x = 8 191: second entry through the overflow table) or different buckets (x = 16 383: two records) occur."""
     from scanerf_amd import network, render
     from scanerf_amd.hashgrid.lib.HASHGRID import embedding_bg_backward_cuda
     from scanerf_amd.tile_model import TileModel
     torch.manual_seed(8)
     B, S_ = 3000, 64
-    m = TileModel([-4, -4, -4], [8, 8, 8], DEV, log2_T=log2_T, seed=2)
+    m = TileModel([-4, -4, -4], [8, 8, 8], DEV, log2_T=log2_T, seed=2, grid_resolution=(32, finest))
+    assert int(m.resolution.max()) >= finest - 1
     with torch.no_grad():
         m.features.mul_(1000.0)
     o = torch.rand(B, 3, device=DEV) * 8 - 4
