@@ -340,7 +340,7 @@ def bench_render(args, world, rank, dev):
             "config": {"workload": f"configs[4] render leg: {ntile} tiles per GPU (f16 tables T=2^{args.log2_T}, shell occupancy) + "
                                    f"blended backgrounds, one {W}x{H} view per step, {args.samples} fg + {args.samples} bg samples",
                        "opaque_fraction": opaque}}))
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 
@@ -586,6 +586,45 @@ def arith_evidence(samples, B=16384, log2_T=19):
     return out
 
 
+class stdout_to_stderr:
+    """RCCL prints a version banner on STDOUT when its first communicator comes up; the contract is ONE JSON line there.  File
+    descriptor 1 points at stderr while the process group is initialised and its first collective has run."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+        return False
+
+
+def init_rccl(world, local):
+    """The `nccl` (= RCCL) process group of this rank: rendezvous from the launcher's environment for N > 1, an in-process
+    store for one rank (no child process) -- so that the consensus exchange runs through RCCL's all-reduce on every box."""
+    with stdout_to_stderr():
+        dev = torch.device("cuda", local)
+        if world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("nccl", store=dist.HashStore(), rank=0, world_size=1, device_id=dev)
+        t = torch.zeros(8, device=dev)
+        dist.all_reduce(t)       # brings the communicator up (and its banner out) here
+        torch.cuda.synchronize()
+
+
+def rccl_mapped():
+    """librccl is mapped into this process (what `torch.distributed`'s nccl backend is on ROCm)."""
+    try:
+        return any("librccl" in ln for ln in open("/proc/self/maps"))
+    except OSError:
+        return False
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "RANK" not in os.environ:
@@ -598,9 +637,14 @@ def main():
     if args.dry_run_cpu:
         return dry_run_cpu(args, world, rank)
     torch.cuda.set_device(local)
+    rccl_error = None
     if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        init_rccl(world, local)
+    else:
+        try:
+            init_rccl(1, local)
+        except Exception as e:  # noqa: BLE001  (reported in the line as rccl_loaded: false + the reason)
+            rccl_error = f"{type(e).__name__}: {e}"
     dev = f"cuda:{local}"
 
     import scanerf_amd  # noqa: F401  (fails loudly if the HIP library is missing)
@@ -729,7 +773,10 @@ def main():
             "metric": "training rays/s per GPU (128 samples, L=16 hash)" if f32_equiv else
                       "training rays/s per GPU (128 samples, L=16 hash) -- REDUCED-PRECISION gradient arithmetic (t16), not the metric",
             "value": value, "value_is": "whole-job aggregate over n_gpus (one tile per GPU)", "value_per_gpu": value / world,
-            "unit": "rays/s", "n_gpus": world, "rccl_world_size": dist.get_world_size() if world > 1 else 1,
+            "unit": "rays/s", "n_gpus": world, "rccl_world_size": dist.get_world_size() if dist.is_initialized() else 1,
+            # the consensus exchanges of this run went through a `nccl` process group and librccl is mapped into the process
+            "rccl_loaded": bool(dist.is_initialized() and dist.get_backend() == "nccl" and rccl_mapped()),
+            "rccl_error": rccl_error,
             "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": dtype_label, "data": "synthetic",
@@ -765,13 +812,17 @@ def main():
                 and ntile == 1 and args.scatter == "auto"):
             del models, dec_opts, model, dec_opt
             torch.cuda.empty_cache()
-            line.update(side_legs(args, dev, rays_o, rays_d, target, S, step0))
+            try:   # (the headline above is already measured: a failing side leg must not discard it)
+                line.update(side_legs(args, dev, rays_o, rays_d, target, S, step0))
+            except Exception as e:  # noqa: BLE001
+                line["side_legs_error"] = f"{type(e).__name__}: {e}"[:400]
+                print(f"bench.py: side legs failed: {e}", file=sys.stderr)
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(S)
             if fused and not occ and not fgbg:
                 line["arith_evidence"] = arith_evidence(S)
         print(json.dumps(line))
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

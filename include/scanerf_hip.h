@@ -220,7 +220,16 @@ int scanerf_render_backward(const float *rays_o, const float *rays_d, const floa
                             void *scatter_ws, size_t scatter_ws_bytes,
                             float *grad_features, int B, int S, int T, scanerf_stream_t stream);
 /* Fused table-gradient path (replaces the atomicAdd scatter of hashgrid_bg_kernel.cu:196-201 for the
- * samples of a render batch).  workspace_bytes == 0 => shape unsupported, use dfeat + the binned op. */
+ * samples of a render batch).  workspace_bytes == 0 => shape unsupported, use dfeat + the binned op.
+ * Precision of the sum: records are added in 64-bit fixed point (bit-reproducible).  Tables of at most 2^21 entries per level:
+ * the records carry what the emitting backward wrote (f32 behind SCANERF_ARITH_F32 / H3, 19-bit-mantissa f32 behind T16S,
+ * 13-bit behind T16).  Tables ABOVE 2^21 entries, when the workspace has the size scanerf_render_scatter_workspace_bytes
+ * returns (it then holds the split pass's second record area): every record -- also an f32 one out of the F32 / H3 backward
+ * -- is re-encoded by the split pass as a 12-byte record (gradient components rounded to 19 mantissa bits, x-weight to 23
+ * bits: ~2^-21 relative per record against the window path), and the second entry of an x-neighbour pair that crosses a
+ * 2^13-entry window (levels with a resolution above 8 192 only) is added to grad_features / overflow_grad with float atomics,
+ * i.e. NOT bit-reproducibly; SCANERF_NO_SPLIT=1 in the environment, or a smaller caller-owned workspace, keeps the window
+ * re-reads (f32 records, reproducible, slower). */
 size_t scanerf_render_scatter_workspace_bytes(int B, int S, int T);
 int scanerf_render_scatter_plan(const float *rays_o, const float *rays_d, const float *z_vals,
                                 const int32_t *resolutions, const scanerf_render_cfg *cfg /*[host]*/,

@@ -526,12 +526,17 @@ class Tile:
         self.occ_size = self.bbox_size / 2.0
 
 
-def render_rays(tile, features, sd, rays_o, rays_d, S_fg, S_bg, mode, global_step, invalid_underground=False):
-    """tile.py:639-692 with hashgrid/__init__.py:413-509 (occlusion_mask=None, BG_MODE 'IZ')."""
+def render_rays(tile, features, sd, rays_o, rays_d, S_fg, S_bg, mode, global_step, invalid_underground=False,
+                occlusion_mask=None):
+    """tile.py:639-692 with hashgrid/__init__.py:413-509 (BG_MODE 'IZ'; occlusion_mask [B,1] bool as tile.py:655,661 passes
+    it: both branches' valid sets are ANDed with it, hashgrid/__init__.py:420-421,479-480).  Besides the merged prediction the
+    result carries the two branches' own dictionaries (out["fg"], out["bg"]: what render_fore_rays / render_bg_rays return)."""
     B = rays_o.shape[0]
     z, d = sample_points_grid(rays_o, rays_d, tile.occ_corner, tile.occ_size, tile.occ, tile.log2dim, S_fg)
     z, d = torch.from_numpy(z), torch.from_numpy(d)
     valid = torch.all(z != -1, dim=-1)
+    if occlusion_mask is not None:
+        valid = valid & occlusion_mask[..., 0]
     out = {"fore_valid": valid}
     zeros3, ones1 = torch.zeros_like(rays_o), torch.ones_like(rays_d[..., :1])
     fg = {"rgb": zeros3.clone(), "depth": torch.zeros_like(ones1), "T_left": ones1.clone(),
@@ -547,19 +552,26 @@ def render_rays(tile, features, sd, rays_o, rays_d, S_fg, S_bg, mode, global_ste
         out["fg_weights"] = f["weights"]
         if mode == TRAIN:
             l2 = l2 + f["l2_reg_specular"]
+            out["fg_l2_reg_specular"] = f["l2_reg_specular"]
     zb, db, vb = inverse_z_sampling(rays_o, rays_d, tile.bbox_center, tile.bbox_size, S_bg, invalid_underground)
+    if occlusion_mask is not None:
+        vb = vb & occlusion_mask[..., 0]
     bg = {"rgb": zeros3.clone(), "depth": torch.zeros_like(ones1), "specular": zeros3.clone(),
           "diffuse": zeros3.clone()}
+    bg_T = ones1.clone()
     if vb.any():
         g = render_batch_rays(rays_o[vb], rays_d[vb], zb[vb], db[vb], features, tile.res, sd, mode,
                               lambda x: contract_bg(x, tile.min_bbox, tile.bbox_size), global_step,
                               infinity=True)
         for k in bg:
             bg[k] = bg[k].index_put((vb,), g[k])
+        bg_T = bg_T.index_put((vb,), g["T_left"][:, None])
         out["bg_weights"] = g["weights"]
         if mode == TRAIN:
             l2 = l2 + g["l2_reg_specular"]
+            out["bg_l2_reg_specular"] = g["l2_reg_specular"]
     out["bg_valid"] = vb
+    out["fg"], out["bg"] = dict(fg), dict(bg, T_left=bg_T)
     out["pred_color"] = fg["rgb"] + fg["T_left"] * bg["rgb"]
     out["pred_depth"] = fg["depth"] + fg["T_left"] * bg["depth"]
     out["pred_specular"] = fg["specular"] + fg["T_left"] * bg["specular"]

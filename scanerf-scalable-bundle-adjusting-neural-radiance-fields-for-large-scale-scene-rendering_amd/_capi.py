@@ -26,12 +26,20 @@ SYMBOLS = [
     "scanerf_render_workspace_floats", "scanerf_pack_decoder", "scanerf_render_forward_packed",
     "scanerf_embedding_bg_forward_ex", "scanerf_embedding_bwd_workspace_bytes",
     "scanerf_embedding_bg_backward_binned", "scanerf_embedding_bg_backward_binned_adam", "scanerf_render_backward_grid", "scanerf_render_backward",
-    "scanerf_h3_selftest", "scanerf_icache_sweep", "scanerf_gather_rate_probe", "scanerf_sort_tracing_blocks", "scanerf_rec8_selftest", "scanerf_render_forward_packed_plan", "scanerf_render_forward_plan_supported", "scanerf_ray_grad_epilogue", "scanerf_photometric_loss_scratch_floats", "scanerf_photometric_loss_grad", "scanerf_render_scatter_workspace_bytes", "scanerf_render_scatter_plan", "scanerf_render_scatter_accumulate", "scanerf_render_scatter_accumulate_adam", "scanerf_render_scatter_accumulate_adam2", "scanerf_photometric_loss_grad_fgbg",
+    "scanerf_sort_tracing_blocks", "scanerf_render_forward_packed_plan", "scanerf_render_forward_plan_supported", "scanerf_ray_grad_epilogue", "scanerf_photometric_loss_scratch_floats", "scanerf_photometric_loss_grad", "scanerf_render_scatter_workspace_bytes", "scanerf_render_scatter_plan", "scanerf_render_scatter_accumulate", "scanerf_render_scatter_accumulate_adam", "scanerf_render_scatter_accumulate_adam2", "scanerf_photometric_loss_grad_fgbg",
     "scanerf_ray_block_intersection", "scanerf_render_sample_points", "scanerf_prepare_points", "scanerf_pts_inference",
     "scanerf_accumulate_color", "scanerf_render_inverse_z_sampling", "scanerf_bg_pts_inference_v2",
     "scanerf_update_outgoing_bidx", "scanerf_update_outgoing_bidx_v2", "scanerf_get_last_block",
     "scanerf_ray_firsthit_block", "scanerf_process_occupied_grid", "scanerf_embedding_bg_point_grad", "scanerf_voxelize_mesh", "scanerf_ray_valid", "scanerf_compact_rays",
 ]
+
+# test / measurement entry points (include/scanerf_hip.h declares them, the default build exports them): NOT required --
+# a lean product build may drop csrc/h3_selftest.hip and the probes; their users (tests, bench.py's live ceiling) check first
+OPTIONAL_SYMBOLS = ["scanerf_h3_selftest", "scanerf_rec8_selftest", "scanerf_icache_sweep", "scanerf_gather_rate_probe"]
+
+
+def has_symbol(name):
+    return hasattr(lib(), name)
 
 
 class RenderCfg(ctypes.Structure):
@@ -71,8 +79,9 @@ def lib():
 
 
 def audit_state():
-    """What tools/isa_audit.py (run by `make`) said about the library file this process loads: {"status": "passed" | "skipped"
-    (built with SCANERF_SKIP_ISA_AUDIT=1) | "failed" | "stale" (the file changed after the audit) | "missing"}."""
+    """What tools/isa_audit.py (run by `make`) said about the library file this process loads: {"status": "passed" | "unvalidated"
+    (another compiler build than the validated one; no packed-f32 instruction found) | "skipped" (built with
+    SCANERF_SKIP_ISA_AUDIT=1) | "failed" | "stale" (the file changed after the audit) | "missing"}."""
     import hashlib
     import json
     side = os.path.join(os.path.dirname(LIB_PATH), "isa_audit.json")
@@ -96,6 +105,8 @@ def check(status, what):
         msg = lib().scanerf_last_error().decode("utf-8", "replace")
         raise RuntimeError(f"scanerf {what} failed ({status}): {msg}")
     if SWEEP_ICACHE:
+        if not has_symbol("scanerf_icache_sweep"):
+            raise RuntimeError("scanerf: SWEEP_ICACHE needs scanerf_icache_sweep (a test entry point this build does not export)")
         if lib().scanerf_icache_sweep(stream()) != 0:
             raise RuntimeError("scanerf icache_sweep failed: " + lib().scanerf_last_error().decode("utf-8", "replace"))
 

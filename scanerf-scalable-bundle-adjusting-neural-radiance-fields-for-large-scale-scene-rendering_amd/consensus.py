@@ -5,8 +5,10 @@ multiprocessing proxies (admm_trainer.py:124-179, tile.py:477-508).  Here every 
 scatters its tiles' {conf*se3 (6), conf (1), 1 (1)} rows into a dense zero [N_cam, 8] fp32
 buffer at the global camera ids and one in-place all-reduce(SUM) replaces the master:
 afterwards each rank computes the shared poses, the overlap set and the residuals locally
-(identical on all ranks up to fp32 summation order).  With one process (no process group)
-the same code runs without the collective.
+(identical on all ranks up to fp32 summation order).  Whenever a process group exists the
+reduce IS the collective, also at world size 1 (so that a one-GPU box exercises RCCL:
+tests/test_gpu_consensus.py, bench.py's `consensus_ms`); only without a process group does the
+same code run without it.
 
 Math (file:line in the reference):
   shared   = sum(conf*pose) / sum(conf), 0 -> 1 guard          admm_trainer.py:147-155
@@ -45,6 +47,11 @@ class ConsensusState:
         return torch.mean(self.rho[None, :] * c[self.overlap_flags])
 
 
+def collective_active(group=None):
+    """A process group exists: the exchanges go through its all-reduce (RCCL for CUDA tensors), whatever the world size."""
+    return dist.is_available() and dist.is_initialized()
+
+
 @torch.no_grad()
 def exchange(states, se3_list, conf_list=None, group=None):
     """One consensus round for the tiles this rank owns (>=1; admm_trainer.py:74-83 maps tile t to
@@ -58,7 +65,7 @@ def exchange(states, se3_list, conf_list=None, group=None):
         rows = torch.cat([conf[:, None] * se3.detach(), conf[:, None], torch.ones_like(conf)[:, None]], 1)
         buf.index_add_(0, st.cam_idx, rows)
     ntiles = torch.tensor([float(len(states))], device=s0.device)
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    if collective_active(group):
         dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)  # RCCL over xGMI, in place, compute stream
     w = buf[:, 6:7]
     shared = buf[:, :6] / torch.where(w == 0, torch.ones_like(w), w)
@@ -67,7 +74,7 @@ def exchange(states, se3_list, conf_list=None, group=None):
     primal = torch.zeros(1, device=s0.device)
     for st, se3 in zip(states, se3_list):
         primal += torch.mean(torch.abs(se3.detach() - shared[st.cam_idx]))
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    if collective_active(group):
         pr = torch.cat([primal, ntiles])
         dist.all_reduce(pr, op=dist.ReduceOp.SUM, group=group)
         primal, ntiles = pr[:1], pr[1:]

@@ -679,7 +679,7 @@ SCANERF_API int scanerf_render_backward(const float *rays_o, const float *rays_d
         BinWorkspace w;
         SCANERF_REQUIRE(bin_workspace_carve(scatter_ws, scatter_ws_bytes, 16 * a.bins.NB, blocks, w),
                         "render_backward: scatter workspace too small (%zu B)", scatter_ws_bytes);
-        a.bins.capacity = w.capacity;
+        a.bins.capacity = fused_coarse_capacity(w.capacity, B, S, a.bins.bucket_log);   // (never into a large table's fine area)
         a.bin_rowprefix = w.counts; a.bin_starts = w.starts; a.recs = w.recs; a.maxbits = w.maxbits;
         a.grad_features = grad_features;
         lds_extra = (size_t)16 * a.bins.NB * sizeof(uint32_t);

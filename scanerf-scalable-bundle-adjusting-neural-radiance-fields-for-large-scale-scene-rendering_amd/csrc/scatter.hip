@@ -821,8 +821,7 @@ struct SplitLayout {
 static bool split_layout(int B, int S, const BinGeom &g, SplitLayout &L)
 {
     if (g.bucket_log <= 13) return false;
-    const size_t n = (size_t)B * S * 16;
-    L.budget = (uint32_t)(n * 4 + n / 8 + 4096);
+    L.budget = (uint32_t)fused_record_budget(B, S);
     L.coarse_bytes = bin_workspace_head(16 * g.NB, g.W) + (size_t)L.budget * sizeof(Rec);
     L.nbins_f = 16 * (g.NB << (g.bucket_log - 13));
     L.fine_off = (L.coarse_bytes + 255) & ~(size_t)255;
@@ -836,10 +835,9 @@ SCANERF_API size_t scanerf_render_scatter_workspace_bytes(int B, int S, int T)
 {
     BinGeom g;
     if (!fused_geom(B, S, T, g)) return 0;
-    const size_t n = (size_t)B * S * 16;
     SplitLayout L;
     if (split_layout(B, S, g, L)) return L.total_bytes;
-    return bin_workspace_head(16 * g.NB, g.W) + (n * 4 + n / 8 + 4096) * sizeof(Rec);
+    return bin_workspace_head(16 * g.NB, g.W) + fused_record_budget(B, S) * sizeof(Rec);
 }
 
 SCANERF_API int scanerf_render_scatter_plan(const float *rays_o, const float *rays_d, const float *z_vals,
@@ -947,7 +945,7 @@ SCANERF_API int scanerf_render_scatter_accumulate(float *grad_features, int B, i
     BinWorkspace w;
     SCANERF_REQUIRE(bin_workspace_carve(workspace, workspace_bytes, nbins, g.W, w),
                     "render_scatter_accumulate: workspace too small (%zu B)", workspace_bytes);
-    g.capacity = w.capacity;
+    g.capacity = w.capacity = fused_coarse_capacity(w.capacity, B, S, g.bucket_log);
     g.rec8 = -1;  // as the plan recorded it in the workspace
     int nbins_acc = nbins;
     if (split_to_fine(B, S, g, w, workspace, workspace_bytes, grad_features, (hipStream_t)stream)) nbins_acc = 16 * g.NB;
@@ -1018,7 +1016,7 @@ static int accumulate_adam(float *params, float *exp_avg, float *exp_avg_sq, voi
     BinWorkspace w;
     SCANERF_REQUIRE(bin_workspace_carve(workspace, workspace_bytes, nbins, g.W, w),
                     "render_scatter_accumulate_adam: workspace too small (%zu B)", workspace_bytes);
-    g.capacity = w.capacity;
+    g.capacity = w.capacity = fused_coarse_capacity(w.capacity, B, S, g.bucket_log);
     g.rec8 = -1;  // as the plan recorded it in the workspace
     AdamEpilogue ad{ nullptr, nullptr, nullptr, 0u, params, exp_avg, exp_avg_sq, half_table, half_dtype, overflow_grad,
                      make_adam_args(lr, beta1, beta2, eps, step) };
@@ -1029,7 +1027,7 @@ static int accumulate_adam(float *params, float *exp_avg, float *exp_avg_sq, voi
                         "render_scatter_accumulate_adam2: second record set B=%d S=%d T=%d does not match the first", B, S2, T);
         SCANERF_REQUIRE(bin_workspace_carve(workspace2, workspace2_bytes, nbins, g2.W, w2),
                         "render_scatter_accumulate_adam2: second workspace too small (%zu B)", workspace2_bytes);
-        g2.capacity = w2.capacity;
+        g2.capacity = w2.capacity = fused_coarse_capacity(w2.capacity, B, S2, g2.bucket_log);
     }
     // large tables: both record sets through the split pass (both or neither: they meet in one image of one geometry)
     int nbins_acc = nbins;

@@ -458,6 +458,22 @@ inline bool bin_workspace_carve(void *workspace, size_t bytes, int nbins, int W,
     w.capacity = cap > 0x7ffffff0u ? 0x7ffffff0u : (uint32_t)cap;
     return true;
 }
+// Record budget of a fused plan (16-byte records): 4 pairs per (sample, level) + straddle slack.
+inline size_t fused_record_budget(int B, int S)
+{
+    const size_t n = (size_t)B * S * 16;
+    return n * 4 + n / 8 + 4096;
+}
+// Large tables (buckets above 2^13 entries): the workspace scanerf_render_scatter_workspace_bytes sizes carries a second, FINE
+// record area behind the coarse records' budget (scatter.hip SplitLayout), and a cached workspace may be larger still.  What the
+// producer and the consumers may fill with coarse records ends at the budget: beyond it the overflow-table fallback takes over
+// (records written into the fine area would be dropped and overwritten by the split pass).
+inline uint32_t fused_coarse_capacity(uint32_t capacity, int B, int S, int bucket_log)
+{
+    if (bucket_log <= 13) return capacity;
+    const size_t budget = fused_record_budget(B, S);
+    return capacity < budget ? capacity : (uint32_t)budget;
+}
 __host__ __device__ inline uint32_t rec_capacity(uint32_t capacity16, int fmt)
 {
     return fmt == 1 ? capacity16 * 2u : (fmt == 2 ? capacity16 + capacity16 / 3u : capacity16);   // 8- / 12- / 16-byte records in the same bytes

@@ -231,17 +231,23 @@ class TileModel(nn.Module):
         return z, d, valid
 
     @torch.no_grad()
-    def render_rays_fused(self, rays_o, rays_d, S_fg, S_bg, global_step, invalid_underground=False):
+    def render_rays_fused(self, rays_o, rays_d, S_fg, S_bg, global_step, invalid_underground=False, occlusion_mask=None):
         """tile.py:639-692 on the fused kernels: foreground (occupancy-sampled, contract_fore) and
-        background (inverse-z, contract_bg, infinity) renders, merged with the foreground's T_left."""
+        background (inverse-z, contract_bg, infinity) renders, merged with the foreground's T_left.
+        occlusion_mask [B,1] bool (tile.py:655,661): both branches' valid sets are ANDed with it
+        (hashgrid/__init__.py:420-421,479-480); a masked ray renders as zeros with T_left = 1, as every invalid ray."""
         self.packed.pack(self.decoder.blob(), network.weight_feature(global_step, self.device), network.skip_levels(global_step))
         table = self.gather_table()
         box = (self.min_bbox.tolist(), self.bbox_size.tolist())
         z, dist = self.sample(rays_o, rays_d, S_fg)
         vf = torch.all(z != -1, dim=-1)
+        if occlusion_mask is not None:
+            vf = vf & occlusion_mask[..., 0]
         fg, wfg = render.render_forward(rays_o, rays_d, z, dist, table, self.resolution, self.packed, *box, render.FORE,
                                         False, ray_valid=vf)
         zb, db, vb = self.inverse_z_sampling(rays_o, rays_d, S_bg, invalid_underground)
+        if occlusion_mask is not None:
+            vb = vb & occlusion_mask[..., 0]
         bg, wbg = render.render_forward(rays_o, rays_d, zb, db, table, self.resolution, self.packed, *box, render.BG,
                                         True, ray_valid=vb)
         T = fg[:, render.T_LEFT, None]

@@ -1,0 +1,148 @@
+"""Golden vectors G13-G15 from the reference's importable Python half (round 5).
+
+Run ONCE in the build container (where /root/reference exists):
+
+    python tests/golden/make_golden_sampling.py
+
+G13  PyHashGridBG.__init__'s per-axis level resolutions (hashgrid/PyHashGridBG.py:53-62) for cubic and NON-cubic boxes, built
+     exactly as HashGrid.__init__ builds its arguments (hashgrid/__init__.py:35,56-57: base / finest = bbox_size /
+     bbox_size.min() * grid_resolution, .int()).
+G14  HashGrid.inverse_z_sampling (hashgrid/__init__.py:306-337) with invalid_underground in {False, True}; the CUDA-only
+     ray_aabb_intersection it calls is replaced by this repo's C oracle of that op (in-place `bounds`, as the binding).
+G15  HashGrid.render_fore_rays / render_bg_rays (hashgrid/__init__.py:413-509): the valid-mask logic (all(z != -1) & occlusion
+     mask; bg valid from inverse_z_sampling & occlusion mask), the zero / one fill of invalid rays and the scatter of the
+     rendered rows back -- with this repo's C oracle standing in for the three CUDA-only ops (sample_points_grid,
+     ray_aabb_intersection, the hash encoder).  TRAIN and INFERENCE, with and without an occlusion mask.
+
+Only DATA is written (inputs + the reference's outputs); no reference text is copied.  Nothing here runs on the GPU box.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+from make_golden import REF, ROOT, _stub_modules  # noqa: E402
+
+sys.dont_write_bytecode = True
+
+
+def main():
+    _stub_modules()
+    sys.path.insert(0, REF)
+    import network  # noqa
+    import hashgrid as ref_hashgrid  # noqa
+    import importlib
+    ref_bg = importlib.import_module("hashgrid.PyHashGridBG")
+    sys.path.insert(0, ROOT)
+    from oracle import oracle
+
+    def save(name, **kw):
+        kw = {k: (v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)) for k, v in kw.items()}
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), **kw)
+        print("wrote", name, {k: v.shape for k, v in kw.items()})
+
+    # ---- G13: level resolutions, per axis
+    g13 = {}
+    cases = [((8.0, 8.0, 8.0), (32, 2048)), ((8.0, 4.0, 16.0), (32, 2048)), ((10.0, 6.0, 7.5), (32, 8192)),
+             ((3.0, 9.0, 4.5), (16, 512)), ((12.0, 12.0, 5.0), (32, 4096))]
+    for i, (tile_size, (gb, gf)) in enumerate(cases):
+        bbox_size = torch.tensor(tile_size) * 2                                       # hashgrid/__init__.py:50
+        fin = (bbox_size / bbox_size.min() * gf).int()                                # :56
+        base = (bbox_size / bbox_size.min() * gb).int()                               # :57
+        he = ref_bg.PyHashGridBG("cpu", torch.zeros(3), bbox_size, 16, 2, 4, base, fin, "uniform")
+        g13[f"tile_size{i}"] = np.array(tile_size, np.float32)
+        g13[f"grid_resolution{i}"] = np.array([gb, gf])
+        g13[f"resolution{i}"] = he.resolution
+    g13["n"] = np.array(len(cases))
+    save("g13_resolutions", **g13)
+
+    # ---- a HashGrid without its native-dependent constructor (as make_golden.py), native ops -> this repo's C oracle
+    hgm = ref_hashgrid.HashGrid.__new__(ref_hashgrid.HashGrid)
+    torch.nn.Module.__init__(hgm)
+    hgm.device = torch.device("cpu")
+    corner, size = torch.tensor([-4.0, -3.0, -5.0]), torch.tensor([8.0, 8.0, 8.0])
+    hgm.bbox_center = corner + size / 2.0
+    hgm.bbox_size = size * 2
+    hgm.min_bbox = hgm.bbox_center - hgm.bbox_size / 2.0
+
+    def aabb(rays_o, rays_d, center, sz, bounds):  # cuda/binding.cpp ray_aabb_intersection: fills `bounds` in place
+        bounds.copy_(torch.from_numpy(oracle.ray_aabb_intersection(rays_o.numpy(), rays_d.numpy(), center.numpy(), sz.numpy())))
+
+    def spg(rays_o, rays_d, z_vals, dists, block_corner, block_size, occ, log2dim):  # sample_points_grid, in place
+        z, d = oracle.sample_points_grid(rays_o.numpy(), rays_d.numpy(), block_corner.numpy(), block_size.numpy(), occ,
+                                         log2dim, z_vals.shape[1])
+        z_vals.copy_(torch.from_numpy(z))
+        dists.copy_(torch.from_numpy(d))
+
+    ref_hashgrid.ray_aabb_intersection = aabb
+    ref_hashgrid.sample_points_grid = spg
+
+    # ---- G14: inverse_z_sampling
+    g = torch.Generator().manual_seed(14)
+    B = 48
+    ro = (torch.rand(B, 3, generator=g) - 0.5) * 8 + hgm.bbox_center          # inside the tile
+    ro[40:] = hgm.bbox_center + torch.tensor([30.0, 2.0, 1.0])                 # outside the 2x box
+    rd = torch.randn(B, 3, generator=g) * (0.5 + torch.rand(B, 1, generator=g))
+    rd[40:44] = torch.tensor([1.0, 0.1, 0.0])                                  # pointing away: they miss the box -> far = 0.1
+    rd[44:] = torch.tensor([-1.0, 0.02, 0.01])                                 # through the box from outside
+    rd[:6, 1] = -torch.abs(rd[:6, 1]) * 4 - 1.0                                # steep downwards: leave through the floor
+    g14 = {"rays_o": ro, "rays_d": rd, "bbox_center": hgm.bbox_center, "bbox_size": hgm.bbox_size, "S": np.array(24)}
+    for ug in (False, True):
+        z, d, v = hgm.inverse_z_sampling(ro, rd, 24, invalid_underground=ug)
+        g14["z_ug%d" % ug], g14["dists_ug%d" % ug], g14["valid_ug%d" % ug] = z.contiguous(), d, v
+    assert g14["valid_ug1"].sum() < B and g14["valid_ug1"].sum() > 0
+    save("g14_inverse_z", **g14)
+
+    # ---- G15: render_fore_rays / render_bg_rays
+    torch.manual_seed(15)
+    mlp = network.ShallowMLP(32)
+    network.init_model(mlp, "xavier")
+    T = 2 ** 10
+    fin = (hgm.bbox_size / hgm.bbox_size.min() * 2048).int()
+    base = (hgm.bbox_size / hgm.bbox_size.min() * 32).int()
+    res = oracle.level_resolutions(base, fin, 16)
+    feats = torch.randn(16, T, 2) * 0.5
+
+    class HE(torch.nn.Module):
+        def forward(self, x):
+            return oracle.encode_bg(x.reshape(-1, 3).contiguous(), feats, res).reshape(*x.shape[:-1], 32)
+
+    hgm.HE = HE()
+    hgm.sampler_log2dim = torch.tensor([4, 4, 4], dtype=torch.int32)
+    occ = torch.rand(16, 16, 16) < 0.25                                       # sparse: some rays meet no occupied cell
+    occ[:, :, :4] = False
+    hgm.occupied_grid = occ
+    B, S = 40, 16
+    ro = (torch.rand(B, 3) - 0.5) * 8 + hgm.bbox_center
+    rd = torch.randn(B, 3) * (0.5 + torch.rand(B, 1))
+    rd[:5, 1] = -torch.abs(rd[:5, 1]) * 4 - 1.0
+    mask = (torch.rand(B, 1) < 0.7)
+    g15 = {"rays_o": ro, "rays_d": rd, "features": feats, "res": res, "occ": occ, "log2dim": hgm.sampler_log2dim,
+           "tile_corner": corner, "tile_size": size, "occlusion_mask": mask, "global_step": np.array(6000), "S": np.array(S)}
+    sd = {k: v for k, v in mlp.state_dict().items()}
+    g15.update({"sd." + k: v for k, v in sd.items()})
+    for tag, m in (("nomask", None), ("mask", mask)):
+        for mode in (0, 1):
+            with torch.no_grad():
+                fo, ok = hgm.render_fore_rays(ro, rd, S, mlp, mode, occlusion_mask=m, global_step=6000)
+                assert ok
+                bo, ok = hgm.render_bg_rays(ro, rd, S, mlp, mode, occlusion_mask=m, global_step=6000, bg_mode="IZ",
+                                            invalid_underground=True)
+                assert ok
+            for k in ("fore_valid", "pred_color", "pred_depth", "specular", "diffuse", "T_left"):
+                g15[f"fg_{tag}_m{mode}_{k}"] = fo[k]
+            for k in ("valid", "rgb", "depth", "specular", "diffuse", "T_left"):
+                g15[f"bg_{tag}_m{mode}_{k}"] = bo[k]
+            if mode == 0:
+                g15[f"fg_{tag}_l2_reg_specular"] = fo["l2_reg_specular"]
+                g15[f"bg_{tag}_l2_reg_specular"] = bo["l2_reg_specular"]
+    nv = int(g15["fg_nomask_m0_fore_valid"].sum())
+    assert 0 < nv < B, nv
+    save("g15_render_masks", **g15)
+
+
+if __name__ == "__main__":
+    main()

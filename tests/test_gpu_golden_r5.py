@@ -1,0 +1,66 @@
+"""The product's GPU path against the reference's own outputs captured in round 5 (tests/golden/make_golden_sampling.py):
+G14 HashGrid.inverse_z_sampling, G15 render_fore_rays / render_bg_rays (valid masks, fills, values)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+T = torch.from_numpy
+
+
+def _sd(g):
+    return {k[3:]: T(v) for k, v in g.items() if k.startswith("sd.")}
+
+
+def test_inverse_z_sampling_reproduces_reference_golden_g14(golden):
+    """hashgrid/__init__.py:306-337 on the GPU (HIP ray_aabb_intersection + torch): the reference's z / dists / valid."""
+    import scanerf_amd  # noqa
+    from scanerf_amd.tile_model import TileModel
+    g = golden("g14_inverse_z")
+    size = g["bbox_size"] / 2
+    corner = g["bbox_center"] - size / 2
+    m = TileModel(corner.tolist(), size.tolist(), DEV, log2_T=10)
+    for ug in (0, 1):
+        z, d, v = m.inverse_z_sampling(T(g["rays_o"]).to(DEV), T(g["rays_d"]).to(DEV), int(g["S"]), invalid_underground=bool(ug))
+        np.testing.assert_array_equal(v.cpu().numpy(), g["valid_ug%d" % ug])
+        np.testing.assert_allclose(z.cpu().numpy(), g["z_ug%d" % ug], rtol=2e-6)
+        np.testing.assert_allclose(d.cpu().numpy(), g["dists_ug%d" % ug], rtol=1e-4, atol=1e-6 * float(g["z_ug0"].max()))
+
+
+@pytest.mark.parametrize("tag", ["nomask", "mask"])
+def test_render_rays_fused_reproduces_reference_golden_g15(golden, tag):
+    """render_fore_rays / render_bg_rays of the reference (INFERENCE mode) vs TileModel.render_rays_fused: same valid sets
+    (sampler sentinel, under-ground rule, occlusion mask), zeros / T_left = 1 on invalid rays, values within 1e-4."""
+    import scanerf_amd  # noqa
+    from scanerf_amd import network, render
+    from scanerf_amd.tile_model import TileModel
+    g = golden("g15_render_masks")
+    m = TileModel(g["tile_corner"].tolist(), g["tile_size"].tolist(), DEV, log2_T=10, sampler_log2dim=4)
+    assert np.array_equal(m.resolution.cpu().numpy(), g["res"])
+    m.set_occupancy(T(g["occ"]))
+    with torch.no_grad():
+        m.features.copy_(T(g["features"]).to(DEV))
+    m.decoder.load_ref_state_dict(_sd(g))
+    mask = T(g["occlusion_mask"]).to(DEV) if tag == "mask" else None
+    S = int(g["S"])
+    out = m.render_rays_fused(T(g["rays_o"]).to(DEV), T(g["rays_d"]).to(DEV), S, S, int(g["global_step"]),
+                              invalid_underground=True, occlusion_mask=mask)
+    vf, vb = out["fore_valid"].bool().cpu().numpy(), out["bg_valid"].bool().cpu().numpy()
+    np.testing.assert_array_equal(vf, g[f"fg_{tag}_m1_fore_valid"])
+    np.testing.assert_array_equal(vb, g[f"bg_{tag}_m1_valid"])
+    assert 0 < vf.sum() < vf.size and 0 < vb.sum() < vb.size
+    fg, bg = out["fg"].cpu().numpy(), out["bg"].cpu().numpy()
+    tol = dict(rtol=1e-4, atol=2e-6)
+    for arr, pre, rgbk, depk in ((fg, "fg", "pred_color", "pred_depth"), (bg, "bg", "rgb", "depth")):
+        np.testing.assert_allclose(arr[:, render.RGB], g[f"{pre}_{tag}_m1_{rgbk}"], **tol)
+        np.testing.assert_allclose(arr[:, render.DEPTH], g[f"{pre}_{tag}_m1_{depk}"][:, 0], rtol=1e-4, atol=1e-4)
+        np.testing.assert_allclose(arr[:, render.DIFFUSE], g[f"{pre}_{tag}_m1_diffuse"], **tol)
+        np.testing.assert_allclose(arr[:, render.SPECULAR], g[f"{pre}_{tag}_m1_specular"], **tol)
+        np.testing.assert_allclose(arr[:, render.T_LEFT], g[f"{pre}_{tag}_m1_T_left"][:, 0], **tol)
+    # invalid rays: exactly the reference's fills
+    assert not fg[~vf][:, [0, 1, 2, 3, 5, 6, 7, 8, 9, 10]].any() and (fg[~vf][:, render.T_LEFT] == 1).all()
+    assert not bg[~vb][:, [0, 1, 2, 3, 5, 6, 7, 8, 9, 10]].any() and (bg[~vb][:, render.T_LEFT] == 1).all()
+    # merged prediction (tile.py:666-690)
+    Tl = g[f"fg_{tag}_m1_T_left"]
+    np.testing.assert_allclose(out["pred_color"].cpu().numpy(), g[f"fg_{tag}_m1_pred_color"] + Tl * g[f"bg_{tag}_m1_rgb"], **tol)

@@ -317,6 +317,8 @@ def test_render_forward_vs_oracle(S, bg, S_):
 def test_h3_backward_primitives(S):
     """csrc/render_h3.h: transposed image reads (dX = W^T dY) and staged sample-reduction products (dW = dY X^T)
     of the split-f16 arithmetic against float64."""
+    from conftest import need_symbol
+    need_symbol("scanerf_h3_selftest")
     import ctypes
     from scanerf_amd import network, render
     from scanerf_amd._capi import check, lib, stream
@@ -1204,6 +1206,8 @@ def test_rec8_codec_against_its_restatement(S):
     f32 values they stand for (half a unit of the 13-bit significand = 2^-13 of the pair's power-of-two ceiling, i.e. 2^-13 to
     2^-12 of its larger component, + 2^-14 in the weight).  Zeros, denormals, 1e38, values
     that round up to the next power of two, one-entry records (k = 15)."""
+    from conftest import need_symbol
+    need_symbol("scanerf_rec8_selftest")
     import ctypes
     from scanerf_amd._capi import check, lib, stream
     rng = np.random.default_rng(21)
@@ -1529,3 +1533,57 @@ def test_coarse_to_fine_level_skip_is_bit_identical(S, step, monkeypatch):
                 lv = 4 * (j >> 1) + 2 * h + (j & 1)
                 both = (sk >> (4 * (j >> 1) + (j & 1))) & (sk >> (4 * (j >> 1) + 2 + (j & 1))) & 1
                 assert torch.equal(xa[:, h, j], torch.zeros_like(xa[:, h, j]) if both else xb[:, h, j]), (h, j, lv)
+
+
+@pytest.mark.parametrize("log2_T,finest,fgbg", [(22, 2048, False), (24, 20000, False), (22, 20000, True), (24, 2048, True)])
+def test_split_pass_feeding_the_adam_epilogue(log2_T, finest, fgbg, monkeypatch):
+    """Round 4's split pass (csrc/scatter.hip k_bin_split) in front of the accumulate's Adam epilogue -- accumulate_adam with one
+    record set (train_step_fused) and adam2 with two (train_step_fgbg), window shifts 1 (2^22) and 3 (2^24), with and without
+    window-crossing pairs (finest resolution above 8 192: second entries through the overflow table, consumed through the fine
+    stream's flag).  Only reachable with SCANERF_LARGE_T_ROUTE=fused.  Compared with the same step under SCANERF_NO_SPLIT=1 (the
+    window re-reads, 16-byte records) AND under the default dfeat route: updated parameters and both moments after two steps.
+    The split re-encodes the records as Rec12 (components rounded to 19 mantissa bits): moments agree to ~1e-5 of their maximum."""
+    from scanerf_amd import render
+    from scanerf_amd.tile_model import TileModel, train_step_fgbg, train_step_fused
+    B, S_ = 3000, 64
+
+    def run(route, no_split):
+        monkeypatch.setenv("SCANERF_LARGE_T_ROUTE", route)
+        if no_split:
+            monkeypatch.setenv("SCANERF_NO_SPLIT", "1")
+        else:
+            monkeypatch.delenv("SCANERF_NO_SPLIT", raising=False)
+        torch.manual_seed(8)
+        m = TileModel([-4, -4, -4], [8, 8, 8], DEV, log2_T=log2_T, seed=2, grid_resolution=(32, finest))
+        with torch.no_grad():
+            m.features.mul_(1000.0)
+        opt = torch.optim.Adam(m.decoder.parameters(), lr=1e-3)
+        o = torch.rand(B, 3, device=DEV) * 8 - 4
+        d = torch.nn.functional.normalize(torch.randn(B, 3, device=DEV), dim=-1)
+        tgt = torch.rand(B, 3, device=DEV)
+        for it in range(2):
+            if fgbg:
+                train_step_fgbg(m, opt, o, d, tgt, S_, S_, 20000 + it, table_lr=1e-2)
+            else:
+                train_step_fused(m, opt, o, d, tgt, S_, 20000 + it, table_lr=1e-2, fused_adam=True)
+        torch.cuda.synchronize()
+        return m.features.detach().clone(), m.exp_avg.clone(), m.exp_avg_sq.clone(), m
+
+    p0, m0, v0, model = run("fused", False)          # the split pass
+    init = TileModel([-4, -4, -4], [8, 8, 8], DEV, log2_T=log2_T, seed=2, grid_resolution=(32, finest)).features.detach() * 1000.0
+    assert model.adam_step == 2 and float((p0 != init).float().mean()) > 1e-4   # the table moved
+    del model
+    for route, no_split in (("fused", True), ("dfeat", False)):
+        p1, m1, v1, _ = run(route, no_split)
+        sm, sv = float(m1.abs().max()), float(v1.abs().max())
+        assert sm > 0 and sv > 0
+        assert float((m0 - m1).abs().max()) <= 2e-5 * sm, (route, no_split, float((m0 - m1).abs().max()) / sm)
+        assert float((v0 - v1).abs().max()) <= 4e-5 * sv, (route, no_split, float((v0 - v1).abs().max()) / sv)
+        # an entry moves iff it has a gradient; entries whose gradient is well above the fixed-point floor move alike
+        big = m1.abs() > 1e-3 * sm
+        assert bool(big.any())
+        dp = (p0 - p1).abs()[big]
+        assert float(dp.max()) <= 2e-4, (route, no_split, float(dp.max()))
+        moved0, moved1 = p0 != init, p1 != init
+        assert float((moved0 != moved1).float().mean()) < 1e-3
+        del p1, m1, v1

@@ -115,3 +115,59 @@ def test_g10_adam_formula_matches_torch_adam(golden):
     np.testing.assert_allclose(p, g["p1"], rtol=2e-5, atol=1e-7)
     O.adam_step(p, g["g1"], m, v, 1e-2, 0.9, 0.99, 1e-15, 1)
     np.testing.assert_allclose(p, g["p2"], rtol=2e-5, atol=1e-7)
+
+
+# ---- round 5: G13-G15 (tests/golden/make_golden_sampling.py)
+def test_g13_level_resolutions_per_axis(golden):
+    """PyHashGridBG.__init__'s resolution rule (hashgrid/PyHashGridBG.py:53-62) on cubic and non-cubic boxes: the oracle's
+    restatement AND the product's host function give the reference's own integers."""
+    import scanerf_amd  # noqa
+    from scanerf_amd.hashgrid import level_resolutions
+    g = golden("g13_resolutions")
+    for i in range(int(g["n"])):
+        bbox_size = T(g[f"tile_size{i}"]) * 2
+        gb, gf = (int(v) for v in g[f"grid_resolution{i}"])
+        fin = (bbox_size / bbox_size.min() * gf).int()
+        base = (bbox_size / bbox_size.min() * gb).int()
+        np.testing.assert_array_equal(O.level_resolutions(base, fin, 16).numpy(), g[f"resolution{i}"])
+        np.testing.assert_array_equal(level_resolutions(base, fin, 16).numpy(), g[f"resolution{i}"])
+        tile = O.Tile([0, 0, 0], g[f"tile_size{i}"].tolist(), grid_resolution=(gb, gf))
+        np.testing.assert_array_equal(tile.res.numpy(), g[f"resolution{i}"])
+
+
+def test_g14_inverse_z_sampling(golden):
+    g = golden("g14_inverse_z")
+    for ug in (0, 1):
+        z, d, v = O.inverse_z_sampling(T(g["rays_o"]), T(g["rays_d"]), T(g["bbox_center"]), T(g["bbox_size"]), int(g["S"]),
+                                       invalid_underground=bool(ug))
+        np.testing.assert_array_equal(v.numpy(), g["valid_ug%d" % ug])
+        np.testing.assert_allclose(z.numpy(), g["z_ug%d" % ug], rtol=1e-6)
+        np.testing.assert_allclose(d.numpy(), g["dists_ug%d" % ug], rtol=1e-5, atol=1e-7)
+
+
+def g15_tile(g):
+    tile = O.Tile(g["tile_corner"].tolist(), g["tile_size"].tolist(), log2_T=10, sampler_log2dim=4)
+    tile.occ = T(g["occ"])
+    assert np.array_equal(tile.res.numpy(), g["res"]) and np.array_equal(tile.log2dim.numpy(), g["log2dim"])
+    return tile
+
+
+def test_g15_fore_and_bg_valid_masks_and_fills(golden):
+    """render_fore_rays / render_bg_rays (hashgrid/__init__.py:413-509): valid sets (sampler sentinel, under-ground rule,
+    occlusion mask), zero / one fills of the invalid rays, values of the valid ones."""
+    g = golden("g15_render_masks")
+    tile, sd = g15_tile(g), _sd(g)
+    for tag, m in (("nomask", None), ("mask", T(g["occlusion_mask"]))):
+        for mode in (0, 1):
+            out = O.render_rays(tile, T(g["features"]), sd, T(g["rays_o"]), T(g["rays_d"]), int(g["S"]), int(g["S"]), mode,
+                                int(g["global_step"]), invalid_underground=True, occlusion_mask=m)
+            np.testing.assert_array_equal(out["fore_valid"].numpy(), g[f"fg_{tag}_m{mode}_fore_valid"])
+            np.testing.assert_array_equal(out["bg_valid"].numpy(), g[f"bg_{tag}_m{mode}_valid"])
+            for k, gk in (("rgb", "pred_color"), ("depth", "pred_depth"), ("specular", "specular"), ("diffuse", "diffuse"),
+                          ("T_left", "T_left")):
+                np.testing.assert_allclose(out["fg"][k].numpy(), g[f"fg_{tag}_m{mode}_{gk}"], rtol=2e-5, atol=1e-7, err_msg=f"fg {k}")
+            for k in ("rgb", "depth", "specular", "diffuse", "T_left"):
+                np.testing.assert_allclose(out["bg"][k].numpy(), g[f"bg_{tag}_m{mode}_{k}"], rtol=2e-5, atol=1e-7, err_msg=f"bg {k}")
+            if mode == O.TRAIN:
+                np.testing.assert_allclose(out["fg_l2_reg_specular"].numpy(), g[f"fg_{tag}_l2_reg_specular"], rtol=2e-5)
+                np.testing.assert_allclose(out["bg_l2_reg_specular"].numpy(), g[f"bg_{tag}_l2_reg_specular"], rtol=2e-5)

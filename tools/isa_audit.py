@@ -4,7 +4,8 @@ launch-to-launch bit-identical for ONE compiled listing each.  This tool pins th
 translation units the spilled-register count, the instruction count and a digest of the instruction stream, next to the
 compiler version, in <pkg>/csrc/isa_manifest.json.
 
-    tools/isa_audit.py --check    (run by `make`: fails if a listing differs from the validated one)
+    tools/isa_audit.py --check    (run by `make`: fails if a listing differs from the validated one UNDER THE VALIDATED COMPILER;
+                                   under another compiler build it passes with status "unvalidated" when no packed-f32 is found)
     tools/isa_audit.py --update   (after re-validating on the GPU: tests/test_gpu_determinism.py + tools/fault_probe.py)
 
 Rule checked besides the digests (found the hard way):
@@ -97,7 +98,20 @@ def main():
         raise SystemExit(f"isa_audit: {MANIFEST} is missing: run tools/isa_audit.py --update after validating on the GPU")
     ref = json.load(open(MANIFEST))
     if ref["compiler"] != now["compiler"]:
-        bad.append(f"compiler changed: validated under [{ref['compiler']}], building with [{now['compiler']}]")
+        # Another compiler build: every listing may differ and none of them has been validated.  That is not a reason to refuse
+        # the BUILD (a product build must survive a ROCm point release): as long as the one rule that can be checked statically
+        # holds -- no packed-f32 arithmetic in any kernel -- the library is built and marked "unvalidated"; _capi.lib() warns
+        # loudly, and the tests that stand on the validated listings (tests/test_gpu_determinism.py) skip with this reason.
+        why = [f"compiler changed: validated under [{ref['compiler']}], built with [{now['compiler']}]; the kernels' listings "
+               "were not compared with the validated ones"]
+        if bad:
+            write_state("failed", now, bad + why)
+            raise SystemExit("isa_audit: " + "\n  ".join(bad + why))
+        write_state("unvalidated", now, why)
+        print("isa_audit: WARNING: " + why[0] + "\n  no packed-f32 instruction in any kernel (the rule of DESIGN.md 4.10 holds); the "
+              "library is marked UNVALIDATED: re-run tests/test_gpu_determinism.py + tools/fault_probe.py on the GPU, then "
+              "tools/isa_audit.py --update", file=sys.stderr)
+        return
     for u in UNITS:
         r, n = ref["units"].get(u, {}), now["units"][u]
         for k in sorted(set(r) | set(n)):
