@@ -390,6 +390,28 @@ int scanerf_voxelize_mesh(const float *vertices, const int32_t *faces, int V, in
                           const float *block_corner, const float *block_size, uint8_t *vis, int init_out,
                           uint8_t *outside, uint32_t *scratch6, scanerf_stream_t stream);
 
+/* ---- stand-alone decoder op (ABI 7): network.ShallowMLP.forward (network.py:172-190) and its adjoint, one launch each, on the
+ * matrix cores at the fused kernels' arithmetic (split-f16 operands, three products per term, f32 accumulate: f32-equivalent).
+ * What an unchanged HashGrid.render_batch_rays calls between the encoder op and its torch compositing
+ * (hashgrid/__init__.py:545-548: decoder(cat([features, rays_d]), weight_feature=...)).
+ *   feats / dirs: rows of 32 / 3 floats with row strides ld_feats / ld_dirs IN FLOATS -- for the reference's concatenated
+ *     x [N,35]: feats = x, dirs = x + 32, both strides 35 (no slicing copy); the direction is normalised inside
+ *     (d / (|d| + 1e-8), network.py:177);
+ *   workspace: scanerf_pack_decoder(blob, weight_feature, workspace) -- weight_feature [32] is folded into the first layer;
+ *   forward outputs: sigma [N] (= [N,1]), diffuse / specular / tint [N,3], contiguous; specular is the RAW sigmoid output
+ *     (the caller multiplies by tint, hashgrid/__init__.py:568);
+ *   backward: g_* = dL/d(those outputs) (contiguous; any may be NULL = zero) -> d_feats rows of 32 floats (stride ld_dfeats;
+ *     dL/d(features), weight_feature applied), d_dirs rows of 3 floats (stride ld_ddirs; NULL = not wanted) -- for the
+ *     gradient of x [N,35]: d_feats = gx, d_dirs = gx + 32, strides 35 -- and grad_blob [13994] += dL/d(blob) (deterministic
+ *     reduction of one partial row per workgroup); dw_partial: scratch of scanerf_decoder_backward_grid(N) x 13994 floats. */
+int scanerf_decoder_forward(const float *feats, int ld_feats, const float *dirs, int ld_dirs, const float *workspace,
+                            float *sigma, float *diffuse, float *specular, float *tint, long long N, scanerf_stream_t stream);
+int scanerf_decoder_backward_grid(long long N);
+int scanerf_decoder_backward(const float *feats, int ld_feats, const float *dirs, int ld_dirs, const float *workspace,
+                             const float *weight_feature, const float *g_sigma, const float *g_diffuse, const float *g_specular,
+                             const float *g_tint, float *d_feats, int ld_dfeats, float *d_dirs, int ld_ddirs, float *dw_partial,
+                             float *grad_blob, long long N, scanerf_stream_t stream);
+
 #define SCANERF_RAY_OUT 16
 
 #ifdef __cplusplus

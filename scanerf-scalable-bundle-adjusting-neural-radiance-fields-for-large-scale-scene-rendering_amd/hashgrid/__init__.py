@@ -7,3 +7,4 @@ from .lib.HASHGRID import (Sampler, accumulate_color, bg_pts_inference, bg_pts_i
                            update_outgoing_bidx_v2)
 from .PyHashGrid import HashEmbedding, PyHashGrid  # noqa: F401
 from .PyHashGridBG import HashEmbeddingBG, PyHashGridBG, level_resolutions  # noqa: F401
+from .grid import INFERENCE, TRAIN, HashGrid  # noqa: F401,E402  (the reference defines HashGrid in hashgrid/__init__.py:32)

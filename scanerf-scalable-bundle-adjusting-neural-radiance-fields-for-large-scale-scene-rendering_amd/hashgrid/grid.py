@@ -1,0 +1,292 @@
+"""`HashGrid`: the reference's scene-representation module (hashgrid/__init__.py:32-596) with its constructor arguments,
+attributes and method names, on this package's HIP ops -- what tile.py constructs (tile.py:114-125) and calls
+(tile.py:639-692: render_fore_rays / render_bg_rays; :866-877: pruning_grid; :510-531: export).
+
+render_batch_rays has two routes with the same outputs (the reference's dictionary):
+  * fused (default where it applies: 16 levels, contract_fore / contract_bg, a decoder that exposes its blob -- this package's
+    network.ShallowMLP or tile_model.Decoder): ONE differentiable op, render.FusedRenderRays (one HIP launch forward, one
+    backward); every loss a caller builds on rgb / depth / diffuse / specular / tint / T_left / l2_reg_specular reaches the
+    table, the decoder and the rays through loss.backward();
+  * op by op (any decoder module, `fused = False`): the reference's own sequence -- HIP encoder op through the autograd
+    wrapper, decoder(inputs, weight_feature=...), torch compositing (hashgrid/__init__.py:545-594).
+"""
+import math
+import os
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import render
+from ..cuda import ray_aabb_intersection, sample_points_grid, voxelize_mesh
+from .lib.HASHGRID import Sampler
+from .PyHashGridBG import PyHashGridBG
+
+TRAIN, INFERENCE = 0, 1   # cfg.py:1-2
+
+
+class HashGrid(nn.Module):
+    def __init__(self, device, bbox_corner, bbox_size, log2_hashmap_size=24, grid_resolution=(32, 2048), sampler_log2dim=4,
+                 init_outside=False, model_path="", near=None, far=None):
+        super().__init__()
+        self.device = device
+        bbox_corner = torch.as_tensor(bbox_corner, dtype=torch.float32)
+        bbox_size = torch.as_tensor(bbox_size, dtype=torch.float32)
+        self.bbox_center = bbox_corner + bbox_size / 2.0
+        self.bbox_size = bbox_size * 2                     # 2 times for the background (:50)
+        self.min_bbox = self.bbox_center - self.bbox_size / 2.0
+        self.max_bbox = self.bbox_center + self.bbox_size / 2.0
+        self.log2_hashmap_size = log2_hashmap_size
+        self.finest_resolution = (self.bbox_size / self.bbox_size.min() * grid_resolution[1]).int().cpu()
+        self.base_resolution = (self.bbox_size / self.bbox_size.min() * grid_resolution[0]).int().cpu()
+        self.HE = PyHashGridBG(self.device, self.min_bbox, self.bbox_size, n_levels=16, n_features_per_level=2,
+                               log2_hashmap_size=log2_hashmap_size, base_resolution=self.base_resolution,
+                               finest_resolution=self.finest_resolution, init_mode="xavier").to(device)
+        self.sampler = Sampler()
+        self.last_sampler_log2dim = sampler_log2dim
+        self.sampler_log2dim = sampler_log2dim - torch.log2(self.bbox_size.max() / self.bbox_size).int()
+        self.occupied_grid = torch.zeros(tuple(int(2 ** k) for k in self.sampler_log2dim), dtype=torch.bool)
+        self.outside = torch.zeros_like(self.occupied_grid)
+        voxelize_mesh(self.sampler_log2dim.cpu().int(), (self.min_bbox + self.bbox_size / 4.0).cpu(), (self.bbox_size / 2.0).cpu(),
+                      model_path, self.occupied_grid, init_outside, self.outside)
+        if near is not None and far is not None:
+            self.occupied_grid[:, -int(near / far * self.occupied_grid.shape[1]):, :] = False
+        self.occupied_grid = self.occupied_grid.to(device)
+        self.outside = self.outside.to(device)
+        self.grid_resolution = torch.tensor([2 ** int(k) for k in self.sampler_log2dim], dtype=torch.int32, device=device)
+        for name in ("bbox_center", "bbox_size", "min_bbox", "max_bbox"):   # (the reference receives device tensors from tile.py)
+            setattr(self, name, getattr(self, name).to(device))
+        self.fused = True
+        self.last_render_route = None
+
+    # ---- checkpoints / deployment files (:94-105, :248-266) ----------------------------------------------------------------
+    def export_check_point(self):
+        return {"occupied_grid": self.occupied_grid.detach().cpu().numpy(), "sampler_log2dim": self.sampler_log2dim.detach().cpu().numpy(),
+                "grid_resolution": self.grid_resolution.detach().cpu().numpy(), "features": self.HE.features.detach().cpu().numpy()}
+
+    def load_check_point(self, ckp):
+        func = lambda x: torch.from_numpy(x).to(self.device)
+        self.occupied_grid = func(ckp["occupied_grid"])
+        self.sampler_log2dim = func(ckp["sampler_log2dim"])
+        self.grid_resolution = func(ckp["grid_resolution"])
+        self.HE.features = nn.Parameter(func(ckp["features"]))
+
+    def export(self, path):
+        np.savez(os.path.join(path, "feature.npz"), features=self.HE.features.detach().cpu().numpy().astype(np.float16),
+                 occupied_grid=self.occupied_grid.detach().cpu(), block_corner=self.min_bbox.cpu().numpy(),
+                 block_size=self.bbox_size.cpu().numpy(), grid_log2dim=self.sampler_log2dim.cpu().numpy(),
+                 resolution=self.HE.resolution.cpu().numpy())
+
+    def load(self, path):
+        f = np.load(os.path.join(path, "feature.npz"))
+        self.HE.features = nn.Parameter(torch.from_numpy(f["features"]).float().to(self.device))
+        self.occupied_grid = torch.from_numpy(f["occupied_grid"]).to(self.device)
+        self.block_corner = torch.from_numpy(f["block_corner"]).to(self.device)
+        self.block_size = torch.from_numpy(f["block_size"]).to(self.device)
+        self.sampler_log2dim = torch.from_numpy(f["grid_log2dim"]).to(self.device)
+        self.HE.resolution = torch.from_numpy(f["resolution"]).to(self.device)
+
+    def toCPU(self):
+        self.HE.resolution = self.HE.resolution.cpu()
+
+    def toGPU(self):
+        self.HE.resolution = self.HE.resolution.to(self.device)
+
+    # ---- coarse-to-fine pruning (:138-225) -----------------------------------------------------------------------------------
+    @torch.no_grad()
+    def pruning_tile_grid(self, global_step, decoder, sub_split=False, pruning_th=0.4, batch_size=92 ** 3):
+        log2dim = self.sampler_log2dim + (1 if sub_split else 0)
+        scale = 2 if sub_split else 1
+        grid_resolution = (2 ** log2dim).to(self.device)
+        total_res = self.finest_resolution / 4.0 if global_step < 10000 else self.finest_resolution / 2.0
+        sample_resolution = ((total_res / 2.0).to(self.device) / grid_resolution).int()
+        occ = self.occupied_grid
+        if scale > 1:
+            occ = occ.repeat_interleave(2, 0).repeat_interleave(2, 1).repeat_interleave(2, 2)
+        locs = torch.nonzero(occ).long()
+        new_grid = torch.zeros(tuple(int(r) for r in grid_resolution), dtype=torch.bool, device=self.device)
+        if locs.shape[0] and int(torch.prod(sample_resolution)) > 0:
+            grid_corner = locs / grid_resolution
+            X, Y, Z = torch.meshgrid(*(torch.arange(0, int(r), 1, device=self.device) for r in sample_resolution), indexing="ij")
+            grid_point = torch.stack([X, Y, Z], -1).reshape(-1, 3) / (sample_resolution * grid_resolution)
+            run = max(int(batch_size / int(torch.prod(sample_resolution))), 1)
+            wf = self.weight_feature(global_step)[None, :].repeat_interleave(2, dim=-1)
+            alpha_res = torch.zeros_like(grid_corner[..., 0])
+            for i in range(0, locs.shape[0], run):
+                pts = (grid_corner[i:i + run, None, :] + grid_point[None, ...]) * 2 - 1
+                n = pts.shape[0]
+                alpha = 1 - torch.exp(-1.0 * decoder.inference_sigma(self.HE(pts.reshape(-1, 3).float()) * wf))
+                alpha_res[i:i + n] = alpha.reshape(n, -1).max(dim=-1)[0]
+            keep = locs[alpha_res > pruning_th]
+            new_grid[keep[:, 0], keep[:, 1], keep[:, 2]] = True
+        self.sampler_log2dim = log2dim
+        self.occupied_grid = new_grid.contiguous()
+        self.grid_resolution = torch.tensor([2 ** int(k) for k in log2dim], dtype=torch.int32, device=self.device)
+
+    @torch.no_grad()
+    def pruning_grid(self, global_step, decoder, log2dim, pruning_th):
+        assert log2dim >= self.last_sampler_log2dim, f"log2dim {log2dim} last_sampler_log2dim {self.last_sampler_log2dim}"
+        sub_split = log2dim != self.last_sampler_log2dim
+        if sub_split:
+            self.last_sampler_log2dim = self.last_sampler_log2dim + 1
+        self.pruning_tile_grid(global_step, decoder, sub_split=sub_split, pruning_th=pruning_th)
+
+    def weight_feature(self, global_step):
+        alpha = max(min(global_step / 10000 * 8 + 8, 16), 0)
+        k = torch.arange(16, dtype=torch.float32, device=self.device)
+        return (1 - (alpha - k).clamp_(min=0, max=1).mul_(math.pi).cos_()) / 2
+
+    def weight_bg_feature(self, ratio):
+        alpha = torch.clamp(ratio * 8 + 8, 0, 16)
+        k = torch.arange(16, dtype=torch.float32, device=self.device)
+        weight = (1 - (alpha - k[None, ...]).clamp_(min=0, max=1).mul_(math.pi).cos_()) / 2
+        return weight.repeat_interleave(2, dim=-1)
+
+    # ---- sampling (:278-337; no gradients) -------------------------------------------------------------------------------------
+    def samplePoints(self, rays_o, rays_d, num_sample):
+        z_vals = torch.full((rays_o.shape[0], num_sample), -1, dtype=torch.float32, device=self.device)
+        dists = torch.full((rays_o.shape[0], num_sample), -1, dtype=torch.float32, device=self.device)
+        sample_points_grid(rays_o.detach().contiguous(), rays_d.detach().contiguous(), z_vals, dists,
+                           (self.min_bbox + self.bbox_size / 4.0).contiguous(), (self.bbox_size / 2.0).contiguous(),
+                           self.occupied_grid, self.sampler_log2dim.to(self.device).int().contiguous())
+        return z_vals, dists
+
+    def invalid_sampling_underground(self, rays_o, rays_d, bound):
+        outgoing_point = rays_o + bound[:, 1:] * rays_d
+        bbox_corner = self.bbox_center - self.bbox_size / 4.0
+        return ~(torch.abs(outgoing_point[:, 1] - bbox_corner[1]) < 0.0001)
+
+    @torch.no_grad()
+    def inverse_z_sampling(self, rays_o, rays_d, num_sample, invalid_underground=True, perturb=False):
+        bounds = torch.full((rays_o.shape[0], 2), -1, dtype=torch.float32, device=rays_o.device)
+        ray_aabb_intersection(rays_o.contiguous(), rays_d.contiguous(), self.bbox_center.contiguous(), (self.bbox_size / 2.0).contiguous(), bounds)
+        if invalid_underground:
+            valid = self.invalid_sampling_underground(rays_o, rays_d, bounds)
+        else:
+            valid = torch.ones_like(rays_d[..., 0]).bool()
+        bounds[torch.any(bounds == -1, dim=-1), 1:] = 0.1
+        t_vals = torch.linspace(0.0, 1.0, steps=num_sample, device=self.device)[None, :]
+        z_vals = 1.0 / (1.0 / (bounds[:, 1:] + 1e-6) * (1.0 - t_vals) + 1.0 / 1e6 * t_vals)
+        z_vals = z_vals.expand([rays_o.shape[0], num_sample])
+        dists = z_vals[:, 1:] - z_vals[:, :-1]
+        dists = torch.cat([dists, 1e-6 * torch.ones(dists[..., :1].shape, device=rays_o.device)], -1)
+        return z_vals, dists, valid
+
+    # ---- compositing in torch (:344-366; used by the op-by-op route) ---------------------------------------------------------
+    def cal_integrate_weight(self, sigma, z_vals, dists, rays_d, infinity=True):
+        dists = dists * torch.norm(rays_d[..., None, :], dim=-1)
+        if infinity:
+            dists = torch.cat([dists[:, :-1], 1e10 * torch.ones_like(dists[:, :1])], -1)
+        alpha = 1.0 - torch.exp(-sigma[..., 0] * dists)
+        T = torch.cumprod(torch.cat([torch.ones((alpha.shape[0], 1), device=alpha.device), 1.0 - alpha + 1e-6], -1), -1)[:, :-1]
+        weights = alpha * T
+        return weights[..., None], T[:, -1]
+
+    def accumulate(self, weights, attr):
+        return torch.sum(weights * attr, dim=1)
+
+    def contract_fore(self, x):
+        return (x - self.min_bbox) / self.bbox_size * 4 - 2, None
+
+    def contract_bg(self, x):
+        x = (x - self.min_bbox) / self.bbox_size * 4 - 2
+        linf = torch.max(torch.abs(x), dim=-1, keepdim=True)[0]
+        return x * ((2 - 1.0 / linf) / linf), None
+
+    # ---- rendering (:413-596) ----------------------------------------------------------------------------------------------------
+    def _masked(self, valid, out, B, like_o, like_d):
+        rgb, depth = torch.zeros_like(like_o), torch.zeros_like(like_d[..., :1])
+        transparency = torch.ones_like(like_d[..., :1])
+        specular, diffuse = torch.zeros_like(like_o), torch.zeros_like(like_o)
+        rgb = rgb.index_put((valid,), out["rgb"])
+        depth = depth.index_put((valid,), out["depth"])
+        transparency = transparency.index_put((valid,), out["T_left"][:, None])
+        specular = specular.index_put((valid,), out["specular"])
+        diffuse = diffuse.index_put((valid,), out["diffuse"])
+        return rgb, depth, transparency, specular, diffuse
+
+    def render_fore_rays(self, rays_o, rays_d, num_sample, decoder, mode, occlusion_mask=None, infinity=False, **kwargs):
+        z_vals, dists = self.samplePoints(rays_o, rays_d, num_sample)
+        valid = torch.all(z_vals != -1, dim=-1)
+        if occlusion_mask is not None:
+            valid = valid & occlusion_mask[..., 0]
+        out, ret = self.render_batch_rays(rays_o[valid], rays_d[valid], z_vals[valid], dists[valid], decoder, mode, self.contract_fore,
+                                          out_normal=False, infinity=infinity, global_step=kwargs["global_step"])
+        if ret is False:
+            return None, False
+        rgb, depth, transparency, specular, diffuse = self._masked(valid, out, rays_o.shape[0], rays_o, rays_d)
+        out_dict = dict(out)
+        out_dict.update({"fore_valid": valid, "pred_color": rgb, "pred_depth": depth, "specular": specular, "diffuse": diffuse,
+                         "T_left": transparency})
+        return out_dict, True
+
+    def render_bg_rays(self, rays_o, rays_d, num_sample, decoder, mode, occlusion_mask=None, infinity=True, **kwargs):
+        if kwargs["bg_mode"] == "IZ":
+            z_vals, dists, valid = self.inverse_z_sampling(rays_o.detach(), rays_d.detach(), num_sample, kwargs["invalid_underground"])
+        else:   # "BS" needs the mesh tracer (fastMesh: out of scope)
+            return None, False
+        if occlusion_mask is not None:
+            valid = valid & occlusion_mask[..., 0]
+        out, ret = self.render_batch_rays(rays_o[valid], rays_d[valid], z_vals[valid], dists[valid], decoder, mode, self.contract_bg,
+                                          out_normal=False, infinity=infinity, global_step=kwargs["global_step"])
+        if ret is False:
+            return None, ret
+        rgb, depth, transparency, specular, diffuse = self._masked(valid, out, rays_o.shape[0], rays_o, rays_d)
+        out_dict = dict(out)
+        out_dict.update({"valid": valid, "rgb": rgb, "depth": depth, "specular": specular, "diffuse": diffuse, "T_left": transparency})
+        return out_dict, ret
+
+    def _fused_route(self, decoder, contract_func, out_normal, rays_o):
+        if not (self.fused and rays_o.is_cuda and not out_normal and hasattr(decoder, "blob") and self.HE.n_levels == 16):
+            return None
+        if getattr(decoder, "in_channel", 32) != 32:
+            return None
+        if contract_func == self.contract_fore:
+            return render.FORE
+        if contract_func == self.contract_bg:
+            return render.BG
+        return None
+
+    def render_batch_rays(self, rays_o, rays_d, z_vals, dists, decoder, mode, contract_func, out_normal=False, infinity=False, **kwargs):
+        if z_vals.shape[0] == 0:
+            return None, False
+        global_step = kwargs["global_step"]
+        cmode = self._fused_route(decoder, contract_func, out_normal, rays_o)
+        if cmode is not None:
+            from .. import network
+            self.last_render_route = "fused"
+            wf = self.weight_feature(global_step).repeat_interleave(2, dim=-1)
+            out_ray, weights = render.fused_render_rays(
+                rays_o, rays_d, z_vals, dists, self.HE.features, decoder.blob(), self.HE.resolution.to(self.device).int().contiguous(),
+                wf, self.min_bbox.tolist(), self.bbox_size.tolist(), cmode, infinity, None, network.skip_levels(global_step), True)
+            return render.render_batch_rays_dict(out_ray, weights, mode is TRAIN or mode == TRAIN), True
+        # ---- op by op: the reference's own sequence
+        self.last_render_route = "ops"
+        samples = rays_o[:, None, :] + z_vals[..., None] * rays_d[:, None, :]
+        num_sample = samples.shape[1]
+        if contract_func is not None:
+            contract_x, weight_feature = contract_func(samples.reshape(-1, 3))
+        else:
+            contract_x, weight_feature = samples.reshape(-1, 3), None
+        features = self.HE(contract_x).reshape(rays_o.shape[0], num_sample, 32)
+        step_weight_feature = self.weight_feature(global_step)[None, None, :].repeat_interleave(2, dim=-1)
+        if weight_feature is not None:
+            step_weight_feature = step_weight_feature * weight_feature.reshape(rays_o.shape[0], num_sample, 32)
+        inputs = torch.cat([features, rays_d[:, None, :].repeat(1, num_sample, 1)], -1)
+        output = decoder(inputs, weight_feature=step_weight_feature)
+        out = {}
+        weights, T_left = self.cal_integrate_weight(output["sigma"], z_vals, dists, rays_d, infinity=infinity)
+        out["diffuse"] = self.accumulate(weights, output["diffuse"])
+        out["tint"] = self.accumulate(weights, output["tint"])
+        out["specular"] = self.accumulate(weights, output["tint"] * output["specular"])
+        out.update({"rgb": torch.clamp(out["diffuse"] + out["specular"], 0, 1), "depth": self.accumulate(weights, z_vals[..., None]),
+                    "T_left": T_left, "weights": weights})
+        if out_normal:
+            d_output = torch.ones_like(output["sigma"], requires_grad=False, device=self.device)
+            p_normal = torch.autograd.grad(outputs=output["sigma"], inputs=samples, grad_outputs=d_output, create_graph=True,
+                                           retain_graph=True, only_inputs=True)[0]
+            p_normal = -1.0 * p_normal / (p_normal.norm(2, dim=-1, keepdim=True) + 1e-8)
+            out["normal"] = self.accumulate(weights, p_normal.detach())
+        if mode is TRAIN or mode == TRAIN:
+            out["l2_reg_specular"] = torch.mean(self.accumulate(weights.detach(), (output["specular"] - 0) ** 2))
+        return out, True

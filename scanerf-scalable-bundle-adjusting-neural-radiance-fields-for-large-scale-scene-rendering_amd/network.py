@@ -63,3 +63,127 @@ def weight_feature(global_step, device="cpu"):
     k = torch.arange(16, dtype=torch.float32)
     w = (1 - torch.cos((alpha - k).clamp(0, 1) * math.pi)) / 2
     return w.repeat_interleave(2).to(device)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Drop-in for the reference's decoder module (network.py:127-190): same class names, same module tree, hence the same
+# state_dict keys (Spatial_MLP.mlp.{0,2}, sigma_layer.mlp.0, diffuse_layer.mlp.0, tint_layer.mlp.0, Directional_MLP.mlp.{0,2,4})
+# -- a checkpoint of the reference loads with load_state_dict, optimiser parameter groups built by name keep working -- and
+# the same forward contract (x [..., 32 + 3], weight_feature broadcastable to [..., 32] -> dict of sigma / diffuse / specular /
+# tint).  The arithmetic runs in ONE HIP launch each way (csrc/decoder.hip: scanerf_decoder_forward / _backward, split-f16
+# matrix cores, f32-equivalent) instead of torch's ~40 kernels over [N,64] intermediates.
+import torch.nn as nn  # noqa: E402
+
+
+class Gaussian_Act(nn.Module):
+    """exp(-x^2 / (2 sigma^2)) (network.py:79-84); kept as a module so that the Sequential indices match the reference's."""
+
+    def __init__(self, sigma=0.1):
+        super().__init__()
+        self.item = 1.0 / (-2 * (sigma ** 2))
+
+    def forward(self, x):
+        return torch.exp((x ** 2) * self.item)
+
+
+class GeneralMLP(nn.Module):
+    """network.py:127-148: Linear / activation stack under `.mlp` (Sequential)."""
+
+    def __init__(self, num_in, num_out, activation, hiden_depth=4, hiden_width=64, output_act=False):
+        super().__init__()
+        assert hiden_depth >= 1
+        if hiden_depth == 1:
+            mods = [nn.Linear(num_in, num_out)]
+        else:
+            mods = [nn.Linear(num_in, hiden_width), activation]
+            for _ in range(hiden_depth - 2):
+                mods += [nn.Linear(hiden_width, hiden_width), activation]
+            mods.append(nn.Linear(hiden_width, num_out))
+        if output_act:
+            mods.append(activation)
+        self.mlp = nn.Sequential(*mods)
+
+    def forward(self, x):
+        return self.mlp(x)
+
+
+class ShallowMLP(nn.Module):
+    """network.py:151-190.  `forward` = the HIP decoder op for CUDA inputs with 32 feature channels (use_hip, default);
+    `forward_torch` = the same computation through the module tree in torch (the reference's own statement of it; what the
+    tests compare the op with, and what runs for other channel counts, e.g. BASELINE configs[0]'s 8 levels)."""
+
+    def __init__(self, in_channel=32):
+        super().__init__()
+        self.in_channel = in_channel
+        self.Spatial_MLP = GeneralMLP(in_channel, 64, Gaussian_Act(0.1), 2, 64)
+        self.sigma_layer = GeneralMLP(32, 1, nn.Softplus(), 1, None, True)
+        self.diffuse_layer = GeneralMLP(32, 3, nn.Sigmoid(), 1, None, True)
+        self.tint_layer = GeneralMLP(32, 3, nn.Sigmoid(), 1, None, True)
+        self.Directional_MLP = GeneralMLP(32 + 16, 3, Gaussian_Act(0.1), 3, 64)
+        self.color_act = nn.Sigmoid()
+        self.use_hip = True
+
+    # -- the render-time blob (rendering.py:101-112) as a differentiable function of the named parameters
+    def blob(self):
+        sd = dict(self.named_parameters())
+        parts = []
+        for name, o, i in layers(self.in_channel):
+            parts += [sd[name + ".bias"].reshape(-1), sd[name + ".weight"].t().reshape(-1)]
+        return torch.cat(parts)
+
+    def load_blob(self, blob):
+        with torch.no_grad():
+            sd, k = dict(self.named_parameters()), 0
+            for name, o, i in layers(self.in_channel):
+                sd[name + ".bias"].copy_(blob[k:k + o])
+                k += o
+                sd[name + ".weight"].copy_(blob[k:k + i * o].reshape(i, o).t())
+                k += i * o
+        return self
+
+    def inference_sigma(self, x):
+        H = self.Spatial_MLP(x)
+        return self.sigma_layer(H[..., :32])
+
+    def forward_torch(self, x, **kwargs):
+        from .tile_model import sh3
+        features, viewdirs = x[..., :-3], x[..., -3:]
+        viewdirs = viewdirs / (viewdirs.norm(2, dim=-1, keepdim=True) + 1e-8)
+        H = self.Spatial_MLP(features * kwargs["weight_feature"])
+        sigma = self.sigma_layer(H[..., :32])
+        tint = self.tint_layer(H[..., :32])
+        c_d = self.diffuse_layer(H[..., :32])
+        c_s = self.color_act(self.Directional_MLP(torch.cat([H[..., 32:], sh3(viewdirs)], -1)))
+        return {"diffuse": c_d, "specular": c_s, "sigma": sigma, "tint": tint}
+
+    def forward(self, x, **kwargs):
+        wf = kwargs["weight_feature"]
+        if not (self.use_hip and x.is_cuda and self.in_channel == 32 and x.shape[-1] == 35 and wf.numel() == 32):
+            return self.forward_torch(x, **kwargs)   # (per-sample masks, other channel counts: the torch graph)
+        from . import decoder_op
+        lead = x.shape[:-1]
+        sigma, dif, spec, tint = decoder_op.decoder_apply(x.reshape(-1, 35), self.blob(), wf.reshape(-1))
+        return {"diffuse": dif.reshape(*lead, 3), "specular": spec.reshape(*lead, 3), "sigma": sigma.reshape(*lead, 1),
+                "tint": tint.reshape(*lead, 3)}
+
+
+def init_model(model, mode="default"):
+    """network.py:196-227 (the modes the reference's callers use)."""
+    def xavier_init(layer):
+        if isinstance(layer, nn.Linear):
+            nn.init.xavier_normal_(layer.weight)
+            layer.bias.data.fill_(0.0)
+
+    def kaiming_init(layer):
+        if isinstance(layer, nn.Linear):
+            nn.init.kaiming_normal_(layer.weight, nonlinearity="relu")
+            layer.bias.data.fill_(0.0)
+
+    def zeros_init(layer):
+        if isinstance(layer, nn.Linear):
+            nn.init.zeros_(layer.weight)
+            layer.bias.data.fill_(0.0)
+    assert mode in ("xavier", "kaiming", "zeros", "default")
+    if mode != "default":
+        model.apply({"xavier": xavier_init, "kaiming": kaiming_init, "zeros": zeros_init}[mode])
+    return model

@@ -446,3 +446,116 @@ def ray_gradients(rays_o, rays_d, z_vals, features, resolutions, blob, min_bbox,
         g_sh, g_dn = g_sh * keep, g_dn * keep
     torch.autograd.backward([x, sh, dn], [gp, g_sh, g_dn])
     return o.grad, d.grad
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Autograd boundary of the fused path: HashGrid.render_batch_rays (hashgrid/__init__.py:512-596) as ONE differentiable op.
+# A caller that keeps the reference's loss code -- depth / smoothness / ADMM penalty terms on the per-ray outputs, summed
+# and sent through loss.backward() (tile.py:954-1011, criterions.py:122-196) -- reaches the fused kernels through it.
+class FusedRenderRays(torch.autograd.Function):
+    """out_ray [B,16], weights [B,S] = render(rays, samples; table, decoder blob).
+
+    forward  = scanerf_render_forward_packed (+ x-stash, + position-Jacobian stash when the rays need gradients);
+    backward = scanerf_render_backward on an ARBITRARY dL/d(out_ray) [B,16], returning the gradient of the hash table (dense
+               [16,T,2]: fused record emission + scanerf_render_scatter_accumulate up to 2^21 entries per level, dfeat + the
+               binned scatter above), of the decoder blob [13994] and of rays_o / rays_d.
+    Not differentiated: z_vals / dists (the sampler runs under no_grad in the reference, hashgrid/__init__.py:278-285) and the
+    `weights` output (returned for inspection: gradients flowing into it are ignored, as for l2_reg_specular's detached
+    weights, hashgrid/__init__.py:593).  The out_ray column W_SPEC2 is differentiated with the weights detached (ibid.)."""
+
+    @staticmethod
+    def forward(ctx, rays_o, rays_d, z_vals, dists, features, blob, resolutions, weight_feature, min_bbox, bbox_size,
+                contract_mode, infinity, ray_valid, skip_levels, want_weights):
+        B, S = z_vals.shape
+        dev = z_vals.device
+        rays_o, rays_d = rays_o.contiguous(), rays_d.contiguous()
+        z_vals, dists = z_vals.contiguous(), dists.contiguous()
+        packed = PackedDecoder(dev).pack(blob.detach().contiguous(), weight_feature.reshape(-1).contiguous(), skip_levels)
+        need_rays = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
+        need_grad = need_rays or ctx.needs_input_grad[4] or ctx.needs_input_grad[5]
+        table = features.detach()
+        tile_T = torch.empty((B, tile_T_columns(S)), dtype=_f32, device=dev) if need_grad else None
+        xstash = torch.empty((B * S, 32), dtype=_f32, device=dev) if need_grad else None
+        jstash = None
+        if need_rays and table.dtype == torch.float32 and ARITH in _capi.T16_FAMILY:
+            jstash = torch.empty(jstash_shape(B, S), dtype=JSTASH_DTYPE, device=dev)
+        if ray_valid is not None and ray_valid.dtype not in (torch.bool, torch.uint8):
+            raise RuntimeError("scanerf: ray_valid must be bool / uint8")
+        r = render_forward(rays_o, rays_d, z_vals, dists, table, resolutions, packed, min_bbox, bbox_size, contract_mode,
+                           infinity, ray_valid=ray_valid, want_weights=want_weights, tile_T=tile_T, xstash=xstash, jstash=jstash)
+        out, weights = r[0], r[1]
+        ctx.save_for_backward(rays_o, rays_d, z_vals, dists, table, resolutions, weight_feature.reshape(-1).contiguous(), out,
+                              tile_T, xstash, jstash, ray_valid, blob.detach())
+        ctx.packed, ctx.geom = packed, (list(min_bbox), list(bbox_size), int(contract_mode), bool(infinity))
+        if weights is None:
+            weights = out.new_empty(0)
+        ctx.mark_non_differentiable(weights)
+        return out, weights
+
+    @staticmethod
+    def backward(ctx, grad_out, _grad_weights):
+        (rays_o, rays_d, z_vals, dists, table, resolutions, wf, out, tile_T, xstash, jstash, ray_valid, blob) = ctx.saved_tensors
+        B, S = z_vals.shape
+        dev = z_vals.device
+        T = table.shape[1]
+        box = ctx.geom
+        need_rays = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
+        need_table = ctx.needs_input_grad[4]
+        grad_out = grad_out.contiguous().to(_f32)
+        arith = backward_arith(True, need_rays)
+        fused = need_table and T <= (1 << 21) and scatter_supported(B, S, T)
+        gtab = torch.zeros((16, T, 2), dtype=_f32, device=dev) if need_table else None
+        gblob = torch.zeros(_capi.PARAMSIZE, dtype=_f32, device=dev)
+        ws = None
+        if fused:   # (count + scan here, on the per-stream workspace: plan, backward and accumulate run back to back)
+            ws = scatter_plan(rays_o, rays_d, z_vals, resolutions, T, *box, ray_valid=ray_valid, arith=arith,
+                              skip_levels=ctx.packed.skip_levels)
+        ntile = (S + 31) // 32
+        bufs = (torch.zeros(B, ntile, device=dev), torch.zeros(B, 2, 64, device=dev)) if need_rays else None
+        rp = torch.zeros(B, 6, device=dev) if (need_rays and jstash is not None) else None
+        want_dfeat = (need_table and not fused) or (need_rays and jstash is None)
+        if not fused and not want_dfeat:
+            want_dfeat = True   # (the kernel needs somewhere to put the feature gradients)
+        dfeat, _ = render_backward(rays_o, rays_d, z_vals, dists, table, resolutions, ctx.packed, wf, *box, out, tile_T,
+                                   grad_out, ray_valid=ray_valid, grad_blob=gblob, xstash=xstash, ray_grad_buffers=bufs,
+                                   scatter=(ws, gtab) if fused else None, want_dfeat=want_dfeat, arith=arith, jstash=jstash,
+                                   ray_pos_grad=rp)
+        g_o = g_d = None
+        if need_rays and jstash is not None:
+            g_o, g_d = ray_gradients_fused(rays_o, rays_d, blob, rp, bufs[0], bufs[1], ray_valid=ray_valid)
+        elif need_rays:
+            g_o, g_d = ray_gradients(rays_o, rays_d, z_vals, table.to(_f32), resolutions, blob, box[0], box[1], box[2], dfeat,
+                                     bufs[0], bufs[1], ray_valid=ray_valid)
+        if fused:
+            scatter_accumulate(ws, gtab, B, S)
+        elif need_table:
+            mn = torch.as_tensor(box[0], dtype=_f32, device=dev)
+            sz = torch.as_tensor(box[1], dtype=_f32, device=dev)
+            pts = ((rays_o[:, None, :] + z_vals[:, :, None] * rays_d[:, None, :]).reshape(-1, 3) - mn) / sz * 4.0 - 2.0
+            if box[2] == BG:
+                linf = pts.abs().amax(-1, keepdim=True)
+                pts = pts * ((2.0 - 1.0 / linf) / linf)
+            scatter_table_grad(pts.contiguous(), dfeat, gtab, resolutions)
+        if gtab is not None and table.dtype != _f32:
+            gtab = gtab.to(table.dtype)
+        return (g_o if ctx.needs_input_grad[0] else None, g_d if ctx.needs_input_grad[1] else None, None, None, gtab,
+                gblob if ctx.needs_input_grad[5] else None, None, None, None, None, None, None, None, None, None)
+
+
+def fused_render_rays(rays_o, rays_d, z_vals, dists, features, blob, resolutions, weight_feature, min_bbox, bbox_size,
+                      contract_mode, infinity, ray_valid=None, skip_levels=0, want_weights=True):
+    """FusedRenderRays.apply with keyword defaults -> (out_ray [B,16], weights [B,S])."""
+    return FusedRenderRays.apply(rays_o, rays_d, z_vals, dists, features, blob, resolutions, weight_feature, min_bbox, bbox_size,
+                                 contract_mode, infinity, ray_valid, skip_levels, want_weights)
+
+
+def render_batch_rays_dict(out_ray, weights, train):
+    """The dictionary HashGrid.render_batch_rays returns (hashgrid/__init__.py:564-596) from the fused op's outputs:
+    diffuse / tint / specular / rgb [B,3], depth [B,1], T_left [B], weights [B,S,1], and in TRAIN mode l2_reg_specular =
+    mean over rays and channels of sum_s w_s c_s^2 (:593: torch.mean over [B,3]; out_ray holds the channel sum)."""
+    out = {"diffuse": out_ray[:, DIFFUSE], "tint": out_ray[:, TINT], "specular": out_ray[:, SPECULAR],
+           "rgb": out_ray[:, RGB], "depth": out_ray[:, DEPTH, None], "T_left": out_ray[:, T_LEFT],
+           "weights": weights[..., None] if weights is not None and weights.numel() else None}
+    if train:
+        out["l2_reg_specular"] = out_ray[:, W_SPEC2].sum() / (3.0 * out_ray.shape[0])
+    return out

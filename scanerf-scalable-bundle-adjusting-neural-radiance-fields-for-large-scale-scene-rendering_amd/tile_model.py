@@ -186,7 +186,13 @@ class TileModel(nn.Module):
         x = (pts.reshape(-1, 3) - self._min_dev) / self._size_dev * 4.0 - 2.0
         feats = HashEmbeddingBG(x.contiguous(), self.features, self.resolution).reshape(B, S, 2 * self.n_levels)
         wf = network.weight_feature(global_step, self.device)[:2 * self.n_levels]
-        sigma, dif, spec, tint = self.decoder(feats, d[:, None, :].expand(B, S, 3), wf)
+        if self.n_levels == 16 and getattr(self, "hip_decoder", True):
+            # the decoder as ONE HIP op each way (csrc/decoder.hip) on the reference's concatenated input (hashgrid/__init__.py:547)
+            from . import decoder_op
+            x = torch.cat([feats, d[:, None, :].expand(B, S, 3)], -1).reshape(-1, 35)
+            sigma, dif, spec, tint = (t.reshape(B, S, -1) for t in decoder_op.decoder_apply(x, self.decoder.blob(), wf))
+        else:   # other level counts (BASELINE configs[0]: 8), or hip_decoder = False: the torch graph
+            sigma, dif, spec, tint = self.decoder(feats, d[:, None, :].expand(B, S, 3), wf)
         delta = dist * d.norm(dim=-1, keepdim=True)
         alpha = 1.0 - torch.exp(-sigma[..., 0] * delta)
         T = torch.cumprod(torch.cat([torch.ones_like(alpha[:, :1]), 1.0 - alpha + 1e-6], 1), 1)[:, :-1]

@@ -1,0 +1,122 @@
+"""The stand-alone decoder op (csrc/decoder.hip: scanerf_decoder_forward / _backward) behind the reference's module
+interface (network.ShallowMLP: same state_dict keys, same forward contract, network.py:151-190):
+forward against the reference's OWN outputs (golden G1), backward against torch autograd through the same module tree in
+float64, weight_feature masks, tails, determinism, and the op-by-op route of an unchanged HashGrid.render_batch_rays."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+T = torch.from_numpy
+
+
+def _rel_l2(a, b):
+    return float((a - b).norm() / b.norm())
+
+
+def test_shallow_mlp_loads_the_reference_state_dict_and_reproduces_its_outputs_golden_g1(golden):
+    import scanerf_amd  # noqa
+    from scanerf_amd import network
+    g = golden("g1_mlp")
+    sd = {k[3:]: T(v) for k, v in g.items() if k.startswith("sd.")}
+    m = network.ShallowMLP(32)
+    m.load_state_dict(sd, strict=True)          # the reference's keys, nothing missing, nothing unexpected
+    assert list(m.state_dict().keys()) == list(sd.keys())   # and in the reference's order
+    m = m.to(DEV)
+    x, wf = T(g["x"]).to(DEV), T(g["weight_feature"]).to(DEV)
+    with torch.no_grad():
+        out = m(x, weight_feature=wf)                          # the HIP op
+        ref_route = m.forward_torch(x, weight_feature=wf)      # the module tree in torch
+    for k in ("sigma", "diffuse", "specular", "tint"):
+        assert out[k].shape == tuple(g[k].shape)
+        np.testing.assert_allclose(out[k].cpu().numpy(), g[k], rtol=1e-4, atol=1e-6, err_msg=k)
+        np.testing.assert_allclose(ref_route[k].cpu().numpy(), g[k], rtol=1e-4, atol=1e-6, err_msg=k)
+    np.testing.assert_allclose(m.inference_sigma(x[:, :32] * wf).detach().cpu().numpy(), g["sigma"], rtol=1e-4, atol=1e-6)
+    # blob <-> named parameters (rendering.py:101-112 order)
+    from oracle import oracle as O
+    assert torch.equal(m.blob().detach().cpu(), O.pack_blob(sd))
+
+
+def _case(N, step, seed, lead=None):
+    import scanerf_amd  # noqa
+    from scanerf_amd import network
+    torch.manual_seed(seed)
+    m = network.ShallowMLP(32)
+    network.init_model(m, "xavier")
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            if n.endswith("bias"):
+                p.copy_(0.05 * torch.randn_like(p))
+    m = m.to(DEV)
+    x = torch.cat([0.3 * torch.randn(N, 32), torch.randn(N, 3) * (0.5 + torch.rand(N, 1))], -1).to(DEV)
+    if lead is not None:
+        x = x.reshape(*lead, 35)
+    wf = network.weight_feature(step, DEV)
+    gw = {k: torch.randn(*x.shape[:-1], c, device=DEV) for k, c in (("sigma", 1), ("diffuse", 3), ("specular", 3), ("tint", 3))}
+    return m, x, wf, gw
+
+
+def _grads(m, x, wf, gw, route, dtype=torch.float32):
+    m = m.to(dtype)
+    for p in m.parameters():
+        p.grad = None
+    xi = x.detach().to(dtype).requires_grad_(True)
+    out = (m.forward if route == "hip" else m.forward_torch)(xi, weight_feature=wf.to(dtype).reshape(*([1] * (x.dim() - 1)), 32))
+    loss = sum((out[k] * gw[k].to(dtype)).sum() for k in gw)
+    loss.backward()
+    res = {"x": xi.grad.detach().double().clone()}
+    res.update({n: p.grad.detach().double().clone() for n, p in m.named_parameters()})
+    vals = {k: out[k].detach().double() for k in out}
+    m.to(torch.float32)
+    return res, vals
+
+
+@pytest.mark.parametrize("N,step,lead", [(5000, 40000, None), (128 * 37 + 5, 2500, None), (13, 40000, None), (96 * 24, 6000, (96, 24))])
+def test_decoder_op_gradients_vs_float64_autograd(N, step, lead):
+    """dL/dx (features AND view direction) and dL/d(every named parameter) of a random linear loss on the four outputs: the HIP
+    op against torch autograd through the same module tree in float64.  Tails (N not a multiple of 16 / 128), a partly
+    masked weight_feature (coarse-to-fine at steps 2500 / 6000: zero columns), [B,S,35]-shaped inputs."""
+    m, x, wf, gw = _case(N, step, 3, lead)
+    ref, vref = _grads(m, x, wf, gw, "torch", torch.float64)
+    got, vgot = _grads(m, x, wf, gw, "hip")
+    f32, _ = _grads(m, x, wf, gw, "torch", torch.float32)     # what torch's own f32 graph gives, for scale
+    for k in vref:
+        np.testing.assert_allclose(vgot[k].cpu().numpy(), vref[k].cpu().numpy(), rtol=1e-4, atol=1e-6, err_msg=k)
+    worst = 0.0
+    for k in ref:
+        e, e32 = _rel_l2(got[k], ref[k]), _rel_l2(f32[k], ref[k])
+        mx = float((got[k] - ref[k]).abs().max() / ref[k].abs().max())
+        worst = max(worst, e)
+        assert e < 5e-5 and mx < 2e-4, (k, e, mx, e32)
+    gx, rx = got["x"].reshape(-1, 35), ref["x"].reshape(-1, 35)
+    e_dir = _rel_l2(gx[:, 32:], rx[:, 32:])
+    assert e_dir < 5e-5, e_dir
+    masked = (wf == 0).nonzero()[:, 0]
+    if masked.numel():   # features that meet a zero mask get exactly zero gradients, and so do their first-layer weights
+        assert float(gx[:, masked].abs().max()) == 0.0
+        assert float(got["Spatial_MLP.mlp.0.weight"][:, masked].abs().max()) == 0.0
+    print(f"decoder op N={N} step={step}: worst relative L2 of any gradient {worst:.2e}, direction gradient {e_dir:.2e}")
+
+
+def test_decoder_op_is_bit_reproducible_and_covers_many_workgroups():
+    m, x, wf, gw = _case(1 << 19, 40000, 5)
+    a, va = _grads(m, x, wf, gw, "hip")
+    b, vb = _grads(m, x, wf, gw, "hip")
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+    for k in va:
+        assert torch.equal(va[k], vb[k]), k
+    ref, _ = _grads(m, x[: 1 << 14], wf, {k: v[: 1 << 14] for k, v in gw.items()}, "torch", torch.float64)
+    got, _ = _grads(m, x[: 1 << 14].contiguous(), wf, {k: v[: 1 << 14].contiguous() for k, v in gw.items()}, "hip")
+    assert _rel_l2(got["x"], ref["x"]) < 5e-5
+
+
+def test_decoder_op_rejects_cpu_tensors_and_wrong_shapes():
+    import scanerf_amd  # noqa
+    from scanerf_amd import decoder_op, network
+    blob = network.xavier_blob(0)
+    with pytest.raises(RuntimeError, match="GPU"):
+        decoder_op.decoder_apply(torch.zeros(4, 35), blob, torch.ones(32))
+    with pytest.raises(RuntimeError, match="32 \\+ 3"):
+        decoder_op.decoder_apply(torch.zeros(4, 32, device=DEV), blob.to(DEV), torch.ones(32, device=DEV))

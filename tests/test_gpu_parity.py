@@ -1540,10 +1540,11 @@ def test_split_pass_feeding_the_adam_epilogue(log2_T, finest, fgbg, monkeypatch)
     """Round 4's split pass (csrc/scatter.hip k_bin_split) in front of the accumulate's Adam epilogue -- accumulate_adam with one
     record set (train_step_fused) and adam2 with two (train_step_fgbg), window shifts 1 (2^22) and 3 (2^24), with and without
     window-crossing pairs (finest resolution above 8 192: second entries through the overflow table, consumed through the fine
-    stream's flag).  Only reachable with SCANERF_LARGE_T_ROUTE=fused.  Compared with the same step under SCANERF_NO_SPLIT=1 (the
-    window re-reads, 16-byte records) AND under the default dfeat route: updated parameters and both moments after two steps.
-    The split re-encodes the records as Rec12 (components rounded to 19 mantissa bits): moments agree to ~1e-5 of their maximum."""
-    from scanerf_amd import render
+    stream's flag).  Only reachable with SCANERF_LARGE_T_ROUTE=fused.  Compared with the same steps under SCANERF_NO_SPLIT=1 (the
+    window re-reads, 16-byte records) AND under the default dfeat route: both moments and the parameters after the first step
+    (the split re-encodes the records as Rec12, components rounded to 19 mantissa bits: moments agree to 2e-5 of their maximum)
+    and after a second one (looser: an entry whose first gradient is below one route's fixed-point floor has moved by lr in
+    the other, which changes the second step's gradients a little)."""
     from scanerf_amd.tile_model import TileModel, train_step_fgbg, train_step_fused
     B, S_ = 3000, 64
 
@@ -1557,33 +1558,36 @@ def test_split_pass_feeding_the_adam_epilogue(log2_T, finest, fgbg, monkeypatch)
         m = TileModel([-4, -4, -4], [8, 8, 8], DEV, log2_T=log2_T, seed=2, grid_resolution=(32, finest))
         with torch.no_grad():
             m.features.mul_(1000.0)
+        init = m.features.detach().clone()
         opt = torch.optim.Adam(m.decoder.parameters(), lr=1e-3)
         o = torch.rand(B, 3, device=DEV) * 8 - 4
         d = torch.nn.functional.normalize(torch.randn(B, 3, device=DEV), dim=-1)
         tgt = torch.rand(B, 3, device=DEV)
+        snaps = []
         for it in range(2):
             if fgbg:
                 train_step_fgbg(m, opt, o, d, tgt, S_, S_, 20000 + it, table_lr=1e-2)
             else:
                 train_step_fused(m, opt, o, d, tgt, S_, 20000 + it, table_lr=1e-2, fused_adam=True)
-        torch.cuda.synchronize()
-        return m.features.detach().clone(), m.exp_avg.clone(), m.exp_avg_sq.clone(), m
+            torch.cuda.synchronize()
+            snaps.append((m.features.detach().clone(), m.exp_avg.clone(), m.exp_avg_sq.clone()))
+        assert m.adam_step == 2
+        return init, snaps
 
-    p0, m0, v0, model = run("fused", False)          # the split pass
-    init = TileModel([-4, -4, -4], [8, 8, 8], DEV, log2_T=log2_T, seed=2, grid_resolution=(32, finest)).features.detach() * 1000.0
-    assert model.adam_step == 2 and float((p0 != init).float().mean()) > 1e-4   # the table moved
-    del model
+    init, ref = run("fused", False)          # the split pass
+    assert float((ref[0][0] != init).float().mean()) > 1e-4   # the table moved
     for route, no_split in (("fused", True), ("dfeat", False)):
-        p1, m1, v1, _ = run(route, no_split)
-        sm, sv = float(m1.abs().max()), float(v1.abs().max())
-        assert sm > 0 and sv > 0
-        assert float((m0 - m1).abs().max()) <= 2e-5 * sm, (route, no_split, float((m0 - m1).abs().max()) / sm)
-        assert float((v0 - v1).abs().max()) <= 4e-5 * sv, (route, no_split, float((v0 - v1).abs().max()) / sv)
-        # an entry moves iff it has a gradient; entries whose gradient is well above the fixed-point floor move alike
-        big = m1.abs() > 1e-3 * sm
-        assert bool(big.any())
-        dp = (p0 - p1).abs()[big]
-        assert float(dp.max()) <= 2e-4, (route, no_split, float(dp.max()))
-        moved0, moved1 = p0 != init, p1 != init
-        assert float((moved0 != moved1).float().mean()) < 1e-3
-        del p1, m1, v1
+        _, other = run(route, no_split)
+        for it, tol in ((0, 2e-5), (1, 3e-4)):
+            (p0, m0, v0), (p1, m1, v1) = ref[it], other[it]
+            sm, sv = float(m1.abs().max()), float(v1.abs().max())
+            assert sm > 0 and sv > 0
+            assert float((m0 - m1).abs().max()) <= tol * sm, (route, no_split, it, float((m0 - m1).abs().max()) / sm)
+            assert float((v0 - v1).abs().max()) <= 2 * tol * sv, (route, no_split, it, float((v0 - v1).abs().max()) / sv)
+            # entries whose gradient is well above the fixed-point floor move alike; an entry moves iff it has a gradient
+            big = m1.abs() > 1e-3 * sm
+            assert bool(big.any())
+            ptol = 2e-4 if it == 0 else 1e-3   # lr = 1e-2: 2 % / 10 % of one Adam move
+            assert float((p0 - p1).abs()[big].max()) <= ptol, (route, no_split, it, float((p0 - p1).abs()[big].max()))
+            assert float(((p0 != init) != (p1 != init)).float().mean()) < 1e-3
+        del other
