@@ -348,8 +348,8 @@ def side_legs(args, dev, rays_o, rays_d, target, S, step0):
     """Two more timings inside the default run, so that they are on the driver's clock too (rank 0, N = 1, configs[1] only;
     `--no-side-legs` skips them):
       ops_path_ms_per_step -- the same training iteration through the binding-surface ops one by one (`--path ops`: sampler,
-        `embedding_bg_forward/backward_cuda` via the autograd wrapper, torch decoder, `adam_step_cuda`): the route a caller
-        takes that keeps `tile.py` / `hashgrid/__init__.py` unchanged;
+        `embedding_bg_forward/backward_cuda` via the autograd wrapper, the decoder op of csrc/decoder.hip (what network.ShallowMLP
+        runs), torch compositing, `adam_step_cuda`): the route a caller takes that keeps `tile.py` / `hashgrid/__init__.py` unchanged;
       render_ms_per_frame -- configs[4]'s render leg (4 resident tiles + backgrounds, one 1920x1080 view)."""
     from scanerf_amd import tile_model as tm
     out = {}
@@ -363,8 +363,9 @@ def side_legs(args, dev, rays_o, rays_d, target, S, step0):
         tm.train_step_ops(m, opt, rays_o, rays_d, target, S, step0 + 1 + i)
     torch.cuda.synchronize()
     out["ops_path_ms_per_step"] = (time.perf_counter() - t0) / n_ops * 1e3
-    out["ops_path_is"] = (f"`--path ops`: the binding-surface ops called one by one + torch decoder and autograd, {rays_o.shape[0]} rays x {S} "
-                          f"samples, 1 warm-up + {n_ops} timed steps")
+    out["ops_path_is"] = (f"`--path ops`: the binding-surface ops called one by one -- sampler, encoder op through its autograd wrapper, the "
+                          f"decoder as ONE HIP op each way (csrc/decoder.hip), torch compositing + autograd, adam_step_cuda -- "
+                          f"{rays_o.shape[0]} rays x {S} samples, 1 warm-up + {n_ops} timed steps (round 4, torch decoder graph: 155 ms)")
     del m, opt
     torch.cuda.empty_cache()
     n_fr = 5

@@ -277,6 +277,19 @@ def bg_pts_inference_v2(rays_o, rays_d, z_vals, bg_idxs, step, corners, sizes, r
     return dif, spec, al
 
 
+def bg_pts_inference(rays_o, rays_d, z_vals, outgoing_bidxs, blend_weights, corners, sizes, res, tables_f16, params):
+    """rendering_kernel.cu:872-1008, :1176-1208 (v1: all of a ray's outgoing blocks blended per sample)."""
+    o, d, z = _f32(_np(rays_o)), _f32(_np(rays_d)), _f32(_np(z_vals))
+    B, S = z.shape
+    tb = np.ascontiguousarray(_np(tables_f16).view(np.uint16))
+    T = tb.shape[2]
+    dif, spec, al = np.zeros((B, S, 3), np.float32), np.zeros((B, S, 3), np.float32), np.zeros((B, S, 1), np.float32)
+    lib().orc_bg_pts_inference(_p(o), _p(d), _p(z), _p(tb), _p(_f32(_np(params))), _p(_f32(_np(corners))), _p(_f32(_np(sizes))),
+                               _p(_i32(_np(res))), _p(_i16(outgoing_bidxs)), _p(_f32(_np(blend_weights))), _p(dif), _p(spec), _p(al),
+                               _ci(T), _ci(B), _ci(S))
+    return dif, spec, al
+
+
 def update_outgoing_bidx(rays_o, rays_d, corners, sizes, tracing_blocks, inter, ratio, skip):
     o, d = _f32(_np(rays_o)), _f32(_np(rays_d))
     B, nb = o.shape[0], np.asarray(corners).shape[0]

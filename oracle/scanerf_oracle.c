@@ -861,6 +861,53 @@ ORC_API void orc_bg_pts_inference_v2(const float *rays_o, const float *rays_d, c
     }
 }
 
+/* rendering_kernel.cu:872-1008 (bg_pts_inference, v1; host entry :1176-1208): per sample, over the ray's outgoing blocks until the
+ * first -1 (the loop BREAKS there), the v2 per-block inference on the SAME z_vals, blended with the ray's blend weights:
+ * diffuse = sum w a c_d / sum w, specular = sum w a (tint c_s) / sum w, alpha = sum w a / sum w (untouched sums where sum w <= 0). */
+ORC_API void orc_bg_pts_inference(const float *rays_o, const float *rays_d, const float *z_vals, const uint16_t *tables,
+                                  const float *params, const float *corners, const float *sizes, const int32_t *res,
+                                  const int16_t *outgoing_bidxs, const float *blend_weights, float *out_dif, float *out_spec,
+                                  float *out_alpha, int T, int B, int S)
+{
+#pragma omp parallel for schedule(dynamic, 64)
+    for (int64_t t = 0; t < (int64_t)B * S; ++t) {
+        int i = (int)(t / S), s = (int)(t % S);
+        const float *o = rays_o + 3 * i, *d = rays_d + 3 * i;
+        float z = z_vals[t];
+        float sample_step = (s == S - 1) ? 10000000.0f : z_vals[t + 1] - z;
+        float dif[3] = { 0, 0, 0 }, spec[3] = { 0, 0, 0 }, alpha = 0.0f, weight = 0.0f;
+        for (int k = 0; k < ORC_MAX_PTS_BLOCKS; ++k) {
+            int b = outgoing_bidxs[i * ORC_MAX_PTS_BLOCKS + k];
+            if (b == -1) break;
+            float pts[3];
+            for (int a = 0; a < 3; ++a) {
+                float w_ = o[a] + z * d[a];
+                pts[a] = 2.0f * (w_ - corners[3 * b + a]) / sizes[3 * b + a] - 1.0f;
+            }
+            float w = blend_weights[i * ORC_MAX_PTS_BLOCKS + k];
+            float inf_norm = fabsf(pts[0]);
+            for (int a = 1; a < 3; ++a) if (fabsf(pts[a]) > inf_norm) inf_norm = fabsf(pts[a]);
+            float temp = 2.0f - 1.0f / inf_norm;
+            float ratio = temp / inf_norm;
+            float p01[3];
+            for (int a = 0; a < 3; ++a) { pts[a] *= ratio; p01[a] = (pts[a] + 2.0f) / 4.0f; }
+            float feat[32], sg, pd[3], ps[3];
+            multilevel_features_h(p01, res + (size_t)b * 48, tables + (size_t)b * 16 * T * 2, T, feat);
+            decoder_one(params + (size_t)b * ORC_PARAMSIZE, feat, d, &sg, pd, ps, NULL);
+            float pa = 1.0f - expf(-1.0f * sg * sample_step);
+            for (int a = 0; a < 3; ++a) { dif[a] = dif[a] + w * pa * pd[a]; spec[a] = spec[a] + w * pa * ps[a]; }
+            alpha = alpha + w * pa;
+            weight += w;
+        }
+        if (weight > 0) {
+            for (int a = 0; a < 3; ++a) { dif[a] /= weight; spec[a] /= weight; }
+            alpha /= weight;
+        }
+        for (int a = 0; a < 3; ++a) { out_dif[3 * t + a] = dif[a]; out_spec[3 * t + a] = spec[a]; }
+        out_alpha[t] = alpha;
+    }
+}
+
 /* rendering_kernel.cu:1263-1401 */
 ORC_API void orc_update_outgoing_bidx(const float *rays_o, const float *rays_d, const float *corners, const float *sizes,
                                       const int32_t *tracing_blocks, const float *inter, int16_t *out_bidx,

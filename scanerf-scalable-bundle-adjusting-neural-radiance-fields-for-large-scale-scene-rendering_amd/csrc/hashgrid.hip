@@ -120,6 +120,77 @@ __global__ void __launch_bounds__(256) k_embed_fwd_lf(const float *__restrict__ 
     }
 }
 
+// ---- forward, row mapping (round 5): what a render batch's sample points want ------------------------------------------
+// One wave per 32 CONSECUTIVE points; lane (s, h) = point s, levels 8h .. 8h+7: the 64 gathers of a lane are independent
+// (issued four levels at a time), consecutive points -- samples along one ray -- share cells at the coarse levels and
+// lines at the fine ones (the fused forward's locality, render.hip), and a lane's 8 results are 64 CONTIGUOUS bytes of the
+// binding surface's [N][16][2] output: the wave writes 4 KB in full lines.  The XCD-partitioned kernel above writes that
+// layout as one 8-byte piece per (point, level) from eight different L2s -- 1.3e8 partial-line writes for 8.4e6 points, and
+// its threads hold 8 gathers each: 6.0 ms for a 65 536 x 128 batch against 3.2 ms here.  Same arithmetic per (point, level)
+// (locate_bg, corner_indices, trilinear_weights, the fmaf chain of interp): the same bits.
+constexpr int kRowsThreads = 512;
+template <int DT>
+__global__ void __launch_bounds__(kRowsThreads, 2) k_embed_fwd_rows(const float *__restrict__ points, float *__restrict__ out,
+                                                                   const void *__restrict__ features,
+                                                                   const int32_t *__restrict__ resolutions, int N, int T)
+{
+    __shared__ int lres[16 * 4];
+    if (threadIdx.x < 64) {
+        const int lv = threadIdx.x >> 2, c = threadIdx.x & 3;
+        lres[threadIdx.x] = c < 3 ? resolutions[3 * lv + c] : 0;
+    }
+    __syncthreads();
+    const uint32_t mask = (uint32_t)T - 1u;
+    const int lane = threadIdx.x & 63, s = lane & 31, h = lane >> 5;
+    const int ntiles = (N + 31) >> 5;
+    const int stride = gridDim.x * (kRowsThreads / 64);
+    for (int tile = blockIdx.x * (kRowsThreads / 64) + (threadIdx.x >> 6); tile < ntiles; tile += stride) {
+        const int i = tile * 32 + s;
+        const bool live = i < N;
+        const int ic = live ? i : N - 1;
+        const float p[3] = { points[3 * (size_t)ic], points[3 * (size_t)ic + 1], points[3 * (size_t)ic + 2] };
+        float2 r[8];
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            uint32_t idx[4][8];
+            float w[4][8];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int level = 8 * h + 4 * half + j;
+                const int4 rr = *reinterpret_cast<const int4 *>(lres + 4 * level);
+                const int res[3] = { rr.x, rr.y, rr.z };
+                int b[3];
+                float t[3], sc[3];
+                locate3<false>(p, res, nullptr, nullptr, b, t, sc);
+                corner_indices(idx[j], b[0], b[1], b[2], mask);
+                trilinear_weights(w[j], t[0], t[1], t[2]);
+            }
+            float2 f[4][8];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const char *slice = (const char *)features + (size_t)(8 * h + 4 * half + j) * T * TableElem<DT>::bytes;
+#pragma unroll
+                for (int c = 0; c < 8; ++c) f[j][c] = TableElem<DT>::load(slice, idx[j][c]);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float ax = 0.0f, ay = 0.0f;
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    ax = fmaf(w[j][c], f[j][c].x, ax);
+                    ay = fmaf(w[j][c], f[j][c].y, ay);
+                }
+                r[4 * half + j] = make_float2(ax, ay);
+            }
+        }
+        if (live) {
+            float4 *o = reinterpret_cast<float4 *>(out + (size_t)i * 32 + 16 * h);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) o[q] = make_float4(r[2 * q].x, r[2 * q].y, r[2 * q + 1].x, r[2 * q + 1].y);
+        }
+    }
+}
+
 // ---- backward, level-fastest ----------------------------------------------------------
 // LP = L rounded up to a power of two (<= 64): the lanes of one point form an aligned group.
 template <bool BOX, int LP, bool GRAD_LM = false>
@@ -203,9 +274,22 @@ int launch_fwd(const float *points, float *outputs, const void *features, const 
                int N, int L, int T, int dt, int variant, int layout, hipStream_t st)
 {
     float2 *out = reinterpret_cast<float2 *>(outputs);
-    // variant: 0 auto, 1 XCD-partitioned, 2 level-fastest
-    if (variant == 0) variant = ((int64_t)N * L >= (1 << 20)) ? 1 : 2;
+    // variant: 0 auto, 1 XCD-partitioned, 2 level-fastest, 3 row mapping (contracted variant, 16 levels, [N][L][2] output)
+    const bool rows_ok = !BOX && L == 16 && layout == OUT_NLF && ((uintptr_t)outputs & 15) == 0;
+    if (variant == 0) variant = ((int64_t)N * L >= (1 << 20)) ? (rows_ok ? 3 : 1) : 2;
+    if (variant == 3 && !rows_ok) variant = 1;
     if (layout == OUT_LNF) variant = 1;
+    if constexpr (!BOX) {
+        if (variant == 3) {
+            int blocks = ceil_div(ceil_div(N, 32), kRowsThreads / 64);
+            if (blocks > 2 * kNumCU) blocks = 2 * kNumCU;   // persistent
+            dim3 grid(blocks), block(kRowsThreads);
+            if (dt == SCANERF_F32) hipLaunchKernelGGL((k_embed_fwd_rows<SCANERF_F32>), grid, block, 0, st, points, outputs, features, resolutions, N, T);
+            else if (dt == SCANERF_F16) hipLaunchKernelGGL((k_embed_fwd_rows<SCANERF_F16>), grid, block, 0, st, points, outputs, features, resolutions, N, T);
+            else hipLaunchKernelGGL((k_embed_fwd_rows<SCANERF_BF16>), grid, block, 0, st, points, outputs, features, resolutions, N, T);
+            return check_launch("embedding_forward(rows)");
+        }
+    }
     if (variant == 1) {
         const int chunks = ceil_div(N, 256);
         int64_t want = (int64_t)chunks * ((L + kNumXCD - 1) / kNumXCD);  // work items per XCD

@@ -167,6 +167,17 @@ __global__ void __launch_bounds__(1024) k_bin_scatter(const float *__restrict__ 
     const uint32_t mask = (uint32_t)g.T - 1u;
     const int lo = blockIdx.x * g.per_wg, hi = min(g.N, lo + g.per_wg);
     // One (sample, level): 4 records.
+    auto one_g = [&](int l, const float p[3], const float2 gi) {
+        gmax = fmaxf(gmax, fmaxf(fabsf(gi.x), fabsf(gi.y)));
+        Pairs pr;
+        make_pairs(p, resolutions + 3 * l, mask, pr);
+        if (REC == 1)
+            emit_pairs8(pr, gi.x, gi.y, cursor + l * g.NB, g.bucket_log, rec_capacity(g.capacity, 1), recs, grad_features + (size_t)l * g.T * 2);
+        else if (REC == 2)
+            emit_pairs12(pr, gi.x, gi.y, cursor + l * g.NB, g.bucket_log, rec_capacity(g.capacity, 2), recs, grad_features + (size_t)l * g.T * 2);
+        else
+            emit_pairs(pr, gi.x, gi.y, cursor + l * g.NB, g.bucket_log, g.capacity, recs, grad_features + (size_t)l * g.T * 2);
+    };
     auto one = [&](int i, int l, const float p[3]) {
         const float2 gi = LEVEL_MAJOR_GRAD ? grad_in[(size_t)l * g.N + i] : grad_in[(size_t)i * g.L + l];
         gmax = fmaxf(gmax, fmaxf(fabsf(gi.x), fabsf(gi.y)));
@@ -206,6 +217,34 @@ __global__ void __launch_bounds__(1024) k_bin_scatter(const float *__restrict__ 
                 const float p[3] = { points[3 * i], points[3 * i + 1], points[3 * i + 2] };
                 one(i, l, p);
             }
+    } else if (g.L == 16 && (((uintptr_t)grad_in) & 15) == 0) {
+        // Point-major gradients [N][16][2] (the binding surface: what autograd hands embedding_bg_backward_cuda), round 5.
+        // A thread reads its point's row ONCE (128 contiguous bytes, eight 16-byte loads: the wave consumes whole lines) and
+        // keeps it in registers; the workgroup then emits LEVEL BY LEVEL, in step (one barrier per level): while it is on a
+        // level it appends to that level's NB ranges only, blockDim * 4 records of them, so the lines of a range fill up
+        // within one pass instead of being revisited 16 levels later (counters at 65 536 x 128 samples, 2048-entry buckets,
+        // 1024 workgroups of 256 threads, a gradient load per level: 2.8e8 fabric write requests for 8.6 GB of records -- twice
+        // what full lines need --, 8.4 GB fetched for a 1 GB gradient, 4.1e8 fabric requests in 7.7 ms = the 54 G/s ceiling
+        // of DESIGN.md 4.11).
+        for (int i0 = lo; i0 < hi; i0 += (int)blockDim.x) {
+            const int i = i0 + (int)threadIdx.x;
+            const bool live = i < hi;
+            float p[3] = { 0.0f, 0.0f, 0.0f };
+            float4 gr[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) gr[k] = make_float4(0, 0, 0, 0);
+            if (live) {
+                p[0] = points[3 * (size_t)i]; p[1] = points[3 * (size_t)i + 1]; p[2] = points[3 * (size_t)i + 2];
+                const float4 *row = reinterpret_cast<const float4 *>(grad_in + (size_t)i * 16);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) gr[k] = row[k];
+            }
+#pragma unroll
+            for (int l = 0; l < 16; ++l) {
+                if (live) one_g(l, p, (l & 1) ? make_float2(gr[l >> 1].z, gr[l >> 1].w) : make_float2(gr[l >> 1].x, gr[l >> 1].y));
+                __syncthreads();
+            }
+        }
     } else {
         for (int i = lo + threadIdx.x; i < hi; i += (int)blockDim.x) {
             const float p[3] = { points[3 * i], points[3 * i + 1], points[3 * i + 2] };
@@ -596,12 +635,28 @@ static int binned_backward(const float *points, const float *grad_in, float *gra
     g.N = N; g.L = L; g.T = T;
     g.rpg = 1;
     g.bucket_log = standalone_bucket_log(T);
-    // 16-byte records, or on request (level-major gradients out of the 16-sample-tile backward kernels) the 8- / 12-byte ones
-    g.rec8 = (compact_records >= 1 && compact_records <= 2 && grad_layout == 1 && g.bucket_log <= kRec8MaxBucketLog && !getenv("SCANERF_REC16")) ? compact_records : 0;
+    // Point-major gradients of 16 levels (round 5): the level-by-level producer (k_bin_scatter) with the fused path's bucket size
+    // (2^13 entries: 64 ranges per level at T = 2^19 instead of 256), 256 persistent-size workgroups of 1024 threads (fewer
+    // open ranges per L2) and 12-byte records.  Measured on the op-by-op training step (tools/ops_path_profile.py, backward
+    // section): 2^11 / 1024 workgroups 16.2 ms, 2^13 / 256 workgroups 12.6 ms, with the row in registers and Rec12: see DESIGN.md.
+    bool rows16 = grad_layout == 0 && L == 16 && ((uintptr_t)grad_in & 15) == 0 && !getenv("SCANERF_SCATTER_OLD");
+    if (rows16) {
+        const int lt = bin_ilog2(T);
+        int bl = lt < 13 ? lt : 13;
+        if (const char *e = getenv("SCANERF_STANDALONE_BUCKET_LOG")) bl = atoi(e) < bl ? atoi(e) : bl;
+        if ((size_t)L * (T >> bl) * 4 > 64 * 1024) rows16 = false;   // (all levels' cursors must fit the producer's LDS: T <= 2^23)
+        else g.bucket_log = bl;
+    }
+    // 16-byte records, or the 8- / 12-byte ones: on request for level-major gradients (out of the 16-sample-tile backward
+    // kernels), 12-byte ones by default for the point-major rows (f32 components with 19-bit mantissas, 23-bit weights:
+    // scatter_common.h Rec12; SCANERF_REC16=1 keeps the 16-byte records)
+    if (rows16 && compact_records == 0) compact_records = 2;
+    g.rec8 = (compact_records >= 1 && compact_records <= 2 && (grad_layout == 1 || (rows16 && compact_records == 2)) &&
+              g.bucket_log <= kRec8MaxBucketLog && !getenv("SCANERF_REC16")) ? compact_records : 0;
     g.NB = T >> g.bucket_log;
     // producer workgroups: every one of them writes and reads a counter per bin, so with the tens of thousands of bins of a
     // large table fewer, longer-running workgroups are cheaper (T = 2^24, 2.1 M points: count 0.62 -> see DESIGN.md)
-    g.W = (size_t)L * g.NB * 4 > 64 * 1024 ? 256 : 1024;
+    g.W = ((size_t)L * g.NB * 4 > 64 * 1024 || rows16) ? 256 : 1024;
     if (const char *e = getenv("SCANERF_SCATTER_W")) { const int v = atoi(e); if (v >= 1 && v <= 1024) g.W = v; }   // tuning experiments
     if (g.W > (N + kThreads - 1) / kThreads) g.W = (N + kThreads - 1) / kThreads;
     g.per_wg = (N + g.W - 1) / g.W;
@@ -620,10 +675,16 @@ static int binned_backward(const float *points, const float *grad_in, float *gra
     if (per_level)
         hipLaunchKernelGGL((k_bin_count<true>), dim3(g.W), dim3(1024), lds_bins, st, points, resolutions, g, counts, maxbits, overflow_flag(recs));
     else
-        hipLaunchKernelGGL((k_bin_count<false>), dim3(g.W), dim3(kThreads), lds_bins, st, points, resolutions, g, counts, maxbits, overflow_flag(recs));
+        hipLaunchKernelGGL((k_bin_count<false>), dim3(g.W), dim3(rows16 ? 1024 : kThreads), lds_bins, st, points, resolutions, g, counts, maxbits, overflow_flag(recs));   // (256 producer workgroups: give them all 16 waves)
     hipLaunchKernelGGL(k_bin_rowscan, dim3(nbins), dim3(kThreads), 0, st, counts, totals, g.W);
     hipLaunchKernelGGL(k_bin_starts, dim3(1), dim3(1024), 0, st, totals, starts, nbins);
-    if (g.rec8 == 1 && per_level)
+    if (rows16 && g.rec8 == 2)
+        hipLaunchKernelGGL((k_bin_scatter<false, false, 2>), dim3(g.W), dim3(1024), lds_bins, st, points, gi, resolutions, g,
+                           counts, starts, recs, grad_features, maxbits);
+    else if (rows16)
+        hipLaunchKernelGGL((k_bin_scatter<false>), dim3(g.W), dim3(1024), lds_bins, st, points, gi, resolutions, g,
+                           counts, starts, recs, grad_features, maxbits);
+    else if (g.rec8 == 1 && per_level)
         hipLaunchKernelGGL((k_bin_scatter<true, true, 1>), dim3(g.W), dim3(1024), lds_bins, st, points, gi, resolutions, g,
                            counts, starts, recs, grad_features, maxbits);
     else if (g.rec8 == 1)
@@ -638,6 +699,7 @@ static int binned_backward(const float *points, const float *grad_in, float *gra
     else if (per_level && grad_layout == 0)
         hipLaunchKernelGGL((k_bin_scatter<false, true>), dim3(g.W), dim3(1024), lds_bins, st, points, gi, resolutions, g,
                            counts, starts, recs, grad_features, maxbits);
+
     else if (per_level)
         hipLaunchKernelGGL((k_bin_scatter<true, true>), dim3(g.W), dim3(1024), lds_bins, st, points, gi, resolutions, g,
                            counts, starts, recs, grad_features, maxbits);

@@ -227,9 +227,32 @@ def bg_pts_inference_v2(rays_o, rays_d, z_vals, bg_idxs, step, block_corners, bl
         _I(int(sample_major)), stream()), "bg_pts_inference_v2")
 
 
-def bg_pts_inference(*args, **kwargs):
-    """hashgrid/binding.cpp:31 (v1): superseded by bg_pts_inference_v2 in rendering.py:497; no caller."""
-    raise NotImplementedError("bg_pts_inference (v1) has no caller in the reference; use bg_pts_inference_v2")
+def bg_pts_inference(rays_o, rays_d, z_vals, outgoing_bidxs, blend_weights, block_corners, block_sizes, resolution,
+                     features_tables, params, diffuse, specular, alpha):
+    """hashgrid/binding.cpp:31 (v1; rendering_kernel.cu:872-1008, :1176-1208; superseded by bg_pts_inference_v2 in
+    rendering.py:497 and without a caller there): every sample blends the inference of ALL of its ray's outgoing tiles --
+    slots of outgoing_bidxs [B,4] up to the first -1 -- on the same z_vals: out = sum_i w_i x_i / sum_i w_i with x_i what
+    bg_pts_inference_v2(step = i) writes and w_i = blend_weights [B,4]; rays without an outgoing tile get zeros.
+    One v2 launch per slot in use (the chunk-major HIP kernel), the blend in torch."""
+    B, S = z_vals.shape[0], z_vals.shape[1]
+    live = torch.cumprod((outgoing_bidxs != -1).to(torch.int32), dim=1).bool()   # the reference's loop breaks at the first -1
+    idx = torch.where(live, outgoing_bidxs, torch.full_like(outgoing_bidxs, -1)).contiguous()
+    acc_d, acc_s, acc_a = torch.zeros_like(diffuse), torch.zeros_like(specular), torch.zeros_like(alpha)
+    wsum = torch.zeros((B, 1, 1), dtype=torch.float32, device=z_vals.device)
+    for i in range(idx.shape[1]):
+        if not bool(live[:, i].any()):
+            break
+        td, ts, ta = torch.zeros_like(diffuse), torch.zeros_like(specular), torch.zeros_like(alpha)
+        bg_pts_inference_v2(rays_o, rays_d, z_vals, idx, i, block_corners, block_sizes, resolution, features_tables, params, td, ts, ta)
+        w = (blend_weights[:, i] * live[:, i]).reshape(B, 1, 1)
+        acc_d += w * td.reshape(B, S, 3)
+        acc_s += w * ts.reshape(B, S, 3)
+        acc_a += w * ta.reshape(B, S, 1)
+        wsum += w
+    norm = torch.where(wsum > 0, wsum, torch.ones_like(wsum))
+    diffuse.copy_((acc_d.reshape(B, S, 3) / norm).reshape(diffuse.shape))
+    specular.copy_((acc_s.reshape(B, S, 3) / norm).reshape(specular.shape))
+    alpha.copy_((acc_a.reshape(B, S, 1) / norm).reshape(alpha.shape))
 
 
 def update_outgoing_bidx(rays_o, rays_d, block_corners, block_sizes, tracing_blocks, intersections, outgoing_bidxs,

@@ -170,6 +170,24 @@ def test_render_loop_stage_by_stage():
         np.testing.assert_allclose(ps.cpu().numpy(), rs_, rtol=1e-4, atol=2e-6)
         if i == 0:
             assert (ob_ref[:, 0] != -1).sum() > B // 2 and ra_.max() > 0.05
+    # ---- bg_pts_inference (v1: hashgrid/binding.cpp:31, rendering_kernel.cu:872-1008 -- every outgoing tile of the ray blended per
+    # sample on ONE set of z_vals; no caller in rendering.py, on the binding surface).  Slots behind a -1 must be ignored.
+    zb = torch.full((B, Sb), -1.0, device=DEV)
+    H.inverse_z_sampling(inter, ob[:, 0].contiguous(), zb, 1e6)
+    zb_ref = O.render_inverse_z_sampling(inter_ref, ob_ref[:, 0], Sb, 1e6)
+    ob_v1, bw_v1 = ob_ref.copy(), np.abs(bw_ref) + 0.1
+    ob_v1[::7, 0] = -1            # rays whose FIRST slot is empty: the loop breaks at once -> zeros, whatever follows
+    ob_v1[1::5, 1] = ob_v1[1::5, 0]   # two tiles on many rays
+    ob_v1[2::9, 2] = 0            # ... and a third behind a second that may be -1 (then ignored)
+    bw_v1[3::11] = 0.0            # zero total weight: sums stay unnormalised (= 0)
+    pd, ps, pa = (torch.full((B, Sb, 3), 5.0, device=DEV), torch.full((B, Sb, 3), 5.0, device=DEV), torch.full((B, Sb, 1), 5.0, device=DEV))
+    H.bg_pts_inference(RO, RD, zb, g(ob_v1), g(bw_v1.astype(np.float32)), C, Z, RES, TAB, PAR, pd, ps, pa)
+    rd_, rs_, ra_ = O.bg_pts_inference(o, d, zb_ref, ob_v1, bw_v1.astype(np.float32), sc["corners"], sc["sizes"], sc["res"], sc["tables"],
+                                       sc["params"])
+    assert ra_.max() > 0.05 and (ra_[::7] == 0).all()
+    np.testing.assert_allclose(pa.cpu().numpy(), ra_, rtol=1e-4, atol=2e-6)
+    np.testing.assert_allclose(pd.cpu().numpy(), rd_, rtol=1e-4, atol=2e-6)
+    np.testing.assert_allclose(ps.cpu().numpy(), rs_, rtol=1e-4, atol=2e-6)
 
 
 def test_pipelined_group_loop_gives_the_bits_of_the_plain_one(monkeypatch):

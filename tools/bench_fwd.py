@@ -19,6 +19,10 @@ if sort != "0":  # ray-ordering experiment: rays sorted by the Morton code of th
     for b in range(k):
         for a in range(3):
             code |= ((c[:, a] >> b) & 1) << (3 * b + a)
+    if os.environ.get("SORT_DIR", "0") != "0":   # ... and, inside a cell, by the direction's octant and dominant axis (coherent bundles)
+        dd = torch.nn.functional.normalize(d, dim=-1)
+        octant = ((dd[:, 0] > 0).long() | ((dd[:, 1] > 0).long() << 1) | ((dd[:, 2] > 0).long() << 2))
+        code = code * 32 + octant * 4 + dd.abs().argmax(-1)
     order = torch.argsort(code)
     o, d = o[order].contiguous(), d[order].contiguous()
 z, dist = m.sample(o, d, S)
