@@ -143,6 +143,47 @@ def main():
     assert 0 < nv < B, nv
     save("g15_render_masks", **g15)
 
+    # ---- G16: HashGrid.pruning_tile_grid (hashgrid/__init__.py:138-213), the coarse-to-fine occupancy pruning, run by the
+    # reference itself (its lattice, its run batching, its threshold) with this repo's C encoder standing in for the CUDA one.
+    # A table with a smooth density bump so that some cells survive and some do not; same level and one 2x split.
+    torch.manual_seed(16)
+    pr = ref_hashgrid.HashGrid.__new__(ref_hashgrid.HashGrid)
+    torch.nn.Module.__init__(pr)
+    pr.device = torch.device("cpu")
+    pcorner, psize = torch.tensor([0.0, 0.0, 0.0]), torch.tensor([4.0, 4.0, 4.0])
+    pr.bbox_center = pcorner + psize / 2.0
+    pr.bbox_size = psize * 2
+    pr.min_bbox = pr.bbox_center - pr.bbox_size / 2.0
+    pr.finest_resolution = (pr.bbox_size / pr.bbox_size.min() * 128).int()
+    pr.base_resolution = (pr.bbox_size / pr.bbox_size.min() * 8).int()
+    pres = oracle.level_resolutions(pr.base_resolution, pr.finest_resolution, 16)
+    pfeat = torch.randn(16, 2 ** 10, 2) * 2.0
+
+    class PHE(torch.nn.Module):
+        def forward(self, x):
+            return oracle.encode_bg(x.reshape(-1, 3).contiguous().float(), pfeat, pres).reshape(*x.shape[:-1], 32)
+
+    pr.HE = PHE()
+    pmlp = network.ShallowMLP(32)
+    network.init_model(pmlp, "xavier")
+    with torch.no_grad():
+        pmlp.sigma_layer.mlp[0].bias.fill_(-1.0)
+    g16 = {"tile_corner": pcorner, "tile_size": psize, "features": pfeat, "res": pres, "grid_resolution": np.array([8, 128])}
+    g16.update({"sd." + k: v for k, v in pmlp.state_dict().items()})
+    occ0 = torch.rand(8, 8, 8) < 0.6
+    g16["occ0"] = occ0
+    for tag, sub, step, th in (("same", False, 6000, 0.4), ("split", True, 12000, 0.35)):
+        pr.sampler_log2dim = torch.tensor([3, 3, 3], dtype=torch.int32)
+        pr.occupied_grid = occ0.clone()
+        with torch.no_grad():
+            pr.pruning_tile_grid(step, pmlp, sub_split=sub, pruning_th=th, batch_size=4096)
+        g16[f"{tag}_grid"], g16[f"{tag}_log2dim"] = pr.occupied_grid, pr.sampler_log2dim
+        g16[f"{tag}_step"], g16[f"{tag}_th"] = np.array(step), np.array(th)
+        frac = float(pr.occupied_grid.float().mean())
+        assert 0.02 < frac < 0.9, (tag, frac)
+        print("G16", tag, "occupied fraction", frac, "of", tuple(pr.occupied_grid.shape))
+    save("g16_pruning", **g16)
+
 
 if __name__ == "__main__":
     main()

@@ -64,3 +64,38 @@ def test_render_rays_fused_reproduces_reference_golden_g15(golden, tag):
     # merged prediction (tile.py:666-690)
     Tl = g[f"fg_{tag}_m1_T_left"]
     np.testing.assert_allclose(out["pred_color"].cpu().numpy(), g[f"fg_{tag}_m1_pred_color"] + Tl * g[f"bg_{tag}_m1_rgb"], **tol)
+
+
+@pytest.mark.parametrize("tag,sub", [("same", False), ("split", True)])
+def test_pruning_reproduces_reference_golden_g16(golden, tag, sub):
+    """Coarse-to-fine occupancy pruning (hashgrid/__init__.py:138-213) as the reference computed it: the reference-shaped
+    HashGrid module (HIP encoder op + decoder.inference_sigma) and trainer.pruning_tile_grid on a TileModel.  A cell whose
+    largest alpha lies within 1e-4 of the threshold may fall either way (f32 encoder differences): at most 2 such cells."""
+    import scanerf_amd  # noqa
+    from scanerf_amd import network, trainer
+    from scanerf_amd.hashgrid import HashGrid
+    from scanerf_amd.tile_model import TileModel
+    g = golden("g16_pruning")
+    gb, gf = (int(v) for v in g["grid_resolution"])
+    step, th = int(g[f"{tag}_step"]), float(g[f"{tag}_th"])
+    sd = _sd(g)
+    hg = HashGrid(DEV, T(g["tile_corner"]), T(g["tile_size"]), log2_hashmap_size=10, grid_resolution=[gb, gf], sampler_log2dim=3)
+    assert np.array_equal(hg.HE.resolution.cpu().numpy(), g["res"])
+    hg.occupied_grid = T(g["occ0"]).to(DEV)
+    with torch.no_grad():
+        hg.HE.features.copy_(T(g["features"]).to(DEV))
+    dec = network.ShallowMLP(32)
+    dec.load_state_dict(sd)
+    hg.pruning_tile_grid(step, dec.to(DEV), sub_split=sub, pruning_th=th, batch_size=4096)
+    assert np.array_equal(hg.sampler_log2dim.cpu().numpy(), g[f"{tag}_log2dim"])
+    d1 = int((hg.occupied_grid.cpu().numpy() != g[f"{tag}_grid"]).sum())
+    m = TileModel(g["tile_corner"].tolist(), g["tile_size"].tolist(), DEV, log2_T=10, grid_resolution=(gb, gf), sampler_log2dim=3)
+    m.set_occupancy(T(g["occ0"]))
+    with torch.no_grad():
+        m.features.copy_(T(g["features"]).to(DEV))
+    m.decoder.load_ref_state_dict(sd)
+    trainer.pruning_tile_grid(m, step, sub_split=sub, pruning_th=th, batch_size=4096, finest_resolution=gf)
+    assert np.array_equal(m.log2dim.cpu().numpy(), g[f"{tag}_log2dim"])
+    d2 = int((m.occupied_grid.cpu().numpy() != g[f"{tag}_grid"]).sum())
+    print(f"pruning vs the reference ({tag}): {d1} / {d2} of {g[f'{tag}_grid'].size} cells differ (HashGrid module / TileModel)")
+    assert d1 <= 2 and d2 <= 2, (d1, d2)

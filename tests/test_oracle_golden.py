@@ -171,3 +171,18 @@ def test_g15_fore_and_bg_valid_masks_and_fills(golden):
             if mode == O.TRAIN:
                 np.testing.assert_allclose(out["fg_l2_reg_specular"].numpy(), g[f"fg_{tag}_l2_reg_specular"], rtol=2e-5)
                 np.testing.assert_allclose(out["bg_l2_reg_specular"].numpy(), g[f"bg_{tag}_l2_reg_specular"], rtol=2e-5)
+
+
+def test_g16_pruning_tile_grid(golden):
+    """HashGrid.pruning_tile_grid run by the reference (hashgrid/__init__.py:138-213): the oracle's restatement gives the same
+    occupancy grids, on the same level and across one 2x split."""
+    g = golden("g16_pruning")
+    sd = _sd(g)
+    bbox_size = T(g["tile_size"]) * 2
+    for tag, sub in (("same", False), ("split", True)):
+        new, l2d = O.pruning_tile_grid(T(g["occ0"]), torch.tensor([3, 3, 3]), T(g["features"]), T(g["res"]), sd, bbox_size,
+                                       int(g[f"{tag}_step"]), sub, float(g[f"{tag}_th"]), finest_resolution=int(g["grid_resolution"][1]),
+                                       batch_size=4096)
+        np.testing.assert_array_equal(l2d.numpy(), g[f"{tag}_log2dim"])
+        diff = int((new.numpy() != g[f"{tag}_grid"]).sum())
+        assert diff == 0, (tag, diff)
