@@ -344,6 +344,47 @@ def bench_render(args, world, rank, dev):
         dist.destroy_process_group()
 
 
+def autograd_route_leg(args, dev, rays_o, rays_d, target, S, step0, n=3):
+    """autograd_route_ms_per_step: the same iteration through the reference-shaped classes with the caller's OWN loss code --
+    hashgrid.HashGrid.render_fore_rays (-> render.FusedRenderRays: the fused forward / backward kernels behind torch autograd),
+    a torch MSE + l2_reg loss, loss.backward(), torch.optim.Adam on the network.ShallowMLP parameters, adam_step_cuda on the
+    table's dense gradient -- what tile.py:880-1015 runs when it keeps its loss terms (depth / smooth / ADMM penalty)."""
+    from scanerf_amd import network
+    from scanerf_amd.cuda import adam_step_cuda
+    from scanerf_amd.hashgrid import HashGrid
+    hg = HashGrid(dev, torch.tensor([-4.0, -4, -4]), torch.tensor([8.0, 8, 8]), log2_hashmap_size=args.log2_T, grid_resolution=[32, 2048],
+                  sampler_log2dim=4)
+    dec = network.init_model(network.ShallowMLP(32), "xavier").to(dev)
+    opt = torch.optim.Adam(dec.parameters(), lr=1e-3, betas=(0.9, 0.99), eps=1e-15)
+    m1, m2 = torch.zeros_like(hg.HE.features), torch.zeros_like(hg.HE.features)
+    K = hg.HE.features.numel() // 8
+
+    def step(i):
+        hg.HE.features.grad = None
+        opt.zero_grad(set_to_none=True)
+        o, ok = hg.render_fore_rays(rays_o, rays_d, S, dec, 0, global_step=step0 + i)
+        loss = torch.nn.functional.mse_loss(o["pred_color"], target) + 0.01 * o["l2_reg_specular"]
+        loss.backward()
+        with torch.no_grad():
+            adam_step_cuda(hg.HE.features.data.view(K, 8), hg.HE.features.grad.view(K, 8), m1.view(K, 8), m2.view(K, 8), 1e-2, 0.9, 0.99,
+                           1e-15, i)
+        opt.step()
+    step(0)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(n):
+        step(1 + i)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / n * 1e3
+    assert hg.last_render_route == "fused"
+    del hg, dec, opt, m1, m2
+    torch.cuda.empty_cache()
+    return {"autograd_route_ms_per_step": ms,
+            "autograd_route_is": (f"hashgrid.HashGrid.render_fore_rays (render.FusedRenderRays) + torch loss + loss.backward() + torch Adam on "
+                                  f"network.ShallowMLP + adam_step_cuda on the dense table gradient, {rays_o.shape[0]} rays x {S} samples, 1 warm-up + "
+                                  f"{n} timed steps")}
+
+
 def side_legs(args, dev, rays_o, rays_d, target, S, step0):
     """Two more timings inside the default run, so that they are on the driver's clock too (rank 0, N = 1, configs[1] only;
     `--no-side-legs` skips them):
@@ -368,6 +409,7 @@ def side_legs(args, dev, rays_o, rays_d, target, S, step0):
                           f"{rays_o.shape[0]} rays x {S} samples, 1 warm-up + {n_ops} timed steps (round 4, torch decoder graph: 155 ms)")
     del m, opt
     torch.cuda.empty_cache()
+    out.update(autograd_route_leg(args, dev, rays_o, rays_d, target, S, step0))
     n_fr = 5
     elapsed, H, W, ntile, opaque = time_render(args, 1, 0, dev, n_fr, 2)
     out["render_ms_per_frame"] = elapsed / n_fr * 1e3

@@ -195,6 +195,8 @@ class HashGrid(nn.Module):
 
     # ---- rendering (:413-596) ----------------------------------------------------------------------------------------------------
     def _masked(self, valid, out, B, like_o, like_d):
+        if valid is None:   # every ray rendered: the scatter into zero / one filled tensors is the identity
+            return out["rgb"], out["depth"], out["T_left"][:, None], out["specular"], out["diffuse"]
         rgb, depth = torch.zeros_like(like_o), torch.zeros_like(like_d[..., :1])
         transparency = torch.ones_like(like_d[..., :1])
         specular, diffuse = torch.zeros_like(like_o), torch.zeros_like(like_o)
@@ -210,11 +212,15 @@ class HashGrid(nn.Module):
         valid = torch.all(z_vals != -1, dim=-1)
         if occlusion_mask is not None:
             valid = valid & occlusion_mask[..., 0]
-        out, ret = self.render_batch_rays(rays_o[valid], rays_d[valid], z_vals[valid], dists[valid], decoder, mode, self.contract_fore,
+        # (all rays valid -- a fully occupied grid, rays from inside the tile: the boolean-mask gathers and the scatter back are
+        # identities; skipping them saves four [B,S]-sized copies per branch and changes no value)
+        sel = None if bool(valid.all()) else valid
+        pick = (lambda t: t) if sel is None else (lambda t: t[sel])
+        out, ret = self.render_batch_rays(pick(rays_o), pick(rays_d), pick(z_vals), pick(dists), decoder, mode, self.contract_fore,
                                           out_normal=False, infinity=infinity, global_step=kwargs["global_step"])
         if ret is False:
             return None, False
-        rgb, depth, transparency, specular, diffuse = self._masked(valid, out, rays_o.shape[0], rays_o, rays_d)
+        rgb, depth, transparency, specular, diffuse = self._masked(sel, out, rays_o.shape[0], rays_o, rays_d)
         out_dict = dict(out)
         out_dict.update({"fore_valid": valid, "pred_color": rgb, "pred_depth": depth, "specular": specular, "diffuse": diffuse,
                          "T_left": transparency})
@@ -227,11 +233,13 @@ class HashGrid(nn.Module):
             return None, False
         if occlusion_mask is not None:
             valid = valid & occlusion_mask[..., 0]
-        out, ret = self.render_batch_rays(rays_o[valid], rays_d[valid], z_vals[valid], dists[valid], decoder, mode, self.contract_bg,
+        sel = None if bool(valid.all()) else valid
+        pick = (lambda t: t) if sel is None else (lambda t: t[sel])
+        out, ret = self.render_batch_rays(pick(rays_o), pick(rays_d), pick(z_vals), pick(dists), decoder, mode, self.contract_bg,
                                           out_normal=False, infinity=infinity, global_step=kwargs["global_step"])
         if ret is False:
             return None, ret
-        rgb, depth, transparency, specular, diffuse = self._masked(valid, out, rays_o.shape[0], rays_o, rays_d)
+        rgb, depth, transparency, specular, diffuse = self._masked(sel, out, rays_o.shape[0], rays_o, rays_d)
         out_dict = dict(out)
         out_dict.update({"valid": valid, "rgb": rgb, "depth": depth, "specular": specular, "diffuse": diffuse, "T_left": transparency})
         return out_dict, ret
