@@ -107,7 +107,7 @@ def test_mse_loss_through_the_boundary_is_bit_equal_to_train_step_fused():
                                        m.bbox_size.tolist(), render.FORE, False, None, 0, False)
     l2 = torch.nn.functional.mse_loss(out2[:, render.RGB], tgt) + 0.01 * out2[:, render.W_SPEC2].sum() / (3.0 * B)
     l2.backward()
-    np.testing.assert_allclose(float(l2), float(loss), rtol=1e-6)
+    np.testing.assert_allclose(float(l2.detach()), float(loss), rtol=1e-6)
     assert _rel_l2(F2.grad, F.grad) < 1e-6
     dummy = torch.optim.SGD(m.decoder.parameters(), lr=0.0)
     train_step_fused(m, dummy, o, d, tgt, S_, step, table_lr=0.0, fused_adam=False, dec_step=False)
