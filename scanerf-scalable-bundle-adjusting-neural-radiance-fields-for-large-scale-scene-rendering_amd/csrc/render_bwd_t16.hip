@@ -463,6 +463,12 @@ __global__ void __launch_bounds__(kThreads, 2) k_render_bwd_t16(BwdArgs a)
             const int s = tile_e * 16 + c;
             if (tile_e < 0 || !(s < S) || !active) return;
             const int j8 = 4 * (q & 1) + jj, level = 4 * (j8 >> 1) + 2 * (q >> 1) + (j8 & 1);
+#ifdef T16_MERGE_EMU   // timing experiment only (results are wrong): the record COUNT a run-merged emission of the coarse levels would leave
+            {          // (a run of k samples in one cell = 8 single-entry records instead of 4k: levels 0-3 have runs of ~8 / 6 / 4.5 / 3.4)
+                const int kk = level == 0 ? 4 : (level == 1 ? 3 : (level <= 3 ? 2 : 1));
+                if (kk > 1 && (c % kk) != 0) return;
+            }
+#endif
             const float gx = jj == 0 ? e0[0] : (jj == 1 ? e0[2] : (jj == 2 ? e1[0] : e1[2]));
             const float gy = jj == 0 ? e0[1] : (jj == 1 ? e0[3] : (jj == 2 ? e1[1] : e1[3]));
             if (a.dfeat) reinterpret_cast<float2 *>(a.dfeat)[(size_t)level * a.f.B * S + (size_t)ray * S + s] = make_float2(gx, gy);
