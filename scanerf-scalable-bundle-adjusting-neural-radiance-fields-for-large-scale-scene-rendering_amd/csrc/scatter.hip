@@ -1013,7 +1013,10 @@ SCANERF_API int scanerf_render_scatter_accumulate(float *grad_features, int B, i
     if (split_to_fine(B, S, g, w, workspace, workspace_bytes, grad_features, (hipStream_t)stream)) nbins_acc = 16 * g.NB;
     const size_t lds_bytes = (size_t)(2 << (g.bucket_log < 13 ? g.bucket_log : 13)) * 8;
     const char *ve = getenv("SCANERF_ACC_VARIANT");  // tuning experiments only
-    const int variant = ve ? atoi(ve) : 0;
+    // launch shape by the records' format, as the Adam-epilogue entry does (12-byte records: 512 threads x 16 records per lane
+    // 1.5 ms against 1.9 ms for the 16-byte records' 256 x 32 at configs[1]; 8-byte ones: 512 x 32)
+    const int pf_acc = (nbins_acc != nbins) ? 2 : plan_format(workspace);
+    const int variant = ve ? atoi(ve) : (pf_acc == 2 ? 8 : (pf_acc == 1 ? 10 : 0));
 #define SCANERF_LAUNCH_ACC(TH, UU)                                                                                  \
     {                                                                                                               \
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bin_accumulate<TH, UU>),               \
