@@ -102,6 +102,18 @@ if __name__ != "__main__" and torch.cuda.device_count() > 0 and not torch.cuda.i
                                        stdout=open(os.path.join(_OUT, f"rank{_r}.log"), "w"), stderr=subprocess.STDOUT))
 
 
+    import atexit
+
+    def _reap():   # (a run that deselects the test must not leave the rank processes behind)
+        for _p in _PROCS:
+            if _p.poll() is None:
+                try:
+                    _p.wait(timeout=120)
+                except subprocess.TimeoutExpired:
+                    _p.kill()
+    atexit.register(_reap)
+
+
 @pytest.mark.gpu
 def test_two_ranks_with_real_tile_trainers_match_each_other_and_the_single_process_run():
     if not _PROCS:
