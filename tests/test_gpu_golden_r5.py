@@ -99,3 +99,23 @@ def test_pruning_reproduces_reference_golden_g16(golden, tag, sub):
     d2 = int((m.occupied_grid.cpu().numpy() != g[f"{tag}_grid"]).sum())
     print(f"pruning vs the reference ({tag}): {d1} / {d2} of {g[f'{tag}_grid'].size} cells differ (HashGrid module / TileModel)")
     assert d1 <= 2 and d2 <= 2, (d1, d2)
+
+
+def test_camera_set_rays_and_pose_gradient_reproduce_reference_golden_g17(golden):
+    """cameras.CameraSet on the HIP ray kernels (compute_ray_forward; backward = compute_ray_backward, the adjoint) against
+    camera_utils.CAM.getRays and the reference's autograd of a loss on the rays w.r.t. se3_refine."""
+    import scanerf_amd  # noqa
+    from scanerf_amd import cameras as CM
+    g = golden("g17_cam_rays")
+    cam = CM.CameraSet(T(g["ks"]), T(g["c2ws"]), DEV, noise=T(g["noise"]))
+    with torch.no_grad():
+        cam.se3_refine.copy_(T(g["se3_refine"]).to(DEV))
+    C, n = g["c2ws"].shape[0], g["ray_idx"].shape[0]
+    np.testing.assert_allclose(cam.get_poses().detach().cpu().numpy(), g["poses"], rtol=1e-5, atol=1e-6)
+    ro, rd = cam.get_rays_idx(int(g["W"]), T(g["ray_idx"]))
+    np.testing.assert_allclose(ro.detach().cpu().numpy().reshape(C, n, 3), g["rays_o"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(rd.detach().cpu().numpy().reshape(C, n, 3), g["rays_d"], rtol=1e-4, atol=1e-5)
+    loss = (ro.reshape(C, n, 3) * T(g["w_o"]).to(DEV)).sum() + (rd.reshape(C, n, 3) * T(g["w_d"]).to(DEV)).sum()
+    np.testing.assert_allclose(float(loss.detach()), float(g["loss"]), rtol=1e-4, atol=1e-4)
+    loss.backward()
+    np.testing.assert_allclose(cam.se3_refine.grad.cpu().numpy(), g["grad_se3_refine"], rtol=2e-4, atol=2e-5)

@@ -186,3 +186,30 @@ def test_g16_pruning_tile_grid(golden):
         np.testing.assert_array_equal(l2d.numpy(), g[f"{tag}_log2dim"])
         diff = int((new.numpy() != g[f"{tag}_grid"]).sum())
         assert diff == 0, (tag, diff)
+
+
+def _cam_from_g17(g, device="cpu"):
+    import scanerf_amd  # noqa
+    from scanerf_amd import cameras as CM
+    cam = CM.CameraSet(T(g["ks"]), T(g["c2ws"]), device, noise=T(g["noise"]))
+    with torch.no_grad():
+        cam.se3_refine.copy_(T(g["se3_refine"]).to(device))
+    return cam, CM
+
+
+def test_g17_cam_rays_and_pose_gradient(golden):
+    """camera_utils.CAM (the reference's pose-parameter module): poses from the product's Lie / pose algebra (pure torch), rays from
+    the oracle's compute_ray_forward, and dL/d(se3_refine) = the oracle's compute_ray_backward (the mathematically correct adjoint,
+    ref_bug = 0) chained through torch autograd of the pose algebra -- against the reference's own autograd."""
+    g = golden("g17_cam_rays")
+    cam, CM = _cam_from_g17(g)
+    poses = cam.get_poses()
+    np.testing.assert_allclose(poses.detach().numpy(), g["poses"], rtol=1e-5, atol=1e-6)
+    C, n, W = g["c2ws"].shape[0], g["ray_idx"].shape[0], int(g["W"])
+    locs = CM.pixel_locs(C, T(g["ray_idx"]), W, "cpu").numpy()
+    o, d = O.compute_ray_forward(locs, g["ks"].reshape(C, 9), poses.detach().numpy().reshape(C, 12))
+    np.testing.assert_allclose(o.reshape(C, n, 3), g["rays_o"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(d.reshape(C, n, 3), g["rays_d"], rtol=1e-4, atol=1e-5)
+    gC = O.compute_ray_backward(g["w_o"].reshape(-1, 3), g["w_d"].reshape(-1, 3), g["ks"].reshape(C, 9), locs, C, ref_bug=False)
+    poses.backward(T(np.asarray(gC, np.float32)).reshape(C, 3, 4))
+    np.testing.assert_allclose(cam.se3_refine.grad.numpy(), g["grad_se3_refine"], rtol=2e-4, atol=2e-5)
