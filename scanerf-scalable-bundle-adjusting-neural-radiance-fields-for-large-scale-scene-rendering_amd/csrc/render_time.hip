@@ -619,6 +619,10 @@ __global__ void __launch_bounds__(kChunkThreads, 1) k_pts_inference_chunks(Infer
             cb[c] = a.t.corners[3 * b + c];
             sb[c] = a.t.sizes[3 * b + c];
         }
+#ifdef RT_SKEW   // timing experiment (tools/build_variant.py render_time="-ffp-contract=off -DRT_SKEW=n"): the second wave of every SIMD starts
+        // a tile step n x 64 cycles late, so that one wave's matrix work meets the other's vector work instead of both competing for the same pipe
+        if (wave >= 4) __builtin_amdgcn_s_sleep(RT_SKEW);
+#endif
       if constexpr (PIPE) {
         // Software pipeline over the wave's groups that run this tile's decoder: while group g is decoded, the 64 corner
         // loads of the next running group and the per-sample inputs of the group after it are in flight (the kernel is bound
