@@ -173,8 +173,48 @@ def test_unchanged_call_sequence_trains_through_the_hip_ops_and_agrees_with_the_
         depth = fo["pred_depth"] + fo["T_left"] * bo["depth"]
         loss = ((pred - tgt) ** 2).mean() + 0.01 * (fo["l2_reg_specular"] + bo["l2_reg_specular"]) + 1e-3 * (depth ** 2).mean()
         loss.backward()
-        grads[fused] = (float(loss), hg.HE.features.grad.clone(), {n: p.grad.clone() for n, p in dec.named_parameters()})
+        grads[fused] = (float(loss.detach()), hg.HE.features.grad.clone(), {n: p.grad.clone() for n, p in dec.named_parameters()})
     np.testing.assert_allclose(grads[True][0], grads[False][0], rtol=1e-5)
     assert _rel_l2(grads[True][1], grads[False][1]) < 1e-4
     for n in grads[True][2]:
         assert _rel_l2(grads[True][2][n], grads[False][2][n]) < 1e-4, n
+
+
+@pytest.mark.parametrize("table_dtype", [torch.float32, torch.bfloat16])
+def test_boundary_with_a_ray_mask_equals_the_compacted_batch(table_dtype):
+    """ray_valid through the autograd boundary: masked rays render as zeros with T_left = 1 and receive zero ray gradients;
+    table / decoder gradients equal those of the batch with the masked rays removed (what hashgrid/__init__.py:419-434 does by
+    boolean-mask indexing).  Also with a bf16 gather table (configs[2]): the gradient comes back in the table's dtype."""
+    import scanerf_amd  # noqa
+    from scanerf_amd import network, render
+    rng = np.random.default_rng(3)
+    B, S_ = 300, 48
+    o, d, z, dist = (T(a).to(DEV) for a in _inputs(rng, B, S_, False))
+    feat = T((rng.normal(size=(16, 2 ** 12, 2)) * 0.5).astype(np.float32)).to(DEV).to(table_dtype)
+    res = O.level_resolutions(torch.tensor([32, 32, 32]), torch.tensor([2048, 2048, 2048])).to(DEV).int().contiguous()
+    blob0 = network.xavier_blob(2, DEV, bias_scale=0.05)
+    keep = T(rng.random(B) < 0.6).to(DEV)
+    w = torch.randn(B, 16, device=DEV)
+    w[:, 15] = 0
+    box = ([-8.0] * 3, [16.0] * 3, render.FORE, False)
+    wf = network.weight_feature(9000, DEV)
+
+    def run(oo, dd, zz, di, mask, ww):
+        F = feat.clone().requires_grad_(True)
+        blob = blob0.clone().requires_grad_(True)
+        og, dg = oo.clone().requires_grad_(True), dd.clone().requires_grad_(True)
+        out, _ = render.fused_render_rays(og, dg, zz, di, F, blob, res, wf, *box, mask, 0, True)
+        (out * ww).sum().backward()
+        return out.detach(), F.grad, blob.grad, og.grad, dg.grad
+
+    out_m, gF_m, gb_m, go_m, gd_m = run(o, d, z, dist, keep, w)
+    out_c, gF_c, gb_c, go_c, gd_c = run(o[keep], d[keep], z[keep], dist[keep], None, w[keep])
+    assert gF_m.dtype == table_dtype and gF_m.shape == feat.shape
+    dead = ~keep
+    assert bool((out_m[dead][:, [0, 1, 2, 3, 5, 6, 7, 8, 9, 10]] == 0).all()) and bool((out_m[dead][:, 4] == 1).all())
+    assert float(go_m[dead].abs().max()) == 0.0 and float(gd_m[dead].abs().max()) == 0.0
+    assert torch.equal(out_m[keep], out_c)
+    tol = 1e-5 if table_dtype == torch.float32 else 2e-2   # (bf16: the returned gradient is rounded to the table's dtype)
+    assert _rel_l2(gF_m.float(), gF_c.float()) < tol
+    assert _rel_l2(gb_m, gb_c) < 1e-5
+    assert _rel_l2(go_m[keep], go_c) < 1e-4 and _rel_l2(gd_m[keep], gd_c) < 1e-4
