@@ -60,31 +60,28 @@ class HashGrid(nn.Module):
         self.last_render_route = None
 
     # ---- checkpoints / deployment files (:94-105, :248-266) ----------------------------------------------------------------
+    _CKPT = (("occupied_grid", "occupied_grid"), ("sampler_log2dim", "sampler_log2dim"), ("grid_resolution", "grid_resolution"))
+
     def export_check_point(self):
-        return {"occupied_grid": self.occupied_grid.detach().cpu().numpy(), "sampler_log2dim": self.sampler_log2dim.detach().cpu().numpy(),
-                "grid_resolution": self.grid_resolution.detach().cpu().numpy(), "features": self.HE.features.detach().cpu().numpy()}
+        ck = {key: getattr(self, attr).detach().cpu().numpy() for key, attr in self._CKPT}
+        ck["features"] = self.HE.features.detach().cpu().numpy()
+        return ck
 
     def load_check_point(self, ckp):
-        func = lambda x: torch.from_numpy(x).to(self.device)
-        self.occupied_grid = func(ckp["occupied_grid"])
-        self.sampler_log2dim = func(ckp["sampler_log2dim"])
-        self.grid_resolution = func(ckp["grid_resolution"])
-        self.HE.features = nn.Parameter(func(ckp["features"]))
+        for key, attr in self._CKPT:
+            setattr(self, attr, torch.from_numpy(ckp[key]).to(self.device))
+        self.HE.features = nn.Parameter(torch.from_numpy(ckp["features"]).to(self.device))
 
     def export(self, path):
-        np.savez(os.path.join(path, "feature.npz"), features=self.HE.features.detach().cpu().numpy().astype(np.float16),
-                 occupied_grid=self.occupied_grid.detach().cpu(), block_corner=self.min_bbox.cpu().numpy(),
-                 block_size=self.bbox_size.cpu().numpy(), grid_log2dim=self.sampler_log2dim.cpu().numpy(),
-                 resolution=self.HE.resolution.cpu().numpy())
+        from ..renderer import write_feature_npz
+        write_feature_npz(path, self.HE.features, self.occupied_grid, self.min_bbox, self.bbox_size, self.sampler_log2dim, self.HE.resolution)
 
     def load(self, path):
         f = np.load(os.path.join(path, "feature.npz"))
-        self.HE.features = nn.Parameter(torch.from_numpy(f["features"]).float().to(self.device))
-        self.occupied_grid = torch.from_numpy(f["occupied_grid"]).to(self.device)
-        self.block_corner = torch.from_numpy(f["block_corner"]).to(self.device)
-        self.block_size = torch.from_numpy(f["block_size"]).to(self.device)
-        self.sampler_log2dim = torch.from_numpy(f["grid_log2dim"]).to(self.device)
-        self.HE.resolution = torch.from_numpy(f["resolution"]).to(self.device)
+        on = lambda k: torch.from_numpy(f[k]).to(self.device)
+        self.HE.features = nn.Parameter(on("features").float())
+        self.occupied_grid, self.sampler_log2dim, self.HE.resolution = on("occupied_grid"), on("grid_log2dim"), on("resolution")
+        self.block_corner, self.block_size = on("block_corner"), on("block_size")
 
     def toCPU(self):
         self.HE.resolution = self.HE.resolution.cpu()
@@ -95,33 +92,12 @@ class HashGrid(nn.Module):
     # ---- coarse-to-fine pruning (:138-225) -----------------------------------------------------------------------------------
     @torch.no_grad()
     def pruning_tile_grid(self, global_step, decoder, sub_split=False, pruning_th=0.4, batch_size=92 ** 3):
-        log2dim = self.sampler_log2dim + (1 if sub_split else 0)
-        scale = 2 if sub_split else 1
-        grid_resolution = (2 ** log2dim).to(self.device)
-        total_res = self.finest_resolution / 4.0 if global_step < 10000 else self.finest_resolution / 2.0
-        sample_resolution = ((total_res / 2.0).to(self.device) / grid_resolution).int()
-        occ = self.occupied_grid
-        if scale > 1:
-            occ = occ.repeat_interleave(2, 0).repeat_interleave(2, 1).repeat_interleave(2, 2)
-        locs = torch.nonzero(occ).long()
-        new_grid = torch.zeros(tuple(int(r) for r in grid_resolution), dtype=torch.bool, device=self.device)
-        if locs.shape[0] and int(torch.prod(sample_resolution)) > 0:
-            grid_corner = locs / grid_resolution
-            X, Y, Z = torch.meshgrid(*(torch.arange(0, int(r), 1, device=self.device) for r in sample_resolution), indexing="ij")
-            grid_point = torch.stack([X, Y, Z], -1).reshape(-1, 3) / (sample_resolution * grid_resolution)
-            run = max(int(batch_size / int(torch.prod(sample_resolution))), 1)
-            wf = self.weight_feature(global_step)[None, :].repeat_interleave(2, dim=-1)
-            alpha_res = torch.zeros_like(grid_corner[..., 0])
-            for i in range(0, locs.shape[0], run):
-                pts = (grid_corner[i:i + run, None, :] + grid_point[None, ...]) * 2 - 1
-                n = pts.shape[0]
-                alpha = 1 - torch.exp(-1.0 * decoder.inference_sigma(self.HE(pts.reshape(-1, 3).float()) * wf))
-                alpha_res[i:i + n] = alpha.reshape(n, -1).max(dim=-1)[0]
-            keep = locs[alpha_res > pruning_th]
-            new_grid[keep[:, 0], keep[:, 1], keep[:, 2]] = True
-        self.sampler_log2dim = log2dim
-        self.occupied_grid = new_grid.contiguous()
-        self.grid_resolution = torch.tensor([2 ** int(k) for k in log2dim], dtype=torch.int32, device=self.device)
+        from .. import trainer
+        wf = self.weight_feature(global_step).repeat_interleave(2, dim=-1)
+        self.occupied_grid, self.sampler_log2dim = trainer.prune_occupancy(
+            self.occupied_grid, self.sampler_log2dim, self.finest_resolution, self.HE, decoder.inference_sigma, wf, global_step, sub_split,
+            pruning_th, batch_size, self.device)
+        self.grid_resolution = torch.tensor([2 ** int(k) for k in self.sampler_log2dim], dtype=torch.int32, device=self.device)
 
     @torch.no_grad()
     def pruning_grid(self, global_step, decoder, log2dim, pruning_th):
@@ -152,35 +128,20 @@ class HashGrid(nn.Module):
         return z_vals, dists
 
     def invalid_sampling_underground(self, rays_o, rays_d, bound):
-        outgoing_point = rays_o + bound[:, 1:] * rays_d
-        bbox_corner = self.bbox_center - self.bbox_size / 4.0
-        return ~(torch.abs(outgoing_point[:, 1] - bbox_corner[1]) < 0.0001)
+        exit_y = rays_o[:, 1] + bound[:, 1] * rays_d[:, 1]
+        return ~(torch.abs(exit_y - (self.bbox_center - self.bbox_size / 4.0)[1]) < 0.0001)
 
     @torch.no_grad()
     def inverse_z_sampling(self, rays_o, rays_d, num_sample, invalid_underground=True, perturb=False):
-        bounds = torch.full((rays_o.shape[0], 2), -1, dtype=torch.float32, device=rays_o.device)
-        ray_aabb_intersection(rays_o.contiguous(), rays_d.contiguous(), self.bbox_center.contiguous(), (self.bbox_size / 2.0).contiguous(), bounds)
-        if invalid_underground:
-            valid = self.invalid_sampling_underground(rays_o, rays_d, bounds)
-        else:
-            valid = torch.ones_like(rays_d[..., 0]).bool()
-        bounds[torch.any(bounds == -1, dim=-1), 1:] = 0.1
-        t_vals = torch.linspace(0.0, 1.0, steps=num_sample, device=self.device)[None, :]
-        z_vals = 1.0 / (1.0 / (bounds[:, 1:] + 1e-6) * (1.0 - t_vals) + 1.0 / 1e6 * t_vals)
-        z_vals = z_vals.expand([rays_o.shape[0], num_sample])
-        dists = z_vals[:, 1:] - z_vals[:, :-1]
-        dists = torch.cat([dists, 1e-6 * torch.ones(dists[..., :1].shape, device=rays_o.device)], -1)
-        return z_vals, dists, valid
+        from ..tile_model import inverse_z_samples
+        return inverse_z_samples(rays_o, rays_d, self.bbox_center, self.bbox_size / 2.0, num_sample, invalid_underground,
+                                 floor_y=(self.bbox_center - self.bbox_size / 4.0)[1])
 
     # ---- compositing in torch (:344-366; used by the op-by-op route) ---------------------------------------------------------
     def cal_integrate_weight(self, sigma, z_vals, dists, rays_d, infinity=True):
-        dists = dists * torch.norm(rays_d[..., None, :], dim=-1)
-        if infinity:
-            dists = torch.cat([dists[:, :-1], 1e10 * torch.ones_like(dists[:, :1])], -1)
-        alpha = 1.0 - torch.exp(-sigma[..., 0] * dists)
-        T = torch.cumprod(torch.cat([torch.ones((alpha.shape[0], 1), device=alpha.device), 1.0 - alpha + 1e-6], -1), -1)[:, :-1]
-        weights = alpha * T
-        return weights[..., None], T[:, -1]
+        from ..tile_model import composite_weights
+        w, T_left = composite_weights(sigma[..., 0], dists, rays_d, infinity)
+        return w[..., None], T_left
 
     def accumulate(self, weights, attr):
         return torch.sum(weights * attr, dim=1)

@@ -17,14 +17,19 @@ from .hashgrid import (accumulate_color, bg_pts_inference_v2, inverse_z_sampling
                        pts_inference, ray_block_intersection, sample_points, sort_tracing_blocks, update_outgoing_bidx)
 
 
+def write_feature_npz(path, features, occupied_grid, min_bbox, bbox_size, log2dim, resolution):
+    """`feature.npz` as HashGrid.export writes it (hashgrid/__init__.py:248-257): fp16 table, occupancy, the 2x box, the sampler's
+    log2dim, the level resolutions -- in that key order (golden G12 compares with a file written by the reference's own writer)."""
+    cpu = lambda t: t.detach().cpu().numpy()
+    np.savez(os.path.join(path, "feature.npz"), features=cpu(features).astype(np.float16), occupied_grid=cpu(occupied_grid),
+             block_corner=cpu(min_bbox), block_size=cpu(bbox_size), grid_log2dim=cpu(log2dim), resolution=cpu(resolution))
+
+
 def export_tile(path, model):
     """feature.npz (fp16 table, occupancy, 2x-box corner/size, log2dim, resolution) + decoder.pth
     (state dict with the reference's ShallowMLP key names)."""
     os.makedirs(path, exist_ok=True)
-    np.savez(os.path.join(path, "feature.npz"), features=model.features.detach().cpu().numpy().astype(np.float16),
-             occupied_grid=model.occupied_grid.cpu().numpy(), block_corner=model.min_bbox.cpu().numpy(),
-             block_size=model.bbox_size.cpu().numpy(), grid_log2dim=model.log2dim.cpu().numpy(),
-             resolution=model.resolution.cpu().numpy())
+    write_feature_npz(path, model.features, model.occupied_grid, model.min_bbox, model.bbox_size, model.log2dim, model.resolution)
     torch.save({k: v.detach().cpu() for k, v in model.decoder.ref_state_dict().items()}, os.path.join(path, "decoder.pth"))
 
 

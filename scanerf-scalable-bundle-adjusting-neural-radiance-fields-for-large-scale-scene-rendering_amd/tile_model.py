@@ -39,6 +39,39 @@ def sh3(v):
                         _C3[4] * x * (4 * zz - xx - yy), _C3[5] * z * (xx - yy), _C3[6] * x * (xx - 3 * yy)], -1)
 
 
+def composite_weights(sigma, dists, rays_d, infinity):
+    """Alpha compositing weights of hashgrid/__init__.py:344-360 in torch: delta = dists * |d| (last sample 1e10 for a background
+    ray), alpha = 1 - exp(-sigma delta), T_i = prod_{j<i} (1 - alpha_j + 1e-6), w = alpha T -> (w [B,S], T_left [B] = the
+    transmittance BEFORE the last sample, the reference's quirk)."""
+    delta = dists * rays_d.norm(dim=-1, keepdim=True)
+    if infinity:
+        delta = torch.cat([delta[:, :-1], torch.full_like(delta[:, :1], 1e10)], 1)
+    alpha = 1.0 - torch.exp(-sigma * delta)
+    T = torch.cumprod(torch.cat([torch.ones_like(alpha[:, :1]), 1.0 - alpha + 1e-6], 1), 1)[:, :-1]
+    return alpha * T, T[:, -1]
+
+
+@torch.no_grad()
+def inverse_z_samples(rays_o, rays_d, box_center, box_half, num_sample, invalid_underground, floor_y=None):
+    """Background samples in inverse depth beyond the HashGrid's 2x box (hashgrid/__init__.py:287-337): far = the ray's exit from
+    the box (HIP ray_aabb_intersection; 0.1 for rays that miss it), z = 1 / ((1 - t) / (far + 1e-6) + t / 1e6) for t = linspace(0, 1, S),
+    dists = differences with 1e-6 last; valid = not leaving through the floor y = floor_y (within 1e-4) when invalid_underground."""
+    from .cuda import ray_aabb_intersection
+    B, dev = rays_o.shape[0], rays_o.device
+    bounds = torch.full((B, 2), -1.0, device=dev)
+    ray_aabb_intersection(rays_o.contiguous(), rays_d.contiguous(), box_center.contiguous(), box_half.contiguous(), bounds)
+    if invalid_underground:
+        exit_y = rays_o[:, 1] + bounds[:, 1] * rays_d[:, 1]
+        valid = ~(torch.abs(exit_y - floor_y) < 0.0001)
+    else:
+        valid = torch.ones(B, dtype=torch.bool, device=dev)
+    far = torch.where(torch.any(bounds == -1, dim=-1, keepdim=True), torch.full_like(bounds[:, 1:], 0.1), bounds[:, 1:])
+    t = torch.linspace(0.0, 1.0, steps=num_sample, device=dev)[None, :]
+    z = (1.0 / (1.0 / (far + 1e-6) * (1.0 - t) + 1.0 / 1e6 * t)).contiguous()
+    d = torch.cat([z[:, 1:] - z[:, :-1], torch.full((B, 1), 1e-6, device=dev)], -1).contiguous()
+    return z, d, valid
+
+
 class Decoder(nn.Module):
     """sigma / diffuse / tint / SH-conditioned specular decoder of the reference's ShallowMLP (network.py:151-190).
     The parameters ARE the render-time blob (rendering.py:101-112: per layer [bias, W^T]), one flat tensor: the fused
@@ -193,12 +226,10 @@ class TileModel(nn.Module):
             sigma, dif, spec, tint = (t.reshape(B, S, -1) for t in decoder_op.decoder_apply(x, self.decoder.blob(), wf))
         else:   # other level counts (BASELINE configs[0]: 8), or hip_decoder = False: the torch graph
             sigma, dif, spec, tint = self.decoder(feats, d[:, None, :].expand(B, S, 3), wf)
-        delta = dist * d.norm(dim=-1, keepdim=True)
-        alpha = 1.0 - torch.exp(-sigma[..., 0] * delta)
-        T = torch.cumprod(torch.cat([torch.ones_like(alpha[:, :1]), 1.0 - alpha + 1e-6], 1), 1)[:, :-1]
-        w = (alpha * T)[..., None]
+        w2, T_left = composite_weights(sigma[..., 0], dist, d, False)
+        w = w2[..., None]
         out = {"valid": valid, "depth": (w[..., 0] * z).sum(1), "diffuse": (w * dif).sum(1),
-               "specular": (w * tint * spec).sum(1), "T_left": T[:, -1], "weights": w[..., 0]}
+               "specular": (w * tint * spec).sum(1), "T_left": T_left, "weights": w[..., 0]}
         out["rgb"] = torch.clamp(out["diffuse"] + out["specular"], 0, 1)
         if train:
             out["l2_reg_specular"] = (w.detach() * spec ** 2).sum(1).mean()
@@ -219,22 +250,9 @@ class TileModel(nn.Module):
     # ---- background branch: inverse-depth sampling beyond the 2x box (hashgrid/__init__.py:306-337) ----
     @torch.no_grad()
     def inverse_z_sampling(self, rays_o, rays_d, S, invalid_underground=False):
-        """z = 1/((1-t)/(far+1e-6) + t/1e6), t = linspace(0,1,S); far = exit of the HashGrid box
-        (0.1 for rays that miss it); dists = diff, last = 1e-6; optional under-ground mask (:287-293)."""
-        from .cuda import ray_aabb_intersection
-        B = rays_o.shape[0]
-        bounds = torch.full((B, 2), -1.0, device=self.device)
-        ray_aabb_intersection(rays_o, rays_d, self._center_dev, self._half_dev, bounds)
-        if invalid_underground:
-            out_pt = rays_o + bounds[:, 1:] * rays_d
-            valid = ~(torch.abs(out_pt[:, 1] - (self._center_dev - self._size_dev / 4.0)[1]) < 0.0001)
-        else:
-            valid = torch.ones(B, dtype=torch.bool, device=self.device)
-        far = torch.where(torch.any(bounds == -1, dim=-1, keepdim=True), torch.full_like(bounds[:, 1:], 0.1), bounds[:, 1:])
-        t = torch.linspace(0.0, 1.0, steps=S, device=self.device)[None, :]
-        z = (1.0 / (1.0 / (far + 1e-6) * (1.0 - t) + 1.0 / 1e6 * t)).contiguous()
-        d = torch.cat([z[:, 1:] - z[:, :-1], torch.full((B, 1), 1e-6, device=self.device)], -1).contiguous()
-        return z, d, valid
+        """hashgrid/__init__.py:306-337 (see inverse_z_samples)."""
+        return inverse_z_samples(rays_o, rays_d, self._center_dev, self._half_dev, S, invalid_underground,
+                                 floor_y=(self._center_dev - self._size_dev / 4.0)[1])
 
     @torch.no_grad()
     def render_rays_fused(self, rays_o, rays_d, S_fg, S_bg, global_step, invalid_underground=False, occlusion_mask=None):

@@ -96,39 +96,49 @@ def sigma_of_features(model, feats):
 
 
 @torch.no_grad()
-def pruning_tile_grid(model, global_step, sub_split=False, pruning_th=0.4, batch_size=92 ** 3, finest_resolution=2048):
-    """Re-derive the sampler's occupancy grid from the current field: every occupied cell (optionally split 2x per
-    axis) is probed on a regular lattice of sample_resolution^3 points; it stays occupied when the largest
-    alpha = 1 - exp(-sigma) over its lattice exceeds pruning_th.  The encoder runs through the HIP binding
-    (embedding_bg_forward) in contracted coordinates, the tile being [-1,1]^3 of the 2x box."""
-    dev = model.device
-    log2dim = model.log2dim + (1 if sub_split else 0)
-    scale = 2 if sub_split else 1
-    grid_resolution = (2 ** log2dim).to(dev)
-    fin = torch.as_tensor(model.bbox_size / model.bbox_size.min() * finest_resolution).int().to(dev)
+def prune_occupancy(occupied_grid, log2dim, finest_resolution, encode, sigma_of, weight_feature32, global_step, sub_split, pruning_th,
+                    batch_size, device):
+    """The occupancy re-derivation of hashgrid/__init__.py:138-213 on arrays: every occupied cell (optionally split 2x per axis) is
+    probed on a regular lattice of sample_resolution^3 points of the tile ([-1,1]^3 of the 2x box, contracted coordinates); it stays
+    occupied when the largest alpha = 1 - exp(-sigma) over its lattice exceeds pruning_th.  encode(points [N,3]) -> features [N,32]
+    (the HIP encoder binding), sigma_of(features * mask) -> sigma; finest_resolution: per-axis int vector (the table's finest level).
+    -> (new grid bool, new log2dim int32)."""
+    log2dim = log2dim.to(device) + (1 if sub_split else 0)
+    grid_resolution = (2 ** log2dim).to(device)
+    fin = torch.as_tensor(finest_resolution).to(device)
     total_res = fin / 4.0 if global_step < 10000 else fin / 2.0
     sample_resolution = ((total_res / 2.0) / grid_resolution).int()
-    occ = model.occupied_grid
-    if scale > 1:
+    occ = occupied_grid
+    if sub_split:
         occ = occ.repeat_interleave(2, 0).repeat_interleave(2, 1).repeat_interleave(2, 2)
     locs = torch.nonzero(occ).long()
-    new_grid = torch.zeros(tuple(int(r) for r in grid_resolution), dtype=torch.bool, device=dev)
+    new_grid = torch.zeros(tuple(int(r) for r in grid_resolution), dtype=torch.bool, device=device)
     if locs.shape[0] and int(torch.prod(sample_resolution)) > 0:
         grid_corner = locs / grid_resolution
-        grid_point = _mesh_grid(sample_resolution, dev) / (sample_resolution * grid_resolution)
+        grid_point = _mesh_grid(sample_resolution, device) / (sample_resolution * grid_resolution)
         run = max(int(batch_size / int(torch.prod(sample_resolution))), 1)
-        wf = network.weight_feature(global_step, dev).reshape(1, 32)
-        alpha_res = torch.zeros(locs.shape[0], device=dev)
+        wf = weight_feature32.reshape(1, 32)
+        alpha_res = torch.zeros(locs.shape[0], device=device)
         for i in range(0, locs.shape[0], run):
             pts = (grid_corner[i:i + run, None, :] + grid_point[None, ...]) * 2 - 1
             n = pts.shape[0]
-            feats = HashEmbeddingBG(pts.reshape(-1, 3).float().contiguous(), model.features.detach(), model.resolution)
-            alpha = 1 - torch.exp(-1.0 * sigma_of_features(model, feats.reshape(-1, 32) * wf))
+            alpha = 1 - torch.exp(-1.0 * sigma_of(encode(pts.reshape(-1, 3).float().contiguous()).reshape(-1, 32) * wf))
             alpha_res[i:i + n] = alpha.reshape(n, -1).max(dim=-1)[0]
         keep = locs[alpha_res > pruning_th]
         new_grid[keep[:, 0], keep[:, 1], keep[:, 2]] = True
-    model.log2dim = log2dim.int()
-    model.occupied_grid = new_grid.contiguous()
+    return new_grid.contiguous(), log2dim.int()
+
+
+@torch.no_grad()
+def pruning_tile_grid(model, global_step, sub_split=False, pruning_th=0.4, batch_size=92 ** 3, finest_resolution=2048):
+    """HashGrid.pruning_tile_grid for a TileModel (prune_occupancy on its table through the HIP encoder binding)."""
+    dev = model.device
+    fin = torch.as_tensor(model.bbox_size / model.bbox_size.min() * finest_resolution).int()
+    new_grid, log2dim = prune_occupancy(
+        model.occupied_grid, model.log2dim, fin, lambda p: HashEmbeddingBG(p, model.features.detach(), model.resolution),
+        lambda f: sigma_of_features(model, f), network.weight_feature(global_step, dev), global_step, sub_split, pruning_th, batch_size, dev)
+    model.log2dim = log2dim
+    model.occupied_grid = new_grid
     model._occ_full = bool(new_grid.all())
     return int(new_grid.sum())
 
