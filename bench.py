@@ -385,6 +385,38 @@ def autograd_route_leg(args, dev, rays_o, rays_d, target, S, step0, n=3):
                                   f"{n} timed steps")}
 
 
+def decoder_op_leg(dev, N, n=5):
+    """decoder_op: the stand-alone decoder (csrc/decoder.hip, what network.ShallowMLP runs) on N samples, HIP-event timed: the one
+    kernel pair of the path that is MATRIX-bound rather than gather- or stream-bound.  flops = SURVEY.md 8(d): 27 456 per sample
+    forward (x3 MFMA products for the hi/lo split), peak = 2.5 PFLOP/s dense f16."""
+    from scanerf_amd import decoder_op, network
+    torch.manual_seed(3)
+    x = torch.cat([0.3 * torch.randn(N, 32, device=dev), torch.randn(N, 3, device=dev)], -1).requires_grad_(True)
+    blob = network.xavier_blob(1, dev, bias_scale=0.05).requires_grad_(True)
+    wf = network.weight_feature(20000, dev)
+    g = [torch.randn(N, c, device=dev) for c in (1, 3, 3, 3)]
+    ev = lambda: torch.cuda.Event(enable_timing=True)
+    tf = tb = 0.0
+    for i in range(n + 1):
+        e0, e1, e2 = ev(), ev(), ev()
+        e0.record()
+        outs = decoder_op.decoder_apply(x, blob, wf)
+        e1.record()
+        torch.autograd.backward(outs, g)
+        e2.record()
+        torch.cuda.synchronize()
+        if i:   # (first pass = warm-up)
+            tf += e0.elapsed_time(e1)
+            tb += e1.elapsed_time(e2)
+        x.grad = blob.grad = None
+    tf, tb = tf / n, tb / n
+    flops = N * 2 * 13728
+    return {"decoder_op": {"samples": N, "forward_ms": tf, "backward_ms": tb, "forward_useful_TFLOPs": flops / tf / 1e9,
+                           "forward_mfma_TFLOPs": 3 * flops / tf / 1e9, "forward_mfma_frac_of_peak": 3 * flops / tf / 1e9 / 2500.0,
+                           "peak_TFLOPs": 2500.0, "is": "scanerf_decoder_forward / _backward (incl. decoder packing and the "
+                           "op's torch glue) on [N,35] inputs; split-f16 operands: three f16 MFMA products per useful product"}}
+
+
 def side_legs(args, dev, rays_o, rays_d, target, S, step0):
     """Two more timings inside the default run, so that they are on the driver's clock too (rank 0, N = 1, configs[1] only;
     `--no-side-legs` skips them):
@@ -410,6 +442,8 @@ def side_legs(args, dev, rays_o, rays_d, target, S, step0):
     del m, opt
     torch.cuda.empty_cache()
     out.update(autograd_route_leg(args, dev, rays_o, rays_d, target, S, step0))
+    out.update(decoder_op_leg(dev, rays_o.shape[0] * S))
+    torch.cuda.empty_cache()
     n_fr = 5
     elapsed, H, W, ntile, opaque = time_render(args, 1, 0, dev, n_fr, 2)
     out["render_ms_per_frame"] = elapsed / n_fr * 1e3
