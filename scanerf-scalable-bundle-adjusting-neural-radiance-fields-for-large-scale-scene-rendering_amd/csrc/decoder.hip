@@ -7,9 +7,9 @@
 // a caller that keeps the reference's own op-by-op structure got torch's graph instead (~40 kernels over [N,64] intermediates:
 // 140 of the 155 ms of such a step at 65 536 x 128 samples).  Here the same arithmetic as the fused kernels' -- split-f16
 // operands, three products per term, f32 accumulate: f32-equivalent (render_h3.h) -- runs per SAMPLE:
-//   forward   k_decoder_fwd_h3:  32-sample tiles on v_mfma_f32_32x32x16_f16, the h3 image of render_h3.h, 8 waves per
-//             workgroup, two workgroups per CU; per-sample view directions (the SH part of Directional_MLP.mlp.0 is one
-//             more k-step per tile instead of a per-ray constant);
+//   forward   k_decoder_fwd_s16: 16-sample tiles on v_mfma_f32_16x16x32_f16, the t16s image of render_t16.h, four waves per
+//             SIMD (k_decoder_fwd_h3, the 32-sample-tile form at two waves per SIMD, stays for comparison); per-sample view
+//             directions (the SH part of Directional_MLP.mlp.0 is one more k-step per tile instead of a per-ray constant);
 //   backward  k_decoder_bwd_s16: the t16s structure of render_bwd_t16.hip (16-sample tiles on v_mfma_f32_16x16x32_f16,
 //             8 waves = two per SIMD, weight-gradient blocks owned by waves and summed over the 8 waves' tiles through LDS
 //             staging, the workgroup's power-of-two gradient scale) with the compositing adjoint replaced by the incoming
@@ -83,6 +83,57 @@ __global__ void __launch_bounds__(kFwdThreads, 2) k_decoder_fwd_h3(DecArgs a)
                 a.dif[3 * n + c] = so.dif[c];
                 a.spec[3 * n + c] = so.spec[c];
                 a.tint[3 * n + c] = so.tint[c];
+            }
+        }
+    }
+}
+
+// ---- forward on 16-sample tiles (default; SCANERF_DECODER_FWD=h3 selects the kernel above): decode_tile_s16 (render_t16.h) --
+// v_mfma_f32_16x16x32_f16 on the t16s image, lane (c, q) = sample c, quarter q: the forward recompute of the backward kernel
+// below, so the op's backward differentiates exactly the values its forward returned.  94 registers -> four waves per SIMD,
+// where the kernel is bound by vector-instruction issue (profiles/r05_decoder_fwd_counters.txt): 1.07 -> 0.97 ms at 8.4e6
+// samples against the 32-sample-tile kernel.  The k-step grouping differs from that kernel's (32 units per MFMA instead of 16),
+// so the f32 sums round differently in the last bits; both are the split-f16 evaluation.
+constexpr int kFwd16Threads = 512;
+#ifndef FWD16_WAVES
+#define FWD16_WAVES 2
+#endif
+__global__ void __launch_bounds__(kFwd16Threads, FWD16_WAVES) k_decoder_fwd_s16(DecArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) char lds16[];
+    {
+        const float4 *src = reinterpret_cast<const float4 *>(a.packed + WS_S16);
+        float4 *dst = reinterpret_cast<float4 *>(lds16);
+        for (int i = threadIdx.x; i < S16_BYTES / 16; i += kFwd16Threads) dst[i] = src[i];
+    }
+    __syncthreads();
+    const char *lds = lds16;
+    const int lane = threadIdx.x & 63, c = lane & 15, q = lane >> 4;
+    const long long ntiles = (a.N + 15) >> 4;
+    const long long stride = (long long)gridDim.x * (kFwd16Threads / 64);
+    for (long long tile = (long long)blockIdx.x * (kFwd16Threads / 64) + (threadIdx.x >> 6); tile < ntiles; tile += stride) {
+        const long long n = tile * 16 + c;
+        const bool live = n < a.N;
+        const long long nc = live ? n : a.N - 1;
+        v4f xa, xb;
+        {
+            const float *row = a.feats + nc * a.ld_feats + 16 * (q & 1) + 4 * (q >> 1);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                xa[g] = row[g];
+                xb[g] = row[8 + g];
+            }
+        }
+        const float *dr = a.dirs + nc * a.ld_dirs;
+        const float d[3] = { dr[0], dr[1], dr[2] };
+        const SampleOut so = decode_tile_s16(lds, lane, xa, xb, d, 1e-8f);
+        if (live && q == 0) {
+            a.sigma[n] = so.sigma;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                a.dif[3 * n + k] = so.dif[k];
+                a.spec[3 * n + k] = so.spec[k];
+                a.tint[3 * n + k] = so.tint[k];
             }
         }
     }
@@ -656,10 +707,20 @@ SCANERF_API int scanerf_decoder_forward(const float *feats, int ld_feats, const 
     DecArgs a = {};
     a.feats = feats; a.ld_feats = ld_feats; a.dirs = dirs; a.ld_dirs = ld_dirs; a.packed = workspace; a.N = N;
     a.sigma = sigma; a.dif = diffuse; a.spec = specular; a.tint = tint;
-    const long long ntiles = (N + 31) >> 5;
-    long long blocks = (ntiles + 7) / 8;
-    if (blocks > 2 * kNumCU) blocks = 2 * kNumCU;   // two resident 512-thread workgroups per CU, persistent
-    hipLaunchKernelGGL(k_decoder_fwd_h3, dim3((int)blocks), dim3(kFwdThreads), 0, (hipStream_t)stream, a);
+    const char *e = getenv("SCANERF_DECODER_FWD");
+    if (e && e[0] == 'h') {   // comparison: 32-sample tiles at two waves per SIMD (202 registers)
+        const long long ntiles = (N + 31) >> 5;
+        long long blocks = (ntiles + 7) / 8;
+        if (blocks > 2 * kNumCU) blocks = 2 * kNumCU;
+        hipLaunchKernelGGL(k_decoder_fwd_h3, dim3((int)blocks), dim3(kFwdThreads), 0, (hipStream_t)stream, a);
+        return check_launch("decoder_forward(h3)");
+    }
+    const long long nt16 = (N + 15) >> 4;
+    long long b16 = (nt16 + 7) / 8;
+    if (b16 > 2 * kNumCU) b16 = 2 * kNumCU;   // two resident 512-thread workgroups per CU (77 KB of LDS each), persistent
+    hipError_t er = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_decoder_fwd_s16), hipFuncAttributeMaxDynamicSharedMemorySize, (int)S16_BYTES);
+    SCANERF_REQUIRE(er == hipSuccess, "decoder_forward: cannot reserve %d B of LDS: %s", (int)S16_BYTES, hipGetErrorString(er));
+    hipLaunchKernelGGL(k_decoder_fwd_s16, dim3((int)b16), dim3(kFwd16Threads), S16_BYTES, (hipStream_t)stream, a);
     return check_launch("decoder_forward");
 }
 

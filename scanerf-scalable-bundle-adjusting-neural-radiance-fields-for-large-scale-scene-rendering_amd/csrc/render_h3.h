@@ -336,8 +336,13 @@ __device__ __forceinline__ v16f act16_fast(const v16f &x)
     return r;
 }
 
-// Decoder forward on one 32-sample tile (same contract as decode_tile in render_device.h)
-__device__ __forceinline__ SampleOut decode_tile_h3(const char *img, int lane, const v16f &x, const v16f dinit[2])
+// Decoder forward on one 32-sample tile (same contract as decode_tile in render_device.h).
+// DIRS: dinit is not used; the SH part of Directional_MLP.mlp.0 is computed from the lane's direction `dir` where that layer
+// starts (same products and sums as h3_dinit + this function: bias, then the SH k-step, then the two H k-steps), so that the 32
+// registers of dinit are not live through the first three layers (the kernels at three and four waves per SIMD).
+template <bool DIRS = false>
+__device__ __forceinline__ SampleOut decode_tile_h3(const char *img, int lane, const v16f &x, const v16f dinit[2], const float *dir = nullptr,
+                                                    float eps = 0.0f)
 {
     const int h = lane >> 5, lo = h3_lane_off(lane);
     // Spatial_MLP.mlp.0 (32 -> 64) + Gaussian
@@ -374,7 +379,15 @@ __device__ __forceinline__ SampleOut decode_tile_h3(const char *img, int lane, c
     // Directional_MLP.mlp.0 (48 -> 64): SH part + bias pre-accumulated in dinit
     HL2 c0[2];
     {
-        v16f u[2] = { dinit[0], dinit[1] };
+        v16f u[2];
+        if constexpr (DIRS) {
+            float sh[16];
+            ray_sh(dir, sqrtf(dir[0] * dir[0] + dir[1] * dir[1] + dir[2] * dir[2]), sh, eps);
+            h3_dinit(img, lane, sh, u);
+        } else {
+            u[0] = dinit[0];
+            u[1] = dinit[1];
+        }
         const HL *const B[2] = { &H[1].t[0], &H[1].t[1] };
         h3_layer2<2>(u, img, H3_D0, 3, lo, B);
         c0[0] = split16(act16_fast(u[0]));

@@ -357,4 +357,120 @@ __device__ __forceinline__ float t16_sum8(const t16_h8 &v, float acc)
 // launcher of the pack kernel (render_bwd_t16.hip)
 int launch_pack_decoder_t16(const float *blob, const float *wf, char *out, hipStream_t st);
 
+// one ray's split SH operand as a 64-byte row: [hi: SH 0..15 as f16][lo: the f16 residuals] -- the bits t16_split gives in registers
+__device__ __forceinline__ void s16_sh_row(char *row, const float d[3], float eps)
+{
+    float sh[16];
+    ray_sh(d, sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]), sh, eps);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const T16HL o = t16_split(v4f{ sh[8 * q], sh[8 * q + 1], sh[8 * q + 2], sh[8 * q + 3] },
+                                  v4f{ sh[8 * q + 4], sh[8 * q + 5], sh[8 * q + 6], sh[8 * q + 7] });
+        *reinterpret_cast<t16_h8 *>(row + 16 * q) = o.hi;
+        *reinterpret_cast<t16_h8 *>(row + 32 + 16 * q) = o.lo;
+    }
+}
+
+// ---- the decoder FORWARD on one 16-sample tile from the t16s image (the forward recompute of render_bwd_t16.hip / decoder.hip's
+// backward as a function): lane (c, q) holds decoder inputs 16 (q & 1) + 4 (q >> 1) + {0..3} in xa and those + 8 in xb, and the
+// sample's view direction; the outputs are valid in the lanes with q == 0.  ~95 VGPRs: four waves per SIMD.
+// SH_ROW: the split SH operand of the sample's ray is read from `sh_row` (this lane's 16 bytes of the hi part; the lo part 32
+// bytes further: a 64-byte row [hi 16][lo 16] per ray written by s16_sh_row below; lanes with q >= 2 point at a row of zeros)
+// instead of being evaluated from d -- per tile the harmonics cost ~100 vector instructions for 16 samples, four lanes each.
+template <bool SH_ROW = false>
+__device__ __forceinline__ SampleOut decode_tile_s16(const char *lds, int lane, const v4f &xa, const v4f &xb, const float d[3], float eps,
+                                                     const char *sh_row = nullptr)
+{
+    const int q = lane >> 4, pos8 = s16_pos(lane) * 8;
+    SampleOut so;
+    T16HL HB[2];
+    {
+        const T16HL xB = t16_split(xa, xb);
+        v4f act[4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) act[b] = t16_bias(lds, 0, b, q, S16_BIAS);
+        s16_layer<4, 1>(act, lds, T16_L0, pos8, &xB);
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) act[b][g] = gauss_fast(act[b][g]);
+        const T16HL aB[2] = { t16_split(act[0], act[1]), t16_split(act[2], act[3]) };
+        v4f hh[4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) hh[b] = t16_bias(lds, 1, b, q, S16_BIAS);
+        s16_layer<4, 2>(hh, lds, T16_L1, pos8, aB);
+        HB[0] = t16_split(hh[0], hh[1]);
+        HB[1] = t16_split(hh[2], hh[3]);
+    }
+    {
+        v4f hd[2] = { t16_ld4(lds, S16_BIAS + 256 * 4), t16_ld4(lds, S16_BIAS + 260 * 4) };
+        s16_layer<2, 1>(hd, lds, T16_HEAD, pos8, &HB[0]);
+        so.sigma = softplus_(hd[0][0]);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            so.dif[k] = sigmoid_fast(hd[0][1 + k]);
+            so.tint[k] = sigmoid_fast(hd[1][k]);
+        }
+    }
+    T16HL cB[2];
+    {
+        T16HL shB;
+        if constexpr (SH_ROW) {
+            shB.hi = *reinterpret_cast<const t16_h8 *>(sh_row);
+            shB.lo = *reinterpret_cast<const t16_h8 *>(sh_row + 32);
+        } else {
+            const float dnorm = sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+            float sh[16];
+            ray_sh(d, dnorm, sh, eps);
+            v4f s0, s1;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                s0[j] = q == 0 ? sh[j] : (q == 1 ? sh[8 + j] : 0.0f);
+                s1[j] = q == 0 ? sh[4 + j] : (q == 1 ? sh[12 + j] : 0.0f);
+            }
+            shB = t16_split(s0, s1);
+        }
+        v4f v0[4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) v0[b] = t16_bias(lds, 2, b, q, S16_BIAS);
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const char *p1 = lds + T16_D0 + (b * 2 + 1) * T16_PAIR + pos8, *p0 = lds + T16_D0 + (b * 2) * T16_PAIR + pos8;
+            const t16_h8 shi = s16_lda(p1), slo = s16_lda(p1 + T16_SUB);
+            const t16_h8 ahi = s16_lda(p0), alo = s16_lda(p0 + T16_SUB);
+            v0[b] = t16_mfma(slo, shB.hi, v0[b]);
+            v0[b] = t16_mfma(shi, shB.lo, v0[b]);
+            v0[b] = t16_mfma(shi, shB.hi, v0[b]);
+            v0[b] = t16_mfma(alo, HB[1].hi, v0[b]);
+            v0[b] = t16_mfma(ahi, HB[1].lo, v0[b]);
+            v0[b] = t16_mfma(ahi, HB[1].hi, v0[b]);
+        }
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) v0[b][g] = gauss_fast(v0[b][g]);
+        cB[0] = t16_split(v0[0], v0[1]);
+        cB[1] = t16_split(v0[2], v0[3]);
+    }
+    {
+        v4f v1[4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) v1[b] = t16_bias(lds, 3, b, q, S16_BIAS);
+        s16_layer<4, 2>(v1, lds, T16_D1, pos8, cB);
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) v1[b][g] = gauss_fast(v1[b][g]);
+        cB[0] = t16_split(v1[0], v1[1]);
+        cB[1] = t16_split(v1[2], v1[3]);
+    }
+    {
+        v4f r[1] = { t16_ld4(lds, S16_BIAS + 264 * 4) };
+        s16_layer<1, 2>(r, lds, T16_D2, pos8, cB);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) so.spec[k] = sigmoid_fast(r[0][k]);
+    }
+    return so;
+}
+
 }  // namespace scanerf

@@ -24,6 +24,7 @@
 #include "render_device.h"
 #define H3_OPAQUE_ADDR 1  // (render_h3.h: one base register for the decoder image reads; measured clean on this kernel, tools/render_soak.py)
 #include "render_h3.h"
+#include "render_t16.h"
 
 using namespace scanerf;
 
@@ -534,9 +535,16 @@ __device__ __forceinline__ void gather_finish(const uint32_t raw[64], float (*tp
 #define RT_STRAIGHT true
 #endif
 constexpr int kChunkThreads = 512, kChunkWaves = kChunkThreads / 64, kChunkWaveGroups = 16;
-template <bool BG, bool PIPE>
-__global__ void __launch_bounds__(kChunkThreads, 1) k_pts_inference_chunks(InferArgs a)
+// NT threads, WPS waves per SIMD: <512, 1> = the software-pipelined form (PIPE; two waves per SIMD by its 142 KB of LDS);
+// <768, 3> without the pipeline = three waves per SIMD (one workgroup of 12 waves per CU around one staged image)
+#ifndef RT_W3_GROUPS
+#define RT_W3_GROUPS 16
+#endif
+template <bool BG, bool PIPE, int NT = kChunkThreads, int WPS = 1, int kWG = kChunkWaveGroups>
+__global__ void __launch_bounds__(NT, WPS) k_pts_inference_chunks(InferArgs a)
 {
+    constexpr int kChunkThreads = NT, kChunkWaves = NT / 64, kChunkWaveGroups = kWG;
+    static_assert(!PIPE || (NT == 512 && WPS == 1), "the pipelined form is the 512-thread one");
     // One block of LDS, the decoder image first: its reads then are `lane base + 16-bit immediate` (with the image behind the
     // other arrays every read past 64 KB took an address register of its own, ~25 live across the group loop).
     // PIPE: tpark = interpolation offsets of the group whose gathers are in flight; ppark = direction, depth step and blend
@@ -783,21 +791,15 @@ __global__ void __launch_bounds__(kChunkThreads, 1) k_pts_inference_chunks(Infer
         } else
 #endif
         encode8_01<SCANERF_F16, RT_GATHER_BATCH, RT_STRAIGHT>((const char *)a.tables + (size_t)b * 16 * a.T * 4, a.res + (size_t)b * 48, a.T, h, p01, run, x);
-        v16f dinit[2];
-        {
-            float sh[16];
-            ray_sh(d, dnorm, sh, 0.0f);
-            h3_dinit(lds, lane, sh, dinit);
-        }
         SampleOut so;
 #ifdef SCANERF_RT_EXPERIMENTS
         if (a.dbg == 1) {
-            so.sigma = x[0] + x[5] + x[10] + x[15] + dinit[0][0];
+            so.sigma = x[0] + x[5] + x[10] + x[15];
 #pragma unroll
             for (int c = 0; c < 3; ++c) { so.dif[c] = x[1 + c] + x[12 + c]; so.tint[c] = x[4 + c] + x[9 + c]; so.spec[c] = x[7 + c] + x[6 + c]; }
         } else
 #endif
-            so = decode_tile_h3(lds, lane, x, dinit);
+            so = decode_tile_h3<true>(lds, lane, x, nullptr, d, 0.0f);
         if (run && h == 0) {
             const float pa = 1.0f - expf(-1.0f * so.sigma * delta);
             if (BG) {
@@ -824,6 +826,312 @@ __global__ void __launch_bounds__(kChunkThreads, 1) k_pts_inference_chunks(Infer
     }
 }
 
+// ---- the same chunk-major kernel on 16-SAMPLE tiles at four waves per SIMD (default) ------------------------------------------
+// k_pts_inference_chunks above runs two waves per SIMD: ~250 registers (64 gather destinations of the software pipeline beside the
+// 32-sample decoder) and 142 KB of LDS per workgroup, and its decoder's dependent MFMA -> activation -> split chains have one
+// other wave to hide behind (de-phasing the two waves changes nothing: profiles/r05_render_pmc.txt).  Here the decoder is
+// decode_tile_s16 (render_t16.h: v_mfma_f32_16x16x32_f16 on the t16s image, the arithmetic of the training backward's recompute,
+// ~95 registers) and a lane gathers 4 levels instead of 8 (32 destinations, dead before the decoder starts): <= 128 registers,
+// no software pipeline, 77 KB of LDS -> two workgroups = 16 waves per CU, and the gathers of one wave wait behind the matrix and
+// vector work of three others.  A wave takes 64 consecutive samples at a time: lane l prepares sample l (position, blend weights,
+// occupancy), then each of the four 16-sample tiles with a live sample is decoded with lane (c, q) = sample 16 t + c, quarter q
+// (inputs by ds_bpermute from the preparing lane).
+constexpr int kT16Threads = 512, kT16Waves = kT16Threads / 64, kT16WaveGroups = 8;   // 8 x 64 = the 512 samples per wave and chunk of the kernel above
+static_assert(kT16Waves * kT16WaveGroups * 64 == kChunkWaves * kChunkWaveGroups * 32, "same chunk");
+
+// lane (c, q): levels l0 + {0, 1, 4, 5}, l0 = 8 (q & 1) + 2 (q >> 1)  =  decoder inputs 2 l0 + {0..3} (xa) and + 8 (xb)
+__device__ __forceinline__ void encode4_t16(const char *table, const float *rs, int T, int q, const float p01[3], v4f &xa, v4f &xb)
+{
+    const uint32_t mask = (uint32_t)T - 1u, l0 = (uint32_t)(8 * (q & 1) + 2 * (q >> 1)), hoff = l0 * (uint32_t)T;
+    uint32_t raw[32];
+    float tf[4][3];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int lu = (k & 1) + 4 * (k >> 1);  // level l0 + lu
+        int bc[3];
+        {
+#pragma clang fp contract(off)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const float v = p01[j] * rs[3 * lu + j];  // rs = (float)(res - 1) from level l0 on (staged in LDS with the tile's image)
+                bc[j] = (int)v;
+                tf[k][j] = __builtin_amdgcn_fractf(v);    // = v - (float)(int)v for the v >= 0 of a live sample, one instruction
+            }
+        }
+        uint32_t idx[8];
+        corner_indices(idx, bc[0], bc[1], bc[2], mask);
+        const char *base = table + (size_t)lu * T * 4;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) raw[8 * k + c] = *reinterpret_cast<const uint32_t *>(base + (size_t)((hoff + idx[c]) * 4u));
+    }
+    float x[8];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        float w[8];
+        trilinear_weights(w, tf[k][0], tf[k][1], tf[k][2]);
+        float ax = 0.0f, ay = 0.0f;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            ax = fma_mix_lo(raw[8 * k + c], w[c], ax);
+            ay = fma_mix_hi(raw[8 * k + c], w[c], ay);
+        }
+        x[2 * k] = ax;  // (lanes without a live sample decode whatever their valid-address loads returned; nothing of theirs is written)
+        x[2 * k + 1] = ay;
+    }
+    xa = v4f{ x[0], x[1], x[2], x[3] };
+    xb = v4f{ x[4], x[5], x[6], x[7] };
+    SCANERF_LOAD_GUARD();
+}
+
+// SHT: the split SH operands of the chunk's rays wait in LDS (render_t16.h s16_sh_row), one row per ray of the chunk's contiguous
+// ray range -- 32 rays for 4096 samples at S = 128 in the layouts 0 and 2 -- written once per chunk, read per tile; the host picks
+// SHT when that range fits (t16_sh_rows_fit), otherwise every tile evaluates the harmonics of its 16 samples' directions.
+constexpr int kShRows = (S16_BIAS - T16_FWD_BYTES) / 64 - 1;   // rows in the unused 12 KB of the image's footprint, less the row of zeros
+__host__ __device__ inline void t16_chunk_rays(int64_t e0, int64_t e1, int B, int S, int sm, int &r0, int &r1)
+{
+    if (sm == 0) { r0 = (int)(e0 / S); r1 = (int)(e1 / S); }
+    else if (sm == 2) { r0 = (int)((e0 >> 5) / S) * 32; r1 = (int)((e1 >> 5) / S) * 32 + 31; }
+    else { r0 = 0; r1 = B - 1; }
+    if (r1 > B - 1) r1 = B - 1;
+}
+inline bool t16_sh_rows_fit(int B, int S, int sm)
+{
+    constexpr int64_t kChunkSamples = 4096;
+    if (sm == 1) return B <= kShRows;
+    // the widest range any chunk can see: ceil(chunk / (samples per ray or ray block)) + 1 units
+    const int64_t per = sm == 0 ? S : (int64_t)S * 32, units = (kChunkSamples + per - 1) / per + 1;
+    return units * (sm == 0 ? 1 : 32) <= kShRows;
+}
+template <bool BG, bool SHT>
+__global__ void __launch_bounds__(kT16Threads, 4) k_pts_inference_t16(InferArgs a)
+{
+    // the t16s image at its own offsets (decode_tile_s16 reads the forward sub-images and the f32 tail; the transposed narrow
+    // sub-images between them are the backward's and are not staged: their 12 KB hold the chunk's SH rows)
+    __shared__ __attribute__((aligned(16))) char smem[S16_BYTES + 48 * 4 + 8];
+    char *const lds = smem;
+    float *const rscale = reinterpret_cast<float *>(smem + S16_BYTES);
+    uint32_t *const tileset = reinterpret_cast<uint32_t *>(smem + S16_BYTES + 48 * 4);
+    char *const shrows = smem + T16_FWD_BYTES;
+    const int lane = threadIdx.x & 63, c16 = lane & 15, q = lane >> 4, wave = threadIdx.x >> 6;
+    const int64_t total = (int64_t)a.B * a.S;
+    constexpr int kChunkSamples = kT16Waves * kT16WaveGroups * 64;
+    static_assert(kChunkSamples == 4096, "t16_sh_rows_fit");
+    const int64_t nchunks = (total + kChunkSamples - 1) / kChunkSamples;
+    for (int64_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+        if (threadIdx.x < 2) tileset[threadIdx.x] = 0;
+        __syncthreads();  // (also: the previous chunk's last tile step is complete)
+        const int64_t wbase = chunk * kChunkSamples + (int64_t)wave * (kT16WaveGroups * 64);
+        int r0 = 0;
+        if constexpr (SHT) {   // the chunk's rays' SH operands (visible after the barriers below, before any tile step)
+            int r1;
+            const int64_t e0 = chunk * kChunkSamples, e1 = e0 + kChunkSamples - 1 < total ? e0 + kChunkSamples - 1 : total - 1;
+            t16_chunk_rays(e0, e1, a.B, a.S, a.sm, r0, r1);
+            const int nr = r1 - r0 + 1 < kShRows ? r1 - r0 + 1 : kShRows;
+            for (int r = threadIdx.x; r <= nr; r += kT16Threads) {
+                if (r < nr) {
+                    const float d[3] = { a.rays_d[3 * (size_t)(r0 + r)], a.rays_d[3 * (size_t)(r0 + r) + 1], a.rays_d[3 * (size_t)(r0 + r) + 2] };
+                    s16_sh_row(shrows + 64 * r, d, 0.0f);
+                }
+            }
+            if (threadIdx.x < 16) reinterpret_cast<float *>(shrows + 64 * kShRows)[threadIdx.x] = 0.0f;   // the row of the lanes with q >= 2
+        }
+        {   // 1. the tiles this chunk's samples list
+            uint32_t mlo = 0, mhi = 0;
+            auto mark = [&](int t) {
+                if (t >= 0) {
+                    if (t < 32) mlo |= 1u << t;
+                    else mhi |= 1u << (t - 32);
+                }
+            };
+#pragma unroll
+            for (int g = 0; g < kT16WaveGroups; ++g) {
+                const int64_t e = wbase + g * 64 + lane;
+                if (e >= total) continue;
+                const uint32_t e32 = (uint32_t)e;
+                if (BG) {
+                    int ri, rs;
+                    pt_decompose(e32, (uint32_t)a.B, (uint32_t)a.S, a.sm, ri, rs);
+                    const int tb = a.block_idxs[ri * kMaxPtsBlocks + a.step];
+                    mark(tb);
+                    if (tb < 0) {  // no background tile at this blend step: the sample's outputs are zero (the caller need not clear them)
+                        a.out_alpha[e] = 0.0f;
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) {
+                            a.out_dif[3 * e + c] = 0.0f;
+                            a.out_spec[3 * e + c] = 0.0f;
+                        }
+                    }
+                } else {
+                    const uint2 raw = *reinterpret_cast<const uint2 *>(a.block_idxs + (size_t)e32 * kMaxPtsBlocks);
+                    const int s0 = (int16_t)(raw.x & 0xffffu), s1 = (int16_t)(raw.x >> 16), s2 = (int16_t)(raw.y & 0xffffu),
+                              s3 = (int16_t)(raw.y >> 16);
+                    mark(s0);  // the list stops at the first -1 (rendering_kernel.cu:499)
+                    if (s0 != -1) { mark(s1); if (s1 != -1) { mark(s2); if (s2 != -1) mark(s3); } }
+                }
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                mlo |= __shfl_xor(mlo, off, 64);
+                mhi |= __shfl_xor(mhi, off, 64);
+            }
+            if (lane == 0) {
+                if (mlo) atomicOr(&tileset[0], mlo);
+                if (mhi) atomicOr(&tileset[1], mhi);
+            }
+        }
+        __syncthreads();
+        uint64_t todo = (uint64_t)tileset[0] | ((uint64_t)tileset[1] << 32);
+        while (todo) {  // 2. one step per listed tile, ascending
+            const int b = __ffsll((long long)todo) - 1;
+            todo &= todo - 1;
+            __syncthreads();  // every wave is done with the previous image
+            {
+                const float4 *src = reinterpret_cast<const float4 *>(a.images + (size_t)b * WS_FLOATS + WS_S16);
+                float4 *dst = reinterpret_cast<float4 *>(lds);
+                for (int i = threadIdx.x; i < T16_FWD_BYTES / 16; i += kT16Threads) dst[i] = src[i];
+                for (int i = S16_BIAS / 16 + threadIdx.x; i < S16_BYTES / 16; i += kT16Threads) dst[i] = src[i];
+                if (threadIdx.x < 48) rscale[threadIdx.x] = (float)(a.res[(size_t)b * 48 + threadIdx.x] - 1);
+            }
+            __syncthreads();
+            float cb[3], sb[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                cb[c] = a.t.corners[3 * b + c];
+                sb[c] = a.t.sizes[3 * b + c];
+            }
+            const char *table = (const char *)a.tables + (size_t)b * 16 * a.T * 4;
+            int rso = 3 * (8 * (q & 1) + 2 * (q >> 1));
+            asm volatile("" : "+v"(rso));  // (opaque: one lane-dependent base register + immediates)
+            const float *rsq = rscale + rso;
+#pragma unroll 1
+            for (int g = 0; g < kT16WaveGroups; ++g) {
+                const int64_t base = wbase + g * 64;
+                if (base >= total) break;
+                const int64_t e = base + lane;
+                const bool in_range = e < total;
+                const uint32_t ec = (uint32_t)(in_range ? e : total - 1);
+                // (32-bit index arithmetic: the host keeps B*S below 2^31 for this kernel)
+                int i, s;
+                pt_decompose(ec, (uint32_t)a.B, (uint32_t)a.S, a.sm, i, s);
+                // does this sample list tile b?  (fg: the slot list stops at the first -1, rendering_kernel.cu:499)
+                int16_t slot[kMaxPtsBlocks] = { -1, -1, -1, -1 };
+                bool mine = false;
+                if (BG) {
+                    mine = in_range && a.block_idxs[i * kMaxPtsBlocks + a.step] == b;
+                } else if (in_range) {
+                    const uint2 raw = *reinterpret_cast<const uint2 *>(a.block_idxs + (size_t)ec * kMaxPtsBlocks);
+                    slot[0] = (int16_t)(raw.x & 0xffffu); slot[1] = (int16_t)(raw.x >> 16);
+                    slot[2] = (int16_t)(raw.y & 0xffffu); slot[3] = (int16_t)(raw.y >> 16);
+                    bool ended = false;
+#pragma unroll
+                    for (int k = 0; k < kMaxPtsBlocks; ++k) {
+                        ended |= slot[k] == -1;
+                        if (ended) slot[k] = -1;
+                        mine |= slot[k] == b;
+                    }
+                }
+                if (!__any(mine)) continue;  // wave-uniform
+                float o[3], d[3];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    o[k] = a.rays_o[3 * i + k];
+                    d[k] = a.rays_d[3 * i + k];
+                }
+                const float z = a.z_vals[ec];
+                float delta;
+                if (BG) delta = (s == a.S - 1) ? 10000000.0f : a.z_vals[ec + (uint32_t)pt_sample_stride(a.B, a.sm)] - z;   // :1045-1047: raw depth step
+                else delta = a.dists[ec] * sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);                               // :557
+                float p01[3], w_b = 0.0f, weight = 0.0f;
+                bool run = mine;
+                if (BG) {
+                    float qq[3];
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) qq[c] = 2.0f * ((o[c] + z * d[c]) - cb[c]) / sb[c] - 1.0f;
+                    const float linf = fmaxf(fabsf(qq[0]), fmaxf(fabsf(qq[1]), fabsf(qq[2])));
+                    const float ratio = (2.0f - 1.0f / linf) / linf;
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) p01[c] = (qq[c] * ratio + 2.0f) / 4.0f;
+                } else {
+                    // blend weights of every listed tile (occupied or not, :523-541), this tile's cell and position
+#pragma unroll
+                    for (int k = 0; k < kMaxPtsBlocks; ++k) {
+                        const int bk = slot[k];
+                        if (bk == -1) continue;
+                        float dis[3];
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) {
+                            const float sz = a.t.sizes[3 * bk + c];
+                            const float pt = ((o[c] + z * d[c]) - a.t.corners[3 * bk + c]) / sz;
+                            dis[c] = (0.5f - fabsf(pt - 0.5f)) * sz;
+                        }
+                        const float w = xz_weight(dis[0], dis[2]);
+                        weight += w;
+                        if (bk == b) w_b = w;
+                    }
+                    int loc[3];
+                    const int l2d[3] = { a.t.log2dim[3 * b], a.t.log2dim[3 * b + 1], a.t.log2dim[3 * b + 2] };
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        const float pt = ((o[c] + z * d[c]) - cb[c]) / sb[c];
+                        const int r = 1 << l2d[c];
+                        const int cc = (int)(pt * (float)r);
+                        loc[c] = cc < 0 ? 0 : (cc > r - 1 ? r - 1 : cc);
+                        p01[c] = pt / 2.0f + 0.25f;  // tile -> the middle half of the 2x box (:548)
+                    }
+                    if (mine) run = a.t.occ[a.t.grid_starts[b] + cell_offset(loc, l2d[1], l2d[2])] != 0;
+                }
+                const uint64_t rm = __ballot(run);
+                if (!rm) continue;  // wave-uniform: nothing of this group is occupied (the outputs stay as they are)
+                const float inv = weight > 0 ? 1.0f / weight : 1.0f;
+                int shrow = i - r0;   // this sample's ray's row (bytes); the host launches SHT only where every chunk's range fits
+                shrow = 64 * (shrow < kShRows ? shrow : kShRows);
+#pragma unroll 1
+                for (int t = 0; t < 4; ++t) {
+                    if (((rm >> (16 * t)) & 0xffffu) == 0) continue;  // wave-uniform
+                    const int src = 16 * t + c16;
+                    const float pt[3] = { __shfl(p01[0], src, 64), __shfl(p01[1], src, 64), __shfl(p01[2], src, 64) };
+                    const bool act = (rm >> src) & 1u;
+                    v4f xa, xb;
+                    encode4_t16(table, rsq, a.T, q, pt, xa, xb);
+                    SampleOut so;
+                    if constexpr (SHT) {
+                        const int row = __shfl(shrow, src, 64);
+                        so = decode_tile_s16<true>(lds, lane, xa, xb, nullptr, 0.0f, shrows + (q < 2 ? row + 16 * q : 64 * kShRows));
+                    } else {
+                        const float dd[3] = { __shfl(d[0], src, 64), __shfl(d[1], src, 64), __shfl(d[2], src, 64) };
+                        so = decode_tile_s16(lds, lane, xa, xb, dd, 0.0f);
+                    }
+                    const uint32_t es = (uint32_t)__shfl((int)ec, src, 64);
+                    const float dl = __shfl(delta, src, 64);
+                    if (BG) {
+                        if (act && q == 0) {
+                            const float pa = 1.0f - expf(-1.0f * so.sigma * dl);
+                            a.out_alpha[es] = pa;
+#pragma unroll
+                            for (int c = 0; c < 3; ++c) {
+                                a.out_dif[3 * (size_t)es + c] = pa * so.dif[c];
+                                a.out_spec[3 * (size_t)es + c] = pa * (so.tint[c] * so.spec[c]);
+                            }
+                        }
+                    } else {
+                        const float wb = __shfl(w_b, src, 64), iv = __shfl(inv, src, 64);
+                        if (act && q == 0) {
+                            const float pa = 1.0f - expf(-1.0f * so.sigma * dl);
+                            a.out_alpha[es] += (wb * pa) * iv;
+#pragma unroll
+                            for (int c = 0; c < 3; ++c) {
+                                a.out_dif[3 * (size_t)es + c] += (wb * pa * so.dif[c]) * iv;
+                                a.out_spec[3 * (size_t)es + c] += (wb * pa * (so.tint[c] * so.spec[c])) * iv;
+                            }
+                        }
+                    }
+                    SCANERF_STORE_GUARD();
+                }
+            }
+        }
+    }
+}
+
 // f32-MFMA single-pass kernel instead of the chunk-major one (SCANERF_RENDER_ARITH=f32; comparison / debugging)
 inline bool render_single_pass(int64_t total, int nb)
 {
@@ -832,11 +1140,46 @@ inline bool render_single_pass(int64_t total, int nb)
     return (e && e[0] == 'f') || total >= ((int64_t)1 << 31) || nb > 64;
 }
 
+// SCANERF_RENDER_ARITH=h3: the 32-sample-tile kernel at two waves per SIMD (k_pts_inference_chunks; comparison) instead of the
+// 16-sample-tile one at four (k_pts_inference_t16, default)
+
 // SCANERF_RENDER_PIPE=0: the group loop without the software pipeline (comparison; the two give the same bits)
 inline bool render_pipelined()
 {
     const char *e = getenv("SCANERF_RENDER_PIPE");
     return !(e && e[0] == '0');
+}
+
+inline bool render_t16_tiles()
+{
+    const char *e = getenv("SCANERF_RENDER_ARITH");
+    return !(e && (e[0] == 'h' || e[0] == 'w'));
+}
+// SCANERF_RENDER_ARITH=w3 / w4: the 32-sample-tile kernel without the software pipeline at three / four waves per SIMD (experiments)
+inline int render_h3_waves()
+{
+    const char *e = getenv("SCANERF_RENDER_ARITH");
+    return e && e[0] == 'w' ? atoi(e + 1) : 0;
+}
+template <bool BG>
+inline void launch_chunks(const InferArgs &a, int64_t tiles32, hipStream_t stream)
+{
+    auto nblocks = [&](int64_t per_chunk) {
+        const int64_t nchunks = (tiles32 + per_chunk - 1) / per_chunk;
+        return (int)(nchunks < kNumCU * 8 ? nchunks : kNumCU * 8);
+    };
+    const int w = render_h3_waves();
+    if (render_t16_tiles()) {
+        const char *e = getenv("SCANERF_RENDER_SH_ROWS");   // =0: every tile evaluates its samples' harmonics (comparison; the same bits)
+        if (t16_sh_rows_fit(a.B, a.S, a.sm) && !(e && e[0] == '0'))
+            hipLaunchKernelGGL((k_pts_inference_t16<BG, true>), dim3(nblocks(kChunkWaves * kChunkWaveGroups)), dim3(kT16Threads), 0, stream, a);
+        else
+            hipLaunchKernelGGL((k_pts_inference_t16<BG, false>), dim3(nblocks(kChunkWaves * kChunkWaveGroups)), dim3(kT16Threads), 0, stream, a);
+    }
+    else if (w == 3) hipLaunchKernelGGL((k_pts_inference_chunks<BG, false, 768, 3, RT_W3_GROUPS>), dim3(nblocks(12 * RT_W3_GROUPS)), dim3(768), 0, stream, a);
+    else if (w == 4) hipLaunchKernelGGL((k_pts_inference_chunks<BG, false, 512, 4, 16>), dim3(nblocks(8 * 16)), dim3(512), 0, stream, a);
+    else if (render_pipelined()) hipLaunchKernelGGL((k_pts_inference_chunks<BG, true>), dim3(nblocks(kChunkWaves * kChunkWaveGroups)), dim3(kChunkThreads), 0, stream, a);
+    else hipLaunchKernelGGL((k_pts_inference_chunks<BG, false>), dim3(nblocks(kChunkWaves * kChunkWaveGroups)), dim3(kChunkThreads), 0, stream, a);
 }
 
 // ---- rendering_kernel.cu:624-702: front-to-back accumulation, one wave per ray ------------------------
@@ -1210,10 +1553,7 @@ SCANERF_API int scanerf_pts_inference(const float *rays_o, const float *rays_d, 
     const hipError_t ce[3] = { hipMemsetAsync(out_dif, 0, n * 12, (hipStream_t)stream), hipMemsetAsync(out_spec, 0, n * 12, (hipStream_t)stream),
                                hipMemsetAsync(out_alpha, 0, n * 4, (hipStream_t)stream) };
     for (hipError_t e : ce) SCANERF_REQUIRE(e == hipSuccess, "pts_inference: clearing the outputs failed: %s", hipGetErrorString(e));
-    const int64_t per_chunk = kChunkWaves * kChunkWaveGroups, nchunks = (tiles32 + per_chunk - 1) / per_chunk;
-    blocks = (int)(nchunks < kNumCU * 8 ? nchunks : kNumCU * 8);
-    if (render_pipelined()) hipLaunchKernelGGL((k_pts_inference_chunks<false, true>), dim3(blocks), dim3(kChunkThreads), 0, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL((k_pts_inference_chunks<false, false>), dim3(blocks), dim3(kChunkThreads), 0, (hipStream_t)stream, a);
+    launch_chunks<false>(a, tiles32, (hipStream_t)stream);
     return check_launch("pts_inference");
 }
 
@@ -1243,10 +1583,7 @@ SCANERF_API int scanerf_bg_pts_inference_v2(const float *rays_o, const float *ra
         hipLaunchKernelGGL((k_pts_inference<true>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
         return check_launch("bg_pts_inference_v2");
     }
-    const int64_t per_chunk = kChunkWaves * kChunkWaveGroups, nchunks = (tiles32 + per_chunk - 1) / per_chunk;
-    blocks = (int)(nchunks < kNumCU * 8 ? nchunks : kNumCU * 8);
-    if (render_pipelined()) hipLaunchKernelGGL((k_pts_inference_chunks<true, true>), dim3(blocks), dim3(kChunkThreads), 0, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL((k_pts_inference_chunks<true, false>), dim3(blocks), dim3(kChunkThreads), 0, (hipStream_t)stream, a);
+    launch_chunks<true>(a, tiles32, (hipStream_t)stream);
     return check_launch("bg_pts_inference_v2");
 }
 

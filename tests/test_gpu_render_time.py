@@ -190,14 +190,13 @@ def test_render_loop_stage_by_stage():
     np.testing.assert_allclose(ps.cpu().numpy(), rs_, rtol=1e-4, atol=2e-6)
 
 
-def test_pipelined_group_loop_gives_the_bits_of_the_plain_one(monkeypatch):
-    """The chunk kernel's software pipeline (next group's corner loads in flight during a group's decoder) reorders memory
-    traffic only: fg (overlapping tiles, occupancy skips, ragged end) and bg outputs equal SCANERF_RENDER_PIPE=0 bit for bit."""
+def _inference_case(B=1000, S=72, seed=5):
+    """fg (overlapping tiles, occupancy skips, ragged end) and bg inputs of the two inference ops -> run() = their six outputs"""
     import scanerf_amd  # noqa
     from scanerf_amd import hashgrid as H
-    rng = np.random.default_rng(5)
+    rng = np.random.default_rng(seed)
     sc = _scene(rng)
-    B, S, nb = 1000, 72, 3
+    nb = 3
     o, d = _rays(rng, B)
     C, Z, OCC, ST, L2 = g(sc["corners"]), g(sc["sizes"]), g(sc["occ"]), g(sc["starts"]), g(sc["l2d"])
     RO, RD, TAB, PAR, RES = g(o), g(d), g(sc["tables"]), g(sc["params"]), g(sc["res"])
@@ -222,6 +221,14 @@ def test_pipelined_group_loop_gives_the_bits_of_the_plain_one(monkeypatch):
         H.bg_pts_inference_v2(RO, RD, zb, ob, 0, C, Z, RES, TAB, PAR, *bg)
         return [t.cpu().numpy() for t in fg + bg]
 
+    return run
+
+
+def test_pipelined_group_loop_gives_the_bits_of_the_plain_one(monkeypatch):
+    """The 32-sample-tile chunk kernel's software pipeline (next group's corner loads in flight during a group's decoder) reorders
+    memory traffic only: fg and bg outputs equal SCANERF_RENDER_PIPE=0 bit for bit."""
+    run = _inference_case()
+    monkeypatch.setenv("SCANERF_RENDER_ARITH", "h3")
     monkeypatch.delenv("SCANERF_RENDER_PIPE", raising=False)
     piped = run()
     monkeypatch.setenv("SCANERF_RENDER_PIPE", "0")
@@ -237,6 +244,34 @@ def test_pipelined_group_loop_gives_the_bits_of_the_plain_one(monkeypatch):
         scratch.fill_(rep)
         again = run()
         for a, b in zip(piped, again):
+            assert np.array_equal(a, b), f"launch {rep} differs"
+
+
+@pytest.mark.parametrize("B,S", [(1000, 72), (517, 128), (3000, 16)])
+def test_sixteen_sample_tile_kernel_against_the_32_sample_one(monkeypatch, B, S):
+    """k_pts_inference_t16 (default: 16-sample tiles, four waves per SIMD, the chunk's SH operands in LDS) against
+    k_pts_inference_chunks (SCANERF_RENDER_ARITH=h3): both evaluate the split-f16 decoder, with different k-step groupings, so
+    they agree to f32 rounding; the SH rows change where the harmonics are evaluated, not their bits (SCANERF_RENDER_SH_ROWS=0:
+    equal bit for bit; S = 16 makes a chunk's ray range too wide for the rows, so that case runs without them anyway); and the
+    default repeats launch after launch."""
+    run = _inference_case(B, S, seed=11)
+    monkeypatch.delenv("SCANERF_RENDER_ARITH", raising=False)
+    monkeypatch.delenv("SCANERF_RENDER_SH_ROWS", raising=False)
+    t16 = run()
+    monkeypatch.setenv("SCANERF_RENDER_SH_ROWS", "0")
+    norows = run()
+    monkeypatch.delenv("SCANERF_RENDER_SH_ROWS", raising=False)
+    monkeypatch.setenv("SCANERF_RENDER_ARITH", "h3")
+    h3 = run()
+    monkeypatch.delenv("SCANERF_RENDER_ARITH", raising=False)
+    assert t16[2].max() > 0.05 and t16[5].max() > 0.05
+    for a, b, c in zip(t16, norows, h3):
+        assert np.array_equal(a, b)
+        np.testing.assert_allclose(a, c, rtol=2e-5, atol=2e-6)
+    scratch = torch.empty(256 << 20, dtype=torch.uint8, device=DEV)
+    for rep in range(6):
+        scratch.fill_(rep)
+        for a, b in zip(t16, run()):
             assert np.array_equal(a, b), f"launch {rep} differs"
 
 
