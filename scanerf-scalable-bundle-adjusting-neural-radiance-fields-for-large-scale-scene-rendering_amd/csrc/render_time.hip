@@ -1169,6 +1169,7 @@ inline void launch_chunks(const InferArgs &a, int64_t tiles32, hipStream_t strea
         return (int)(nchunks < kNumCU * 8 ? nchunks : kNumCU * 8);
     };
     const int w = render_h3_waves();
+    (void)w;
     if (render_t16_tiles()) {
         const char *e = getenv("SCANERF_RENDER_SH_ROWS");   // =0: every tile evaluates its samples' harmonics (comparison; the same bits)
         if (t16_sh_rows_fit(a.B, a.S, a.sm) && !(e && e[0] == '0'))
@@ -1176,8 +1177,11 @@ inline void launch_chunks(const InferArgs &a, int64_t tiles32, hipStream_t strea
         else
             hipLaunchKernelGGL((k_pts_inference_t16<BG, false>), dim3(nblocks(kChunkWaves * kChunkWaveGroups)), dim3(kT16Threads), 0, stream, a);
     }
+#ifdef RT_H3_WAVES_EXPERIMENT   // (tools/build_variant.py render_time="-ffp-contract=off -DRT_H3_WAVES_EXPERIMENT": 23 / 70 spilled registers;
+    // 85.0 / 91.2 ms per frame against 89.8 for the pipelined form and 82.8 for the first 16-sample-tile kernel on the same box)
     else if (w == 3) hipLaunchKernelGGL((k_pts_inference_chunks<BG, false, 768, 3, RT_W3_GROUPS>), dim3(nblocks(12 * RT_W3_GROUPS)), dim3(768), 0, stream, a);
     else if (w == 4) hipLaunchKernelGGL((k_pts_inference_chunks<BG, false, 512, 4, 16>), dim3(nblocks(8 * 16)), dim3(512), 0, stream, a);
+#endif
     else if (render_pipelined()) hipLaunchKernelGGL((k_pts_inference_chunks<BG, true>), dim3(nblocks(kChunkWaves * kChunkWaveGroups)), dim3(kChunkThreads), 0, stream, a);
     else hipLaunchKernelGGL((k_pts_inference_chunks<BG, false>), dim3(nblocks(kChunkWaves * kChunkWaveGroups)), dim3(kChunkThreads), 0, stream, a);
 }
