@@ -13,7 +13,7 @@ for set in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY" \
            "SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS GRBM_GUI_ACTIVE SQ_CYCLES"; do
   i=$((i+1))
   timeout -k 10 240 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $out/p$i -- python3 $GRAFT_REPO_ROOT/bench.py --workload configs4-render --steps 2 --warmup 1 --no-cpu-baseline > $out/p$i.log 2>&1 || echo "pass $i failed"
-  python3 $GRAFT_REPO_ROOT/tools/summarize_prof.py pmc $out/p$i 2>/dev/null | grep "k_pts_inference_chunks" >> $out/summary.txt || true
+  python3 $GRAFT_REPO_ROOT/tools/summarize_prof.py pmc $out/p$i 2>/dev/null | grep "k_pts_inference" >> $out/summary.txt || true
   find $out/p$i -name "*.csv" -size +2M -delete
 done
 cat $out/summary.txt
