@@ -350,6 +350,16 @@ int scanerf_pts_inference(const float *rays_o, const float *rays_d, const float 
                           const int32_t *log2dim, const float *corners, const float *sizes, float *diffuse,
                           float *specular, float *alpha, int B, int S, int T, int nb,
                           int sample_major, scanerf_stream_t stream);                                            /* :467-621 */
+/* prepare_points + pts_inference as ONE launch (no reference counterpart; the renderer's own route): the slot lists are derived
+ * in the kernel from running_mask [B] and intersections [B,nb,2] at every use instead of being written and read back (8 bytes per
+ * sample, once per tile step).  Same values as the two ops in sequence.  Needs the 16-sample-tile kernel (the default) and
+ * nb <= 8; otherwise it fails and the caller runs the two ops. */
+int scanerf_pts_inference_tracing(const float *rays_o, const float *rays_d, const float *z_vals, const float *dists,
+                                  const uint8_t *running_mask, const float *intersections, const void *tables_f16,
+                                  const float *images, const int32_t *resolution, const uint8_t *occ,
+                                  const int64_t *grid_starts, const int32_t *log2dim, const float *corners,
+                                  const float *sizes, float *diffuse, float *specular, float *alpha, int B, int S, int T,
+                                  int nb, int sample_major, scanerf_stream_t stream);
 int scanerf_accumulate_color(const float *pts_diffuse, const float *pts_specular, const float *pts_alpha,
                              float *transparency, const float *z_vals, float *diffuse, float *specular,
                              float *depth, int B, int S, int sample_major, scanerf_stream_t stream);             /* :624-702 */

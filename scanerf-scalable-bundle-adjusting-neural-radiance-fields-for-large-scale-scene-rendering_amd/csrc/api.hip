@@ -16,4 +16,4 @@ void set_error(const char *fmt, ...)
 }  // namespace scanerf
 
 SCANERF_API const char *scanerf_last_error(void) { return scanerf::g_err; }
-SCANERF_API int scanerf_abi_version(void) { return 7; }
+SCANERF_API int scanerf_abi_version(void) { return 8; }

@@ -217,6 +217,8 @@ struct InferArgs {
     float *out_dif, *out_spec, *out_alpha;
     int T, B, S, step;
     int sm;   // layout of the per-sample arrays (pt_index)
+    const uint8_t *running;   // scanerf_pts_inference_tracing: the slot lists are derived in the kernel from the running mask,
+    const float *inter;       // the samples' depths and the rays' [nb] (near, far) intervals (= prepare_points, :391-449)
     int dbg;  // timing experiments only (-DSCANERF_RT_EXPERIMENTS, SCANERF_DEBUG_RT): 1 = no decoder, 2 = no table gathers
 };
 
@@ -883,6 +885,25 @@ __device__ __forceinline__ void encode4_t16(const char *table, const float *rs, 
     SCANERF_LOAD_GUARD();
 }
 
+// the slot list of one sample -- what prepare_points (rendering_kernel.cu:391-449) would have stored for it: the first
+// kMaxPtsBlocks tiles (ascending) whose (near, far) interval along the ray holds its depth; none for a stopped ray or an unset depth
+__device__ __forceinline__ uint2 tracing_slots(const InferArgs &a, int i, float z)
+{
+    int sl[kMaxPtsBlocks] = { -1, -1, -1, -1 };
+    if (a.running[i] && z != -1.0f) {
+        const float2 *ci = reinterpret_cast<const float2 *>(a.inter) + (size_t)i * a.t.nb;
+        int n = 0;
+        for (int b = 0; b < a.t.nb; ++b) {
+            const float2 bd = ci[b];
+            const bool hit = z >= bd.x && z <= bd.y;
+#pragma unroll
+            for (int k = 0; k < kMaxPtsBlocks; ++k) sl[k] = hit && n == k ? b : sl[k];
+            n += hit;
+        }
+    }
+    return make_uint2(((uint32_t)sl[0] & 0xffffu) | ((uint32_t)sl[1] << 16), ((uint32_t)sl[2] & 0xffffu) | ((uint32_t)sl[3] << 16));
+}
+
 // SHT: the split SH operands of the chunk's rays wait in LDS (render_t16.h s16_sh_row), one row per ray of the chunk's contiguous
 // ray range -- 32 rays for 4096 samples at S = 128 in the layouts 0 and 2 -- written once per chunk, read per tile; the host picks
 // SHT when that range fits (t16_sh_rows_fit), otherwise every tile evaluates the harmonics of its 16 samples' directions.
@@ -902,7 +923,8 @@ inline bool t16_sh_rows_fit(int B, int S, int sm)
     const int64_t per = sm == 0 ? S : (int64_t)S * 32, units = (kChunkSamples + per - 1) / per + 1;
     return units * (sm == 0 ? 1 : 32) <= kShRows;
 }
-template <bool BG, bool SHT>
+// TR (fg): no block_idxs array -- every use derives the sample's slot list (tracing_slots)
+template <bool BG, bool SHT, bool TR = false>
 __global__ void __launch_bounds__(kT16Threads, 4) k_pts_inference_t16(InferArgs a)
 {
     // the t16s image at its own offsets (decode_tile_s16 reads the forward sub-images and the f32 tail; the transposed narrow
@@ -962,11 +984,27 @@ __global__ void __launch_bounds__(kT16Threads, 4) k_pts_inference_t16(InferArgs 
                         }
                     }
                 } else {
-                    const uint2 raw = *reinterpret_cast<const uint2 *>(a.block_idxs + (size_t)e32 * kMaxPtsBlocks);
+                    uint2 raw;
+                    if constexpr (TR) {
+                        int ri, rs;
+                        pt_decompose(e32, (uint32_t)a.B, (uint32_t)a.S, a.sm, ri, rs);
+                        raw = tracing_slots(a, ri, a.z_vals[e]);
+                    } else {
+                        raw = *reinterpret_cast<const uint2 *>(a.block_idxs + (size_t)e32 * kMaxPtsBlocks);
+                    }
                     const int s0 = (int16_t)(raw.x & 0xffffu), s1 = (int16_t)(raw.x >> 16), s2 = (int16_t)(raw.y & 0xffffu),
                               s3 = (int16_t)(raw.y >> 16);
                     mark(s0);  // the list stops at the first -1 (rendering_kernel.cu:499)
                     if (s0 != -1) { mark(s1); if (s1 != -1) { mark(s2); if (s2 != -1) mark(s3); } }
+                    else {   // no tile: zeros (:569-571).  Every other sample is WRITTEN by the step of its first listed tile and added
+                             // to by the later ones, so the caller's arrays need no clearing pass (7.4 GB per launch at 1920x1080x128)
+                        a.out_alpha[e] = 0.0f;
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) {
+                            a.out_dif[3 * e + c] = 0.0f;
+                            a.out_spec[3 * e + c] = 0.0f;
+                        }
+                    }
                 }
             }
 #pragma unroll
@@ -1015,13 +1053,14 @@ __global__ void __launch_bounds__(kT16Threads, 4) k_pts_inference_t16(InferArgs 
                 pt_decompose(ec, (uint32_t)a.B, (uint32_t)a.S, a.sm, i, s);
                 // does this sample list tile b?  (fg: the slot list stops at the first -1, rendering_kernel.cu:499)
                 int16_t slot[kMaxPtsBlocks] = { -1, -1, -1, -1 };
-                bool mine = false;
+                bool mine = false, first = false;   // first: b is the sample's first listed tile (fg): this step writes, later ones add
                 if (BG) {
                     mine = in_range && a.block_idxs[i * kMaxPtsBlocks + a.step] == b;
                 } else if (in_range) {
-                    const uint2 raw = *reinterpret_cast<const uint2 *>(a.block_idxs + (size_t)ec * kMaxPtsBlocks);
+                    const uint2 raw = TR ? tracing_slots(a, i, a.z_vals[ec]) : *reinterpret_cast<const uint2 *>(a.block_idxs + (size_t)ec * kMaxPtsBlocks);
                     slot[0] = (int16_t)(raw.x & 0xffffu); slot[1] = (int16_t)(raw.x >> 16);
                     slot[2] = (int16_t)(raw.y & 0xffffu); slot[3] = (int16_t)(raw.y >> 16);
+                    first = slot[0] == b;
                     bool ended = false;
 #pragma unroll
                     for (int k = 0; k < kMaxPtsBlocks; ++k) {
@@ -1080,8 +1119,16 @@ __global__ void __launch_bounds__(kT16Threads, 4) k_pts_inference_t16(InferArgs 
                     }
                     if (mine) run = a.t.occ[a.t.grid_starts[b] + cell_offset(loc, l2d[1], l2d[2])] != 0;
                 }
+                if (!BG && first && !run) {   // listed but not occupied here: the sample's value starts at zero
+                    a.out_alpha[ec] = 0.0f;
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        a.out_dif[3 * (size_t)ec + c] = 0.0f;
+                        a.out_spec[3 * (size_t)ec + c] = 0.0f;
+                    }
+                }
                 const uint64_t rm = __ballot(run);
-                if (!rm) continue;  // wave-uniform: nothing of this group is occupied (the outputs stay as they are)
+                if (!rm) continue;  // wave-uniform: nothing of this group is occupied
                 const float inv = weight > 0 ? 1.0f / weight : 1.0f;
                 int shrow = i - r0;   // this sample's ray's row (bytes); the host launches SHT only where every chunk's range fits
                 shrow = 64 * (shrow < kShRows ? shrow : kShRows);
@@ -1115,13 +1162,15 @@ __global__ void __launch_bounds__(kT16Threads, 4) k_pts_inference_t16(InferArgs 
                         }
                     } else {
                         const float wb = __shfl(w_b, src, 64), iv = __shfl(inv, src, 64);
+                        const bool fst = __shfl((int)first, src, 64) != 0;
                         if (act && q == 0) {
                             const float pa = 1.0f - expf(-1.0f * so.sigma * dl);
-                            a.out_alpha[es] += (wb * pa) * iv;
+                            // (0 + x == x exactly: writing x where the cleared array held 0 gives the bits the += gave)
+                            a.out_alpha[es] = (fst ? 0.0f : a.out_alpha[es]) + (wb * pa) * iv;
 #pragma unroll
                             for (int c = 0; c < 3; ++c) {
-                                a.out_dif[3 * (size_t)es + c] += (wb * pa * so.dif[c]) * iv;
-                                a.out_spec[3 * (size_t)es + c] += (wb * pa * (so.tint[c] * so.spec[c])) * iv;
+                                a.out_dif[3 * (size_t)es + c] = (fst ? 0.0f : a.out_dif[3 * (size_t)es + c]) + (wb * pa * so.dif[c]) * iv;
+                                a.out_spec[3 * (size_t)es + c] = (fst ? 0.0f : a.out_spec[3 * (size_t)es + c]) + (wb * pa * (so.tint[c] * so.spec[c])) * iv;
                             }
                         }
                     }
@@ -1172,10 +1221,17 @@ inline void launch_chunks(const InferArgs &a, int64_t tiles32, hipStream_t strea
     (void)w;
     if (render_t16_tiles()) {
         const char *e = getenv("SCANERF_RENDER_SH_ROWS");   // =0: every tile evaluates its samples' harmonics (comparison; the same bits)
-        if (t16_sh_rows_fit(a.B, a.S, a.sm) && !(e && e[0] == '0'))
-            hipLaunchKernelGGL((k_pts_inference_t16<BG, true>), dim3(nblocks(kChunkWaves * kChunkWaveGroups)), dim3(kT16Threads), 0, stream, a);
-        else
-            hipLaunchKernelGGL((k_pts_inference_t16<BG, false>), dim3(nblocks(kChunkWaves * kChunkWaveGroups)), dim3(kT16Threads), 0, stream, a);
+        const bool rows = t16_sh_rows_fit(a.B, a.S, a.sm) && !(e && e[0] == '0');
+        const dim3 grid(nblocks(kChunkWaves * kChunkWaveGroups));
+        if constexpr (!BG) {
+            if (a.running) {   // scanerf_pts_inference_tracing
+                if (rows) hipLaunchKernelGGL((k_pts_inference_t16<false, true, true>), grid, dim3(kT16Threads), 0, stream, a);
+                else hipLaunchKernelGGL((k_pts_inference_t16<false, false, true>), grid, dim3(kT16Threads), 0, stream, a);
+                return;
+            }
+        }
+        if (rows) hipLaunchKernelGGL((k_pts_inference_t16<BG, true>), grid, dim3(kT16Threads), 0, stream, a);
+        else hipLaunchKernelGGL((k_pts_inference_t16<BG, false>), grid, dim3(kT16Threads), 0, stream, a);
     }
 #ifdef RT_H3_WAVES_EXPERIMENT   // (tools/build_variant.py render_time="-ffp-contract=off -DRT_H3_WAVES_EXPERIMENT": 23 / 70 spilled registers;
     // 85.0 / 91.2 ms per frame against 89.8 for the pipelined form and 82.8 for the first 16-sample-tile kernel on the same box)
@@ -1525,8 +1581,9 @@ SCANERF_API int scanerf_prepare_points(const float *z_vals, const uint8_t *runni
 }
 
 // images: [nb][scanerf_render_workspace_floats()] decoders packed by scanerf_pack_decoder with weight_feature == 1
-SCANERF_API int scanerf_pts_inference(const float *rays_o, const float *rays_d, const float *z_vals, const float *dists,
-                                      const int16_t *block_idxs, const void *tables_f16, const float *images,
+constexpr int kTracingMaxTiles = 8;
+static int pts_inference_impl(const float *rays_o, const float *rays_d, const float *z_vals, const float *dists,
+                              const int16_t *block_idxs, const uint8_t *running, const float *inter, const void *tables_f16, const float *images,
                                       const int32_t *res, const uint8_t *occ, const int64_t *grid_starts,
                                       const int32_t *log2dim, const float *corners, const float *sizes, float *out_dif,
                                       float *out_spec, float *out_alpha, int B, int S, int T, int nb, int sample_major,
@@ -1537,28 +1594,60 @@ SCANERF_API int scanerf_pts_inference(const float *rays_o, const float *rays_d, 
                     "pts_inference" ": sample_major=%d (0, 1, or 2 with B a multiple of 32; B=%d)", sample_major, B);
     SCANERF_REQUIRE(T >= 2 && (T & (T - 1)) == 0, "pts_inference: T=%d must be a power of two", T);
     if (B == 0) return 0;
-    RT_REQ(rays_o && rays_d && z_vals && dists && block_idxs && tables_f16 && images && res && occ && grid_starts && log2dim &&
+    RT_REQ(rays_o && rays_d && z_vals && dists && (block_idxs || (running && inter)) && tables_f16 && images && res && occ && grid_starts && log2dim &&
                corners && sizes && out_dif && out_spec && out_alpha, "pts_inference");
     InferArgs a;
     a.rays_o = rays_o; a.rays_d = rays_d; a.z_vals = z_vals; a.dists = dists; a.block_idxs = block_idxs;
     a.tables = tables_f16; a.images = images; a.res = res; a.t = make_tiles(corners, sizes, occ, grid_starts, log2dim, nb);
     a.out_dif = out_dif; a.out_spec = out_spec; a.out_alpha = out_alpha; a.T = T; a.B = B; a.S = S; a.step = 0;
-    a.sm = sample_major;
+    a.sm = sample_major; a.running = block_idxs ? nullptr : running; a.inter = inter;
     { const char *de = getenv("SCANERF_DEBUG_RT"); a.dbg = de ? atoi(de) : 0; }
     const int64_t tiles32 = ((int64_t)B * S + 31) / 32;
     int blocks = (int)((tiles32 + 3) / 4 < kNumCU * 4 ? (tiles32 + 3) / 4 : kNumCU * 4);
     SCANERF_REQUIRE(!sample_major || !render_single_pass((int64_t)B * S, nb), "pts_inference: sample-major arrays need the chunk kernel");
+    SCANERF_REQUIRE(block_idxs || (render_t16_tiles() && !render_single_pass((int64_t)B * S, nb) && nb <= kTracingMaxTiles),
+                    "pts_inference_tracing: needs the 16-sample-tile kernel and nb <= %d tiles (nb=%d); use prepare_points + pts_inference", kTracingMaxTiles, nb);
     if (render_single_pass((int64_t)B * S, nb)) {
         hipLaunchKernelGGL((k_pts_inference<false>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
         return check_launch("pts_inference");
     }
-    // every sample is written (zeros where no tile applies, :569-571); the tile passes add into it
-    const size_t n = (size_t)B * S;
-    const hipError_t ce[3] = { hipMemsetAsync(out_dif, 0, n * 12, (hipStream_t)stream), hipMemsetAsync(out_spec, 0, n * 12, (hipStream_t)stream),
-                               hipMemsetAsync(out_alpha, 0, n * 4, (hipStream_t)stream) };
-    for (hipError_t e : ce) SCANERF_REQUIRE(e == hipSuccess, "pts_inference: clearing the outputs failed: %s", hipGetErrorString(e));
+    // every sample is written (zeros where no tile applies, :569-571).  The 32-sample-tile kernels add into cleared arrays; the
+    // 16-sample-tile kernel writes each sample at its first listed tile's step and needs no clearing pass
+    const char *clr = getenv("SCANERF_RENDER_CLEAR");   // =1: clear anyway (timing comparison)
+    if (!render_t16_tiles() || (clr && clr[0] == '1')) {
+        const size_t n = (size_t)B * S;
+        const hipError_t ce[3] = { hipMemsetAsync(out_dif, 0, n * 12, (hipStream_t)stream), hipMemsetAsync(out_spec, 0, n * 12, (hipStream_t)stream),
+                                   hipMemsetAsync(out_alpha, 0, n * 4, (hipStream_t)stream) };
+        for (hipError_t e : ce) SCANERF_REQUIRE(e == hipSuccess, "pts_inference: clearing the outputs failed: %s", hipGetErrorString(e));
+    }
     launch_chunks<false>(a, tiles32, (hipStream_t)stream);
     return check_launch("pts_inference");
+}
+
+SCANERF_API int scanerf_pts_inference(const float *rays_o, const float *rays_d, const float *z_vals, const float *dists,
+                                      const int16_t *block_idxs, const void *tables_f16, const float *images,
+                                      const int32_t *res, const uint8_t *occ, const int64_t *grid_starts,
+                                      const int32_t *log2dim, const float *corners, const float *sizes, float *out_dif,
+                                      float *out_spec, float *out_alpha, int B, int S, int T, int nb, int sample_major,
+                                      scanerf_stream_t stream)
+{
+    SCANERF_REQUIRE(block_idxs, "pts_inference: null block_idxs");
+    return pts_inference_impl(rays_o, rays_d, z_vals, dists, block_idxs, nullptr, nullptr, tables_f16, images, res, occ, grid_starts, log2dim,
+                              corners, sizes, out_dif, out_spec, out_alpha, B, S, T, nb, sample_major, stream);
+}
+
+// prepare_points + pts_inference in one launch: the slot lists (8 bytes per sample written, then read once per tile step) never
+// exist; every use re-derives them from the ray's intervals (nb comparisons per sample, nb <= 8).  Same values as the two ops.
+SCANERF_API int scanerf_pts_inference_tracing(const float *rays_o, const float *rays_d, const float *z_vals, const float *dists,
+                                              const uint8_t *running_mask, const float *intersections, const void *tables_f16,
+                                              const float *images, const int32_t *res, const uint8_t *occ, const int64_t *grid_starts,
+                                              const int32_t *log2dim, const float *corners, const float *sizes, float *out_dif,
+                                              float *out_spec, float *out_alpha, int B, int S, int T, int nb, int sample_major,
+                                              scanerf_stream_t stream)
+{
+    SCANERF_REQUIRE(running_mask && intersections, "pts_inference_tracing: null running_mask / intersections");
+    return pts_inference_impl(rays_o, rays_d, z_vals, dists, nullptr, running_mask, intersections, tables_f16, images, res, occ, grid_starts,
+                              log2dim, corners, sizes, out_dif, out_spec, out_alpha, B, S, T, nb, sample_major, stream);
 }
 
 SCANERF_API int scanerf_bg_pts_inference_v2(const float *rays_o, const float *rays_d, const float *z_vals,
@@ -1578,7 +1667,7 @@ SCANERF_API int scanerf_bg_pts_inference_v2(const float *rays_o, const float *ra
     a.rays_o = rays_o; a.rays_d = rays_d; a.z_vals = z_vals; a.dists = nullptr; a.block_idxs = bg_idxs;
     a.tables = tables_f16; a.images = images; a.res = res; a.t = make_tiles(corners, sizes, nullptr, nullptr, nullptr, nb);
     a.out_dif = out_dif; a.out_spec = out_spec; a.out_alpha = out_alpha; a.T = T; a.B = B; a.S = S; a.step = step;
-    a.sm = sample_major;
+    a.sm = sample_major; a.running = nullptr; a.inter = nullptr;
     { const char *de = getenv("SCANERF_DEBUG_RT"); a.dbg = de ? atoi(de) : 0; }
     const int64_t tiles32 = ((int64_t)B * S + 31) / 32;
     int blocks = (int)((tiles32 + 3) / 4 < kNumCU * 4 ? (tiles32 + 3) / 4 : kNumCU * 4);

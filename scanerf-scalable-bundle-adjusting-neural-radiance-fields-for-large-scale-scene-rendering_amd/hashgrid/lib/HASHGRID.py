@@ -198,6 +198,31 @@ def pts_inference(rays_o, rays_d, z_vals, dists, block_idxs, features_tables, pa
         _I(int(sample_major)), stream()), "pts_inference")
 
 
+def tracing_fusable(nb):
+    """pts_inference_tracing serves up to 8 tiles on the 16-sample-tile kernel (include/scanerf_hip.h)"""
+    ar = os.environ.get("SCANERF_RENDER_ARITH", "")
+    return nb <= 8 and not ar[:1] in ("f", "h", "w")
+
+
+def pts_inference_tracing(rays_o, rays_d, z_vals, dists, running_mask, intersections, features_tables, params, resolution,
+                          grid_occupied, grid_starts, grid_log2dim, block_corners, block_sizes, diffuse, specular, alpha,
+                          sample_major=False):
+    """prepare_points + pts_inference in one launch (no reference counterpart): same outputs as
+    `prepare_points(z_vals, running_mask, intersections, block_idxs); pts_inference(..., block_idxs, ...)` without the
+    block_idxs array."""
+    img = _packed_images(params)
+    check(lib().scanerf_pts_inference_tracing(
+        dev_ptr(rays_o, _f32, "rays_o"), dev_ptr(rays_d, _f32, "rays_d"), dev_ptr(z_vals, _f32, "z_vals"),
+        dev_ptr(dists, _f32, "dists"), dev_ptr(running_mask, _bool, "running_mask"), dev_ptr(intersections, _f32, "intersections"),
+        dev_ptr(features_tables, torch.float16, "features_tables"), dev_ptr(img, _f32, "images"),
+        dev_ptr(resolution, _i32, "resolution"), dev_ptr(grid_occupied, _bool, "grid_occupied"),
+        dev_ptr(grid_starts, _i64, "grid_starts"), dev_ptr(grid_log2dim, _i32, "grid_log2dim"),
+        dev_ptr(block_corners, _f32, "block_corners"), dev_ptr(block_sizes, _f32, "block_sizes"),
+        dev_ptr(diffuse, _f32, "diffuse"), dev_ptr(specular, _f32, "specular"), dev_ptr(alpha, _f32, "alpha"),
+        _I(rays_d.shape[0]), _S(z_vals, sample_major), _I(features_tables.shape[2]), _I(block_corners.shape[0]),
+        _I(int(sample_major)), stream()), "pts_inference_tracing")
+
+
 def accumulate_color(pts_diffuse, pts_specular, pts_alpha, transparency, z_vals, diffuse, specular, depth, sample_major=False):
     check(lib().scanerf_accumulate_color(
         dev_ptr(pts_diffuse, _f32, "pts_diffuse"), dev_ptr(pts_specular, _f32, "pts_specular"),

@@ -14,7 +14,8 @@ import torch
 from . import network
 from .cuda import compute_ray_forward
 from .hashgrid import (accumulate_color, bg_pts_inference_v2, inverse_z_sampling, prepare_points, process_occupied_grid,
-                       pts_inference, ray_block_intersection, sample_points, sort_tracing_blocks, update_outgoing_bidx)
+                       pts_inference, pts_inference_tracing, ray_block_intersection, sample_points, sort_tracing_blocks,
+                       tracing_fusable, update_outgoing_bidx)
 
 
 def write_feature_npz(path, features, occupied_grid, min_bbox, bbox_size, log2dim, resolution):
@@ -101,8 +102,9 @@ class TileSetRenderer:
         n_rays = rays_o.shape[0]
         # the single-pass comparison kernel (SCANERF_RENDER_ARITH=f32; also what > 64 tiles or >= 2^31 samples fall back to)
         # reads the reference's [B,S] arrays only
-        if (os.environ.get("SCANERF_RENDER_ARITH", "").startswith("f") or nb > 64
-                or (n_rays + 31) * max(num_sample, num_bg_sample) >= 2 ** 31):
+        single_pass = (os.environ.get("SCANERF_RENDER_ARITH", "").startswith("f") or nb > 64
+                       or (n_rays + 31) * max(num_sample, num_bg_sample) >= 2 ** 31)
+        if single_pass:
             lay = 0
         if lay == 2 and n_rays % 32:  # pad with copies of the last ray
             pad = 32 - n_rays % 32
@@ -122,19 +124,49 @@ class TileSetRenderer:
         pd = torch.empty(shp(num_sample, 3), device=dev)
         ps = torch.empty(shp(num_sample, 3), device=dev)
         pa = torch.empty(shp(num_sample, 1), device=dev)
+
+        fuse_slots = tracing_fusable(nb) and not single_pass and os.environ.get("SCANERF_RENDER_FUSE_SLOTS", "1") != "0"
+
+        def fg_pass(ro, rd, it, tb, tidx, zst, tr, df, sp, dp, running, pd, ps, pa):
+            """One tracing pass (rendering.py:356-420) over the rays given: per-ray state tidx / zst / tr / df / sp / dp updated in place."""
+            n = ro.shape[0]
+            shp_ = {0: lambda S, *tail: (n, S, *tail), 1: lambda S, *tail: (S, n, *tail), 2: lambda S, *tail: (n // 32, S, 32, *tail)}[lay]
+            z = torch.full(shp_(num_sample), -1.0, device=dev)
+            dd = torch.full(shp_(num_sample), -1.0, device=dev)
+            sample_points(ro, rd, self.block_corner, self.block_size, self.fake_occupied_grid, self.grid_starts,
+                          self.grid_log2dim, tb, it, tidx, zst, z, dd, sample_major=sm)
+            if fuse_slots:   # the slot lists never exist: the inference kernel derives them (pts_inference_tracing)
+                pts_inference_tracing(ro, rd, z, dd, running, it, self.feature_tables, self.packed, self.resolution, self.occupied_grid,
+                                      self.grid_starts, self.grid_log2dim, self.block_corner, self.block_size, pd, ps, pa, sample_major=sm)
+            else:
+                bi = torch.full(shp_(num_sample, 4), -1, dtype=torch.int16, device=dev)
+                prepare_points(z, running, it, bi, sample_major=sm)
+                pts_inference(ro, rd, z, dd, bi, self.feature_tables, self.packed, self.resolution, self.occupied_grid,
+                              self.grid_starts, self.grid_log2dim, self.block_corner, self.block_size, pd, ps, pa, sample_major=sm)
+            accumulate_color(pd, ps, pa, tr, z, df, sp, dp, sample_major=sm)
+
         for _ in range(max_tracing):
             running = ((tracing_idx < max_tracing) & (transp > 1e-5))[:, 0].contiguous()
-            if running.sum() == 0:
+            n_run = int(running.sum())
+            if n_run == 0:
                 break
-            z = torch.full(shp(num_sample), -1.0, device=dev)
-            dd = torch.full(shp(num_sample), -1.0, device=dev)
-            sample_points(rays_o, rays_d, self.block_corner, self.block_size, self.fake_occupied_grid, self.grid_starts,
-                          self.grid_log2dim, tracing_blocks, inter, tracing_idx, z_start, z, dd, sample_major=sm)
-            bi = torch.full(shp(num_sample, 4), -1, dtype=torch.int16, device=dev)
-            prepare_points(z, running, inter, bi, sample_major=sm)
-            pts_inference(rays_o, rays_d, z, dd, bi, self.feature_tables, self.packed, self.resolution, self.occupied_grid,
-                          self.grid_starts, self.grid_log2dim, self.block_corner, self.block_size, pd, ps, pa, sample_major=sm)
-            accumulate_color(pd, ps, pa, transp, z, dif, spec, depth, sample_major=sm)
+            if n_run * 2 > B:
+                fg_pass(rays_o, rays_d, inter, tracing_blocks, tracing_idx, z_start, transp, dif, spec, depth, running, pd, ps, pa)
+                continue
+            # Few rays left (later passes: most have left the tiles or are saturated): the pass runs on those rays alone -- every op
+            # is per ray, so each running ray gets the values the full-size pass gives it; the others' colours are untouched either
+            # way, and their tracing state (which the full-size pass advances) is never read again: a ray that stopped stays stopped
+            # (the full-size pass costs its fills, slot lists and accumulation for every ray: ~4 ms at 1920x1080 for nothing)
+            idx = running.nonzero()[:, 0]
+            if lay == 2 and n_run % 32:
+                idx = torch.cat([idx, idx[-1:].expand(32 - n_run % 32)])
+            n = idx.shape[0]
+            sub = [t[idx].contiguous() for t in (rays_o, rays_d, inter, tracing_blocks, tracing_idx, z_start, transp, dif, spec, depth)]
+            shp_n = {0: lambda S, *tail: (n, S, *tail), 1: lambda S, *tail: (S, n, *tail), 2: lambda S, *tail: (n // 32, S, 32, *tail)}[lay]
+            fg_pass(*sub, torch.ones(n, dtype=torch.bool, device=dev), torch.empty(shp_n(num_sample, 3), device=dev),
+                    torch.empty(shp_n(num_sample, 3), device=dev), torch.empty(shp_n(num_sample, 1), device=dev))
+            for full, part in zip((tracing_idx, z_start, transp, dif, spec, depth), sub[4:]):
+                full[idx] = part   # (the padding repeats the last ray: equal values land on it twice)
         # blended backgrounds of the exit tile(s)
         bg_b = torch.full((B, 4), -1, dtype=torch.int16, device=dev)
         bg_w = torch.zeros(B, 4, device=dev)

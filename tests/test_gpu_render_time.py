@@ -215,12 +215,14 @@ def _inference_case(B=1000, S=72, seed=5):
     H.inverse_z_sampling(inter, ob[:, 0].contiguous(), zb, 1e6)
 
     def run():
-        fg = [torch.zeros(B, S, 3, device=DEV), torch.zeros(B, S, 3, device=DEV), torch.zeros(B, S, 1, device=DEV)]
+        # (both ops write EVERY sample -- zeros where no tile applies, rendering_kernel.cu:569-571 -- whatever the arrays held)
+        fg = [torch.full((B, S, 3), 7.0, device=DEV), torch.full((B, S, 3), 7.0, device=DEV), torch.full((B, S, 1), 7.0, device=DEV)]
         H.pts_inference(RO, RD, z, dd, bi, TAB, PAR, RES, OCC, ST, L2, C, Z, *fg)
         bg = [torch.full((B, S, 3), 7.0, device=DEV), torch.full((B, S, 3), 7.0, device=DEV), torch.full((B, S, 1), 7.0, device=DEV)]
         H.bg_pts_inference_v2(RO, RD, zb, ob, 0, C, Z, RES, TAB, PAR, *bg)
         return [t.cpu().numpy() for t in fg + bg]
 
+    run.ctx = dict(H=H, RO=RO, RD=RD, z=z, dd=dd, bi=bi, inter=inter, TAB=TAB, PAR=PAR, RES=RES, OCC=OCC, ST=ST, L2=L2, C=C, Z=Z, B=B, S=S)
     return run
 
 
@@ -245,6 +247,26 @@ def test_pipelined_group_loop_gives_the_bits_of_the_plain_one(monkeypatch):
         again = run()
         for a, b in zip(piped, again):
             assert np.array_equal(a, b), f"launch {rep} differs"
+
+
+@pytest.mark.parametrize("B,S", [(1000, 72), (3000, 16)])
+def test_inference_that_derives_its_slot_lists_equals_prepare_points_then_pts_inference(B, S):
+    """pts_inference_tracing (one launch, no block_idxs array) against prepare_points + pts_inference: bit for bit, with a third
+    of the rays stopped; and every sample written whatever the arrays held."""
+    c = _inference_case(B, S, seed=13).ctx
+    H = c["H"]
+    running = (torch.arange(B, device=DEV) % 3 != 1).contiguous()
+    bi = torch.full((B, S, 4), -1, dtype=torch.int16, device=DEV)
+    H.prepare_points(c["z"], running, c["inter"], bi)
+    tail = (c["TAB"], c["PAR"], c["RES"], c["OCC"], c["ST"], c["L2"], c["C"], c["Z"])
+    two = [torch.full((B, S, 3), 7.0, device=DEV), torch.full((B, S, 3), 7.0, device=DEV), torch.full((B, S, 1), 7.0, device=DEV)]
+    H.pts_inference(c["RO"], c["RD"], c["z"], c["dd"], bi, *tail, *two)
+    one = [torch.full((B, S, 3), -3.0, device=DEV), torch.full((B, S, 3), -3.0, device=DEV), torch.full((B, S, 1), -3.0, device=DEV)]
+    H.pts_inference_tracing(c["RO"], c["RD"], c["z"], c["dd"], running, c["inter"], *tail, *one)
+    assert float(two[2].max()) > 0.05 and float((two[2][running] > 0).float().mean()) > 0.01
+    assert float(two[2][~running].abs().max()) == 0.0
+    for a, b in zip(one, two):
+        assert torch.equal(a, b)
 
 
 @pytest.mark.parametrize("B,S", [(1000, 72), (517, 128), (3000, 16)])
