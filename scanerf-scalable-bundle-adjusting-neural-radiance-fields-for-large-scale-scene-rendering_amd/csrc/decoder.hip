@@ -7,9 +7,10 @@
 // a caller that keeps the reference's own op-by-op structure got torch's graph instead (~40 kernels over [N,64] intermediates:
 // 140 of the 155 ms of such a step at 65 536 x 128 samples).  Here the same arithmetic as the fused kernels' -- split-f16
 // operands, three products per term, f32 accumulate: f32-equivalent (render_h3.h) -- runs per SAMPLE:
-//   forward   k_decoder_fwd_s16: 16-sample tiles on v_mfma_f32_16x16x32_f16, the t16s image of render_t16.h, four waves per
-//             SIMD (k_decoder_fwd_h3, the 32-sample-tile form at two waves per SIMD, stays for comparison); per-sample view
-//             directions (the SH part of Directional_MLP.mlp.0 is one more k-step per tile instead of a per-ray constant);
+//   forward   k_decoder_fwd_h3:  32-sample tiles on v_mfma_f32_32x32x16_f16, the h3 image of render_h3.h, 8 waves per
+//             workgroup, two waves per SIMD (k_decoder_fwd_s16, 16-sample tiles at four waves per SIMD, for comparison);
+//             per-sample view directions (the SH part of Directional_MLP.mlp.0 is one more k-step per tile instead of a
+//             per-ray constant);
 //   backward  k_decoder_bwd_s16: the t16s structure of render_bwd_t16.hip (16-sample tiles on v_mfma_f32_16x16x32_f16,
 //             8 waves = two per SIMD, weight-gradient blocks owned by waves and summed over the 8 waves' tiles through LDS
 //             staging, the workgroup's power-of-two gradient scale) with the compositing adjoint replaced by the incoming
@@ -88,19 +89,22 @@ __global__ void __launch_bounds__(kFwdThreads, 2) k_decoder_fwd_h3(DecArgs a)
     }
 }
 
-// ---- forward on 16-sample tiles (default; SCANERF_DECODER_FWD=h3 selects the kernel above): decode_tile_s16 (render_t16.h) --
-// v_mfma_f32_16x16x32_f16 on the t16s image, lane (c, q) = sample c, quarter q: the forward recompute of the backward kernel
-// below, so the op's backward differentiates exactly the values its forward returned.  94 registers -> four waves per SIMD,
-// where the kernel is bound by vector-instruction issue (profiles/r05_decoder_fwd_counters.txt): 1.07 -> 0.97 ms at 8.4e6
-// samples against the 32-sample-tile kernel.  The k-step grouping differs from that kernel's (32 units per MFMA instead of 16),
-// so the f32 sums round differently in the last bits; both are the split-f16 evaluation.
+// ---- forward on 16-sample tiles (SCANERF_DECODER_FWD=s16; comparison): decode_tile_s16 (render_t16.h) -- v_mfma_f32_16x16x32_f16
+// on the t16s image, lane (c, q) = sample c, quarter q: the forward recompute of the backward kernel below, and the decoder of the
+// render-time kernel k_pts_inference_t16.  94 registers -> four waves per SIMD, where the kernel is bound by vector-instruction
+// issue (profiles/r05_decoder_fwd_counters.txt).  Measured per launch at 8.4e6 samples (rocprofv3 kernel trace, same box):
+//   one launch between other kernels (the op inside a training step):  32-sample tiles 0.92 ms, 16-sample tiles 1.02 ms
+//   13 launches back to back (sustained matrix load, lower clock):     32-sample tiles 1.22 ms, 16-sample tiles 1.13 ms
+// so the op keeps the 32-sample-tile kernel and the long-running render-time kernels use this decoder.  The k-step grouping
+// differs between the two (32 units per MFMA instead of 16): the f32 sums round differently in the last bits; both are the
+// split-f16 evaluation.
 constexpr int kFwd16Threads = 512;
 #ifndef FWD16_WAVES
 #define FWD16_WAVES 2
 #endif
 __global__ void __launch_bounds__(kFwd16Threads, FWD16_WAVES) k_decoder_fwd_s16(DecArgs a)
 {
-    extern __shared__ __attribute__((aligned(16))) char lds16[];
+    __shared__ __attribute__((aligned(16))) char lds16[S16_BYTES];
     {
         const float4 *src = reinterpret_cast<const float4 *>(a.packed + WS_S16);
         float4 *dst = reinterpret_cast<float4 *>(lds16);
@@ -708,19 +712,17 @@ SCANERF_API int scanerf_decoder_forward(const float *feats, int ld_feats, const 
     a.feats = feats; a.ld_feats = ld_feats; a.dirs = dirs; a.ld_dirs = ld_dirs; a.packed = workspace; a.N = N;
     a.sigma = sigma; a.dif = diffuse; a.spec = specular; a.tint = tint;
     const char *e = getenv("SCANERF_DECODER_FWD");
-    if (e && e[0] == 'h') {   // comparison: 32-sample tiles at two waves per SIMD (202 registers)
-        const long long ntiles = (N + 31) >> 5;
-        long long blocks = (ntiles + 7) / 8;
-        if (blocks > 2 * kNumCU) blocks = 2 * kNumCU;
-        hipLaunchKernelGGL(k_decoder_fwd_h3, dim3((int)blocks), dim3(kFwdThreads), 0, (hipStream_t)stream, a);
-        return check_launch("decoder_forward(h3)");
+    if (e && e[0] == 's') {   // 16-sample tiles at four waves per SIMD (see k_decoder_fwd_s16)
+        const long long nt16 = (N + 15) >> 4;
+        long long b16 = (nt16 + 7) / 8;
+        if (b16 > 2 * kNumCU) b16 = 2 * kNumCU;   // two resident 512-thread workgroups per CU (77 KB of LDS each), persistent
+        hipLaunchKernelGGL(k_decoder_fwd_s16, dim3((int)b16), dim3(kFwd16Threads), 0, (hipStream_t)stream, a);
+        return check_launch("decoder_forward(s16)");
     }
-    const long long nt16 = (N + 15) >> 4;
-    long long b16 = (nt16 + 7) / 8;
-    if (b16 > 2 * kNumCU) b16 = 2 * kNumCU;   // two resident 512-thread workgroups per CU (77 KB of LDS each), persistent
-    hipError_t er = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_decoder_fwd_s16), hipFuncAttributeMaxDynamicSharedMemorySize, (int)S16_BYTES);
-    SCANERF_REQUIRE(er == hipSuccess, "decoder_forward: cannot reserve %d B of LDS: %s", (int)S16_BYTES, hipGetErrorString(er));
-    hipLaunchKernelGGL(k_decoder_fwd_s16, dim3((int)b16), dim3(kFwd16Threads), S16_BYTES, (hipStream_t)stream, a);
+    const long long ntiles = (N + 31) >> 5;
+    long long blocks = (ntiles + 7) / 8;
+    if (blocks > 2 * kNumCU) blocks = 2 * kNumCU;
+    hipLaunchKernelGGL(k_decoder_fwd_h3, dim3((int)blocks), dim3(kFwdThreads), 0, (hipStream_t)stream, a);
     return check_launch("decoder_forward");
 }
 

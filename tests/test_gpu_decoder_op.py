@@ -112,6 +112,21 @@ def test_decoder_op_is_bit_reproducible_and_covers_many_workgroups():
     assert _rel_l2(got["x"], ref["x"]) < 5e-5
 
 
+def test_decoder_forward_on_16_sample_tiles_agrees_with_the_default_and_repeats(monkeypatch):
+    """SCANERF_DECODER_FWD=s16 (k_decoder_fwd_s16: the render-time kernel's decoder as a kernel of its own) against the default
+    32-sample-tile forward: both are the split-f16 evaluation with different k-step groupings -> equal to f32 rounding; ragged
+    tail; launch after launch the same bits."""
+    m, x, wf, _ = _case((1 << 17) + 13, 40000, 5)
+    with torch.no_grad():
+        ref = m(x, weight_feature=wf)
+        monkeypatch.setenv("SCANERF_DECODER_FWD", "s16")
+        a = m(x, weight_feature=wf)
+        b = m(x, weight_feature=wf)
+    for k in ("sigma", "diffuse", "specular", "tint"):
+        assert torch.equal(a[k], b[k]), k
+        np.testing.assert_allclose(a[k].cpu().numpy(), ref[k].cpu().numpy(), rtol=2e-5, atol=2e-6, err_msg=k)
+
+
 def test_decoder_op_rejects_cpu_tensors_and_wrong_shapes():
     import scanerf_amd  # noqa
     from scanerf_amd import decoder_op, network
