@@ -145,8 +145,13 @@ class TileSetRenderer:
                               self.grid_starts, self.grid_log2dim, self.block_corner, self.block_size, pd, ps, pa, sample_major=sm)
             accumulate_color(pd, ps, pa, tr, z, df, sp, dp, sample_major=sm)
 
+        # tiles each ray's path meets (the sorted list ends at the first miss): a ray whose tracing index has reached its own count has
+        # nothing left to sample -- sample_points leaves it at once (`bound.x == kInf`), so dropping it from `running` here (the
+        # reference's mask compares with the view's maximum, rendering.py:356) changes no value and lets the later passes run on
+        # the few rays that do cross a second tile
+        n_hit = (inter[..., 0] != 1e7).sum(dim=-1, keepdim=True).to(torch.int32).clamp_(max=max_tracing)
         for _ in range(max_tracing):
-            running = ((tracing_idx < max_tracing) & (transp > 1e-5))[:, 0].contiguous()
+            running = ((tracing_idx < n_hit) & (transp > 1e-5))[:, 0].contiguous()
             n_run = int(running.sum())
             if n_run == 0:
                 break
