@@ -1213,9 +1213,15 @@ inline int render_h3_waves()
 template <bool BG>
 inline void launch_chunks(const InferArgs &a, int64_t tiles32, hipStream_t stream)
 {
+    // One workgroup per chunk (up to 2^20).  A foreground chunk's cost is anything between nothing (rays that miss) and 4096 decoded
+    // samples; with 8 workgroups per CU walking ~30 chunks each at a fixed stride the busiest workgroup had ~1.6x the mean share
+    // of live chunks and the launch waited for it.  The dispatcher hands a finished workgroup's slot to the next chunk instead
+    // (same box, ms per frame: 8 per CU 71.2, 64 per CU 69.2, one per chunk 67.5; the background launch gains its tail too).
+    const char *cap_env = getenv("SCANERF_RENDER_GRID_CAP");   // workgroups per CU (comparison)
+    const int64_t cap = cap_env ? (int64_t)kNumCU * atoi(cap_env) : (int64_t)1 << 20;
     auto nblocks = [&](int64_t per_chunk) {
         const int64_t nchunks = (tiles32 + per_chunk - 1) / per_chunk;
-        return (int)(nchunks < kNumCU * 8 ? nchunks : kNumCU * 8);
+        return (int)(nchunks < cap ? nchunks : cap);
     };
     const int w = render_h3_waves();
     (void)w;
