@@ -155,10 +155,11 @@ class TileSetRenderer:
             n_run = int(running.sum())
             if n_run == 0:
                 break
-            if n_run * 2 > B:
+            if n_run * 10 > B * int(os.environ.get("SCANERF_RENDER_COMPACT_TENTHS", "9")):   # (compaction costs ~0.1 ms of gathers)
                 fg_pass(rays_o, rays_d, inter, tracing_blocks, tracing_idx, z_start, transp, dif, spec, depth, running, pd, ps, pa)
                 continue
-            # Few rays left (later passes: most have left the tiles or are saturated): the pass runs on those rays alone -- every op
+            # Not every ray runs (rays that miss every tile; later passes: most have left the tiles or are saturated): the pass runs
+            # on the running rays alone -- every op
             # is per ray, so each running ray gets the values the full-size pass gives it; the others' colours are untouched either
             # way, and their tracing state (which the full-size pass advances) is never read again: a ray that stopped stays stopped
             # (the full-size pass costs its fills, slot lists and accumulation for every ray: ~4 ms at 1920x1080 for nothing)
