@@ -1336,10 +1336,30 @@ __global__ void __launch_bounds__(256) k_accumulate_color_sm(const float *__rest
 __global__ void __launch_bounds__(256) k_render_inverse_z(const float *__restrict__ inter, const int16_t *__restrict__ related,
                                                           int S, int nb, float range, float *__restrict__ z_vals, int B, int sm)
 {
-    const int64_t total = (int64_t)B * S;
-    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
-        int i, k;
-        pt_decompose((uint32_t)e, (uint32_t)B, (uint32_t)S, sm, i, k);
+    // a thread keeps ONE ray and walks its depths: the ray's constants (three divisions, the interval load) once instead of per
+    // sample, no index division.  Threads of a wave hold neighbouring rays (layouts 1 and 2: one depth of 64 / 32 rays is
+    // contiguous) or, for the reference's [B,S], the 64 lanes of a wave share a ray and take every 64th depth.
+    if (sm == 0) {
+        const int lane = threadIdx.x & 63;
+        const int64_t nw = (int64_t)gridDim.x * (blockDim.x >> 6);
+        for (int64_t i = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); i < B; i += nw) {
+            const int b = related[i];
+            if (b == -1) continue;
+            const float2 bd = reinterpret_cast<const float2 *>(inter)[(size_t)i * nb + b];
+            if (bd.x == kInf) continue;
+            const float near_ = bd.y, far_ = near_ + range;
+            const float inv_near = 1.0f / near_, inv_far = 1.0f / far_, inv_bound = inv_far - inv_near;
+            const float stp = 1.0f / (float)(S - 1);
+            for (int k = lane; k < S; k += 64) z_vals[(size_t)i * S + k] = 1.0f / (stp * (float)k * inv_bound + inv_near);
+        }
+        return;
+    }
+    // layouts 1 / 2: thread = (ray i, depth phase); a ray's depths k = phase, phase + P, ...
+    const int P = 4;   // depth phases per ray: 4 x B threads' worth of parallelism
+    const int64_t total = (int64_t)B * P;
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        // consecutive threads = consecutive rays of one 32-ray block (layout 2) / of the batch (layout 1); the phase is the slow index
+        const int i = (int)(t % B), ph = (int)(t / B);
         const int b = related[i];
         if (b == -1) continue;
         const float2 bd = reinterpret_cast<const float2 *>(inter)[(size_t)i * nb + b];
@@ -1347,7 +1367,9 @@ __global__ void __launch_bounds__(256) k_render_inverse_z(const float *__restric
         const float near_ = bd.y, far_ = near_ + range;
         const float inv_near = 1.0f / near_, inv_far = 1.0f / far_, inv_bound = inv_far - inv_near;
         const float stp = 1.0f / (float)(S - 1);
-        z_vals[e] = 1.0f / (stp * (float)k * inv_bound + inv_near);
+        float *col = z_vals + pt_index(i, 0, B, S, sm);
+        const size_t ks = pt_sample_stride(B, sm);
+        for (int k = ph; k < S; k += P) col[(size_t)k * ks] = 1.0f / (stp * (float)k * inv_bound + inv_near);
     }
 }
 
@@ -1713,8 +1735,8 @@ SCANERF_API int scanerf_render_inverse_z_sampling(const float *inter, const int1
                     "inverse_z_sampling" ": sample_major=%d (0, 1, or 2 with B a multiple of 32; B=%d)", sample_major, B);
     if (B == 0) return 0;
     RT_REQ(inter && related_bidx && z_vals, "inverse_z_sampling");
-    hipLaunchKernelGGL(k_render_inverse_z, dim3(stream_grid((int64_t)B * S, 256)), dim3(256), 0, (hipStream_t)stream, inter,
-                       related_bidx, S, nb, sample_range, z_vals, B, sample_major);
+    hipLaunchKernelGGL(k_render_inverse_z, dim3(stream_grid(sample_major == 0 ? (int64_t)B * 64 : (int64_t)B * 4, 256)), dim3(256), 0,
+                       (hipStream_t)stream, inter, related_bidx, S, nb, sample_range, z_vals, B, sample_major);
     return check_launch("inverse_z_sampling");
 }
 
