@@ -377,9 +377,16 @@ __device__ __forceinline__ void s16_sh_row(char *row, const float d[3], float ep
 // SH_ROW: the split SH operand of the sample's ray is read from `sh_row` (this lane's 16 bytes of the hi part; the lo part 32
 // bytes further: a 64-byte row [hi 16][lo 16] per ray written by s16_sh_row below; lanes with q >= 2 point at a row of zeros)
 // instead of being evaluated from d -- per tile the harmonics cost ~100 vector instructions for 16 samples, four lanes each.
-template <bool SH_ROW = false>
+// `gate(sigma)` (wave-uniform) is asked after the heads whether the directional half is needed at all: the render-time kernel
+// answers no when every live sample of the tile has an opacity of exactly zero (1 - exp(-sigma delta) == 0: empty space inside
+// occupied cells) -- their colours are multiplied by that zero, so the three directional layers (54 of the tile's 96 MFMAs and
+// half its vector work) change nothing.  specular is then returned as zero.
+struct S16NoGate {
+    __device__ __forceinline__ bool operator()(float) const { return true; }
+};
+template <bool SH_ROW = false, class Gate = S16NoGate>
 __device__ __forceinline__ SampleOut decode_tile_s16(const char *lds, int lane, const v4f &xa, const v4f &xb, const float d[3], float eps,
-                                                     const char *sh_row = nullptr)
+                                                     const char *sh_row = nullptr, Gate gate = Gate())
 {
     const int q = lane >> 4, pos8 = s16_pos(lane) * 8;
     SampleOut so;
@@ -411,6 +418,10 @@ __device__ __forceinline__ SampleOut decode_tile_s16(const char *lds, int lane, 
             so.dif[k] = sigmoid_fast(hd[0][1 + k]);
             so.tint[k] = sigmoid_fast(hd[1][k]);
         }
+    }
+    if (!gate(so.sigma)) {
+        so.spec[0] = so.spec[1] = so.spec[2] = 0.0f;
+        return so;
     }
     T16HL cB[2];
     {

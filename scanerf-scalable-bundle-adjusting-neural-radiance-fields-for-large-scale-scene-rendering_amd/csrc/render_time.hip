@@ -1140,16 +1140,18 @@ __global__ void __launch_bounds__(kT16Threads, 4) k_pts_inference_t16(InferArgs 
                     const bool act = (rm >> src) & 1u;
                     v4f xa, xb;
                     encode4_t16(table, rsq, a.T, q, pt, xa, xb);
+                    const uint32_t es = (uint32_t)__shfl((int)ec, src, 64);
+                    const float dl = __shfl(delta, src, 64);
+                    // no live sample of the tile with a non-zero opacity -> the directional layers are skipped (decode_tile_s16)
+                    auto gate = [&](float sigma) { return __any(act && q == 0 && 1.0f - expf(-1.0f * sigma * dl) != 0.0f) != 0; };
                     SampleOut so;
                     if constexpr (SHT) {
                         const int row = __shfl(shrow, src, 64);
-                        so = decode_tile_s16<true>(lds, lane, xa, xb, nullptr, 0.0f, shrows + (q < 2 ? row + 16 * q : 64 * kShRows));
+                        so = decode_tile_s16<true>(lds, lane, xa, xb, nullptr, 0.0f, shrows + (q < 2 ? row + 16 * q : 64 * kShRows), gate);
                     } else {
                         const float dd[3] = { __shfl(d[0], src, 64), __shfl(d[1], src, 64), __shfl(d[2], src, 64) };
-                        so = decode_tile_s16(lds, lane, xa, xb, dd, 0.0f);
+                        so = decode_tile_s16<false>(lds, lane, xa, xb, dd, 0.0f, nullptr, gate);
                     }
-                    const uint32_t es = (uint32_t)__shfl((int)ec, src, 64);
-                    const float dl = __shfl(delta, src, 64);
                     if (BG) {
                         if (act && q == 0) {
                             const float pa = 1.0f - expf(-1.0f * so.sigma * dl);

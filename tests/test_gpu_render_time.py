@@ -190,13 +190,18 @@ def test_render_loop_stage_by_stage():
     np.testing.assert_allclose(ps.cpu().numpy(), rs_, rtol=1e-4, atol=2e-6)
 
 
-def _inference_case(B=1000, S=72, seed=5):
+def _inference_case(B=1000, S=72, seed=5, empty_tile=None):
     """fg (overlapping tiles, occupancy skips, ragged end) and bg inputs of the two inference ops -> run() = their six outputs"""
     import scanerf_amd  # noqa
     from scanerf_amd import hashgrid as H
     rng = np.random.default_rng(seed)
     sc = _scene(rng)
     nb = 3
+    if empty_tile is not None:   # a tile whose density head answers -300 everywhere: softplus -> 0, opacity exactly 0
+        sd = O.init_mlp(seed=20 + empty_tile, bias_scale=0.05)
+        sd["sigma_layer.mlp.0.weight"] = sd["sigma_layer.mlp.0.weight"] * 0.0
+        sd["sigma_layer.mlp.0.bias"] = sd["sigma_layer.mlp.0.bias"] * 0.0 - 300.0
+        sc["params"][empty_tile] = O.pack_blob(sd).numpy()
     o, d = _rays(rng, B)
     C, Z, OCC, ST, L2 = g(sc["corners"]), g(sc["sizes"]), g(sc["occ"]), g(sc["starts"]), g(sc["l2d"])
     RO, RD, TAB, PAR, RES = g(o), g(d), g(sc["tables"]), g(sc["params"]), g(sc["res"])
@@ -267,6 +272,25 @@ def test_inference_that_derives_its_slot_lists_equals_prepare_points_then_pts_in
     assert float(two[2][~running].abs().max()) == 0.0
     for a, b in zip(one, two):
         assert torch.equal(a, b)
+
+
+def test_tiles_of_zero_opacity_skip_the_directional_layers_and_change_nothing(monkeypatch):
+    """Samples whose opacity 1 - exp(-sigma delta) is exactly zero (tile 1's density head answers -300) leave zeros; the
+    16-sample-tile kernel skips the directional layers of tiles that hold only such samples, the 32-sample-tile kernel does not:
+    equal outputs, exact zeros where tile 1 is the only tile, the other tiles untouched."""
+    run = _inference_case(1000, 72, seed=17, empty_tile=1)
+    monkeypatch.delenv("SCANERF_RENDER_ARITH", raising=False)
+    t16 = run()
+    monkeypatch.setenv("SCANERF_RENDER_ARITH", "h3")
+    h3 = run()
+    monkeypatch.delenv("SCANERF_RENDER_ARITH", raising=False)
+    bi = run.ctx["bi"].cpu().numpy()
+    only1 = (bi[..., 0] == 1) & (bi[..., 1] == -1)
+    assert only1.sum() > 1000 and t16[2].max() > 0.05
+    for a, b in zip(t16[:3], h3[:3]):
+        assert np.all(a[only1] == 0.0) and np.all(b[only1] == 0.0)
+    for a, b in zip(t16, h3):
+        np.testing.assert_allclose(a, b, rtol=2e-5, atol=2e-6)
 
 
 @pytest.mark.parametrize("B,S", [(1000, 72), (517, 128), (3000, 16)])
