@@ -350,6 +350,11 @@ int scanerf_pts_inference(const float *rays_o, const float *rays_d, const float 
                           const int32_t *log2dim, const float *corners, const float *sizes, float *diffuse,
                           float *specular, float *alpha, int B, int S, int T, int nb,
                           int sample_major, scanerf_stream_t stream);                                            /* :467-621 */
+/* SCANERF_SKIP_UNSAMPLED, OR-ed into `sample_major` of scanerf_pts_inference_tracing and scanerf_accumulate_color (the renderer's own
+ * pair; no reference counterpart): a ray whose FIRST depth is -1 holds no sample in this tracing pass (sample_points fills a ray's
+ * depths from index 0) -- the inference leaves its outputs unwritten and the accumulation does not read them, instead of 28 bytes
+ * of zeros written and read per sample slot of such a ray.  Same per-ray results. */
+#define SCANERF_SKIP_UNSAMPLED 4
 /* prepare_points + pts_inference as ONE launch (no reference counterpart; the renderer's own route): the slot lists are derived
  * in the kernel from running_mask [B] and intersections [B,nb,2] at every use instead of being written and read back (8 bytes per
  * sample, once per tile step).  Same values as the two ops in sequence.  Needs the 16-sample-tile kernel (the default) and

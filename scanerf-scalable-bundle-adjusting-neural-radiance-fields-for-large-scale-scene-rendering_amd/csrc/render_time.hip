@@ -219,6 +219,7 @@ struct InferArgs {
     int sm;   // layout of the per-sample arrays (pt_index)
     const uint8_t *running;   // scanerf_pts_inference_tracing: the slot lists are derived in the kernel from the running mask,
     const float *inter;       // the samples' depths and the rays' [nb] (near, far) intervals (= prepare_points, :391-449)
+    int skip_unsampled;       // (tracing only) rays whose first depth is -1 hold no sample: their outputs are left unwritten
     int dbg;  // timing experiments only (-DSCANERF_RT_EXPERIMENTS, SCANERF_DEBUG_RT): 1 = no decoder, 2 = no table gathers
 };
 
@@ -985,10 +986,14 @@ __global__ void __launch_bounds__(kT16Threads, 4) k_pts_inference_t16(InferArgs 
                     }
                 } else {
                     uint2 raw;
+                    bool unsampled = false;
                     if constexpr (TR) {
                         int ri, rs;
                         pt_decompose(e32, (uint32_t)a.B, (uint32_t)a.S, a.sm, ri, rs);
                         raw = tracing_slots(a, ri, a.z_vals[e]);
+                        // (sample_points fills a ray's depths from index 0: a first depth of -1 = a ray without samples in this pass,
+                        // which the accumulation under the same flag does not read)
+                        unsampled = a.skip_unsampled && a.z_vals[pt_index(ri, 0, a.B, a.S, a.sm)] == -1.0f;
                     } else {
                         raw = *reinterpret_cast<const uint2 *>(a.block_idxs + (size_t)e32 * kMaxPtsBlocks);
                     }
@@ -996,7 +1001,7 @@ __global__ void __launch_bounds__(kT16Threads, 4) k_pts_inference_t16(InferArgs 
                               s3 = (int16_t)(raw.y >> 16);
                     mark(s0);  // the list stops at the first -1 (rendering_kernel.cu:499)
                     if (s0 != -1) { mark(s1); if (s1 != -1) { mark(s2); if (s2 != -1) mark(s3); } }
-                    else {   // no tile: zeros (:569-571).  Every other sample is WRITTEN by the step of its first listed tile and added
+                    else if (!unsampled) {   // no tile: zeros (:569-571).  Every other sample is WRITTEN by the step of its first listed tile and added
                              // to by the later ones, so the caller's arrays need no clearing pass (7.4 GB per launch at 1920x1080x128)
                         a.out_alpha[e] = 0.0f;
 #pragma unroll
@@ -1255,13 +1260,14 @@ __global__ void __launch_bounds__(256) k_accumulate_color(const float *__restric
                                                           const float *__restrict__ pts_spec,
                                                           const float *__restrict__ pts_alpha, float *__restrict__ transp,
                                                           const float *__restrict__ z_vals, float *__restrict__ dif,
-                                                          float *__restrict__ spec, float *__restrict__ depth, int B, int S)
+                                                          float *__restrict__ spec, float *__restrict__ depth, int B, int S, int skip)
 {
     const int lane = threadIdx.x & 63;
     const int nw = gridDim.x * (blockDim.x >> 6);
     for (int i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); i < B; i += nw) {
         float T = transp[i];
         if (T < 0.00001f) continue;  // wave-uniform
+        if (skip && z_vals[(size_t)i * S] == -1.0f) continue;   // SCANERF_SKIP_UNSAMPLED: a ray without samples in this pass
         float acc[7] = { 0, 0, 0, 0, 0, 0, 0 };
         for (int s0 = 0; s0 < S; s0 += 64) {
             const int s = s0 + lane;
@@ -1307,11 +1313,13 @@ __global__ void __launch_bounds__(256) k_accumulate_color(const float *__restric
 __global__ void __launch_bounds__(256) k_accumulate_color_sm(const float *__restrict__ pts_dif, const float *__restrict__ pts_spec,
                                                              const float *__restrict__ pts_alpha, float *__restrict__ transp,
                                                              const float *__restrict__ z_vals, float *__restrict__ dif,
-                                                             float *__restrict__ spec, float *__restrict__ depth, int B, int S, int lay)
+                                                             float *__restrict__ spec, float *__restrict__ depth, int B, int S, int lay,
+                                                             int skip)
 {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < B; i += gridDim.x * blockDim.x) {
         float T = transp[i];
         if (T < 0.00001f) continue;
+        if (skip && z_vals[pt_index(i, 0, B, S, lay)] == -1.0f) continue;   // SCANERF_SKIP_UNSAMPLED: a ray without samples in this pass
         float acc[7] = { 0, 0, 0, 0, 0, 0, 0 };
         for (int s = 0; s < S; ++s) {
             const size_t e = pt_index(i, s, B, S, lay);
@@ -1620,6 +1628,8 @@ static int pts_inference_impl(const float *rays_o, const float *rays_d, const fl
                                       scanerf_stream_t stream)
 {
     RT_REQ(B >= 0 && S >= 1 && nb >= 1, "pts_inference");
+    const int skip_unsampled = !block_idxs && (sample_major & SCANERF_SKIP_UNSAMPLED);   // (the tracing entry point only)
+    sample_major &= ~SCANERF_SKIP_UNSAMPLED;
     SCANERF_REQUIRE(sample_major >= 0 && sample_major <= 2 && (sample_major != 2 || B % 32 == 0),
                     "pts_inference" ": sample_major=%d (0, 1, or 2 with B a multiple of 32; B=%d)", sample_major, B);
     SCANERF_REQUIRE(T >= 2 && (T & (T - 1)) == 0, "pts_inference: T=%d must be a power of two", T);
@@ -1630,7 +1640,7 @@ static int pts_inference_impl(const float *rays_o, const float *rays_d, const fl
     a.rays_o = rays_o; a.rays_d = rays_d; a.z_vals = z_vals; a.dists = dists; a.block_idxs = block_idxs;
     a.tables = tables_f16; a.images = images; a.res = res; a.t = make_tiles(corners, sizes, occ, grid_starts, log2dim, nb);
     a.out_dif = out_dif; a.out_spec = out_spec; a.out_alpha = out_alpha; a.T = T; a.B = B; a.S = S; a.step = 0;
-    a.sm = sample_major; a.running = block_idxs ? nullptr : running; a.inter = inter;
+    a.sm = sample_major; a.running = block_idxs ? nullptr : running; a.inter = inter; a.skip_unsampled = skip_unsampled;
     { const char *de = getenv("SCANERF_DEBUG_RT"); a.dbg = de ? atoi(de) : 0; }
     const int64_t tiles32 = ((int64_t)B * S + 31) / 32;
     int blocks = (int)((tiles32 + 3) / 4 < kNumCU * 4 ? (tiles32 + 3) / 4 : kNumCU * 4);
@@ -1697,7 +1707,7 @@ SCANERF_API int scanerf_bg_pts_inference_v2(const float *rays_o, const float *ra
     a.rays_o = rays_o; a.rays_d = rays_d; a.z_vals = z_vals; a.dists = nullptr; a.block_idxs = bg_idxs;
     a.tables = tables_f16; a.images = images; a.res = res; a.t = make_tiles(corners, sizes, nullptr, nullptr, nullptr, nb);
     a.out_dif = out_dif; a.out_spec = out_spec; a.out_alpha = out_alpha; a.T = T; a.B = B; a.S = S; a.step = step;
-    a.sm = sample_major; a.running = nullptr; a.inter = nullptr;
+    a.sm = sample_major; a.running = nullptr; a.inter = nullptr; a.skip_unsampled = 0;
     { const char *de = getenv("SCANERF_DEBUG_RT"); a.dbg = de ? atoi(de) : 0; }
     const int64_t tiles32 = ((int64_t)B * S + 31) / 32;
     int blocks = (int)((tiles32 + 3) / 4 < kNumCU * 4 ? (tiles32 + 3) / 4 : kNumCU * 4);
@@ -1715,16 +1725,18 @@ SCANERF_API int scanerf_accumulate_color(const float *pts_dif, const float *pts_
                                          int sample_major, scanerf_stream_t stream)
 {
     RT_REQ(B >= 0 && S >= 1, "accumulate_color");
+    const int skip = (sample_major & SCANERF_SKIP_UNSAMPLED) != 0;
+    sample_major &= ~SCANERF_SKIP_UNSAMPLED;
     SCANERF_REQUIRE(sample_major >= 0 && sample_major <= 2 && (sample_major != 2 || B % 32 == 0),
                     "accumulate_color" ": sample_major=%d (0, 1, or 2 with B a multiple of 32; B=%d)", sample_major, B);
     if (B == 0) return 0;
     RT_REQ(pts_dif && pts_spec && pts_alpha && transp && z_vals && dif && spec && depth, "accumulate_color");
     if (sample_major)
         hipLaunchKernelGGL(k_accumulate_color_sm, dim3(stream_grid(B, 256)), dim3(256), 0, (hipStream_t)stream, pts_dif, pts_spec,
-                           pts_alpha, transp, z_vals, dif, spec, depth, B, S, sample_major);
+                           pts_alpha, transp, z_vals, dif, spec, depth, B, S, sample_major, skip);
     else
         hipLaunchKernelGGL(k_accumulate_color, dim3(stream_grid((int64_t)B * 64, 256)), dim3(256), 0, (hipStream_t)stream, pts_dif,
-                           pts_spec, pts_alpha, transp, z_vals, dif, spec, depth, B, S);
+                           pts_spec, pts_alpha, transp, z_vals, dif, spec, depth, B, S, skip);
     return check_launch("accumulate_color");
 }
 

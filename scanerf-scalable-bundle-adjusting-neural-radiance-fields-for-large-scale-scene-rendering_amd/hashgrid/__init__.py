@@ -1,5 +1,5 @@
 """Package `hashgrid` of the reference: the HASHGRID op names plus the encoder modules."""
-from .lib.HASHGRID import (Sampler, accumulate_color, bg_pts_inference, bg_pts_inference_v2,  # noqa: F401
+from .lib.HASHGRID import (SKIP_UNSAMPLED, Sampler, accumulate_color, bg_pts_inference, bg_pts_inference_v2,  # noqa: F401
                            embedding_backward_cuda, embedding_bg_backward_cuda, embedding_bg_forward_cuda,
                            embedding_forward_cuda, get_last_block, inverse_z_sampling, prepare_points,
                            process_occupied_grid, pts_inference, pts_inference_tracing, ray_block_intersection, ray_firsthit_block,

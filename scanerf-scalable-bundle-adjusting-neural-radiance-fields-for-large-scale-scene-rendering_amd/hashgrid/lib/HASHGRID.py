@@ -150,7 +150,7 @@ def ray_block_intersection(rays_o, rays_d, block_corners, block_sizes, intersect
 
 def _S(z_vals, sample_major):
     """per-sample arrays: [B,S] (0, the reference's), [S,B] (1) or [B/32,S,32] (2) -- scanerf_hip.h `sample_major`"""
-    return _I(z_vals.shape[0] if int(sample_major) == 1 else z_vals.shape[1])
+    return _I(z_vals.shape[0] if (int(sample_major) & 3) == 1 else z_vals.shape[1])
 
 
 def sort_tracing_blocks(intersections):
@@ -196,6 +196,9 @@ def pts_inference(rays_o, rays_d, z_vals, dists, block_idxs, features_tables, pa
         dev_ptr(diffuse, _f32, "diffuse"), dev_ptr(specular, _f32, "specular"), dev_ptr(alpha, _f32, "alpha"),
         _I(rays_d.shape[0]), _S(z_vals, sample_major), _I(features_tables.shape[2]), _I(block_corners.shape[0]),
         _I(int(sample_major)), stream()), "pts_inference")
+
+
+SKIP_UNSAMPLED = 4   # include/scanerf_hip.h SCANERF_SKIP_UNSAMPLED: OR into `sample_major` of pts_inference_tracing / accumulate_color
 
 
 def tracing_fusable(nb):

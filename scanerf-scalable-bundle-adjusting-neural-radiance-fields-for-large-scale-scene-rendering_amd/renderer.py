@@ -14,7 +14,7 @@ import torch
 from . import network
 from .cuda import compute_ray_forward
 from .hashgrid import (accumulate_color, bg_pts_inference_v2, inverse_z_sampling, prepare_points, process_occupied_grid,
-                       pts_inference, pts_inference_tracing, ray_block_intersection, sample_points, sort_tracing_blocks,
+                       SKIP_UNSAMPLED, pts_inference, pts_inference_tracing, ray_block_intersection, sample_points, sort_tracing_blocks,
                        tracing_fusable, update_outgoing_bidx)
 
 
@@ -135,9 +135,13 @@ class TileSetRenderer:
             dd = torch.full(shp_(num_sample), -1.0, device=dev)
             sample_points(ro, rd, self.block_corner, self.block_size, self.fake_occupied_grid, self.grid_starts,
                           self.grid_log2dim, tb, it, tidx, zst, z, dd, sample_major=sm)
-            if fuse_slots:   # the slot lists never exist: the inference kernel derives them (pts_inference_tracing)
+            if fuse_slots:   # the slot lists never exist: the inference kernel derives them (pts_inference_tracing); rays that
+                # got no sample in this pass (first depth -1) are neither written by it nor read by the accumulation
                 pts_inference_tracing(ro, rd, z, dd, running, it, self.feature_tables, self.packed, self.resolution, self.occupied_grid,
-                                      self.grid_starts, self.grid_log2dim, self.block_corner, self.block_size, pd, ps, pa, sample_major=sm)
+                                      self.grid_starts, self.grid_log2dim, self.block_corner, self.block_size, pd, ps, pa,
+                                      sample_major=sm | SKIP_UNSAMPLED)
+                accumulate_color(pd, ps, pa, tr, z, df, sp, dp, sample_major=sm | SKIP_UNSAMPLED)
+                return
             else:
                 bi = torch.full(shp_(num_sample, 4), -1, dtype=torch.int16, device=dev)
                 prepare_points(z, running, it, bi, sample_major=sm)

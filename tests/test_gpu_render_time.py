@@ -272,6 +272,24 @@ def test_inference_that_derives_its_slot_lists_equals_prepare_points_then_pts_in
     assert float(two[2][~running].abs().max()) == 0.0
     for a, b in zip(one, two):
         assert torch.equal(a, b)
+    # SKIP_UNSAMPLED: rays whose first depth is -1 (they got no sample) are left unwritten by the inference and unread by the
+    # accumulation; the per-ray results are those of the plain pair
+    z = c["z"]
+    unsampled = z[:, 0] == -1.0
+    assert 0 < int(unsampled.sum()) < B and bool((z[unsampled] == -1.0).all())
+    skp = [torch.full((B, S, 3), -3.0, device=DEV), torch.full((B, S, 3), -3.0, device=DEV), torch.full((B, S, 1), -3.0, device=DEV)]
+    H.pts_inference_tracing(c["RO"], c["RD"], z, c["dd"], running, c["inter"], *tail, *skp, sample_major=H.SKIP_UNSAMPLED)
+    for a, b in zip(skp, one):
+        assert torch.equal(a[~unsampled], b[~unsampled])
+        assert bool((a[unsampled] == -3.0).all())
+
+    def acc(arrs, flag):
+        tr = torch.linspace(0.2, 1.0, B, device=DEV).reshape(B, 1).contiguous()
+        out = [torch.zeros(B, 3, device=DEV), torch.zeros(B, 3, device=DEV), torch.zeros(B, 1, device=DEV)]
+        H.accumulate_color(*arrs, tr, z, *out, sample_major=flag)
+        return [tr] + out
+    for a, b in zip(acc(skp, H.SKIP_UNSAMPLED), acc(one, 0)):
+        assert torch.equal(a, b)
 
 
 def test_tiles_of_zero_opacity_skip_the_directional_layers_and_change_nothing(monkeypatch):
