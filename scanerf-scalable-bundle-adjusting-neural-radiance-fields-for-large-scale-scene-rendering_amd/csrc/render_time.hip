@@ -839,8 +839,11 @@ __global__ void __launch_bounds__(NT, WPS) k_pts_inference_chunks(InferArgs a)
 // vector work of three others.  A wave takes 64 consecutive samples at a time: lane l prepares sample l (position, blend weights,
 // occupancy), then each of the four 16-sample tiles with a live sample is decoded with lane (c, q) = sample 16 t + c, quarter q
 // (inputs by ds_bpermute from the preparing lane).
-constexpr int kT16Threads = 512, kT16Waves = kT16Threads / 64, kT16WaveGroups = 8;   // 8 x 64 = the 512 samples per wave and chunk of the kernel above
-static_assert(kT16Waves * kT16WaveGroups * 64 == kChunkWaves * kChunkWaveGroups * 32, "same chunk");
+#ifndef T16_WAVE_GROUPS
+#define T16_WAVE_GROUPS 8   // 8 x 64 = the 512 samples per wave and chunk of the kernel above (4 / 16: chunk-size experiments)
+#endif
+constexpr int kT16Threads = 512, kT16Waves = kT16Threads / 64, kT16WaveGroups = T16_WAVE_GROUPS;
+constexpr int kT16ChunkGroups32 = kT16Waves * kT16WaveGroups * 2;   // a chunk in 32-sample groups
 
 // lane (c, q): levels l0 + {0, 1, 4, 5}, l0 = 8 (q & 1) + 2 (q >> 1)  =  decoder inputs 2 l0 + {0..3} (xa) and + 8 (xb)
 __device__ __forceinline__ void encode4_t16(const char *table, const float *rs, int T, int q, const float p01[3], v4f &xa, v4f &xb)
@@ -918,7 +921,7 @@ __host__ __device__ inline void t16_chunk_rays(int64_t e0, int64_t e1, int B, in
 }
 inline bool t16_sh_rows_fit(int B, int S, int sm)
 {
-    constexpr int64_t kChunkSamples = 4096;
+    constexpr int64_t kChunkSamples = kT16Waves * kT16WaveGroups * 64;
     if (sm == 1) return B <= kShRows;
     // the widest range any chunk can see: ceil(chunk / (samples per ray or ray block)) + 1 units
     const int64_t per = sm == 0 ? S : (int64_t)S * 32, units = (kChunkSamples + per - 1) / per + 1;
@@ -938,7 +941,7 @@ __global__ void __launch_bounds__(kT16Threads, 4) k_pts_inference_t16(InferArgs 
     const int lane = threadIdx.x & 63, c16 = lane & 15, q = lane >> 4, wave = threadIdx.x >> 6;
     const int64_t total = (int64_t)a.B * a.S;
     constexpr int kChunkSamples = kT16Waves * kT16WaveGroups * 64;
-    static_assert(kChunkSamples == 4096, "t16_sh_rows_fit");
+
     const int64_t nchunks = (total + kChunkSamples - 1) / kChunkSamples;
     for (int64_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
         if (threadIdx.x < 2) tileset[threadIdx.x] = 0;
@@ -1235,7 +1238,7 @@ inline void launch_chunks(const InferArgs &a, int64_t tiles32, hipStream_t strea
     if (render_t16_tiles()) {
         const char *e = getenv("SCANERF_RENDER_SH_ROWS");   // =0: every tile evaluates its samples' harmonics (comparison; the same bits)
         const bool rows = t16_sh_rows_fit(a.B, a.S, a.sm) && !(e && e[0] == '0');
-        const dim3 grid(nblocks(kChunkWaves * kChunkWaveGroups));
+        const dim3 grid(nblocks(kT16ChunkGroups32));
         if constexpr (!BG) {
             if (a.running) {   // scanerf_pts_inference_tracing
                 if (rows) hipLaunchKernelGGL((k_pts_inference_t16<false, true, true>), grid, dim3(kT16Threads), 0, stream, a);
