@@ -450,7 +450,39 @@ def side_legs(args, dev, rays_o, rays_d, target, S, step0):
     out["render_is"] = (f"configs[4] render leg: {ntile} resident tiles (f16 tables T=2^{args.log2_T}, shell occupancy) + blended backgrounds, "
                         f"one {W}x{H} view, {args.samples} + {args.samples} samples, 2 warm-up + {n_fr} timed frames; opaque fraction {opaque:.3f}")
     torch.cuda.empty_cache()
+    out.update(reference_default_leg(args, dev, S, step0))
+    torch.cuda.empty_cache()
     return out
+
+
+def reference_default_leg(args, dev, S, step0, n=8):
+    """The iteration of the reference's SHIPPED configuration (config/default.yaml:2,15-18; tile.py:301,1010): T = 2^24 entries
+    per level, 16 384 rays, foreground + T_left * background (128 + 128 samples), ray gradients for the pose refinement, one
+    sparse Adam step over both branches' table gradients -- `--workload configs1-fgbg --log2-T 24 --rays 16384 --pose-grads` as a
+    side leg of the default line (2 warm-up + n timed iterations; per-section HIP-event times beside the wall clock)."""
+    from scanerf_amd import tile_model as tm
+    Bd = 16384
+    g = torch.Generator(device=dev).manual_seed(24)
+    m = tm.TileModel([-4.0, -4, -4], [8, 8, 8], dev, log2_T=24, seed=24, sampler_log2dim=4)
+    opt = torch.optim.Adam(m.decoder.parameters(), lr=1e-3, betas=(0.9, 0.99), eps=1e-15)
+    ro = torch.rand(Bd, 3, device=dev, generator=g) * 8 - 4
+    rd = torch.nn.functional.normalize(torch.randn(Bd, 3, device=dev, generator=g), dim=-1) * (0.5 + torch.rand(Bd, 1, device=dev, generator=g))
+    tg = torch.rand(Bd, 3, device=dev, generator=g)
+    for i in range(2):
+        tm.train_step_fgbg(m, opt, ro, rd, tg, S, S, step0 + i, pose_grads=True)
+    torch.cuda.synchronize()
+    timer = tm.KernelTimer()
+    t0 = time.perf_counter()
+    for i in range(n):
+        tm.train_step_fgbg(m, opt, ro, rd, tg, S, S, step0 + 2 + i, pose_grads=True, timer=timer)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / n * 1e3
+    secs = {k: round(v, 4) for k, v in timer.summary().items()}   # (average per LAUNCH of the section: two forwards / backwards per iteration)
+    del m, opt
+    return {"reference_default_ms_per_iteration": ms, "reference_default_rays_per_s": Bd / ms * 1e3,
+            "reference_default_sections_ms": secs,
+            "reference_default_is": (f"the reference's shipped configuration: T=2^24 fp32 table (fp32 Adam moments), {Bd} rays x ({S} + {S}) "
+                                     f"samples, fg + T_left*bg, pose (ray) gradients, one sparse Adam; 2 warm-up + {n} timed iterations")}
 
 
 # rocprof kernel names of the timer's sections, per arithmetic (profiles/r05_kernel_stats.txt lists them with their durations)
@@ -722,6 +754,8 @@ def main():
             init_rccl(1, local)
         except Exception as e:  # noqa: BLE001  (reported in the line as rccl_loaded: false + the reason)
             rccl_error = f"{type(e).__name__}: {e}"
+            if dist.is_initialized():   # a group whose first all-reduce failed must not stay up: every later exchange would re-enter it
+                dist.destroy_process_group()
     dev = f"cuda:{local}"
 
     import scanerf_amd  # noqa: F401  (fails loudly if the HIP library is missing)

@@ -48,8 +48,9 @@ class ConsensusState:
 
 
 def collective_active(group=None):
-    """A process group exists: the exchanges go through its all-reduce (RCCL for CUDA tensors), whatever the world size."""
-    return dist.is_available() and dist.is_initialized()
+    """A process group exists AND this rank is a member of `group` (None = the default group): the exchanges go through its
+    all-reduce (RCCL for CUDA tensors), whatever the world size.  A rank outside `group` takes the local path."""
+    return dist.is_available() and dist.is_initialized() and dist.get_rank(group) >= 0
 
 
 @torch.no_grad()

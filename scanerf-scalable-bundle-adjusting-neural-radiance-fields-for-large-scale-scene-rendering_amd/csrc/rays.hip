@@ -40,49 +40,52 @@ __device__ __forceinline__ float wave_sum(float v)
     return v;
 }
 
-// Adjoint of k_compute_ray_fwd w.r.t. C2W.  Rays of one camera are usually contiguous, so
-// each wave first reduces the lanes that share a view and issues 12 atomics per distinct
-// view instead of 12 per ray (the reference: 12 atomics/ray into <=400 rows).
-__global__ void __launch_bounds__(256) k_compute_ray_bwd(const float *__restrict__ g_o, const float *__restrict__ g_d,
-                                                         const float *__restrict__ Ks, float *__restrict__ grad_C2Ws,
-                                                         const int32_t *__restrict__ locs, int B)
+// Adjoint of k_compute_ray_fwd w.r.t. C2W, summed in a FIXED order (round 6; the reference issues 12 float atomics per ray into
+// <= 400 rows, compute_ray_kernel.cu:46-92, and rounds 1-5 here issued 12 per (wave, view): the one launch-to-launch difference
+// left in a training step).  One workgroup per camera: thread t adds up the camera's rays t, t+1024, ... in index order, the
+// 16 waves reduce by the same butterfly every launch, wave sums are added 0..15 by one thread, which alone writes the camera's
+// row (+=, the binding's accumulate-into-the-caller's-buffer contract).  Every workgroup reads the view column of locs once
+// (B * 12 bytes from the L2s per camera: 0.3 GB at 65 536 rays x 400 cameras); only the owning camera's rays load gradients.
+constexpr int kRayBwdThreads = 1024;
+__global__ void __launch_bounds__(kRayBwdThreads) k_compute_ray_bwd(const float *__restrict__ g_o, const float *__restrict__ g_d,
+                                                                    const float *__restrict__ Ks, float *__restrict__ grad_C2Ws,
+                                                                    const int32_t *__restrict__ locs, int B, int num_cam)
 {
-    int base = (blockIdx.x * blockDim.x + threadIdx.x) & ~63;  // wave-uniform trip count
-    int lane = threadIdx.x & 63;
-    for (; base < B; base += gridDim.x * blockDim.x) {
-        int i = base + lane;
-        bool live = i < B;
-        int v = -1;
+    __shared__ float part[kRayBwdThreads / 64][12];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int v = blockIdx.x; v < num_cam; v += gridDim.x) {
+        const float *K = Ks + 9 * v;
+        const float k0 = K[0], k2 = K[2], k4 = K[4], k5 = K[5];
         float c[12];
 #pragma unroll
         for (int k = 0; k < 12; ++k) c[k] = 0.0f;
-        if (live) {
-            v = locs[3 * i];
+        for (int i = threadIdx.x; i < B; i += kRayBwdThreads) {
+            if (locs[3 * i] != v) continue;
             int px = locs[3 * i + 1], py = locs[3 * i + 2];
-            const float *K = Ks + 9 * v;
-            float x = (1.0f * px + 0.5f - K[2]) / K[0];
-            float y = (1.0f * py + 0.5f - K[5]) / K[4];
+            float x = (1.0f * px + 0.5f - k2) / k0;
+            float y = (1.0f * py + 0.5f - k5) / k4;
 #pragma unroll
             for (int r = 0; r < 3; ++r) {
                 float gd = g_d[3 * i + r];
-                c[4 * r + 0] = gd * x;
-                c[4 * r + 1] = gd * y;
-                c[4 * r + 2] = gd;
-                c[4 * r + 3] = g_o[3 * i + r];
+                c[4 * r + 0] += gd * x;
+                c[4 * r + 1] += gd * y;
+                c[4 * r + 2] += gd;
+                c[4 * r + 3] += g_o[3 * i + r];
             }
         }
-        unsigned long long todo = __ballot(live);
-        while (todo) {
-            int leader = __ffsll((long long)todo) - 1;
-            int vv = __shfl(v, leader, 64);
-            bool mine = live && v == vv;
 #pragma unroll
-            for (int k = 0; k < 12; ++k) {
-                float s = wave_sum(mine ? c[k] : 0.0f);
-                if (lane == leader) atomicAdd(grad_C2Ws + 12 * vv + k, s);
-            }
-            todo &= ~__ballot(mine);
+        for (int k = 0; k < 12; ++k) {
+            float s = wave_sum(c[k]);
+            if (lane == 0) part[wave][k] = s;
         }
+        __syncthreads();
+        if (threadIdx.x < 12) {
+            float s = 0.0f;
+#pragma unroll
+            for (int w = 0; w < kRayBwdThreads / 64; ++w) s += part[w][threadIdx.x];
+            grad_C2Ws[12 * v + threadIdx.x] += s;
+        }
+        __syncthreads();
     }
 }
 
@@ -237,8 +240,9 @@ SCANERF_API int scanerf_compute_ray_backward(const float *g_o, const float *g_d,
     SCANERF_REQUIRE(B >= 0 && num_cam >= 0, "compute_ray_backward: B=%d num_cam=%d", B, num_cam);
     if (B == 0) return 0;
     SCANERF_REQUIRE(g_o && g_d && Ks && grad_C2Ws && locs, "compute_ray_backward: null pointer");
-    hipLaunchKernelGGL(k_compute_ray_bwd, dim3(stream_grid(B, 256)), dim3(256), 0, (hipStream_t)stream, g_o, g_d,
-                       Ks, grad_C2Ws, locs, B);
+    if (num_cam == 0) return 0;
+    hipLaunchKernelGGL(k_compute_ray_bwd, dim3(num_cam < kNumCU * 2 ? num_cam : kNumCU * 2), dim3(kRayBwdThreads), 0,
+                       (hipStream_t)stream, g_o, g_d, Ks, grad_C2Ws, locs, B, num_cam);
     return check_launch("compute_ray_backward");
 }
 

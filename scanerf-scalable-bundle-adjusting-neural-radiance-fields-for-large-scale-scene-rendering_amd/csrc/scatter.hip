@@ -23,6 +23,7 @@
 
 #include "adam_common.h"
 #include "render_device.h"
+#include <algorithm>
 #include <mutex>
 #include <unordered_map>
 #include "scatter_common.h"
@@ -65,7 +66,9 @@ __global__ void __launch_bounds__(1024) k_bin_count(const float *__restrict__ po
                 count_pairs(pr, hist, g.bucket_log);
             }
             __syncthreads();
-            for (int i = threadIdx.x; i < g.NB; i += (int)blockDim.x) counts[((size_t)l * g.NB + i) * g.W + blockIdx.x] = hist[i];
+            // (format 3: the range of this (bucket, workgroup) is counted in 64-byte segments of kSegRecs records)
+            for (int i = threadIdx.x; i < g.NB; i += (int)blockDim.x)
+                counts[((size_t)l * g.NB + i) * g.W + blockIdx.x] = g.rec8 == 3 ? (hist[i] + kSegRecs - 1) / kSegRecs : hist[i];
             __syncthreads();
         }
         return;
@@ -257,6 +260,154 @@ __global__ void __launch_bounds__(1024) k_bin_scatter(const float *__restrict__ 
     if ((threadIdx.x & 63) == 0 && gmax > 0.0f) atomicMax(maxbits, __float_as_uint(gmax));
 }
 
+// ---- pass 2 for LARGE tables (round 6): records leave the CU as full 64-byte segments -------------------------------------
+// k_bin_scatter<.., PER_LEVEL> stores every 12-byte record on its own into one of NB = 2048 open ranges per workgroup: 256
+// workgroups x 2048 ranges x 128-byte lines = 67 MB of partially written lines against 32 MB of L2 that turn over every ~13 us,
+// and a range receives two records per batch -- the lines reach HBM a few records at a time (T = 2^24, 4.2e6 samples: 6.3 GB
+// written for 3.2 GB of records, 2.55 ms; sub-passes and fewer workgroups did not help).  Lines fill only with
+// temporal density, so the density is created where nothing is evicted: the workgroup keeps ONE 60-byte slot per bucket in its
+// LDS (2048 x 60 B = 120 KB), a record goes to slot position (ordinal mod 5) of its bucket, and a slot that holds its five
+// records is written as one aligned 64-byte store to the range's next segment (format 3 of scatter_common.h).
+//   per batch of 1024 points (one level at a time):  reserve ordinals (LDS atomics on cnt[bucket])
+//     round:  barrier | records whose segment is the slot's current one are written into it | barrier | full slots are flushed,
+//             their segment number advances | repeat while any record waits (a bucket that received more than its slot had
+//             room for: ~2 rounds per batch, a third one for a handful of buckets)
+//   end of level: the partly filled slots are flushed with zero words in the unused positions.
+// A range's ordinal -> address map is exact (counted by k_bin_count in segments), so results do not depend on timing beyond
+// the order of records inside a bucket, which the integer accumulate does not see.
+template <bool LEVEL_MAJOR_GRAD>
+__global__ void __launch_bounds__(1024) k_bin_scatter_seg(const float *__restrict__ points, const float2 *__restrict__ grad_in,
+                                                          const int32_t *__restrict__ resolutions, BinGeom g,
+                                                          const uint32_t *__restrict__ rowprefix, const uint32_t *__restrict__ starts,
+                                                          Rec *__restrict__ recs, float *__restrict__ grad_features,
+                                                          uint32_t *__restrict__ maxbits)
+{
+    extern __shared__ uint32_t lds[];
+    const int NB = g.NB;
+    uint32_t *cnt = lds, *segn = lds + NB, *gbase = lds + 2 * NB, *slot = lds + 3 * NB;   // slot[NB][15]
+    const uint32_t cap_segs = rec_capacity(g.capacity, 3);
+    uint4 *segs = reinterpret_cast<uint4 *>(recs);
+    const uint32_t mask = (uint32_t)g.T - 1u, lmask = (1u << g.bucket_log) - 1u;
+    const int lo = blockIdx.x * g.per_wg, hi = min(g.N, lo + g.per_wg);
+    float gmax = 0.0f;
+    for (int l = 0; l < g.L; ++l) {
+        for (int i = threadIdx.x; i < NB; i += 1024) {
+            const int bin = l * NB + i;
+            cnt[i] = 0;
+            segn[i] = 0;
+            gbase[i] = starts[bin] + rowprefix[(size_t)bin * g.W + blockIdx.x];
+        }
+        float *grad_level = grad_features + (size_t)l * g.T * 2;
+        // n (<= 5) records of bucket b's slot -> the range's next segment; beyond the workspace: the overflow table (atomics)
+        auto flush = [&](int b, uint32_t n) {
+            const uint32_t *sl = slot + b * 15;
+            uint32_t w[16];
+#pragma unroll
+            for (int j = 0; j < 15; ++j) w[j] = (uint32_t)j < 3u * n ? sl[j] : 0u;
+            w[15] = 0u;
+            const uint32_t gs = gbase[b] + segn[b];
+            segn[b] += 1u;
+            if (gs < cap_segs) {
+                uint4 *d = segs + (size_t)gs * 4;
+                d[0] = make_uint4(w[0], w[1], w[2], w[3]);
+                d[1] = make_uint4(w[4], w[5], w[6], w[7]);
+                d[2] = make_uint4(w[8], w[9], w[10], w[11]);
+                d[3] = make_uint4(w[12], w[13], w[14], w[15]);
+            } else {
+                *overflow_flag(recs) = 1u;
+                float *gsb = grad_level + ((size_t)b << g.bucket_log) * 2;
+                for (uint32_t r = 0; r < n; ++r) {
+                    const Rec12Fields f = unpack_rec12(sl[3 * r], sl[3 * r + 1], sl[3 * r + 2]);
+                    unsafeAtomicAdd(gsb + 2 * f.l0, (1.0f - f.w1) * f.gx);
+                    unsafeAtomicAdd(gsb + 2 * f.l0 + 1, (1.0f - f.w1) * f.gy);
+                    if (f.l1 <= lmask) {
+                        unsafeAtomicAdd(gsb + 2 * f.l1, f.w1 * f.gx);
+                        unsafeAtomicAdd(gsb + 2 * f.l1 + 1, f.w1 * f.gy);
+                    }
+                }
+            }
+        };
+        auto place = [&](const uint32_t (&bk)[4], const uint32_t (&rw)[4][3], bool have) {
+            uint32_t pos[4] = { 0u, 0u, 0u, 0u };
+            uint32_t pend = have ? 15u : 0u;
+            if (have) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) pos[q] = atomicAdd(&cnt[bk[q]], 1u);
+            }
+            for (;;) {
+                __syncthreads();
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (!((pend >> q) & 1u)) continue;
+                    const uint32_t sg = pos[q] / (uint32_t)kSegRecs;
+                    if (sg != segn[bk[q]]) continue;
+                    uint32_t *d = slot + bk[q] * 15u + (pos[q] - sg * kSegRecs) * 3u;
+                    d[0] = rw[q][0];
+                    d[1] = rw[q][1];
+                    d[2] = rw[q][2];
+                    pend &= ~(1u << q);
+                }
+                __syncthreads();
+                for (int b = threadIdx.x; b < NB; b += 1024)
+                    if (cnt[b] >= (uint32_t)kSegRecs * (segn[b] + 1u)) flush(b, (uint32_t)kSegRecs);
+                if (!__syncthreads_or(pend != 0u)) break;
+            }
+        };
+        __syncthreads();
+        for (int i0 = lo; i0 < hi; i0 += 1024) {
+            const int i = i0 + (int)threadIdx.x;
+            const bool live = i < hi;
+            uint32_t bk[4] = { 0u, 0u, 0u, 0u }, rw[4][3];
+            Pairs pr;
+            float2 gi = make_float2(0.0f, 0.0f);
+            bool straddle = false;
+            if (live) {
+                const float p[3] = { points[3 * (size_t)i], points[3 * (size_t)i + 1], points[3 * (size_t)i + 2] };
+                gi = LEVEL_MAJOR_GRAD ? grad_in[(size_t)l * g.N + i] : grad_in[(size_t)i * g.L + l];
+                gmax = fmaxf(gmax, fmaxf(fabsf(gi.x), fabsf(gi.y)));
+                make_pairs(p, resolutions + 3 * l, mask, pr);
+                straddle = (pr.xm >> g.bucket_log) != 0u;
+                const uint32_t k = straddle ? 15u : (uint32_t)(31 - __clz((int)pr.xm));
+                const uint32_t t = straddle ? 0u : (uint32_t)min(__float2int_rn(pr.tx * 8388608.0f), 8388607);
+                const float a0 = 1.0f - pr.tx;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float gx = pr.wyz[q] * gi.x, gy = pr.wyz[q] * gi.y;
+                    bk[q] = pr.idx0[q] >> g.bucket_log;
+                    rw[q][0] = (pr.idx0[q] & lmask) | (k << 13) | ((t >> 8) << 17);
+                    rw[q][1] = rec12_round(straddle ? a0 * gx : gx) | ((t >> 4) & 15u);
+                    rw[q][2] = rec12_round(straddle ? a0 * gy : gy) | (t & 15u);
+                }
+            }
+            place(bk, rw, live);
+            // x-neighbours in different buckets (only where a level's resolution exceeds the bucket size): the second entries
+            if (__syncthreads_or(straddle)) {
+                if (straddle) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const uint32_t i1 = pr.idx0[q] ^ pr.xm;
+                        const float gx = pr.wyz[q] * gi.x, gy = pr.wyz[q] * gi.y;
+                        bk[q] = i1 >> g.bucket_log;
+                        rw[q][0] = (i1 & lmask) | (15u << 13);
+                        rw[q][1] = rec12_round(pr.tx * gx);
+                        rw[q][2] = rec12_round(pr.tx * gy);
+                    }
+                }
+                place(bk, rw, straddle);
+            }
+        }
+        // (place() ends on a barrier with every full slot flushed: what is left holds 1..4 records)
+        for (int b = threadIdx.x; b < NB; b += 1024) {
+            const uint32_t n = cnt[b] - (uint32_t)kSegRecs * segn[b];
+            if (n) flush(b, n);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) gmax = fmaxf(gmax, __shfl_xor(gmax, off, 64));
+    if ((threadIdx.x & 63) == 0 && gmax > 0.0f) atomicMax(maxbits, __float_as_uint(gmax));
+}
+
 // ---- accumulate: one workgroup per bin -------------------------------------------------------
 // One workgroup per bin.  The bucket image is accumulated in 64-bit FIXED POINT with integer
 // LDS atomics: on gfx950 ds_add_f32 is ~12x slower than ds_add_u32/u64 (measured: 2.1e9 float
@@ -303,10 +454,10 @@ __global__ void __launch_bounds__(kThreads) k_bin_accumulate(const Rec *__restri
     float M = two ? fmaxf(__uint_as_float(*maxbits), __uint_as_float(*ad.maxbits2)) : __uint_as_float(*maxbits);
     // Rec12 components are ROUNDED to 19 mantissa bits after the maximum was taken (scatter_common.h rec12_round): a value just
     // below 2^eM may have become 2^eM.  One 19-bit unit on top of the maximum keeps "every |v| < 2^eM" true for the stored values.
-    if (fmt == 2 && M > 0.0f && M < 3.0e38f) M = __uint_as_float(__float_as_uint(M) + 16u);
+    if ((fmt == 2 || fmt == 3) && M > 0.0f && M < 3.0e38f) M = __uint_as_float(__float_as_uint(M) + 16u);
     const bool overflowed = ADAM && ad.overflow_grad &&
                             (*overflow_flag(const_cast<Rec *>(recs)) != 0u || (two && *overflow_flag(const_cast<Rec *>(ad.recs2)) != 0u));  // uniform
-    const uint32_t nrec = (hi1 - lo1) + (hi2 - lo2);
+    const uint32_t nrec = ((hi1 - lo1) + (hi2 - lo2)) * (fmt == 3 ? (uint32_t)kSegRecs : 1u);
     if ((nrec == 0 || !(M > 0.0f)) && !overflowed) return;  // nothing to add (uniform per workgroup)
     int eM;
     frexpf(M, &eM);  // M < 2^eM
@@ -385,6 +536,35 @@ __global__ void __launch_bounds__(kThreads) k_bin_accumulate(const Rec *__restri
         for (int set = 0; set < (two ? 2 : 1); ++set) {   // (one copy of the streaming code for both record sets)
         const float4 *r4 = reinterpret_cast<const float4 *>(set ? ad.recs2 : recs);
         const uint32_t lo = set ? lo2 : lo1, hi = set ? hi2 : hi1;
+        if (fmt == 3) {
+            // 64-byte segments of five records (k_bin_scatter_seg): a lane takes SEGS consecutive segments, four 16-byte loads
+            // each; all-zero record slots (a range's padding) and records with an exactly zero gradient add nothing and are skipped
+            const uint4 *u4 = reinterpret_cast<const uint4 *>(r4);
+            constexpr int SEGS = U / 8 > 0 ? U / 8 : 1;
+            auto apply12z = [&](uint32_t w0, uint32_t w1, uint32_t w2) {
+                if (((w1 | w2) & ~15u) != 0u) apply12(w0, w1, w2);
+            };
+            for (uint32_t c = lo + threadIdx.x * SEGS; c < hi; c += SEGS * kThreads) {
+                uint4 r[4 * SEGS];
+#pragma unroll
+                for (int u = 0; u < SEGS; ++u)
+                    if (c + u < hi) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) r[4 * u + j] = u4[(size_t)(c + u) * 4 + j];
+                    }
+#pragma unroll
+                for (int u = 0; u < SEGS; ++u)
+                    if (c + u < hi) {
+                        const uint4 &a0 = r[4 * u], &a1 = r[4 * u + 1], &a2 = r[4 * u + 2], &a3 = r[4 * u + 3];
+                        apply12z(a0.x, a0.y, a0.z);
+                        apply12z(a0.w, a1.x, a1.y);
+                        apply12z(a1.z, a1.w, a2.x);
+                        apply12z(a2.y, a2.z, a2.w);
+                        apply12z(a3.x, a3.y, a3.z);
+                    }
+            }
+            continue;
+        }
         if (fmt == 2) {
             // each lane takes runs of 4 consecutive records = three aligned 16-byte loads, U / 4 runs in flight (the bin's range
             // may start anywhere: runs start at multiples of 4 records, partial runs go one record at a time)
@@ -480,9 +660,15 @@ __global__ void __launch_bounds__(kThreads) k_bin_accumulate(const Rec *__restri
             float2 *P = reinterpret_cast<float2 *>(ad.params) + ebase, *Mo = reinterpret_cast<float2 *>(ad.exp_avg) + ebase,
                    *Vo = reinterpret_cast<float2 *>(ad.exp_avg_sq) + ebase;
             float2 *og = overflowed ? reinterpret_cast<float2 *>(ad.overflow_grad) + ebase : nullptr;
-            for (int j = threadIdx.x; j < ws; j += kThreads) {
+            // Round 6: a thread takes NI PAIRS of neighbouring entries at a time and issues the parameter / moment loads of all of
+            // them (16 bytes each) before the first use.  The loop over single entries that stood here put each entry's three
+            // loads inside the "touched" branch: 8 dependent HBM round trips per thread and bucket at T = 2^24 (32 768 buckets of
+            // 8 192 records: the epilogue, not the record stream, was the launch's time).  Same arithmetic per element.
+            constexpr int NI = 4;
+            auto grad_of = [&](int j, float &gx, float &gy) {
                 const long long qx = acc64[2 * j], qy = acc64[2 * j + 1];
-                float gx = 0.0f + (float)ldexp((double)qx, -k), gy = 0.0f + (float)ldexp((double)qy, -k);  // as grad_features would hold them
+                gx = 0.0f + (float)ldexp((double)qx, -k);   // as grad_features would hold them
+                gy = 0.0f + (float)ldexp((double)qy, -k);
                 if (og) {
                     const float2 e = og[j];
                     if (e.x != 0.0f || e.y != 0.0f) {
@@ -491,19 +677,49 @@ __global__ void __launch_bounds__(kThreads) k_bin_accumulate(const Rec *__restri
                         og[j] = make_float2(0.0f, 0.0f);
                     }
                 }
-                if (gx != 0.0f || gy != 0.0f) {
-                    float2 p = P[j], m = Mo[j], v = Vo[j];
-                    adam_update_one<false>(p.x, m.x, v.x, gx, ad.a);
-                    adam_update_one<false>(p.y, m.y, v.y, gy, ad.a);
-                    P[j] = p;
-                    Mo[j] = m;
-                    Vo[j] = v;
-                    if (ad.half_table) {
-                        if (ad.half_dtype == SCANERF_F16)
-                            reinterpret_cast<__half2 *>(ad.half_table)[ebase + j] = __floats2half2_rn(p.x, p.y);
-                        else
-                            reinterpret_cast<__hip_bfloat162 *>(ad.half_table)[ebase + j] =
-                                __hip_bfloat162{ __float2bfloat16(p.x), __float2bfloat16(p.y) };  // round to nearest even, as torch
+            };
+            for (int j0 = 2 * (int)threadIdx.x; j0 < ws; j0 += 2 * kThreads * NI) {
+                float g[NI][4];
+                float4 p[NI], m[NI], v[NI];
+                bool hit[NI];
+#pragma unroll
+                for (int i = 0; i < NI; ++i) {
+                    const int j = j0 + 2 * kThreads * i;
+                    hit[i] = false;
+                    if (j < ws) {   // (ws is a power of two >= 2: pairs never straddle the window's end)
+                        grad_of(j, g[i][0], g[i][1]);
+                        grad_of(j + 1, g[i][2], g[i][3]);
+                        hit[i] = g[i][0] != 0.0f || g[i][1] != 0.0f || g[i][2] != 0.0f || g[i][3] != 0.0f;
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < NI; ++i) {
+                    const int j = j0 + 2 * kThreads * i;
+                    if (hit[i]) {
+                        p[i] = *reinterpret_cast<const float4 *>(P + j);
+                        m[i] = *reinterpret_cast<const float4 *>(Mo + j);
+                        v[i] = *reinterpret_cast<const float4 *>(Vo + j);
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < NI; ++i) {
+                    const int j = j0 + 2 * kThreads * i;
+                    if (!hit[i]) continue;
+                    adam_update_one<false>(p[i].x, m[i].x, v[i].x, g[i][0], ad.a);
+                    adam_update_one<false>(p[i].y, m[i].y, v[i].y, g[i][1], ad.a);
+                    adam_update_one<false>(p[i].z, m[i].z, v[i].z, g[i][2], ad.a);
+                    adam_update_one<false>(p[i].w, m[i].w, v[i].w, g[i][3], ad.a);
+                    *reinterpret_cast<float4 *>(P + j) = p[i];
+                    *reinterpret_cast<float4 *>(Mo + j) = m[i];
+                    *reinterpret_cast<float4 *>(Vo + j) = v[i];
+                    if (ad.half_table) {   // (an untouched entry of the pair is rewritten with the bits it already holds)
+                        if (ad.half_dtype == SCANERF_F16) {
+                            reinterpret_cast<__half2 *>(ad.half_table)[ebase + j] = __floats2half2_rn(p[i].x, p[i].y);
+                            reinterpret_cast<__half2 *>(ad.half_table)[ebase + j + 1] = __floats2half2_rn(p[i].z, p[i].w);
+                        } else {   // round to nearest even, as torch
+                            reinterpret_cast<__hip_bfloat162 *>(ad.half_table)[ebase + j] = __hip_bfloat162{ __float2bfloat16(p[i].x), __float2bfloat16(p[i].y) };
+                            reinterpret_cast<__hip_bfloat162 *>(ad.half_table)[ebase + j + 1] = __hip_bfloat162{ __float2bfloat16(p[i].z), __float2bfloat16(p[i].w) };
+                        }
                     }
                 }
             }
@@ -602,6 +818,14 @@ static int standalone_bucket_log(int T)
     return lt < bl ? lt : bl;
 }
 
+// Segments the large-table producer may need: the records (4 per (point, level) + the straddle slack of the record budget) in
+// fives, plus one partly filled segment per (bucket, producer workgroup) range.
+constexpr int kSegProducers = 256;
+static size_t seg_route_segments(int N, int L, int64_t nbins)
+{
+    return ((size_t)N * L * 4 + (size_t)N * L / 8) / kSegRecs + (size_t)nbins * kSegProducers + 4096;
+}
+
 // Workspace bytes for a binned backward of N points.  0 => shape unsupported by the binned path
 // (the atomics kernel is used instead).
 SCANERF_API size_t scanerf_embedding_bwd_workspace_bytes(int N, int L, int T)
@@ -612,7 +836,10 @@ SCANERF_API size_t scanerf_embedding_bwd_workspace_bytes(int N, int L, int T)
     if ((T >> bl) * 4 > 64 * 1024) return 0;                   // one level's LDS counters
     if ((int64_t)N * L * 4 + (1 << 20) >= (int64_t)1 << 31) return 0;  // 32-bit record offsets
     const int W = 1024;
-    const size_t recs = ((size_t)N * L * 4 + (size_t)N * L / 8 + 4096) * sizeof(Rec);
+    size_t recs = ((size_t)N * L * 4 + (size_t)N * L / 8 + 4096) * sizeof(Rec);
+    // large tables (one level's counters in LDS at a time): records in 64-byte segments of five, every (bucket, workgroup)
+    // range rounded up to whole segments (k_bin_scatter_seg)
+    if ((size_t)nbins * 4 > 64 * 1024) recs = std::max(recs, seg_route_segments(N, L, nbins) * 64);
     return recs + (size_t)nbins * W * 4 + (size_t)(2 * nbins + 6) * 4 + 256;
 }
 
@@ -654,6 +881,13 @@ static int binned_backward(const float *points, const float *grad_in, float *gra
     g.rec8 = (compact_records >= 1 && compact_records <= 2 && (grad_layout == 1 || (rows16 && compact_records == 2)) &&
               g.bucket_log <= kRec8MaxBucketLog && !getenv("SCANERF_REC16")) ? compact_records : 0;
     g.NB = T >> g.bucket_log;
+    // Large tables (round 6): 12-byte records leave the producer as full 64-byte segments (k_bin_scatter_seg, format 3) -- for the
+    // level-major gradients of the t16s backward and for the point-major rows of the binding surface (whose default is Rec12
+    // as well, see rows16); SCANERF_REC16 / SCANERF_SCATTER_OLD keep the record-at-a-time producer
+    const bool seg_route = (size_t)L * g.NB * 4 > 64 * 1024 && g.bucket_log == 13 && g.NB <= 2048 &&
+                           (compact_records == 2 || (grad_layout == 0 && compact_records == 0)) &&
+                           !getenv("SCANERF_REC16") && !getenv("SCANERF_SCATTER_OLD");
+    if (seg_route) g.rec8 = 3;
     // producer workgroups: every one of them writes and reads a counter per bin, so with the tens of thousands of bins of a
     // large table fewer, longer-running workgroups are cheaper (T = 2^24, 2.1 M points: count 0.62 -> see DESIGN.md)
     g.W = ((size_t)L * g.NB * 4 > 64 * 1024 || rows16) ? 256 : 1024;
@@ -665,6 +899,8 @@ static int binned_backward(const float *points, const float *grad_in, float *gra
     SCANERF_REQUIRE(bin_workspace_carve(workspace, workspace_bytes, nbins, g.W, w),
                     "embedding_bg_backward_binned: workspace too small (%zu B)", workspace_bytes);
     g.capacity = w.capacity;
+    if (g.rec8 == 3 && (g.W > kSegProducers || rec_capacity(g.capacity, 3) < seg_route_segments(N, L, L * g.NB)))
+        g.rec8 = (compact_records == 2 && g.bucket_log <= kRec8MaxBucketLog) ? 2 : 0;   // (a caller's smaller workspace: the old producer)
     uint32_t *counts = w.counts, *totals = w.totals, *starts = w.starts, *maxbits = w.maxbits;
     Rec *recs = w.recs;
 
@@ -678,7 +914,19 @@ static int binned_backward(const float *points, const float *grad_in, float *gra
         hipLaunchKernelGGL((k_bin_count<false>), dim3(g.W), dim3(rows16 ? 1024 : kThreads), lds_bins, st, points, resolutions, g, counts, maxbits, overflow_flag(recs));   // (256 producer workgroups: give them all 16 waves)
     hipLaunchKernelGGL(k_bin_rowscan, dim3(nbins), dim3(kThreads), 0, st, counts, totals, g.W);
     hipLaunchKernelGGL(k_bin_starts, dim3(1), dim3(1024), 0, st, totals, starts, nbins);
-    if (rows16 && g.rec8 == 2)
+    if (g.rec8 == 3) {
+        const size_t lds_seg = (size_t)g.NB * 18 * 4;   // cnt, segn, gbase, 15-word slots
+        for (const void *fn : { reinterpret_cast<const void *>(&k_bin_scatter_seg<true>), reinterpret_cast<const void *>(&k_bin_scatter_seg<false>) }) {
+            hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_seg);
+            SCANERF_REQUIRE(e == hipSuccess, "embedding_bg_backward_binned: cannot reserve %zu B of LDS: %s", lds_seg, hipGetErrorString(e));
+        }
+        if (grad_layout == 1)
+            hipLaunchKernelGGL((k_bin_scatter_seg<true>), dim3(g.W), dim3(1024), lds_seg, st, points, gi, resolutions, g, counts, starts,
+                               recs, grad_features, maxbits);
+        else
+            hipLaunchKernelGGL((k_bin_scatter_seg<false>), dim3(g.W), dim3(1024), lds_seg, st, points, gi, resolutions, g, counts, starts,
+                               recs, grad_features, maxbits);
+    } else if (rows16 && g.rec8 == 2)
         hipLaunchKernelGGL((k_bin_scatter<false, false, 2>), dim3(g.W), dim3(1024), lds_bins, st, points, gi, resolutions, g,
                            counts, starts, recs, grad_features, maxbits);
     else if (rows16)

@@ -23,8 +23,13 @@ struct BinGeom {
     int per_wg;       // samples per producer workgroup
     int rpg;          // fused producer: rays per workgroup visit (ray = (wg + i*W)*rpg + r): 1 f32 kernel, 4 h3 kernel
     uint32_t capacity;  // records that fit the workspace
-    int rec8;         // record format: 0 = Rec (16 bytes), 1 = Rec8 (8 bytes), 2 = Rec12 (12 bytes), -1 = read format_word() (accumulate of a fused plan)
+    int rec8;         // record format: 0 = Rec (16 bytes), 1 = Rec8 (8 bytes), 2 = Rec12 (12 bytes), 3 = Rec12 in 64-byte segments of five (kSegRecs), -1 = read format_word() (accumulate of a fused plan)
 };
+// Format 3 (round 6, large tables): a (bucket, workgroup) range is a whole number of 64-BYTE SEGMENTS, each holding five Rec12
+// records (60 bytes) and one spare word; counts, starts and capacities are in segments.  The stand-alone producer fills a
+// segment in its LDS and writes it with ONE aligned 64-byte store (k_bin_scatter_seg); unused record slots of a range's last
+// segment are all-zero words, which the accumulate skips (a record whose two gradient words are zero adds nothing).
+constexpr int kSegRecs = 5;
 
 struct Rec {
     uint32_t hdr;
@@ -476,6 +481,7 @@ inline uint32_t fused_coarse_capacity(uint32_t capacity, int B, int S, int bucke
 }
 __host__ __device__ inline uint32_t rec_capacity(uint32_t capacity16, int fmt)
 {
+    if (fmt == 3) return capacity16 / 4u;   // 64-byte segments
     return fmt == 1 ? capacity16 * 2u : (fmt == 2 ? capacity16 + capacity16 / 3u : capacity16);   // 8- / 12- / 16-byte records in the same bytes
 }
 // bucket size of the FUSED producer (k_render_bwd* emits, scanerf_render_scatter_accumulate consumes): log2 entries

@@ -16,6 +16,7 @@ import torch.distributed as dist
 import torch.nn.functional as F
 
 from .cuda import ray_aabb_intersection
+from .consensus import collective_active
 
 NO_DEPTH = float("inf")
 
@@ -68,7 +69,7 @@ def exchange_shared_depth(shared_depth, published=None, group=None):
     publisher per camera, so MIN is a gather).  Reducing the persistent buffer itself would mix rounds: ranks that hold a
     camera's OLD map would contribute it again and the result would be min(old, new), so depths could only ever decrease.
     Every rank must call this the same number of times (it is a collective): AdmmDriver does, once per stretch."""
-    multi = dist.is_available() and dist.is_initialized()   # (world size 1 included: the same collective path everywhere)
+    multi = collective_active(group)   # (world size 1 included: the same collective path everywhere; members of `group` only)
     if published is None and not multi:
         return shared_depth
     fresh = torch.full_like(shared_depth, NO_DEPTH)
