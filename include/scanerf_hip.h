@@ -116,6 +116,20 @@ int scanerf_embedding_bg_backward_binned_adam(const float *points, const float *
                                               float *params, float *exp_avg, float *exp_avg_sq, void *half_table,
                                               int half_dtype, float *overflow_grad, float lr, float beta1, float beta2,
                                               float eps, int step, int compact_records, scanerf_stream_t stream);
+/* The same scatter + sparse Adam for the samples of up to TWO render branches over the same B rays (a tile's foreground and
+ * background, tile.py:639-692 -- one optimiser step for both, tile.py:1010), without materialising or concatenating contracted
+ * points: point positions are formed from rays_o/rays_d [B,3] and each branch's depths z [B,S] exactly as the render kernels form
+ * them (contract_mode 0 = contract_fore, 1 = contract_bg; min_bbox / bbox_size [3] on the HOST), gradients are each branch's
+ * level-major dfeat [16][B*S][2] out of scanerf_render_backward; valid [B] u8 (may be NULL) masks rays out.  z2 = NULL: one branch.
+ * Tables of >= 2^22 entries per level, L = 16, 12-byte records in 64-byte segments (csrc/scatter_common.h format 3); workspace
+ * of scanerf_embedding_bwd_workspace_bytes(B*(S1+S2), 16, T).  Replaces hashgrid_bg_kernel.cu:152-226 + torch.optim.Adam. */
+int scanerf_table_grad_scatter_adam_rays(const float *rays_o, const float *rays_d, int B, const float *z1, const float *dfeat1,
+                                         const uint8_t *valid1, int S1, int contract_mode1, const float *z2, const float *dfeat2,
+                                         const uint8_t *valid2, int S2, int contract_mode2, const float *min_bbox /*[host]*/,
+                                         const float *bbox_size /*[host]*/, const int32_t *resolutions, int T, void *workspace,
+                                         size_t workspace_bytes, float *params, float *exp_avg, float *exp_avg_sq, void *half_table,
+                                         int half_dtype, float *overflow_grad, float lr, float beta1, float beta2, float eps, int step,
+                                         scanerf_stream_t stream);
 /* hashgrid/src/hashgrid_kernel.cu:246-270 / :272-300 (world-space box variant) */
 int scanerf_embedding_forward(const float *points, float *outputs, const float *features,
                               const float *block_corner, const float *block_size,

@@ -64,6 +64,22 @@ inline int check_launch(const char *what)
 #define SCANERF_STORE_GUARD() do { } while (0)
 #endif
 
+// Tuning switches of the A/B experiments (launch shapes, alternative producers): environment variables read at launch time ONLY in
+// a library built with -DSCANERF_EXPERIMENTS (make EXP=1); the product build compiles every one of them to its default -- no
+// getenv, no hidden global state on a launch path (thread-safe, re-entrant, no globals).
+#ifdef SCANERF_EXPERIMENTS
+#include <stdlib.h>
+inline int tune_int(const char *name, int dflt)
+{
+    const char *e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+inline bool tune_set(const char *name) { return getenv(name) != nullptr; }
+#else
+inline int tune_int(const char *, int dflt) { return dflt; }
+inline bool tune_set(const char *) { return false; }
+#endif
+
 inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
 // Grid for memory-bound 1-thread-per-item kernels: enough blocks to fill 256 CUs several

@@ -311,22 +311,28 @@ __device__ __forceinline__ void encode8(const RenderArgs &a, const int *lds_res,
     }
 }
 
-__device__ __forceinline__ void contract_point(const RenderArgs &a, const float o[3], const float d[3], float z,
-                                               float p[3])
+// (box and mode as plain arguments: the stand-alone scatter of scatter.hip places the samples of a render branch with it)
+__device__ __forceinline__ void contract_point_box(const float min_bbox[3], const float bbox_size[3], int contract_mode,
+                                                   const float o[3], const float d[3], float z, float p[3])
 {
 #pragma clang fp contract(off)  // torch evaluates these as separate ops (hashgrid/__init__.py:394-411,519)
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         float w = o[k] + z * d[k];
-        p[k] = (w - a.min_bbox[k]) / a.bbox_size[k] * 4.0f - 2.0f;
+        p[k] = (w - min_bbox[k]) / bbox_size[k] * 4.0f - 2.0f;
     }
-    if (a.contract_mode == 1) {
+    if (contract_mode == 1) {
         float linf = fmaxf(fabsf(p[0]), fmaxf(fabsf(p[1]), fabsf(p[2])));
         float ratio = (2.0f - 1.0f / linf) / linf;
         p[0] *= ratio;
         p[1] *= ratio;
         p[2] *= ratio;
     }
+}
+__device__ __forceinline__ void contract_point(const RenderArgs &a, const float o[3], const float d[3], float z,
+                                               float p[3])
+{
+    contract_point_box(a.min_bbox, a.bbox_size, a.contract_mode, o, d, z, p);
 }
 
 // per-sample decoder outputs (identical in both halves of the wave)

@@ -39,10 +39,50 @@ constexpr int kRun = 8;  // consecutive points per lane in the stand-alone count
     for (int c_ = (lo) + threadIdx.x * kRun; c_ < (hi); c_ += (int)blockDim.x * kRun)    \
         for (int i = c_; i < c_ + kRun && i < (hi); ++i)
 
+// Where the points of a stand-alone scatter come from: an array of contracted points with its gradient rows (the binding
+// surface), or -- RAYS -- the samples of up to two render branches over the same B rays (a tile's foreground and background,
+// tile.py:639-692): point i < N1 is sample i % S[0] of ray i / S[0] of branch 0, the rest belong to branch 1; positions are formed
+// as the render kernels form them (contract_point_box), gradients are the backward's level-major dfeat [16][B * S[k]][2] of each
+// branch.  Round 6: replaces torch's construction of the contracted points (a dozen elementwise launches) and the
+// concatenation of both branches' points and gradients (0.5 GB copied per iteration at T = 2^24, 16 384 rays).
+struct PointSrc {
+    const float *rays_o, *rays_d;
+    const float *z[2];
+    const uint8_t *valid[2];   // per ray, may be null
+    const float2 *grad[2];
+    int S[2], mode[2], N1;
+    float min_bbox[3], bbox_size[3];
+};
+// point i of a ray source: position and branch / index inside the branch; false = its ray is masked out (no records)
+__device__ __forceinline__ bool src_point(const PointSrc &s, int i, float p[3], int &br, int &j)
+{
+    br = i >= s.N1 ? 1 : 0;
+    j = br ? i - s.N1 : i;
+    const int ray = j / s.S[br];
+    if (s.valid[br] && !s.valid[br][ray]) return false;
+    const float o[3] = { s.rays_o[3 * ray], s.rays_o[3 * ray + 1], s.rays_o[3 * ray + 2] };
+    const float d[3] = { s.rays_d[3 * ray], s.rays_d[3 * ray + 1], s.rays_d[3 * ray + 2] };
+    contract_point_box(s.min_bbox, s.bbox_size, s.mode[br], o, d, s.z[br][j], p);
+    return true;
+}
+
+__global__ void __launch_bounds__(256) k_src_points(PointSrc src, float *__restrict__ pts, int N)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N; i += gridDim.x * blockDim.x) {
+        float p[3];
+        int br, j;
+        if (!src_point(src, i, p, br, j)) p[0] = p[1] = p[2] = __builtin_nanf("");
+        pts[3 * (size_t)i] = p[0];
+        pts[3 * (size_t)i + 1] = p[1];
+        pts[3 * (size_t)i + 2] = p[2];
+    }
+}
+
 // ---- pass 1: count ---------------------------------------------------------------------
 // PER_LEVEL: the LDS holds one level's NB counters at a time (large tables: L*NB counters do not fit); the points are
 // walked once per level (re-read from L2).
-template <bool PER_LEVEL>
+// MASKED: points of rays that are masked out carry a NaN x coordinate (k_src_points) and leave no records.
+template <bool PER_LEVEL, bool MASKED = false>
 __global__ void __launch_bounds__(1024) k_bin_count(const float *__restrict__ points,
                                                         const int32_t *__restrict__ resolutions, BinGeom g,
                                                         uint32_t *__restrict__ counts, uint32_t *__restrict__ maxbits,
@@ -62,8 +102,8 @@ __global__ void __launch_bounds__(1024) k_bin_count(const float *__restrict__ po
             SCANERF_RUN_WALK(i, lo, hi) {
                 const float p[3] = { points[3 * i], points[3 * i + 1], points[3 * i + 2] };
                 Pairs pr;
-                make_pairs(p, resolutions + 3 * l, mask, pr);
-                count_pairs(pr, hist, g.bucket_log);
+                make_pairs(p, resolutions + 3 * l, mask, pr);   // (a NaN position gives finite indices: the conversions saturate)
+                if (!MASKED || p[0] == p[0]) count_pairs(pr, hist, g.bucket_log);
             }
             __syncthreads();
             // (format 3: the range of this (bucket, workgroup) is counted in 64-byte segments of kSegRecs records)
@@ -268,21 +308,24 @@ __global__ void __launch_bounds__(1024) k_bin_scatter(const float *__restrict__ 
 // temporal density, so the density is created where nothing is evicted: the workgroup keeps ONE 60-byte slot per bucket in its
 // LDS (2048 x 60 B = 120 KB), a record goes to slot position (ordinal mod 5) of its bucket, and a slot that holds its five
 // records is written as one aligned 64-byte store to the range's next segment (format 3 of scatter_common.h).
-//   per batch of 1024 points (one level at a time):  reserve ordinals (LDS atomics on cnt[bucket])
-//     round:  barrier | records whose segment is the slot's current one are written into it | barrier | full slots are flushed,
-//             their segment number advances | repeat while any record waits (a bucket that received more than its slot had
-//             room for: ~2 rounds per batch, a third one for a handful of buckets)
+//   per batch of 1024 points (one level at a time): reserve ordinals (LDS atomics on cnt[bucket]) | barrier | records of the
+//   slot's segment go into it, records of segments the batch completes on its own are stored directly | barrier | slots whose
+//   segment is complete are flushed and move on | barrier | records of the new current segment go into the slot (see place()).
+//   A first version repeated "fill the slot, flush" until no record waited: the coarse levels put ~100 records of a batch into
+//   one bucket = 20 rounds, 7.0 ms per launch against the old producer's 2.4.
 //   end of level: the partly filled slots are flushed with zero words in the unused positions.
 // A range's ordinal -> address map is exact (counted by k_bin_count in segments), so results do not depend on timing beyond
 // the order of records inside a bucket, which the integer accumulate does not see.
-template <bool LEVEL_MAJOR_GRAD>
+// PTS: points per lane and batch (a batch = 1024 * PTS points: the three barriers are paid per batch).
+template <bool LEVEL_MAJOR_GRAD, bool RAYS, int PTS>
 __global__ void __launch_bounds__(1024) k_bin_scatter_seg(const float *__restrict__ points, const float2 *__restrict__ grad_in,
                                                           const int32_t *__restrict__ resolutions, BinGeom g,
                                                           const uint32_t *__restrict__ rowprefix, const uint32_t *__restrict__ starts,
                                                           Rec *__restrict__ recs, float *__restrict__ grad_features,
-                                                          uint32_t *__restrict__ maxbits)
+                                                          uint32_t *__restrict__ maxbits, PointSrc src)
 {
     extern __shared__ uint32_t lds[];
+    constexpr int R = 4 * PTS;   // records per lane and batch
     const int NB = g.NB;
     uint32_t *cnt = lds, *segn = lds + NB, *gbase = lds + 2 * NB, *slot = lds + 3 * NB;   // slot[NB][15]
     const uint32_t cap_segs = rec_capacity(g.capacity, 3);
@@ -298,105 +341,167 @@ __global__ void __launch_bounds__(1024) k_bin_scatter_seg(const float *__restric
             gbase[i] = starts[bin] + rowprefix[(size_t)bin * g.W + blockIdx.x];
         }
         float *grad_level = grad_features + (size_t)l * g.T * 2;
-        // n (<= 5) records of bucket b's slot -> the range's next segment; beyond the workspace: the overflow table (atomics)
+        auto to_overflow_table = [&](uint32_t b, uint32_t w0, uint32_t w1, uint32_t w2) {
+            *overflow_flag(recs) = 1u;
+            float *gsb = grad_level + ((size_t)b << g.bucket_log) * 2;
+            const Rec12Fields f = unpack_rec12(w0, w1, w2);
+            unsafeAtomicAdd(gsb + 2 * f.l0, (1.0f - f.w1) * f.gx);
+            unsafeAtomicAdd(gsb + 2 * f.l0 + 1, (1.0f - f.w1) * f.gy);
+            if (f.l1 <= lmask) {
+                unsafeAtomicAdd(gsb + 2 * f.l1, f.w1 * f.gx);
+                unsafeAtomicAdd(gsb + 2 * f.l1 + 1, f.w1 * f.gy);
+            }
+        };
+        // n (<= 5) records of bucket b's slot -> segment segn[b] of the range; beyond the workspace: the overflow table (atomics)
         auto flush = [&](int b, uint32_t n) {
             const uint32_t *sl = slot + b * 15;
-            uint32_t w[16];
-#pragma unroll
-            for (int j = 0; j < 15; ++j) w[j] = (uint32_t)j < 3u * n ? sl[j] : 0u;
-            w[15] = 0u;
             const uint32_t gs = gbase[b] + segn[b];
-            segn[b] += 1u;
             if (gs < cap_segs) {
+                uint32_t w[16];
+#pragma unroll
+                for (int j = 0; j < 15; ++j) w[j] = (uint32_t)j < 3u * n ? sl[j] : 0u;
+                w[15] = 0u;
                 uint4 *d = segs + (size_t)gs * 4;
                 d[0] = make_uint4(w[0], w[1], w[2], w[3]);
                 d[1] = make_uint4(w[4], w[5], w[6], w[7]);
                 d[2] = make_uint4(w[8], w[9], w[10], w[11]);
                 d[3] = make_uint4(w[12], w[13], w[14], w[15]);
             } else {
-                *overflow_flag(recs) = 1u;
-                float *gsb = grad_level + ((size_t)b << g.bucket_log) * 2;
-                for (uint32_t r = 0; r < n; ++r) {
-                    const Rec12Fields f = unpack_rec12(sl[3 * r], sl[3 * r + 1], sl[3 * r + 2]);
-                    unsafeAtomicAdd(gsb + 2 * f.l0, (1.0f - f.w1) * f.gx);
-                    unsafeAtomicAdd(gsb + 2 * f.l0 + 1, (1.0f - f.w1) * f.gy);
-                    if (f.l1 <= lmask) {
-                        unsafeAtomicAdd(gsb + 2 * f.l1, f.w1 * f.gx);
-                        unsafeAtomicAdd(gsb + 2 * f.l1 + 1, f.w1 * f.gy);
-                    }
-                }
+                for (uint32_t r = 0; r < n; ++r) to_overflow_table((uint32_t)b, sl[3 * r], sl[3 * r + 1], sl[3 * r + 2]);
             }
         };
-        auto place = [&](const uint32_t (&bk)[4], const uint32_t (&rw)[4][3], bool have) {
-            uint32_t pos[4] = { 0u, 0u, 0u, 0u };
-            uint32_t pend = have ? 15u : 0u;
-            if (have) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) pos[q] = atomicAdd(&cnt[bk[q]], 1u);
+        // one record straight to its final place (a segment that this batch completes without the slot)
+        auto direct = [&](uint32_t b, uint32_t sg, uint32_t within, const uint32_t (&w)[3]) {
+            const uint32_t gs = gbase[b] + sg;
+            if (gs < cap_segs) {
+                struct __attribute__((aligned(4))) W3 { uint32_t a, b, c; };
+                *reinterpret_cast<W3 *>(reinterpret_cast<uint32_t *>(segs + (size_t)gs * 4) + within * 3u) = W3{ w[0], w[1], w[2] };
+            } else {
+                to_overflow_table(b, w[0], w[1], w[2]);
             }
-            for (;;) {
-                __syncthreads();
+        };
+        // A batch's records of one bucket have the ordinals [c0, c1).  With cur = the slot's segment (c0 / 5) and full = c1 / 5:
+        //   segment cur           -> the slot (it is flushed below once full > cur)
+        //   cur < segment < full  -> completed by this batch alone: its five records are stored directly, 12 bytes each, by
+        //                            their lanes at the same moment (coarse levels put a hundred samples of a batch into one
+        //                            bucket: those lines fill in L2 without help)
+        //   segment full (> cur)  -> the slot's NEXT segment: written after the flush
+        // Three barriers per batch, whatever the distribution.
+        auto place = [&](const uint32_t (&bk)[R], const uint32_t (&rw)[R][3], uint32_t have) {   // have: bit r = record r exists
+            uint32_t pos[R];
+            uint32_t late = 0u;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    if (!((pend >> q) & 1u)) continue;
-                    const uint32_t sg = pos[q] / (uint32_t)kSegRecs;
-                    if (sg != segn[bk[q]]) continue;
-                    uint32_t *d = slot + bk[q] * 15u + (pos[q] - sg * kSegRecs) * 3u;
-                    d[0] = rw[q][0];
-                    d[1] = rw[q][1];
-                    d[2] = rw[q][2];
-                    pend &= ~(1u << q);
+            for (int r = 0; r < R; ++r) pos[r] = (have >> r) & 1u ? atomicAdd(&cnt[bk[r]], 1u) : 0u;
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                if (!((have >> r) & 1u)) continue;
+                const uint32_t b = bk[r], sg = pos[r] / (uint32_t)kSegRecs, within = pos[r] - sg * kSegRecs;
+                const uint32_t cur = segn[b], full = cnt[b] / (uint32_t)kSegRecs;
+                if (sg == cur) {
+                    uint32_t *d = slot + b * 15u + within * 3u;
+                    d[0] = rw[r][0];
+                    d[1] = rw[r][1];
+                    d[2] = rw[r][2];
+                } else if (sg < full) {
+#ifdef SCANERF_EXPERIMENTS
+                    if (g.dbg & 4) { if (rw[r][0] == 0x12345u) segs[0] = make_uint4(rw[r][0], rw[r][1], rw[r][2], 0u); } else
+#endif
+                    direct(b, sg, within, rw[r]);
+                } else {
+                    late |= 1u << r;
                 }
-                __syncthreads();
-                for (int b = threadIdx.x; b < NB; b += 1024)
-                    if (cnt[b] >= (uint32_t)kSegRecs * (segn[b] + 1u)) flush(b, (uint32_t)kSegRecs);
-                if (!__syncthreads_or(pend != 0u)) break;
             }
+            __syncthreads();
+            // four neighbouring lanes write one segment, 16 bytes each: a store instruction covers 16 whole 64-byte segments
+            // (one lane per segment and four stores each = 64 separate 16-byte requests per instruction)
+            for (int b = threadIdx.x >> 2; b < NB; b += 256) {
+                const uint32_t full = cnt[b] / (uint32_t)kSegRecs, cur = segn[b], qd = threadIdx.x & 3u;
+                if (full > cur) {
+                    const uint32_t *sl = slot + b * 15 + qd * 4;
+                    const uint4 w = make_uint4(sl[0], sl[1], sl[2], qd == 3u ? 0u : sl[3]);   // (slot[b][15] does not exist: the spare word)
+                    const uint32_t gs = gbase[b] + cur;
+#ifdef SCANERF_EXPERIMENTS
+                    if (g.dbg & 4) { if (w.x == 0x12345u) segs[0] = w; } else
+#endif
+                    if (gs < cap_segs) segs[(size_t)gs * 4 + qd] = w;
+                    else if (qd == 0u) flush(b, (uint32_t)kSegRecs);   // (beyond the workspace: the overflow table)
+                    if (qd == 0u) segn[b] = full;   // (the four lanes read `cur` in the same instruction above)
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+                if ((late >> r) & 1u) {
+                    uint32_t *d = slot + bk[r] * 15u + (pos[r] % (uint32_t)kSegRecs) * 3u;
+                    d[0] = rw[r][0];
+                    d[1] = rw[r][1];
+                    d[2] = rw[r][2];
+                }
         };
         __syncthreads();
-        for (int i0 = lo; i0 < hi; i0 += 1024) {
-            const int i = i0 + (int)threadIdx.x;
-            const bool live = i < hi;
-            uint32_t bk[4] = { 0u, 0u, 0u, 0u }, rw[4][3];
-            Pairs pr;
-            float2 gi = make_float2(0.0f, 0.0f);
-            bool straddle = false;
-            if (live) {
+        for (int i0 = lo; i0 < hi; i0 += 1024 * PTS) {
+            uint32_t bk[R], rw[R][3];
+            uint32_t have = 0u, strad = 0u;
+            Pairs pr[PTS];
+            float2 gi[PTS];
+#pragma unroll
+            for (int u = 0; u < PTS; ++u) {
+                const int i = i0 + u * 1024 + (int)threadIdx.x;   // (lane-interleaved: a wave's loads of one u are contiguous)
+                gi[u] = make_float2(0.0f, 0.0f);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) bk[4 * u + q] = 0u;
+                if (i >= hi) continue;
                 const float p[3] = { points[3 * (size_t)i], points[3 * (size_t)i + 1], points[3 * (size_t)i + 2] };
-                gi = LEVEL_MAJOR_GRAD ? grad_in[(size_t)l * g.N + i] : grad_in[(size_t)i * g.L + l];
-                gmax = fmaxf(gmax, fmaxf(fabsf(gi.x), fabsf(gi.y)));
-                make_pairs(p, resolutions + 3 * l, mask, pr);
-                straddle = (pr.xm >> g.bucket_log) != 0u;
-                const uint32_t k = straddle ? 15u : (uint32_t)(31 - __clz((int)pr.xm));
-                const uint32_t t = straddle ? 0u : (uint32_t)min(__float2int_rn(pr.tx * 8388608.0f), 8388607);
-                const float a0 = 1.0f - pr.tx;
+                const bool masked = RAYS && p[0] != p[0];   // (positions by k_src_points: NaN = the ray is masked out)
+                if (RAYS) {   // (gradients from the branch's own dfeat)
+                    gi[u] = i >= src.N1 ? src.grad[1][(size_t)l * (g.N - src.N1) + (i - src.N1)] : src.grad[0][(size_t)l * src.N1 + i];
+                } else {
+                    gi[u] = LEVEL_MAJOR_GRAD ? grad_in[(size_t)l * g.N + i] : grad_in[(size_t)i * g.L + l];
+                }
+                if (!masked) gmax = fmaxf(gmax, fmaxf(fabsf(gi[u].x), fabsf(gi[u].y)));
+                make_pairs(p, resolutions + 3 * l, mask, pr[u]);
+                const bool straddle = (pr[u].xm >> g.bucket_log) != 0u;
+                const uint32_t k = straddle ? 15u : (uint32_t)(31 - __clz((int)pr[u].xm));
+                const uint32_t t = straddle ? 0u : (uint32_t)min(__float2int_rn(pr[u].tx * 8388608.0f), 8388607);
+                const float a0 = 1.0f - pr[u].tx;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const float gx = pr.wyz[q] * gi.x, gy = pr.wyz[q] * gi.y;
-                    bk[q] = pr.idx0[q] >> g.bucket_log;
-                    rw[q][0] = (pr.idx0[q] & lmask) | (k << 13) | ((t >> 8) << 17);
-                    rw[q][1] = rec12_round(straddle ? a0 * gx : gx) | ((t >> 4) & 15u);
-                    rw[q][2] = rec12_round(straddle ? a0 * gy : gy) | (t & 15u);
+                    const float gx = pr[u].wyz[q] * gi[u].x, gy = pr[u].wyz[q] * gi[u].y;
+                    bk[4 * u + q] = pr[u].idx0[q] >> g.bucket_log;
+                    rw[4 * u + q][0] = (pr[u].idx0[q] & lmask) | (k << 13) | ((t >> 8) << 17);
+                    rw[4 * u + q][1] = rec12_round(straddle ? a0 * gx : gx) | ((t >> 4) & 15u);
+                    rw[4 * u + q][2] = rec12_round(straddle ? a0 * gy : gy) | (t & 15u);
+                }
+                if (!masked) {
+                    have |= 15u << (4 * u);
+                    if (straddle) strad |= 15u << (4 * u);
                 }
             }
-            place(bk, rw, live);
+#ifdef SCANERF_EXPERIMENTS
+            if (g.dbg & 8) { if (have == 0x12345u) segs[0] = make_uint4(rw[0][0], rw[1][1], rw[2][2], bk[3]); continue; }
+#endif
+            place(bk, rw, have);
             // x-neighbours in different buckets (only where a level's resolution exceeds the bucket size): the second entries
-            if (__syncthreads_or(straddle)) {
-                if (straddle) {
+            if (__syncthreads_or(strad != 0u)) {
+#pragma unroll
+                for (int u = 0; u < PTS; ++u) {
+                    if (!((strad >> (4 * u)) & 1u)) continue;
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        const uint32_t i1 = pr.idx0[q] ^ pr.xm;
-                        const float gx = pr.wyz[q] * gi.x, gy = pr.wyz[q] * gi.y;
-                        bk[q] = i1 >> g.bucket_log;
-                        rw[q][0] = (i1 & lmask) | (15u << 13);
-                        rw[q][1] = rec12_round(pr.tx * gx);
-                        rw[q][2] = rec12_round(pr.tx * gy);
+                        const uint32_t i1 = pr[u].idx0[q] ^ pr[u].xm;
+                        const float gx = pr[u].wyz[q] * gi[u].x, gy = pr[u].wyz[q] * gi[u].y;
+                        bk[4 * u + q] = i1 >> g.bucket_log;
+                        rw[4 * u + q][0] = (i1 & lmask) | (15u << 13);
+                        rw[4 * u + q][1] = rec12_round(pr[u].tx * gx);
+                        rw[4 * u + q][2] = rec12_round(pr[u].tx * gy);
                     }
                 }
-                place(bk, rw, straddle);
+                place(bk, rw, strad);
             }
         }
-        // (place() ends on a barrier with every full slot flushed: what is left holds 1..4 records)
+        // (after place() every slot holds the 0..4 records of its range's last, incomplete segment)
+        __syncthreads();
         for (int b = threadIdx.x; b < NB; b += 1024) {
             const uint32_t n = cnt[b] - (uint32_t)kSegRecs * segn[b];
             if (n) flush(b, n);
@@ -533,6 +638,9 @@ __global__ void __launch_bounds__(kThreads) k_bin_accumulate(const Rec *__restri
                 atomicAdd(&a[2 * f.l1 + ob], fx(f.w1 * gb));
             }
         };
+#ifdef SCANERF_EXPERIMENTS
+        if (!(g.dbg & 1))
+#endif
         for (int set = 0; set < (two ? 2 : 1); ++set) {   // (one copy of the streaming code for both record sets)
         const float4 *r4 = reinterpret_cast<const float4 *>(set ? ad.recs2 : recs);
         const uint32_t lo = set ? lo2 : lo1, hi = set ? hi2 : hi1;
@@ -656,19 +764,19 @@ __global__ void __launch_bounds__(kThreads) k_bin_accumulate(const Rec *__restri
         }
         __syncthreads();
         const size_t ebase = (size_t)level * g.T + ((size_t)bucket << g.bucket_log) + wbase;  // first entry of the window
+#ifdef SCANERF_EXPERIMENTS
+        if (g.dbg & 2) continue;
+#endif
         if (ADAM) {
             float2 *P = reinterpret_cast<float2 *>(ad.params) + ebase, *Mo = reinterpret_cast<float2 *>(ad.exp_avg) + ebase,
                    *Vo = reinterpret_cast<float2 *>(ad.exp_avg_sq) + ebase;
             float2 *og = overflowed ? reinterpret_cast<float2 *>(ad.overflow_grad) + ebase : nullptr;
-            // Round 6: a thread takes NI PAIRS of neighbouring entries at a time and issues the parameter / moment loads of all of
-            // them (16 bytes each) before the first use.  The loop over single entries that stood here put each entry's three
-            // loads inside the "touched" branch: 8 dependent HBM round trips per thread and bucket at T = 2^24 (32 768 buckets of
-            // 8 192 records: the epilogue, not the record stream, was the launch's time).  Same arithmetic per element.
-            constexpr int NI = 4;
-            auto grad_of = [&](int j, float &gx, float &gy) {
+            // (measured, round 6: issuing the loads of four entry PAIRS per thread before the first use -- 16-byte accesses, no
+            // dependent round trips -- is SLOWER at T = 2^24, 2.85 vs 2.46 ms: the 16 waves already keep enough loads in flight,
+            // and pairs touch 98 % of the fine levels' entries where single entries touch 86 %)
+            for (int j = threadIdx.x; j < ws; j += kThreads) {
                 const long long qx = acc64[2 * j], qy = acc64[2 * j + 1];
-                gx = 0.0f + (float)ldexp((double)qx, -k);   // as grad_features would hold them
-                gy = 0.0f + (float)ldexp((double)qy, -k);
+                float gx = 0.0f + (float)ldexp((double)qx, -k), gy = 0.0f + (float)ldexp((double)qy, -k);  // as grad_features would hold them
                 if (og) {
                     const float2 e = og[j];
                     if (e.x != 0.0f || e.y != 0.0f) {
@@ -677,49 +785,19 @@ __global__ void __launch_bounds__(kThreads) k_bin_accumulate(const Rec *__restri
                         og[j] = make_float2(0.0f, 0.0f);
                     }
                 }
-            };
-            for (int j0 = 2 * (int)threadIdx.x; j0 < ws; j0 += 2 * kThreads * NI) {
-                float g[NI][4];
-                float4 p[NI], m[NI], v[NI];
-                bool hit[NI];
-#pragma unroll
-                for (int i = 0; i < NI; ++i) {
-                    const int j = j0 + 2 * kThreads * i;
-                    hit[i] = false;
-                    if (j < ws) {   // (ws is a power of two >= 2: pairs never straddle the window's end)
-                        grad_of(j, g[i][0], g[i][1]);
-                        grad_of(j + 1, g[i][2], g[i][3]);
-                        hit[i] = g[i][0] != 0.0f || g[i][1] != 0.0f || g[i][2] != 0.0f || g[i][3] != 0.0f;
-                    }
-                }
-#pragma unroll
-                for (int i = 0; i < NI; ++i) {
-                    const int j = j0 + 2 * kThreads * i;
-                    if (hit[i]) {
-                        p[i] = *reinterpret_cast<const float4 *>(P + j);
-                        m[i] = *reinterpret_cast<const float4 *>(Mo + j);
-                        v[i] = *reinterpret_cast<const float4 *>(Vo + j);
-                    }
-                }
-#pragma unroll
-                for (int i = 0; i < NI; ++i) {
-                    const int j = j0 + 2 * kThreads * i;
-                    if (!hit[i]) continue;
-                    adam_update_one<false>(p[i].x, m[i].x, v[i].x, g[i][0], ad.a);
-                    adam_update_one<false>(p[i].y, m[i].y, v[i].y, g[i][1], ad.a);
-                    adam_update_one<false>(p[i].z, m[i].z, v[i].z, g[i][2], ad.a);
-                    adam_update_one<false>(p[i].w, m[i].w, v[i].w, g[i][3], ad.a);
-                    *reinterpret_cast<float4 *>(P + j) = p[i];
-                    *reinterpret_cast<float4 *>(Mo + j) = m[i];
-                    *reinterpret_cast<float4 *>(Vo + j) = v[i];
-                    if (ad.half_table) {   // (an untouched entry of the pair is rewritten with the bits it already holds)
-                        if (ad.half_dtype == SCANERF_F16) {
-                            reinterpret_cast<__half2 *>(ad.half_table)[ebase + j] = __floats2half2_rn(p[i].x, p[i].y);
-                            reinterpret_cast<__half2 *>(ad.half_table)[ebase + j + 1] = __floats2half2_rn(p[i].z, p[i].w);
-                        } else {   // round to nearest even, as torch
-                            reinterpret_cast<__hip_bfloat162 *>(ad.half_table)[ebase + j] = __hip_bfloat162{ __float2bfloat16(p[i].x), __float2bfloat16(p[i].y) };
-                            reinterpret_cast<__hip_bfloat162 *>(ad.half_table)[ebase + j + 1] = __hip_bfloat162{ __float2bfloat16(p[i].z), __float2bfloat16(p[i].w) };
-                        }
+                if (gx != 0.0f || gy != 0.0f) {
+                    float2 p = P[j], m = Mo[j], v = Vo[j];
+                    adam_update_one<false>(p.x, m.x, v.x, gx, ad.a);
+                    adam_update_one<false>(p.y, m.y, v.y, gy, ad.a);
+                    P[j] = p;
+                    Mo[j] = m;
+                    Vo[j] = v;
+                    if (ad.half_table) {
+                        if (ad.half_dtype == SCANERF_F16)
+                            reinterpret_cast<__half2 *>(ad.half_table)[ebase + j] = __floats2half2_rn(p.x, p.y);
+                        else
+                            reinterpret_cast<__hip_bfloat162 *>(ad.half_table)[ebase + j] =
+                                __hip_bfloat162{ __float2bfloat16(p.x), __float2bfloat16(p.y) };  // round to nearest even, as torch
                     }
                 }
             }
@@ -796,6 +874,7 @@ bool fused_geom(int B, int S, int T, BinGeom &g, int arith = SCANERF_ARITH_F32)
     if (g.bucket_log > 16) return false;  // local entry indices are 16-bit; buckets above 2^13 entries are accumulated in windows
     if ((int64_t)B * S * 16 * 4 + (1 << 20) >= (int64_t)1 << 31) return false;  // 32-bit record offsets
     g.N = B * S; g.L = 16; g.T = T;
+    g.dbg = 0;
     g.NB = T >> g.bucket_log;
     g.W = scanerf_render_backward_grid(B);
     g.per_wg = 0;
@@ -839,7 +918,7 @@ SCANERF_API size_t scanerf_embedding_bwd_workspace_bytes(int N, int L, int T)
     size_t recs = ((size_t)N * L * 4 + (size_t)N * L / 8 + 4096) * sizeof(Rec);
     // large tables (one level's counters in LDS at a time): records in 64-byte segments of five, every (bucket, workgroup)
     // range rounded up to whole segments (k_bin_scatter_seg)
-    if ((size_t)nbins * 4 > 64 * 1024) recs = std::max(recs, seg_route_segments(N, L, nbins) * 64);
+    if ((size_t)nbins * 4 > 64 * 1024) recs = std::max(recs, seg_route_segments(N, L, nbins) * 64) + (((size_t)N * 12 + 255) & ~(size_t)255);   // (+ the contracted points of scanerf_table_grad_scatter_adam_rays)
     return recs + (size_t)nbins * W * 4 + (size_t)(2 * nbins + 6) * 4 + 256;
 }
 
@@ -847,20 +926,21 @@ SCANERF_API size_t scanerf_embedding_bwd_workspace_bytes(int N, int L, int T)
 // grad_features: the table the image is added to -- or, with an Adam epilogue, the overflow table (ad->overflow_grad)
 static int binned_backward(const float *points, const float *grad_in, float *grad_features, const int32_t *resolutions, int N,
                            int L, int T, int grad_layout, void *workspace, size_t workspace_bytes, const AdamEpilogue *ad,
-                           scanerf_stream_t stream, int compact_records = 0)
+                           scanerf_stream_t stream, int compact_records = 0, const PointSrc *rays = nullptr)
 {
     SCANERF_REQUIRE(N >= 0 && L >= 1, "embedding_bg_backward_binned: N=%d L=%d", N, L);
     if (N == 0) return 0;
     const size_t need = scanerf_embedding_bwd_workspace_bytes(N, L, T);
     SCANERF_REQUIRE(need != 0, "embedding_bg_backward_binned: shape N=%d L=%d T=%d not supported by the binned path", N, L,
                     T);
-    SCANERF_REQUIRE(points && grad_in && grad_features && resolutions && workspace,
+    SCANERF_REQUIRE((rays || (points && grad_in)) && grad_features && resolutions && workspace,
                     "embedding_bg_backward_binned: null pointer");
     SCANERF_REQUIRE(((uintptr_t)workspace & 15) == 0, "embedding_bg_backward_binned: workspace must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
     BinGeom g;
     g.N = N; g.L = L; g.T = T;
     g.rpg = 1;
+    g.dbg = tune_int("SCANERF_ACC_DBG", 0);
     g.bucket_log = standalone_bucket_log(T);
     // Point-major gradients of 16 levels (round 5): the level-by-level producer (k_bin_scatter) with the fused path's bucket size
     // (2^13 entries: 64 ranges per level at T = 2^19 instead of 256), 256 persistent-size workgroups of 1024 threads (fewer
@@ -884,7 +964,7 @@ static int binned_backward(const float *points, const float *grad_in, float *gra
     // Large tables (round 6): 12-byte records leave the producer as full 64-byte segments (k_bin_scatter_seg, format 3) -- for the
     // level-major gradients of the t16s backward and for the point-major rows of the binding surface (whose default is Rec12
     // as well, see rows16); SCANERF_REC16 / SCANERF_SCATTER_OLD keep the record-at-a-time producer
-    const bool seg_route = (size_t)L * g.NB * 4 > 64 * 1024 && g.bucket_log == 13 && g.NB <= 2048 &&
+    const bool seg_route = (size_t)L * g.NB * 4 > 64 * 1024 && g.bucket_log <= 13 && g.NB <= 2048 &&
                            (compact_records == 2 || (grad_layout == 0 && compact_records == 0)) &&
                            !getenv("SCANERF_REC16") && !getenv("SCANERF_SCATTER_OLD");
     if (seg_route) g.rec8 = 3;
@@ -896,11 +976,14 @@ static int binned_backward(const float *points, const float *grad_in, float *gra
     g.per_wg = (N + g.W - 1) / g.W;
     const int nbins = L * g.NB;
     BinWorkspace w;
-    SCANERF_REQUIRE(bin_workspace_carve(workspace, workspace_bytes, nbins, g.W, w),
+    const size_t pts_tail = rays ? (((size_t)N * 12 + 255) & ~(size_t)255) : 0;
+    SCANERF_REQUIRE(workspace_bytes > pts_tail && bin_workspace_carve(workspace, workspace_bytes - pts_tail, nbins, g.W, w),
                     "embedding_bg_backward_binned: workspace too small (%zu B)", workspace_bytes);
     g.capacity = w.capacity;
     if (g.rec8 == 3 && (g.W > kSegProducers || rec_capacity(g.capacity, 3) < seg_route_segments(N, L, L * g.NB)))
         g.rec8 = (compact_records == 2 && g.bucket_log <= kRec8MaxBucketLog) ? 2 : 0;   // (a caller's smaller workspace: the old producer)
+    SCANERF_REQUIRE(!rays || g.rec8 == 3, "table_grad_scatter_adam_rays: T=%d N=%d needs the large-table producer (T >= 2^22, L = 16, "
+                    "12-byte records, workspace of scanerf_embedding_bwd_workspace_bytes)", T, N);
     uint32_t *counts = w.counts, *totals = w.totals, *starts = w.starts, *maxbits = w.maxbits;
     Rec *recs = w.recs;
 
@@ -908,7 +991,13 @@ static int binned_backward(const float *points, const float *grad_in, float *gra
     const bool per_level = (size_t)nbins * 4 > 64 * 1024;
     const size_t lds_bins = per_level ? (size_t)g.NB * 4 : (size_t)nbins * 4;
     const float2 *gi = reinterpret_cast<const float2 *>(grad_in);
-    if (per_level)
+    if (rays) {
+        // the contracted points of both branches, once, into the workspace's tail (read 2 x 16 times from the L2s afterwards)
+        float *pts = reinterpret_cast<float *>(static_cast<char *>(workspace) + workspace_bytes - (((size_t)N * 12 + 255) & ~(size_t)255));
+        hipLaunchKernelGGL(k_src_points, dim3(stream_grid(N, 256)), dim3(256), 0, st, *rays, pts, N);
+        points = pts;
+        hipLaunchKernelGGL((k_bin_count<true, true>), dim3(g.W), dim3(1024), lds_bins, st, points, resolutions, g, counts, maxbits, overflow_flag(recs));
+    } else if (per_level)
         hipLaunchKernelGGL((k_bin_count<true>), dim3(g.W), dim3(1024), lds_bins, st, points, resolutions, g, counts, maxbits, overflow_flag(recs));
     else
         hipLaunchKernelGGL((k_bin_count<false>), dim3(g.W), dim3(rows16 ? 1024 : kThreads), lds_bins, st, points, resolutions, g, counts, maxbits, overflow_flag(recs));   // (256 producer workgroups: give them all 16 waves)
@@ -916,16 +1005,24 @@ static int binned_backward(const float *points, const float *grad_in, float *gra
     hipLaunchKernelGGL(k_bin_starts, dim3(1), dim3(1024), 0, st, totals, starts, nbins);
     if (g.rec8 == 3) {
         const size_t lds_seg = (size_t)g.NB * 18 * 4;   // cnt, segn, gbase, 15-word slots
-        for (const void *fn : { reinterpret_cast<const void *>(&k_bin_scatter_seg<true>), reinterpret_cast<const void *>(&k_bin_scatter_seg<false>) }) {
-            hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_seg);
-            SCANERF_REQUIRE(e == hipSuccess, "embedding_bg_backward_binned: cannot reserve %zu B of LDS: %s", lds_seg, hipGetErrorString(e));
+        const int pts = tune_int("SCANERF_SEG_PTS", 2);   // points per lane and batch
+        const PointSrc none{};
+#define SCANERF_LAUNCH_SEG(LM, RY, PT)                                                                                          \
+    {                                                                                                                           \
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bin_scatter_seg<LM, RY, PT>),                        \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_seg);                          \
+        SCANERF_REQUIRE(e == hipSuccess, "embedding_bg_backward_binned: cannot reserve %zu B of LDS: %s", lds_seg, hipGetErrorString(e)); \
+        hipLaunchKernelGGL((k_bin_scatter_seg<LM, RY, PT>), dim3(g.W), dim3(1024), lds_seg, st, points, gi, resolutions, g, counts, \
+                           starts, recs, grad_features, maxbits, rays ? *rays : none);                                          \
+    }
+        if (rays) {
+            if (pts == 1) SCANERF_LAUNCH_SEG(true, true, 1) else if (pts == 4) SCANERF_LAUNCH_SEG(true, true, 4) else SCANERF_LAUNCH_SEG(true, true, 2)
+        } else if (grad_layout == 1) {
+            if (pts == 1) SCANERF_LAUNCH_SEG(true, false, 1) else if (pts == 4) SCANERF_LAUNCH_SEG(true, false, 4) else SCANERF_LAUNCH_SEG(true, false, 2)
+        } else {
+            SCANERF_LAUNCH_SEG(false, false, 2)
         }
-        if (grad_layout == 1)
-            hipLaunchKernelGGL((k_bin_scatter_seg<true>), dim3(g.W), dim3(1024), lds_seg, st, points, gi, resolutions, g, counts, starts,
-                               recs, grad_features, maxbits);
-        else
-            hipLaunchKernelGGL((k_bin_scatter_seg<false>), dim3(g.W), dim3(1024), lds_seg, st, points, gi, resolutions, g, counts, starts,
-                               recs, grad_features, maxbits);
+#undef SCANERF_LAUNCH_SEG
     } else if (rows16 && g.rec8 == 2)
         hipLaunchKernelGGL((k_bin_scatter<false, false, 2>), dim3(g.W), dim3(1024), lds_bins, st, points, gi, resolutions, g,
                            counts, starts, recs, grad_features, maxbits);
@@ -1005,6 +1102,38 @@ SCANERF_API int scanerf_embedding_bg_backward_binned_adam(const float *points, c
                            make_adam_args(lr, beta1, beta2, eps, step) };
     return binned_backward(points, grad_in, overflow_grad, resolutions, N, L, T, grad_layout, workspace, workspace_bytes, &ad, stream,
                            compact_records);
+}
+
+// The same for the samples of up to two render branches over the same rays (PointSrc above): positions from rays and depths,
+// gradients = each branch's level-major dfeat; both branches' gradients meet in ONE Adam step (tile.py:639-692, :1010).  Tables of
+// at least 2^22 entries per level (below, the backward kernel emits its own records: scanerf_render_scatter_*).
+SCANERF_API int scanerf_table_grad_scatter_adam_rays(const float *rays_o, const float *rays_d, int B, const float *z1, const float *dfeat1,
+                                                     const uint8_t *valid1, int S1, int contract_mode1, const float *z2,
+                                                     const float *dfeat2, const uint8_t *valid2, int S2, int contract_mode2,
+                                                     const float *min_bbox, const float *bbox_size, const int32_t *resolutions, int T,
+                                                     void *workspace, size_t workspace_bytes, float *params, float *exp_avg,
+                                                     float *exp_avg_sq, void *half_table, int half_dtype, float *overflow_grad, float lr,
+                                                     float beta1, float beta2, float eps, int step, scanerf_stream_t stream)
+{
+    SCANERF_REQUIRE(B >= 0 && S1 >= 1 && (!z2 || S2 >= 1), "table_grad_scatter_adam_rays: B=%d S1=%d S2=%d", B, S1, S2);
+    if (B == 0) return 0;
+    SCANERF_REQUIRE(rays_o && rays_d && z1 && dfeat1 && (!z2 || dfeat2) && min_bbox && bbox_size && params && exp_avg && exp_avg_sq &&
+                    overflow_grad, "table_grad_scatter_adam_rays: null pointer");
+    SCANERF_REQUIRE(!half_table || half_dtype == SCANERF_F16 || half_dtype == SCANERF_BF16, "table_grad_scatter_adam_rays: half_dtype=%d", half_dtype);
+    const int64_t N = (int64_t)B * S1 + (z2 ? (int64_t)B * S2 : 0);
+    SCANERF_REQUIRE(N < ((int64_t)1 << 31) / 64, "table_grad_scatter_adam_rays: %lld points", (long long)N);
+    PointSrc src{};
+    src.rays_o = rays_o; src.rays_d = rays_d;
+    src.z[0] = z1; src.z[1] = z2;
+    src.valid[0] = valid1; src.valid[1] = valid2;
+    src.grad[0] = reinterpret_cast<const float2 *>(dfeat1); src.grad[1] = reinterpret_cast<const float2 *>(dfeat2);
+    src.S[0] = S1; src.S[1] = z2 ? S2 : 1;
+    src.mode[0] = contract_mode1; src.mode[1] = contract_mode2;
+    src.N1 = B * S1;
+    for (int k = 0; k < 3; ++k) { src.min_bbox[k] = min_bbox[k]; src.bbox_size[k] = bbox_size[k]; }
+    const AdamEpilogue ad{ nullptr, nullptr, nullptr, 0u, params, exp_avg, exp_avg_sq, half_table, half_dtype, overflow_grad,
+                           make_adam_args(lr, beta1, beta2, eps, step) };
+    return binned_backward(nullptr, nullptr, overflow_grad, resolutions, (int)N, 16, T, 1, workspace, workspace_bytes, &ad, stream, 2, &src);
 }
 
 // Launch-shape hint for the accumulate: which record format the last plan on a workspace chose.  The kernel decodes by the

@@ -23,6 +23,7 @@ struct BinGeom {
     int per_wg;       // samples per producer workgroup
     int rpg;          // fused producer: rays per workgroup visit (ray = (wg + i*W)*rpg + r): 1 f32 kernel, 4 h3 kernel
     uint32_t capacity;  // records that fit the workspace
+    int dbg;
     int rec8;         // record format: 0 = Rec (16 bytes), 1 = Rec8 (8 bytes), 2 = Rec12 (12 bytes), 3 = Rec12 in 64-byte segments of five (kSegRecs), -1 = read format_word() (accumulate of a fused plan)
 };
 // Format 3 (round 6, large tables): a (bucket, workgroup) range is a whole number of 64-BYTE SEGMENTS, each holding five Rec12
@@ -30,6 +31,7 @@ struct BinGeom {
 // segment in its LDS and writes it with ONE aligned 64-byte store (k_bin_scatter_seg); unused record slots of a range's last
 // segment are all-zero words, which the accumulate skips (a record whose two gradient words are zero adds nothing).
 constexpr int kSegRecs = 5;
+// (BinGeom.dbg: timing experiments of a -DSCANERF_EXPERIMENTS build only -- wrong results; always 0 in the product build)
 
 struct Rec {
     uint32_t hdr;

@@ -377,6 +377,46 @@ def scatter_table_grad_adam(points, dfeat, resolutions, params, exp_avg, exp_avg
         ctypes.c_int(int(compact_records)), stream()), "scatter_table_grad_adam")
 
 
+def scatter_rays_supported(T, arith_code):
+    """scatter_table_grad_adam_rays applies: tables of at least 2^22 entries per level (one level's counters in the producer's LDS
+    at a time) behind the f32-grade backward (12-byte records)."""
+    return T >= (1 << 22) and compact_record_format(arith_code) == 2 and not _os.environ.get("SCANERF_NO_RAYS_SCATTER") and not _os.environ.get("SCANERF_REC16")
+
+
+def scatter_table_grad_adam_rays(rays_o, rays_d, branches, min_bbox, bbox_size, resolutions, params, exp_avg, exp_avg_sq, lr, beta1,
+                                 beta2, eps, step, half_table=None, overflow_grad=None):
+    """The table gradient of one or two render branches over the same rays, scattered and applied by ONE sparse Adam step
+    (scanerf_table_grad_scatter_adam_rays; tile.py:639-692, :1010).  branches: [(z [B,S], dfeat [16,B*S,2], ray_valid [B] or None,
+    contract mode FORE / BG), ...] -- no contracted-point tensors, no concatenation."""
+    B, T = rays_o.shape[0], params.shape[1]
+    if not 1 <= len(branches) <= 2 or params.shape[0] != 16:
+        raise RuntimeError("scanerf: scatter_table_grad_adam_rays takes one or two branches and 16 levels")
+    N = sum(B * z.shape[1] for z, _, _, _ in branches)
+    need = lib().scanerf_embedding_bwd_workspace_bytes(ctypes.c_int(N), ctypes.c_int(16), ctypes.c_int(T))
+    if not need:
+        raise RuntimeError("scanerf: shape not supported by the binned scatter")
+    ws = _capi.workspace(rays_o.device, need, "scatter")
+    args = []
+    for k in range(2):
+        if k < len(branches):
+            z, dfeat, valid, mode = branches[k]
+            if tuple(dfeat.shape) != (16, B * z.shape[1], 2) or z.shape[0] != B:
+                raise RuntimeError(f"scanerf: branch {k}: dfeat {tuple(dfeat.shape)} does not match z {tuple(z.shape)}")
+            args += [dev_ptr(z, _f32, f"z{k}"), dev_ptr(dfeat, _f32, f"dfeat{k}"),
+                     dev_ptr(valid, (torch.bool, torch.uint8), f"valid{k}", allow_none=True), ctypes.c_int(z.shape[1]), ctypes.c_int(int(mode))]
+        else:
+            args += [None, None, None, ctypes.c_int(0), ctypes.c_int(0)]
+    mn, sz = (ctypes.c_float * 3)(*[float(v) for v in min_bbox]), (ctypes.c_float * 3)(*[float(v) for v in bbox_size])
+    check(lib().scanerf_table_grad_scatter_adam_rays(
+        dev_ptr(rays_o, _f32, "rays_o"), dev_ptr(rays_d, _f32, "rays_d"), ctypes.c_int(B), *args, mn, sz,
+        dev_ptr(resolutions, torch.int32, "resolutions"), ctypes.c_int(T), ctypes.c_void_p(ws.data_ptr()), ctypes.c_size_t(ws.numel()),
+        dev_ptr(params, _f32, "params"), dev_ptr(exp_avg, _f32, "exp_avg"), dev_ptr(exp_avg_sq, _f32, "exp_avg_sq"),
+        dev_ptr(half_table, (torch.float16, torch.bfloat16), "half_table", allow_none=True),
+        ctypes.c_int(feat_dtype_code(half_table) if half_table is not None else 0), dev_ptr(overflow_grad, _f32, "overflow_grad"),
+        ctypes.c_float(lr), ctypes.c_float(beta1), ctypes.c_float(beta2), ctypes.c_float(eps), ctypes.c_int(step), stream()),
+        "scatter_table_grad_adam_rays")
+
+
 def ray_gradients_fused(rays_o, rays_d, blob, ray_pos_grad, g_dnorm, g_rowsum, ray_valid=None):
     """dL/d(rays_o), dL/d(rays_d) when the backward kernel produced the position path itself (render_backward(jstash=...,
     ray_pos_grad=...)): adds the two per-ray paths -- |d| through delta = dist * |d| and SH(d / |d|) of the decoder -- in one

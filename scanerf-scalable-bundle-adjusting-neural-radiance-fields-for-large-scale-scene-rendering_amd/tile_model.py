@@ -494,7 +494,14 @@ def train_step_fused(model, dec_opt, rays_o, rays_d, target, S, global_step, tab
                 render.scatter_accumulate_adam(ws, model.features.data, model.exp_avg, model.exp_avg_sq, table_lr, 0.9, 0.99, 1e-15,
                                                model.adam_step, B, S, half_table=model._half_table, overflow_grad=gtab)
             model.adam_step += 1
-        elif adam_epilogue:   # large tables: stand-alone binned scatter from dfeat, same epilogue
+        elif adam_epilogue and render.scatter_rays_supported(T, bwd_arith) and model._half_table is None:
+            # large tables: the stand-alone scatter places the samples itself (rays + depths), same epilogue
+            with _sec(timer, "table_grad_scatter_adam", B * S * 16 * (8 + 16 * 8)):
+                render.scatter_table_grad_adam_rays(rays_o, rays_d, [(z, dfeat, valid, render.FORE)], box[0], box[1], model.resolution,
+                                                    model.features.data, model.exp_avg, model.exp_avg_sq, table_lr, 0.9, 0.99, 1e-15,
+                                                    model.adam_step, overflow_grad=gtab)
+            model.adam_step += 1
+        elif adam_epilogue:   # (the other record formats: contracted points from torch, stand-alone binned scatter from dfeat)
             pts = ((rays_o[:, None, :] + z[:, :, None] * rays_d[:, None, :]).reshape(-1, 3) - model._min_dev) \
                 / model._size_dev * 4.0 - 2.0
             with _sec(timer, "table_grad_scatter_adam", B * S * 16 * (8 + 16 * 8)):
@@ -522,13 +529,14 @@ def train_step_fused(model, dec_opt, rays_o, rays_d, target, S, global_step, tab
 
 
 def fgbg_gradients(model, rays_o, rays_d, target, S_fg, S_bg, global_step, invalid_underground=False, timer=None,
-                   pose_grads=False, collect=None):
+                   pose_grads=False, collect=None, collect_rays=False):
     """Loss and parameter gradients of the complete per-tile render of tile.py:639-692 / :880-1015: foreground
     (occupancy-sampled, contract_fore) + T_left * background (inverse-z, contract_bg, infinity), MSE on the merged colour
     over all rays + 0.01 * (l2_reg_specular of both branches) -- two fused forward/backward pairs over the same table and
     decoder.  Returns (loss, grad_table [16,T,2], grad_blob [13994]) (+ dL/d(rays_o), dL/d(rays_d) with pose_grads: t16
     backward on the fp32 table, any table size).  collect: a list that receives (contracted points [N,3], dfeat [16,N,2]) of
-    each branch INSTEAD of their scatter into the gradient table (the caller scatters them together: large tables)."""
+    each branch INSTEAD of their scatter into the gradient table (the caller scatters them together: large tables); with
+    collect_rays it receives (z [B,S], dfeat, ray_valid, contract mode) -- the input of render.scatter_table_grad_adam_rays."""
     B = rays_o.shape[0]
     dev = model.device
     T = model.features.shape[1]
@@ -581,6 +589,8 @@ def fgbg_gradients(model, rays_o, rays_d, target, S_fg, S_bg, global_step, inval
                 g_o, g_d = (go_b, gd_b) if g_o is None else (g_o + go_b, g_d + gd_b)
             if fused:
                 render.scatter_accumulate(ws, gtab, B, S)
+            elif collect is not None and collect_rays:
+                collect.append((z_, dfeat, v_, mode))   # (scatter_table_grad_adam_rays places the samples itself)
             else:
                 pts = (rays_o[:, None, :] + z_[:, :, None] * rays_d[:, None, :]).reshape(-1, 3)
                 pts = (pts - model._min_dev) / model._size_dev * 4.0 - 2.0
@@ -615,11 +625,18 @@ def train_step_fgbg(model, dec_opt, rays_o, rays_d, target, S_fg, S_bg, global_s
         # stand-alone binned scatter that ends in the sparse Adam (no gradient table, no zero-fill, no dense optimiser scan)
         binned = T > (1 << 21) and render.backward_arith() != render._capi.ARITH_F32 and model._half_table is None
         parts = [] if binned else None
+        by_rays = binned and render.scatter_rays_supported(T, render.backward_arith())
         r = fgbg_gradients(model, rays_o, rays_d, target, S_fg, S_bg, global_step, invalid_underground, timer, pose_grads=pose_grads,
-                           collect=parts)
+                           collect=parts, collect_rays=by_rays)
         loss, gtab, gblob = r[:3]
         with torch.no_grad():
-            if binned:
+            if by_rays:
+                with _sec(timer, "table_grad_scatter_adam", B * (S_fg + S_bg) * 16 * (8 + 16 * 8)):
+                    render.scatter_table_grad_adam_rays(rays_o, rays_d, parts, model.min_bbox.tolist(), model.bbox_size.tolist(),
+                                                        model.resolution, model.features.data, model.exp_avg, model.exp_avg_sq, table_lr,
+                                                        0.9, 0.99, 1e-15, model.adam_step, overflow_grad=model.overflow_grad())
+                model.adam_step += 1
+            elif binned:
                 pts = torch.cat([p_ for p_, _ in parts], 0)
                 dfe = torch.cat([f_ for _, f_ in parts], 1).contiguous()
                 with _sec(timer, "table_grad_scatter_adam", pts.shape[0] * 16 * (8 + 16 * 8)):

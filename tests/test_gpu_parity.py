@@ -1591,3 +1591,102 @@ def test_split_pass_feeding_the_adam_epilogue(log2_T, finest, fgbg, monkeypatch)
             assert float((p0 - p1).abs()[big].max()) <= ptol, (route, no_split, it, float((p0 - p1).abs()[big].max()))
             assert float(((p0 != init) != (p1 != init)).float().mean()) < 1e-3
         del other
+
+
+@pytest.mark.parametrize("layout,log2_T,N", [(1, 22, 300_007), (0, 22, 70_001), (1, 24, 120_011), (1, 22, 777)])
+def test_large_table_producer_writes_whole_segments(S, layout, log2_T, N, monkeypatch):
+    """Round 6: above 2^21 entries per level the stand-alone producer keeps one five-record slot per bucket in LDS and writes
+    each full slot as one 64-byte segment (csrc/scatter.hip k_bin_scatter_seg, record format 3).  The SAME set of 12-byte records
+    reaches the integer accumulate as through the record-at-a-time producer (SCANERF_SCATTER_OLD=1), so parameters and both
+    moments after two Adam steps are bit-equal between the routes -- over several rounds per batch (300 007 points: ~2.3 records
+    per bucket and batch), points on the upper faces (x + 1 in the next bucket at T = 2^22), fewer points than one batch per
+    workgroup (777), point-major rows (layout 0) -- and the first moment follows the oracle's sequential scatter."""
+    from scanerf_amd import render
+    rng = np.random.default_rng(61)
+    L, T = 16, 2 ** log2_T
+    res = O.level_resolutions(torch.tensor([32, 32, 32]), torch.tensor([2048, 2048, 2048])).numpy()
+    pts = rng.uniform(-2, 2, (N, 3)).astype(np.float32)
+    pts[:50] = 2.0
+    gin = (rng.normal(size=(N, L, 2)) * np.exp(rng.uniform(-6, 0, (N, L, 1)))).astype(np.float32)
+    gin[100:140] = 0.0    # records with an exactly zero gradient: skipped by the accumulate, entries stay untouched
+    P, R = g(pts), g(res)
+    gi = g(np.ascontiguousarray(gin.transpose(1, 0, 2)) if layout == 1 else gin)
+    out = {}
+    for old in (False, True):
+        if old:
+            monkeypatch.setenv("SCANERF_SCATTER_OLD", "1")
+        params, m1, m2 = (torch.zeros(L, T, 2, device=DEV) for _ in range(3))
+        over = torch.zeros(L, T, 2, device=DEV)
+        for step in range(2):
+            if layout == 1:
+                render.scatter_table_grad_adam(P, gi, R, params, m1, m2, 1e-2, 0.9, 0.99, 1e-15, step, overflow_grad=over, compact_records=2)
+            else:
+                import ctypes
+                from scanerf_amd._capi import check, lib, stream, workspace
+                need = lib().scanerf_embedding_bwd_workspace_bytes(N, L, T)
+                ws = workspace(DEV, need)
+                check(lib().scanerf_embedding_bg_backward_binned_adam(
+                    ctypes.c_void_p(P.data_ptr()), ctypes.c_void_p(gi.data_ptr()), ctypes.c_void_p(R.data_ptr()), N, L, T, 0,
+                    ctypes.c_void_p(ws.data_ptr()), ctypes.c_size_t(ws.numel()), ctypes.c_void_p(params.data_ptr()),
+                    ctypes.c_void_p(m1.data_ptr()), ctypes.c_void_p(m2.data_ptr()), None, 0, ctypes.c_void_p(over.data_ptr()),
+                    ctypes.c_float(1e-2), ctypes.c_float(0.9), ctypes.c_float(0.99), ctypes.c_float(1e-15), step, 2, stream()), "binned_adam")
+        assert not bool(over.any())
+        out[old] = (params.clone(), m1.clone(), m2.clone())
+    for a, b in zip(out[False], out[True]):
+        if layout == 1:
+            assert torch.equal(a, b)
+        else:   # (the old producer keeps 16-byte records for point-major rows of a large table: same sums to the records' rounding)
+            assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max())
+    if N <= 130_000 and log2_T == 22:
+        feat = np.zeros((L, T, 2), np.float32)
+        _, gf_ref = O.embedding_backward(pts, gin, feat, res)
+        got = out[False][1].cpu().numpy() / 0.19     # m after two steps on the same gradient: (0.1 + 0.9 * 0.1) g
+        assert float(np.abs(got - gf_ref).max()) / float(np.abs(gf_ref).max()) <= 4e-6
+
+
+@pytest.mark.parametrize("two", [True, False])
+def test_ray_source_scatter_equals_points_and_concatenation(S, two):
+    """scanerf_table_grad_scatter_adam_rays (round 6): the large-table scatter + sparse Adam fed with rays, depths and each branch's
+    dfeat places the samples itself (contract_fore / contract_bg as the render kernels) -- against torch's contracted points and
+    the concatenation of both branches' points and gradients through scanerf_embedding_bg_backward_binned_adam: bit-equal
+    parameters and moments after two steps.  Rays masked out by ray_valid leave no records (their dfeat rows hold garbage here)."""
+    from scanerf_amd import render
+    gen = torch.Generator().manual_seed(77)
+    B, S1, S2, T = 700, 48, 40, 2 ** 22
+    res = g(O.level_resolutions(torch.tensor([32, 32, 32]), torch.tensor([2048, 2048, 2048])).numpy())
+    mn, sz = torch.tensor([-8.0, -8.0, -8.0]), torch.tensor([16.0, 16.0, 16.0])
+    o = (torch.rand(B, 3, generator=gen) * 8 - 4).to(DEV)
+    d = torch.nn.functional.normalize(torch.randn(B, 3, generator=gen), dim=-1).to(DEV)
+    z1 = (torch.rand(B, S1, generator=gen) * 3).to(DEV)
+    z2 = (8 + torch.rand(B, S2, generator=gen) * 50).to(DEV)
+    v1 = (torch.rand(B, generator=gen) > 0.2).to(DEV)
+    d1 = torch.randn(16, B * S1, 2, generator=gen).to(DEV)
+    d2 = torch.randn(16, B * S2, 2, generator=gen).to(DEV)
+
+    def pts_of(z, bg):
+        p = (o[:, None, :] + z[:, :, None] * d[:, None, :]).reshape(-1, 3)
+        p = (p - mn.to(DEV)) / sz.to(DEV) * 4.0 - 2.0
+        if bg:
+            linf = p.abs().amax(-1, keepdim=True)
+            p = p * ((2.0 - 1.0 / linf) / linf)
+        return p
+    d1_ref = d1.clone()
+    d1_ref.reshape(16, B, S1, 2)[:, ~v1] = 0.0    # the points route has no mask: zero gradients there
+    out = {}
+    for rays in (True, False):
+        params, m1, m2 = (torch.zeros(16, T, 2, device=DEV) for _ in range(3))
+        over = torch.zeros(16, T, 2, device=DEV)
+        for step in range(2):
+            if rays:
+                br = [(z1, d1, v1, render.FORE)] + ([(z2, d2, None, render.BG)] if two else [])
+                render.scatter_table_grad_adam_rays(o, d, br, mn.tolist(), sz.tolist(), res, params, m1, m2, 1e-2, 0.9, 0.99, 1e-15, step,
+                                                    overflow_grad=over)
+            else:
+                pts = torch.cat([pts_of(z1, False)] + ([pts_of(z2, True)] if two else []), 0).contiguous()
+                dfe = torch.cat([d1_ref] + ([d2] if two else []), 1).contiguous()
+                render.scatter_table_grad_adam(pts, dfe, res, params, m1, m2, 1e-2, 0.9, 0.99, 1e-15, step, overflow_grad=over, compact_records=2)
+        assert not bool(over.any())
+        out[rays] = (params, m1, m2)
+    for a, b in zip(out[True], out[False]):
+        assert torch.equal(a, b)
+    assert int((out[True][1] != 0).sum()) > 100_000
