@@ -36,7 +36,19 @@ typedef void *scanerf_stream_t; /* hipStream_t */
 #define SCANERF_BF16 2
 
 const char *scanerf_last_error(void);
-int scanerf_abi_version(void);
+int scanerf_abi_version(void); /* 9 */
+/* Options.  The library keeps no global or per-process state and reads no environment variable: what a caller may choose is an
+ * argument of the call it affects --
+ *   decoder arithmetic of the fused training kernels      scanerf_render_cfg.arith (SCANERF_ARITH_*)
+ *   levels masked by the coarse-to-fine schedule          scanerf_render_cfg.skip_levels
+ *   decoder arithmetic of the render-time inference ops   SCANERF_INFER_H3 / SCANERF_INFER_F32 in `sample_major`
+ *   per-sample array layout of the render-time ops        `sample_major` (0 / 1 / 2), SCANERF_SKIP_UNSAMPLED
+ *   table-gradient record format of the stand-alone op    `compact_records` (-1 default / 0 / 1 / 2)
+ *   large-table route (dfeat + stand-alone scatter, or the backward's own records + split pass): which entry points are called
+ * Launch shapes, alternative producers and timing builds of the A/B experiments exist only in a library built with
+ * `make EXP=1` (-DSCANERF_EXPERIMENTS), where they are read from the environment; scanerf_experiments_enabled() tells which
+ * build this is (0 = product build). */
+int scanerf_experiments_enabled(void);
 
 /* ---- CUDA_EXT surface ------------------------------------------------------------ */
 
@@ -104,7 +116,11 @@ int scanerf_embedding_bg_backward(const float *points, const float *grad_in, flo
 size_t scanerf_embedding_bwd_workspace_bytes(int N, int L, int T);
 int scanerf_embedding_bg_backward_binned(const float *points, const float *grad_in, float *grad_features,
                                          const int32_t *resolutions, int N, int L, int T, int grad_layout,
-                                         void *workspace, size_t workspace_bytes, scanerf_stream_t stream);
+                                         void *workspace, size_t workspace_bytes,
+                                         int compact_records /* record format: -1 = the layout's default (12-byte records for point-major
+                                            rows of 16 levels, 16-byte ones for level-major gradients), 0 = 16-byte (exact products),
+                                            1 = 8-byte (level-major only), 2 = 12-byte: csrc/scatter_common.h */,
+                                         scanerf_stream_t stream);
 /* The same ending in the fused sparse Adam (the bucket images are the touched-entry list: no gradient table, no zero-fill, no
  * scan; per element the IEEE sequence of scanerf_adam_step, `step` = previous count).  half_table (may be NULL): f16 / bf16
  * gather copy refreshed where params change.  overflow_grad: zero [L][T][2] f32 table, written (and consumed) only if the
@@ -369,6 +385,12 @@ int scanerf_pts_inference(const float *rays_o, const float *rays_d, const float 
  * depths from index 0) -- the inference leaves its outputs unwritten and the accumulation does not read them, instead of 28 bytes
  * of zeros written and read per sample slot of such a ray.  Same per-ray results. */
 #define SCANERF_SKIP_UNSAMPLED 4
+/* Decoder arithmetic of scanerf_pts_inference / scanerf_pts_inference_tracing / scanerf_bg_pts_inference_v2, OR-ed into their
+ * `sample_major` as well: none = 16-sample tiles at four waves per SIMD, every product on split-f16 MFMA (default; 1e-4 of the
+ * reference); SCANERF_INFER_H3 = the 32-sample-tile kernel at two waves per SIMD (same arithmetic, round 4's kernel);
+ * SCANERF_INFER_F32 = the single-pass f32-input MFMA kernel (exact f32; [B][S] arrays only, also what > 64 tiles fall back to). */
+#define SCANERF_INFER_H3 8
+#define SCANERF_INFER_F32 16
 /* prepare_points + pts_inference as ONE launch (no reference counterpart; the renderer's own route): the slot lists are derived
  * in the kernel from running_mask [B] and intersections [B,nb,2] at every use instead of being written and read back (8 bytes per
  * sample, once per tile step).  Same values as the two ops in sequence.  Needs the 16-sample-tile kernel (the default) and

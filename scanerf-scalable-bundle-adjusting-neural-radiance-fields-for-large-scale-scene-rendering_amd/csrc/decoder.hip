@@ -711,14 +711,15 @@ SCANERF_API int scanerf_decoder_forward(const float *feats, int ld_feats, const 
     DecArgs a = {};
     a.feats = feats; a.ld_feats = ld_feats; a.dirs = dirs; a.ld_dirs = ld_dirs; a.packed = workspace; a.N = N;
     a.sigma = sigma; a.dif = diffuse; a.spec = specular; a.tint = tint;
-    const char *e = getenv("SCANERF_DECODER_FWD");
-    if (e && e[0] == 's') {   // 16-sample tiles at four waves per SIMD (see k_decoder_fwd_s16)
+#ifdef SCANERF_EXPERIMENTS
+    if (tune_int("SCANERF_DECODER_FWD_S16", 0)) {   // 16-sample tiles at four waves per SIMD (see k_decoder_fwd_s16; experiments build)
         const long long nt16 = (N + 15) >> 4;
         long long b16 = (nt16 + 7) / 8;
         if (b16 > 2 * kNumCU) b16 = 2 * kNumCU;   // two resident 512-thread workgroups per CU (77 KB of LDS each), persistent
         hipLaunchKernelGGL(k_decoder_fwd_s16, dim3((int)b16), dim3(kFwd16Threads), 0, (hipStream_t)stream, a);
         return check_launch("decoder_forward(s16)");
     }
+#endif
     const long long ntiles = (N + 31) >> 5;
     long long blocks = (ntiles + 7) / 8;
     if (blocks > 2 * kNumCU) blocks = 2 * kNumCU;

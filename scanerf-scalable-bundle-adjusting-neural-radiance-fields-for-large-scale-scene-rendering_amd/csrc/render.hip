@@ -473,17 +473,17 @@ static int render_forward(const float *rays_o, const float *rays_d, const float 
     a.out_ray = out_ray; a.weights = weights; a.tile_T = tile_T; a.xstash = xstash; a.jstash = static_cast<uint32_t *>(jstash);
     a.B = B; a.S = S; a.T = T;
     a.contract_mode = cfg->contract_mode; a.infinity = cfg->infinity;
-    a.skip_levels = getenv("SCANERF_NO_LEVEL_SKIP") ? 0u : pair_masked_levels(cfg->skip_levels);
+    a.skip_levels = tune_set("SCANERF_NO_LEVEL_SKIP") ? 0u : pair_masked_levels(cfg->skip_levels);
     for (int k = 0; k < 3; ++k) {
         a.min_bbox[k] = cfg->min_bbox[k];
         a.bbox_size[k] = cfg->bbox_size[k];
         a.inv_size4[k] = 4.0f / cfg->bbox_size[k];
     }
-    { const char *e = getenv("SCANERF_DEBUG_FWD"); a.dbg = e ? atoi(e) : 0; }
+    a.dbg = tune_int("SCANERF_DEBUG_FWD", 0);
     const int waves_per_block = kRenderThreads / 64;
     int blocks = ceil_div(B, waves_per_block);
     if (blocks > kNumCU) blocks = kNumCU;  // one resident 512-thread workgroup per CU (VGPR-bound), persistent
-    if (const char *e = getenv("SCANERF_FWD_GRID")) { const int v = atoi(e); if (v >= 1 && v < blocks) blocks = v; }   // (render_bwd.hip scanerf_render_backward_grid)
+    { const int v = tune_int("SCANERF_FWD_GRID", 0); if (v >= 1 && v < blocks) blocks = v; }   // (render_bwd.hip scanerf_render_backward_grid)
     dim3 grid(blocks), block(kRenderThreads);
     hipStream_t st = (hipStream_t)stream;
     SCANERF_REQUIRE(cfg->arith >= SCANERF_ARITH_F32 && cfg->arith <= SCANERF_ARITH_T16S, "render_forward: arith=%d", cfg->arith);
@@ -546,7 +546,7 @@ SCANERF_API int scanerf_render_forward_plan_supported(int B, int S, int T)
 {
     if (scanerf_render_scatter_workspace_bytes(B, S, T) == 0) return 0;
     int fwd_grid = ceil_div(B, kRenderThreads / 64) > kNumCU ? kNumCU : ceil_div(B, kRenderThreads / 64);
-    if (const char *e = getenv("SCANERF_FWD_GRID")) { const int v = atoi(e); if (v >= 1 && v < fwd_grid) fwd_grid = v; }
+    { const int v = tune_int("SCANERF_FWD_GRID", 0); if (v >= 1 && v < fwd_grid) fwd_grid = v; }
     if (fwd_grid != scanerf_render_backward_grid(B)) return 0;
     return 1;  // (NB <= 256 buckets per level whatever T: scatter_common.h fused_bucket_log)
 }

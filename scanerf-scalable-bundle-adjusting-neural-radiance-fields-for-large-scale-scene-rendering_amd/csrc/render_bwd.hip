@@ -618,7 +618,7 @@ int launch_render_bwd_f32(const BwdArgs &a, int feat_dtype, int blocks, size_t l
 SCANERF_API int scanerf_render_backward_grid(int B)
 {
     int cap = kNumCU;
-    if (const char *e = getenv("SCANERF_BWD_GRID")) { const int v = atoi(e); if (v >= 1 && v < cap) cap = v; }
+    { const int v = tune_int("SCANERF_BWD_GRID", 0); if (v >= 1 && v < cap) cap = v; }
     return B > cap ? cap : (B < 1 ? 1 : B);
 }
 
@@ -654,7 +654,7 @@ SCANERF_API int scanerf_render_backward(const float *rays_o, const float *rays_d
         a.f.bbox_size[k] = cfg->bbox_size[k];
         a.f.inv_size4[k] = 4.0f / cfg->bbox_size[k];
     }
-    { const char *e = getenv("SCANERF_DEBUG_BWD"); a.f.dbg = e ? atoi(e) : 0; }  // timing experiments only (-DSCANERF_BWD_EXPERIMENTS builds)
+    a.f.dbg = tune_int("SCANERF_DEBUG_BWD", 0);  // timing experiments only (-DSCANERF_BWD_EXPERIMENTS builds)
     a.grad_out = grad_out; a.tile_T = tile_T; a.dfeat = dfeat; a.dw_partial = dw_partial; a.xstash = xstash;
     a.g_dnorm = g_dnorm; a.g_rowsum = g_rowsum; a.g_raypos = g_raypos;
     a.f.jstash = static_cast<uint32_t *>(const_cast<void *>(jstash));

@@ -1341,8 +1341,7 @@ int launch_render_bwd_t16(const BwdArgs &a_in, int feat_dtype, int blocks, size_
     BwdArgs a = a_in;
     // skewed emission (the t16s kernel's waves 4-7 park a tile's dX in LDS): whenever its 8 KB fit next to the record cursors
     // (T <= 2^20 entries per level at 2^13-entry buckets); SCANERF_BWD_PARK=0 switches it off (A/B timing)
-    const char *pe_ = getenv("SCANERF_BWD_PARK");
-    a.park = split && a.recs && lds_bytes + Lds<true>::kParkBytes <= 160 * 1024 && !(pe_ && atoi(pe_) == 0);
+    a.park = split && a.recs && lds_bytes + Lds<true>::kParkBytes <= 160 * 1024 && tune_int("SCANERF_BWD_PARK", 1) != 0;
     if (a.park) lds_bytes += Lds<true>::kParkBytes;
     SCANERF_REQUIRE(lds_bytes <= 160 * 1024, "render_backward(t16): %zu B of LDS needed (table too large for the fused scatter)", lds_bytes);
     SCANERF_REQUIRE(a.xstash, "render_backward(t16): needs the x-stash");

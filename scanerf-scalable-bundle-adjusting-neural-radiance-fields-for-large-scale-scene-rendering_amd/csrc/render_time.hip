@@ -1191,53 +1191,47 @@ __global__ void __launch_bounds__(kT16Threads, 4) k_pts_inference_t16(InferArgs 
     }
 }
 
-// f32-MFMA single-pass kernel instead of the chunk-major one (SCANERF_RENDER_ARITH=f32; comparison / debugging)
-inline bool render_single_pass(int64_t total, int nb)
+// Decoder arithmetic of the inference entry points: flag bits OR-ed into their `sample_major` argument (scanerf_hip.h):
+// none = the 16-sample-tile kernel at four waves per SIMD (default); SCANERF_INFER_H3 = the 32-sample-tile kernel at two
+// (round 4's); SCANERF_INFER_F32 = the f32-MFMA single-pass kernel (exact f32; comparison / debugging).
+inline int infer_arith_of(int &sample_major)
 {
-    const char *e = getenv("SCANERF_RENDER_ARITH");
+    const int ar = (sample_major & SCANERF_INFER_F32) ? 2 : ((sample_major & SCANERF_INFER_H3) ? 1 : 0);
+    sample_major &= ~(SCANERF_INFER_F32 | SCANERF_INFER_H3);
+    return ar;
+}
+inline bool render_single_pass(int64_t total, int nb, int arith)
+{
     // the chunk-major kernel indexes samples in 32 bits and keeps a chunk's tile set in 64 bits
-    return (e && e[0] == 'f') || total >= ((int64_t)1 << 31) || nb > 64;
+    return arith == 2 || total >= ((int64_t)1 << 31) || nb > 64;
 }
 
 // SCANERF_RENDER_ARITH=h3: the 32-sample-tile kernel at two waves per SIMD (k_pts_inference_chunks; comparison) instead of the
 // 16-sample-tile one at four (k_pts_inference_t16, default)
 
-// SCANERF_RENDER_PIPE=0: the group loop without the software pipeline (comparison; the two give the same bits)
-inline bool render_pipelined()
-{
-    const char *e = getenv("SCANERF_RENDER_PIPE");
-    return !(e && e[0] == '0');
-}
-
-inline bool render_t16_tiles()
-{
-    const char *e = getenv("SCANERF_RENDER_ARITH");
-    return !(e && (e[0] == 'h' || e[0] == 'w'));
-}
-// SCANERF_RENDER_ARITH=w3 / w4: the 32-sample-tile kernel without the software pipeline at three / four waves per SIMD (experiments)
-inline int render_h3_waves()
-{
-    const char *e = getenv("SCANERF_RENDER_ARITH");
-    return e && e[0] == 'w' ? atoi(e + 1) : 0;
-}
+// SCANERF_RENDER_PIPE=0 (experiments build): the group loop without the software pipeline (comparison; the two give the same bits)
+inline bool render_pipelined() { return tune_int("SCANERF_RENDER_PIPE", 1) != 0; }
+inline bool render_t16_tiles(int arith) { return arith == 0 && tune_int("SCANERF_RENDER_H3_WAVES", 0) == 0; }
+// SCANERF_RENDER_H3_WAVES=3 / 4 (experiments build): the 32-sample-tile kernel without the software pipeline at three / four waves per SIMD
+inline int render_h3_waves() { return tune_int("SCANERF_RENDER_H3_WAVES", 0); }
 template <bool BG>
-inline void launch_chunks(const InferArgs &a, int64_t tiles32, hipStream_t stream)
+inline void launch_chunks(const InferArgs &a, int64_t tiles32, int arith, hipStream_t stream)
 {
     // One workgroup per chunk (up to 2^20).  A foreground chunk's cost is anything between nothing (rays that miss) and 4096 decoded
     // samples; with 8 workgroups per CU walking ~30 chunks each at a fixed stride the busiest workgroup had ~1.6x the mean share
     // of live chunks and the launch waited for it.  The dispatcher hands a finished workgroup's slot to the next chunk instead
     // (same box, ms per frame: 8 per CU 71.2, 64 per CU 69.2, one per chunk 67.5; the background launch gains its tail too).
-    const char *cap_env = getenv("SCANERF_RENDER_GRID_CAP");   // workgroups per CU (comparison)
-    const int64_t cap = cap_env ? (int64_t)kNumCU * atoi(cap_env) : (int64_t)1 << 20;
+    const int cap_cu = tune_int("SCANERF_RENDER_GRID_CAP", 0);   // workgroups per CU (comparison; experiments build)
+    const int64_t cap = cap_cu > 0 ? (int64_t)kNumCU * cap_cu : (int64_t)1 << 20;
     auto nblocks = [&](int64_t per_chunk) {
         const int64_t nchunks = (tiles32 + per_chunk - 1) / per_chunk;
         return (int)(nchunks < cap ? nchunks : cap);
     };
     const int w = render_h3_waves();
     (void)w;
-    if (render_t16_tiles()) {
-        const char *e = getenv("SCANERF_RENDER_SH_ROWS");   // =0: every tile evaluates its samples' harmonics (comparison; the same bits)
-        const bool rows = t16_sh_rows_fit(a.B, a.S, a.sm) && !(e && e[0] == '0');
+    if (render_t16_tiles(arith)) {
+        // SCANERF_RENDER_SH_ROWS=0 (experiments build): every tile evaluates its samples' harmonics (comparison; the same bits)
+        const bool rows = t16_sh_rows_fit(a.B, a.S, a.sm) && tune_int("SCANERF_RENDER_SH_ROWS", 1) != 0;
         const dim3 grid(nblocks(kT16ChunkGroups32));
         if constexpr (!BG) {
             if (a.running) {   // scanerf_pts_inference_tracing
@@ -1254,8 +1248,10 @@ inline void launch_chunks(const InferArgs &a, int64_t tiles32, hipStream_t strea
     else if (w == 3) hipLaunchKernelGGL((k_pts_inference_chunks<BG, false, 768, 3, RT_W3_GROUPS>), dim3(nblocks(12 * RT_W3_GROUPS)), dim3(768), 0, stream, a);
     else if (w == 4) hipLaunchKernelGGL((k_pts_inference_chunks<BG, false, 512, 4, 16>), dim3(nblocks(8 * 16)), dim3(512), 0, stream, a);
 #endif
-    else if (render_pipelined()) hipLaunchKernelGGL((k_pts_inference_chunks<BG, true>), dim3(nblocks(kChunkWaves * kChunkWaveGroups)), dim3(kChunkThreads), 0, stream, a);
-    else hipLaunchKernelGGL((k_pts_inference_chunks<BG, false>), dim3(nblocks(kChunkWaves * kChunkWaveGroups)), dim3(kChunkThreads), 0, stream, a);
+#ifdef SCANERF_EXPERIMENTS
+    else if (!render_pipelined()) hipLaunchKernelGGL((k_pts_inference_chunks<BG, false>), dim3(nblocks(kChunkWaves * kChunkWaveGroups)), dim3(kChunkThreads), 0, stream, a);
+#endif
+    else hipLaunchKernelGGL((k_pts_inference_chunks<BG, true>), dim3(nblocks(kChunkWaves * kChunkWaveGroups)), dim3(kChunkThreads), 0, stream, a);
 }
 
 // ---- rendering_kernel.cu:624-702: front-to-back accumulation, one wave per ray ------------------------
@@ -1633,6 +1629,7 @@ static int pts_inference_impl(const float *rays_o, const float *rays_d, const fl
     RT_REQ(B >= 0 && S >= 1 && nb >= 1, "pts_inference");
     const int skip_unsampled = !block_idxs && (sample_major & SCANERF_SKIP_UNSAMPLED);   // (the tracing entry point only)
     sample_major &= ~SCANERF_SKIP_UNSAMPLED;
+    const int arith = infer_arith_of(sample_major);
     SCANERF_REQUIRE(sample_major >= 0 && sample_major <= 2 && (sample_major != 2 || B % 32 == 0),
                     "pts_inference" ": sample_major=%d (0, 1, or 2 with B a multiple of 32; B=%d)", sample_major, B);
     SCANERF_REQUIRE(T >= 2 && (T & (T - 1)) == 0, "pts_inference: T=%d must be a power of two", T);
@@ -1644,26 +1641,25 @@ static int pts_inference_impl(const float *rays_o, const float *rays_d, const fl
     a.tables = tables_f16; a.images = images; a.res = res; a.t = make_tiles(corners, sizes, occ, grid_starts, log2dim, nb);
     a.out_dif = out_dif; a.out_spec = out_spec; a.out_alpha = out_alpha; a.T = T; a.B = B; a.S = S; a.step = 0;
     a.sm = sample_major; a.running = block_idxs ? nullptr : running; a.inter = inter; a.skip_unsampled = skip_unsampled;
-    { const char *de = getenv("SCANERF_DEBUG_RT"); a.dbg = de ? atoi(de) : 0; }
+    a.dbg = tune_int("SCANERF_DEBUG_RT", 0);
     const int64_t tiles32 = ((int64_t)B * S + 31) / 32;
     int blocks = (int)((tiles32 + 3) / 4 < kNumCU * 4 ? (tiles32 + 3) / 4 : kNumCU * 4);
-    SCANERF_REQUIRE(!sample_major || !render_single_pass((int64_t)B * S, nb), "pts_inference: sample-major arrays need the chunk kernel");
-    SCANERF_REQUIRE(block_idxs || (render_t16_tiles() && !render_single_pass((int64_t)B * S, nb) && nb <= kTracingMaxTiles),
+    SCANERF_REQUIRE(!sample_major || !render_single_pass((int64_t)B * S, nb, arith), "pts_inference: sample-major arrays need the chunk kernel");
+    SCANERF_REQUIRE(block_idxs || (render_t16_tiles(arith) && !render_single_pass((int64_t)B * S, nb, arith) && nb <= kTracingMaxTiles),
                     "pts_inference_tracing: needs the 16-sample-tile kernel and nb <= %d tiles (nb=%d); use prepare_points + pts_inference", kTracingMaxTiles, nb);
-    if (render_single_pass((int64_t)B * S, nb)) {
+    if (render_single_pass((int64_t)B * S, nb, arith)) {
         hipLaunchKernelGGL((k_pts_inference<false>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
         return check_launch("pts_inference");
     }
     // every sample is written (zeros where no tile applies, :569-571).  The 32-sample-tile kernels add into cleared arrays; the
     // 16-sample-tile kernel writes each sample at its first listed tile's step and needs no clearing pass
-    const char *clr = getenv("SCANERF_RENDER_CLEAR");   // =1: clear anyway (timing comparison)
-    if (!render_t16_tiles() || (clr && clr[0] == '1')) {
+    if (!render_t16_tiles(arith) || tune_int("SCANERF_RENDER_CLEAR", 0) == 1) {   // (=1: clear anyway: timing comparison, experiments build)
         const size_t n = (size_t)B * S;
         const hipError_t ce[3] = { hipMemsetAsync(out_dif, 0, n * 12, (hipStream_t)stream), hipMemsetAsync(out_spec, 0, n * 12, (hipStream_t)stream),
                                    hipMemsetAsync(out_alpha, 0, n * 4, (hipStream_t)stream) };
         for (hipError_t e : ce) SCANERF_REQUIRE(e == hipSuccess, "pts_inference: clearing the outputs failed: %s", hipGetErrorString(e));
     }
-    launch_chunks<false>(a, tiles32, (hipStream_t)stream);
+    launch_chunks<false>(a, tiles32, arith, (hipStream_t)stream);
     return check_launch("pts_inference");
 }
 
@@ -1700,6 +1696,7 @@ SCANERF_API int scanerf_bg_pts_inference_v2(const float *rays_o, const float *ra
                                             scanerf_stream_t stream)
 {
     RT_REQ(B >= 0 && S >= 1 && nb >= 1 && step >= 0 && step < kMaxPtsBlocks, "bg_pts_inference_v2");
+    const int arith = infer_arith_of(sample_major);
     SCANERF_REQUIRE(sample_major >= 0 && sample_major <= 2 && (sample_major != 2 || B % 32 == 0),
                     "bg_pts_inference_v2" ": sample_major=%d (0, 1, or 2 with B a multiple of 32; B=%d)", sample_major, B);
     SCANERF_REQUIRE(T >= 2 && (T & (T - 1)) == 0, "bg_pts_inference_v2: T=%d must be a power of two", T);
@@ -1711,15 +1708,15 @@ SCANERF_API int scanerf_bg_pts_inference_v2(const float *rays_o, const float *ra
     a.tables = tables_f16; a.images = images; a.res = res; a.t = make_tiles(corners, sizes, nullptr, nullptr, nullptr, nb);
     a.out_dif = out_dif; a.out_spec = out_spec; a.out_alpha = out_alpha; a.T = T; a.B = B; a.S = S; a.step = step;
     a.sm = sample_major; a.running = nullptr; a.inter = nullptr; a.skip_unsampled = 0;
-    { const char *de = getenv("SCANERF_DEBUG_RT"); a.dbg = de ? atoi(de) : 0; }
+    a.dbg = tune_int("SCANERF_DEBUG_RT", 0);
     const int64_t tiles32 = ((int64_t)B * S + 31) / 32;
     int blocks = (int)((tiles32 + 3) / 4 < kNumCU * 4 ? (tiles32 + 3) / 4 : kNumCU * 4);
-    SCANERF_REQUIRE(!sample_major || !render_single_pass((int64_t)B * S, nb), "bg_pts_inference_v2: sample-major arrays need the chunk kernel");
-    if (render_single_pass((int64_t)B * S, nb)) {
+    SCANERF_REQUIRE(!sample_major || !render_single_pass((int64_t)B * S, nb, arith), "bg_pts_inference_v2: sample-major arrays need the chunk kernel");
+    if (render_single_pass((int64_t)B * S, nb, arith)) {
         hipLaunchKernelGGL((k_pts_inference<true>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
         return check_launch("bg_pts_inference_v2");
     }
-    launch_chunks<true>(a, tiles32, (hipStream_t)stream);
+    launch_chunks<true>(a, tiles32, arith, (hipStream_t)stream);
     return check_launch("bg_pts_inference_v2");
 }
 

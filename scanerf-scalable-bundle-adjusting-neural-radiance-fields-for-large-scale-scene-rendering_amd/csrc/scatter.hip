@@ -19,8 +19,6 @@
 //                       atomics; see k_bin_accumulate), then adds the image to grad_features
 //                       with plain stores.  No global atomics anywhere; bit-reproducible.
 // HBM traffic: 64 B written + 64 B read per (point, level) instead of 16 memory-side atomics.
-#include <stdlib.h>
-
 #include "adam_common.h"
 #include "render_device.h"
 #include <algorithm>
@@ -892,7 +890,7 @@ static int standalone_bucket_log(int T)
 {
     const int lt = bin_ilog2(T);
     int bl = lt - 11 > kBucketLog ? lt - 11 : kBucketLog;
-    if (const char *e = getenv("SCANERF_STANDALONE_BUCKET_LOG")) bl = atoi(e);  // tuning experiments only
+    bl = tune_int("SCANERF_STANDALONE_BUCKET_LOG", bl);  // tuning experiments only
     if (bl > 13) bl = 13;
     return lt < bl ? lt : bl;
 }
@@ -900,9 +898,10 @@ static int standalone_bucket_log(int T)
 // Segments the large-table producer may need: the records (4 per (point, level) + the straddle slack of the record budget) in
 // fives, plus one partly filled segment per (bucket, producer workgroup) range.
 constexpr int kSegProducers = 256;
+static int seg_route_producers(int N) { return N >= kSegProducers * 256 ? kSegProducers : (N + 255) / 256; }   // (as binned_backward's g.W)
 static size_t seg_route_segments(int N, int L, int64_t nbins)
 {
-    return ((size_t)N * L * 4 + (size_t)N * L / 8) / kSegRecs + (size_t)nbins * kSegProducers + 4096;
+    return ((size_t)N * L * 4 + (size_t)N * L / 8) / kSegRecs + (size_t)nbins * seg_route_producers(N) + 4096;
 }
 
 // Workspace bytes for a binned backward of N points.  0 => shape unsupported by the binned path
@@ -926,8 +925,12 @@ SCANERF_API size_t scanerf_embedding_bwd_workspace_bytes(int N, int L, int T)
 // grad_features: the table the image is added to -- or, with an Adam epilogue, the overflow table (ad->overflow_grad)
 static int binned_backward(const float *points, const float *grad_in, float *grad_features, const int32_t *resolutions, int N,
                            int L, int T, int grad_layout, void *workspace, size_t workspace_bytes, const AdamEpilogue *ad,
-                           scanerf_stream_t stream, int compact_records = 0, const PointSrc *rays = nullptr)
+                           scanerf_stream_t stream, int compact_records = -1, const PointSrc *rays = nullptr)
 {
+    // compact_records: -1 = the layout's default (point-major rows of 16 levels: 12-byte records; level-major: 16-byte),
+    // 0 = 16-byte records wherever a 16-byte producer exists, 1 = 8-byte (level-major only), 2 = 12-byte
+    const bool want16 = compact_records == 0;
+    if (compact_records < 0) compact_records = 0;
     SCANERF_REQUIRE(N >= 0 && L >= 1, "embedding_bg_backward_binned: N=%d L=%d", N, L);
     if (N == 0) return 0;
     const size_t need = scanerf_embedding_bwd_workspace_bytes(N, L, T);
@@ -946,11 +949,11 @@ static int binned_backward(const float *points, const float *grad_in, float *gra
     // (2^13 entries: 64 ranges per level at T = 2^19 instead of 256), 256 persistent-size workgroups of 1024 threads (fewer
     // open ranges per L2) and 12-byte records.  Measured on the op-by-op training step (tools/ops_path_profile.py, backward
     // section): 2^11 / 1024 workgroups 16.2 ms, 2^13 / 256 workgroups 12.6 ms, with the row in registers and Rec12: see DESIGN.md.
-    bool rows16 = grad_layout == 0 && L == 16 && ((uintptr_t)grad_in & 15) == 0 && !getenv("SCANERF_SCATTER_OLD");
+    bool rows16 = grad_layout == 0 && L == 16 && ((uintptr_t)grad_in & 15) == 0 && !want16 && !tune_set("SCANERF_SCATTER_OLD");
     if (rows16) {
         const int lt = bin_ilog2(T);
         int bl = lt < 13 ? lt : 13;
-        if (const char *e = getenv("SCANERF_STANDALONE_BUCKET_LOG")) bl = atoi(e) < bl ? atoi(e) : bl;
+        { const int v = tune_int("SCANERF_STANDALONE_BUCKET_LOG", bl); bl = v < bl ? v : bl; }
         if ((size_t)L * (T >> bl) * 4 > 64 * 1024) rows16 = false;   // (all levels' cursors must fit the producer's LDS: T <= 2^23)
         else g.bucket_log = bl;
     }
@@ -959,19 +962,19 @@ static int binned_backward(const float *points, const float *grad_in, float *gra
     // scatter_common.h Rec12; SCANERF_REC16=1 keeps the 16-byte records)
     if (rows16 && compact_records == 0) compact_records = 2;
     g.rec8 = (compact_records >= 1 && compact_records <= 2 && (grad_layout == 1 || (rows16 && compact_records == 2)) &&
-              g.bucket_log <= kRec8MaxBucketLog && !getenv("SCANERF_REC16")) ? compact_records : 0;
+              g.bucket_log <= kRec8MaxBucketLog && !tune_set("SCANERF_REC16")) ? compact_records : 0;
     g.NB = T >> g.bucket_log;
     // Large tables (round 6): 12-byte records leave the producer as full 64-byte segments (k_bin_scatter_seg, format 3) -- for the
     // level-major gradients of the t16s backward and for the point-major rows of the binding surface (whose default is Rec12
     // as well, see rows16); SCANERF_REC16 / SCANERF_SCATTER_OLD keep the record-at-a-time producer
     const bool seg_route = (size_t)L * g.NB * 4 > 64 * 1024 && g.bucket_log <= 13 && g.NB <= 2048 &&
-                           (compact_records == 2 || (grad_layout == 0 && compact_records == 0)) &&
-                           !getenv("SCANERF_REC16") && !getenv("SCANERF_SCATTER_OLD");
+                           (compact_records == 2 || (grad_layout == 0 && compact_records == 0 && !want16)) &&
+                           !tune_set("SCANERF_REC16") && !tune_set("SCANERF_SCATTER_OLD");
     if (seg_route) g.rec8 = 3;
     // producer workgroups: every one of them writes and reads a counter per bin, so with the tens of thousands of bins of a
     // large table fewer, longer-running workgroups are cheaper (T = 2^24, 2.1 M points: count 0.62 -> see DESIGN.md)
     g.W = ((size_t)L * g.NB * 4 > 64 * 1024 || rows16) ? 256 : 1024;
-    if (const char *e = getenv("SCANERF_SCATTER_W")) { const int v = atoi(e); if (v >= 1 && v <= 1024) g.W = v; }   // tuning experiments
+    { const int v = tune_int("SCANERF_SCATTER_W", 0); if (v >= 1 && v <= 1024) g.W = v; }   // tuning experiments
     if (g.W > (N + kThreads - 1) / kThreads) g.W = (N + kThreads - 1) / kThreads;
     g.per_wg = (N + g.W - 1) / g.W;
     const int nbins = L * g.NB;
@@ -980,7 +983,7 @@ static int binned_backward(const float *points, const float *grad_in, float *gra
     SCANERF_REQUIRE(workspace_bytes > pts_tail && bin_workspace_carve(workspace, workspace_bytes - pts_tail, nbins, g.W, w),
                     "embedding_bg_backward_binned: workspace too small (%zu B)", workspace_bytes);
     g.capacity = w.capacity;
-    if (g.rec8 == 3 && (g.W > kSegProducers || rec_capacity(g.capacity, 3) < seg_route_segments(N, L, L * g.NB)))
+    if (g.rec8 == 3 && (g.W > seg_route_producers(N) || rec_capacity(g.capacity, 3) < seg_route_segments(N, L, L * g.NB)))
         g.rec8 = (compact_records == 2 && g.bucket_log <= kRec8MaxBucketLog) ? 2 : 0;   // (a caller's smaller workspace: the old producer)
     SCANERF_REQUIRE(!rays || g.rec8 == 3, "table_grad_scatter_adam_rays: T=%d N=%d needs the large-table producer (T >= 2^22, L = 16, "
                     "12-byte records, workspace of scanerf_embedding_bwd_workspace_bytes)", T, N);
@@ -1005,7 +1008,6 @@ static int binned_backward(const float *points, const float *grad_in, float *gra
     hipLaunchKernelGGL(k_bin_starts, dim3(1), dim3(1024), 0, st, totals, starts, nbins);
     if (g.rec8 == 3) {
         const size_t lds_seg = (size_t)g.NB * 18 * 4;   // cnt, segn, gbase, 15-word slots
-        const int pts = tune_int("SCANERF_SEG_PTS", 2);   // points per lane and batch
         const PointSrc none{};
 #define SCANERF_LAUNCH_SEG(LM, RY, PT)                                                                                          \
     {                                                                                                                           \
@@ -1015,13 +1017,10 @@ static int binned_backward(const float *points, const float *grad_in, float *gra
         hipLaunchKernelGGL((k_bin_scatter_seg<LM, RY, PT>), dim3(g.W), dim3(1024), lds_seg, st, points, gi, resolutions, g, counts, \
                            starts, recs, grad_features, maxbits, rays ? *rays : none);                                          \
     }
-        if (rays) {
-            if (pts == 1) SCANERF_LAUNCH_SEG(true, true, 1) else if (pts == 4) SCANERF_LAUNCH_SEG(true, true, 4) else SCANERF_LAUNCH_SEG(true, true, 2)
-        } else if (grad_layout == 1) {
-            if (pts == 1) SCANERF_LAUNCH_SEG(true, false, 1) else if (pts == 4) SCANERF_LAUNCH_SEG(true, false, 4) else SCANERF_LAUNCH_SEG(true, false, 2)
-        } else {
-            SCANERF_LAUNCH_SEG(false, false, 2)
-        }
+        // two points per lane and batch (measured at T = 2^24, 4.2e6 points: 1 / 2 points 1.94 / 1.91 ms; 4 spill registers)
+        if (rays) SCANERF_LAUNCH_SEG(true, true, 2)
+        else if (grad_layout == 1) SCANERF_LAUNCH_SEG(true, false, 2)
+        else SCANERF_LAUNCH_SEG(false, false, 2)
 #undef SCANERF_LAUNCH_SEG
     } else if (rows16 && g.rec8 == 2)
         hipLaunchKernelGGL((k_bin_scatter<false, false, 2>), dim3(g.W), dim3(1024), lds_bins, st, points, gi, resolutions, g,
@@ -1080,9 +1079,12 @@ static int binned_backward(const float *points, const float *grad_in, float *gra
 
 SCANERF_API int scanerf_embedding_bg_backward_binned(const float *points, const float *grad_in, float *grad_features,
                                                      const int32_t *resolutions, int N, int L, int T, int grad_layout,
-                                                     void *workspace, size_t workspace_bytes, scanerf_stream_t stream)
+                                                     void *workspace, size_t workspace_bytes, int compact_records,
+                                                     scanerf_stream_t stream)
 {
-    return binned_backward(points, grad_in, grad_features, resolutions, N, L, T, grad_layout, workspace, workspace_bytes, nullptr, stream);
+    SCANERF_REQUIRE(compact_records >= -1 && compact_records <= 2, "embedding_bg_backward_binned: compact_records=%d", compact_records);
+    return binned_backward(points, grad_in, grad_features, resolutions, N, L, T, grad_layout, workspace, workspace_bytes, nullptr, stream,
+                           compact_records);
 }
 
 // The binned scatter ending in the fused sparse Adam (see scanerf_render_scatter_accumulate_adam): the table-gradient path of
@@ -1100,6 +1102,7 @@ SCANERF_API int scanerf_embedding_bg_backward_binned_adam(const float *points, c
                     "embedding_bg_backward_binned_adam: half_dtype=%d", half_dtype);
     const AdamEpilogue ad{ nullptr, nullptr, nullptr, 0u, params, exp_avg, exp_avg_sq, half_table, half_dtype, overflow_grad,
                            make_adam_args(lr, beta1, beta2, eps, step) };
+    SCANERF_REQUIRE(compact_records >= -1 && compact_records <= 2, "embedding_bg_backward_binned_adam: compact_records=%d", compact_records);
     return binned_backward(points, grad_in, overflow_grad, resolutions, N, L, T, grad_layout, workspace, workspace_bytes, &ad, stream,
                            compact_records);
 }
@@ -1300,7 +1303,7 @@ SCANERF_API int scanerf_render_scatter_plan(const float *rays_o, const float *ra
     f.B = B; f.S = S; f.T = T;
     f.contract_mode = cfg->contract_mode; f.infinity = cfg->infinity;
     // (only the t16 backward leaves masked levels' records out; the other two emit every level)
-    f.skip_levels = ((cfg->arith == SCANERF_ARITH_T16 || cfg->arith == SCANERF_ARITH_T16S) && !getenv("SCANERF_NO_LEVEL_SKIP")) ? pair_masked_levels(cfg->skip_levels) : 0u;
+    f.skip_levels = ((cfg->arith == SCANERF_ARITH_T16 || cfg->arith == SCANERF_ARITH_T16S) && !tune_set("SCANERF_NO_LEVEL_SKIP")) ? pair_masked_levels(cfg->skip_levels) : 0u;
     for (int k = 0; k < 3; ++k) {
         f.min_bbox[k] = cfg->min_bbox[k];
         f.bbox_size[k] = cfg->bbox_size[k];
@@ -1353,7 +1356,7 @@ static bool split_to_fine(int B, int S, BinGeom &g, BinWorkspace &w, void *works
                           hipStream_t st)
 {
     SplitLayout L;
-    if (!split_layout(B, S, g, L) || workspace_bytes < L.total_bytes || !overflow_table || getenv("SCANERF_NO_SPLIT")) return false;
+    if (!split_layout(B, S, g, L) || workspace_bytes < L.total_bytes || !overflow_table || tune_set("SCANERF_NO_SPLIT")) return false;
     if (plan_format(workspace) != 0) return false;   // (coarse records of a large table are the 16-byte ones)
     char *base = static_cast<char *>(workspace);
     uint32_t *starts_f = reinterpret_cast<uint32_t *>(base + L.fine_off);
@@ -1389,11 +1392,10 @@ SCANERF_API int scanerf_render_scatter_accumulate(float *grad_features, int B, i
     int nbins_acc = nbins;
     if (split_to_fine(B, S, g, w, workspace, workspace_bytes, grad_features, (hipStream_t)stream)) nbins_acc = 16 * g.NB;
     const size_t lds_bytes = (size_t)(2 << (g.bucket_log < 13 ? g.bucket_log : 13)) * 8;
-    const char *ve = getenv("SCANERF_ACC_VARIANT");  // tuning experiments only
     // launch shape by the records' format, as the Adam-epilogue entry does (12-byte records: 512 threads x 16 records per lane
     // 1.5 ms against 1.9 ms for the 16-byte records' 256 x 32 at configs[1]; 8-byte ones: 512 x 32)
     const int pf_acc = (nbins_acc != nbins) ? 2 : plan_format(workspace);
-    const int variant = ve ? atoi(ve) : (pf_acc == 2 ? 8 : (pf_acc == 1 ? 10 : 0));
+    const int variant = tune_int("SCANERF_ACC_VARIANT", pf_acc == 2 ? 8 : (pf_acc == 1 ? 10 : 0));   // (other shapes: experiments build)
 #define SCANERF_LAUNCH_ACC(TH, UU)                                                                                  \
     {                                                                                                               \
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bin_accumulate<TH, UU>),               \
@@ -1417,20 +1419,23 @@ SCANERF_API int scanerf_render_scatter_accumulate(float *grad_features, int B, i
     // 512x16 1.86, 256x16 1.86, 128x16 1.82, 512x32 1.95, 256x32 1.73-1.79 (default), 128x32 1.73, 64x32 1.78.  The
     // interleaved forms were bound by same-address serialisation in the LDS (coarse levels), not by the atomic rate itself
     // (5.8 distinct 64-bit adds per clock per CU: tools/lds_atomic_bench.hip); what is left is mostly the record stream.
+#ifdef SCANERF_EXPERIMENTS
     if (variant == 1) SCANERF_LAUNCH_ACC(256, 8)
     else if (variant == 2) SCANERF_LAUNCH_ACC(512, 8)
     else if (variant == 3) SCANERF_LAUNCH_ACC(1024, 4)
     else if (variant == 4) SCANERF_LAUNCH_ACC_RUN(1024, 4)
     else if (variant == 5) SCANERF_LAUNCH_ACC_RUN(512, 8)
     else if (variant == 6) SCANERF_LAUNCH_ACC_RUN(1024, 8)
-    else if (variant == 8) SCANERF_LAUNCH_ACC_RUN(512, 16)
     else if (variant == 9) SCANERF_LAUNCH_ACC_RUN(256, 16)
-    else if (variant == 10) SCANERF_LAUNCH_ACC_RUN(512, 32)
     else if (variant == 11) SCANERF_LAUNCH_ACC_RUN(256, 32)
     else if (variant == 12) SCANERF_LAUNCH_ACC_RUN(128, 32)
     else if (variant == 13) SCANERF_LAUNCH_ACC_RUN(64, 32)
     else if (variant == 14) SCANERF_LAUNCH_ACC_RUN(128, 16)
     else if (variant == 7) SCANERF_LAUNCH_ACC_RUN(1024, 16)
+    else
+#endif
+    if (variant == 8) SCANERF_LAUNCH_ACC_RUN(512, 16)
+    else if (variant == 10) SCANERF_LAUNCH_ACC_RUN(512, 32)
     else SCANERF_LAUNCH_ACC_RUN(256, 32)
 #undef SCANERF_LAUNCH_ACC
 #undef SCANERF_LAUNCH_ACC_RUN
@@ -1478,7 +1483,7 @@ static int accumulate_adam(float *params, float *exp_avg, float *exp_avg_sq, voi
         SplitLayout L1, L2;
         const bool can1 = split_layout(B, S, g, L1) && workspace_bytes >= L1.total_bytes && plan_format(workspace) == 0;
         const bool can2 = !workspace2 || (split_layout(B, S2, g2, L2) && workspace2_bytes >= L2.total_bytes && plan_format(workspace2) == 0);
-        if (can1 && can2 && overflow_grad && !getenv("SCANERF_NO_SPLIT")) {
+        if (can1 && can2 && overflow_grad && !tune_set("SCANERF_NO_SPLIT")) {
             split = split_to_fine(B, S, g, w, workspace, workspace_bytes, overflow_grad, (hipStream_t)stream);
             if (split && workspace2) split_to_fine(B, S2, g2, w2, workspace2, workspace2_bytes, overflow_grad, (hipStream_t)stream);
             if (split) nbins_acc = 16 * g.NB;
@@ -1497,14 +1502,12 @@ static int accumulate_adam(float *params, float *exp_avg, float *exp_avg_sq, voi
     }
     // measured (configs[1], MI355X), threads x 16-byte loads per lane: 16-byte records 256x32 2.28 ms, 512x32 2.55, 768x32 2.59;
     // 8-byte records 256x32 1.77, 512x16 1.58, 1024x8 1.70, 1024x16 1.55, 768x32 1.51, 512x48 1.53, 512x32 1.47
-    const char *ve = getenv("SCANERF_ACC_VARIANT");  // tuning experiments only
     // 12-byte records (t16s), threads x records per lane: 256x32 1.72 ms, 512x32 1.74, 768x32 1.67, 1024x16 1.53, 512x8 1.52, 512x16 1.43
     const int pf = split ? 2 : plan_format(workspace);
-    const int variant = ve ? atoi(ve) : (pf == 1 ? 4 : (pf == 2 ? 1 : 0));
-    if (variant == 1) SCANERF_LAUNCH_ACC_ADAM(512, 16)
-    else if (variant == 2) SCANERF_LAUNCH_ACC_ADAM(1024, 8)
+    const int variant = tune_int("SCANERF_ACC_VARIANT", pf == 1 ? 4 : (pf == 2 ? 1 : 0));   // (other shapes: experiments build)
+#ifdef SCANERF_EXPERIMENTS
+    if (variant == 2) SCANERF_LAUNCH_ACC_ADAM(1024, 8)
     else if (variant == 3) SCANERF_LAUNCH_ACC_ADAM(256, 16)
-    else if (variant == 4) SCANERF_LAUNCH_ACC_ADAM(512, 32)
     else if (variant == 5) SCANERF_LAUNCH_ACC_ADAM(1024, 16)
     else if (variant == 6) SCANERF_LAUNCH_ACC_ADAM(512, 8)
     else if (variant == 7) SCANERF_LAUNCH_ACC_ADAM(1024, 4)
@@ -1512,6 +1515,10 @@ static int accumulate_adam(float *params, float *exp_avg, float *exp_avg_sq, voi
     else if (variant == 9) SCANERF_LAUNCH_ACC_ADAM(512, 48)
     else if (variant == 10) SCANERF_LAUNCH_ACC_ADAM(640, 32)
     else if (variant == 11) SCANERF_LAUNCH_ACC_ADAM(768, 16)
+    else
+#endif
+    if (variant == 1) SCANERF_LAUNCH_ACC_ADAM(512, 16)
+    else if (variant == 4) SCANERF_LAUNCH_ACC_ADAM(512, 32)
     else SCANERF_LAUNCH_ACC_ADAM(256, 32)
 #undef SCANERF_LAUNCH_ACC_ADAM
     return check_launch("render_scatter_accumulate_adam");

@@ -2,7 +2,6 @@
 // scatter, shared by scatter.hip (count / scan / accumulate, stand-alone producer) and render_bwd.hip
 // (which emits the records straight from the fused backward kernel).
 #pragma once
-#include <stdlib.h>
 #include "hashgrid_common.h"
 
 namespace scanerf {
@@ -239,7 +238,7 @@ constexpr int kRec8MaxBucketLog = 13;
 // record format of a fused plan by the backward's arithmetic: 1 (Rec8) for T16, 2 (Rec12) for T16S, else 0 (Rec, 16 bytes)
 inline int fused_rec8(int arith, int bucket_log)
 {
-    if (getenv("SCANERF_REC16")) return 0;  // experiments: the 16-sample-tile kernels on 16-byte records
+    if (tune_set("SCANERF_REC16")) return 0;  // experiments build: the 16-sample-tile kernels on 16-byte records
     if (bucket_log > kRec8MaxBucketLog) return 0;
     return arith == 2 /* SCANERF_ARITH_T16 */ ? 1 : (arith == 3 /* SCANERF_ARITH_T16S */ ? 2 : 0);
 }
@@ -499,7 +498,7 @@ inline int fused_bucket_log(int T)
 {
     const int lt = bin_ilog2(T);
     int want = kFusedBucketLog;
-    if (const char *e = getenv("SCANERF_FUSED_BUCKET_LOG")) want = atoi(e);  // tuning experiments only
+    want = tune_int("SCANERF_FUSED_BUCKET_LOG", want);  // tuning experiments only
     // at most 256 buckets per level (16 KB of cursors in the producer's LDS), at least `want` entries per bucket
     const int bl = lt - 8 > want ? lt - 8 : want;
     return lt < bl ? lt : bl;

@@ -31,21 +31,30 @@ def embedding_bg_forward_cuda(points, outputs, features, resolutions):
           "embedding_bg_forward_cuda")
 
 
+TABLE_GRAD_ROUTE = "binned"   # or "atomics"
+RECORD_FORMAT = -1
+# Decoder arithmetic of the render-time inference ops: "t16" (default: 16-sample tiles, four waves per SIMD), "h3" (round 4's
+# 32-sample-tile kernel) or "f32" (single-pass f32 MFMA: exact f32, [B,S] arrays only) -- flag bits OR-ed into the ops' `sample_major`
+INFER_ARITH = "t16"
+_INFER_FLAGS = {"t16": 0, "h3": 8, "f32": 16}   # include/scanerf_hip.h SCANERF_INFER_H3 / SCANERF_INFER_F32
+
+
 def embedding_bg_backward_cuda(points, grad_in, grad_points, grad_features, features, resolutions):
     """hashgrid.h:45-51: accumulates into grad_points [N,3] and grad_features [L,T,2].
     The table gradient goes through the atomic-free binned scatter (csrc/scatter.hip) when the
-    shape allows; SCANERF_SCATTER=atomics forces the reference-style atomic kernel."""
+    shape allows; TABLE_GRAD_ROUTE = "atomics" (module attribute) forces the reference-style atomic kernel; RECORD_FORMAT
+    (-1 = default: 12-byte records for 16-level point-major rows, 0 = 16-byte, 2 = 12-byte) is the op's `compact_records`."""
     N, (L, T) = points.shape[0], features.shape[:2]
     need = 0
-    if grad_features is not None and N >= 4096 and os.environ.get("SCANERF_SCATTER", "binned") != "atomics":
+    if grad_features is not None and N >= 4096 and TABLE_GRAD_ROUTE != "atomics":
         need = lib().scanerf_embedding_bwd_workspace_bytes(ctypes.c_int(N), ctypes.c_int(L), ctypes.c_int(T))
     if need:
         ws = workspace(points.device, need)
         check(lib().scanerf_embedding_bg_backward_binned(
             dev_ptr(points, _f32, "points"), dev_ptr(grad_in, _f32, "grad_in"),
             dev_ptr(grad_features, _f32, "grad_features"), _res(resolutions), ctypes.c_int(N), ctypes.c_int(L),
-            ctypes.c_int(T), ctypes.c_int(0), ctypes.c_void_p(ws.data_ptr()), ctypes.c_size_t(ws.numel()), stream()),
-            "embedding_bg_backward_cuda(binned)")
+            ctypes.c_int(T), ctypes.c_int(0), ctypes.c_void_p(ws.data_ptr()), ctypes.c_size_t(ws.numel()), ctypes.c_int(RECORD_FORMAT),
+            stream()), "embedding_bg_backward_cuda(binned)")
         if grad_points is None:
             return
         grad_features = None  # the point gradient still needs the corner features: gather kernel
@@ -195,7 +204,7 @@ def pts_inference(rays_o, rays_d, z_vals, dists, block_idxs, features_tables, pa
         dev_ptr(block_corners, _f32, "block_corners"), dev_ptr(block_sizes, _f32, "block_sizes"),
         dev_ptr(diffuse, _f32, "diffuse"), dev_ptr(specular, _f32, "specular"), dev_ptr(alpha, _f32, "alpha"),
         _I(rays_d.shape[0]), _S(z_vals, sample_major), _I(features_tables.shape[2]), _I(block_corners.shape[0]),
-        _I(int(sample_major)), stream()), "pts_inference")
+        _I(int(sample_major) | _INFER_FLAGS[INFER_ARITH]), stream()), "pts_inference")
 
 
 SKIP_UNSAMPLED = 4   # include/scanerf_hip.h SCANERF_SKIP_UNSAMPLED: OR into `sample_major` of pts_inference_tracing / accumulate_color
@@ -203,8 +212,7 @@ SKIP_UNSAMPLED = 4   # include/scanerf_hip.h SCANERF_SKIP_UNSAMPLED: OR into `sa
 
 def tracing_fusable(nb):
     """pts_inference_tracing serves up to 8 tiles on the 16-sample-tile kernel (include/scanerf_hip.h)"""
-    ar = os.environ.get("SCANERF_RENDER_ARITH", "")
-    return nb <= 8 and not ar[:1] in ("f", "h", "w")
+    return nb <= 8 and INFER_ARITH == "t16"
 
 
 def pts_inference_tracing(rays_o, rays_d, z_vals, dists, running_mask, intersections, features_tables, params, resolution,
@@ -223,7 +231,7 @@ def pts_inference_tracing(rays_o, rays_d, z_vals, dists, running_mask, intersect
         dev_ptr(block_corners, _f32, "block_corners"), dev_ptr(block_sizes, _f32, "block_sizes"),
         dev_ptr(diffuse, _f32, "diffuse"), dev_ptr(specular, _f32, "specular"), dev_ptr(alpha, _f32, "alpha"),
         _I(rays_d.shape[0]), _S(z_vals, sample_major), _I(features_tables.shape[2]), _I(block_corners.shape[0]),
-        _I(int(sample_major)), stream()), "pts_inference_tracing")
+        _I(int(sample_major) | _INFER_FLAGS[INFER_ARITH]), stream()), "pts_inference_tracing")
 
 
 def accumulate_color(pts_diffuse, pts_specular, pts_alpha, transparency, z_vals, diffuse, specular, depth, sample_major=False):
@@ -252,7 +260,7 @@ def bg_pts_inference_v2(rays_o, rays_d, z_vals, bg_idxs, step, block_corners, bl
         dev_ptr(features_tables, torch.float16, "features_tables"), dev_ptr(img, _f32, "images"),
         dev_ptr(diffuse, _f32, "diffuse"), dev_ptr(specular, _f32, "specular"), dev_ptr(alpha, _f32, "alpha"),
         _I(rays_d.shape[0]), _S(z_vals, sample_major), _I(features_tables.shape[2]), _I(block_corners.shape[0]),
-        _I(int(sample_major)), stream()), "bg_pts_inference_v2")
+        _I(int(sample_major) | _INFER_FLAGS[INFER_ARITH]), stream()), "bg_pts_inference_v2")
 
 
 def bg_pts_inference(rays_o, rays_d, z_vals, outgoing_bidxs, blend_weights, block_corners, block_sizes, resolution,

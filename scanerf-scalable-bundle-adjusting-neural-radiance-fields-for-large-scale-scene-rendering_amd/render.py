@@ -9,7 +9,7 @@ from ._capi import RAY_OUT, RenderCfg, check, dev_ptr, feat_dtype_code, lib, str
 _f32 = torch.float32
 FORE, BG = 0, 1
 
-# Decoder arithmetic of the fused kernels (module-level switch, also SCANERF_ARITH=f32|h3|t16|t16s in the environment):
+# Decoder arithmetic of the fused kernels (module-level switch: set_arith(); it becomes scanerf_render_cfg.arith of every call):
 #   "f32"  = the f32-input MFMA (exact f32);
 #   "h3"   = f16 matrix cores on hi/lo-split operands, three products per term, f32 accumulate: results as close to fp64 as
 #            the f32 evaluation (csrc/render_h3.h), forward and backward (32-sample tiles, one wave per SIMD);
@@ -23,7 +23,7 @@ import os as _os
 _ARITH_CODES = {"f32": _capi.ARITH_F32, "h3": _capi.ARITH_H3, "t16": _capi.ARITH_T16, "t16s": _capi.ARITH_T16S}
 ARITH_NAMES = tuple(_ARITH_CODES)
 FP32_EQUIV_ARITH = "t16s"   # the fastest arithmetic whose gradients are f32-equivalent: what bench.py's headline runs
-DEFAULT_ARITH = _os.environ.get("SCANERF_ARITH", FP32_EQUIV_ARITH)
+DEFAULT_ARITH = FP32_EQUIV_ARITH
 ARITH = _ARITH_CODES[DEFAULT_ARITH]
 # what each arithmetic computes in, for bench.py's `dtype`
 ARITH_DTYPE = {
@@ -342,8 +342,9 @@ def scatter_accumulate_adam(ws, params, exp_avg, exp_avg_sq, lr, beta1, beta2, e
         "scatter_accumulate_adam")
 
 
-def scatter_table_grad(points, dfeat, grad_features, resolutions):
-    """grad_features [16,T,2] += binned scatter of level-major dfeat at contracted `points` [N,3]."""
+def scatter_table_grad(points, dfeat, grad_features, resolutions, compact_records=-1):
+    """grad_features [16,T,2] += binned scatter of level-major dfeat at contracted `points` [N,3].
+    compact_records: -1 = the layout's default (16-byte records for level-major gradients), 0 / 1 / 2 = 16- / 8- / 12-byte records."""
     N, (L, T) = points.shape[0], grad_features.shape[:2]
     need = lib().scanerf_embedding_bwd_workspace_bytes(ctypes.c_int(N), ctypes.c_int(L), ctypes.c_int(T))
     if not need:
@@ -352,7 +353,8 @@ def scatter_table_grad(points, dfeat, grad_features, resolutions):
     check(lib().scanerf_embedding_bg_backward_binned(
         dev_ptr(points, _f32, "points"), dev_ptr(dfeat, _f32, "dfeat"), dev_ptr(grad_features, _f32, "grad_features"),
         dev_ptr(resolutions, torch.int32, "resolutions"), ctypes.c_int(N), ctypes.c_int(L), ctypes.c_int(T),
-        ctypes.c_int(1), ctypes.c_void_p(ws.data_ptr()), ctypes.c_size_t(ws.numel()), stream()), "scatter_table_grad")
+        ctypes.c_int(1), ctypes.c_void_p(ws.data_ptr()), ctypes.c_size_t(ws.numel()), ctypes.c_int(int(compact_records)), stream()),
+        "scatter_table_grad")
     return grad_features
 
 
@@ -377,10 +379,13 @@ def scatter_table_grad_adam(points, dfeat, resolutions, params, exp_avg, exp_avg
         ctypes.c_int(int(compact_records)), stream()), "scatter_table_grad_adam")
 
 
+RAYS_SCATTER = True   # (False: tile_model builds contracted points in torch and concatenates the branches, as rounds 1-5 did)
+
+
 def scatter_rays_supported(T, arith_code):
     """scatter_table_grad_adam_rays applies: tables of at least 2^22 entries per level (one level's counters in the producer's LDS
     at a time) behind the f32-grade backward (12-byte records)."""
-    return T >= (1 << 22) and compact_record_format(arith_code) == 2 and not _os.environ.get("SCANERF_NO_RAYS_SCATTER") and not _os.environ.get("SCANERF_REC16")
+    return T >= (1 << 22) and compact_record_format(arith_code) == 2 and RAYS_SCATTER
 
 
 def scatter_table_grad_adam_rays(rays_o, rays_d, branches, min_bbox, bbox_size, resolutions, params, exp_avg, exp_avg_sq, lr, beta1,

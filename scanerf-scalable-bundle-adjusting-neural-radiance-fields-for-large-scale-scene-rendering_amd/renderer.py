@@ -13,6 +13,7 @@ import torch
 
 from . import network
 from .cuda import compute_ray_forward
+from .hashgrid.lib import HASHGRID as _HG
 from .hashgrid import (accumulate_color, bg_pts_inference_v2, inverse_z_sampling, prepare_points, process_occupied_grid,
                        SKIP_UNSAMPLED, pts_inference, pts_inference_tracing, ray_block_intersection, sample_points, sort_tracing_blocks,
                        tracing_fusable, update_outgoing_bidx)
@@ -53,6 +54,10 @@ class TileSetRenderer:
         """tiles: dicts as returned by load_tile (block_corner / block_size describe the 2x HashGrid box;
         the renderer works on the inner tile box: rendering.py:164-165)."""
         self.device = device
+        # route switches (A/B timing, tests): slot lists derived inside the inference kernel (pts_inference_tracing) instead of
+        # prepare_points + pts_inference; a tracing pass runs on the running rays alone when fewer than this many tenths run
+        self.fuse_slots = True
+        self.compact_below_tenths = 9
         t = lambda a, dt: torch.as_tensor(np.ascontiguousarray(a), dtype=dt).to(device).contiguous()
         self.feature_tables = t(np.stack([x["features"] for x in tiles]), torch.float16)
         self.params = t(np.stack([x["blob"] for x in tiles]), torch.float32)
@@ -98,11 +103,11 @@ class TileSetRenderer:
         a wave fall on a few lines instead of 32 per level -- and walks along those rays; 1 = [S,B] (measured slower: every
         CU on the same depth slab)."""
         dev, nb = self.device, self.block_corner.shape[0]
-        lay = int(os.environ.get("SCANERF_RENDER_LAYOUT", layout))  # (env: A/B timing)
+        lay = int(layout)
         n_rays = rays_o.shape[0]
-        # the single-pass comparison kernel (SCANERF_RENDER_ARITH=f32; also what > 64 tiles or >= 2^31 samples fall back to)
+        # the single-pass comparison kernel (HASHGRID.INFER_ARITH = "f32"; also what > 64 tiles or >= 2^31 samples fall back to)
         # reads the reference's [B,S] arrays only
-        single_pass = (os.environ.get("SCANERF_RENDER_ARITH", "").startswith("f") or nb > 64
+        single_pass = (_HG.INFER_ARITH == "f32" or nb > 64
                        or (n_rays + 31) * max(num_sample, num_bg_sample) >= 2 ** 31)
         if single_pass:
             lay = 0
@@ -125,7 +130,7 @@ class TileSetRenderer:
         ps = torch.empty(shp(num_sample, 3), device=dev)
         pa = torch.empty(shp(num_sample, 1), device=dev)
 
-        fuse_slots = tracing_fusable(nb) and not single_pass and os.environ.get("SCANERF_RENDER_FUSE_SLOTS", "1") != "0"
+        fuse_slots = tracing_fusable(nb) and not single_pass and self.fuse_slots
 
         def fg_pass(ro, rd, it, tb, tidx, zst, tr, df, sp, dp, running, pd, ps, pa):
             """One tracing pass (rendering.py:356-420) over the rays given: per-ray state tidx / zst / tr / df / sp / dp updated in place."""
@@ -159,7 +164,7 @@ class TileSetRenderer:
             n_run = int(running.sum())
             if n_run == 0:
                 break
-            if n_run * 10 > B * int(os.environ.get("SCANERF_RENDER_COMPACT_TENTHS", "9")):   # (compaction costs ~0.1 ms of gathers)
+            if n_run * 10 > B * self.compact_below_tenths:   # (compaction costs ~0.1 ms of gathers)
                 fg_pass(rays_o, rays_d, inter, tracing_blocks, tracing_idx, z_start, transp, dif, spec, depth, running, pd, ps, pa)
                 continue
             # Not every ray runs (rays that miss every tile; later passes: most have left the tiles or are saturated): the pass runs

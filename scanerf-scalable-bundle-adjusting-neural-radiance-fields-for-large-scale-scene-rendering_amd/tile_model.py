@@ -240,7 +240,7 @@ class TileModel(nn.Module):
     def render_fore_fused(self, rays_o, rays_d, S, global_step):
         z, dist = self.sample(rays_o, rays_d, S)
         valid = torch.all(z != -1, dim=-1)
-        self.packed.pack(self.decoder.blob(), network.weight_feature(global_step, self.device), network.skip_levels(global_step))
+        self.packed.pack(self.decoder.blob(), network.weight_feature(global_step, self.device), (network.skip_levels(global_step) if LEVEL_SKIP else 0))
         table = self.gather_table()
         out, w = render.render_forward(rays_o, rays_d, z, dist, table, self.resolution, self.packed,
                                        self.min_bbox.tolist(), self.bbox_size.tolist(), render.FORE, False,
@@ -260,7 +260,7 @@ class TileModel(nn.Module):
         background (inverse-z, contract_bg, infinity) renders, merged with the foreground's T_left.
         occlusion_mask [B,1] bool (tile.py:655,661): both branches' valid sets are ANDed with it
         (hashgrid/__init__.py:420-421,479-480); a masked ray renders as zeros with T_left = 1, as every invalid ray."""
-        self.packed.pack(self.decoder.blob(), network.weight_feature(global_step, self.device), network.skip_levels(global_step))
+        self.packed.pack(self.decoder.blob(), network.weight_feature(global_step, self.device), (network.skip_levels(global_step) if LEVEL_SKIP else 0))
         table = self.gather_table()
         box = (self.min_bbox.tolist(), self.bbox_size.tolist())
         z, dist = self.sample(rays_o, rays_d, S_fg)
@@ -385,6 +385,14 @@ def train_step_ops(model, dec_opt, rays_o, rays_d, target, S, global_step, table
     return loss.detach()
 
 
+# Route switches of the fused steps (module attributes; tests and A/B timings flip them, nothing reads the environment):
+LARGE_T_ROUTE = "dfeat"     # tables above 2^21 entries: "dfeat" = stand-alone scatter from the backward's dfeat (default), "fused" = the
+                            # backward's own records + the split pass
+FORWARD_PLAN = True         # the forward launch counts the backward's record ranges (no separate plan launch)
+LEVEL_SKIP = True           # levels whose coarse-to-fine weight is exactly zero are left out of gathers and records (same results)
+JSTASH = True               # pose gradients: the forward stashes the encoder's position Jacobians for the backward
+
+
 def train_step_fused(model, dec_opt, rays_o, rays_d, target, S, global_step, table_lr=1e-2, timer=None,
                      pose_grads=False, fused_scatter=None, compact_rays=None, overlap_plan=False, dec_step=True,
                      fused_adam=True):
@@ -416,7 +424,7 @@ def train_step_fused(model, dec_opt, rays_o, rays_d, target, S, global_step, tab
                 return torch.zeros((), device=dev)
         wf = model.weight_feature(global_step)
         blob = model.decoder.blob()
-        model.packed.pack(blob, wf, network.skip_levels(global_step))
+        model.packed.pack(blob, wf, (network.skip_levels(global_step) if LEVEL_SKIP else 0))
         ntile = (S + 31) // 32
         tile_T = torch.empty((B, render.tile_T_columns(S)), device=dev)
         bwd_arith = render.backward_arith(True, pose_grads)
@@ -428,8 +436,8 @@ def train_step_fused(model, dec_opt, rays_o, rays_d, target, S, global_step, tab
             # entries its buckets (T / 256) outgrow the accumulate's LDS image.  Round 4 put a split pass in front of the
             # accumulate (csrc/scatter.hip k_bin_split: T = 2^24, 16 384 rays: 9.6 -> 6.1 ms per step on the fused route), but
             # the stand-alone scatter from dfeat, which emits straight into 2^13-entry buckets, is still ahead there (5.6 ms):
-            # it stays the default above 2^21; SCANERF_LARGE_T_ROUTE=fused selects the fused route
-            fused_scatter = T <= (1 << 21) or os.environ.get("SCANERF_LARGE_T_ROUTE", "dfeat") == "fused"
+            # it stays the default above 2^21; LARGE_T_ROUTE = "fused" selects the fused route
+            fused_scatter = T <= (1 << 21) or LARGE_T_ROUTE == "fused"
         fused = fused_scatter and render.scatter_supported(B, S, T)
         ws = plan_done = None
         side = model._side_stream if overlap_plan else None  # (the plan then has no timer section of its own)
@@ -450,10 +458,10 @@ def train_step_fused(model, dec_opt, rays_o, rays_d, target, S, global_step, tab
             # indices are the plan's) -- no separate plan launch (0.25 ms at configs[1])
             jstash = None
             if (fused and ws is None and bwd_arith in render._capi.T16_FAMILY and render.forward_plan_supported(B, S, T)
-                    and not os.environ.get("SCANERF_NO_FORWARD_PLAN")):
+                    and FORWARD_PLAN):
                 # pose refinement: the forward also stashes the encoder's position Jacobians (it has the corner values in
                 # registers), so that the backward can chain the feature gradients to the rays without a second pass over the table
-                if pose_grads and table.dtype == torch.float32 and not os.environ.get("SCANERF_NO_JSTASH"):
+                if pose_grads and table.dtype == torch.float32 and JSTASH:
                     jstash = torch.empty(render.jstash_shape(B, S), dtype=render.JSTASH_DTYPE, device=dev)
                 out, _, ws = render.render_forward(rays_o, rays_d, z, dist, table, model.resolution, model.packed, *box,
                                                    ray_valid=valid, want_weights=False, tile_T=tile_T, xstash=xstash, plan=True,
@@ -517,7 +525,8 @@ def train_step_fused(model, dec_opt, rays_o, rays_d, target, S, global_step, tab
             pts = ((rays_o[:, None, :] + z[:, :, None] * rays_d[:, None, :]).reshape(-1, 3) - model._min_dev) \
                 / model._size_dev * 4.0 - 2.0
             with _sec(timer, "table_grad_scatter", B * S * 16 * (8 + 16 * 8)):
-                render.scatter_table_grad(pts.contiguous(), dfeat, gtab, model.resolution)
+                render.scatter_table_grad(pts.contiguous(), dfeat, gtab, model.resolution,
+                                          compact_records=render.compact_record_format(bwd_arith) if T > (1 << 21) else -1)
         if not adam_epilogue:
             model.features.grad = gtab
             with _sec(timer, "sparse_adam", model.features.numel() * 28):
@@ -545,7 +554,7 @@ def fgbg_gradients(model, rays_o, rays_d, target, S_fg, S_bg, global_step, inval
     g_o = g_d = None
     with torch.no_grad():
         wf = model.weight_feature(global_step)
-        model.packed.pack(model.decoder.blob(), wf, network.skip_levels(global_step))
+        model.packed.pack(model.decoder.blob(), wf, (network.skip_levels(global_step) if LEVEL_SKIP else 0))
         box = (model.min_bbox.tolist(), model.bbox_size.tolist())
         branches = []
         z, dist = model.sample(rays_o, rays_d, S_fg)
@@ -616,7 +625,7 @@ def train_step_fgbg(model, dec_opt, rays_o, rays_d, target, S_fg, S_bg, global_s
     B = rays_o.shape[0]
     dev = model.device
     T = model.features.shape[1]
-    fused = (T <= (1 << 21) or os.environ.get("SCANERF_LARGE_T_ROUTE", "dfeat") == "fused") and render.scatter_supported(B, S_fg, T) \
+    fused = (T <= (1 << 21) or LARGE_T_ROUTE == "fused") and render.scatter_supported(B, S_fg, T) \
         and render.scatter_supported(B, S_bg, T) and render.backward_arith() != render._capi.ARITH_F32
     if pose_grads and model.gather_table().dtype != torch.float32:
         raise RuntimeError("scanerf: train_step_fgbg(pose_grads=True) gathers from the fp32 table")
@@ -653,7 +662,7 @@ def train_step_fgbg(model, dec_opt, rays_o, rays_d, target, S_fg, S_bg, global_s
         return (loss, r[3], r[4]) if pose_grads else loss
     with torch.no_grad():
         wf = model.weight_feature(global_step)
-        model.packed.pack(model.decoder.blob(), wf, network.skip_levels(global_step))
+        model.packed.pack(model.decoder.blob(), wf, (network.skip_levels(global_step) if LEVEL_SKIP else 0))
         box = (model.min_bbox.tolist(), model.bbox_size.tolist())
         table = model.gather_table()
         with _sec(timer, "sample_points_grid", B * (24 + 2 * 4 * S_fg)):
@@ -670,7 +679,7 @@ def train_step_fgbg(model, dec_opt, rays_o, rays_d, target, S_fg, S_bg, global_s
             xs = torch.empty((B * S, 32), device=dev)
             # (the forward launch reserves the backward's record ranges as well where the two kernels share a grid)
             in_fwd = (render.backward_arith(True, False) in render._capi.T16_FAMILY and render.forward_plan_supported(B, S, T)
-                      and not os.environ.get("SCANERF_NO_FORWARD_PLAN"))
+                      and FORWARD_PLAN)
             js = torch.empty(render.jstash_shape(B, S), dtype=render.JSTASH_DTYPE, device=dev) if pose_grads else None
             with _sec(timer, "render_forward", B * (24 + 20 + S * 16 * 8 * 2 * table.element_size()), B * S * MLP_FLOPS_PER_SAMPLE):
                 r = render.render_forward(rays_o, rays_d, z_, d_, table, model.resolution, model.packed, *box, mode, inf,

@@ -24,6 +24,19 @@ def golden():
     return load
 
 
+def experiments_build():
+    """The library under test was built with `make EXP=1`: the A/B switches of csrc/common.h (tune_int / tune_set) read the
+    environment.  The product build compiles them to their defaults; tests of an alternative launch shape skip there."""
+    import scanerf_amd  # noqa: F401
+    from scanerf_amd import _capi
+    return bool(_capi.lib().scanerf_experiments_enabled())
+
+
+def need_experiments(what):
+    if not experiments_build():
+        pytest.skip(f"{what}: only in a library built with `make EXP=1` (the product build has no environment switches)")
+
+
 def need_symbol(name):
     """Skip a test whose entry point is one of the OPTIONAL test / measurement symbols a lean build may not export."""
     import scanerf_amd  # noqa: F401

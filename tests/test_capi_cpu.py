@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
     assert not missing, missing
     assert set(_capi.SYMBOLS) <= set(declared), sorted(set(_capi.SYMBOLS) - set(declared))
     assert set(_capi.OPTIONAL_SYMBOLS) <= set(declared) and not set(_capi.OPTIONAL_SYMBOLS) & set(_capi.SYMBOLS)
-    assert lib.scanerf_abi_version() == 8
+    assert lib.scanerf_abi_version() == 9
     lib.scanerf_last_error.restype = ctypes.c_char_p
     assert isinstance(lib.scanerf_last_error(), bytes)
 

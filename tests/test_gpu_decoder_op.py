@@ -113,13 +113,15 @@ def test_decoder_op_is_bit_reproducible_and_covers_many_workgroups():
 
 
 def test_decoder_forward_on_16_sample_tiles_agrees_with_the_default_and_repeats(monkeypatch):
-    """SCANERF_DECODER_FWD=s16 (k_decoder_fwd_s16: the render-time kernel's decoder as a kernel of its own) against the default
+    """SCANERF_DECODER_FWD_S16=1 of an experiments build (k_decoder_fwd_s16: the render-time kernel's decoder as a kernel of its own) against the default
     32-sample-tile forward: both are the split-f16 evaluation with different k-step groupings -> equal to f32 rounding; ragged
     tail; launch after launch the same bits."""
+    from conftest import need_experiments
+    need_experiments("the stand-alone decoder forward on 16-sample tiles")
     m, x, wf, _ = _case((1 << 17) + 13, 40000, 5)
     with torch.no_grad():
         ref = m(x, weight_feature=wf)
-        monkeypatch.setenv("SCANERF_DECODER_FWD", "s16")
+        monkeypatch.setenv("SCANERF_DECODER_FWD_S16", "1")
         a = m(x, weight_feature=wf)
         b = m(x, weight_feature=wf)
     for k in ("sigma", "diffuse", "specular", "tint"):

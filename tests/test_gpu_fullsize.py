@@ -91,11 +91,12 @@ def test_full_size_fused_scatter_vs_atomics_and_conservation(full, arith, tol):
     pts = (((o[:, None, :] + z[:, :, None] * d[:, None, :]).reshape(-1, 3) - m._min_dev) / m._size_dev * 4.0 - 2.0).contiguous()
     g1 = torch.zeros_like(m.features)
     gin = dfeat.permute(1, 0, 2).contiguous()  # [N, 16, 2]
-    os.environ["SCANERF_SCATTER"] = "atomics"
+    from scanerf_amd.hashgrid.lib import HASHGRID as _HG
+    _HG.TABLE_GRAD_ROUTE = "atomics"
     try:
         embedding_bg_backward_cuda(pts, gin, None, g1, m.features, m.resolution)
     finally:
-        del os.environ["SCANERF_SCATTER"]
+        _HG.TABLE_GRAD_ROUTE = "binned"
     torch.cuda.synchronize()
     sc = float(g1.abs().max())
     assert sc > 0

@@ -405,7 +405,7 @@ def test_binned_scatter_matches_oracle_and_atomics(S, layout, log2_T):
         check(lib().scanerf_embedding_bg_backward_binned(
             ctypes.c_void_p(P.data_ptr()), ctypes.c_void_p(gi.data_ptr()), ctypes.c_void_p(gf.data_ptr()),
             ctypes.c_void_p(R.data_ptr()), N, L, T, layout, ctypes.c_void_p(ws.data_ptr()),
-            ctypes.c_size_t(ws_bytes), stream()), "binned")
+            ctypes.c_size_t(ws_bytes), ctypes.c_int(-1), stream()), "binned")
         np.testing.assert_allclose(gf.cpu().numpy(), gf_ref, rtol=1e-3, atol=3e-4)
 
 
@@ -615,11 +615,12 @@ def test_fused_scatter_large_table(S, log2_T, finest):
     render.scatter_accumulate(ws, g2, B, S_)
     pts = (((o[:, None, :] + z[:, :, None] * d[:, None, :]).reshape(-1, 3) - m._min_dev) / m._size_dev * 4.0 - 2.0).contiguous()
     g1 = torch.zeros_like(m.features)
-    os.environ["SCANERF_SCATTER"] = "atomics"
+    from scanerf_amd.hashgrid.lib import HASHGRID as _HG
+    _HG.TABLE_GRAD_ROUTE = "atomics"
     try:
         embedding_bg_backward_cuda(pts, dfeat.permute(1, 0, 2).contiguous(), None, g1, m.features, m.resolution)
     finally:
-        del os.environ["SCANERF_SCATTER"]
+        _HG.TABLE_GRAD_ROUTE = "binned"
     torch.cuda.synchronize()
     sc = float(g1.abs().max())
     assert sc > 0
@@ -1177,10 +1178,9 @@ def test_train_step_fgbg_one_adam_step_over_both_branches(S, log2_T):
 def test_train_step_large_table_adam_epilogue(S, monkeypatch):
     """Tables above 2^21 entries (the reference's default is 2^24) take the stand-alone binned scatter from dfeat; with
     fused_adam it ends in the same Adam epilogue (no gradient table): bit-identical to accumulate -> adam_step_cuda (on the
-    same 16-byte records: SCANERF_REC16; the default 8-byte ones of this route are compared in
+    same records on both routes: 12-byte ones in 64-byte segments behind the t16s backward; the 8-byte ones are compared in
     test_train_step_fgbg_one_adam_step_over_both_branches[22])."""
     from scanerf_amd.tile_model import TileModel, train_step_fused
-    monkeypatch.setenv("SCANERF_REC16", "1")
     torch.manual_seed(21)
     B, S_ = 2048, 64
     o = torch.rand(B, 3, device=DEV) * 8 - 4
@@ -1307,10 +1307,9 @@ def test_forward_counts_the_scatter_plan(S, monkeypatch):
     d = torch.nn.functional.normalize(torch.randn(B, 3, device=DEV), dim=-1) * (0.5 + torch.rand(B, 1, device=DEV))
     tgt = torch.rand(B, 3, device=DEV)
     res = {}
-    monkeypatch.delenv("SCANERF_NO_FORWARD_PLAN", raising=False)
+    from scanerf_amd import tile_model as _tm
     for tag in ("forward", "separate"):
-        if tag == "separate":
-            monkeypatch.setenv("SCANERF_NO_FORWARD_PLAN", "1")
+        monkeypatch.setattr(_tm, "FORWARD_PLAN", tag == "forward")
         m = TileModel([-4, -4, -4], [8, 8, 8], DEV, log2_T=14, seed=1)
         with torch.no_grad():
             m.features.mul_(30.0)
@@ -1507,15 +1506,14 @@ def test_coarse_to_fine_level_skip_is_bit_identical(S, step, monkeypatch):
     d = torch.nn.functional.normalize(torch.randn(B, 3, device=DEV), dim=-1)
     tgt = torch.rand(B, 3, device=DEV)
     res = {}
-    monkeypatch.delenv("SCANERF_NO_LEVEL_SKIP", raising=False)
+    from scanerf_amd import tile_model as _tm
     for tag in ("skip", "all"):
-        if tag == "all":
-            monkeypatch.setenv("SCANERF_NO_LEVEL_SKIP", "1")
+        monkeypatch.setattr(_tm, "LEVEL_SKIP", tag == "skip")
         m = TileModel([-4, -4, -4], [8, 8, 8], DEV, log2_T=14, seed=1)
         with torch.no_grad():
             m.features.mul_(30.0)
         z, dist = m.sample(o, d, S_)
-        m.packed.pack(m.decoder.blob(), network.weight_feature(step, DEV), network.skip_levels(step))
+        m.packed.pack(m.decoder.blob(), network.weight_feature(step, DEV), network.skip_levels(step) if tag == "skip" else 0)
         box = (m.min_bbox.tolist(), m.bbox_size.tolist(), render.FORE, False)
         xs = torch.empty(B * S_, 32, device=DEV)
         out, w = render.render_forward(o, d, z, dist, m.features, m.resolution, m.packed, *box, xstash=xs)
@@ -1540,8 +1538,8 @@ def test_split_pass_feeding_the_adam_epilogue(log2_T, finest, fgbg, monkeypatch)
     """Round 4's split pass (csrc/scatter.hip k_bin_split) in front of the accumulate's Adam epilogue -- accumulate_adam with one
     record set (train_step_fused) and adam2 with two (train_step_fgbg), window shifts 1 (2^22) and 3 (2^24), with and without
     window-crossing pairs (finest resolution above 8 192: second entries through the overflow table, consumed through the fine
-    stream's flag).  Only reachable with SCANERF_LARGE_T_ROUTE=fused.  Compared with the same steps under SCANERF_NO_SPLIT=1 (the
-    window re-reads, 16-byte records) AND under the default dfeat route: both moments and the parameters after the first step
+    stream's flag).  Only reachable with tile_model.LARGE_T_ROUTE = "fused".  Compared with the same steps under SCANERF_NO_SPLIT=1 (the
+    window re-reads, 16-byte records; experiments build only) AND under the default dfeat route: both moments and the parameters after the first step
     (the split re-encodes the records as Rec12, components rounded to 19 mantissa bits: moments agree to 2e-5 of their maximum)
     and after a second one (looser: an entry whose first gradient is below one route's fixed-point floor has moved by lr in
     the other, which changes the second step's gradients a little)."""
@@ -1549,9 +1547,10 @@ def test_split_pass_feeding_the_adam_epilogue(log2_T, finest, fgbg, monkeypatch)
     B, S_ = 3000, 64
 
     def run(route, no_split):
-        monkeypatch.setenv("SCANERF_LARGE_T_ROUTE", route)
+        from scanerf_amd import tile_model as _tm
+        monkeypatch.setattr(_tm, "LARGE_T_ROUTE", route)
         if no_split:
-            monkeypatch.setenv("SCANERF_NO_SPLIT", "1")
+            monkeypatch.setenv("SCANERF_NO_SPLIT", "1")   # (read by an experiments build only)
         else:
             monkeypatch.delenv("SCANERF_NO_SPLIT", raising=False)
         torch.manual_seed(8)
@@ -1576,7 +1575,8 @@ def test_split_pass_feeding_the_adam_epilogue(log2_T, finest, fgbg, monkeypatch)
 
     init, ref = run("fused", False)          # the split pass
     assert float((ref[0][0] != init).float().mean()) > 1e-4   # the table moved
-    for route, no_split in (("fused", True), ("dfeat", False)):
+    from conftest import experiments_build
+    for route, no_split in ((("fused", True),) if experiments_build() else ()) + (("dfeat", False),):
         _, other = run(route, no_split)
         for it, tol in ((0, 2e-5), (1, 3e-4)):
             (p0, m0, v0), (p1, m1, v1) = ref[it], other[it]
@@ -1594,14 +1594,16 @@ def test_split_pass_feeding_the_adam_epilogue(log2_T, finest, fgbg, monkeypatch)
 
 
 @pytest.mark.parametrize("layout,log2_T,N", [(1, 22, 300_007), (0, 22, 70_001), (1, 24, 120_011), (1, 22, 777)])
-def test_large_table_producer_writes_whole_segments(S, layout, log2_T, N, monkeypatch):
+def test_large_table_producer_writes_whole_segments(S, layout, log2_T, N):
     """Round 6: above 2^21 entries per level the stand-alone producer keeps one five-record slot per bucket in LDS and writes
     each full slot as one 64-byte segment (csrc/scatter.hip k_bin_scatter_seg, record format 3).  The SAME set of 12-byte records
-    reaches the integer accumulate as through the record-at-a-time producer (SCANERF_SCATTER_OLD=1), so parameters and both
-    moments after two Adam steps are bit-equal between the routes -- over several rounds per batch (300 007 points: ~2.3 records
-    per bucket and batch), points on the upper faces (x + 1 in the next bucket at T = 2^22), fewer points than one batch per
-    workgroup (777), point-major rows (layout 0) -- and the first moment follows the oracle's sequential scatter."""
-    from scanerf_amd import render
+    reaches the integer accumulate as through the record-at-a-time producer -- which still serves a caller whose workspace has no
+    room for the segments' padding (the size rounds 1-5 asked for) --, so parameters and both moments after two Adam steps are
+    bit-equal between the two: over several records per bucket and batch (300 007 points), points on the upper faces (x + 1 in the
+    next bucket at T = 2^22), fewer points than one batch per workgroup (777), point-major rows (layout 0: the old producer keeps
+    16-byte records there, so equal to the records' rounding) -- and the first moment follows the oracle's sequential scatter."""
+    import ctypes
+    from scanerf_amd._capi import check, lib, stream, workspace
     rng = np.random.default_rng(61)
     L, T = 16, 2 ** log2_T
     res = O.level_resolutions(torch.tensor([32, 32, 32]), torch.tensor([2048, 2048, 2048])).numpy()
@@ -1611,36 +1613,32 @@ def test_large_table_producer_writes_whole_segments(S, layout, log2_T, N, monkey
     gin[100:140] = 0.0    # records with an exactly zero gradient: skipped by the accumulate, entries stay untouched
     P, R = g(pts), g(res)
     gi = g(np.ascontiguousarray(gin.transpose(1, 0, 2)) if layout == 1 else gin)
+    need = lib().scanerf_embedding_bwd_workspace_bytes(N, L, T)
+    nbins = L * 2048
+    small = (N * L * 4 + N * L // 8 + 4096) * 16 + nbins * 1024 * 4 + (2 * nbins + 6) * 4 + 256   # what rounds 1-5 sized: no segment padding
+    assert 0 < small < need
+    ws = workspace(DEV, need)
     out = {}
-    for old in (False, True):
-        if old:
-            monkeypatch.setenv("SCANERF_SCATTER_OLD", "1")
+    for ws_bytes in (need, small):
         params, m1, m2 = (torch.zeros(L, T, 2, device=DEV) for _ in range(3))
         over = torch.zeros(L, T, 2, device=DEV)
         for step in range(2):
-            if layout == 1:
-                render.scatter_table_grad_adam(P, gi, R, params, m1, m2, 1e-2, 0.9, 0.99, 1e-15, step, overflow_grad=over, compact_records=2)
-            else:
-                import ctypes
-                from scanerf_amd._capi import check, lib, stream, workspace
-                need = lib().scanerf_embedding_bwd_workspace_bytes(N, L, T)
-                ws = workspace(DEV, need)
-                check(lib().scanerf_embedding_bg_backward_binned_adam(
-                    ctypes.c_void_p(P.data_ptr()), ctypes.c_void_p(gi.data_ptr()), ctypes.c_void_p(R.data_ptr()), N, L, T, 0,
-                    ctypes.c_void_p(ws.data_ptr()), ctypes.c_size_t(ws.numel()), ctypes.c_void_p(params.data_ptr()),
-                    ctypes.c_void_p(m1.data_ptr()), ctypes.c_void_p(m2.data_ptr()), None, 0, ctypes.c_void_p(over.data_ptr()),
-                    ctypes.c_float(1e-2), ctypes.c_float(0.9), ctypes.c_float(0.99), ctypes.c_float(1e-15), step, 2, stream()), "binned_adam")
+            check(lib().scanerf_embedding_bg_backward_binned_adam(
+                ctypes.c_void_p(P.data_ptr()), ctypes.c_void_p(gi.data_ptr()), ctypes.c_void_p(R.data_ptr()), N, L, T, layout,
+                ctypes.c_void_p(ws.data_ptr()), ctypes.c_size_t(ws_bytes), ctypes.c_void_p(params.data_ptr()),
+                ctypes.c_void_p(m1.data_ptr()), ctypes.c_void_p(m2.data_ptr()), None, 0, ctypes.c_void_p(over.data_ptr()),
+                ctypes.c_float(1e-2), ctypes.c_float(0.9), ctypes.c_float(0.99), ctypes.c_float(1e-15), step, 2, stream()), "binned_adam")
         assert not bool(over.any())
-        out[old] = (params.clone(), m1.clone(), m2.clone())
-    for a, b in zip(out[False], out[True]):
+        out[ws_bytes] = (params.clone(), m1.clone(), m2.clone())
+    for a, b in zip(out[need], out[small]):
         if layout == 1:
             assert torch.equal(a, b)
-        else:   # (the old producer keeps 16-byte records for point-major rows of a large table: same sums to the records' rounding)
+        else:
             assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max())
     if N <= 130_000 and log2_T == 22:
         feat = np.zeros((L, T, 2), np.float32)
         _, gf_ref = O.embedding_backward(pts, gin, feat, res)
-        got = out[False][1].cpu().numpy() / 0.19     # m after two steps on the same gradient: (0.1 + 0.9 * 0.1) g
+        got = out[need][1].cpu().numpy() / 0.19     # m after two steps on the same gradient: (0.1 + 0.9 * 0.1) g
         assert float(np.abs(got - gf_ref).max()) / float(np.abs(gf_ref).max()) <= 4e-6
 
 

@@ -234,8 +234,11 @@ def _inference_case(B=1000, S=72, seed=5, empty_tile=None):
 def test_pipelined_group_loop_gives_the_bits_of_the_plain_one(monkeypatch):
     """The 32-sample-tile chunk kernel's software pipeline (next group's corner loads in flight during a group's decoder) reorders
     memory traffic only: fg and bg outputs equal SCANERF_RENDER_PIPE=0 bit for bit."""
+    from conftest import need_experiments
+    need_experiments("the 32-sample-tile kernel without its software pipeline")
+    from scanerf_amd.hashgrid.lib import HASHGRID as _HG
     run = _inference_case()
-    monkeypatch.setenv("SCANERF_RENDER_ARITH", "h3")
+    monkeypatch.setattr(_HG, "INFER_ARITH", "h3")
     monkeypatch.delenv("SCANERF_RENDER_PIPE", raising=False)
     piped = run()
     monkeypatch.setenv("SCANERF_RENDER_PIPE", "0")
@@ -296,12 +299,12 @@ def test_tiles_of_zero_opacity_skip_the_directional_layers_and_change_nothing(mo
     """Samples whose opacity 1 - exp(-sigma delta) is exactly zero (tile 1's density head answers -300) leave zeros; the
     16-sample-tile kernel skips the directional layers of tiles that hold only such samples, the 32-sample-tile kernel does not:
     equal outputs, exact zeros where tile 1 is the only tile, the other tiles untouched."""
+    from scanerf_amd.hashgrid.lib import HASHGRID as _HG
     run = _inference_case(1000, 72, seed=17, empty_tile=1)
-    monkeypatch.delenv("SCANERF_RENDER_ARITH", raising=False)
     t16 = run()
-    monkeypatch.setenv("SCANERF_RENDER_ARITH", "h3")
+    monkeypatch.setattr(_HG, "INFER_ARITH", "h3")
     h3 = run()
-    monkeypatch.delenv("SCANERF_RENDER_ARITH", raising=False)
+    monkeypatch.setattr(_HG, "INFER_ARITH", "t16")
     bi = run.ctx["bi"].cpu().numpy()
     only1 = (bi[..., 0] == 1) & (bi[..., 1] == -1)
     assert only1.sum() > 1000 and t16[2].max() > 0.05
@@ -318,16 +321,19 @@ def test_sixteen_sample_tile_kernel_against_the_32_sample_one(monkeypatch, B, S)
     they agree to f32 rounding; the SH rows change where the harmonics are evaluated, not their bits (SCANERF_RENDER_SH_ROWS=0:
     equal bit for bit; S = 16 makes a chunk's ray range too wide for the rows, so that case runs without them anyway); and the
     default repeats launch after launch."""
+    from conftest import experiments_build
+    from scanerf_amd.hashgrid.lib import HASHGRID as _HG
     run = _inference_case(B, S, seed=11)
-    monkeypatch.delenv("SCANERF_RENDER_ARITH", raising=False)
     monkeypatch.delenv("SCANERF_RENDER_SH_ROWS", raising=False)
     t16 = run()
-    monkeypatch.setenv("SCANERF_RENDER_SH_ROWS", "0")
-    norows = run()
-    monkeypatch.delenv("SCANERF_RENDER_SH_ROWS", raising=False)
-    monkeypatch.setenv("SCANERF_RENDER_ARITH", "h3")
+    norows = t16
+    if experiments_build():   # (the switch exists in a `make EXP=1` library only; S = 16 runs without the rows in every build)
+        monkeypatch.setenv("SCANERF_RENDER_SH_ROWS", "0")
+        norows = run()
+        monkeypatch.delenv("SCANERF_RENDER_SH_ROWS", raising=False)
+    monkeypatch.setattr(_HG, "INFER_ARITH", "h3")
     h3 = run()
-    monkeypatch.delenv("SCANERF_RENDER_ARITH", raising=False)
+    monkeypatch.setattr(_HG, "INFER_ARITH", "t16")
     assert t16[2].max() > 0.05 and t16[5].max() > 0.05
     for a, b, c in zip(t16, norows, h3):
         assert np.array_equal(a, b)
