@@ -479,8 +479,26 @@ def reference_default_leg(args, dev, S, step0, n=8):
     ms = (time.perf_counter() - t0) / n * 1e3
     secs = {k: round(v, 4) for k, v in timer.summary().items()}   # (average per LAUNCH of the section: two forwards / backwards per iteration)
     del m, opt
+    torch.cuda.empty_cache()
+    # OPT-IN variant, under its own key: the table's Adam moments in half precision (adam_step_cuda_fp16 semantics,
+    # cuda/adam_kernel.cu:98-144) -- not what the reference's live code runs (torch.optim.Adam, fp32 state), never the default
+    ms16 = None
+    try:
+        m = tm.TileModel([-4.0, -4, -4], [8, 8, 8], dev, log2_T=24, seed=24, sampler_log2dim=4, fp16_moments=True)
+        opt = torch.optim.Adam(m.decoder.parameters(), lr=1e-3, betas=(0.9, 0.99), eps=1e-15)
+        for i in range(2):
+            tm.train_step_fgbg(m, opt, ro, rd, tg, S, S, step0 + i, pose_grads=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(n):
+            tm.train_step_fgbg(m, opt, ro, rd, tg, S, S, step0 + 2 + i, pose_grads=True)
+        torch.cuda.synchronize()
+        ms16 = (time.perf_counter() - t0) / n * 1e3
+        del m, opt
+    except Exception as e:  # noqa: BLE001
+        print(f"bench.py: fp16-moment leg failed: {e}", file=sys.stderr)
     return {"reference_default_ms_per_iteration": ms, "reference_default_rays_per_s": Bd / ms * 1e3,
-            "reference_default_sections_ms": secs,
+            "reference_default_sections_ms": secs, "reference_default_fp16_moments_ms_per_iteration": ms16,
             "reference_default_is": (f"the reference's shipped configuration: T=2^24 fp32 table (fp32 Adam moments), {Bd} rays x ({S} + {S}) "
                                      f"samples, fg + T_left*bg, pose (ray) gradients, one sparse Adam; 2 warm-up + {n} timed iterations")}
 
@@ -726,6 +744,14 @@ def init_rccl(world, local):
         torch.cuda.synchronize()
 
 
+def library_state():
+    from scanerf_amd import _capi
+    st = _capi.audit_state()
+    lib = _capi.lib()
+    return {"isa_audit": st.get("status"), "compiler": st.get("compiler"), "abi": int(lib.scanerf_abi_version()),
+            "experiments_build": bool(lib.scanerf_experiments_enabled()), "so_bytes": os.path.getsize(_capi.LIB_PATH)}
+
+
 def rccl_mapped():
     """librccl is mapped into this process (what `torch.distributed`'s nccl backend is on ROCm)."""
     try:
@@ -908,6 +934,9 @@ def main():
             "t16_ms_per_step": side_ms.get("t16"), "h3_ms_per_step": side_ms.get("h3"), "f32_arith_ms_per_step": side_ms.get("f32"),
             "consensus_ms": consensus_ms,
             "consensus_frac_of_iteration": consensus_ms / (SYN_ITERS * ms_per_step),
+            # which library produced these numbers: the ISA audit's verdict on the loaded file (tools/isa_audit.py), its compiler, and
+            # whether it is the product build (no environment switches) or an experiments build (make EXP=1)
+            "library": library_state(),
         }
         if timer and timer.count:
             line["roofline"] = roofline(timer, arith if fused else "f32", args, B, S, valid_frac, fgbg, ms_per_step)

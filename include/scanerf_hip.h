@@ -145,6 +145,10 @@ int scanerf_table_grad_scatter_adam_rays(const float *rays_o, const float *rays_
                                          const float *bbox_size /*[host]*/, const int32_t *resolutions, int T, void *workspace,
                                          size_t workspace_bytes, float *params, float *exp_avg, float *exp_avg_sq, void *half_table,
                                          int half_dtype, float *overflow_grad, float lr, float beta1, float beta2, float eps, int step,
+                                         int fp16_moments /* OPT-IN, default 0: exp_avg / exp_avg_sq are [16][T][2] HALF arrays and the
+                                            update is adam_step_cuda_fp16's (cuda/adam_kernel.cu:98-144: gradient x 128, moments stored in
+                                            half): 16 instead of 24 bytes of optimiser state moved per touched entry each way.  NOT what the
+                                            reference's live code runs (torch.optim.Adam, fp32 state, tile.py:301) */,
                                          scanerf_stream_t stream);
 /* hashgrid/src/hashgrid_kernel.cu:246-270 / :272-300 (world-space box variant) */
 int scanerf_embedding_forward(const float *points, float *outputs, const float *features,

@@ -99,6 +99,23 @@ def audit_state():
     return {"status": st.get("status", "missing"), "why": "; ".join(st.get("detail") or [])[:400], "compiler": st.get("compiler")}
 
 
+def audit_required():
+    """True where an "unvalidated" library is NOT acceptable: SCANERF_REQUIRE_AUDITED=1 (the project's own CI / bench box), or the
+    installed hipcc IS the compiler build csrc/isa_manifest.json was validated with -- then nothing excuses a library that was
+    not built and audited by it.  Elsewhere (a downstream user's other ROCm) "unvalidated" stays a loud warning."""
+    import json
+    import subprocess
+    if os.environ.get("SCANERF_REQUIRE_AUDITED") == "1":
+        return True
+    try:
+        want = json.load(open(os.path.join(_HERE, "csrc", "isa_manifest.json"))).get("compiler", "")
+        out = subprocess.run(["/opt/rocm/bin/hipcc", "--version"], capture_output=True, text=True, timeout=60).stdout
+        have = " | ".join(ln.strip() for ln in out.splitlines() if ln.startswith(("HIP version", "AMD clang version")))
+        return bool(want) and want == have
+    except (OSError, ValueError, subprocess.SubprocessError):
+        return False
+
+
 SWEEP_ICACHE = False   # tests only: evict the instruction caches after every library call (scanerf_icache_sweep)
 
 

@@ -258,7 +258,7 @@ __global__ void __launch_bounds__(1024) k_bin_scatter(const float *__restrict__ 
                 const float p[3] = { points[3 * i], points[3 * i + 1], points[3 * i + 2] };
                 one(i, l, p);
             }
-    } else if (g.L == 16 && (((uintptr_t)grad_in) & 15) == 0) {
+    } else if (g.rows16) {
         // Point-major gradients [N][16][2] (the binding surface: what autograd hands embedding_bg_backward_cuda), round 5.
         // A thread reads its point's row ONCE (128 contiguous bytes, eight 16-byte loads: the wave consumes whole lines) and
         // keeps it in registers; the workgroup then emits LEVEL BY LEVEL, in step (one barrier per level): while it is on a
@@ -535,6 +535,8 @@ struct AdamEpilogue {
     int half_dtype;          // SCANERF_F16 / SCANERF_BF16
     float *overflow_grad;    // optional
     AdamArgs a;
+    int half_state;          // OPT-IN: exp_avg / exp_avg_sq are __half arrays, adam_step_cuda_fp16 semantics (cuda/adam_kernel.cu:98-144:
+                             // loss scale 128, moments stored in half); the default -- what the reference's live code runs, torch.optim.Adam -- is 0
 };
 template <int kThreads, int U, bool LANE_OWNS_RUN = false, bool ADAM = false>
 __global__ void __launch_bounds__(kThreads) k_bin_accumulate(const Rec *__restrict__ recs,
@@ -783,7 +785,25 @@ __global__ void __launch_bounds__(kThreads) k_bin_accumulate(const Rec *__restri
                         og[j] = make_float2(0.0f, 0.0f);
                     }
                 }
-                if (gx != 0.0f || gy != 0.0f) {
+                if ((gx != 0.0f || gy != 0.0f) && ad.half_state) {   // (uniform) fp16 moments: 8 + 4 + 4 bytes per entry each way
+                    __half2 *Mh = reinterpret_cast<__half2 *>(ad.exp_avg) + ebase, *Vh = reinterpret_cast<__half2 *>(ad.exp_avg_sq) + ebase;
+                    float2 p = P[j];
+                    const __half2 mh = Mh[j], vh = Vh[j];
+                    float mx = __low2float(mh), my = __high2float(mh), vx = __low2float(vh), vy = __high2float(vh);
+                    // (an untouched component keeps its stored bits: a float round trip of a half is exact)
+                    adam_update_one<true>(p.x, mx, vx, gx, ad.a);
+                    adam_update_one<true>(p.y, my, vy, gy, ad.a);
+                    P[j] = p;
+                    Mh[j] = __halves2half2(__float2half(mx), __float2half(my));
+                    Vh[j] = __halves2half2(__float2half(vx), __float2half(vy));
+                    if (ad.half_table) {
+                        if (ad.half_dtype == SCANERF_F16)
+                            reinterpret_cast<__half2 *>(ad.half_table)[ebase + j] = __floats2half2_rn(p.x, p.y);
+                        else
+                            reinterpret_cast<__hip_bfloat162 *>(ad.half_table)[ebase + j] =
+                                __hip_bfloat162{ __float2bfloat16(p.x), __float2bfloat16(p.y) };
+                    }
+                } else if (gx != 0.0f || gy != 0.0f) {
                     float2 p = P[j], m = Mo[j], v = Vo[j];
                     adam_update_one<false>(p.x, m.x, v.x, gx, ad.a);
                     adam_update_one<false>(p.y, m.y, v.y, gy, ad.a);
@@ -873,6 +893,7 @@ bool fused_geom(int B, int S, int T, BinGeom &g, int arith = SCANERF_ARITH_F32)
     if ((int64_t)B * S * 16 * 4 + (1 << 20) >= (int64_t)1 << 31) return false;  // 32-bit record offsets
     g.N = B * S; g.L = 16; g.T = T;
     g.dbg = 0;
+    g.rows16 = 0;
     g.NB = T >> g.bucket_log;
     g.W = scanerf_render_backward_grid(B);
     g.per_wg = 0;
@@ -943,6 +964,7 @@ static int binned_backward(const float *points, const float *grad_in, float *gra
     BinGeom g;
     g.N = N; g.L = L; g.T = T;
     g.rpg = 1;
+    g.rows16 = 0;
     g.dbg = tune_int("SCANERF_ACC_DBG", 0);
     g.bucket_log = standalone_bucket_log(T);
     // Point-major gradients of 16 levels (round 5): the level-by-level producer (k_bin_scatter) with the fused path's bucket size
@@ -961,6 +983,7 @@ static int binned_backward(const float *points, const float *grad_in, float *gra
     // kernels), 12-byte ones by default for the point-major rows (f32 components with 19-bit mantissas, 23-bit weights:
     // scatter_common.h Rec12; SCANERF_REC16=1 keeps the 16-byte records)
     if (rows16 && compact_records == 0) compact_records = 2;
+    g.rows16 = rows16 ? 1 : 0;
     g.rec8 = (compact_records >= 1 && compact_records <= 2 && (grad_layout == 1 || (rows16 && compact_records == 2)) &&
               g.bucket_log <= kRec8MaxBucketLog && !tune_set("SCANERF_REC16")) ? compact_records : 0;
     g.NB = T >> g.bucket_log;
@@ -1101,7 +1124,7 @@ SCANERF_API int scanerf_embedding_bg_backward_binned_adam(const float *points, c
     SCANERF_REQUIRE(!half_table || half_dtype == SCANERF_F16 || half_dtype == SCANERF_BF16,
                     "embedding_bg_backward_binned_adam: half_dtype=%d", half_dtype);
     const AdamEpilogue ad{ nullptr, nullptr, nullptr, 0u, params, exp_avg, exp_avg_sq, half_table, half_dtype, overflow_grad,
-                           make_adam_args(lr, beta1, beta2, eps, step) };
+                           make_adam_args(lr, beta1, beta2, eps, step), 0 };
     SCANERF_REQUIRE(compact_records >= -1 && compact_records <= 2, "embedding_bg_backward_binned_adam: compact_records=%d", compact_records);
     return binned_backward(points, grad_in, overflow_grad, resolutions, N, L, T, grad_layout, workspace, workspace_bytes, &ad, stream,
                            compact_records);
@@ -1116,7 +1139,8 @@ SCANERF_API int scanerf_table_grad_scatter_adam_rays(const float *rays_o, const 
                                                      const float *min_bbox, const float *bbox_size, const int32_t *resolutions, int T,
                                                      void *workspace, size_t workspace_bytes, float *params, float *exp_avg,
                                                      float *exp_avg_sq, void *half_table, int half_dtype, float *overflow_grad, float lr,
-                                                     float beta1, float beta2, float eps, int step, scanerf_stream_t stream)
+                                                     float beta1, float beta2, float eps, int step, int fp16_moments,
+                                                     scanerf_stream_t stream)
 {
     SCANERF_REQUIRE(B >= 0 && S1 >= 1 && (!z2 || S2 >= 1), "table_grad_scatter_adam_rays: B=%d S1=%d S2=%d", B, S1, S2);
     if (B == 0) return 0;
@@ -1135,7 +1159,7 @@ SCANERF_API int scanerf_table_grad_scatter_adam_rays(const float *rays_o, const 
     src.N1 = B * S1;
     for (int k = 0; k < 3; ++k) { src.min_bbox[k] = min_bbox[k]; src.bbox_size[k] = bbox_size[k]; }
     const AdamEpilogue ad{ nullptr, nullptr, nullptr, 0u, params, exp_avg, exp_avg_sq, half_table, half_dtype, overflow_grad,
-                           make_adam_args(lr, beta1, beta2, eps, step) };
+                           make_adam_args(lr, beta1, beta2, eps, step), fp16_moments ? 1 : 0 };
     return binned_backward(nullptr, nullptr, overflow_grad, resolutions, (int)N, 16, T, 1, workspace, workspace_bytes, &ad, stream, 2, &src);
 }
 
@@ -1466,7 +1490,7 @@ static int accumulate_adam(float *params, float *exp_avg, float *exp_avg_sq, voi
     g.capacity = w.capacity = fused_coarse_capacity(w.capacity, B, S, g.bucket_log);
     g.rec8 = -1;  // as the plan recorded it in the workspace
     AdamEpilogue ad{ nullptr, nullptr, nullptr, 0u, params, exp_avg, exp_avg_sq, half_table, half_dtype, overflow_grad,
-                     make_adam_args(lr, beta1, beta2, eps, step) };
+                     make_adam_args(lr, beta1, beta2, eps, step), 0 };
     BinGeom g2;
     BinWorkspace w2;
     if (workspace2) {  // the second branch's records: planned on the same B and T (same bins and producer grid), its own S

@@ -23,6 +23,7 @@ struct BinGeom {
     int rpg;          // fused producer: rays per workgroup visit (ray = (wg + i*W)*rpg + r): 1 f32 kernel, 4 h3 kernel
     uint32_t capacity;  // records that fit the workspace
     int dbg;
+    int rows16;       // stand-alone producer: point-major gradient rows of 16 levels are read once and emitted level by level (host's decision; the kernel follows it)
     int rec8;         // record format: 0 = Rec (16 bytes), 1 = Rec8 (8 bytes), 2 = Rec12 (12 bytes), 3 = Rec12 in 64-byte segments of five (kSegRecs), -1 = read format_word() (accumulate of a fused plan)
 };
 // Format 3 (round 6, large tables): a (bucket, workgroup) range is a whole number of 64-BYTE SEGMENTS, each holding five Rec12

@@ -389,10 +389,12 @@ def scatter_rays_supported(T, arith_code):
 
 
 def scatter_table_grad_adam_rays(rays_o, rays_d, branches, min_bbox, bbox_size, resolutions, params, exp_avg, exp_avg_sq, lr, beta1,
-                                 beta2, eps, step, half_table=None, overflow_grad=None):
+                                 beta2, eps, step, half_table=None, overflow_grad=None, fp16_moments=False):
     """The table gradient of one or two render branches over the same rays, scattered and applied by ONE sparse Adam step
     (scanerf_table_grad_scatter_adam_rays; tile.py:639-692, :1010).  branches: [(z [B,S], dfeat [16,B*S,2], ray_valid [B] or None,
-    contract mode FORE / BG), ...] -- no contracted-point tensors, no concatenation."""
+    contract mode FORE / BG), ...] -- no contracted-point tensors, no concatenation.
+    fp16_moments (opt-in): exp_avg / exp_avg_sq are float16 tensors, the update is adam_step_cuda_fp16's (cuda/adam_kernel.cu:98-144)."""
+    mdt = torch.float16 if fp16_moments else _f32
     B, T = rays_o.shape[0], params.shape[1]
     if not 1 <= len(branches) <= 2 or params.shape[0] != 16:
         raise RuntimeError("scanerf: scatter_table_grad_adam_rays takes one or two branches and 16 levels")
@@ -415,11 +417,11 @@ def scatter_table_grad_adam_rays(rays_o, rays_d, branches, min_bbox, bbox_size, 
     check(lib().scanerf_table_grad_scatter_adam_rays(
         dev_ptr(rays_o, _f32, "rays_o"), dev_ptr(rays_d, _f32, "rays_d"), ctypes.c_int(B), *args, mn, sz,
         dev_ptr(resolutions, torch.int32, "resolutions"), ctypes.c_int(T), ctypes.c_void_p(ws.data_ptr()), ctypes.c_size_t(ws.numel()),
-        dev_ptr(params, _f32, "params"), dev_ptr(exp_avg, _f32, "exp_avg"), dev_ptr(exp_avg_sq, _f32, "exp_avg_sq"),
+        dev_ptr(params, _f32, "params"), dev_ptr(exp_avg, mdt, "exp_avg"), dev_ptr(exp_avg_sq, mdt, "exp_avg_sq"),
         dev_ptr(half_table, (torch.float16, torch.bfloat16), "half_table", allow_none=True),
         ctypes.c_int(feat_dtype_code(half_table) if half_table is not None else 0), dev_ptr(overflow_grad, _f32, "overflow_grad"),
-        ctypes.c_float(lr), ctypes.c_float(beta1), ctypes.c_float(beta2), ctypes.c_float(eps), ctypes.c_int(step), stream()),
-        "scatter_table_grad_adam_rays")
+        ctypes.c_float(lr), ctypes.c_float(beta1), ctypes.c_float(beta2), ctypes.c_float(eps), ctypes.c_int(step),
+        ctypes.c_int(1 if fp16_moments else 0), stream()), "scatter_table_grad_adam_rays")
 
 
 def ray_gradients_fused(rays_o, rays_d, blob, ray_pos_grad, g_dnorm, g_rowsum, ray_valid=None):

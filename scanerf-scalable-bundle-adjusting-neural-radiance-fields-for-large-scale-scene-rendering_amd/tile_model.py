@@ -132,8 +132,12 @@ class TileModel(nn.Module):
     `corner`/`size` describe the tile; the hash grid covers the 2x box around it."""
 
     def __init__(self, corner, size, device, log2_T=19, grid_resolution=(32, 2048), sampler_log2dim=4, seed=0,
-                 table_dtype=torch.float32, n_levels=16):
+                 table_dtype=torch.float32, n_levels=16, fp16_moments=False):
+        """fp16_moments (opt-in; tables of >= 2^22 entries behind the t16s backward only): the table's Adam moments are kept in
+        half precision and updated as adam_step_cuda_fp16 does (cuda/adam_kernel.cu:98-144) -- NOT what the reference's live code
+        runs (torch.optim.Adam with fp32 state, tile.py:301), hence never the default."""
         super().__init__()
+        self.fp16_moments = bool(fp16_moments)
         self.n_levels = n_levels  # the reference hard-codes 16; other counts run on the "ops" path only (configs[0]: 8)
         corner = torch.as_tensor(corner, dtype=torch.float32)
         size = torch.as_tensor(size, dtype=torch.float32)
@@ -162,8 +166,8 @@ class TileModel(nn.Module):
         self.packed = render.PackedDecoder(device)
         self._side_stream = torch.cuda.Stream(device=device) if str(device).startswith("cuda") else None
         # fused sparse Adam state for the table (cuda/adam_kernel.cu semantics)
-        self.exp_avg = torch.zeros_like(self.features)
-        self.exp_avg_sq = torch.zeros_like(self.features)
+        self.exp_avg = torch.zeros_like(self.features, dtype=torch.float16 if self.fp16_moments else torch.float32)
+        self.exp_avg_sq = torch.zeros_like(self.exp_avg)
         self.adam_step = 0
         self._half_table = None       # f16 / bf16 gather copy of the table (configs[2]); kept in step by the Adam epilogue
         self._overflow_grad = None    # zero table for the fused scatter's workspace-overflow path (never filled per step)
@@ -507,7 +511,7 @@ def train_step_fused(model, dec_opt, rays_o, rays_d, target, S, global_step, tab
             with _sec(timer, "table_grad_scatter_adam", B * S * 16 * (8 + 16 * 8)):
                 render.scatter_table_grad_adam_rays(rays_o, rays_d, [(z, dfeat, valid, render.FORE)], box[0], box[1], model.resolution,
                                                     model.features.data, model.exp_avg, model.exp_avg_sq, table_lr, 0.9, 0.99, 1e-15,
-                                                    model.adam_step, overflow_grad=gtab)
+                                                    model.adam_step, overflow_grad=gtab, fp16_moments=model.fp16_moments)
             model.adam_step += 1
         elif adam_epilogue:   # (the other record formats: contracted points from torch, stand-alone binned scatter from dfeat)
             pts = ((rays_o[:, None, :] + z[:, :, None] * rays_d[:, None, :]).reshape(-1, 3) - model._min_dev) \
@@ -643,7 +647,8 @@ def train_step_fgbg(model, dec_opt, rays_o, rays_d, target, S_fg, S_bg, global_s
                 with _sec(timer, "table_grad_scatter_adam", B * (S_fg + S_bg) * 16 * (8 + 16 * 8)):
                     render.scatter_table_grad_adam_rays(rays_o, rays_d, parts, model.min_bbox.tolist(), model.bbox_size.tolist(),
                                                         model.resolution, model.features.data, model.exp_avg, model.exp_avg_sq, table_lr,
-                                                        0.9, 0.99, 1e-15, model.adam_step, overflow_grad=model.overflow_grad())
+                                                        0.9, 0.99, 1e-15, model.adam_step, overflow_grad=model.overflow_grad(),
+                                                        fp16_moments=model.fp16_moments)
                 model.adam_step += 1
             elif binned:
                 pts = torch.cat([p_ for p_, _ in parts], 0)

@@ -16,7 +16,7 @@ def test_the_library_under_test_is_the_audited_build():
     import scanerf_amd  # noqa: F401
     from scanerf_amd import _capi
     st = _capi.audit_state()
-    if st["status"] == "unvalidated":
+    if st["status"] == "unvalidated" and not _capi.audit_required():
         pytest.skip("library built by another compiler build than the validated one (no packed-f32 found): " + st.get("why", ""))
     assert st["status"] == "passed", st
 

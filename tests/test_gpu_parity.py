@@ -1688,3 +1688,36 @@ def test_ray_source_scatter_equals_points_and_concatenation(S, two):
     for a, b in zip(out[True], out[False]):
         assert torch.equal(a, b)
     assert int((out[True][1] != 0).sum()) > 100_000
+
+
+def test_fp16_moment_epilogue_equals_adam_step_cuda_fp16(S):
+    """The opt-in half-precision optimiser state of the large-table scatter (scanerf_table_grad_scatter_adam_rays(fp16_moments=1)):
+    the epilogue applies adam_step_cuda_fp16's update (cuda/adam_kernel.cu:98-144: gradient x 128, moments stored in half) to the
+    bucket images -- against the same records added into a gradient table and the stand-alone fp16 Adam op on it: parameters and
+    both half moments bit-equal after two steps; entries without a gradient keep their bits."""
+    from scanerf_amd import render
+    from scanerf_amd.cuda import adam_step_cuda_fp16
+    gen = torch.Generator().manual_seed(5)
+    B, S1, T = 600, 64, 2 ** 22
+    res = g(O.level_resolutions(torch.tensor([32, 32, 32]), torch.tensor([2048, 2048, 2048])).numpy())
+    mn, sz = torch.tensor([-8.0, -8.0, -8.0]), torch.tensor([16.0, 16.0, 16.0])
+    o = (torch.rand(B, 3, generator=gen) * 8 - 4).to(DEV)
+    d = torch.nn.functional.normalize(torch.randn(B, 3, generator=gen), dim=-1).to(DEV)
+    z1 = (torch.rand(B, S1, generator=gen) * 3).to(DEV)
+    d1 = (torch.randn(16, B * S1, 2, generator=gen) * 1e-3).to(DEV)
+    p0 = (torch.randn(16, T, 2, generator=gen) * 0.1).to(DEV)
+    pts = (((o[:, None, :] + z1[:, :, None] * d[:, None, :]).reshape(-1, 3) - mn.to(DEV)) / sz.to(DEV) * 4.0 - 2.0).contiguous()
+    pa, ma, va = p0.clone(), torch.zeros(16, T, 2, dtype=torch.float16, device=DEV), torch.zeros(16, T, 2, dtype=torch.float16, device=DEV)
+    pb, mb, vb = p0.clone(), torch.zeros_like(ma), torch.zeros_like(va)
+    over = torch.zeros(16, T, 2, device=DEV)
+    K = 16 * T * 2 // 8
+    for step in range(2):
+        render.scatter_table_grad_adam_rays(o, d, [(z1, d1, None, render.FORE)], mn.tolist(), sz.tolist(), res, pa, ma, va, 1e-2, 0.9, 0.99,
+                                            1e-15, step, overflow_grad=over, fp16_moments=True)
+        gtab = torch.zeros(16, T, 2, device=DEV)
+        render.scatter_table_grad(pts, d1, gtab, res, compact_records=2)
+        adam_step_cuda_fp16(pb.view(K, 8), gtab.view(K, 8), mb.view(K, 8), vb.view(K, 8), 1e-2, 0.9, 0.99, 1e-15, step)
+    assert not bool(over.any())
+    assert torch.equal(pa, pb) and torch.equal(ma, mb) and torch.equal(va, vb)
+    touched = (gtab != 0).any(-1)     # (the same gradient in both steps)
+    assert 100_000 < int(touched.sum()) < 16 * T and torch.equal(pa[~touched], p0[~touched]) and not bool(ma[~touched].any())
