@@ -56,6 +56,12 @@ using namespace scanerf;
 #define T16_LOAD_AT 4
 #endif
 
+// -DT16_MIN_WAVES=3 (investigation builds): the register budget of THREE waves per SIMD (168) for the same 8-wave workgroup -- what
+// the code would have to fit before a 12-wave workgroup could share one image (profiles/r06_bwd_3waves.txt)
+#ifndef T16_MIN_WAVES
+#define T16_MIN_WAVES 2
+#endif
+
 namespace {
 
 constexpr int kThreads = 512;
@@ -324,7 +330,7 @@ __device__ __forceinline__ void stage_act(char *stX, const T16Lane &L, const v4f
 // the weight gradients as hi + lo, three MFMAs per term; G'(u) in f32 (pre-activations are held, activations recomputed); f32
 // records.  Same structure, same barriers; fp32-equivalent gradients (tests/test_gpu_parity.py).
 template <int DT, int REC, bool POSE, bool SPLIT = false>
-__global__ void __launch_bounds__(kThreads, 2) k_render_bwd_t16(BwdArgs a)
+__global__ void __launch_bounds__(kThreads, T16_MIN_WAVES) k_render_bwd_t16(BwdArgs a)
 {
     using LD = Lds<SPLIT>;
     extern __shared__ __attribute__((aligned(16))) char lds[];
