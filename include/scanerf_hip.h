@@ -310,6 +310,21 @@ int scanerf_compact_rays(const uint8_t *valid, int B, int S, const float *rays_o
 int scanerf_ray_grad_epilogue(const float *rays_d, const float *mlp_blob, const float *g_raypos, const float *g_dnorm,
                               const float *g_rowsum, const uint8_t *ray_valid, float *g_o, float *g_d, int B, int S,
                               scanerf_stream_t stream);
+/* Alpha compositing of per-sample decoder outputs along rays and its adjoint, as stand-alone ops: HashGrid.cal_integrate_weight
+ * (hashgrid/__init__.py:344-360) + the accumulate calls and the l2_reg_specular sum of render_batch_rays (:362-366, :564-574,
+ * :591-594) in one launch each way, for callers that keep the decoder outputs as tensors (the op-by-op route).
+ *   sigma [B*S], diffuse / specular / tint [B*S,3], z_vals / dists [B,S], rays_d [B,3]; infinity: the last sample's delta is 1e10;
+ *   out_ray [B,16]: the columns scanerf_render_forward_packed writes (rgb, depth, T_left = transmittance BEFORE the last sample,
+ *   diffuse, specular, tint, sum w |c_s|^2); weights [B,S] (may be NULL).
+ * Backward: grad_out [B,16] (column 14 differentiates sum w |c_s|^2 with w detached, as :593), grad_weights [B,S] (may be NULL) ->
+ *   dL/d(sigma) [B*S], dL/d(diffuse / specular / tint) [B*S,3], g_dnorm [B] (may be NULL) = dL/d|rays_d| through delta. */
+int scanerf_composite_forward(const float *sigma, const float *diffuse, const float *specular, const float *tint, const float *z_vals,
+                              const float *dists, const float *rays_d, float *out_ray, float *weights, int B, int S, int infinity,
+                              scanerf_stream_t stream);
+int scanerf_composite_backward(const float *sigma, const float *diffuse, const float *specular, const float *tint, const float *z_vals,
+                               const float *dists, const float *rays_d, const float *out_ray, const float *grad_out,
+                               const float *grad_weights, float *g_sigma, float *g_diffuse, float *g_specular, float *g_tint,
+                               float *g_dnorm, int B, int S /* <= 512 */, int infinity, scanerf_stream_t stream);
 int scanerf_photometric_loss_scratch_floats(void);
 int scanerf_photometric_loss_grad(const float *out_ray, const float *target /*[B,3]*/, const uint8_t *ray_valid,
                                   float reg_weight, float *grad_out, float *loss, float *scratch, int B,

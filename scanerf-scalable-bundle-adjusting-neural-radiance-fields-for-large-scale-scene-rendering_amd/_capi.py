@@ -32,7 +32,7 @@ SYMBOLS = [
     "scanerf_update_outgoing_bidx", "scanerf_update_outgoing_bidx_v2", "scanerf_get_last_block",
     "scanerf_ray_firsthit_block", "scanerf_process_occupied_grid", "scanerf_embedding_bg_point_grad", "scanerf_voxelize_mesh", "scanerf_ray_valid", "scanerf_compact_rays",
     "scanerf_decoder_forward", "scanerf_decoder_backward_grid", "scanerf_decoder_backward", "scanerf_pts_inference_tracing",
-    "scanerf_table_grad_scatter_adam_rays", "scanerf_experiments_enabled",
+    "scanerf_table_grad_scatter_adam_rays", "scanerf_experiments_enabled", "scanerf_composite_forward", "scanerf_composite_backward",
 ]
 
 # test / measurement entry points (include/scanerf_hip.h declares them, the default build exports them): NOT required --

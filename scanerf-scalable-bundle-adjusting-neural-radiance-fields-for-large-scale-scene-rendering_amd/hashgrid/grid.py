@@ -229,33 +229,39 @@ class HashGrid(nn.Module):
                 rays_o, rays_d, z_vals, dists, self.HE.features, decoder.blob(), self.HE.resolution.to(self.device).int().contiguous(),
                 wf, self.min_bbox.tolist(), self.bbox_size.tolist(), cmode, infinity, None, network.skip_levels(global_step), True)
             return render.render_batch_rays_dict(out_ray, weights, mode is TRAIN or mode == TRAIN), True
-        # ---- op by op: the reference's own sequence
+        # ---- op by op: encoder op -> decoder module -> compositing op, each a library call behind its own autograd node (the
+        # route for a caller that holds the pieces apart: `self.HE`, `decoder`, the per-sample outputs)
         self.last_render_route = "ops"
-        samples = rays_o[:, None, :] + z_vals[..., None] * rays_d[:, None, :]
-        num_sample = samples.shape[1]
+        B, S = z_vals.shape
+        world = (rays_o[:, None, :] + z_vals[..., None] * rays_d[:, None, :]).reshape(-1, 3)
+        if out_normal and not world.requires_grad:
+            world.requires_grad_(True)
+        pts, per_sample_mask = world, None
         if contract_func is not None:
-            contract_x, weight_feature = contract_func(samples.reshape(-1, 3))
-        else:
-            contract_x, weight_feature = samples.reshape(-1, 3), None
-        features = self.HE(contract_x).reshape(rays_o.shape[0], num_sample, 32)
-        step_weight_feature = self.weight_feature(global_step)[None, None, :].repeat_interleave(2, dim=-1)
-        if weight_feature is not None:
-            step_weight_feature = step_weight_feature * weight_feature.reshape(rays_o.shape[0], num_sample, 32)
-        inputs = torch.cat([features, rays_d[:, None, :].repeat(1, num_sample, 1)], -1)
-        output = decoder(inputs, weight_feature=step_weight_feature)
-        out = {}
-        weights, T_left = self.cal_integrate_weight(output["sigma"], z_vals, dists, rays_d, infinity=infinity)
-        out["diffuse"] = self.accumulate(weights, output["diffuse"])
-        out["tint"] = self.accumulate(weights, output["tint"])
-        out["specular"] = self.accumulate(weights, output["tint"] * output["specular"])
-        out.update({"rgb": torch.clamp(out["diffuse"] + out["specular"], 0, 1), "depth": self.accumulate(weights, z_vals[..., None]),
-                    "T_left": T_left, "weights": weights})
-        if out_normal:
-            d_output = torch.ones_like(output["sigma"], requires_grad=False, device=self.device)
-            p_normal = torch.autograd.grad(outputs=output["sigma"], inputs=samples, grad_outputs=d_output, create_graph=True,
-                                           retain_graph=True, only_inputs=True)[0]
-            p_normal = -1.0 * p_normal / (p_normal.norm(2, dim=-1, keepdim=True) + 1e-8)
-            out["normal"] = self.accumulate(weights, p_normal.detach())
-        if mode is TRAIN or mode == TRAIN:
-            out["l2_reg_specular"] = torch.mean(self.accumulate(weights.detach(), (output["specular"] - 0) ** 2))
+            pts, per_sample_mask = contract_func(world)
+        feats = self.HE(pts).reshape(B, S, 32)
+        wf = self.weight_feature(global_step).repeat_interleave(2, dim=-1)[None, None, :]
+        if per_sample_mask is not None:
+            wf = wf * per_sample_mask.reshape(B, S, 32)
+        dirs = rays_d[:, None, :].expand(B, S, 3)
+        if hasattr(decoder, "forward_parts"):
+            dec = decoder.forward_parts(feats, dirs, weight_feature=wf)
+        else:   # (any module with the reference's call signature)
+            dec = decoder(torch.cat([feats, dirs], -1), weight_feature=wf)
+        train = mode is TRAIN or mode == TRAIN
+        if rays_o.is_cuda and S <= 512:
+            out_ray, weights = render.composite_rays(dec["sigma"], dec["diffuse"], dec["specular"], dec["tint"], z_vals, dists, rays_d, infinity)
+            out = render.render_batch_rays_dict(out_ray, weights, train)
+        else:   # (CPU tensors never reach here on the product path: the encoder op raises first; kept for S > 512)
+            weights, T_left = self.cal_integrate_weight(dec["sigma"], z_vals, dists, rays_d, infinity=infinity)
+            acc = lambda v: self.accumulate(weights, v)
+            out = {"diffuse": acc(dec["diffuse"]), "tint": acc(dec["tint"]), "specular": acc(dec["tint"] * dec["specular"]),
+                   "depth": acc(z_vals[..., None]), "T_left": T_left, "weights": weights}
+            out["rgb"] = torch.clamp(out["diffuse"] + out["specular"], 0, 1)
+            if train:
+                out["l2_reg_specular"] = self.accumulate(weights.detach(), dec["specular"] ** 2).mean()
+        if out_normal:   # surface normals: -d(sigma)/d(position), normalised, composited with the (detached) weights
+            g = torch.autograd.grad(dec["sigma"].sum(), world, retain_graph=True)[0]
+            n = -g / (g.norm(2, dim=-1, keepdim=True) + 1e-8)
+            out["normal"] = (out["weights"].detach() * n.reshape(B, S, 3)).sum(1)
         return out, True

@@ -167,6 +167,24 @@ class ShallowMLP(nn.Module):
                 "tint": tint.reshape(*lead, 3)}
 
 
+def _shallow_forward_parts(self, features, viewdirs, **kwargs):
+    """forward() on the two halves of the reference's concatenated input (hashgrid/__init__.py:547: cat([features, rays_d]))
+    as separate tensors -- features [..., 32], viewdirs [..., 3] (broadcastable views are fine) -- so that a caller which has
+    them apart never builds the [..., 35] tensor.  Same dictionary."""
+    wf = kwargs["weight_feature"]
+    if not (self.use_hip and features.is_cuda and self.in_channel == 32 and features.shape[-1] == 32 and wf.numel() == 32):
+        return self.forward_torch(torch.cat([features, viewdirs.expand(*features.shape[:-1], 3)], -1), **kwargs)
+    from . import decoder_op
+    lead = features.shape[:-1]
+    sigma, dif, spec, tint = decoder_op.decoder_apply_parts(features.reshape(-1, 32), viewdirs.expand(*lead, 3).reshape(-1, 3),
+                                                            self.blob(), wf.reshape(-1))
+    return {"diffuse": dif.reshape(*lead, 3), "specular": spec.reshape(*lead, 3), "sigma": sigma.reshape(*lead, 1),
+            "tint": tint.reshape(*lead, 3)}
+
+
+ShallowMLP.forward_parts = _shallow_forward_parts
+
+
 def init_model(model, mode="default"):
     """network.py:196-227 (the modes the reference's callers use)."""
     def xavier_init(layer):

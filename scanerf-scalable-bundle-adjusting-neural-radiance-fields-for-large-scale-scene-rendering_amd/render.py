@@ -596,6 +596,57 @@ def fused_render_rays(rays_o, rays_d, z_vals, dists, features, blob, resolutions
                                  contract_mode, infinity, ray_valid, skip_levels, want_weights)
 
 
+class CompositeRays(torch.autograd.Function):
+    """Alpha compositing of per-sample decoder outputs along rays as ONE op each way (csrc/composite.hip): what
+    HashGrid.cal_integrate_weight + accumulate x 4 + the l2_reg_specular sum do in ~35 torch kernels (hashgrid/__init__.py:344-366,
+    :564-574, :591-594).  sigma [B,S,1] or [B,S]; diffuse / specular / tint [B,S,3]; z_vals / dists [B,S]; rays_d [B,3] ->
+    out_ray [B,16] (columns as the fused forward's: RGB, DEPTH, T_LEFT, DIFFUSE, SPECULAR, TINT, W_SPEC2), weights [B,S].
+    Gradients flow to sigma, diffuse, specular, tint and (through delta = dists |d|) rays_d; z_vals / dists are sampler outputs."""
+
+    @staticmethod
+    def forward(ctx, sigma, diffuse, specular, tint, z_vals, dists, rays_d, infinity):
+        B, S = z_vals.shape
+        dev = z_vals.device
+        sg = sigma.reshape(B * S).contiguous()
+        cd, cs, tn = (t.reshape(B * S, 3).contiguous() for t in (diffuse, specular, tint))
+        z, dd, rd = z_vals.contiguous(), dists.contiguous(), rays_d.detach().contiguous()
+        out = torch.empty((B, _capi.RAY_OUT), dtype=_f32, device=dev)
+        w = torch.empty((B, S), dtype=_f32, device=dev)
+        check(lib().scanerf_composite_forward(
+            dev_ptr(sg, _f32, "sigma"), dev_ptr(cd, _f32, "diffuse"), dev_ptr(cs, _f32, "specular"), dev_ptr(tn, _f32, "tint"),
+            dev_ptr(z, _f32, "z_vals"), dev_ptr(dd, _f32, "dists"), dev_ptr(rd, _f32, "rays_d"), dev_ptr(out, _f32, "out_ray"),
+            dev_ptr(w, _f32, "weights"), ctypes.c_int(B), ctypes.c_int(S), ctypes.c_int(1 if infinity else 0), stream()), "composite_forward")
+        ctx.save_for_backward(sg, cd, cs, tn, z, dd, rd, out)
+        ctx.infinity, ctx.shapes = bool(infinity), (sigma.shape, diffuse.shape)
+        return out, w
+
+    @staticmethod
+    def backward(ctx, g_out, g_w):
+        sg, cd, cs, tn, z, dd, rd, out = ctx.saved_tensors
+        B, S = z.shape
+        dev = z.device
+        g_sigma = torch.empty_like(sg)
+        g_cd, g_cs, g_tn = torch.empty_like(cd), torch.empty_like(cs), torch.empty_like(tn)
+        g_dn = torch.empty(B, dtype=_f32, device=dev)
+        go = g_out.contiguous().to(_f32) if g_out is not None else torch.zeros_like(out)
+        gw = g_w.contiguous().to(_f32) if g_w is not None else None
+        check(lib().scanerf_composite_backward(
+            dev_ptr(sg, _f32, "sigma"), dev_ptr(cd, _f32, "diffuse"), dev_ptr(cs, _f32, "specular"), dev_ptr(tn, _f32, "tint"),
+            dev_ptr(z, _f32, "z_vals"), dev_ptr(dd, _f32, "dists"), dev_ptr(rd, _f32, "rays_d"), dev_ptr(out, _f32, "out_ray"),
+            dev_ptr(go, _f32, "grad_out"), dev_ptr(gw, _f32, "grad_weights", allow_none=True), dev_ptr(g_sigma, _f32, "g_sigma"),
+            dev_ptr(g_cd, _f32, "g_diffuse"), dev_ptr(g_cs, _f32, "g_specular"), dev_ptr(g_tn, _f32, "g_tint"),
+            dev_ptr(g_dn, _f32, "g_dnorm"), ctypes.c_int(B), ctypes.c_int(S), ctypes.c_int(1 if ctx.infinity else 0), stream()),
+            "composite_backward")
+        g_rd = g_dn[:, None] * rd / rd.norm(dim=-1, keepdim=True) if ctx.needs_input_grad[6] else None
+        sshape, cshape = ctx.shapes
+        return g_sigma.reshape(sshape), g_cd.reshape(cshape), g_cs.reshape(cshape), g_tn.reshape(cshape), None, None, g_rd, None
+
+
+def composite_rays(sigma, diffuse, specular, tint, z_vals, dists, rays_d, infinity=False):
+    """-> (out_ray [B,16], weights [B,S]); see CompositeRays."""
+    return CompositeRays.apply(sigma, diffuse, specular, tint, z_vals, dists, rays_d, infinity)
+
+
 def render_batch_rays_dict(out_ray, weights, train):
     """The dictionary HashGrid.render_batch_rays returns (hashgrid/__init__.py:564-596) from the fused op's outputs:
     diffuse / tint / specular / rgb [B,3], depth [B,1], T_left [B], weights [B,S,1], and in TRAIN mode l2_reg_specular =

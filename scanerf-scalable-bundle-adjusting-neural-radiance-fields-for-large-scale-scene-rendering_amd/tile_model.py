@@ -224,12 +224,20 @@ class TileModel(nn.Module):
         feats = HashEmbeddingBG(x.contiguous(), self.features, self.resolution).reshape(B, S, 2 * self.n_levels)
         wf = network.weight_feature(global_step, self.device)[:2 * self.n_levels]
         if self.n_levels == 16 and getattr(self, "hip_decoder", True):
-            # the decoder as ONE HIP op each way (csrc/decoder.hip) on the reference's concatenated input (hashgrid/__init__.py:547)
+            # the decoder as ONE HIP op each way (csrc/decoder.hip) on the encoder's rows and the per-sample directions -- the two
+            # halves of the reference's concatenated input (hashgrid/__init__.py:547), never concatenated (round 6) -- and the
+            # compositing as one op each way (csrc/composite.hip) instead of cal_integrate_weight + accumulate x 4 in torch
             from . import decoder_op
-            x = torch.cat([feats, d[:, None, :].expand(B, S, 3)], -1).reshape(-1, 35)
-            sigma, dif, spec, tint = (t.reshape(B, S, -1) for t in decoder_op.decoder_apply(x, self.decoder.blob(), wf))
-        else:   # other level counts (BASELINE configs[0]: 8), or hip_decoder = False: the torch graph
-            sigma, dif, spec, tint = self.decoder(feats, d[:, None, :].expand(B, S, 3), wf)
+            sigma, dif, spec, tint = decoder_op.decoder_apply_parts(feats.reshape(-1, 32), d[:, None, :].expand(B, S, 3).reshape(-1, 3),
+                                                                    self.decoder.blob(), wf)
+            out_ray, w2 = render.composite_rays(sigma, dif, spec, tint, z, dist, d, False)
+            out = {"valid": valid, "depth": out_ray[:, render.DEPTH], "diffuse": out_ray[:, render.DIFFUSE],
+                   "specular": out_ray[:, render.SPECULAR], "T_left": out_ray[:, render.T_LEFT], "weights": w2, "rgb": out_ray[:, render.RGB]}
+            if train:
+                out["l2_reg_specular"] = out_ray[:, render.W_SPEC2].sum() / (3.0 * B)   # = (w.detach() * spec ** 2).sum(1).mean() of the torch form below
+            return out
+        # other level counts (BASELINE configs[0]: 8), or hip_decoder = False: the torch graph
+        sigma, dif, spec, tint = self.decoder(feats, d[:, None, :].expand(B, S, 3), wf)
         w2, T_left = composite_weights(sigma[..., 0], dist, d, False)
         w = w2[..., None]
         out = {"valid": valid, "depth": (w[..., 0] * z).sum(1), "diffuse": (w * dif).sum(1),

@@ -14,7 +14,7 @@ PKG = os.path.join(ROOT, "scanerf-scalable-bundle-adjusting-neural-radiance-fiel
 CSRC, OBJ, DBG = os.path.join(PKG, "csrc"), os.path.join(PKG, "lib", "obj"), os.path.join(PKG, "lib", "debug")
 COMMON = ("-O3 --offload-arch=gfx950 -fPIC -fvisibility=hidden -std=c++17 -munsafe-fp-atomics -Wall -I../../include -I. "
           "-fno-slp-vectorize -Xclang -target-feature -Xclang -packed-fp32-ops").split()   # (csrc/Makefile COMMON; a unit's flags may undo them)
-UNITS = "rays adam render_time voxelize api hashgrid render scatter render_bwd render_bwd_h3 render_bwd_t16 h3_selftest loss compact decoder".split()
+UNITS = "rays adam render_time voxelize api hashgrid render scatter render_bwd render_bwd_h3 render_bwd_t16 h3_selftest loss compact decoder composite".split()
 tag, specs = sys.argv[1], dict(a.split("=", 1) for a in sys.argv[2:])
 assert all(u in UNITS for u in specs), specs
 os.makedirs(DBG, exist_ok=True)

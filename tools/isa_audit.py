@@ -31,7 +31,7 @@ def write_state(status, now, detail=None):
     sha = hashlib.sha256(open(LIBSO, "rb").read()).hexdigest() if os.path.exists(LIBSO) else None
     json.dump({"status": status, "library_sha256": sha, "compiler": now["compiler"],
                "kernels": sum(len(k) for k in now["units"].values()), "detail": detail}, open(STATE, "w"), indent=1)
-UNITS = ["render", "render_bwd_t16", "render_bwd_h3", "render_bwd", "render_time", "scatter", "hashgrid", "rays", "adam", "loss", "compact", "voxelize", "h3_selftest", "decoder"]
+UNITS = ["render", "render_bwd_t16", "render_bwd_h3", "render_bwd", "render_time", "scatter", "hashgrid", "rays", "adam", "loss", "compact", "voxelize", "h3_selftest", "decoder", "composite"]
 NO_PACKED_F32_UNITS = tuple(UNITS)
 PACKED = re.compile(r"^v_pk_(mul|add|fma)_f32\b")
 
