@@ -1087,6 +1087,14 @@ static int binned_backward(const float *points, const float *grad_in, float *gra
             SCANERF_REQUIRE(e == hipSuccess, "embedding_bg_backward_binned: cannot reserve %zu B of LDS: %s", lds_acc, hipGetErrorString(e));
             hipLaunchKernelGGL((k_bin_accumulate<1024, 16, true, true>), dim3(nbins), dim3(1024), lds_acc, st, recs, starts, maxbits,
                                g, (float *)nullptr, *ad);
+        } else if (g.rec8 == 2 && nbins <= 4096) {
+            // few, long ranges of 12-byte records (small tables: 1 024 buckets of 5e5 records at configs[1]): the fused accumulate's
+            // shape (512 threads x 16 records per lane 1.43 ms against 1.53 for 1024 x 16, scanerf_render_scatter_accumulate_adam)
+            e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bin_accumulate<512, 16, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)lds_acc);
+            SCANERF_REQUIRE(e == hipSuccess, "embedding_bg_backward_binned: cannot reserve %zu B of LDS: %s", lds_acc, hipGetErrorString(e));
+            hipLaunchKernelGGL((k_bin_accumulate<512, 16, true>), dim3(nbins), dim3(512), lds_acc, st, recs, starts, maxbits, g, grad_features,
+                               AdamEpilogue{});
         } else
             hipLaunchKernelGGL((k_bin_accumulate<1024, 16, true>), dim3(nbins), dim3(1024), lds_acc, st, recs, starts, maxbits, g,
                                grad_features, AdamEpilogue{});

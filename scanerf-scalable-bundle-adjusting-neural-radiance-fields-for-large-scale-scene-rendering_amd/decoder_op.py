@@ -86,7 +86,8 @@ class _DecoderPartsFn(torch.autograd.Function):
     def backward(ctx, g_sigma, g_dif, g_spec, g_tint):
         feats, dirs, wf = ctx.saved_tensors
         N, dev = feats.shape[0], feats.device
-        gf, gd = torch.empty_like(feats), torch.empty_like(dirs)
+        # (directions that carry no gradient -- no pose refinement -- skip the harmonics' adjoint: d_dirs = NULL)
+        gf, gd = torch.empty_like(feats), (torch.empty_like(dirs) if ctx.needs_input_grad[1] else None)
         gblob = torch.zeros(_capi.PARAMSIZE, dtype=_f32, device=dev)
         nblk = lib().scanerf_decoder_backward_grid(ctypes.c_longlong(N))
         dw_partial = torch.empty((nblk, _capi.PARAMSIZE), dtype=_f32, device=dev)
@@ -95,7 +96,7 @@ class _DecoderPartsFn(torch.autograd.Function):
             dev_ptr(feats, _f32, "features"), ctypes.c_int(32), dev_ptr(dirs, _f32, "dirs"), ctypes.c_int(3),
             dev_ptr(ctx.packed.workspace, _f32, "workspace"), dev_ptr(wf, _f32, "weight_feature"),
             *(dev_ptr(t, _f32, n, allow_none=True) for t, n in zip(keep, ("g_sigma", "g_diffuse", "g_specular", "g_tint"))),
-            dev_ptr(gf, _f32, "g_features"), ctypes.c_int(32), dev_ptr(gd, _f32, "g_dirs"), ctypes.c_int(3),
+            dev_ptr(gf, _f32, "g_features"), ctypes.c_int(32), dev_ptr(gd, _f32, "g_dirs", allow_none=True), ctypes.c_int(3),
             dev_ptr(dw_partial, _f32, "dw_partial"), dev_ptr(gblob, _f32, "grad_blob"), ctypes.c_longlong(N), stream()), "decoder_backward")
         return gf, gd, gblob, None
 

@@ -499,6 +499,9 @@ def ray_gradients(rays_o, rays_d, z_vals, features, resolutions, blob, min_bbox,
 # Autograd boundary of the fused path: HashGrid.render_batch_rays (hashgrid/__init__.py:512-596) as ONE differentiable op.
 # A caller that keeps the reference's loss code -- depth / smoothness / ADMM penalty terms on the per-ray outputs, summed
 # and sent through loss.backward() (tile.py:954-1011, criterions.py:122-196) -- reaches the fused kernels through it.
+FORWARD_PLAN_IN_AUTOGRAD = True   # (False: FusedRenderRays plans in its backward, as rounds 1-5 did: A/B and tests)
+
+
 class FusedRenderRays(torch.autograd.Function):
     """out_ray [B,16], weights [B,S] = render(rays, samples; table, decoder blob).
 
@@ -528,8 +531,19 @@ class FusedRenderRays(torch.autograd.Function):
             jstash = torch.empty(jstash_shape(B, S), dtype=JSTASH_DTYPE, device=dev)
         if ray_valid is not None and ray_valid.dtype not in (torch.bool, torch.uint8):
             raise RuntimeError("scanerf: ray_valid must be bool / uint8")
+        # The forward launch counts the backward's record ranges (its hash indices are the plan's: no separate count launch, 0.27 ms at
+        # configs[1]) where the table gradient will go through the fused records -- into a workspace this call OWNS until its
+        # backward has run (other render calls may come between the two and use the per-stream one).
+        T = table.shape[1]
+        own_ws = None
+        if (FORWARD_PLAN_IN_AUTOGRAD and ctx.needs_input_grad[4] and T <= (1 << 21) and scatter_supported(B, S, T)
+                and forward_plan_supported(B, S, T) and backward_arith(True, need_rays) in _capi.T16_FAMILY):
+            own_ws = torch.empty(lib().scanerf_render_scatter_workspace_bytes(ctypes.c_int(B), ctypes.c_int(S), ctypes.c_int(T)),
+                                 dtype=torch.uint8, device=dev)
         r = render_forward(rays_o, rays_d, z_vals, dists, table, resolutions, packed, min_bbox, bbox_size, contract_mode,
-                           infinity, ray_valid=ray_valid, want_weights=want_weights, tile_T=tile_T, xstash=xstash, jstash=jstash)
+                           infinity, ray_valid=ray_valid, want_weights=want_weights, tile_T=tile_T, xstash=xstash, jstash=jstash,
+                           plan=own_ws is not None, plan_workspace=own_ws)
+        ctx.plan_ws, ctx.plan_arith = own_ws, (backward_arith(True, need_rays) if own_ws is not None else None)
         out, weights = r[0], r[1]
         ctx.save_for_backward(rays_o, rays_d, z_vals, dists, table, resolutions, weight_feature.reshape(-1).contiguous(), out,
                               tile_T, xstash, jstash, ray_valid, blob.detach())
@@ -554,7 +568,9 @@ class FusedRenderRays(torch.autograd.Function):
         gtab = torch.zeros((16, T, 2), dtype=_f32, device=dev) if need_table else None
         gblob = torch.zeros(_capi.PARAMSIZE, dtype=_f32, device=dev)
         ws = None
-        if fused:   # (count + scan here, on the per-stream workspace: plan, backward and accumulate run back to back)
+        if fused and ctx.plan_ws is not None and ctx.plan_arith == arith:
+            ws = ctx.plan_ws   # (counted by the forward launch)
+        elif fused:   # (count + scan here, on the per-stream workspace: plan, backward and accumulate run back to back)
             ws = scatter_plan(rays_o, rays_d, z_vals, resolutions, T, *box, ray_valid=ray_valid, arith=arith,
                               skip_levels=ctx.packed.skip_levels)
         ntile = (S + 31) // 32

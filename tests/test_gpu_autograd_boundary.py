@@ -218,3 +218,34 @@ def test_boundary_with_a_ray_mask_equals_the_compacted_batch(table_dtype):
     assert _rel_l2(gF_m.float(), gF_c.float()) < tol
     assert _rel_l2(gb_m, gb_c) < 1e-5
     assert _rel_l2(go_m[keep], go_c) < 1e-4 and _rel_l2(gd_m[keep], gd_c) < 1e-4
+
+
+def test_boundary_plans_in_its_forward_launch_and_two_calls_do_not_share_a_workspace(monkeypatch):
+    """Round 6: FusedRenderRays.forward lets the forward kernel count the backward's record ranges into a workspace the call owns
+    (no separate count launch in backward).  Two calls whose backwards run AFTER both forwards (foreground + background of a tile:
+    the per-stream workspace of the first would have been re-planned by the second) give the table / decoder / ray gradients of
+    the plan-in-backward form, bit for bit."""
+    import scanerf_amd  # noqa
+    from scanerf_amd import network, render
+    rng = np.random.default_rng(4)
+    B, S_, Tn = 2048, 64, 2 ** 14
+    res = O.level_resolutions(torch.tensor([32, 32, 32]), torch.tensor([2048, 2048, 2048])).to(DEV).int().contiguous()
+    feat = T((rng.normal(size=(16, Tn, 2)) * 0.5).astype(np.float32)).to(DEV)
+    blob = network.xavier_blob(3).to(DEV)
+    wf = network.weight_feature(20000, DEV)
+    fg = [T(a).to(DEV) for a in _inputs(rng, B, S_, False)]
+    bg = [T(a).to(DEV) for a in _inputs(rng, B, S_, True)]
+    grads = {}
+    for in_fwd in (True, False):
+        monkeypatch.setattr(render, "FORWARD_PLAN_IN_AUTOGRAD", in_fwd)
+        F, bl = feat.clone().requires_grad_(True), blob.clone().requires_grad_(True)
+        outs = []
+        for (o, d, z, dist), mode, inf in ((fg, render.FORE, False), (bg, render.BG, True)):
+            out, _ = render.fused_render_rays(o, d, z, dist, F, bl, res, wf, [-8.0] * 3, [16.0] * 3, mode, inf)
+            outs.append(out)
+        assert (outs[0].grad_fn.plan_ws is not None) == in_fwd
+        loss = (outs[0][:, render.RGB] + outs[0][:, render.T_LEFT, None] * outs[1][:, render.RGB]).square().sum() + outs[1][:, render.DEPTH].sum() * 1e-3
+        loss.backward()
+        grads[in_fwd] = (F.grad.clone(), bl.grad.clone())
+    assert torch.equal(grads[True][0], grads[False][0]) and torch.equal(grads[True][1], grads[False][1])
+    assert float(grads[True][0].abs().max()) > 0
