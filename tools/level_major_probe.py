@@ -29,11 +29,14 @@ def timed(f, n=5):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n
 
-r = {"all_levels_ms": timed(lambda: H.embedding_bg_forward_cuda(pts, out16, tab, res))}
-per = []
-for l in range(16):
-    tl, rl = tab[l:l + 1].contiguous(), res[l:l + 1].contiguous()
-    per.append(timed(lambda: H.embedding_bg_forward_cuda(pts, out1, tl, rl)))
-r["per_level_ms"] = [round(x, 3) for x in per]
-r["sum_of_levels_ms"] = sum(per)
-print(json.dumps(r))
+# round 6: the same with half-precision gather copies (2 MB per level against 4 MB of L2 per XCD): `level_major_probe.py f16 bf16`
+for name in (sys.argv[1:] or ["f32"]):
+    tb = tab.to({"f32": torch.float32, "f16": torch.float16, "bf16": torch.bfloat16}[name]).contiguous()
+    r = {"table": name, "all_levels_ms": timed(lambda: H.embedding_bg_forward_cuda(pts, out16, tb, res))}
+    per = []
+    for l in range(16):
+        tl, rl = tb[l:l + 1].contiguous(), res[l:l + 1].contiguous()
+        per.append(timed(lambda: H.embedding_bg_forward_cuda(pts, out1, tl, rl)))
+    r["per_level_ms"] = [round(x, 3) for x in per]
+    r["sum_of_levels_ms"] = sum(per)
+    print(json.dumps(r))
