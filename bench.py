@@ -503,14 +503,14 @@ def reference_default_leg(args, dev, S, step0, n=8):
                                      f"samples, fg + T_left*bg, pose (ray) gradients, one sparse Adam; 2 warm-up + {n} timed iterations")}
 
 
-# rocprof kernel names of the timer's sections, per arithmetic (profiles/r05_kernel_stats.txt lists them with their durations)
+# rocprof kernel names of the timer's sections, per arithmetic (profiles/r06_kernel_stats.txt lists them with their durations)
 KERNEL_OF = {
     "render_forward": lambda ar: "k_render_fwd<0>" if ar == "f32" else ("k_render_fwd_h3<0, true, false>" if ar in ("t16", "t16s") else "k_render_fwd_h3<0, false, false>"),
     "render_backward": lambda ar: {"f32": "k_render_bwd<0>", "h3": "k_render_bwd_h3<0>", "t16": "k_render_bwd_t16<0, 1, false, false>",
                                    "t16s": "k_render_bwd_t16<0, 2, false, true>"}[ar],
     "table_grad_accumulate_adam": lambda ar: {"t16": "k_bin_accumulate<512, 32, true, true>", "t16s": "k_bin_accumulate<512, 16, true, true>"}.get(ar, "k_bin_accumulate<256, 32, true, true>"),
 }
-PMC_FILES = ("r05_pmc.json", "r04_pmc.json", "r03_pmc.json")   # the newest committed counter file wins
+PMC_FILES = ("r06_pmc.json", "r05_pmc.json", "r04_pmc.json", "r03_pmc.json")   # the newest committed counter file wins
 
 
 def load_pmc():

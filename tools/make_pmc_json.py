@@ -11,7 +11,7 @@ d = sys.argv[1]
 # (MI355X_MICROARCH.md, HBM) says to double it.  k_bin_accumulate: the record stream (three aligned 16-byte loads per lane and run);
 # k_render_bwd_t16 / _h3: the x-stash (two float4 per lane).  The forward's reads are scattered 8-byte gathers: uncalibrated, left as read.
 FETCH_X2 = ("k_bin_accumulate", "k_render_bwd_t16", "k_render_bwd_h3")
-KEEP = ("k_render_fwd", "k_render_bwd", "k_bin_accumulate", "k_sample_points_grid", "k_reduce_dw", "k_bin_rowscan", "k_loss")
+KEEP = ("k_render_fwd", "k_render_bwd", "k_bin_accumulate", "k_bin_scatter", "k_bin_count", "k_src_points", "k_sample_points_grid", "k_reduce_dw", "k_bin_rowscan", "k_loss")
 
 
 def short(name):   # "void (anonymous namespace)::k_render_bwd_t16<0, false, false, true>(scanerf::BwdArgs)" -> "k_render_bwd_t16<0, false, false, true>"
