@@ -123,3 +123,19 @@ def test_decoder_blob_layout_roundtrip_and_weight_feature(golden):
     g5 = golden("g5_weight_feature")
     for s, w in zip(g5["steps"], g5["w"]):  # the product's mask == the reference's HashGrid.weight_feature
         np.testing.assert_allclose(network.weight_feature(int(s)).numpy()[::2], w, rtol=1e-6, atol=1e-7)
+
+
+def test_the_shipped_library_is_the_product_build_and_reads_no_environment():
+    """thread-safe, re-entrant, no globals -- the product library has no environment switches: it does not import
+    getenv at all (the A/B switches of csrc/common.h exist only under `make EXP=1`) and says so itself."""
+    import shutil
+    import subprocess
+    import scanerf_amd  # noqa
+    from scanerf_amd import _capi
+    if os.environ.get("SCANERF_LIB"):
+        pytest.skip("SCANERF_LIB selects an investigation build")
+    assert _capi.lib().scanerf_experiments_enabled() == 0, "libscanerf_hip.so was built with EXP=1: rebuild with tools/rebuild.sh"
+    nm = shutil.which("nm")
+    if nm:
+        syms = subprocess.run([nm, "-D", "--undefined-only", _capi.LIB_PATH], capture_output=True, text=True, check=True).stdout
+        assert "getenv" not in syms
