@@ -72,6 +72,9 @@ def parse():
     ap.add_argument("--arith", default=None, choices=["f32", "h3", "t16", "t16s"],
                     help="decoder arithmetic of the timed step (default: the fastest f32-equivalent one, render.FP32_EQUIV_ARITH; "
                          "\"t16\" is the reduced-precision option and is reported under its own name, never as the metric)")
+    ap.add_argument("--infer-arith", default="t16", choices=["t16", "h3", "f32"],
+                    help="decoder arithmetic of the render-time inference ops (configs4-render; hashgrid.lib.HASHGRID.INFER_ARITH): 16-sample "
+                         "tiles (default), round 4's 32-sample-tile kernel, or the single-pass f32 kernel")
     ap.add_argument("--arith-side-off", action="store_true", help="skip the side timings of the other arithmetics (profiling passes)")
     ap.add_argument("--pose-grads", action="store_true",
                     help="with --workload configs1 / configs1-fgbg: the iteration also returns dL/d(rays_o), dL/d(rays_d) (the "
@@ -294,6 +297,8 @@ def time_render(args, world, rank, dev, steps, warmup):
 
     from scanerf_amd import renderer as R
     from scanerf_amd import tile_model as tm
+    from scanerf_amd.hashgrid.lib import HASHGRID as _HG
+    _HG.INFER_ARITH = getattr(args, "infer_arith", "t16")
     H, W, ntile = 1080, 1920, (args.tiles_per_gpu if args.tiles_per_gpu > 1 else 4)
     tiles = []
     with tempfile.TemporaryDirectory() as tmp:

@@ -249,3 +249,22 @@ def test_boundary_plans_in_its_forward_launch_and_two_calls_do_not_share_a_works
         grads[in_fwd] = (F.grad.clone(), bl.grad.clone())
     assert torch.equal(grads[True][0], grads[False][0]) and torch.equal(grads[True][1], grads[False][1])
     assert float(grads[True][0].abs().max()) > 0
+
+
+def test_surface_normals_of_the_op_by_op_route_follow_the_torch_decoder(golden):
+    """render_batch_rays(out_normal=True) on the op-by-op route (hashgrid/__init__.py:576-584: -d(sigma)/d(position), normalised,
+    composited with the weights): a first-order autograd.grad through the HIP decoder op and the encoder op's point gradient --
+    against the same call with the torch decoder graph (ShallowMLP.use_hip = False)."""
+    g = golden("g15_render_masks")
+    res = {}
+    for use_hip in (True, False):
+        hg, dec = _hashgrid_from_g15(g, False)
+        dec.use_hip = use_hip
+        o, d = T(g["rays_o"]).to(DEV), T(g["rays_d"]).to(DEV)
+        z, dist = hg.samplePoints(o, d, 16)
+        v = torch.all(z != -1, dim=-1)
+        out, ok = hg.render_batch_rays(o[v], d[v], z[v], dist[v], dec, 1, hg.contract_fore, out_normal=True, global_step=20000)
+        assert ok and out["normal"].shape == (int(v.sum()), 3) and bool(torch.isfinite(out["normal"]).all())
+        res[use_hip] = out["normal"].detach()
+    assert float(res[True].abs().max()) > 1e-3
+    assert _rel_l2(res[True], res[False]) < 1e-3

@@ -1,10 +1,10 @@
 #!/bin/bash
-# Same-box A/B of the render-time decode kernels: frame time of configs[4]'s render leg per SCANERF_RENDER_ARITH value.
+# Same-box A/B of the render-time decode kernels: frame time of configs[4]'s render leg per --infer-arith value (t16 / h3 / f32).
 # Usage: tools/ab_render_arith.sh <outdir under gpurun_out> <arith> [<arith> ...]
 out=$GRAFT_REPO_ROOT/gpurun_out/$1; shift
 mkdir -p $out
 for ar in "$@"; do
-  SCANERF_RENDER_ARITH=$ar timeout -k 10 200 python bench.py --workload configs4-render --steps 5 --warmup 2 --no-cpu-baseline --no-side-legs > $out/render_$ar.json 2> $out/render_$ar.err || echo "$ar failed"
+  timeout -k 10 200 python bench.py --infer-arith $ar --workload configs4-render --steps 5 --warmup 2 --no-cpu-baseline --no-side-legs > $out/render_$ar.json 2> $out/render_$ar.err || echo "$ar failed"
   python - "$out/render_$ar.json" "$ar" <<'PY'
 import json,sys
 try:
