@@ -262,7 +262,7 @@ int scanerf_render_backward(const float *rays_o, const float *rays_d, const floa
  * -- is re-encoded by the split pass as a 12-byte record (gradient components rounded to 19 mantissa bits, x-weight to 23
  * bits: ~2^-21 relative per record against the window path), and the second entry of an x-neighbour pair that crosses a
  * 2^13-entry window (levels with a resolution above 8 192 only) is added to grad_features / overflow_grad with float atomics,
- * i.e. NOT bit-reproducibly; SCANERF_NO_SPLIT=1 in the environment, or a smaller caller-owned workspace, keeps the window
+ * i.e. NOT bit-reproducibly; a smaller caller-owned workspace (or SCANERF_NO_SPLIT=1 in an experiments build) keeps the window
  * re-reads (f32 records, reproducible, slower). */
 size_t scanerf_render_scatter_workspace_bytes(int B, int S, int T);
 int scanerf_render_scatter_plan(const float *rays_o, const float *rays_d, const float *z_vals,

@@ -89,7 +89,7 @@ __global__ void __launch_bounds__(kFwdThreads, 2) k_decoder_fwd_h3(DecArgs a)
     }
 }
 
-// ---- forward on 16-sample tiles (SCANERF_DECODER_FWD=s16; comparison): decode_tile_s16 (render_t16.h) -- v_mfma_f32_16x16x32_f16
+// ---- forward on 16-sample tiles (experiments build, SCANERF_DECODER_FWD_S16=1; comparison): decode_tile_s16 (render_t16.h) -- v_mfma_f32_16x16x32_f16
 // on the t16s image, lane (c, q) = sample c, quarter q: the forward recompute of the backward kernel below, and the decoder of the
 // render-time kernel k_pts_inference_t16.  94 registers -> four waves per SIMD, where the kernel is bound by vector-instruction
 // issue (profiles/r05_decoder_fwd_counters.txt).  Measured per launch at 8.4e6 samples (rocprofv3 kernel trace, same box):

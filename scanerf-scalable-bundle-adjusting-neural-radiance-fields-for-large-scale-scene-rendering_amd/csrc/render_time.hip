@@ -13,7 +13,7 @@
 // takes 32 consecutive samples and runs the decoder on the matrix cores.  Default: chunk-major
 // with the split-f16 decoder image of each tile a chunk touches staged in LDS
 // (k_pts_inference_chunks: the rate of the training forward -- table gathers bound it).  Kept for comparison
-// (SCANERF_RENDER_ARITH=f32): a single pass on the fp32 matrix pipe that reads the packed image of
+// (SCANERF_INFER_F32 in sample_major): a single pass on the fp32 matrix pipe that reads the packed image of
 // whichever tile the samples reference through L2 and loops over the distinct tiles of a wave
 // (1.5e9 samples/s).
 #include <hip/hip_fp16.h>
@@ -1206,7 +1206,7 @@ inline bool render_single_pass(int64_t total, int nb, int arith)
     return arith == 2 || total >= ((int64_t)1 << 31) || nb > 64;
 }
 
-// SCANERF_RENDER_ARITH=h3: the 32-sample-tile kernel at two waves per SIMD (k_pts_inference_chunks; comparison) instead of the
+// SCANERF_INFER_H3 in sample_major: the 32-sample-tile kernel at two waves per SIMD (k_pts_inference_chunks; comparison) instead of the
 // 16-sample-tile one at four (k_pts_inference_t16, default)
 
 // SCANERF_RENDER_PIPE=0 (experiments build): the group loop without the software pipeline (comparison; the two give the same bits)

@@ -981,7 +981,7 @@ static int binned_backward(const float *points, const float *grad_in, float *gra
     }
     // 16-byte records, or the 8- / 12-byte ones: on request for level-major gradients (out of the 16-sample-tile backward
     // kernels), 12-byte ones by default for the point-major rows (f32 components with 19-bit mantissas, 23-bit weights:
-    // scatter_common.h Rec12; SCANERF_REC16=1 keeps the 16-byte records)
+    // scatter_common.h Rec12; compact_records = 0 keeps the 16-byte records)
     if (rows16 && compact_records == 0) compact_records = 2;
     g.rows16 = rows16 ? 1 : 0;
     g.rec8 = (compact_records >= 1 && compact_records <= 2 && (grad_layout == 1 || (rows16 && compact_records == 2)) &&
@@ -989,7 +989,7 @@ static int binned_backward(const float *points, const float *grad_in, float *gra
     g.NB = T >> g.bucket_log;
     // Large tables (round 6): 12-byte records leave the producer as full 64-byte segments (k_bin_scatter_seg, format 3) -- for the
     // level-major gradients of the t16s backward and for the point-major rows of the binding surface (whose default is Rec12
-    // as well, see rows16); SCANERF_REC16 / SCANERF_SCATTER_OLD keep the record-at-a-time producer
+    // as well, see rows16); compact_records = 0, a smaller workspace, or SCANERF_REC16 / SCANERF_SCATTER_OLD of an experiments build keep the record-at-a-time producer
     const bool seg_route = (size_t)L * g.NB * 4 > 64 * 1024 && g.bucket_log <= 13 && g.NB <= 2048 &&
                            (compact_records == 2 || (grad_layout == 0 && compact_records == 0 && !want16)) &&
                            !tune_set("SCANERF_REC16") && !tune_set("SCANERF_SCATTER_OLD");
