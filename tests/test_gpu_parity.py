@@ -1690,7 +1690,8 @@ def test_ray_source_scatter_equals_points_and_concatenation(S, two):
     assert int((out[True][1] != 0).sum()) > 100_000
 
 
-def test_fp16_moment_epilogue_equals_adam_step_cuda_fp16(S):
+@pytest.mark.parametrize("log2_T", [22, 24])   # (2^24: the persistent segment accumulate, csrc/scatter.hip k_seg_accumulate_adam)
+def test_fp16_moment_epilogue_equals_adam_step_cuda_fp16(S, log2_T):
     """The opt-in half-precision optimiser state of the large-table scatter (scanerf_table_grad_scatter_adam_rays(fp16_moments=1)):
     the epilogue applies adam_step_cuda_fp16's update (cuda/adam_kernel.cu:98-144: gradient x 128, moments stored in half) to the
     bucket images -- against the same records added into a gradient table and the stand-alone fp16 Adam op on it: parameters and
@@ -1698,7 +1699,7 @@ def test_fp16_moment_epilogue_equals_adam_step_cuda_fp16(S):
     from scanerf_amd import render
     from scanerf_amd.cuda import adam_step_cuda_fp16
     gen = torch.Generator().manual_seed(5)
-    B, S1, T = 600, 64, 2 ** 22
+    B, S1, T = 600, 64, 2 ** log2_T
     res = g(O.level_resolutions(torch.tensor([32, 32, 32]), torch.tensor([2048, 2048, 2048])).numpy())
     mn, sz = torch.tensor([-8.0, -8.0, -8.0]), torch.tensor([16.0, 16.0, 16.0])
     o = (torch.rand(B, 3, generator=gen) * 8 - 4).to(DEV)
