@@ -18,7 +18,7 @@ import torch
 import torch.nn as nn
 
 from .. import render
-from ..cuda import ray_aabb_intersection, sample_points_grid, voxelize_mesh
+from ..cuda import sample_points_grid, voxelize_mesh
 from .lib.HASHGRID import Sampler
 from .PyHashGridBG import PyHashGridBG
 

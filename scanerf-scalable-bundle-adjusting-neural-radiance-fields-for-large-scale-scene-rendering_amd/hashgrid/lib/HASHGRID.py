@@ -4,7 +4,6 @@ Same names / positional order / in-place outputs as hashgrid/include/hashgrid.h:
 hashgrid/include/rendering.h:20-182 (the render-time ops of rendering.py's novel-view loop, second half of this file).
 """
 import ctypes
-import os
 
 import torch
 

@@ -19,7 +19,6 @@ FORE, BG = 0, 1
 #            (7e-4 relative L2): the fast, reduced-precision option (3.9 ms); converges like the others on the procedural
 #            scene (tests/test_gpu_harness.py: 27.1 dB each) but is not what the reference computes.
 #   Calls the 16-sample-tile kernels cannot serve (no x-stash) run the "h3" backward: see backward_arith().
-import os as _os
 _ARITH_CODES = {"f32": _capi.ARITH_F32, "h3": _capi.ARITH_H3, "t16": _capi.ARITH_T16, "t16s": _capi.ARITH_T16S}
 ARITH_NAMES = tuple(_ARITH_CODES)
 FP32_EQUIV_ARITH = "t16s"   # the fastest arithmetic whose gradients are f32-equivalent: what bench.py's headline runs

@@ -13,7 +13,6 @@ Scope is the foreground branch on synthetic rays; data loading, warp/mono losses
 refinement and pruning schedules belong to the trainer.
 """
 import math
-import os
 
 import torch
 import torch.nn as nn
