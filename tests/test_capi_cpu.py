@@ -139,3 +139,28 @@ def test_the_shipped_library_is_the_product_build_and_reads_no_environment():
     if nm:
         syms = subprocess.run([nm, "-D", "--undefined-only", _capi.LIB_PATH], capture_output=True, text=True, check=True).stdout
         assert "getenv" not in syms
+
+
+def test_round6_entry_points_validate_before_any_launch():
+    """scanerf_table_grad_scatter_adam_rays / scanerf_composite_forward / _backward: empty batches are no-ops, null pointers and
+    unsupported sizes are refused with a message -- all before a kernel is launched (no GPU needed)."""
+    import scanerf_amd  # noqa
+    from scanerf_amd import _capi
+    lib = _capi.lib()
+    lib.scanerf_last_error.restype = ctypes.c_char_p
+    null = ctypes.c_void_p(0)
+    f = ctypes.c_float
+    rays = lambda B, S1: lib.scanerf_table_grad_scatter_adam_rays(null, null, B, null, null, null, S1, 0, null, null, null, 0, 0, null, null, null,
+                                                                  1 << 24, null, ctypes.c_size_t(0), null, null, null, null, 0, null, f(1e-2), f(0.9),
+                                                                  f(0.99), f(1e-15), 0, 0, null)
+    assert rays(0, 128) == 0
+    assert rays(16, 128) != 0 and b"null" in lib.scanerf_last_error()
+    assert rays(16, 0) != 0 and b"S1=0" in lib.scanerf_last_error()
+    comp_f = lambda B, S: lib.scanerf_composite_forward(null, null, null, null, null, null, null, null, null, B, S, 0, null)
+    comp_b = lambda B, S: lib.scanerf_composite_backward(null, null, null, null, null, null, null, null, null, null, null, null, null, null, null,
+                                                         B, S, 0, null)
+    assert comp_f(0, 128) == 0 and comp_b(0, 128) == 0
+    assert comp_f(4, 128) != 0 and b"null" in lib.scanerf_last_error()
+    assert comp_b(4, 513) != 0 and b"S <= 512" in lib.scanerf_last_error()
+    assert lib.scanerf_embedding_bg_backward_binned(null, null, null, null, 100, 16, 1 << 19, 0, null, ctypes.c_size_t(0), 7, null) != 0
+    assert b"compact_records=7" in lib.scanerf_last_error()
