@@ -58,6 +58,7 @@ class TileSetRenderer:
         # prepare_points + pts_inference; a tracing pass runs on the running rays alone when fewer than this many tenths run
         self.fuse_slots = True
         self.compact_below_tenths = 9
+        self.skip_zero_transmittance_background = True   # exact: see render_rays
         t = lambda a, dt: torch.as_tensor(np.ascontiguousarray(a), dtype=dt).to(device).contiguous()
         self.feature_tables = t(np.stack([x["features"] for x in tiles]), torch.float16)
         self.params = t(np.stack([x["blob"] for x in tiles]), torch.float32)
@@ -187,6 +188,11 @@ class TileSetRenderer:
         bg_w = torch.zeros(B, 4, device=dev)
         update_outgoing_bidx(rays_o, rays_d, self.block_corner, self.block_size, tracing_blocks, inter, bg_b, bg_w, 0.12, False)
         bg_w = bg_w / torch.sum(bg_w, dim=-1, keepdim=True)
+        # rays whose foreground transmittance is EXACTLY zero (an opacity rounded to 1.0 on the way: hard surfaces) get no background:
+        # it would be multiplied by that zero -- `dif + 0 * bgd` is `dif` bit for bit, colour and depth alike -- so nothing changes
+        # but the decoder work of their 128 background samples (exact, unlike skip_saturated_background below)
+        if self.skip_zero_transmittance_background:
+            bg_b[(transp == 0)[:, 0]] = -1
         if skip_saturated_background:
             # rays the foreground has saturated get no background: it would enter the pixel with weight <= 1e-5 -- 400x below
             # one 8-bit step -- and on an opaque scene it is most of the frame's decoder work

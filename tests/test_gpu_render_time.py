@@ -516,3 +516,29 @@ def test_sort_tracing_blocks_equals_stable_argsort():
         got = H.sort_tracing_blocks(inter.contiguous())
         want = torch.argsort(inter[..., 0], dim=-1, stable=True).int()
         assert got.dtype == torch.int32 and torch.equal(got, want), (B, nb)
+
+
+def test_background_of_rays_with_exactly_zero_transmittance_is_skipped_without_changing_a_bit(tmp_path):
+    """Round 6: a ray whose foreground transmittance is EXACTLY 0.0 (an opacity rounded to 1: the density head answers +40 here)
+    gets no background samples -- `dif + 0 * bgd` is `dif`: colour, depth and transmittance are the bits of the unskipped render."""
+    import scanerf_amd  # noqa
+    from scanerf_amd import renderer as R
+    from scanerf_amd.tile_model import TileModel
+    rng = np.random.default_rng(5)
+    m = TileModel([-4.0, -4, -4], [8, 8, 8], DEV, log2_T=10, seed=3, sampler_log2dim=4)
+    with torch.no_grad():
+        m.features.mul_(60.0)
+        m.decoder.sigma_layer_mlp_0_bias.add_(40.0)
+    m.occupied_grid = g(rng.random((16, 16, 16)) < 0.5)
+    R.export_tile(str(tmp_path / "tile0"), m)
+    rnd = R.TileSetRenderer(DEV, [R.load_tile(str(tmp_path / "tile0"))])
+    H, W = 24, 32
+    K = np.float32([[30, 0, 16], [0, 30, 12], [0, 0, 1]])
+    c2w = np.float32([[0, 0, 1, -9], [0, 1, 0, 0.3], [-1, 0, 0, 0.2]])
+    on = rnd.render(H, W, K, c2w, num_sample=64, num_bg_sample=32)
+    rnd.skip_zero_transmittance_background = False
+    off = rnd.render(H, W, K, c2w, num_sample=64, num_bg_sample=32)
+    zero = int((on[3] == 0).sum())
+    assert 50 < zero < H * W, zero      # some rays are exactly opaque, some see the background
+    for a_, b_ in zip(on, off):
+        assert torch.equal(a_, b_)

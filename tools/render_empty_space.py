@@ -1,6 +1,8 @@
 """What the zero-opacity gate of the render-time decoder is worth on empty space: configs[4]'s frame with every tile's density head
 forced to -300 (softplus -> 0: every sample's opacity is exactly zero, every tile skips its directional layers) beside the ordinary
-frame.  Usage: python tools/render_empty_space.py"""
+frame; and (round 6) with the density head forced to +40 -- a hard surface: the rays that hit the shell end with a transmittance
+of EXACTLY zero, get no background samples (TileSetRenderer.skip_zero_transmittance_background, exact) and stop tracing.
+Usage: python tools/render_empty_space.py"""
 import os, sys, time, tempfile
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -9,7 +11,7 @@ from scanerf_amd import renderer as R, tile_model as tm
 
 dev = torch.device("cuda:0")
 H, W, ntile = 1080, 1920, 4
-for empty in (False, True):
+for empty in (False, True, "opaque", "opaque-noskip"):
     tiles = []
     with tempfile.TemporaryDirectory() as tmp:
         for t in range(ntile):
@@ -17,13 +19,17 @@ for empty in (False, True):
             m.set_occupancy(tm.sphere_shell_occupancy(m, 3.0, 0.5))
             with torch.no_grad():
                 m.features.mul_(300.0)
-                if empty:
+                if empty is True:
                     m.decoder.sigma_layer_mlp_0_weight.zero_()
                     m.decoder.sigma_layer_mlp_0_bias.fill_(-300.0)
+                elif empty:
+                    m.decoder.sigma_layer_mlp_0_weight.zero_()
+                    m.decoder.sigma_layer_mlp_0_bias.fill_(40.0)
             R.export_tile(os.path.join(tmp, f"tile{t}"), m)
             tiles.append(R.load_tile(os.path.join(tmp, f"tile{t}")))
             del m
     rend = R.TileSetRenderer(dev, tiles)
+    rend.skip_zero_transmittance_background = empty != "opaque-noskip"
     K = [1600.0, 0, W / 2, 0, 1600.0, H / 2, 0, 0, 1]
     c2w = torch.tensor([[1.0, 0, 0, 0.0], [0, 1, 0, 0.5], [0, 0, 1, -14.0]])
     for _ in range(2):
@@ -33,6 +39,7 @@ for empty in (False, True):
     for _ in range(5):
         out = rend.render(H, W, K, c2w)
     torch.cuda.synchronize()
-    print("zero opacity everywhere" if empty else "ordinary scene", f"{(time.perf_counter() - t0) / 5 * 1e3:.2f} ms per frame; max |colour| {float(out[0].abs().max()):.3g}")
+    print({False: "ordinary scene", True: "zero opacity everywhere", "opaque": "opaque shell (density head +40)",
+           "opaque-noskip": "opaque shell, backgrounds of zero-transmittance rays NOT skipped"}[empty], f"exactly opaque rays {float((out[3] == 0).float().mean()):.3f};", f"{(time.perf_counter() - t0) / 5 * 1e3:.2f} ms per frame; max |colour| {float(out[0].abs().max()):.3g}")
     del rend, tiles
     torch.cuda.empty_cache()
