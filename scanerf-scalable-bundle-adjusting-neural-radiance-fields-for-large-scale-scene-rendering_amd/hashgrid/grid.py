@@ -260,8 +260,8 @@ class HashGrid(nn.Module):
             out["rgb"] = torch.clamp(out["diffuse"] + out["specular"], 0, 1)
             if train:
                 out["l2_reg_specular"] = self.accumulate(weights.detach(), dec["specular"] ** 2).mean()
-        if out_normal:   # surface normals: -d(sigma)/d(position), normalised, composited with the (detached) weights
+        if out_normal:   # surface normals: -d(sigma)/d(position), normalised and detached, composited with the weights
             g = torch.autograd.grad(dec["sigma"].sum(), world, retain_graph=True)[0]
             n = -g / (g.norm(2, dim=-1, keepdim=True) + 1e-8)
-            out["normal"] = (out["weights"].detach() * n.reshape(B, S, 3)).sum(1)
+            out["normal"] = self.accumulate(out["weights"], n.reshape(B, S, 3).detach())   # (weights NOT detached: :586)
         return out, True

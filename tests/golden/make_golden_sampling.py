@@ -184,6 +184,20 @@ def main():
         print("G16", tag, "occupied fraction", frac, "of", tuple(pr.occupied_grid.shape))
     save("g16_pruning", **g16)
 
+    # ---- G18 (round 6): render_batch_rays(out_normal=True) (hashgrid/__init__.py:576-588): surface normals = -d(sigma)/d(sample
+    # position), normalised, composited with the weights -- the reference's own autograd through ITS decoder and compositing, with
+    # this repo's C oracle as the encoder (its point gradient is the adjoint the CUDA op returns).  The G15 tile, table and decoder.
+    zz = torch.full((ro.shape[0], S), -1.0)
+    dd = torch.full((ro.shape[0], S), -1.0)
+    hgm.samplePoints = None   # (not used: the sampler op is called directly)
+    spg(ro, rd, zz, dd, hgm.bbox_center - hgm.bbox_size / 4.0, hgm.bbox_size / 2.0, occ.numpy(), hgm.sampler_log2dim.numpy())
+    v = torch.all(zz != -1, dim=-1)
+    rov = ro[v].clone().requires_grad_(True)
+    out, ok = hgm.render_batch_rays(rov, rd[v], zz[v], dd[v], mlp, 0, hgm.contract_fore, out_normal=True, infinity=False, global_step=20000)
+    assert ok and bool(torch.isfinite(out["normal"]).all())
+    save("g18_normals", rays_o=ro[v], rays_d=rd[v], z_vals=zz[v], dists=dd[v], normal=out["normal"], rgb=out["rgb"], depth=out["depth"],
+         global_step=np.array(20000))
+
 
 if __name__ == "__main__":
     main()

@@ -268,3 +268,19 @@ def test_surface_normals_of_the_op_by_op_route_follow_the_torch_decoder(golden):
         res[use_hip] = out["normal"].detach()
     assert float(res[True].abs().max()) > 1e-3
     assert _rel_l2(res[True], res[False]) < 1e-3
+
+
+def test_surface_normals_against_the_reference_golden_g18(golden):
+    """G18: the reference's own render_batch_rays(out_normal=True) (hashgrid/__init__.py:576-588: autograd of sigma w.r.t. the sample
+    positions through ITS decoder, normalised, composited with ITS weights; the C oracle as its encoder) on G15's tile, table and
+    decoder -- against the op-by-op route here: a first-order autograd.grad through the HIP decoder op and the HIP encoder's point
+    gradient, the compositing op's weights."""
+    g15, g18 = golden("g15_render_masks"), golden("g18_normals")
+    hg, dec = _hashgrid_from_g15(g15, False)
+    o, d, z, dist = (T(g18[k]).to(DEV) for k in ("rays_o", "rays_d", "z_vals", "dists"))
+    out, ok = hg.render_batch_rays(o, d, z, dist, dec, 0, hg.contract_fore, out_normal=True, global_step=int(g18["global_step"]))
+    assert ok and hg.last_render_route == "ops"
+    np.testing.assert_allclose(out["rgb"].detach().cpu().numpy(), g18["rgb"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(out["depth"].detach().cpu().numpy(), g18["depth"], rtol=1e-4, atol=1e-5)
+    n, ref = out["normal"].detach().cpu(), T(g18["normal"])
+    assert float(ref.norm(dim=-1).max()) > 0.1 and _rel_l2(n, ref) < 2e-3, _rel_l2(n, ref)
