@@ -198,6 +198,39 @@ def main():
     save("g18_normals", rays_o=ro[v], rays_d=rd[v], z_vals=zz[v], dists=dd[v], normal=out["normal"], rgb=out["rgb"], depth=out["depth"],
          global_step=np.array(20000))
 
+    # ---- G19 (round 6): the compositing sequence of render_batch_rays -- cal_integrate_weight + accumulate x 4 + the detached-weight
+    # l2_reg_specular sum (hashgrid/__init__.py:344-366, :564-574, :591-594) -- run by the REFERENCE's own methods under torch
+    # autograd: outputs AND the gradients of a random linear functional of every output w.r.t. sigma, the colours and rays_d.
+    # Pins csrc/composite.hip's forward and adjoint (scanerf_composite_forward / _backward).
+    gg = torch.Generator().manual_seed(19)
+    Bc, Sc = 37, 48
+    g19 = {}
+    for inf in (False, True):
+        sigma = (torch.rand(Bc, Sc, 1, generator=gg) ** 3 * 8).requires_grad_(True)
+        dif, spc, tnt = (torch.rand(Bc, Sc, 3, generator=gg).requires_grad_(True) for _ in range(3))
+        zc = torch.cumsum(torch.rand(Bc, Sc, generator=gg) * 0.1 + 0.01, 1)
+        dc = torch.cat([zc[:, 1:] - zc[:, :-1], torch.full((Bc, 1), 1e-6)], 1)
+        rdc = (torch.randn(Bc, 3, generator=gg) * (0.5 + torch.rand(Bc, 1, generator=gg))).requires_grad_(True)
+        w, T_left = hgm.cal_integrate_weight(sigma, zc, dc, rdc, infinity=inf)
+        depth = hgm.accumulate(w, zc[..., None])
+        tint_o, dif_o = hgm.accumulate(w, tnt), hgm.accumulate(w, dif)
+        spec_o = hgm.accumulate(w, tnt * spc)
+        rgb = torch.clamp(dif_o + spec_o, 0, 1)
+        l2 = torch.mean(hgm.accumulate(w.detach(), (spc - 0) ** 2))
+        cw = {k: torch.randn(*v.shape, generator=gg) for k, v in (("rgb", rgb), ("depth", depth), ("T", T_left), ("dif", dif_o),
+                                                                   ("spec", spec_o), ("tint", tint_o), ("w", w))}
+        loss = ((rgb * cw["rgb"]).sum() + (depth * cw["depth"]).sum() + (T_left * cw["T"]).sum() + (dif_o * cw["dif"]).sum()
+                + (spec_o * cw["spec"]).sum() + (tint_o * cw["tint"]).sum() + 0.1 * (w * cw["w"]).sum() + 0.37 * l2)
+        loss.backward()
+        t = "inf%d_" % inf
+        g19.update({t + "sigma": sigma, t + "diffuse": dif, t + "specular": spc, t + "tint": tnt, t + "z_vals": zc, t + "dists": dc,
+                    t + "rays_d": rdc, t + "weights": w, t + "T_left": T_left, t + "depth": depth, t + "tint_out": tint_o,
+                    t + "diffuse_out": dif_o, t + "specular_out": spec_o, t + "rgb": rgb, t + "l2_reg_specular": l2,
+                    t + "g_sigma": sigma.grad, t + "g_diffuse": dif.grad, t + "g_specular": spc.grad, t + "g_tint": tnt.grad,
+                    t + "g_rays_d": rdc.grad})
+        g19.update({t + "cw_" + k: v for k, v in cw.items()})
+    save("g19_composite_grads", **g19)
+
 
 if __name__ == "__main__":
     main()

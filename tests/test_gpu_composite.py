@@ -100,3 +100,29 @@ def test_decoder_on_separate_feature_and_direction_tensors_equals_the_concatenat
         res.append([o.detach() for o in outs] + [f.grad, d.grad, b.grad])
     for a, b in zip(*res):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("infinity", [False, True])
+def test_composite_against_the_reference_own_autograd_golden_g19(golden, infinity):
+    """G19: HashGrid.cal_integrate_weight + accumulate + the l2_reg_specular sum run by the REFERENCE's methods under torch autograd
+    (hashgrid/__init__.py:344-366, :564-574, :591-594): its outputs and its gradients of a random functional of every output --
+    against scanerf_composite_forward / _backward (f32 both sides: 1e-4 of the largest gradient)."""
+    import scanerf_amd  # noqa: F401
+    from scanerf_amd import render
+    g = golden("g19_composite_grads")
+    t = "inf%d_" % infinity
+    G = lambda k: torch.from_numpy(g[t + k]).to(DEV)
+    ins = [G(k).requires_grad_(k not in ("z_vals", "dists")) for k in ("sigma", "diffuse", "specular", "tint", "z_vals", "dists", "rays_d")]
+    out, w = render.composite_rays(*ins, infinity)
+    d = render.render_batch_rays_dict(out, w, True)
+    for key, ref in (("rgb", "rgb"), ("depth", "depth"), ("T_left", "T_left"), ("diffuse", "diffuse_out"), ("specular", "specular_out"),
+                     ("tint", "tint_out"), ("weights", "weights"), ("l2_reg_specular", "l2_reg_specular")):
+        np.testing.assert_allclose(d[key].detach().cpu().numpy(), g[t + ref], rtol=1e-4, atol=1e-6, err_msg=key)
+    loss = ((d["rgb"] * G("cw_rgb")).sum() + (d["depth"] * G("cw_depth")).sum() + (d["T_left"] * G("cw_T")).sum()
+            + (d["diffuse"] * G("cw_dif")).sum() + (d["specular"] * G("cw_spec")).sum() + (d["tint"] * G("cw_tint")).sum()
+            + 0.1 * (d["weights"] * G("cw_w")).sum() + 0.37 * d["l2_reg_specular"])
+    loss.backward()
+    for i, key in ((0, "g_sigma"), (1, "g_diffuse"), (2, "g_specular"), (3, "g_tint"), (6, "g_rays_d")):
+        a, b = ins[i].grad.cpu(), torch.from_numpy(g[t + key])
+        scale = float(b.abs().max())
+        assert scale > 0 and float((a - b).abs().max()) <= 1e-4 * scale, (key, float((a - b).abs().max()) / scale)

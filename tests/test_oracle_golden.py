@@ -213,3 +213,27 @@ def test_g17_cam_rays_and_pose_gradient(golden):
     gC = O.compute_ray_backward(g["w_o"].reshape(-1, 3), g["w_d"].reshape(-1, 3), g["ks"].reshape(C, 9), locs, C, ref_bug=False)
     poses.backward(T(np.asarray(gC, np.float32)).reshape(C, 3, 4))
     np.testing.assert_allclose(cam.se3_refine.grad.numpy(), g["grad_se3_refine"], rtol=2e-4, atol=2e-5)
+
+
+def test_g19_composite_values_and_gradients(golden):
+    """G19 (round 6): the reference's compositing sequence under its own autograd -- the oracle's cal_integrate_weight follows the
+    values, and torch autograd through the oracle's formulation follows the reference's gradients (what the GPU test holds
+    csrc/composite.hip to)."""
+    g = golden("g19_composite_grads")
+    for inf in (0, 1):
+        t = "inf%d_" % inf
+        sigma = T(g[t + "sigma"]).clone().requires_grad_(True)
+        rd = T(g[t + "rays_d"]).clone().requires_grad_(True)
+        w, tl = O.cal_integrate_weight(sigma, T(g[t + "dists"]), rd, infinity=bool(inf))
+        np.testing.assert_allclose(w.detach().numpy(), g[t + "weights"], rtol=1e-6, atol=1e-9)
+        np.testing.assert_allclose(tl.detach().numpy(), g[t + "T_left"], rtol=1e-6)
+        dif, spc, tnt = (T(g[t + k]) for k in ("diffuse", "specular", "tint"))
+        acc = lambda v: torch.sum(w * v, 1)
+        dif_o, spec_o, tint_o, depth = acc(dif), acc(tnt * spc), acc(tnt), acc(T(g[t + "z_vals"])[..., None])
+        rgb = torch.clamp(dif_o + spec_o, 0, 1)
+        loss = ((rgb * T(g[t + "cw_rgb"])).sum() + (depth * T(g[t + "cw_depth"])).sum() + (tl * T(g[t + "cw_T"])).sum()
+                + (dif_o * T(g[t + "cw_dif"])).sum() + (spec_o * T(g[t + "cw_spec"])).sum() + (tint_o * T(g[t + "cw_tint"])).sum()
+                + 0.1 * (w * T(g[t + "cw_w"])).sum())
+        loss.backward()
+        np.testing.assert_allclose(sigma.grad.numpy(), g[t + "g_sigma"], rtol=1e-4, atol=1e-5 * float(np.abs(g[t + "g_sigma"]).max()))
+        np.testing.assert_allclose(rd.grad.numpy(), g[t + "g_rays_d"], rtol=1e-4, atol=1e-5 * float(np.abs(g[t + "g_rays_d"]).max()))
