@@ -107,6 +107,11 @@ int scanerf_embedding_bg_forward(const float *points, float *outputs, const void
 int scanerf_embedding_bg_backward(const float *points, const float *grad_in, float *grad_points,
                                   float *grad_features, const float *features, const int32_t *resolutions,
                                   int N, int L, int T, scanerf_stream_t stream);
+/* Domain: as the reference's kernels (hashgrid_bg_kernel.cu:107-150 does not clamp), every encoder op takes points in [-2, 2]^3.
+ * Outside, the plain ops extrapolate like the reference (negative / > 1 interpolation weights); the COMPACT table-gradient records
+ * (8- and 12-byte formats: scanerf_embedding_bg_backward_binned[_adam] with compact_records 1 / 2 or the default for point-major
+ * rows, the fused path behind SCANERF_ARITH_T16 / T16S, scanerf_table_grad_scatter_adam_rays) store the x-weight as an unsigned
+ * fraction in [0, 1) and are defined for in-domain points only -- which is what the samplers and the two contractions produce. */
 /* The same table gradient without global atomics: radix partition of the contributions by
  * 2048-entry table bucket + LDS accumulation (csrc/scatter.hip).  grad_layout 0: grad_in is
  * [N][L][2] (binding surface), 1: [L][N][2].  workspace: caller-owned scratch of at least

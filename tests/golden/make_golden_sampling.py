@@ -231,6 +231,43 @@ def main():
         g19.update({t + "cw_" + k: v for k, v in cw.items()})
     save("g19_composite_grads", **g19)
 
+    # ---- G20 (round 6): the GRADIENTS of render_batch_rays as the reference's own autograd gives them (its decoder module, its
+    # compositing, its contraction; the C oracle's encoder adjoint underneath) for a loss with a term on every output -- w.r.t. the
+    # hash table, every decoder parameter and both ray tensors; foreground (contract_fore) and background (contract_bg, infinity).
+    # Pins the fused backward kernels' results (render.FusedRenderRays) to the reference, not only to the oracle's autograd.
+    g20 = {"features": feats.detach().clone(), "res": res, "tile_corner": corner, "tile_size": size, "global_step": np.array(7000)}
+    g20.update({"sd." + k: v for k, v in sd.items()})
+    gg = torch.Generator().manual_seed(20)
+    for tag, cfn, inf in (("fg", hgm.contract_fore, False), ("bg", hgm.contract_bg, True)):
+        Bq, Sq = 24, 32
+        roq = ((torch.rand(Bq, 3, generator=gg) - 0.5) * 6 + hgm.bbox_center).requires_grad_(True)
+        # (unit directions x [0.5, 1.5]: with |o - centre| <= 3 and z <= 3.2 every foreground sample stays inside the 2x box, the
+        # encoder's domain [-2, 2] -- hashgrid_bg_kernel.cu does not clamp, and neither does anything here)
+        rdq = (torch.nn.functional.normalize(torch.randn(Bq, 3, generator=gg), dim=-1) * (0.5 + torch.rand(Bq, 1, generator=gg))).requires_grad_(True)
+        if inf:
+            zq = torch.sort(9 + torch.rand(Bq, Sq, generator=gg) * 60, 1).values
+            dq = torch.cat([zq[:, 1:] - zq[:, :-1], torch.full((Bq, 1), 1e-6)], 1)
+        else:
+            zq = torch.sort(0.2 + torch.rand(Bq, Sq, generator=gg) * 3, 1).values
+            dq = torch.cat([zq[:, 1:] - zq[:, :-1], torch.full((Bq, 1), 0.05)], 1)
+        feats.grad = None
+        feats.requires_grad_(True)
+        mlp.zero_grad()
+        with torch.no_grad():
+            chk = cfn((roq[:, None, :] + zq[..., None] * rdq[:, None, :]).reshape(-1, 3))[0]
+            assert float(chk.abs().max()) <= 2.0, float(chk.abs().max())
+        out, ok = hgm.render_batch_rays(roq, rdq, zq, dq, mlp, 0, cfn, out_normal=False, infinity=inf, global_step=7000)
+        assert ok
+        cw = {k: torch.randn(*out[k].shape, generator=gg) for k in ("rgb", "depth", "T_left", "diffuse", "specular", "tint")}
+        loss = sum((out[k] * cw[k]).sum() for k in cw) + 0.37 * out["l2_reg_specular"] + 0.1 * (out["depth"][:, 0] * out["T_left"]).sum()
+        loss.backward()
+        g20.update({f"{tag}_rays_o": roq, f"{tag}_rays_d": rdq, f"{tag}_z_vals": zq, f"{tag}_dists": dq, f"{tag}_loss": loss,
+                    f"{tag}_g_features": feats.grad.clone(), f"{tag}_g_rays_o": roq.grad, f"{tag}_g_rays_d": rdq.grad})
+        g20.update({f"{tag}_cw_{k}": v for k, v in cw.items()})
+        g20.update({f"{tag}_g_sd.{k}": p_.grad.clone() for k, p_ in mlp.named_parameters()})
+        feats.requires_grad_(False)
+    save("g20_render_grads", **g20)
+
 
 if __name__ == "__main__":
     main()

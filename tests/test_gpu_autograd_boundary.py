@@ -284,3 +284,41 @@ def test_surface_normals_against_the_reference_golden_g18(golden):
     np.testing.assert_allclose(out["depth"].detach().cpu().numpy(), g18["depth"], rtol=1e-4, atol=1e-5)
     n, ref = out["normal"].detach().cpu(), T(g18["normal"])
     assert float(ref.norm(dim=-1).max()) > 0.1 and _rel_l2(n, ref) < 2e-3, _rel_l2(n, ref)
+
+
+@pytest.mark.parametrize("fused", [True, False])
+@pytest.mark.parametrize("tag", ["fg", "bg"])
+def test_gradients_against_the_reference_own_autograd_golden_g20(golden, fused, tag):
+    """G20: the reference's own loss.backward() through ITS render_batch_rays (decoder module, compositing, contraction; the C oracle's
+    encoder adjoint underneath) for a loss with a term on every output -- gradients of the hash table, of every decoder parameter
+    and of both ray tensors, foreground and background / infinity, at a step where the coarse-to-fine mask is partly closed.
+    Both routes of the module (the fused kernels behind render.FusedRenderRays; encoder op + decoder op + compositing op)."""
+    import scanerf_amd  # noqa
+    from scanerf_amd import network
+    from scanerf_amd.hashgrid import HashGrid
+    g = golden("g20_render_grads")
+    hg = HashGrid(DEV, T(g["tile_corner"]), T(g["tile_size"]), log2_hashmap_size=10, grid_resolution=[32, 2048], sampler_log2dim=4)
+    assert np.array_equal(hg.HE.resolution.cpu().numpy(), g["res"])
+    with torch.no_grad():
+        hg.HE.features.copy_(T(g["features"]).to(DEV))
+    dec = network.ShallowMLP(32)
+    dec.load_state_dict({k[3:]: T(v) for k, v in g.items() if k.startswith("sd.")})
+    dec = dec.to(DEV)
+    hg.fused = fused
+    o = T(g[f"{tag}_rays_o"]).to(DEV).requires_grad_(True)
+    d = T(g[f"{tag}_rays_d"]).to(DEV).requires_grad_(True)
+    z, dist = T(g[f"{tag}_z_vals"]).to(DEV), T(g[f"{tag}_dists"]).to(DEV)
+    cfn, inf = (hg.contract_bg, True) if tag == "bg" else (hg.contract_fore, False)
+    out, ok = hg.render_batch_rays(o, d, z, dist, dec, 0, cfn, out_normal=False, infinity=inf, global_step=int(g["global_step"]))
+    assert ok and hg.last_render_route == ("fused" if fused else "ops")
+    cw = {k: T(g[f"{tag}_cw_{k}"]).to(DEV) for k in ("rgb", "depth", "T_left", "diffuse", "specular", "tint")}
+    loss = sum((out[k] * cw[k]).sum() for k in cw) + 0.37 * out["l2_reg_specular"] + 0.1 * (out["depth"][:, 0] * out["T_left"]).sum()
+    np.testing.assert_allclose(float(loss.detach()), float(g[f"{tag}_loss"]), rtol=2e-4)
+    loss.backward()
+    assert _rel_l2(hg.HE.features.grad.cpu(), T(g[f"{tag}_g_features"])) < 2e-4
+    for n, p in dec.named_parameters():
+        ref = T(g[f"{tag}_g_sd.{n}"])
+        if float(ref.abs().max()) > 0:
+            assert _rel_l2(p.grad.cpu(), ref) < 2e-4, n
+    assert _rel_l2(o.grad.cpu(), T(g[f"{tag}_g_rays_o"])) < 1e-3
+    assert _rel_l2(d.grad.cpu(), T(g[f"{tag}_g_rays_d"])) < 1e-3

@@ -237,3 +237,30 @@ def test_g19_composite_values_and_gradients(golden):
         loss.backward()
         np.testing.assert_allclose(sigma.grad.numpy(), g[t + "g_sigma"], rtol=1e-4, atol=1e-5 * float(np.abs(g[t + "g_sigma"]).max()))
         np.testing.assert_allclose(rd.grad.numpy(), g[t + "g_rays_d"], rtol=1e-4, atol=1e-5 * float(np.abs(g[t + "g_rays_d"]).max()))
+
+
+def test_g20_render_batch_rays_gradients(golden):
+    """G20 (round 6): the reference's own loss.backward() through its render_batch_rays (the C oracle's encoder underneath) --
+    autograd through the oracle's restatement gives the same gradients of the table, every decoder parameter and both ray tensors
+    (foreground and background / infinity; step 7000: the coarse-to-fine mask partly closed)."""
+    g = golden("g20_render_grads")
+    mn = T(g["tile_corner"]) + T(g["tile_size"]) / 2 - T(g["tile_size"])
+    sz = T(g["tile_size"]) * 2
+    rel = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm())
+    for tag in ("fg", "bg"):
+        sd = {k[3:]: T(v).clone().requires_grad_(True) for k, v in g.items() if k.startswith("sd.")}
+        F = T(g["features"]).clone().requires_grad_(True)
+        o, d = T(g[f"{tag}_rays_o"]).clone().requires_grad_(True), T(g[f"{tag}_rays_d"]).clone().requires_grad_(True)
+        fn = (lambda x: O.contract_bg(x, mn, sz)) if tag == "bg" else (lambda x: O.contract_fore(x, mn, sz))
+        out = O.render_batch_rays(o, d, T(g[f"{tag}_z_vals"]), T(g[f"{tag}_dists"]), F, T(g["res"]), sd, O.TRAIN, fn, int(g["global_step"]),
+                                  infinity=(tag == "bg"))
+        cw = {k: T(g[f"{tag}_cw_{k}"]) for k in ("rgb", "depth", "T_left", "diffuse", "specular", "tint")}
+        loss = sum((out[k] * cw[k]).sum() for k in cw) + 0.37 * out["l2_reg_specular"] + 0.1 * (out["depth"][:, 0] * out["T_left"]).sum()
+        np.testing.assert_allclose(float(loss), float(g[f"{tag}_loss"]), rtol=1e-6)
+        loss.backward()
+        assert rel(F.grad, T(g[f"{tag}_g_features"])) < 1e-5
+        assert rel(o.grad, T(g[f"{tag}_g_rays_o"])) < 1e-5 and rel(d.grad, T(g[f"{tag}_g_rays_d"])) < 1e-5
+        for n, v in sd.items():
+            ref = T(g[f"{tag}_g_sd.{n}"])
+            if float(ref.abs().max()) > 0:
+                assert rel(v.grad, ref) < 1e-5, n
