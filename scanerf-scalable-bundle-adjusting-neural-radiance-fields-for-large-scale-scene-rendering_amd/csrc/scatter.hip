@@ -97,6 +97,18 @@ __global__ void __launch_bounds__(1024) k_bin_count(const float *__restrict__ po
         for (int l = 0; l < g.L; ++l) {
             for (int i = threadIdx.x; i < g.NB; i += (int)blockDim.x) hist[i] = 0;
             __syncthreads();
+            // Coarse levels: lane-owned runs of consecutive points (neighbouring samples of a ray share cells there and would meet
+            // in one histogram word from neighbouring lanes: see below); from level 6 on the cells are smaller than a ray's sample
+            // spacing and a lane-interleaved walk reads the points coalesced (T = 2^24, 4.2e6 points: 0.39 -> 0.32 ms; all
+            // levels interleaved 0.37, from level 8 on 0.33).  Counts do not depend on the order.
+            if (l >= 6) {
+                for (int i = lo + threadIdx.x; i < hi; i += (int)blockDim.x) {
+                    const float p[3] = { points[3 * i], points[3 * i + 1], points[3 * i + 2] };
+                    Pairs pr;
+                    make_pairs(p, resolutions + 3 * l, mask, pr);
+                    if (!MASKED || p[0] == p[0]) count_pairs(pr, hist, g.bucket_log);
+                }
+            } else
             SCANERF_RUN_WALK(i, lo, hi) {
                 const float p[3] = { points[3 * i], points[3 * i + 1], points[3 * i + 2] };
                 Pairs pr;
