@@ -660,7 +660,9 @@ __global__ void __launch_bounds__(kThreads) k_bin_accumulate(const Rec *__restri
             // 64-byte segments of five records (k_bin_scatter_seg): a lane takes SEGS consecutive segments, four 16-byte loads
             // each; all-zero record slots (a range's padding) and records with an exactly zero gradient add nothing and are skipped
             const uint4 *u4 = reinterpret_cast<const uint4 *>(r4);
-            constexpr int SEGS = U / 8 > 0 ? U / 8 : 1;
+            // (ONE segment per lane and round: a large table's bucket holds ~1 700 segments, which 1 024 lanes share best one at a
+            // time -- same-box A/B at T = 2^24, interleaved runs: two per lane 2.57 / 2.59 / 2.58 ms, one per lane 2.40 / 2.42 / 2.39 / 2.40)
+            constexpr int SEGS = 1;
             auto apply12z = [&](uint32_t w0, uint32_t w1, uint32_t w2) {
                 if (((w1 | w2) & ~15u) != 0u) apply12(w0, w1, w2);
             };
