@@ -415,6 +415,11 @@ int scanerf_pts_inference(const float *rays_o, const float *rays_d, const float 
  * SCANERF_INFER_F32 = the single-pass f32-input MFMA kernel (exact f32; [B][S] arrays only, also what > 64 tiles fall back to). */
 #define SCANERF_INFER_H3 8
 #define SCANERF_INFER_F32 16
+/* SCANERF_INFER_FOLDED (16-sample-tile kernel only): `images` were packed by scanerf_pack_decoder from blobs whose three
+ * Gaussian-activated layers -- Spatial_MLP.mlp.0, Directional_MLP.mlp.0 and .2, biases and weights: blob floats [0, 2112),
+ * [6503, 9639), [9639, 13799) -- were multiplied by sqrt(50 log2 e) = 8.4932184 beforehand; the kernel then evaluates the
+ * activation exp(-u^2 / 0.02) as exp2(-(u')^2): one vector instruction less per activation (48 per lane and 16-sample tile). */
+#define SCANERF_INFER_FOLDED 32
 /* prepare_points + pts_inference as ONE launch (no reference counterpart; the renderer's own route): the slot lists are derived
  * in the kernel from running_mask [B] and intersections [B,nb,2] at every use instead of being written and read back (8 bytes per
  * sample, once per tile step).  Same values as the two ops in sequence.  Needs the 16-sample-tile kernel (the default) and

@@ -384,7 +384,16 @@ __device__ __forceinline__ void s16_sh_row(char *row, const float d[3], float ep
 struct S16NoGate {
     __device__ __forceinline__ bool operator()(float) const { return true; }
 };
-template <bool SH_ROW = false, class Gate = S16NoGate>
+// FOLD (render-time inference, SCANERF_INFER_FOLDED): the image was packed from a blob whose three Gaussian-activated layers
+// (Spatial_MLP.mlp.0, Directional_MLP.mlp.0 / .2: weights AND biases) carry the activation's constant sqrt(50 log2 e), so
+// G(u) = exp2(-(u')^2) is a multiply and an exponential instead of two multiplies and an exponential (48 activations per lane and tile).
+template <bool FOLD>
+__device__ __forceinline__ float s16_gauss(float u)
+{
+    if constexpr (FOLD) return __builtin_amdgcn_exp2f(-(u * u));
+    else return gauss_fast(u);
+}
+template <bool SH_ROW = false, class Gate = S16NoGate, bool FOLD = false>
 __device__ __forceinline__ SampleOut decode_tile_s16(const char *lds, int lane, const v4f &xa, const v4f &xb, const float d[3], float eps,
                                                      const char *sh_row = nullptr, Gate gate = Gate())
 {
@@ -400,7 +409,7 @@ __device__ __forceinline__ SampleOut decode_tile_s16(const char *lds, int lane, 
 #pragma unroll
         for (int b = 0; b < 4; ++b)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) act[b][g] = gauss_fast(act[b][g]);
+            for (int g = 0; g < 4; ++g) act[b][g] = s16_gauss<FOLD>(act[b][g]);
         const T16HL aB[2] = { t16_split(act[0], act[1]), t16_split(act[2], act[3]) };
         v4f hh[4];
 #pragma unroll
@@ -459,7 +468,7 @@ __device__ __forceinline__ SampleOut decode_tile_s16(const char *lds, int lane, 
 #pragma unroll
         for (int b = 0; b < 4; ++b)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) v0[b][g] = gauss_fast(v0[b][g]);
+            for (int g = 0; g < 4; ++g) v0[b][g] = s16_gauss<FOLD>(v0[b][g]);
         cB[0] = t16_split(v0[0], v0[1]);
         cB[1] = t16_split(v0[2], v0[3]);
     }
@@ -471,7 +480,7 @@ __device__ __forceinline__ SampleOut decode_tile_s16(const char *lds, int lane, 
 #pragma unroll
         for (int b = 0; b < 4; ++b)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) v1[b][g] = gauss_fast(v1[b][g]);
+            for (int g = 0; g < 4; ++g) v1[b][g] = s16_gauss<FOLD>(v1[b][g]);
         cB[0] = t16_split(v1[0], v1[1]);
         cB[1] = t16_split(v1[2], v1[3]);
     }

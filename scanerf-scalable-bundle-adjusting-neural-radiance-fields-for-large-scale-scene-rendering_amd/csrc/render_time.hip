@@ -928,7 +928,8 @@ inline bool t16_sh_rows_fit(int B, int S, int sm)
     return units * (sm == 0 ? 1 : 32) <= kShRows;
 }
 // TR (fg): no block_idxs array -- every use derives the sample's slot list (tracing_slots)
-template <bool BG, bool SHT, bool TR = false>
+// FOLD: the images hold the activation constant in the three Gaussian layers (SCANERF_INFER_FOLDED; decode_tile_s16<.., FOLD>)
+template <bool BG, bool SHT, bool TR = false, bool FOLD = false>
 __global__ void __launch_bounds__(kT16Threads, 4) k_pts_inference_t16(InferArgs a)
 {
     // the t16s image at its own offsets (decode_tile_s16 reads the forward sub-images and the f32 tail; the transposed narrow
@@ -1155,10 +1156,10 @@ __global__ void __launch_bounds__(kT16Threads, 4) k_pts_inference_t16(InferArgs 
                     SampleOut so;
                     if constexpr (SHT) {
                         const int row = __shfl(shrow, src, 64);
-                        so = decode_tile_s16<true>(lds, lane, xa, xb, nullptr, 0.0f, shrows + (q < 2 ? row + 16 * q : 64 * kShRows), gate);
+                        so = decode_tile_s16<true, decltype(gate), FOLD>(lds, lane, xa, xb, nullptr, 0.0f, shrows + (q < 2 ? row + 16 * q : 64 * kShRows), gate);
                     } else {
                         const float dd[3] = { __shfl(d[0], src, 64), __shfl(d[1], src, 64), __shfl(d[2], src, 64) };
-                        so = decode_tile_s16<false>(lds, lane, xa, xb, dd, 0.0f, nullptr, gate);
+                        so = decode_tile_s16<false, decltype(gate), FOLD>(lds, lane, xa, xb, dd, 0.0f, nullptr, gate);
                     }
                     if (BG) {
                         if (act && q == 0) {
@@ -1194,16 +1195,17 @@ __global__ void __launch_bounds__(kT16Threads, 4) k_pts_inference_t16(InferArgs 
 // Decoder arithmetic of the inference entry points: flag bits OR-ed into their `sample_major` argument (scanerf_hip.h):
 // none = the 16-sample-tile kernel at four waves per SIMD (default); SCANERF_INFER_H3 = the 32-sample-tile kernel at two
 // (round 4's); SCANERF_INFER_F32 = the f32-MFMA single-pass kernel (exact f32; comparison / debugging).
+// (+ 4: SCANERF_INFER_FOLDED, the images carry the activation constant: the 16-sample-tile kernel only)
 inline int infer_arith_of(int &sample_major)
 {
-    const int ar = (sample_major & SCANERF_INFER_F32) ? 2 : ((sample_major & SCANERF_INFER_H3) ? 1 : 0);
-    sample_major &= ~(SCANERF_INFER_F32 | SCANERF_INFER_H3);
+    const int ar = ((sample_major & SCANERF_INFER_F32) ? 2 : ((sample_major & SCANERF_INFER_H3) ? 1 : 0)) | ((sample_major & SCANERF_INFER_FOLDED) ? 4 : 0);
+    sample_major &= ~(SCANERF_INFER_F32 | SCANERF_INFER_H3 | SCANERF_INFER_FOLDED);
     return ar;
 }
 inline bool render_single_pass(int64_t total, int nb, int arith)
 {
     // the chunk-major kernel indexes samples in 32 bits and keeps a chunk's tile set in 64 bits
-    return arith == 2 || total >= ((int64_t)1 << 31) || nb > 64;
+    return (arith & 3) == 2 || total >= ((int64_t)1 << 31) || nb > 64;
 }
 
 // SCANERF_INFER_H3 in sample_major: the 32-sample-tile kernel at two waves per SIMD (k_pts_inference_chunks; comparison) instead of the
@@ -1211,7 +1213,7 @@ inline bool render_single_pass(int64_t total, int nb, int arith)
 
 // SCANERF_RENDER_PIPE=0 (experiments build): the group loop without the software pipeline (comparison; the two give the same bits)
 inline bool render_pipelined() { return tune_int("SCANERF_RENDER_PIPE", 1) != 0; }
-inline bool render_t16_tiles(int arith) { return arith == 0 && tune_int("SCANERF_RENDER_H3_WAVES", 0) == 0; }
+inline bool render_t16_tiles(int arith) { return (arith & 3) == 0 && tune_int("SCANERF_RENDER_H3_WAVES", 0) == 0; }
 // SCANERF_RENDER_H3_WAVES=3 / 4 (experiments build): the 32-sample-tile kernel without the software pipeline at three / four waves per SIMD
 inline int render_h3_waves() { return tune_int("SCANERF_RENDER_H3_WAVES", 0); }
 template <bool BG>
@@ -1233,14 +1235,19 @@ inline void launch_chunks(const InferArgs &a, int64_t tiles32, int arith, hipStr
         // SCANERF_RENDER_SH_ROWS=0 (experiments build): every tile evaluates its samples' harmonics (comparison; the same bits)
         const bool rows = t16_sh_rows_fit(a.B, a.S, a.sm) && tune_int("SCANERF_RENDER_SH_ROWS", 1) != 0;
         const dim3 grid(nblocks(kT16ChunkGroups32));
+        const bool fold = (arith & 4) != 0;
         if constexpr (!BG) {
             if (a.running) {   // scanerf_pts_inference_tracing
-                if (rows) hipLaunchKernelGGL((k_pts_inference_t16<false, true, true>), grid, dim3(kT16Threads), 0, stream, a);
+                if (rows && fold) hipLaunchKernelGGL((k_pts_inference_t16<false, true, true, true>), grid, dim3(kT16Threads), 0, stream, a);
+                else if (rows) hipLaunchKernelGGL((k_pts_inference_t16<false, true, true>), grid, dim3(kT16Threads), 0, stream, a);
+                else if (fold) hipLaunchKernelGGL((k_pts_inference_t16<false, false, true, true>), grid, dim3(kT16Threads), 0, stream, a);
                 else hipLaunchKernelGGL((k_pts_inference_t16<false, false, true>), grid, dim3(kT16Threads), 0, stream, a);
                 return;
             }
         }
-        if (rows) hipLaunchKernelGGL((k_pts_inference_t16<BG, true>), grid, dim3(kT16Threads), 0, stream, a);
+        if (rows && fold) hipLaunchKernelGGL((k_pts_inference_t16<BG, true, false, true>), grid, dim3(kT16Threads), 0, stream, a);
+        else if (rows) hipLaunchKernelGGL((k_pts_inference_t16<BG, true>), grid, dim3(kT16Threads), 0, stream, a);
+        else if (fold) hipLaunchKernelGGL((k_pts_inference_t16<BG, false, false, true>), grid, dim3(kT16Threads), 0, stream, a);
         else hipLaunchKernelGGL((k_pts_inference_t16<BG, false>), grid, dim3(kT16Threads), 0, stream, a);
     }
 #ifdef RT_H3_WAVES_EXPERIMENT   // (tools/build_variant.py render_time="-ffp-contract=off -DRT_H3_WAVES_EXPERIMENT": 23 / 70 spilled registers;
@@ -1644,6 +1651,8 @@ static int pts_inference_impl(const float *rays_o, const float *rays_d, const fl
     a.dbg = tune_int("SCANERF_DEBUG_RT", 0);
     const int64_t tiles32 = ((int64_t)B * S + 31) / 32;
     int blocks = (int)((tiles32 + 3) / 4 < kNumCU * 4 ? (tiles32 + 3) / 4 : kNumCU * 4);
+    SCANERF_REQUIRE(!(arith & 4) || (render_t16_tiles(arith) && !render_single_pass((int64_t)B * S, nb, arith)),
+                    "pts_inference: SCANERF_INFER_FOLDED images are for the 16-sample-tile kernel only (nb <= 64, no SCANERF_INFER_H3 / _F32)");
     SCANERF_REQUIRE(!sample_major || !render_single_pass((int64_t)B * S, nb, arith), "pts_inference: sample-major arrays need the chunk kernel");
     SCANERF_REQUIRE(block_idxs || (render_t16_tiles(arith) && !render_single_pass((int64_t)B * S, nb, arith) && nb <= kTracingMaxTiles),
                     "pts_inference_tracing: needs the 16-sample-tile kernel and nb <= %d tiles (nb=%d); use prepare_points + pts_inference", kTracingMaxTiles, nb);
@@ -1711,6 +1720,8 @@ SCANERF_API int scanerf_bg_pts_inference_v2(const float *rays_o, const float *ra
     a.dbg = tune_int("SCANERF_DEBUG_RT", 0);
     const int64_t tiles32 = ((int64_t)B * S + 31) / 32;
     int blocks = (int)((tiles32 + 3) / 4 < kNumCU * 4 ? (tiles32 + 3) / 4 : kNumCU * 4);
+    SCANERF_REQUIRE(!(arith & 4) || (render_t16_tiles(arith) && !render_single_pass((int64_t)B * S, nb, arith)),
+                    "bg_pts_inference_v2: SCANERF_INFER_FOLDED images are for the 16-sample-tile kernel only (nb <= 64, no SCANERF_INFER_H3 / _F32)");
     SCANERF_REQUIRE(!sample_major || !render_single_pass((int64_t)B * S, nb, arith), "bg_pts_inference_v2: sample-major arrays need the chunk kernel");
     if (render_single_pass((int64_t)B * S, nb, arith)) {
         hipLaunchKernelGGL((k_pts_inference<true>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);

@@ -95,8 +95,22 @@ _i16, _i64, _bool = torch.int16, torch.int64, (torch.bool, torch.uint8)
 _I = ctypes.c_int
 
 
-def _pack_images(params, images):
+# The 16-sample-tile inference kernel takes images whose three Gaussian-activated layers (blob floats [0, 2112): Spatial_MLP.mlp.0,
+# [6503, 9639): Directional_MLP.mlp.0, [9639, 13799): Directional_MLP.mlp.2 -- bias + weights each) carry the activation's constant
+# sqrt(50 log2 e), so that exp(-u^2 / 0.02) = exp2(-(u')^2) (include/scanerf_hip.h SCANERF_INFER_FOLDED): one vector instruction
+# less per activation.  The other kernels (INFER_ARITH "h3" / "f32") read the plain images.
+FOLD_ACTIVATION = True
+_FOLD_C = 8.493218  # sqrt(72.13475204444817)
+_FOLD_RANGES = ((0, 2112), (6503, 9639), (9639, 13799))
+_INFER_FOLDED = 32
+
+
+def _pack_images(params, images, folded=False):
     p = params.contiguous()
+    if folded:
+        p = p.clone()
+        for lo, hi in _FOLD_RANGES:
+            p[:, lo:hi] *= _FOLD_C
     ones = torch.ones(32, dtype=_f32, device=p.device)
     for b in range(p.shape[0]):
         check(lib().scanerf_pack_decoder(ctypes.c_void_p(p[b].data_ptr()), dev_ptr(ones, _f32, "wf"),
@@ -119,10 +133,12 @@ class PackedDecoders:
     def __init__(self, params):
         self.params = params
         self.images = _new_images(params)
+        self.images_folded = _new_images(params)   # (for the 16-sample-tile kernel: FOLD_ACTIVATION)
         self.repack()
 
     def repack(self):
         _pack_images(self.params, self.images)
+        _pack_images(self.params, self.images_folded, folded=True)
         return self
 
 
@@ -134,15 +150,25 @@ class PackedDecoders:
 _images = {}
 
 
-def _packed_images(params):
+def _infer_folded(nb, z_vals):
+    """The call will run the 16-sample-tile kernel (not its single-pass fallback for > 64 tiles / >= 2^31 samples)."""
+    return FOLD_ACTIVATION and INFER_ARITH == "t16" and nb <= 64 and z_vals.numel() < 2 ** 31
+
+
+def _infer_flags(folded):
+    return _INFER_FLAGS[INFER_ARITH] | (_INFER_FOLDED if folded else 0)
+
+
+def _packed_images(params, folded=False):
+    """The packed images a call reads: folded for the 16-sample-tile kernel, plain otherwise."""
     if isinstance(params, PackedDecoders):
-        return params.images
+        return params.images_folded if folded else params.images
     import weakref
-    key = id(params)
+    key = (id(params), folded)
     hit = _images.get(key)
     if hit is not None and hit[0]() is params and hit[1] == params._version:
         return hit[2]
-    images = _pack_images(params, _new_images(params))
+    images = _pack_images(params, _new_images(params), folded)
     _images[key] = (weakref.ref(params, lambda _r, key=key: _images.pop(key, None)), params._version, images)
     return images
 
@@ -193,7 +219,8 @@ def prepare_points(z_vals, runing_mask, intersections, block_idxs, sample_major=
 
 def pts_inference(rays_o, rays_d, z_vals, dists, block_idxs, features_tables, params, resolution, grid_occupied,
                   grid_starts, grid_log2dim, block_corners, block_sizes, diffuse, specular, alpha, sample_major=False):
-    img = _packed_images(params)
+    folded = _infer_folded(block_corners.shape[0], z_vals)
+    img = _packed_images(params, folded)
     check(lib().scanerf_pts_inference(
         dev_ptr(rays_o, _f32, "rays_o"), dev_ptr(rays_d, _f32, "rays_d"), dev_ptr(z_vals, _f32, "z_vals"),
         dev_ptr(dists, _f32, "dists"), dev_ptr(block_idxs, _i16, "block_idxs"),
@@ -203,7 +230,7 @@ def pts_inference(rays_o, rays_d, z_vals, dists, block_idxs, features_tables, pa
         dev_ptr(block_corners, _f32, "block_corners"), dev_ptr(block_sizes, _f32, "block_sizes"),
         dev_ptr(diffuse, _f32, "diffuse"), dev_ptr(specular, _f32, "specular"), dev_ptr(alpha, _f32, "alpha"),
         _I(rays_d.shape[0]), _S(z_vals, sample_major), _I(features_tables.shape[2]), _I(block_corners.shape[0]),
-        _I(int(sample_major) | _INFER_FLAGS[INFER_ARITH]), stream()), "pts_inference")
+        _I(int(sample_major) | _infer_flags(folded)), stream()), "pts_inference")
 
 
 SKIP_UNSAMPLED = 4   # include/scanerf_hip.h SCANERF_SKIP_UNSAMPLED: OR into `sample_major` of pts_inference_tracing / accumulate_color
@@ -220,7 +247,8 @@ def pts_inference_tracing(rays_o, rays_d, z_vals, dists, running_mask, intersect
     """prepare_points + pts_inference in one launch (no reference counterpart): same outputs as
     `prepare_points(z_vals, running_mask, intersections, block_idxs); pts_inference(..., block_idxs, ...)` without the
     block_idxs array."""
-    img = _packed_images(params)
+    folded = _infer_folded(block_corners.shape[0], z_vals)
+    img = _packed_images(params, folded)
     check(lib().scanerf_pts_inference_tracing(
         dev_ptr(rays_o, _f32, "rays_o"), dev_ptr(rays_d, _f32, "rays_d"), dev_ptr(z_vals, _f32, "z_vals"),
         dev_ptr(dists, _f32, "dists"), dev_ptr(running_mask, _bool, "running_mask"), dev_ptr(intersections, _f32, "intersections"),
@@ -230,7 +258,7 @@ def pts_inference_tracing(rays_o, rays_d, z_vals, dists, running_mask, intersect
         dev_ptr(block_corners, _f32, "block_corners"), dev_ptr(block_sizes, _f32, "block_sizes"),
         dev_ptr(diffuse, _f32, "diffuse"), dev_ptr(specular, _f32, "specular"), dev_ptr(alpha, _f32, "alpha"),
         _I(rays_d.shape[0]), _S(z_vals, sample_major), _I(features_tables.shape[2]), _I(block_corners.shape[0]),
-        _I(int(sample_major) | _INFER_FLAGS[INFER_ARITH]), stream()), "pts_inference_tracing")
+        _I(int(sample_major) | _infer_flags(folded)), stream()), "pts_inference_tracing")
 
 
 def accumulate_color(pts_diffuse, pts_specular, pts_alpha, transparency, z_vals, diffuse, specular, depth, sample_major=False):
@@ -251,7 +279,8 @@ def inverse_z_sampling(intersections, related_bidx, z_vals, sample_range, sample
 
 def bg_pts_inference_v2(rays_o, rays_d, z_vals, bg_idxs, step, block_corners, block_sizes, resolution, features_tables,
                         params, diffuse, specular, alpha, sample_major=False):
-    img = _packed_images(params)
+    folded = _infer_folded(block_corners.shape[0], z_vals)
+    img = _packed_images(params, folded)
     check(lib().scanerf_bg_pts_inference_v2(
         dev_ptr(rays_o, _f32, "rays_o"), dev_ptr(rays_d, _f32, "rays_d"), dev_ptr(z_vals, _f32, "z_vals"),
         dev_ptr(bg_idxs, _i16, "bg_idxs"), _I(step), dev_ptr(block_corners, _f32, "block_corners"),
@@ -259,7 +288,7 @@ def bg_pts_inference_v2(rays_o, rays_d, z_vals, bg_idxs, step, block_corners, bl
         dev_ptr(features_tables, torch.float16, "features_tables"), dev_ptr(img, _f32, "images"),
         dev_ptr(diffuse, _f32, "diffuse"), dev_ptr(specular, _f32, "specular"), dev_ptr(alpha, _f32, "alpha"),
         _I(rays_d.shape[0]), _S(z_vals, sample_major), _I(features_tables.shape[2]), _I(block_corners.shape[0]),
-        _I(int(sample_major) | _INFER_FLAGS[INFER_ARITH]), stream()), "bg_pts_inference_v2")
+        _I(int(sample_major) | _infer_flags(folded)), stream()), "bg_pts_inference_v2")
 
 
 def bg_pts_inference(rays_o, rays_d, z_vals, outgoing_bidxs, blend_weights, block_corners, block_sizes, resolution,
