@@ -386,7 +386,7 @@ __global__ void __launch_bounds__(kRenderThreads, 2) k_render_fwd_h3(RenderArgs 
                 so = decode_tile_h3(lds, lane, x, dinit);
             }
 
-            const float alpha = live ? 1.0f - expf(-so.sigma * delta) : 0.0f;
+            const float alpha = live ? 1.0f - __builtin_amdgcn_exp2f(-1.4426950408889634f * (so.sigma * delta)) : 0.0f;   // (as the 16-sample-tile backward forms it)
             float incl = 1.0f - alpha + 1e-6f;
 #pragma unroll
             for (int off = 1; off < 32; off <<= 1) {

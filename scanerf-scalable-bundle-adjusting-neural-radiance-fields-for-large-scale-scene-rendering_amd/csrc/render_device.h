@@ -24,6 +24,15 @@ __device__ __forceinline__ float sigmoid_fast(float x)
     return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.4426950408889634f));
 }
 __device__ __forceinline__ float softplus_(float x) { return x > 20.0f ? x : log1pf(__expf(x)); }
+// softplus at hardware-instruction cost: max(x, 0) + log1p(exp(-|x|)) on v_exp_f32 / v_log_f32, with the series e - e^2 / 2 + e^3 / 3
+// where 1 + e would lose e's digits (e < 2^-6: truncation 1e-6 relative to that term; above, 1 + e keeps e to 2^-18).  The library's
+// log1pf is ~40 vector instructions per call.
+__device__ __forceinline__ float softplus_fast(float x)
+{
+    const float e = __builtin_amdgcn_exp2f(-fabsf(x) * 1.4426950408889634f);
+    const float l = e < 0x1p-6f ? e * (1.0f - e * (0.5f - e * 0.33333334f)) : __builtin_amdgcn_logf(1.0f + e) * 0.6931471805599453f;
+    return fmaxf(x, 0.0f) + l;
+}
 
 __device__ __forceinline__ v16f load_bias(const float *lds, int layer, int blk, int h)
 {

@@ -369,7 +369,7 @@ __device__ __forceinline__ SampleOut decode_tile_h3(const char *img, int lane, c
         v16f u = h3_ld16(img, H3_HB);
         const HL *const B[2] = { &H[0].t[0], &H[0].t[1] };
         h3_layer1<2>(u, img, H3_HEAD, lo, B);
-        so.sigma = softplus_(u[0]);
+        so.sigma = softplus_fast(u[0]);
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             so.dif[c] = sigmoid_fast(u[1 + c]);

@@ -387,15 +387,6 @@ struct S16NoGate {
 // FOLD (render-time inference, SCANERF_INFER_FOLDED): the image was packed from a blob whose three Gaussian-activated layers
 // (Spatial_MLP.mlp.0, Directional_MLP.mlp.0 / .2: weights AND biases) carry the activation's constant sqrt(50 log2 e), so
 // G(u) = exp2(-(u')^2) is a multiply and an exponential instead of two multiplies and an exponential (48 activations per lane and tile).
-// softplus for the folded (render-time) form: max(x, 0) + log1p(exp(-|x|)) on the fast exponential / logarithm, with the series
-// e - e^2 / 2 + e^3 / 3 where 1 + e would lose e's digits (e < 2^-6: truncation 1e-6 relative; above, 1 + e keeps e to 2^-18);
-// softplus_'s library log1pf costs ~25 vector instructions per lane and tile.  Tests hold the render to 1e-4.
-__device__ __forceinline__ float s16_softplus_fast(float x)
-{
-    const float e = __builtin_amdgcn_exp2f(-fabsf(x) * 1.4426950408889634f);
-    const float l = e < 0x1p-6f ? e * (1.0f - e * (0.5f - e * 0.33333334f)) : __builtin_amdgcn_logf(1.0f + e) * 0.6931471805599453f;
-    return fmaxf(x, 0.0f) + l;
-}
 template <bool FOLD>
 __device__ __forceinline__ float s16_gauss(float u)
 {
@@ -430,7 +421,7 @@ __device__ __forceinline__ SampleOut decode_tile_s16(const char *lds, int lane, 
     {
         v4f hd[2] = { t16_ld4(lds, S16_BIAS + 256 * 4), t16_ld4(lds, S16_BIAS + 260 * 4) };
         s16_layer<2, 1>(hd, lds, T16_HEAD, pos8, &HB[0]);
-        so.sigma = FOLD ? s16_softplus_fast(hd[0][0]) : softplus_(hd[0][0]);
+        so.sigma = softplus_fast(hd[0][0]);
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             so.dif[k] = sigmoid_fast(hd[0][1 + k]);
