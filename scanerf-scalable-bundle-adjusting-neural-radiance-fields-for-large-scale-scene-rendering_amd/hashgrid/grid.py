@@ -118,13 +118,25 @@ class HashGrid(nn.Module):
         weight = (1 - (alpha - k[None, ...]).clamp_(min=0, max=1).mul_(math.pi).cos_()) / 2
         return weight.repeat_interleave(2, dim=-1)
 
+    # Small constant tensors the C ABI wants on the other side (host floats of the box; the sampler's log2dim on the device): converted
+    # once per VALUE, not per call -- `.tolist()` of a device tensor and `.to(device)` of a pageable host tensor each stall the host
+    # until the device has drained (three of the four synchronisations of a step, tools/sync_probe.py).  Keyed by tensor object and
+    # version counter: a reassigned or in-place modified attribute (checkpoint load, pruning) is converted again.
+    def _converted(self, name, how):
+        t = getattr(self, name)
+        hit = self.__dict__.setdefault("_conv_cache", {}).get(name + how)
+        if hit is None or hit[0] is not t or hit[1] != t._version:   # (the entry holds the tensor: its address cannot be reused meanwhile)
+            hit = (t, t._version, t.tolist() if how == "list" else t.to(self.device).int().contiguous())
+            self._conv_cache[name + how] = hit
+        return hit[2]
+
     # ---- sampling (:278-337; no gradients) -------------------------------------------------------------------------------------
     def samplePoints(self, rays_o, rays_d, num_sample):
         z_vals = torch.full((rays_o.shape[0], num_sample), -1, dtype=torch.float32, device=self.device)
         dists = torch.full((rays_o.shape[0], num_sample), -1, dtype=torch.float32, device=self.device)
         sample_points_grid(rays_o.detach().contiguous(), rays_d.detach().contiguous(), z_vals, dists,
                            (self.min_bbox + self.bbox_size / 4.0).contiguous(), (self.bbox_size / 2.0).contiguous(),
-                           self.occupied_grid, self.sampler_log2dim.to(self.device).int().contiguous())
+                           self.occupied_grid, self._converted("sampler_log2dim", "dev_int"))
         return z_vals, dists
 
     def invalid_sampling_underground(self, rays_o, rays_d, bound):
@@ -227,7 +239,7 @@ class HashGrid(nn.Module):
             wf = self.weight_feature(global_step).repeat_interleave(2, dim=-1)
             out_ray, weights = render.fused_render_rays(
                 rays_o, rays_d, z_vals, dists, self.HE.features, decoder.blob(), self.HE.resolution.to(self.device).int().contiguous(),
-                wf, self.min_bbox.tolist(), self.bbox_size.tolist(), cmode, infinity, None, network.skip_levels(global_step), True)
+                wf, self._converted("min_bbox", "list"), self._converted("bbox_size", "list"), cmode, infinity, None, network.skip_levels(global_step), True)
             return render.render_batch_rays_dict(out_ray, weights, mode is TRAIN or mode == TRAIN), True
         # ---- op by op: encoder op -> decoder module -> compositing op, each a library call behind its own autograd node (the
         # route for a caller that holds the pieces apart: `self.HE`, `decoder`, the per-sample outputs)
