@@ -1,4 +1,4 @@
-"""GPU idle gaps in the steady state of the autograd route (default) or the op-by-op route (`ops`): torch.profiler device timeline
+"""GPU idle gaps in the steady state of the autograd route (default), the op-by-op route (`ops`) or the fused step (`fused`): torch.profiler device timeline
 of two steps after warm-up; gaps > 3 us with the kernels on either side."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -13,11 +13,12 @@ torch.manual_seed(0)
 o = torch.rand(B, 3, device=dev) * 8 - 4
 d = torch.nn.functional.normalize(torch.randn(B, 3, device=dev), dim=-1) * (0.5 + torch.rand(B, 1, device=dev))
 tgt = torch.rand(B, 3, device=dev)
-if route == "ops":
+if route in ("ops", "fused"):
     from scanerf_amd import tile_model as tm
     m = tm.TileModel([-4.0, -4, -4], [8, 8, 8], dev, log2_T=19, seed=17, sampler_log2dim=4)
     opt = torch.optim.Adam(m.decoder.parameters(), lr=1e-3, betas=(0.9, 0.99), eps=1e-15)
-    step = lambda i: tm.train_step_ops(m, opt, o, d, tgt, S, 20000 + i)
+    step = (lambda i: tm.train_step_ops(m, opt, o, d, tgt, S, 20000 + i)) if route == "ops" else \
+           (lambda i: tm.train_step_fused(m, opt, o, d, tgt, S, 20000 + i))
 else:
     from scanerf_amd import network
     from scanerf_amd.cuda import adam_step_cuda
