@@ -64,6 +64,17 @@ using namespace scanerf;
 
 namespace {
 
+#ifdef T16_LIBM_HEADS   // A/B only (tools/ab_heads.sh): the forms of rounds 1-5 -- libm's log1pf / expf and an IEEE division on the tile's chain
+#define T16_SOFTPLUS(x) softplus_(x)
+#define T16_DSOFTPLUS(x) ((x) > 20.0f ? 1.0f : sigmoid_fast(x))
+#define T16_EXPNEG(x) expf(-(x))
+#define T16_DIV(a, b) ((a) / (b))
+#else
+#define T16_SOFTPLUS(x) softplus_fast(x)
+#define T16_DSOFTPLUS(x) sigmoid_fast(x)
+#define T16_EXPNEG(x) __builtin_amdgcn_exp2f(-1.4426950408889634f * (x))
+#define T16_DIV(a, b) ((a) * __builtin_amdgcn_rcpf(b))
+#endif
 constexpr int kThreads = 512;
 constexpr int kWaves = 8;
 // LDS carve (SPLIT = the t16s variant: its own images, staging of hi AND lo parts)
@@ -622,8 +633,8 @@ __global__ void __launch_bounds__(kThreads, T16_MIN_WAVES) k_render_bwd_t16(BwdA
                 {   // heads on H[:32]
                     v4f hd[2] = { t16_ld4(lds, LD::kBias + 256 * 4), t16_ld4(lds, LD::kBias + 260 * 4) };
                     s16_layer<2, 1>(hd, lds, T16_HEAD, L.pos8, &HB[0]);
-                    sigma = softplus_fast(hd[0][0]);
-                    dsig_dpre = sigmoid_fast(hd[0][0]);
+                    sigma = T16_SOFTPLUS(hd[0][0]);
+                    dsig_dpre = T16_DSOFTPLUS(hd[0][0]);
 #pragma unroll
                     for (int k = 0; k < 3; ++k) {
                         dif[k] = sigmoid_fast(hd[0][1 + k]);
@@ -697,8 +708,8 @@ __global__ void __launch_bounds__(kThreads, T16_MIN_WAVES) k_render_bwd_t16(BwdA
                 {   // heads on H[:32]
                     v4f hd[2] = { t16_ld4(lds, T16_BIAS + 256 * 4), t16_ld4(lds, T16_BIAS + 260 * 4) };
                     t16_layer<2, 1>(hd, lds, T16_HEAD, L.lo16, &HB[0]);
-                    sigma = softplus_fast(hd[0][0]);
-                    dsig_dpre = sigmoid_fast(hd[0][0]);
+                    sigma = T16_SOFTPLUS(hd[0][0]);
+                    dsig_dpre = T16_DSOFTPLUS(hd[0][0]);
 #pragma unroll
                     for (int k = 0; k < 3; ++k) {
                         dif[k] = sigmoid_fast(hd[0][1 + k]);
@@ -755,7 +766,7 @@ __global__ void __launch_bounds__(kThreads, T16_MIN_WAVES) k_render_bwd_t16(BwdA
             // ================= compositing: recompute and adjoint (16-lane scans, identical in the 4 lane groups) =================
             // (the density head and the opacity on v_exp / v_log / v_rcp, not the library's log1pf / expf and an IEEE division: ~65 vector
             // instructions per lane and tile on the tile's dependent chain; plan + backward 5.25 -> 5.17 ms same-box, tools/ab_heads.sh)
-            const float ex = live ? __builtin_amdgcn_exp2f(-1.4426950408889634f * (sigma * delta)) : 1.0f;  // 1 - alpha
+            const float ex = live ? T16_EXPNEG(sigma * delta) : 1.0f;  // 1 - alpha
             const float alpha = 1.0f - ex;
             const float fi = 1.0f - alpha + 1e-6f;
             float incl = fi;   // inclusive prefix product over the row (DPP row shifts, identity shifted in)
@@ -788,7 +799,7 @@ __global__ void __launch_bounds__(kThreads, T16_MIN_WAVES) k_render_bwd_t16(BwdA
             const float suffix = Rcarry + rs - aw;
             // the tile's total = lane 0's suffix sum (the four rows hold the same samples), through a scalar register
             Rcarry += __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, rs)));
-            float dalpha = Ti * ai - (suffix + ((s < S - 1) ? gTl * Tl : 0.0f)) * __builtin_amdgcn_rcpf(fi);
+            float dalpha = Ti * ai - T16_DIV(suffix + ((s < S - 1) ? gTl * Tl : 0.0f), fi);
             if (!live) dalpha = 0.0f;
             const float dsigma = dalpha * delta * ex;
             if (POSE && active && q == 0)  // (the infinity sample's delta is a constant)

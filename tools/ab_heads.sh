@@ -1,4 +1,5 @@
-D=$(ls -d scanerf-*/lib/debug)
-bash tools/ab_bwd.sh plainhead fasthead fasthead2
-for rep in 1 2; do for tag in plainhead fastfwd; do echo -n "$tag: "; SCANERF_LIB=$D/libscanerf_hip_$tag.so python bench.py --no-cpu-baseline --no-side-legs --steps 20 --warmup 3 2>/dev/null | python -c "
-import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['ms_per_step'], d['roofline'].get('kernels_live_ms', d['roofline'].get('achieved')))"; done; done
+# Same-box A/B of the t16s backward with libm's log1pf / expf and an IEEE division on the tile's chain (rounds 1-5) against
+# v_exp / v_log / v_rcp (round 6).  Build first, here:
+#   tools/build_variant.py libmhead render_bwd_t16="-DT16_LIBM_HEADS=1"; tools/build_variant.py plainhead render_bwd_t16=""
+# then on the GPU box: bash tools/ab_heads.sh      (round 6: 5.25 / 5.24 -> 5.18 / 5.17 ms plan + backward; a second box 5.33 / 5.24 -> 5.26 / 5.23)
+bash tools/ab_bwd.sh libmhead plainhead
