@@ -296,3 +296,28 @@ def test_tile_export_read_from_the_reference_writers_files_golden_g12(golden, tm
     assert list(ref_sd.keys()) == list(my_sd.keys())                                          # the consumer walks the keys IN ORDER
     for k in ref_sd:
         assert ref_sd[k].shape == my_sd[k].shape and torch.equal(ref_sd[k], my_sd[k]), k
+
+
+def test_hashgrid_constant_conversions_follow_the_value():
+    """HashGrid._converted (round 6): the host lists / device copies of the box and the sampler's log2dim are made once per VALUE --
+    an in-place change (version counter) or a reassigned attribute (checkpoint load) is converted again; an unchanged one is the
+    same object (no `.tolist()` / `.to(device)`: each stalls the host on a GPU)."""
+    import scanerf_amd  # noqa: F401
+    from scanerf_amd.hashgrid.grid import HashGrid
+
+    class Stub:   # (the method needs `device` and the attribute only)
+        device = "cpu"
+        _converted = HashGrid._converted
+    g = Stub()
+    g.min_bbox = torch.tensor([1.0, 2.0, 3.0])
+    g.sampler_log2dim = torch.tensor([4, 4, 3])
+    a = g._converted("min_bbox", "list")
+    assert a == [1.0, 2.0, 3.0] and g._converted("min_bbox", "list") is a
+    d = g._converted("sampler_log2dim", "dev_int")
+    assert d.dtype == torch.int32 and d.tolist() == [4, 4, 3] and g._converted("sampler_log2dim", "dev_int") is d
+    g.min_bbox.add_(1.0)
+    assert g._converted("min_bbox", "list") == [2.0, 3.0, 4.0]
+    g.min_bbox = torch.tensor([9.0, 9.0, 9.0])
+    assert g._converted("min_bbox", "list") == [9.0, 9.0, 9.0]
+    g.sampler_log2dim = torch.tensor([5, 5, 5])
+    assert g._converted("sampler_log2dim", "dev_int").tolist() == [5, 5, 5]
