@@ -592,6 +592,12 @@ __global__ void __launch_bounds__(kThreads) k_bin_accumulate(const Rec *__restri
         return (unsigned long long)(__double_as_longlong(fma((double)v, scale, magic)) - __double_as_longlong(magic));
     };
     const int level = blockIdx.x / g.NB, bucket = blockIdx.x % g.NB;
+#ifdef SCANERF_EXPERIMENTS   // timing only (wrong results): bins of levels below N = dbg bits 8..15 do nothing (bit 16: the others do nothing)
+    if ((g.dbg >> 8) & 0xff) {
+        const bool below = level < ((g.dbg >> 8) & 0xff);
+        if (below != (((g.dbg >> 16) & 1) != 0)) return;
+    }
+#endif
     for (int win = 0; win < (1 << (g.bucket_log - wl)); ++win) {
         for (int i = threadIdx.x; i < 2 * ws; i += kThreads) acc64[i] = 0;
         __syncthreads();
@@ -906,7 +912,7 @@ bool fused_geom(int B, int S, int T, BinGeom &g, int arith = SCANERF_ARITH_F32)
     if (g.bucket_log > 16) return false;  // local entry indices are 16-bit; buckets above 2^13 entries are accumulated in windows
     if ((int64_t)B * S * 16 * 4 + (1 << 20) >= (int64_t)1 << 31) return false;  // 32-bit record offsets
     g.N = B * S; g.L = 16; g.T = T;
-    g.dbg = 0;
+    g.dbg = tune_int("SCANERF_ACC_DBG", 0) & ~0xff;   // (experiments build: the accumulate's level switches; 0 in the product build)
     g.rows16 = 0;
     g.NB = T >> g.bucket_log;
     g.W = scanerf_render_backward_grid(B);
